@@ -1,0 +1,204 @@
+/*
+ * lsnet_hip.h -- C ABI of liblsnet_hip.so: the MI355X (gfx950) replacement for the reference's
+ * native-op boundary on the LSNet hot path.
+ *
+ * What it replaces (all paths relative to /root/reference/code):
+ *   mmdet/ops/dcn/src/deform_conv_ext.cpp:227-250      pybind module `deform_conv_ext` (8 functions)
+ *   mmdet/ops/sigmoid_focal_loss/src/sigmoid_focal_loss_ext.cpp:19-57   `sigmoid_focal_loss_ext`
+ *   mmdet/ops/nms/src/nms_ext.cpp:18-49                 `nms_ext.nms`
+ * plus fused device kernels for work the reference does as chains of small torch kernels
+ * (cross-IOU loss, group-norm + ReLU, softplus heads) -- those are marked [fused] below.
+ *
+ * Conventions
+ *   - plain C: raw device pointers, int sizes, an explicit hipStream_t.  No torch types.
+ *   - every function returns 0 on success, a negative lsn_status otherwise; lsn_last_error()
+ *     returns a thread-local message (the reference raises RuntimeError from TORCH_CHECK,
+ *     deform_conv_cuda.cpp:92-180,182-272; the Python mirror raises RuntimeError with this text).
+ *   - the caller owns all buffers (as in the reference, deform_conv.py:40-42,141-142,215-217).
+ *     Outputs and gradient buffers are OVERWRITTEN (the reference's Python always passes
+ *     zero-filled gradient tensors, deform_conv.py:75-76,86,157-161, so results are identical).
+ *   - work is enqueued on `stream` and is asynchronous w.r.t. the host, except lsn_nms_host_count.
+ *   - float32 throughout; indices int64 where the reference uses int64.
+ *   - one process per GPU; entry points are re-entrant across streams (no global mutable state
+ *     except the thread-local error string and a per-device cached attribute query).
+ *
+ * Activation layout.  `layout` selects how 4-D activation tensors (input, output, their grads)
+ * and the weight tensor are laid out in memory:
+ *     LSN_NCHW : input (B,C,H,W) contiguous, weight (Co,C/g,kh,kw) contiguous -- exactly what the
+ *                reference extension receives.  Handled by device-side permutes around the NHWC
+ *                kernels (a stream-ordered workspace is allocated with hipMallocAsync).
+ *     LSN_NHWC : the same logical tensors in channels-last memory (B,H,W,C) / (Co,kh,kw,C/g).  This
+ *                is the native layout of the kernels: the bilinear gather reads contiguous channel
+ *                vectors, so every global access of a wavefront is a coalesced 128-256 B segment.
+ * Offset / mask tensors (and their grads) are described by explicit element strides
+ * (lsn_strides4), so either memory format works without a copy.
+ */
+#ifndef LSNET_HIP_H_
+#define LSNET_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t *lsn_stream_t; /* == hipStream_t */
+
+typedef enum {
+    LSN_OK = 0,
+    LSN_ERR_INVALID = -1,     /* shape / argument check failed (TORCH_CHECK in the reference) */
+    LSN_ERR_UNSUPPORTED = -2, /* valid in the reference, not implemented by this build        */
+    LSN_ERR_RUNTIME = -3      /* HIP runtime error (launch, allocation)                        */
+} lsn_status;
+
+typedef enum { LSN_NCHW = 0, LSN_NHWC = 1 } lsn_layout;
+
+/* element strides of a logical (B, Ch, H, W) tensor */
+typedef struct { int64_t b, c, h, w; } lsn_strides4;
+
+/* One deformable-convolution call site.  (H,W) is the sampled source map; (Ho,Wo) the output
+ * grid, which for the pyramid op is the OFFSET grid (deform_conv.py:215-217).
+ * stride/pad/dil are the same for h and w (deform_conv.py:146-148).
+ * scale_h/scale_w: 1 for DCNv1/v2; the pyramid op samples at
+ *      (ho*stride - pad + i*dil) * scale_h + dy      (deform_conv_cuda_kernel.cu:281-282). */
+typedef struct {
+    int B, C, H, W;
+    int Co, Ho, Wo;
+    int kh, kw, stride, pad, dil;
+    int groups, deformable_groups;
+    float scale_h, scale_w;
+} lsn_dcn_shape;
+
+/* One (source map, offset field, output) triple of a batched launch.  All levels of a launch
+ * share weight/bias and the conv hyper-parameters; B,H,W,Ho,Wo,scale_* may differ per level.
+ * This is how the five FPN levels of LSHead's shared towers (lsnet_head.py:502-513) and the
+ * 15 (dst,src) pairs of one PyramidDeformConv (lsnet_head.py:622-638) become ONE launch. */
+typedef struct {
+    const float *input;      /* (B,C,H,W) in `layout`                                  */
+    const float *offset;     /* (B, dg*2*kh*kw, Ho, Wo), strides off_st                */
+    const float *mask;       /* (B, dg*kh*kw, Ho, Wo), strides mask_st; NULL = no mask */
+    float *output;           /* (B,Co,Ho,Wo) in `layout`  [forward]                    */
+    const float *grad_output;/* (B,Co,Ho,Wo) in `layout`  [backward]                   */
+    float *grad_input;       /* may be NULL                                            */
+    float *grad_offset;      /* same strides as offset; may be NULL                    */
+    float *grad_mask;        /* same strides as mask;   may be NULL                    */
+    lsn_strides4 off_st, mask_st;
+    int B, H, W, Ho, Wo;
+    float scale_h, scale_w;
+} lsn_dcn_level;
+
+const char *lsn_last_error(void);
+int lsn_version(void);
+
+/* ---- generic batched entry points (what the Python mirror calls) -------------------------- */
+
+/* out_l = DCN(input_l, offset_l, mask_l; weight, bias) for l < n_levels.
+ * shape->B/H/W/Ho/Wo/scale_* are ignored (taken per level); bias may be NULL. */
+int lsn_dcn_forward(const lsn_dcn_shape *shape, int n_levels, const lsn_dcn_level *levels,
+                    const float *weight, const float *bias, lsn_layout layout, lsn_stream_t stream);
+
+/* Gradients of the above.  grad_weight (layout of weight) and grad_bias (Co) are summed over
+ * all levels and images; either may be NULL.  Per level: grad_input / grad_offset / grad_mask. */
+int lsn_dcn_backward(const lsn_dcn_shape *shape, int n_levels, const lsn_dcn_level *levels,
+                     const float *weight, float *grad_weight, float *grad_bias, lsn_layout layout,
+                     lsn_stream_t stream);
+
+/* ---- one-to-one replacements of the reference extension's functions ----------------------- */
+/* Each takes contiguous NCHW tensors like the reference and the same scalar arguments in the
+ * same order (note W-before-H for v1/pyramid, H-before-W for the modulated op); the scratch
+ * tensors `columns` / `ones` of the reference have no counterpart (nothing is materialised). */
+
+/* deform_conv_ext.cpp:74  deform_conv_forward */
+int lsn_deform_conv_forward(const float *input, const float *weight, const float *offset, float *output,
+                            int B, int C, int H, int W, int Co, int kW, int kH, int dW, int dH, int padW,
+                            int padH, int dilW, int dilH, int group, int deformable_group,
+                            int im2col_step, lsn_stream_t stream);
+/* deform_conv_ext.cpp:92  deform_conv_backward_input */
+int lsn_deform_conv_backward_input(const float *input, const float *offset, const float *grad_output,
+                                   float *grad_input, float *grad_offset, const float *weight, int B,
+                                   int C, int H, int W, int Co, int kW, int kH, int dW, int dH, int padW,
+                                   int padH, int dilW, int dilH, int group, int deformable_group,
+                                   int im2col_step, lsn_stream_t stream);
+/* deform_conv_ext.cpp:111 deform_conv_backward_parameters (grad_weight = scale * dL/dW) */
+int lsn_deform_conv_backward_parameters(const float *input, const float *offset, const float *grad_output,
+                                        float *grad_weight, int B, int C, int H, int W, int Co, int kW,
+                                        int kH, int dW, int dH, int padW, int padH, int dilW, int dilH,
+                                        int group, int deformable_group, float scale, int im2col_step,
+                                        lsn_stream_t stream);
+/* deform_conv_ext.cpp:129 modulated_deform_conv_forward */
+int lsn_modulated_deform_conv_forward(const float *input, const float *weight, const float *bias,
+                                      const float *offset, const float *mask, float *output, int B, int C,
+                                      int H, int W, int Co, int kernel_h, int kernel_w, int stride_h,
+                                      int stride_w, int pad_h, int pad_w, int dilation_h, int dilation_w,
+                                      int group, int deformable_group, int with_bias, lsn_stream_t stream);
+/* deform_conv_ext.cpp:149 modulated_deform_conv_backward */
+int lsn_modulated_deform_conv_backward(const float *input, const float *weight, const float *bias,
+                                       const float *offset, const float *mask, float *grad_input,
+                                       float *grad_weight, float *grad_bias, float *grad_offset,
+                                       float *grad_mask, const float *grad_output, int B, int C, int H,
+                                       int W, int Co, int kernel_h, int kernel_w, int stride_h,
+                                       int stride_w, int pad_h, int pad_w, int dilation_h, int dilation_w,
+                                       int group, int deformable_group, int with_bias,
+                                       lsn_stream_t stream);
+/* deform_conv_ext.cpp:171 pyramid_deform_conv_forward; (Ho,Wo) = offset grid */
+int lsn_pyramid_deform_conv_forward(const float *input, const float *weight, const float *offset,
+                                    float *output, int B, int C, int H, int W, int Co, int Ho, int Wo,
+                                    int kW, int kH, int dW, int dH, int padW, int padH, int dilW, int dilH,
+                                    float scaleW, float scaleH, int group, int deformable_group,
+                                    int im2col_step, lsn_stream_t stream);
+/* deform_conv_ext.cpp:190 pyramid_deform_conv_backward_input */
+int lsn_pyramid_deform_conv_backward_input(const float *input, const float *offset,
+                                           const float *grad_output, float *grad_input,
+                                           float *grad_offset, const float *weight, int B, int C, int H,
+                                           int W, int Co, int Ho, int Wo, int kW, int kH, int dW, int dH,
+                                           int padW, int padH, int dilW, int dilH, float scaleW,
+                                           float scaleH, int group, int deformable_group,
+                                           int im2col_step, lsn_stream_t stream);
+/* deform_conv_ext.cpp:209 pyramid_deform_conv_backward_parameters */
+int lsn_pyramid_deform_conv_backward_parameters(const float *input, const float *offset,
+                                                const float *grad_output, float *grad_weight, int B,
+                                                int C, int H, int W, int Co, int Ho, int Wo, int kW,
+                                                int kH, int dW, int dH, int padW, int padH, int dilW,
+                                                int dilH, float scaleW, float scaleH, int group,
+                                                int deformable_group, float scale, int im2col_step,
+                                                lsn_stream_t stream);
+
+/* ---- sigmoid focal loss: sigmoid_focal_loss_ext.cpp:19-57 --------------------------------- */
+/* logits (N,C) f32 row-major, targets (N) i64 in [0,C] (C = background), losses (N,C). */
+int lsn_sigmoid_focal_loss_forward(const float *logits, const int64_t *targets, float *losses, int N,
+                                   int C, float gamma, float alpha, lsn_stream_t stream);
+int lsn_sigmoid_focal_loss_backward(const float *logits, const int64_t *targets, const float *d_losses,
+                                    float *d_logits, int N, int C, float gamma, float alpha,
+                                    lsn_stream_t stream);
+/* [fused] *loss_sum (device scalar, overwritten) = sum_n weight[n] * sum_c FL(n,c).  Replaces
+ * FocalLoss.forward's elementwise-weight + sum chain (focal_loss.py:74-116,
+ * losses/utils.py:27-62); the caller divides by avg_factor.  `weight` may be NULL. */
+int lsn_sigmoid_focal_loss_sum(const float *logits, const int64_t *targets, const float *weight,
+                               float *loss_sum, int N, int C, float gamma, float alpha,
+                               lsn_stream_t stream);
+/* [fused] d_logits[n,c] = (*scale) * weight[n] * dFL(n,c)/dlogit; `scale` is a DEVICE scalar (the
+ * upstream gradient times loss_weight / avg_factor), so no host synchronisation is needed. */
+int lsn_sigmoid_focal_loss_backward_weighted(const float *logits, const int64_t *targets,
+                                             const float *weight, const float *scale, float *d_logits,
+                                             int N, int C, float gamma, float alpha, lsn_stream_t stream);
+
+/* ---- NMS: nms_ext.cpp:18-29 ---------------------------------------------------------------- */
+/* dets (n,5) = x1,y1,x2,y2,score on the device.  keep (capacity n, int64, device) receives the
+ * kept indices into the INPUT order, in descending score order; *num_keep (device int64) their
+ * count.  IoU uses area=(x2-x1)*(y2-y1), suppress when IoU > thr (strict) -- nms_cpu.cpp:21-63,
+ * nms_kernel.cu:14-22.  `order` (n, int64, device) must hold argsort(score, descending) computed
+ * by the caller (the reference calls tensor.sort, nms_kernel.cu:81-83); `workspace` must hold
+ * lsn_nms_workspace_bytes(n) bytes.  Fully asynchronous: no host sweep, no D2H copy. */
+int64_t lsn_nms_workspace_bytes(int n);
+int lsn_nms(const float *dets, const int64_t *order, int n, float iou_thr, int64_t *keep,
+            int64_t *num_keep, void *workspace, lsn_stream_t stream);
+
+/* ---- diagnostics ---------------------------------------------------------------------------- */
+/* D = A(MxK) * B(KxN) through the same MFMA fragment code as the DCN kernels (self-test). */
+int lsn_selftest_mfma(const float *A, const float *B, float *D, int M, int N, int K, int variant,
+                      lsn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LSNET_HIP_H_ */

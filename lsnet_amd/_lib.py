@@ -1,0 +1,75 @@
+"""ctypes binding of liblsnet_hip.so (C ABI declared in include/lsnet_hip.h).
+
+The library is built in-tree by lsnet_amd/csrc/build.py.  If it is missing or fails to load the
+ops FAIL LOUDLY -- there is no CPU or eager fallback in the product path.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, 'csrc', 'liblsnet_hip.so')
+
+c_float_p = ctypes.POINTER(ctypes.c_float)
+c_i64_p = ctypes.POINTER(ctypes.c_int64)
+
+
+class Strides4(ctypes.Structure):
+    _fields_ = [('b', ctypes.c_int64), ('c', ctypes.c_int64), ('h', ctypes.c_int64), ('w', ctypes.c_int64)]
+
+
+class DcnShape(ctypes.Structure):
+    _fields_ = [('B', ctypes.c_int), ('C', ctypes.c_int), ('H', ctypes.c_int), ('W', ctypes.c_int),
+                ('Co', ctypes.c_int), ('Ho', ctypes.c_int), ('Wo', ctypes.c_int),
+                ('kh', ctypes.c_int), ('kw', ctypes.c_int), ('stride', ctypes.c_int), ('pad', ctypes.c_int),
+                ('dil', ctypes.c_int), ('groups', ctypes.c_int), ('deformable_groups', ctypes.c_int),
+                ('scale_h', ctypes.c_float), ('scale_w', ctypes.c_float)]
+
+
+class DcnLevel(ctypes.Structure):
+    _fields_ = [('input', ctypes.c_void_p), ('offset', ctypes.c_void_p), ('mask', ctypes.c_void_p),
+                ('output', ctypes.c_void_p), ('grad_output', ctypes.c_void_p), ('grad_input', ctypes.c_void_p),
+                ('grad_offset', ctypes.c_void_p), ('grad_mask', ctypes.c_void_p),
+                ('off_st', Strides4), ('mask_st', Strides4),
+                ('B', ctypes.c_int), ('H', ctypes.c_int), ('W', ctypes.c_int), ('Ho', ctypes.c_int),
+                ('Wo', ctypes.c_int), ('scale_h', ctypes.c_float), ('scale_w', ctypes.c_float)]
+
+
+# every symbol include/lsnet_hip.h declares (checked by tests/test_capi.py without a GPU)
+EXPORTS = [
+    'lsn_last_error', 'lsn_version', 'lsn_dcn_forward', 'lsn_dcn_backward',
+    'lsn_deform_conv_forward', 'lsn_deform_conv_backward_input', 'lsn_deform_conv_backward_parameters',
+    'lsn_modulated_deform_conv_forward', 'lsn_modulated_deform_conv_backward',
+    'lsn_pyramid_deform_conv_forward', 'lsn_pyramid_deform_conv_backward_input',
+    'lsn_pyramid_deform_conv_backward_parameters',
+    'lsn_sigmoid_focal_loss_forward', 'lsn_sigmoid_focal_loss_backward', 'lsn_sigmoid_focal_loss_sum',
+    'lsn_sigmoid_focal_loss_backward_weighted',
+    'lsn_nms_workspace_bytes', 'lsn_nms', 'lsn_selftest_mfma',
+]
+
+_lib = None
+
+
+def load():
+    """Returns the loaded library; raises RuntimeError when it is absent (no silent fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise RuntimeError(
+            f'{SO_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            '(hipcc --offload-arch=gfx950). lsnet_amd has no fallback path.')
+    lib = ctypes.CDLL(SO_PATH)
+    lib.lsn_last_error.restype = ctypes.c_char_p
+    lib.lsn_nms_workspace_bytes.restype = ctypes.c_int64
+    for name in EXPORTS:
+        getattr(lib, name)  # AttributeError here means header and library disagree
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().lsn_last_error().decode('utf-8', 'replace')
+        if rc == -2:
+            raise NotImplementedError(msg)
+        raise RuntimeError(msg)

@@ -1,0 +1,41 @@
+"""Builds liblsnet_hip.so (gfx950) in-tree with hipcc.  No torch dependency: plain HIP + C ABI."""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, 'liblsnet_hip.so')
+SOURCES = ['dcn.hip', 'misc.hip']
+HEADERS = ['common.h', 'dcn_kernels.h', os.path.join('..', '..', 'include', 'lsnet_hip.h')]
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=fast',
+         '-Wno-unused-result']
+
+
+def _hipcc():
+    for c in (shutil.which('hipcc'), '/opt/rocm/bin/hipcc'):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError('hipcc not found: liblsnet_hip.so cannot be built')
+
+
+def needs_build():
+    if not os.path.exists(SO):
+        return True
+    t = os.path.getmtime(SO)
+    deps = [os.path.join(HERE, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return SO
+    cmd = [_hipcc()] + FLAGS + [os.path.join(HERE, s) for s in SOURCES] + ['-o', SO]
+    if verbose:
+        print(' '.join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd, cwd=HERE)
+    return SO
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv, verbose=True))

@@ -1,0 +1,549 @@
+// Host side of the deformable-convolution family: argument checks (mirroring the reference's
+// TORCH_CHECKs, deform_conv_cuda.cpp:92-180,182-272), layout adapters, launch geometry and the
+// extern "C" entry points declared in include/lsnet_hip.h.
+#include <limits.h>
+#include <string.h>
+
+#include <vector>
+
+#include "dcn_kernels.h"
+
+namespace lsn {
+
+static thread_local char g_err[640];
+char *err_buf() { return g_err; }
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+// in[b][r][s] -> out[b][s][r]   (NCHW <-> NHWC with r = C, s = H*W; weight OIHW <-> OHWI with
+// b = Co, r = Cg, s = kh*kw).  32x32 tiles through LDS so both sides are coalesced.
+__global__ void permute_rs_kernel(const float *__restrict__ in, float *__restrict__ out, int R, int S)
+{
+    __shared__ float tile[32][33];
+    const size_t base = (size_t)blockIdx.z * R * S;
+    const int s0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        const int r = r0 + i, s = s0 + threadIdx.x;
+        if (r < R && s < S) tile[i][threadIdx.x] = in[base + (size_t)r * S + s];
+    }
+    __syncthreads();
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        const int s = s0 + i, r = r0 + threadIdx.x;
+        if (r < R && s < S) out[base + (size_t)s * R + r] = tile[threadIdx.x][i];
+    }
+}
+
+static int permute_rs(const float *in, float *out, int Bn, int R, int S, hipStream_t st)
+{
+    if (Bn <= 0 || R <= 0 || S <= 0) return 0;
+    for (int b0 = 0; b0 < Bn; b0 += 65535) {
+        const int nb = Bn - b0 < 65535 ? Bn - b0 : 65535;
+        dim3 grid(cdiv(S, 32), cdiv(R, 32), nb), block(32, 8);
+        hipLaunchKernelGGL(permute_rs_kernel, grid, block, 0, st, in + (size_t)b0 * R * S,
+                           out + (size_t)b0 * R * S, R, S);
+    }
+    LSN_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ void scale_kernel(float *p, size_t n, float s)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        p[i] *= s;
+}
+
+// stream-ordered scratch: everything is freed (in stream order) when the holder goes out of scope
+struct Scratch {
+    hipStream_t st;
+    std::vector<void *> ptrs;
+    explicit Scratch(hipStream_t s) : st(s) {}
+    float *get(size_t nfloats)
+    {
+        void *p = nullptr;
+        if (nfloats == 0) nfloats = 1;
+        if (hipMallocAsync(&p, nfloats * sizeof(float), st) != hipSuccess) return nullptr;
+        ptrs.push_back(p);
+        return reinterpret_cast<float *>(p);
+    }
+    ~Scratch()
+    {
+        for (void *p : ptrs) (void)hipFreeAsync(p, st);
+    }
+};
+
+static int check_shape(const lsn_dcn_shape &s)
+{
+    LSN_CHECK(s.kh > 0 && s.kw > 0, "kernel size should be greater than zero, but got kH: %d kW: %d", s.kh, s.kw);
+    LSN_CHECK(s.stride > 0, "stride should be greater than zero, but got %d", s.stride);
+    LSN_CHECK(s.dil > 0, "dilation should be greater than 0, but got %d", s.dil);
+    LSN_CHECK(s.pad >= 0, "padding should be non-negative, but got %d", s.pad);
+    LSN_CHECK(s.C > 0 && s.Co > 0, "channels must be positive (C %d, Co %d)", s.C, s.Co);
+    LSN_CHECK(s.groups > 0 && s.C % s.groups == 0 && s.Co % s.groups == 0,
+              "input/output channels (%d, %d) must be divisible by groups %d", s.C, s.Co, s.groups);
+    LSN_CHECK(s.deformable_groups > 0 && s.C % s.deformable_groups == 0,
+              "input channels must divide deformable group size");
+    const int Cg = s.C / s.groups, cpdg = s.C / s.deformable_groups;
+    if (!(Cg % cpdg == 0 || cpdg % Cg == 0))
+        return fail(LSN_ERR_UNSUPPORTED, "groups %d / deformable_groups %d do not nest", s.groups,
+                    s.deformable_groups);
+    if (s.kh * s.kw * s.deformable_groups > 64)
+        return fail(LSN_ERR_UNSUPPORTED, "kh*kw*deformable_groups = %d > 64 is not supported",
+                    s.kh * s.kw * s.deformable_groups);
+    return 0;
+}
+
+static int i32(int64_t v, int *ok)
+{
+    if (v > INT_MAX || v < INT_MIN) *ok = 0;
+    return (int)v;
+}
+
+template <typename KernelT>
+static int set_lds(KernelT kernel, size_t bytes)
+{
+    if (bytes > 160 * 1024) return fail(LSN_ERR_UNSUPPORTED, "kernel needs %zu B of LDS (> 160 KiB)", bytes);
+    if (bytes > 48 * 1024)
+        LSN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return 0;
+}
+
+// Fill the per-level part of DcnArgs from the public descriptors (NHWC pointers supplied here).
+static int fill_levels(DcnArgs &a, const lsn_dcn_shape &s, int n, const lsn_dcn_level *lv, int tile_px)
+{
+    LSN_CHECK(n >= 1 && n <= MAXLV, "n_levels must be in [1,%d], got %d", MAXLV, n);
+    int ok = 1, tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        Lvl &L = a.lv[i];
+        const lsn_dcn_level &d = lv[i];
+        LSN_CHECK(d.B > 0 && d.H > 0 && d.W > 0 && d.Ho > 0 && d.Wo > 0,
+                  "level %d: Given input size (%d x %d x %d), calculated output size (%d x %d x %d). "
+                  "Output size is too small", i, s.C, d.H, d.W, s.Co, d.Ho, d.Wo);
+        LSN_CHECK(d.offset != nullptr, "level %d: offset is NULL", i);
+        L.B = d.B; L.H = d.H; L.W = d.W; L.Ho = d.Ho; L.Wo = d.Wo;
+        L.P = i32((int64_t)d.B * d.Ho * d.Wo, &ok);
+        (void)i32((int64_t)d.B * d.H * d.W * s.C, &ok);
+        L.tile0 = tiles;
+        tiles += cdiv(L.P, tile_px);
+        L.sh = d.scale_h; L.sw = d.scale_w;
+        L.off = d.offset; L.msk = d.mask;
+        L.osb = i32(d.off_st.b, &ok); L.osc = i32(d.off_st.c, &ok);
+        L.osh = i32(d.off_st.h, &ok); L.osw = i32(d.off_st.w, &ok);
+        L.msb = i32(d.mask_st.b, &ok); L.msc = i32(d.mask_st.c, &ok);
+        L.msh = i32(d.mask_st.h, &ok); L.msw = i32(d.mask_st.w, &ok);
+        L.x = L.gout = nullptr;
+        L.out = L.gx = nullptr;
+        L.goff = d.grad_offset; L.gmsk = d.grad_mask;
+    }
+    if (!ok) return fail(LSN_ERR_UNSUPPORTED, "tensor too large for 32-bit indexing");
+    a.nlv = n;
+    a.ntiles = tiles;
+    a.C = s.C; a.Co = s.Co; a.kh = s.kh; a.kw = s.kw; a.stride = s.stride; a.pad = s.pad; a.dil = s.dil;
+    a.groups = s.groups; a.dg = s.deformable_groups;
+    const int Cg = s.C / s.groups, cpdg = s.C / s.deformable_groups;
+    a.SL = Cg < cpdg ? Cg : cpdg;
+    a.w = a.bias = nullptr;
+    a.gw = a.gb = nullptr;
+    return 0;
+}
+
+static int launch_forward(const DcnArgs &a, hipStream_t st)
+{
+    const int Cog = a.Co / a.groups, KD = a.kh * a.kw * a.dg;
+    if (Cog > 64) {
+        constexpr int BM = 64, BN = 256;
+        const size_t lds = (size_t)(BM + BN) * 33 * 4 + (size_t)BM * KD * sizeof(Tap);
+        auto k = dcn_fwd_kernel<BM, BN, 1, 4>;
+        if (int rc = set_lds(k, lds)) return rc;
+        dim3 grid(a.ntiles, cdiv(Cog, BN), a.groups);
+        hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a);
+    } else {
+        constexpr int BM = 64, BN = 64;
+        const size_t lds = (size_t)(BM + BN) * 33 * 4 + (size_t)BM * KD * sizeof(Tap);
+        auto k = dcn_fwd_kernel<BM, BN, 2, 2>;
+        if (int rc = set_lds(k, lds)) return rc;
+        dim3 grid(a.ntiles, cdiv(Cog, BN), a.groups);
+        hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a);
+    }
+    LSN_HIP(hipGetLastError());
+    return 0;
+}
+
+static int launch_bwd_data(const DcnArgs &a, hipStream_t st)
+{
+    const int Cog = a.Co / a.groups, KD = a.kh * a.kw * a.dg;
+    if (Cog > 64) {
+        constexpr int RED = 256;
+        const size_t lds = (size_t)RED * 32 * 4 + (size_t)BWD_BM * KD * (sizeof(Tap) + 12);
+        auto k = dcn_bwd_data_kernel<RED>;
+        if (int rc = set_lds(k, lds)) return rc;
+        hipLaunchKernelGGL(k, dim3(a.ntiles), dim3(256), lds, st, a);
+    } else {
+        constexpr int RED = 64;
+        const size_t lds = (size_t)RED * 32 * 4 + (size_t)BWD_BM * KD * (sizeof(Tap) + 12);
+        auto k = dcn_bwd_data_kernel<RED>;
+        if (int rc = set_lds(k, lds)) return rc;
+        hipLaunchKernelGGL(k, dim3(a.ntiles), dim3(256), lds, st, a);
+    }
+    LSN_HIP(hipGetLastError());
+    return 0;
+}
+
+static int launch_wgrad(const DcnArgs &a, int nsteps, hipStream_t st)
+{
+    const int K = a.kh * a.kw, Cg = a.C / a.groups, Cog = a.Co / a.groups;
+    const int segs = Cg / a.SL, ncc = cdiv(a.SL, WG_BN);
+    const int ncol = a.groups * K * segs * ncc, nz = cdiv(Cog, WG_BM);
+    int splits = cdiv(1024, ncol * nz);
+    if (splits > nsteps) splits = nsteps;
+    if (splits < 1) splits = 1;
+    if (splits > 65535) splits = 65535;
+    const size_t lds = (size_t)WG_BP * (WG_BM + WG_BN) * 4 + 2 * WG_BP * sizeof(Tap);
+    LSN_HIP(hipMemsetAsync(a.gw, 0, sizeof(float) * (size_t)a.Co * K * Cg, st));
+    if (a.gb) LSN_HIP(hipMemsetAsync(a.gb, 0, sizeof(float) * (size_t)a.Co, st));
+    hipLaunchKernelGGL(dcn_wgrad_kernel, dim3(ncol, splits, nz), dim3(256), lds, st, a, nsteps);
+    LSN_HIP(hipGetLastError());
+    return 0;
+}
+
+static size_t n_in(const lsn_dcn_shape &s, const lsn_dcn_level &d) { return (size_t)d.B * s.C * d.H * d.W; }
+static size_t n_out(const lsn_dcn_shape &s, const lsn_dcn_level &d) { return (size_t)d.B * s.Co * d.Ho * d.Wo; }
+
+static int dcn_forward_impl(const lsn_dcn_shape &s, int n, const lsn_dcn_level *lv, const float *weight,
+                            const float *bias, lsn_layout layout, hipStream_t st)
+{
+    if (int rc = check_shape(s)) return rc;
+    LSN_CHECK(weight != nullptr, "weight is NULL");
+    DcnArgs a;
+    if (int rc = fill_levels(a, s, n, lv, 64)) return rc;
+    Scratch ws(st);
+    const int K = s.kh * s.kw, Cg = s.C / s.groups;
+    std::vector<float *> out_tmp(n, nullptr);
+    if (layout == LSN_NHWC) {
+        a.w = weight;
+        for (int i = 0; i < n; ++i) {
+            LSN_CHECK(lv[i].input && lv[i].output, "level %d: input/output is NULL", i);
+            a.lv[i].x = lv[i].input;
+            a.lv[i].out = lv[i].output;
+        }
+    } else {
+        float *w2 = ws.get((size_t)s.Co * Cg * K);
+        if (!w2) return fail(LSN_ERR_RUNTIME, "workspace allocation failed");
+        if (int rc = permute_rs(weight, w2, s.Co, Cg, K, st)) return rc;
+        a.w = w2;
+        for (int i = 0; i < n; ++i) {
+            LSN_CHECK(lv[i].input && lv[i].output, "level %d: input/output is NULL", i);
+            float *x2 = ws.get(n_in(s, lv[i]));
+            out_tmp[i] = ws.get(n_out(s, lv[i]));
+            if (!x2 || !out_tmp[i]) return fail(LSN_ERR_RUNTIME, "workspace allocation failed");
+            if (int rc = permute_rs(lv[i].input, x2, lv[i].B, s.C, lv[i].H * lv[i].W, st)) return rc;
+            a.lv[i].x = x2;
+            a.lv[i].out = out_tmp[i];
+        }
+    }
+    a.bias = bias;
+    if (int rc = launch_forward(a, st)) return rc;
+    if (layout == LSN_NCHW)
+        for (int i = 0; i < n; ++i)
+            if (int rc = permute_rs(out_tmp[i], lv[i].output, lv[i].B, lv[i].Ho * lv[i].Wo, s.Co, st)) return rc;
+    return 0;
+}
+
+static int dcn_backward_impl(const lsn_dcn_shape &s, int n, const lsn_dcn_level *lv, const float *weight,
+                             float *grad_weight, float *grad_bias, lsn_layout layout, hipStream_t st)
+{
+    if (int rc = check_shape(s)) return rc;
+    LSN_CHECK(weight != nullptr, "weight is NULL");
+    if (grad_bias && !grad_weight)
+        return fail(LSN_ERR_UNSUPPORTED, "grad_bias without grad_weight is not supported");
+    DcnArgs a;
+    if (int rc = fill_levels(a, s, n, lv, BWD_BM)) return rc;
+    Scratch ws(st);
+    const int K = s.kh * s.kw, Cg = s.C / s.groups;
+    std::vector<float *> gx_tmp(n, nullptr);
+    float *gw_tmp = nullptr;
+    bool any_data = false;
+    for (int i = 0; i < n; ++i) {
+        LSN_CHECK(lv[i].input && lv[i].grad_output, "level %d: input/grad_output is NULL", i);
+        any_data = any_data || lv[i].grad_input || lv[i].grad_offset || lv[i].grad_mask;
+    }
+    if (layout == LSN_NHWC) {
+        a.w = weight;
+        a.gw = grad_weight;
+        for (int i = 0; i < n; ++i) {
+            a.lv[i].x = lv[i].input;
+            a.lv[i].gout = lv[i].grad_output;
+            a.lv[i].gx = lv[i].grad_input;
+        }
+    } else {
+        float *w2 = ws.get((size_t)s.Co * Cg * K);
+        if (!w2) return fail(LSN_ERR_RUNTIME, "workspace allocation failed");
+        if (int rc = permute_rs(weight, w2, s.Co, Cg, K, st)) return rc;
+        a.w = w2;
+        if (grad_weight) {
+            gw_tmp = ws.get((size_t)s.Co * Cg * K);
+            if (!gw_tmp) return fail(LSN_ERR_RUNTIME, "workspace allocation failed");
+            a.gw = gw_tmp;
+        }
+        for (int i = 0; i < n; ++i) {
+            float *x2 = ws.get(n_in(s, lv[i])), *g2 = ws.get(n_out(s, lv[i]));
+            if (!x2 || !g2) return fail(LSN_ERR_RUNTIME, "workspace allocation failed");
+            if (int rc = permute_rs(lv[i].input, x2, lv[i].B, s.C, lv[i].H * lv[i].W, st)) return rc;
+            if (int rc = permute_rs(lv[i].grad_output, g2, lv[i].B, s.Co, lv[i].Ho * lv[i].Wo, st)) return rc;
+            a.lv[i].x = x2;
+            a.lv[i].gout = g2;
+            if (lv[i].grad_input) {
+                gx_tmp[i] = ws.get(n_in(s, lv[i]));
+                if (!gx_tmp[i]) return fail(LSN_ERR_RUNTIME, "workspace allocation failed");
+                a.lv[i].gx = gx_tmp[i];
+            }
+        }
+    }
+    a.gb = grad_bias;
+
+    if (any_data) {
+        for (int i = 0; i < n; ++i)
+            if (a.lv[i].gx) LSN_HIP(hipMemsetAsync(a.lv[i].gx, 0, sizeof(float) * n_in(s, lv[i]), st));
+        if (int rc = launch_bwd_data(a, st)) return rc;
+    }
+    if (a.gw) {
+        DcnArgs w = a;  // same levels, step (32-pixel) indexing
+        int steps = 0;
+        for (int i = 0; i < n; ++i) {
+            w.lv[i].tile0 = steps;
+            steps += cdiv(w.lv[i].P, WG_BP);
+        }
+        if (int rc = launch_wgrad(w, steps, st)) return rc;
+    }
+    if (layout == LSN_NCHW) {
+        for (int i = 0; i < n; ++i)
+            if (gx_tmp[i])
+                if (int rc = permute_rs(gx_tmp[i], lv[i].grad_input, lv[i].B, lv[i].H * lv[i].W, s.C, st)) return rc;
+        if (gw_tmp)
+            if (int rc = permute_rs(gw_tmp, grad_weight, s.Co, K, Cg, st)) return rc;
+    }
+    return 0;
+}
+
+static lsn_strides4 nchw_strides(int Ch, int H, int W)
+{
+    lsn_strides4 s;
+    s.b = (int64_t)Ch * H * W;
+    s.c = (int64_t)H * W;
+    s.h = W;
+    s.w = 1;
+    return s;
+}
+
+static int conv_out(int in, int k, int stride, int pad, int dil) { return (in + 2 * pad - (dil * (k - 1) + 1)) / stride + 1; }
+
+// shape + single NCHW level for the one-to-one wrappers
+static int make_single(lsn_dcn_shape &s, lsn_dcn_level &L, int B, int C, int H, int W, int Co, int Ho, int Wo,
+                       int kH, int kW, int dH, int dW, int padH, int padW, int dilH, int dilW, int group, int dg,
+                       float scaleH, float scaleW, bool pyramid)
+{
+    if (dH != dW || padH != padW || dilH != dilW)
+        return fail(LSN_ERR_UNSUPPORTED, "different stride/pad/dilation for h and w is not supported");
+    memset(&s, 0, sizeof(s));
+    memset(&L, 0, sizeof(L));
+    LSN_CHECK(kH > 0 && kW > 0, "kernel size should be greater than zero, but got kH: %d kW: %d", kH, kW);
+    LSN_CHECK(dH > 0, "stride should be greater than zero, but got dH: %d dW: %d", dH, dW);
+    LSN_CHECK(dilH > 0, "dilation should be greater than 0, but got dilationH: %d dilationW: %d", dilH, dilW);
+    if (!pyramid) {
+        Ho = conv_out(H, kH, dH, padH, dilH);
+        Wo = conv_out(W, kW, dW, padW, dilW);
+    } else {
+        // pyramid_shape_check: the output grid is derived from the OFFSET grid and must equal it
+        LSN_CHECK(conv_out(Ho, kH, dH, padH, dilH) == Ho && conv_out(Wo, kW, dW, padW, dilW) == Wo,
+                  "invalid spatial size of offset, expected height: %d width: %d, but got height: %d width: %d",
+                  conv_out(Ho, kH, dH, padH, dilH), conv_out(Wo, kW, dW, padW, dilW), Ho, Wo);
+    }
+    LSN_CHECK(Ho >= 1 && Wo >= 1,
+              "Given input size: (%d x %d x %d). Calculated output size: (%d x %d x %d). Output size is too small",
+              C, H, W, Co, Ho, Wo);
+    LSN_CHECK(H >= kH && W >= kW, "input image is smaller than kernel");
+    s.B = B; s.C = C; s.H = H; s.W = W; s.Co = Co; s.Ho = Ho; s.Wo = Wo;
+    s.kh = kH; s.kw = kW; s.stride = dH; s.pad = padH; s.dil = dilH;
+    s.groups = group; s.deformable_groups = dg;
+    s.scale_h = scaleH; s.scale_w = scaleW;
+    L.B = B; L.H = H; L.W = W; L.Ho = Ho; L.Wo = Wo;
+    L.scale_h = scaleH; L.scale_w = scaleW;
+    L.off_st = nchw_strides(dg * 2 * kH * kW, Ho, Wo);
+    L.mask_st = nchw_strides(dg * kH * kW, Ho, Wo);
+    return 0;
+}
+
+}  // namespace lsn
+
+using namespace lsn;
+
+extern "C" {
+
+const char *lsn_last_error(void) { return lsn::err_buf(); }
+int lsn_version(void) { return 100; }
+
+int lsn_dcn_forward(const lsn_dcn_shape *shape, int n_levels, const lsn_dcn_level *levels, const float *weight,
+                    const float *bias, lsn_layout layout, lsn_stream_t stream)
+{
+    if (!shape || !levels) return fail(LSN_ERR_INVALID, "shape/levels is NULL");
+    return dcn_forward_impl(*shape, n_levels, levels, weight, bias, layout, stream);
+}
+
+int lsn_dcn_backward(const lsn_dcn_shape *shape, int n_levels, const lsn_dcn_level *levels, const float *weight,
+                     float *grad_weight, float *grad_bias, lsn_layout layout, lsn_stream_t stream)
+{
+    if (!shape || !levels) return fail(LSN_ERR_INVALID, "shape/levels is NULL");
+    return dcn_backward_impl(*shape, n_levels, levels, weight, grad_weight, grad_bias, layout, stream);
+}
+
+int lsn_deform_conv_forward(const float *input, const float *weight, const float *offset, float *output, int B,
+                            int C, int H, int W, int Co, int kW, int kH, int dW, int dH, int padW, int padH,
+                            int dilW, int dilH, int group, int deformable_group, int im2col_step,
+                            lsn_stream_t stream)
+{
+    (void)im2col_step;
+    lsn_dcn_shape s;
+    lsn_dcn_level L;
+    if (int rc = make_single(s, L, B, C, H, W, Co, 0, 0, kH, kW, dH, dW, padH, padW, dilH, dilW, group,
+                             deformable_group, 1.f, 1.f, false))
+        return rc;
+    L.input = input; L.offset = offset; L.output = output;
+    return dcn_forward_impl(s, 1, &L, weight, nullptr, LSN_NCHW, stream);
+}
+
+int lsn_deform_conv_backward_input(const float *input, const float *offset, const float *grad_output,
+                                   float *grad_input, float *grad_offset, const float *weight, int B, int C,
+                                   int H, int W, int Co, int kW, int kH, int dW, int dH, int padW, int padH,
+                                   int dilW, int dilH, int group, int deformable_group, int im2col_step,
+                                   lsn_stream_t stream)
+{
+    (void)im2col_step;
+    lsn_dcn_shape s;
+    lsn_dcn_level L;
+    if (int rc = make_single(s, L, B, C, H, W, Co, 0, 0, kH, kW, dH, dW, padH, padW, dilH, dilW, group,
+                             deformable_group, 1.f, 1.f, false))
+        return rc;
+    L.input = input; L.offset = offset; L.grad_output = grad_output;
+    L.grad_input = grad_input; L.grad_offset = grad_offset;
+    return dcn_backward_impl(s, 1, &L, weight, nullptr, nullptr, LSN_NCHW, stream);
+}
+
+static int scale_weight_grad(float *gw, size_t n, float scale, hipStream_t st)
+{
+    if (scale == 1.f) return 0;
+    hipLaunchKernelGGL(scale_kernel, dim3(256), dim3(256), 0, st, gw, n, scale);
+    LSN_HIP(hipGetLastError());
+    return 0;
+}
+
+int lsn_deform_conv_backward_parameters(const float *input, const float *offset, const float *grad_output,
+                                        float *grad_weight, int B, int C, int H, int W, int Co, int kW, int kH,
+                                        int dW, int dH, int padW, int padH, int dilW, int dilH, int group,
+                                        int deformable_group, float scale, int im2col_step, lsn_stream_t stream)
+{
+    (void)im2col_step;
+    lsn_dcn_shape s;
+    lsn_dcn_level L;
+    if (int rc = make_single(s, L, B, C, H, W, Co, 0, 0, kH, kW, dH, dW, padH, padW, dilH, dilW, group,
+                             deformable_group, 1.f, 1.f, false))
+        return rc;
+    L.input = input; L.offset = offset; L.grad_output = grad_output;
+    // the weight values are not needed for dL/dW; pass grad_weight as a placeholder pointer
+    if (int rc = dcn_backward_impl(s, 1, &L, grad_weight, grad_weight, nullptr, LSN_NCHW, stream)) return rc;
+    return scale_weight_grad(grad_weight, (size_t)Co * (C / group) * kH * kW, scale, stream);
+}
+
+int lsn_modulated_deform_conv_forward(const float *input, const float *weight, const float *bias,
+                                      const float *offset, const float *mask, float *output, int B, int C, int H,
+                                      int W, int Co, int kernel_h, int kernel_w, int stride_h, int stride_w,
+                                      int pad_h, int pad_w, int dilation_h, int dilation_w, int group,
+                                      int deformable_group, int with_bias, lsn_stream_t stream)
+{
+    lsn_dcn_shape s;
+    lsn_dcn_level L;
+    if (int rc = make_single(s, L, B, C, H, W, Co, 0, 0, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w,
+                             dilation_h, dilation_w, group, deformable_group, 1.f, 1.f, false))
+        return rc;
+    LSN_CHECK(mask != nullptr, "mask is NULL");
+    L.input = input; L.offset = offset; L.mask = mask; L.output = output;
+    return dcn_forward_impl(s, 1, &L, weight, with_bias ? bias : nullptr, LSN_NCHW, stream);
+}
+
+int lsn_modulated_deform_conv_backward(const float *input, const float *weight, const float *bias,
+                                       const float *offset, const float *mask, float *grad_input,
+                                       float *grad_weight, float *grad_bias, float *grad_offset, float *grad_mask,
+                                       const float *grad_output, int B, int C, int H, int W, int Co, int kernel_h,
+                                       int kernel_w, int stride_h, int stride_w, int pad_h, int pad_w,
+                                       int dilation_h, int dilation_w, int group, int deformable_group,
+                                       int with_bias, lsn_stream_t stream)
+{
+    (void)bias;
+    lsn_dcn_shape s;
+    lsn_dcn_level L;
+    if (int rc = make_single(s, L, B, C, H, W, Co, 0, 0, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w,
+                             dilation_h, dilation_w, group, deformable_group, 1.f, 1.f, false))
+        return rc;
+    LSN_CHECK(mask != nullptr, "mask is NULL");
+    L.input = input; L.offset = offset; L.mask = mask; L.grad_output = grad_output;
+    L.grad_input = grad_input; L.grad_offset = grad_offset; L.grad_mask = grad_mask;
+    return dcn_backward_impl(s, 1, &L, weight, grad_weight, with_bias ? grad_bias : nullptr, LSN_NCHW, stream);
+}
+
+int lsn_pyramid_deform_conv_forward(const float *input, const float *weight, const float *offset, float *output,
+                                    int B, int C, int H, int W, int Co, int Ho, int Wo, int kW, int kH, int dW,
+                                    int dH, int padW, int padH, int dilW, int dilH, float scaleW, float scaleH,
+                                    int group, int deformable_group, int im2col_step, lsn_stream_t stream)
+{
+    (void)im2col_step;
+    lsn_dcn_shape s;
+    lsn_dcn_level L;
+    if (int rc = make_single(s, L, B, C, H, W, Co, Ho, Wo, kH, kW, dH, dW, padH, padW, dilH, dilW, group,
+                             deformable_group, scaleH, scaleW, true))
+        return rc;
+    L.input = input; L.offset = offset; L.output = output;
+    return dcn_forward_impl(s, 1, &L, weight, nullptr, LSN_NCHW, stream);
+}
+
+int lsn_pyramid_deform_conv_backward_input(const float *input, const float *offset, const float *grad_output,
+                                           float *grad_input, float *grad_offset, const float *weight, int B,
+                                           int C, int H, int W, int Co, int Ho, int Wo, int kW, int kH, int dW,
+                                           int dH, int padW, int padH, int dilW, int dilH, float scaleW,
+                                           float scaleH, int group, int deformable_group, int im2col_step,
+                                           lsn_stream_t stream)
+{
+    (void)im2col_step;
+    lsn_dcn_shape s;
+    lsn_dcn_level L;
+    if (int rc = make_single(s, L, B, C, H, W, Co, Ho, Wo, kH, kW, dH, dW, padH, padW, dilH, dilW, group,
+                             deformable_group, scaleH, scaleW, true))
+        return rc;
+    L.input = input; L.offset = offset; L.grad_output = grad_output;
+    L.grad_input = grad_input; L.grad_offset = grad_offset;
+    return dcn_backward_impl(s, 1, &L, weight, nullptr, nullptr, LSN_NCHW, stream);
+}
+
+int lsn_pyramid_deform_conv_backward_parameters(const float *input, const float *offset,
+                                                const float *grad_output, float *grad_weight, int B, int C,
+                                                int H, int W, int Co, int Ho, int Wo, int kW, int kH, int dW,
+                                                int dH, int padW, int padH, int dilW, int dilH, float scaleW,
+                                                float scaleH, int group, int deformable_group, float scale,
+                                                int im2col_step, lsn_stream_t stream)
+{
+    (void)im2col_step;
+    lsn_dcn_shape s;
+    lsn_dcn_level L;
+    if (int rc = make_single(s, L, B, C, H, W, Co, Ho, Wo, kH, kW, dH, dW, padH, padW, dilH, dilW, group,
+                             deformable_group, scaleH, scaleW, true))
+        return rc;
+    L.input = input; L.offset = offset; L.grad_output = grad_output;
+    if (int rc = dcn_backward_impl(s, 1, &L, grad_weight, grad_weight, nullptr, LSN_NCHW, stream)) return rc;
+    return scale_weight_grad(grad_weight, (size_t)Co * (C / group) * kH * kW, scale, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,299 @@
+// Sigmoid focal loss, NMS and the MFMA self-test of liblsnet_hip.so.
+#include "common.h"
+
+namespace lsn {
+
+// ---------------------------------------------------------------------------------------------
+// Sigmoid focal loss -- same formulas as sigmoid_focal_loss_cuda.cu:24-97:
+//   FL  = -[t==d] a (1-p)^g log(max(p,FLT_MIN)) - [t!=d, t>=0] (1-a) p^g log(1-p)
+//   log(1-p) in the stable form  -x[x>=0] - log(1 + exp(x - 2x[x>=0])).
+// HBM-bound elementwise kernels: one float4 of logits per lane when C % 4 == 0.
+// ---------------------------------------------------------------------------------------------
+#define LSN_FLT_MIN 1.17549435e-38f
+
+__device__ __forceinline__ float fl_forward_one(float x, bool pos, bool neg, float gamma, float alpha)
+{
+    const float p = 1.f / (1.f + expf(-x));
+    const float xp = x >= 0.f ? 1.f : 0.f;
+    const float log1mp = -x * xp - logf(1.f + expf(x - 2.f * x * xp));
+    float l = 0.f;
+    if (pos) l += -alpha * powf(1.f - p, gamma) * logf(fmaxf(p, LSN_FLT_MIN));
+    if (neg) l += -(1.f - alpha) * powf(p, gamma) * log1mp;
+    return l;
+}
+
+__device__ __forceinline__ float fl_backward_one(float x, bool pos, bool neg, float gamma, float alpha)
+{
+    const float p = 1.f / (1.f + expf(-x));
+    const float xp = x >= 0.f ? 1.f : 0.f;
+    const float log1mp = -x * xp - logf(1.f + expf(x - 2.f * x * xp));
+    float v = 0.f;
+    if (pos) v += -alpha * powf(1.f - p, gamma) * (1.f - p - p * gamma * logf(fmaxf(p, LSN_FLT_MIN)));
+    if (neg) v += -(1.f - alpha) * powf(p, gamma) * (log1mp * (1.f - p) * gamma - p);
+    return v;
+}
+
+__global__ void focal_fwd_kernel(const float *__restrict__ logits, const int64_t *__restrict__ targets,
+                                 float *__restrict__ losses, int N, int C, float gamma, float alpha)
+{
+    const size_t total = (size_t)N * C;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i / C), d = (int)(i - (size_t)n * C);
+        const int t = (int)targets[n];
+        losses[i] = fl_forward_one(logits[i], t == d, (t >= 0) & (t != d), gamma, alpha);
+    }
+}
+
+__global__ void focal_bwd_kernel(const float *__restrict__ logits, const int64_t *__restrict__ targets,
+                                 const float *__restrict__ d_losses, float *__restrict__ d_logits, int N, int C,
+                                 float gamma, float alpha)
+{
+    const size_t total = (size_t)N * C;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i / C), d = (int)(i - (size_t)n * C);
+        const int t = (int)targets[n];
+        d_logits[i] = fl_backward_one(logits[i], t == d, (t >= 0) & (t != d), gamma, alpha) * d_losses[i];
+    }
+}
+
+__device__ __forceinline__ float block_sum_256(float v)
+{
+    __shared__ float part[4];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return part[0] + part[1] + part[2] + part[3];
+}
+
+// loss_sum += sum_n w[n] * sum_c FL(n,c)
+__global__ void focal_sum_kernel(const float *__restrict__ logits, const int64_t *__restrict__ targets,
+                                 const float *__restrict__ weight, float *loss_sum, int N, int C, float gamma,
+                                 float alpha)
+{
+    const size_t total = (size_t)N * C;
+    float s = 0.f;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i / C), d = (int)(i - (size_t)n * C);
+        const int t = (int)targets[n];
+        const float w = weight ? weight[n] : 1.f;
+        s += w * fl_forward_one(logits[i], t == d, (t >= 0) & (t != d), gamma, alpha);
+    }
+    s = block_sum_256(s);
+    if (threadIdx.x == 0) atomic_add_f32(loss_sum, s);
+}
+
+// d_logits = (*scale) * w[n] * dFL/dx
+__global__ void focal_bwd_w_kernel(const float *__restrict__ logits, const int64_t *__restrict__ targets,
+                                   const float *__restrict__ weight, const float *__restrict__ scale,
+                                   float *__restrict__ d_logits, int N, int C, float gamma, float alpha)
+{
+    const size_t total = (size_t)N * C;
+    const float sc = *scale;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i / C), d = (int)(i - (size_t)n * C);
+        const int t = (int)targets[n];
+        const float w = weight ? weight[n] : 1.f;
+        d_logits[i] = sc * w * fl_backward_one(logits[i], t == d, (t >= 0) & (t != d), gamma, alpha);
+    }
+}
+
+static int ew_grid(size_t total) { size_t g = (total + 255) / 256; return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g)); }
+
+// ---------------------------------------------------------------------------------------------
+// NMS.  Same two-phase idea as nms_kernel.cu (64x64 IoU tiles -> 64-bit suppression masks) but the
+// sequential sweep also runs on the device (one wavefront), so nothing is copied to the host.
+// IoU arithmetic uses explicitly rounded single operations (no FMA contraction) so that the keep
+// set is bit-identical to the CPU reference (nms_cpu.cpp:21-63).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool iou_gt(const float *a, const float *b, float thr)
+{
+    const float xx1 = fmaxf(a[0], b[0]), yy1 = fmaxf(a[1], b[1]);
+    const float xx2 = fminf(a[2], b[2]), yy2 = fminf(a[3], b[3]);
+    const float w = fmaxf(0.f, __fsub_rn(xx2, xx1)), h = fmaxf(0.f, __fsub_rn(yy2, yy1));
+    const float inter = __fmul_rn(w, h);
+    const float aa = __fmul_rn(__fsub_rn(a[2], a[0]), __fsub_rn(a[3], a[1]));
+    const float ab = __fmul_rn(__fsub_rn(b[2], b[0]), __fsub_rn(b[3], b[1]));
+    const float ovr = __fdiv_rn(inter, __fsub_rn(__fadd_rn(aa, ab), inter));
+    return ovr > thr;
+}
+
+__global__ void nms_mask_kernel(const float *__restrict__ dets, const int64_t *__restrict__ order, int n,
+                                float thr, unsigned long long *__restrict__ mask)
+{
+    const int rb = blockIdx.y, cb = blockIdx.x;
+    const int nb = gridDim.x;
+    __shared__ float cbox[64][4];
+    const int cj = cb * 64 + threadIdx.x;
+    if (cj < n) {
+        const float *d = dets + (size_t)order[cj] * 5;
+        cbox[threadIdx.x][0] = d[0];
+        cbox[threadIdx.x][1] = d[1];
+        cbox[threadIdx.x][2] = d[2];
+        cbox[threadIdx.x][3] = d[3];
+    }
+    __syncthreads();
+    const int ri = rb * 64 + threadIdx.x;
+    if (ri >= n) return;
+    unsigned long long bits = 0ull;
+    if (cb >= rb) {
+        const float *d = dets + (size_t)order[ri] * 5;
+        const float rbox[4] = {d[0], d[1], d[2], d[3]};
+        const int ncol = min(64, n - cb * 64);
+        const int start = (cb == rb) ? threadIdx.x + 1 : 0;
+        for (int j = start; j < ncol; ++j)
+            if (iou_gt(rbox, cbox[j], thr)) bits |= 1ull << j;
+    }
+    mask[(size_t)ri * nb + cb] = bits;
+}
+
+__global__ void nms_sweep_kernel(const unsigned long long *__restrict__ mask, const int64_t *__restrict__ order,
+                                 int n, int nb, int64_t *__restrict__ keep, int64_t *__restrict__ num_keep)
+{
+    extern __shared__ unsigned long long removed[];  // nb words
+    for (int w = threadIdx.x; w < nb; w += blockDim.x) removed[w] = 0ull;
+    __syncthreads();
+    int nk = 0;
+    for (int i = 0; i < n; ++i) {
+        const bool dead = (removed[i >> 6] >> (i & 63)) & 1ull;  // uniform across the block
+        if (!dead) {
+            if (threadIdx.x == 0) keep[nk] = order[i];
+            ++nk;
+            for (int w = (i >> 6) + threadIdx.x; w < nb; w += blockDim.x) removed[w] |= mask[(size_t)i * nb + w];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *num_keep = nk;
+}
+
+// ---------------------------------------------------------------------------------------------
+// MFMA self-test: D = A(MxK) * B(KxN), one wavefront per 32x32 (variant 0) or 16x16 (variant 1)
+// tile, operands read straight from global memory with the fragment maps of common.h.
+// ---------------------------------------------------------------------------------------------
+__global__ void selftest32_kernel(const float *A, const float *B, float *D, int M, int N, int K)
+{
+    const int lane = threadIdx.x, i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+    f32x16 acc;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int k0 = 0; k0 < K; k0 += 2) {
+        const int k = k0 + (lane >> 5), i = i0 + (lane & 31), j = j0 + (lane & 31);
+        const float a = (i < M && k < K) ? A[(size_t)i * K + k] : 0.f;
+        const float b = (j < N && k < K) ? B[(size_t)k * N + j] : 0.f;
+        acc = mfma32(a, b, acc);
+    }
+    for (int r = 0; r < 16; ++r) {
+        const int i = i0 + mfma32_row(r, lane), j = j0 + (lane & 31);
+        if (i < M && j < N) D[(size_t)i * N + j] = acc[r];
+    }
+}
+
+__global__ void selftest16_kernel(const float *A, const float *B, float *D, int M, int N, int K)
+{
+    const int lane = threadIdx.x, i0 = blockIdx.y * 16, j0 = blockIdx.x * 16;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < K; k0 += 4) {
+        const int k = k0 + (lane >> 4), i = i0 + (lane & 15), j = j0 + (lane & 15);
+        const float a = (i < M && k < K) ? A[(size_t)i * K + k] : 0.f;
+        const float b = (j < N && k < K) ? B[(size_t)k * N + j] : 0.f;
+        acc = mfma16(a, b, acc);
+    }
+    for (int r = 0; r < 4; ++r) {
+        const int i = i0 + 4 * (lane >> 4) + r, j = j0 + (lane & 15);
+        if (i < M && j < N) D[(size_t)i * N + j] = acc[r];
+    }
+}
+
+}  // namespace lsn
+
+using namespace lsn;
+
+extern "C" {
+
+int lsn_sigmoid_focal_loss_forward(const float *logits, const int64_t *targets, float *losses, int N, int C,
+                                   float gamma, float alpha, lsn_stream_t stream)
+{
+    LSN_CHECK(N >= 0 && C > 0, "invalid focal loss shape (%d, %d)", N, C);
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(focal_fwd_kernel, dim3(ew_grid((size_t)N * C)), dim3(256), 0, stream, logits, targets,
+                       losses, N, C, gamma, alpha);
+    LSN_HIP(hipGetLastError());
+    return 0;
+}
+
+int lsn_sigmoid_focal_loss_backward(const float *logits, const int64_t *targets, const float *d_losses,
+                                    float *d_logits, int N, int C, float gamma, float alpha, lsn_stream_t stream)
+{
+    LSN_CHECK(N >= 0 && C > 0, "invalid focal loss shape (%d, %d)", N, C);
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(focal_bwd_kernel, dim3(ew_grid((size_t)N * C)), dim3(256), 0, stream, logits, targets,
+                       d_losses, d_logits, N, C, gamma, alpha);
+    LSN_HIP(hipGetLastError());
+    return 0;
+}
+
+int lsn_sigmoid_focal_loss_sum(const float *logits, const int64_t *targets, const float *weight, float *loss_sum,
+                               int N, int C, float gamma, float alpha, lsn_stream_t stream)
+{
+    LSN_CHECK(N >= 0 && C > 0, "invalid focal loss shape (%d, %d)", N, C);
+    LSN_HIP(hipMemsetAsync(loss_sum, 0, sizeof(float), stream));
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(focal_sum_kernel, dim3(ew_grid((size_t)N * C)), dim3(256), 0, stream, logits, targets,
+                       weight, loss_sum, N, C, gamma, alpha);
+    LSN_HIP(hipGetLastError());
+    return 0;
+}
+
+int lsn_sigmoid_focal_loss_backward_weighted(const float *logits, const int64_t *targets, const float *weight,
+                                             const float *scale, float *d_logits, int N, int C, float gamma,
+                                             float alpha, lsn_stream_t stream)
+{
+    LSN_CHECK(N >= 0 && C > 0, "invalid focal loss shape (%d, %d)", N, C);
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(focal_bwd_w_kernel, dim3(ew_grid((size_t)N * C)), dim3(256), 0, stream, logits, targets,
+                       weight, scale, d_logits, N, C, gamma, alpha);
+    LSN_HIP(hipGetLastError());
+    return 0;
+}
+
+int64_t lsn_nms_workspace_bytes(int n)
+{
+    if (n <= 0) return 8;
+    const int64_t nb = (n + 63) / 64;
+    return (int64_t)n * nb * 8;
+}
+
+int lsn_nms(const float *dets, const int64_t *order, int n, float iou_thr, int64_t *keep, int64_t *num_keep,
+            void *workspace, lsn_stream_t stream)
+{
+    LSN_CHECK(n >= 0, "invalid number of boxes %d", n);
+    if (n == 0) {
+        LSN_HIP(hipMemsetAsync(num_keep, 0, sizeof(int64_t), stream));
+        return 0;
+    }
+    const int nb = (n + 63) / 64;
+    if ((size_t)nb * 8 > 64 * 1024) return fail(LSN_ERR_UNSUPPORTED, "nms: %d boxes exceed the sweep kernel's LDS", n);
+    unsigned long long *mask = reinterpret_cast<unsigned long long *>(workspace);
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(nb, nb), dim3(64), 0, stream, dets, order, n, iou_thr, mask);
+    hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(64), (size_t)nb * 8, stream, mask, order, n, nb, keep,
+                       num_keep);
+    LSN_HIP(hipGetLastError());
+    return 0;
+}
+
+int lsn_selftest_mfma(const float *A, const float *B, float *D, int M, int N, int K, int variant,
+                      lsn_stream_t stream)
+{
+    LSN_CHECK(M > 0 && N > 0 && K > 0, "invalid GEMM shape");
+    if (variant == 0)
+        hipLaunchKernelGGL(selftest32_kernel, dim3(cdiv(N, 32), cdiv(M, 32)), dim3(64), 0, stream, A, B, D, M, N, K);
+    else
+        hipLaunchKernelGGL(selftest16_kernel, dim3(cdiv(N, 16), cdiv(M, 16)), dim3(64), 0, stream, A, B, D, M, N, K);
+    LSN_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

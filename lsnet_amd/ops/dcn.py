@@ -1,0 +1,349 @@
+"""Deformable convolution family -- Python mirror of mmdet/ops/dcn/deform_conv.py.
+
+Same public names, argument meaning and error behaviour as the reference
+(`deform_conv`, `modulated_deform_conv`, `pyramid_deform_conv`, `DeformConv`, `DeformConvPack`,
+`ModulatedDeformConv`, `ModulatedDeformConvPack`, `PyramidDeformConv`;
+deform_conv.py:15-111,114-185,188-287,295-630), plus `dcn_multi`: several (input, offset, mask)
+triples that share one weight -- e.g. the five FPN levels of a shared tower -- in ONE launch.
+
+All of them funnel into one autograd Function that calls the C ABI (lsn_dcn_forward /
+lsn_dcn_backward, include/lsnet_hip.h).  Tensors stay logically NCHW; when they are in
+channels-last memory the kernels run without any layout copy.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+from torch.nn.modules.utils import _pair, _single
+
+from ..cnn.registry import CONV_LAYERS
+from .backend import get_backend
+
+
+def _conv_out(size, k, stride, pad, dil):
+    return (size + 2 * pad - (dil * (k - 1) + 1)) // stride + 1
+
+
+def _same_int(v, what):
+    v = _pair(v)
+    if v[0] != v[1]:
+        raise NotImplementedError(f'{what} must be the same for height and width, got {v}')
+    return int(v[0])
+
+
+class _DCNFunction(Function):
+    """forward(weight, bias, cfg, n, x_0..x_{n-1}, off_0..off_{n-1}, mask_0..mask_{n-1})"""
+
+    @staticmethod
+    def forward(ctx, weight, bias, cfg, n, *tensors):
+        inputs, offsets, masks = tensors[:n], tensors[n:2 * n], tensors[2 * n:3 * n]
+        backend = get_backend(inputs[0])
+        out_hw = []
+        for x, off in zip(inputs, offsets):
+            if cfg['pyramid']:
+                hw = (_conv_out(off.shape[2], weight.shape[2], cfg['stride'], cfg['pad'], cfg['dil']),
+                      _conv_out(off.shape[3], weight.shape[3], cfg['stride'], cfg['pad'], cfg['dil']))
+            else:
+                hw = (_conv_out(x.shape[2], weight.shape[2], cfg['stride'], cfg['pad'], cfg['dil']),
+                      _conv_out(x.shape[3], weight.shape[3], cfg['stride'], cfg['pad'], cfg['dil']))
+            if not all(s > 0 for s in hw):
+                raise ValueError('convolution input is too small (output would be '
+                                 f'{x.shape[0]}x{weight.shape[0]}x{hw[0]}x{hw[1]})')
+            if tuple(off.shape[2:]) != hw:
+                raise RuntimeError(f'invalid spatial size of offset, expected height: {hw[0]} width: {hw[1]}, '
+                                   f'but got height: {off.shape[2]} width: {off.shape[3]}')
+            if off.shape[1] != cfg['dg'] * 2 * weight.shape[2] * weight.shape[3]:
+                raise RuntimeError('invalid number of channels of offset')
+            out_hw.append(hw)
+        ctx.cfg, ctx.n, ctx.backend = cfg, n, backend
+        ctx.has_bias = bias is not None
+        ctx.mask_none = [m is None for m in masks]
+        ctx.save_for_backward(weight, *inputs, *offsets, *[m for m in masks if m is not None])
+        outs = backend.dcn_forward(list(inputs), list(offsets), list(masks), weight, bias, cfg, out_hw)
+        return tuple(outs)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *grad_outs):
+        n, cfg = ctx.n, ctx.cfg
+        saved = ctx.saved_tensors
+        weight, inputs, offsets = saved[0], saved[1:1 + n], saved[1 + n:1 + 2 * n]
+        rest = list(saved[1 + 2 * n:])
+        masks = [None if none else rest.pop(0) for none in ctx.mask_none]
+        nig = ctx.needs_input_grad  # (weight, bias, cfg, n, *tensors)
+        need = dict(weight=nig[0], bias=ctx.has_bias and nig[1],
+                    input=[nig[4 + i] for i in range(n)],
+                    offset=[nig[4 + n + i] for i in range(n)],
+                    mask=[nig[4 + 2 * n + i] for i in range(n)])
+        gos = []
+        for i, g in enumerate(grad_outs):
+            if g is None:  # this level's output was not used downstream
+                x, off = inputs[i], offsets[i]
+                g = x.new_zeros((x.shape[0], weight.shape[0], off.shape[2], off.shape[3]))
+            gos.append(g)
+        gxs, goffs, gmsks, gw, gb = ctx.backend.dcn_backward(list(inputs), list(offsets), masks, weight, gos,
+                                                            cfg, need)
+        gxs = [g if need['input'][i] else None for i, g in enumerate(gxs)]
+        goffs = [g if need['offset'][i] else None for i, g in enumerate(goffs)]
+        gmsks = [g if (need['mask'][i] and not ctx.mask_none[i]) else None for i, g in enumerate(gmsks)]
+        if gw is not None and gw.stride() != weight.stride():
+            gw = gw.contiguous(memory_format=torch.channels_last if weight.is_contiguous(
+                memory_format=torch.channels_last) and not weight.is_contiguous() else torch.contiguous_format)
+        return (gw if need['weight'] else None, gb if need['bias'] else None, None, None, *gxs, *goffs, *gmsks)
+
+
+def dcn_multi(inputs, offsets, masks, weight, bias=None, stride=1, padding=0, dilation=1, groups=1,
+              deformable_groups=1, scales=None, pyramid=False):
+    """Batched deformable convolution: out_i = DCN(inputs[i], offsets[i], masks[i]; weight, bias).
+
+    masks may be None (DCNv1 / pyramid) or a list with None entries.  scales: per-level
+    (scale_h, scale_w) for the pyramid op (default 1).  With pyramid=True the output grid is the
+    offset grid (deform_conv.py:215-217)."""
+    n = len(inputs)
+    if masks is None:
+        masks = [None] * n
+    if scales is None:
+        scales = [(1.0, 1.0)] * n
+    for x in inputs:
+        if x is not None and x.dim() != 4:
+            raise ValueError(f'Expected 4D tensor as input, got {x.dim()}D tensor instead.')
+    cfg = dict(stride=_same_int(stride, 'stride'), pad=_same_int(padding, 'padding'),
+               dil=_same_int(dilation, 'dilation'), groups=int(groups), dg=int(deformable_groups),
+               scales=[(float(a), float(b)) for a, b in scales], pyramid=bool(pyramid))
+    return list(_DCNFunction.apply(weight, bias, cfg, n, *inputs, *offsets, *masks))
+
+
+def deform_conv(input, offset, weight, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1,
+                im2col_step=64):
+    """DCNv1, deform_conv.py:15-111 (`DeformConvFunction.apply`)."""
+    if input is not None and input.dim() != 4:
+        raise ValueError(f'Expected 4D tensor as input, got {input.dim()}D tensor instead.')
+    cur = min(im2col_step, input.shape[0])
+    assert (input.shape[0] % cur) == 0, 'im2col step must divide batchsize'
+    return dcn_multi([input], [offset], None, weight, None, stride, padding, dilation, groups,
+                     deformable_groups)[0]
+
+
+def modulated_deform_conv(input, offset, mask, weight, bias=None, stride=1, padding=0, dilation=1, groups=1,
+                          deformable_groups=1):
+    """DCNv2, deform_conv.py:114-185 (`ModulatedDeformConvFunction.apply`)."""
+    return dcn_multi([input], [offset], [mask], weight, bias, stride, padding, dilation, groups,
+                     deformable_groups)[0]
+
+
+def pyramid_deform_conv(input, offset, weight, scales=1, stride=1, padding=0, dilation=1, groups=1,
+                        deformable_groups=1, im2col_step=64):
+    """Pyramid DCN, deform_conv.py:188-287: DCNv1 sampling a map of another resolution; `scales`
+    = (scale_h, scale_w) multiply the regular grid position before the offset is added."""
+    if input is not None and input.dim() != 4:
+        raise ValueError(f'Expected 4D tensor as input, got {input.dim()}D tensor instead.')
+    cur = min(im2col_step, input.shape[0])
+    assert (input.shape[0] % cur) == 0, 'im2col step must divide batchsize'
+    return dcn_multi([input], [offset], None, weight, None, stride, padding, dilation, groups,
+                     deformable_groups, scales=[_pair(scales)], pyramid=True)[0]
+
+
+class DeformConv(nn.Module):
+    """deform_conv.py:295-357"""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                 deformable_groups=1, bias=False):
+        super().__init__()
+        assert not bias
+        assert in_channels % groups == 0, f'in_channels {in_channels} is not divisible by groups {groups}'
+        assert out_channels % groups == 0, f'out_channels {out_channels} is not divisible by groups {groups}'
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size = _pair(kernel_size)
+        self.stride, self.padding, self.dilation = _pair(stride), _pair(padding), _pair(dilation)
+        self.groups, self.deformable_groups = groups, deformable_groups
+        self.transposed = False  # nn.Conv2d compatibility
+        self.output_padding = _single(0)
+        self.weight = nn.Parameter(torch.Tensor(out_channels, in_channels // groups, *self.kernel_size))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        n = self.in_channels * self.kernel_size[0] * self.kernel_size[1]
+        stdv = 1. / math.sqrt(n)
+        self.weight.data.uniform_(-stdv, stdv)
+
+    def forward(self, x, offset):
+        # pad inputs smaller than the kernel (deform_conv.py:339-356)
+        pad_h = max(self.kernel_size[0] - x.size(2), 0)
+        pad_w = max(self.kernel_size[1] - x.size(3), 0)
+        if pad_h or pad_w:
+            x = F.pad(x, (0, pad_w, 0, pad_h), 'constant', 0).contiguous()
+            offset = F.pad(offset, (0, pad_w, 0, pad_h), 'constant', 0).contiguous()
+        out = deform_conv(x, offset, self.weight, self.stride, self.padding, self.dilation, self.groups,
+                          self.deformable_groups)
+        if pad_h or pad_w:
+            out = out[:, :, :out.size(2) - pad_h, :out.size(3) - pad_w].contiguous()
+        return out
+
+
+@CONV_LAYERS.register_module(name='DCN')
+class DeformConvPack(DeformConv):
+    """DCNv1 with its own offset conv, deform_conv.py:360-435."""
+    _version = 2
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.conv_offset = nn.Conv2d(self.in_channels,
+                                     self.deformable_groups * 2 * self.kernel_size[0] * self.kernel_size[1],
+                                     kernel_size=self.kernel_size, stride=_pair(self.stride),
+                                     padding=_pair(self.padding), dilation=_pair(self.dilation), bias=True)
+        self.init_offset()
+
+    def init_offset(self):
+        self.conv_offset.weight.data.zero_()
+        self.conv_offset.bias.data.zero_()
+
+    def forward(self, x):
+        offset = self.conv_offset(x)
+        return deform_conv(x, offset, self.weight, self.stride, self.padding, self.dilation, self.groups,
+                           self.deformable_groups)
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                              error_msgs):
+        _remap_old_offset_keys(state_dict, prefix, local_metadata)
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys,
+                                      unexpected_keys, error_msgs)
+
+
+def _remap_old_offset_keys(state_dict, prefix, local_metadata):
+    """Checkpoints written before version 2 name the offset conv `<name>_offset`
+    (deform_conv.py:410-425, 536-552)."""
+    version = local_metadata.get('version', None)
+    if version is None or version < 2:
+        for suffix in ('weight', 'bias'):
+            new, old = prefix + 'conv_offset.' + suffix, prefix[:-1] + '_offset.' + suffix
+            if new not in state_dict and old in state_dict:
+                state_dict[new] = state_dict.pop(old)
+
+
+class ModulatedDeformConv(nn.Module):
+    """deform_conv.py:438-484"""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                 deformable_groups=1, bias=True):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size = _pair(kernel_size)
+        self.stride, self.padding, self.dilation = stride, padding, dilation
+        self.groups, self.deformable_groups = groups, deformable_groups
+        self.with_bias = bias
+        self.transposed = False
+        self.output_padding = _single(0)
+        self.weight = nn.Parameter(torch.Tensor(out_channels, in_channels // groups, *self.kernel_size))
+        if bias:
+            self.bias = nn.Parameter(torch.Tensor(out_channels))
+        else:
+            self.register_parameter('bias', None)
+        self.init_weights()
+
+    def init_weights(self):
+        n = self.in_channels * self.kernel_size[0] * self.kernel_size[1]
+        stdv = 1. / math.sqrt(n)
+        self.weight.data.uniform_(-stdv, stdv)
+        if self.bias is not None:
+            self.bias.data.zero_()
+
+    def forward(self, x, offset, mask):
+        return modulated_deform_conv(x, offset, mask, self.weight, self.bias, self.stride, self.padding,
+                                     self.dilation, self.groups, self.deformable_groups)
+
+
+@CONV_LAYERS.register_module(name='DCNv2')
+class ModulatedDeformConvPack(ModulatedDeformConv):
+    """DCNv2 with its own offset/mask conv (zero-initialised), deform_conv.py:488-562.
+
+    `forward_multi` runs the same layer over several feature maps (the FPN levels of a shared
+    tower) with one kernel launch for the deformable part."""
+    _version = 2
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.conv_offset = nn.Conv2d(self.in_channels,
+                                     self.deformable_groups * 3 * self.kernel_size[0] * self.kernel_size[1],
+                                     kernel_size=self.kernel_size, stride=_pair(self.stride),
+                                     padding=_pair(self.padding), dilation=_pair(self.dilation), bias=True)
+        self.init_weights()
+
+    def init_weights(self):
+        super().init_weights()
+        if hasattr(self, 'conv_offset'):
+            self.conv_offset.weight.data.zero_()
+            self.conv_offset.bias.data.zero_()
+
+    def _offset_mask(self, x):
+        out = self.conv_offset(x)
+        k2 = 2 * self.deformable_groups * self.kernel_size[0] * self.kernel_size[1]
+        # chunk(3) + cat(o1, o2) of the reference == the first 2/3 of the channels
+        return out[:, :k2], torch.sigmoid(out[:, k2:])
+
+    def forward(self, x):
+        offset, mask = self._offset_mask(x)
+        return modulated_deform_conv(x, offset, mask, self.weight, self.bias, self.stride, self.padding,
+                                     self.dilation, self.groups, self.deformable_groups)
+
+    def forward_multi(self, xs):
+        oms = [self._offset_mask(x) for x in xs]
+        return dcn_multi(list(xs), [o for o, _ in oms], [m for _, m in oms], self.weight, self.bias,
+                         self.stride, self.padding, self.dilation, self.groups, self.deformable_groups)
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                              error_msgs):
+        _remap_old_offset_keys(state_dict, prefix, local_metadata)
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys,
+                                      unexpected_keys, error_msgs)
+
+
+class PyramidDeformConv(nn.Module):
+    """DCNv1 whose output grid is the offset grid and whose source map has another resolution
+    (deform_conv.py:565-630).  `forward_multi` evaluates many (source, offset, scale) triples
+    with one launch."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                 deformable_groups=1, bias=False):
+        super().__init__()
+        assert not bias
+        assert in_channels % groups == 0, f'in_channels {in_channels} is not divisible by groups {groups}'
+        assert out_channels % groups == 0, f'out_channels {out_channels} is not divisible by groups {groups}'
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size = _pair(kernel_size)
+        self.stride, self.padding, self.dilation = _pair(stride), _pair(padding), _pair(dilation)
+        self.groups, self.deformable_groups = groups, deformable_groups
+        self.transposed = False
+        self.output_padding = _single(0)
+        self.weight = nn.Parameter(torch.Tensor(out_channels, in_channels // groups, *self.kernel_size))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        n = self.in_channels * self.kernel_size[0] * self.kernel_size[1]
+        stdv = 1. / math.sqrt(n)
+        self.weight.data.uniform_(-stdv, stdv)
+
+    def _pad_small(self, x, offset):
+        pad_h = max(self.kernel_size[0] - x.size(2), 0)
+        pad_w = max(self.kernel_size[1] - x.size(3), 0)
+        if pad_h or pad_w:  # deform_conv.py:614-621
+            x = F.pad(x, (0, pad_w, 0, pad_h), 'constant', 0).contiguous()
+            offset = F.pad(offset, (0, pad_w, 0, pad_h), 'constant', 0).contiguous()
+        return x, offset, pad_h, pad_w
+
+    def forward(self, x, offset, scale_h, scale_w):
+        return self.forward_multi([x], [offset], [(scale_h, scale_w)])[0]
+
+    def forward_multi(self, xs, offsets, scales):
+        prepped = [self._pad_small(x, o) for x, o in zip(xs, offsets)]
+        outs = dcn_multi([p[0] for p in prepped], [p[1] for p in prepped], None, self.weight, None, self.stride,
+                         self.padding, self.dilation, self.groups, self.deformable_groups,
+                         scales=[_pair(s) for s in scales], pyramid=True)
+        res = []
+        for out, (_, _, pad_h, pad_w) in zip(outs, prepped):
+            if pad_h or pad_w:
+                out = out[:, :, :out.size(2) - pad_h, :out.size(3) - pad_w].contiguous()
+            res.append(out)
+        return res

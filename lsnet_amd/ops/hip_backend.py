@@ -1,0 +1,203 @@
+"""The 'cuda' (HIP) backend: marshals torch tensors into the C ABI of liblsnet_hip.so."""
+import ctypes
+
+import torch
+
+from .. import _lib
+from .backend import register_backend
+
+_CL = torch.channels_last
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _f32(t, what):
+    if t.dtype != torch.float32:
+        raise TypeError(f'{what} must be float32, got {t.dtype}')
+    return t
+
+
+def _is_nhwc(t):
+    return t.dim() == 4 and t.is_contiguous(memory_format=_CL)
+
+
+def _dense(t, nhwc):
+    """offset / mask tensors travel by strides; they only need to be non-overlapping and dense so
+    that `empty_like` gives a gradient buffer with identical strides."""
+    if t.is_contiguous() or t.is_contiguous(memory_format=_CL):
+        return t
+    return t.contiguous(memory_format=_CL) if nhwc else t.contiguous()
+
+
+def _strides(t):
+    s = t.stride()
+    return _lib.Strides4(s[0], s[1], s[2], s[3])
+
+
+class HipBackend:
+    name = 'hip'
+
+    # ------------------------------------------------------------------ deformable conv family
+    @staticmethod
+    def _prep(inputs, offsets, masks, weight):
+        nhwc = all(_is_nhwc(x) for x in inputs)
+        if nhwc:
+            xs = list(inputs)
+            w = weight.contiguous(memory_format=_CL)
+        else:
+            xs = [x.contiguous() for x in inputs]
+            w = weight.contiguous()
+        offs = [_dense(_f32(o, 'offset'), nhwc) for o in offsets]
+        msks = [None if m is None else _dense(_f32(m, 'mask'), nhwc) for m in masks]
+        for x in xs:
+            _f32(x, 'input')
+        _f32(w, 'weight')
+        return nhwc, xs, offs, msks, w
+
+    @staticmethod
+    def _shape(w, cfg):
+        Co, Cg, kh, kw = w.shape
+        return _lib.DcnShape(0, Cg * cfg['groups'], 0, 0, Co, 0, 0, kh, kw, cfg['stride'], cfg['pad'],
+                             cfg['dil'], cfg['groups'], cfg['dg'], 1.0, 1.0)
+
+    def dcn_forward(self, inputs, offsets, masks, weight, bias, cfg, out_hw):
+        """inputs/offsets/masks: per-level lists (mask entries may be None); cfg: stride, pad, dil,
+        groups, dg, scales[(sh, sw)]; out_hw: per-level (Ho, Wo).  Returns the per-level outputs."""
+        lib = _lib.load()
+        nhwc, xs, offs, msks, w = self._prep(inputs, offsets, masks, weight)
+        n = len(xs)
+        shape = self._shape(w, cfg)
+        levels = (_lib.DcnLevel * n)()
+        outs = []
+        for i in range(n):
+            B, C, H, W = xs[i].shape
+            Ho, Wo = out_hw[i]
+            out = torch.empty((B, w.shape[0], Ho, Wo), device=xs[i].device, dtype=torch.float32,
+                              memory_format=_CL if nhwc else torch.contiguous_format)
+            outs.append(out)
+            L = levels[i]
+            L.input, L.offset, L.mask, L.output = _ptr(xs[i]), _ptr(offs[i]), _ptr(msks[i]), _ptr(out)
+            L.off_st = _strides(offs[i])
+            if msks[i] is not None:
+                L.mask_st = _strides(msks[i])
+            L.B, L.H, L.W, L.Ho, L.Wo = B, H, W, Ho, Wo
+            L.scale_h, L.scale_w = cfg['scales'][i]
+        b = None if bias is None else _f32(bias.contiguous(), 'bias')
+        _lib.check(lib.lsn_dcn_forward(ctypes.byref(shape), n, levels, _ptr(w), _ptr(b), 1 if nhwc else 0,
+                                       _stream()))
+        return outs
+
+    def dcn_backward(self, inputs, offsets, masks, weight, grad_outs, cfg, need):
+        """need: dict(input=[bool]*n, offset=[bool]*n, mask=[bool]*n, weight=bool, bias=bool).
+        Returns (grad_inputs, grad_offsets, grad_masks, grad_weight, grad_bias)."""
+        lib = _lib.load()
+        nhwc, xs, offs, msks, w = self._prep(inputs, offsets, masks, weight)
+        n = len(xs)
+        shape = self._shape(w, cfg)
+        levels = (_lib.DcnLevel * n)()
+        gxs, goffs, gmsks, keep = [], [], [], []
+        for i in range(n):
+            B, C, H, W = xs[i].shape
+            go = grad_outs[i]
+            go = go.contiguous(memory_format=_CL) if nhwc else go.contiguous()
+            keep.append(go)
+            Ho, Wo = go.shape[2], go.shape[3]
+            gx = torch.empty_like(xs[i]) if need['input'][i] else None
+            want_om = need['offset'][i] or (msks[i] is not None and need['mask'][i])
+            goff = torch.empty_like(offs[i]) if want_om else None
+            gmsk = torch.empty_like(msks[i]) if (want_om and msks[i] is not None) else None
+            gxs.append(gx); goffs.append(goff); gmsks.append(gmsk)
+            L = levels[i]
+            L.input, L.offset, L.mask = _ptr(xs[i]), _ptr(offs[i]), _ptr(msks[i])
+            L.grad_output, L.grad_input, L.grad_offset, L.grad_mask = _ptr(go), _ptr(gx), _ptr(goff), _ptr(gmsk)
+            L.off_st = _strides(offs[i])
+            if msks[i] is not None:
+                L.mask_st = _strides(msks[i])
+            L.B, L.H, L.W, L.Ho, L.Wo = B, H, W, Ho, Wo
+            L.scale_h, L.scale_w = cfg['scales'][i]
+        gw = torch.empty_like(w) if (need['weight'] or need['bias']) else None
+        gb = torch.empty(w.shape[0], device=w.device, dtype=torch.float32) if need['bias'] else None
+        _lib.check(lib.lsn_dcn_backward(ctypes.byref(shape), n, levels, _ptr(w), _ptr(gw), _ptr(gb),
+                                        1 if nhwc else 0, _stream()))
+        return gxs, goffs, gmsks, gw, gb
+
+    # ------------------------------------------------------------------ sigmoid focal loss
+    def focal_forward(self, logits, targets, gamma, alpha):
+        lib = _lib.load()
+        logits = _f32(logits, 'logits').contiguous()
+        targets = targets.contiguous()
+        if targets.dtype != torch.int64:
+            raise TypeError('targets must be int64')
+        out = torch.empty_like(logits)
+        N, C = logits.shape
+        _lib.check(lib.lsn_sigmoid_focal_loss_forward(_ptr(logits), _ptr(targets), _ptr(out), N, C,
+                                                      ctypes.c_float(gamma), ctypes.c_float(alpha), _stream()))
+        return out
+
+    def focal_backward(self, logits, targets, d_losses, gamma, alpha):
+        lib = _lib.load()
+        logits = logits.contiguous()
+        d_losses = d_losses.contiguous()
+        out = torch.empty_like(logits)
+        N, C = logits.shape
+        _lib.check(lib.lsn_sigmoid_focal_loss_backward(_ptr(logits), _ptr(targets.contiguous()), _ptr(d_losses),
+                                                       _ptr(out), N, C, ctypes.c_float(gamma),
+                                                       ctypes.c_float(alpha), _stream()))
+        return out
+
+    def focal_sum(self, logits, targets, weight, gamma, alpha):
+        lib = _lib.load()
+        logits = _f32(logits, 'logits').contiguous()
+        out = torch.empty((), device=logits.device, dtype=torch.float32)
+        N, C = logits.shape
+        w = None if weight is None else _f32(weight, 'weight').contiguous()
+        _lib.check(lib.lsn_sigmoid_focal_loss_sum(_ptr(logits), _ptr(targets.contiguous()), _ptr(w), _ptr(out), N,
+                                                  C, ctypes.c_float(gamma), ctypes.c_float(alpha), _stream()))
+        return out
+
+    def focal_backward_weighted(self, logits, targets, weight, scale, gamma, alpha):
+        lib = _lib.load()
+        logits = logits.contiguous()
+        out = torch.empty_like(logits)
+        N, C = logits.shape
+        w = None if weight is None else weight.contiguous()
+        scale = scale.to(torch.float32).contiguous()
+        _lib.check(lib.lsn_sigmoid_focal_loss_backward_weighted(
+            _ptr(logits), _ptr(targets.contiguous()), _ptr(w), _ptr(scale), _ptr(out), N, C,
+            ctypes.c_float(gamma), ctypes.c_float(alpha), _stream()))
+        return out
+
+    # ------------------------------------------------------------------ NMS
+    def nms(self, dets, iou_thr):
+        """dets (n,5) float32 on the device -> keep indices (int64), descending score."""
+        lib = _lib.load()
+        dets = _f32(dets, 'dets').contiguous()
+        n = dets.shape[0]
+        if n == 0:
+            return dets.new_zeros(0, dtype=torch.long)
+        order = dets[:, 4].sort(0, descending=True)[1].contiguous()  # nms_kernel.cu:81-83
+        keep = torch.empty(n, dtype=torch.int64, device=dets.device)
+        num = torch.zeros(1, dtype=torch.int64, device=dets.device)
+        ws = torch.empty(int(lib.lsn_nms_workspace_bytes(n)), dtype=torch.uint8, device=dets.device)
+        _lib.check(lib.lsn_nms(_ptr(dets), _ptr(order), n, ctypes.c_float(iou_thr), _ptr(keep), _ptr(num),
+                               _ptr(ws), _stream()))
+        return keep[:int(num.item())]
+
+    def selftest_mfma(self, A, B, variant):
+        lib = _lib.load()
+        A, B = A.contiguous(), B.contiguous()
+        M, K = A.shape
+        N = B.shape[1]
+        D = torch.empty(M, N, device=A.device, dtype=torch.float32)
+        _lib.check(lib.lsn_selftest_mfma(_ptr(A), _ptr(B), _ptr(D), M, N, K, variant, _stream()))
+        return D
+
+
+_lib.load()  # fail loudly at registration time when the library is missing
+register_backend('cuda', HipBackend())
