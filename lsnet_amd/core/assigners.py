@@ -1,0 +1,214 @@
+"""Point / box -> ground-truth assignment for the two LSNet stages, and the pseudo sampler.
+
+  init stage   : CentroidAssigner(scale=4, pos_num=1)  mmdet/core/bbox/assigners/centroid_assigner.py:26-93
+  refine stage : ATSSAssigner(topk=9)                   mmdet/core/bbox/assigners/atss_assigner.py:29-164
+  sampler      : PseudoSampler                          mmdet/core/bbox/samplers/pseudo_sampler.py:22-41
+
+Same arithmetic and tie behaviour as the reference (bit-exact gt indices are part of the parity
+contract), written with `where`/`scatter` instead of masked assignment so that nothing depends on
+host-side shapes."""
+import torch
+
+from ..utils.registry import Registry, build_from_cfg
+
+BBOX_ASSIGNERS = Registry('bbox_assigner')
+BBOX_SAMPLERS = Registry('bbox_sampler')
+IOU_CALCULATORS = Registry('IoU calculator')
+
+
+def build_assigner(cfg, **default_args):
+    return build_from_cfg(cfg, BBOX_ASSIGNERS, default_args)
+
+
+def build_sampler(cfg, **default_args):
+    return build_from_cfg(cfg, BBOX_SAMPLERS, default_args)
+
+
+def build_iou_calculator(cfg, default_args=None):
+    return build_from_cfg(cfg, IOU_CALCULATORS, default_args)
+
+
+def bbox_overlaps(bboxes1, bboxes2, mode='iou', is_aligned=False, eps=1e-6):
+    """IoU / IoF of xyxy boxes without the +1 convention (iou2d_calculator.py:36-130)."""
+    assert mode in ('iou', 'iof')
+    rows, cols = bboxes1.size(0), bboxes2.size(0)
+    if is_aligned:
+        assert rows == cols
+    if rows * cols == 0:
+        return bboxes1.new_zeros((rows, 1) if is_aligned else (rows, cols))
+    b1 = bboxes1 if is_aligned else bboxes1[:, None, :]
+    lt = torch.max(b1[..., :2], bboxes2[..., :2])
+    rb = torch.min(b1[..., 2:], bboxes2[..., 2:])
+    wh = (rb - lt).clamp(min=0)
+    overlap = wh[..., 0] * wh[..., 1]
+    area1 = (bboxes1[:, 2] - bboxes1[:, 0]) * (bboxes1[:, 3] - bboxes1[:, 1])
+    if not is_aligned:
+        area1 = area1[:, None]
+    if mode == 'iou':
+        area2 = (bboxes2[:, 2] - bboxes2[:, 0]) * (bboxes2[:, 3] - bboxes2[:, 1])
+        union = area1 + area2 - overlap
+    else:
+        union = area1
+    return overlap / torch.max(union, union.new_tensor([eps]))
+
+
+@IOU_CALCULATORS.register_module()
+class BboxOverlaps2D:
+
+    def __call__(self, bboxes1, bboxes2, mode='iou', is_aligned=False):
+        assert bboxes1.size(-1) in (0, 4, 5) and bboxes2.size(-1) in (0, 4, 5)
+        return bbox_overlaps(bboxes1[..., :4], bboxes2[..., :4], mode, is_aligned)
+
+    def __repr__(self):
+        return self.__class__.__name__ + '()'
+
+
+class AssignResult:
+    """gt_inds: 0 = background, k > 0 = (1-based) index of the assigned gt."""
+
+    def __init__(self, num_gts, gt_inds, max_overlaps, labels=None):
+        self.num_gts, self.gt_inds, self.max_overlaps, self.labels = num_gts, gt_inds, max_overlaps, labels
+
+    @property
+    def num_preds(self):
+        return len(self.gt_inds)
+
+
+def _labels_of(gt_inds, gt_labels):
+    if gt_labels is None:
+        return None
+    pos = gt_inds > 0
+    return torch.where(pos, gt_labels[(gt_inds - 1).clamp(min=0)], gt_inds.new_full((), -1))
+
+
+def _empty_assignment(ref, num_gts, num_preds, gt_labels, with_overlaps):
+    gt_inds = ref.new_zeros((num_preds,), dtype=torch.long)
+    labels = None if gt_labels is None else ref.new_full((num_preds,), -1, dtype=torch.long)
+    return AssignResult(num_gts, gt_inds, ref.new_zeros((num_preds,)) if with_overlaps else None, labels)
+
+
+@BBOX_ASSIGNERS.register_module()
+class CentroidAssigner:
+    """Each gt picks, on the FPN level matching its size, its `pos_num` nearest points (distance
+    normalised by the gt's width/height); a point claimed by several gts keeps the nearest."""
+
+    def __init__(self, scale=4, pos_num=3, iou_type='center'):
+        self.scale, self.pos_num, self.iou_type = scale, pos_num, iou_type
+
+    def assign(self, points, gt_bboxes, gt_extreme_pts, gt_bboxes_ignore=None, gt_labels=None):
+        INF = 1e8
+        num_gts, num_points = gt_bboxes.shape[0], points.shape[0]
+        if num_gts == 0 or num_points == 0:
+            return _empty_assignment(points, num_gts, num_points, gt_labels, False)
+        xy = points[:, :2]
+        lvl = torch.log2(points[:, 2]).int()
+        lvl_min, lvl_max = lvl.min(), lvl.max()
+        if self.iou_type == 'centroid':
+            centers = self.gen_centroid(gt_extreme_pts, num_gts)
+        else:
+            centers = (gt_bboxes[:, :2] + gt_bboxes[:, 2:]) / 2
+        wh = (gt_bboxes[:, 2:] - gt_bboxes[:, :2]).clamp(min=1e-6)
+        gt_lvl = ((torch.log2(wh[:, 0] / self.scale) + torch.log2(wh[:, 1] / self.scale)) / 2).int()
+        gt_lvl = torch.clamp(gt_lvl, min=lvl_min, max=lvl_max)
+        dist = ((xy[:, None, :] - centers[None, :, :]) / wh[None, :, :]).norm(dim=2)
+        dist = torch.where(lvl[:, None] != gt_lvl[None, :], dist.new_full((), INF), dist)
+        near_d, near_i = torch.topk(dist, self.pos_num, dim=0, largest=False)
+        claimed = torch.full_like(dist, INF).scatter_(0, near_i, near_d)
+        best_d, best_gt = claimed.min(dim=1)
+        gt_inds = torch.where(best_d != INF, best_gt + 1, torch.zeros_like(best_gt))
+        return AssignResult(num_gts, gt_inds, None, labels=_labels_of(gt_inds, gt_labels))
+
+    @staticmethod
+    def gen_centroid(pts, num_gts):
+        """Intersection of the two lines joining opposite triangle centroids of the extreme-point
+        quadrilateral (centroid_assigner.py:95-139)."""
+        ext = pts[:, :-2].reshape(pts.shape[0], -1, 2)      # (G, 4, 2)
+        ring = torch.cat([ext, ext], dim=1)                  # indices i..i+2 wrap around
+        cen = torch.stack([ring[:, i:i + 3].sum(1) / 3.0 for i in range(4)], dim=1)  # (G, 4, 2)
+        (x1, y1), (x2, y2) = (cen[:, 0, 0], cen[:, 0, 1]), (cen[:, 2, 0], cen[:, 2, 1])
+        (x3, y3), (x4, y4) = (cen[:, 1, 0], cen[:, 1, 1]), (cen[:, 3, 0], cen[:, 3, 1])
+        d1, d2 = x1 * y2 - y1 * x2, x3 * y4 - y3 * x4
+        den = (x1 - x2) * (y3 - y4) - (y1 - y2) * (x3 - x4)
+        cx = (d1 * (x3 - x4) - d2 * (x1 - x2)) / den
+        cy = (d1 * (y3 - y4) - d2 * (y1 - y2)) / den
+        return torch.stack([cx, cy], dim=-1)
+
+
+@BBOX_ASSIGNERS.register_module()
+class ATSSAssigner:
+    """Adaptive training sample selection: per level the `topk` boxes whose centres are nearest to
+    the gt centre are candidates; IoU threshold = mean + std over a gt's candidates; positives
+    must have their centre inside the gt; ties between gts go to the highest IoU."""
+
+    def __init__(self, topk, iou_calculator=dict(type='BboxOverlaps2D')):
+        self.topk = topk
+        self.iou_calculator = build_iou_calculator(iou_calculator)
+
+    def assign(self, bboxes, num_level_bboxes, gt_bboxes, gt_bboxes_ignore=None, gt_labels=None):
+        INF = 100000000
+        bboxes = bboxes[:, :4]
+        num_gt, num_bboxes = gt_bboxes.size(0), bboxes.size(0)
+        if num_gt == 0 or num_bboxes == 0:
+            return _empty_assignment(bboxes, num_gt, num_bboxes, gt_labels, True)
+        overlaps = self.iou_calculator(bboxes, gt_bboxes)                      # (N, G)
+        gt_c = torch.stack(((gt_bboxes[:, 0] + gt_bboxes[:, 2]) / 2.0, (gt_bboxes[:, 1] + gt_bboxes[:, 3]) / 2.0), 1)
+        cx, cy = (bboxes[:, 0] + bboxes[:, 2]) / 2.0, (bboxes[:, 1] + bboxes[:, 3]) / 2.0
+        box_c = torch.stack((cx, cy), dim=1)
+        dist = (box_c[:, None, :] - gt_c[None, :, :]).pow(2).sum(-1).sqrt()
+
+        cand, start = [], 0
+        for n in num_level_bboxes:  # k nearest per level and gt
+            _, idx = dist[start:start + n, :].topk(self.topk, dim=0, largest=False)
+            cand.append(idx + start)
+            start += n
+        cand = torch.cat(cand, dim=0)                                           # (L*k, G)
+        gcol = torch.arange(num_gt, device=bboxes.device)
+        cand_iou = overlaps[cand, gcol]
+        thr = cand_iou.mean(0) + cand_iou.std(0)
+        is_pos = cand_iou >= thr[None, :]
+        ccx, ccy = cx[cand], cy[cand]
+        inside = torch.stack([ccx - gt_bboxes[:, 0], ccy - gt_bboxes[:, 1], gt_bboxes[:, 2] - ccx,
+                              gt_bboxes[:, 3] - ccy], dim=1).min(dim=1)[0] > 0.01
+        is_pos = is_pos & inside
+
+        # (G*N) flat table of the positives' IoU, -INF elsewhere; column-major per gt as in the reference
+        # (candidate rows of different levels / gts never collide, so a plain index_put is exact and
+        # no data-dependent shape -- hence no host sync -- is involved)
+        flat = (cand + gcol[None, :] * num_bboxes).view(-1)
+        chosen = torch.zeros(num_gt * num_bboxes, dtype=torch.bool, device=bboxes.device)
+        chosen[flat] = is_pos.view(-1)
+        iou_t = overlaps.t().contiguous().view(-1)
+        table = torch.where(chosen, iou_t, iou_t.new_full((), -INF))
+        max_overlaps, argmax = table.view(num_gt, -1).t().max(dim=1)
+        gt_inds = torch.where(max_overlaps != -INF, argmax + 1, torch.zeros_like(argmax))
+        return AssignResult(num_gt, gt_inds, max_overlaps, labels=_labels_of(gt_inds, gt_labels))
+
+
+class SamplingResult:
+
+    def __init__(self, pos_inds, neg_inds, bboxes, gt_bboxes, assign_result, gt_flags):
+        self.pos_inds, self.neg_inds = pos_inds, neg_inds
+        self.pos_bboxes, self.neg_bboxes = bboxes[pos_inds], bboxes[neg_inds]
+        self.pos_is_gt = gt_flags[pos_inds]
+        self.num_gts = gt_bboxes.shape[0]
+        self.pos_assigned_gt_inds = assign_result.gt_inds[pos_inds] - 1
+        if gt_bboxes.numel() == 0:
+            assert self.pos_assigned_gt_inds.numel() == 0
+            self.pos_gt_bboxes = torch.empty_like(gt_bboxes).view(-1, 4)
+        else:
+            self.pos_gt_bboxes = gt_bboxes.view(-1, 4)[self.pos_assigned_gt_inds, :]
+        self.pos_gt_labels = None if assign_result.labels is None else assign_result.labels[pos_inds]
+
+
+@BBOX_SAMPLERS.register_module()
+class PseudoSampler:
+    """No sampling: every assigned point is a positive, every unassigned one a negative."""
+
+    def __init__(self, **kwargs):
+        pass
+
+    def sample(self, assign_result, bboxes, gt_bboxes, **kwargs):
+        pos = torch.nonzero(assign_result.gt_inds > 0, as_tuple=False).squeeze(-1).unique()
+        neg = torch.nonzero(assign_result.gt_inds == 0, as_tuple=False).squeeze(-1).unique()
+        flags = bboxes.new_zeros(bboxes.shape[0], dtype=torch.uint8)
+        return SamplingResult(pos, neg, bboxes, gt_bboxes, assign_result, flags)

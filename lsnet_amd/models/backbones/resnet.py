@@ -1,0 +1,257 @@
+"""ResNet / ResNeXt backbones with optional DCN in conv2 (mmdet/models/backbones/resnet.py:261-301,
+303-661; resnext.py:11-131; utils/res_layer.py:24-102).
+
+Module and parameter names are the reference's (`conv1`, `bn1`, `layerN.M.conv2.conv_offset`,
+`downsample.0/1`) so torchvision / reference checkpoints load unchanged.  One Bottleneck class
+serves both families: ResNeXt is the grouped-width case."""
+import math
+
+import torch.nn as nn
+import torch.utils.checkpoint as cp
+from torch.nn.modules.batchnorm import _BatchNorm
+
+from ...cnn import build_conv_layer, build_norm_layer, constant_init, kaiming_init
+from ..builder import BACKBONES
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None, style='pytorch', with_cp=False,
+                 conv_cfg=None, norm_cfg=dict(type='BN'), dcn=None, plugins=None, **_):
+        super().__init__()
+        assert dcn is None and plugins is None, 'Not implemented yet.'
+        self.norm1_name, norm1 = build_norm_layer(norm_cfg, planes, postfix=1)
+        self.norm2_name, norm2 = build_norm_layer(norm_cfg, planes, postfix=2)
+        self.conv1 = build_conv_layer(conv_cfg, inplanes, planes, 3, stride=stride, padding=dilation,
+                                      dilation=dilation, bias=False)
+        self.add_module(self.norm1_name, norm1)
+        self.conv2 = build_conv_layer(conv_cfg, planes, planes, 3, padding=1, bias=False)
+        self.add_module(self.norm2_name, norm2)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample, self.stride, self.dilation, self.with_cp = downsample, stride, dilation, with_cp
+
+    norm1 = property(lambda self: getattr(self, self.norm1_name))
+    norm2 = property(lambda self: getattr(self, self.norm2_name))
+
+    def _body(self, x):
+        out = self.relu(self.norm1(self.conv1(x)))
+        out = self.norm2(self.conv2(out))
+        return out + (x if self.downsample is None else self.downsample(x))
+
+    def forward(self, x):
+        out = cp.checkpoint(self._body, x) if (self.with_cp and x.requires_grad) else self._body(x)
+        return self.relu(out)
+
+
+class Bottleneck(nn.Module):
+    """1x1 -> 3x3 (stride here for style='pytorch'; DCN here when `dcn` is given) -> 1x1, + identity.
+    groups > 1 gives the ResNeXt block with width floor(planes * base_width / base_channels) * groups."""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None, style='pytorch', with_cp=False,
+                 conv_cfg=None, norm_cfg=dict(type='BN'), dcn=None, plugins=None, groups=1, base_width=4,
+                 base_channels=64):
+        super().__init__()
+        assert style in ('pytorch', 'caffe')
+        assert dcn is None or isinstance(dcn, dict)
+        if plugins:
+            raise NotImplementedError('backbone plugins are outside the LSNet hot path')
+        self.inplanes, self.planes, self.stride, self.dilation = inplanes, planes, stride, dilation
+        self.style, self.with_cp, self.conv_cfg, self.norm_cfg = style, with_cp, conv_cfg, norm_cfg
+        self.dcn, self.with_dcn = dcn, dcn is not None
+        self.conv1_stride, self.conv2_stride = (1, stride) if style == 'pytorch' else (stride, 1)
+        width = planes if groups == 1 else math.floor(planes * (base_width / base_channels)) * groups
+
+        self.norm1_name, norm1 = build_norm_layer(norm_cfg, width, postfix=1)
+        self.norm2_name, norm2 = build_norm_layer(norm_cfg, width, postfix=2)
+        self.norm3_name, norm3 = build_norm_layer(norm_cfg, planes * self.expansion, postfix=3)
+        self.conv1 = build_conv_layer(conv_cfg, inplanes, width, kernel_size=1, stride=self.conv1_stride,
+                                      bias=False)
+        self.add_module(self.norm1_name, norm1)
+        conv2_cfg = conv_cfg
+        if self.with_dcn:
+            dcn = dict(dcn)
+            if not dcn.pop('fallback_on_stride', False):
+                assert conv_cfg is None, 'conv_cfg must be None for DCN'
+                conv2_cfg = dcn
+        self.conv2 = build_conv_layer(conv2_cfg, width, width, kernel_size=3, stride=self.conv2_stride,
+                                      padding=dilation, dilation=dilation, groups=groups, bias=False)
+        self.add_module(self.norm2_name, norm2)
+        self.conv3 = build_conv_layer(conv_cfg, width, planes * self.expansion, kernel_size=1, bias=False)
+        self.add_module(self.norm3_name, norm3)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    norm1 = property(lambda self: getattr(self, self.norm1_name))
+    norm2 = property(lambda self: getattr(self, self.norm2_name))
+    norm3 = property(lambda self: getattr(self, self.norm3_name))
+
+    def _body(self, x):
+        out = self.relu(self.norm1(self.conv1(x)))
+        out = self.relu(self.norm2(self.conv2(out)))
+        out = self.norm3(self.conv3(out))
+        return out + (x if self.downsample is None else self.downsample(x))
+
+    def forward(self, x):
+        out = cp.checkpoint(self._body, x) if (self.with_cp and x.requires_grad) else self._body(x)
+        return self.relu(out)
+
+
+class ResLayer(nn.Sequential):
+    """One stage: the first block carries the stride and the projection shortcut."""
+
+    def __init__(self, block, inplanes, planes, num_blocks, stride=1, avg_down=False, conv_cfg=None,
+                 norm_cfg=dict(type='BN'), **kwargs):
+        self.block = block
+        downsample = None
+        out_planes = planes * block.expansion
+        if stride != 1 or inplanes != out_planes:
+            mods, conv_stride = [], stride
+            if avg_down and stride != 1:
+                conv_stride = 1
+                mods.append(nn.AvgPool2d(kernel_size=stride, stride=stride, ceil_mode=True,
+                                         count_include_pad=False))
+            mods += [build_conv_layer(conv_cfg, inplanes, out_planes, kernel_size=1, stride=conv_stride,
+                                      bias=False),
+                     build_norm_layer(norm_cfg, out_planes)[1]]
+            downsample = nn.Sequential(*mods)
+        blocks = [block(inplanes=inplanes, planes=planes, stride=stride, downsample=downsample, conv_cfg=conv_cfg,
+                        norm_cfg=norm_cfg, **kwargs)]
+        blocks += [block(inplanes=out_planes, planes=planes, stride=1, conv_cfg=conv_cfg, norm_cfg=norm_cfg,
+                         **kwargs) for _ in range(1, num_blocks)]
+        super().__init__(*blocks)
+
+
+@BACKBONES.register_module()
+class ResNet(nn.Module):
+    arch_settings = {
+        18: (BasicBlock, (2, 2, 2, 2)),
+        34: (BasicBlock, (3, 4, 6, 3)),
+        50: (Bottleneck, (3, 4, 6, 3)),
+        101: (Bottleneck, (3, 4, 23, 3)),
+        152: (Bottleneck, (3, 8, 36, 3)),
+    }
+
+    def __init__(self, depth, in_channels=3, stem_channels=64, base_channels=64, num_stages=4,
+                 strides=(1, 2, 2, 2), dilations=(1, 1, 1, 1), out_indices=(0, 1, 2, 3), style='pytorch',
+                 deep_stem=False, avg_down=False, frozen_stages=-1, conv_cfg=None,
+                 norm_cfg=dict(type='BN', requires_grad=True), norm_eval=True, dcn=None,
+                 stage_with_dcn=(False, False, False, False), plugins=None, with_cp=False,
+                 zero_init_residual=True):
+        super().__init__()
+        if depth not in self.arch_settings:
+            raise KeyError(f'invalid depth {depth} for resnet')
+        if deep_stem:
+            raise NotImplementedError('deep_stem (ResNetV1d) is outside the LSNet hot path')
+        assert 1 <= num_stages <= 4
+        assert len(strides) == len(dilations) == num_stages
+        assert max(out_indices) < num_stages
+        if dcn is not None:
+            assert len(stage_with_dcn) == num_stages
+        self.depth, self.stem_channels, self.base_channels = depth, stem_channels, base_channels
+        self.num_stages, self.strides, self.dilations = num_stages, strides, dilations
+        self.out_indices, self.style, self.avg_down = out_indices, style, avg_down
+        self.frozen_stages, self.conv_cfg, self.norm_cfg = frozen_stages, conv_cfg, norm_cfg
+        self.with_cp, self.norm_eval, self.dcn, self.stage_with_dcn = with_cp, norm_eval, dcn, stage_with_dcn
+        self.zero_init_residual = zero_init_residual
+        self.block, stage_blocks = self.arch_settings[depth]
+        self.stage_blocks = stage_blocks[:num_stages]
+
+        self.conv1 = build_conv_layer(conv_cfg, in_channels, stem_channels, kernel_size=7, stride=2, padding=3,
+                                      bias=False)
+        self.norm1_name, norm1 = build_norm_layer(norm_cfg, stem_channels, postfix=1)
+        self.add_module(self.norm1_name, norm1)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+
+        self.res_layers, inplanes = [], stem_channels
+        for i, num_blocks in enumerate(self.stage_blocks):
+            planes = base_channels * 2 ** i
+            layer = self.make_res_layer(block=self.block, inplanes=inplanes, planes=planes,
+                                        num_blocks=num_blocks, stride=strides[i], dilation=dilations[i],
+                                        style=style, avg_down=avg_down, with_cp=with_cp, conv_cfg=conv_cfg,
+                                        norm_cfg=norm_cfg, dcn=dcn if stage_with_dcn[i] else None, plugins=None)
+            inplanes = planes * self.block.expansion
+            name = f'layer{i + 1}'
+            self.add_module(name, layer)
+            self.res_layers.append(name)
+        self._freeze_stages()
+        self.feat_dim = self.block.expansion * base_channels * 2 ** (len(self.stage_blocks) - 1)
+
+    def make_res_layer(self, **kwargs):
+        return ResLayer(**kwargs)
+
+    norm1 = property(lambda self: getattr(self, self.norm1_name))
+
+    def _freeze_stages(self):
+        """Stem (frozen_stages >= 0) and the first `frozen_stages` stages: eval mode, no grads."""
+        frozen = []
+        if self.frozen_stages >= 0:
+            self.norm1.eval()
+            frozen += [self.conv1, self.norm1]
+        for i in range(1, self.frozen_stages + 1):
+            m = getattr(self, f'layer{i}')
+            m.eval()
+            frozen.append(m)
+        for m in frozen:
+            for p in m.parameters():
+                p.requires_grad = False
+
+    def init_weights(self, pretrained=None):
+        if isinstance(pretrained, str):
+            from ...runner.checkpoint import load_checkpoint
+            load_checkpoint(self, pretrained, strict=False)
+            return
+        if pretrained is not None:
+            raise TypeError('pretrained must be a str or None')
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                kaiming_init(m)
+            elif isinstance(m, (_BatchNorm, nn.GroupNorm)):
+                constant_init(m, 1)
+        if self.dcn is not None:
+            for m in self.modules():
+                if isinstance(m, Bottleneck) and hasattr(m.conv2, 'conv_offset'):
+                    constant_init(m.conv2.conv_offset, 0)
+        if self.zero_init_residual:
+            for m in self.modules():
+                if isinstance(m, Bottleneck):
+                    constant_init(m.norm3, 0)
+                elif isinstance(m, BasicBlock):
+                    constant_init(m.norm2, 0)
+
+    def forward(self, x):
+        x = self.maxpool(self.relu(self.norm1(self.conv1(x))))
+        outs = []
+        for i, name in enumerate(self.res_layers):
+            x = getattr(self, name)(x)
+            if i in self.out_indices:
+                outs.append(x)
+        return tuple(outs)
+
+    def train(self, mode=True):
+        super().train(mode)
+        self._freeze_stages()
+        if mode and self.norm_eval:
+            for m in self.modules():
+                if isinstance(m, _BatchNorm):
+                    m.eval()
+        return self
+
+
+@BACKBONES.register_module()
+class ResNeXt(ResNet):
+    arch_settings = {
+        50: (Bottleneck, (3, 4, 6, 3)),
+        101: (Bottleneck, (3, 4, 23, 3)),
+        152: (Bottleneck, (3, 8, 36, 3)),
+    }
+
+    def __init__(self, groups=1, base_width=4, **kwargs):
+        self.groups, self.base_width = groups, base_width
+        super().__init__(**kwargs)
+
+    def make_res_layer(self, **kwargs):
+        return ResLayer(groups=self.groups, base_width=self.base_width, base_channels=self.base_channels,
+                        **kwargs)

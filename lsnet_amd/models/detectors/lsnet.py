@@ -1,0 +1,91 @@
+"""Single-stage detector shell and LSDetector (mmdet/models/detectors/single_stage.py:9-121,
+detectors/lsnet.py:12-100): backbone -> neck -> LSHead; training returns the head's loss dict,
+`simple_test` returns per-class lists of boxes and landmark vectors."""
+import numpy as np
+import torch.nn as nn
+
+from ..builder import DETECTORS, build_backbone, build_head, build_neck
+from .base import BaseDetector
+
+
+def bbox_extreme2result(bboxes, extremes, labels, num_classes, width=8):
+    """(k,5) boxes + (k,w) vectors + (k,) labels -> [per-class boxes], [per-class vectors]
+    (mmdet/core/bbox/transforms.py:198-218)."""
+    if bboxes.shape[0] == 0:
+        return [[np.zeros((0, 5), dtype=np.float32) for _ in range(num_classes)],
+                [np.zeros((0, width), dtype=np.float32) for _ in range(num_classes)]]
+    b, e, l = bboxes.cpu().numpy(), extremes.cpu().numpy(), labels.cpu().numpy()
+    return [[b[l == i, :] for i in range(num_classes)], [e[l == i, :] for i in range(num_classes)]]
+
+
+def bbox_poly2result(bboxes, polygons, labels, num_classes, num_contour_points):
+    return bbox_extreme2result(bboxes, polygons, labels, num_classes, num_contour_points * 2)
+
+
+@DETECTORS.register_module()
+class SingleStageDetector(BaseDetector):
+
+    def __init__(self, backbone, neck=None, bbox_head=None, train_cfg=None, test_cfg=None, pretrained=None):
+        super().__init__()
+        self.backbone = build_backbone(backbone)
+        if neck is not None:
+            self.neck = build_neck(neck)
+        bbox_head = dict(bbox_head)
+        bbox_head.update(train_cfg=train_cfg, test_cfg=test_cfg)
+        self.bbox_head = build_head(bbox_head)
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.init_weights(pretrained=pretrained)
+
+    def init_weights(self, pretrained=None):
+        self.backbone.init_weights(pretrained=pretrained)
+        if self.with_neck:
+            for m in (self.neck if isinstance(self.neck, nn.Sequential) else [self.neck]):
+                m.init_weights()
+        self.bbox_head.init_weights()
+
+    def extract_feat(self, img):
+        x = self.backbone(img)
+        return self.neck(x) if self.with_neck else x
+
+    def forward_dummy(self, img):
+        return self.bbox_head(self.extract_feat(img))
+
+
+@DETECTORS.register_module()
+class LSDetector(SingleStageDetector):
+
+    def forward_train(self, img, img_metas, gt_bboxes, gt_labels, gt_masks=None, gt_extremes=None,
+                      gt_keypoints=None, gt_bboxes_ignore=None):
+        x = self.extract_feat(img)
+        return self.bbox_head.forward_train(x, img_metas, gt_bboxes, gt_extremes, gt_keypoints, gt_masks,
+                                            gt_labels, gt_bboxes_ignore)
+
+    def simple_test(self, img, img_metas, rescale=False, show=False, out_dir=False):
+        head = self.bbox_head
+        outs = head(self.extract_feat(img))
+        dets = head.get_bboxes(*outs, img_metas, rescale=rescale)
+        if head.task == 'bbox':
+            results = [bbox_extreme2result(b, v, l, head.num_classes) for b, v, l in dets]
+        elif head.task == 'segm' or show or out_dir:
+            results = [bbox_poly2result(b, v, l, head.num_classes, head.num_vectors) for b, v, l in dets]
+        else:
+            # pose: drop boxes of area <= 32^2.  Like the reference (lsnet.py:85-98) only the LAST
+            # image of the batch is reported; its test loader always uses one image per batch.
+            for b, v, l in dets:
+                big = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1]) > 1024
+                b, v, l = b[big], v[big], l[big]
+            results = [bbox_poly2result(b, v, l, head.num_classes, head.num_vectors)]
+        return results[0]
+
+    def simple_test_batch(self, img, img_metas, rescale=False):
+        """Device-resident per-image (boxes, vectors, labels) for a whole batch -- what the
+        inference benchmark times (no host conversion)."""
+        head = self.bbox_head
+        dets = head.get_bboxes(*head(self.extract_feat(img)), img_metas, rescale=rescale)
+        if head.task in ('pose_bbox', 'pose_kbox'):
+            out = []
+            for b, v, l in dets:
+                big = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1]) > 1024
+                out.append((b[big], v[big], l[big]))
+            return out
+        return dets

@@ -1,0 +1,202 @@
+"""Generates tests/golden/*.npz by running the REFERENCE's own Python (imported from
+/root/reference through bootstrap.py, native ops backed by the CPU oracle) on seeded inputs.
+
+Runs only in the build container.  Fixtures are data (inputs are re-derived from seeds by
+tests/golden_util.py; outputs are stored as strided samples + sums, integer results in full).
+
+    python oracle/ref_harness/make_golden.py [--only head_bbox,...]
+"""
+import argparse
+import copy
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+from oracle.ref_harness import bootstrap  # noqa: E402
+from tests import golden_util as gu  # noqa: E402
+
+OUT = os.path.join(REPO, 'tests', 'golden')
+
+
+def _save(name, data):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + '.npz')
+    np.savez_compressed(path, **data)
+    print(f'{name}: {os.path.getsize(path) / 1024:.1f} KiB, {len(data)} arrays')
+
+
+def _ref_head(task, channels=32):
+    import mmcv
+    from mmdet.models import build_head
+    cfg, train_cfg, test_cfg = gu.head_cfg(task, channels)
+    cfg = mmcv.Config(copy.deepcopy(cfg))._cfg_dict     # attribute-style dicts, as Config.fromfile gives
+    cfg.update(train_cfg=mmcv.Config(train_cfg), test_cfg=mmcv.Config(test_cfg))
+    head = build_head(cfg)
+    gu.fill_params(head, seed=7)
+    return head
+
+
+def _gt_for(task, batch=2):
+    h, w = gu.HEAD_IMG
+    boxes, labels, extremes, masks, kps = [], [], [], [], []
+    for i in range(batch):
+        b, l, e = gu.make_gt(100 + i, 4 + i, h, w, num_classes=8)
+        boxes.append(b); labels.append(l); extremes.append(e)
+        masks.append(gu.make_polygons(b))
+        kps.append(gu.make_keypoints(200 + i, b))
+    metas = [dict(pad_shape=(h, w, 3), img_shape=(h, w, 3), scale_factor=1.0) for _ in range(batch)]
+    return boxes, labels, extremes, masks, kps, metas
+
+
+def golden_head(task):
+    """(8) full LSHead.forward + loss (+ gradients) and get_bboxes, reference code end to end."""
+    head = _ref_head(task)
+    head.train()
+    feats = [f.requires_grad_() for f in gu.head_inputs(11)]
+    outs = head(feats)
+    data = {}
+    names = ['cls', 'bbox_init', 'bbox_refine', 'segm_init', 'segm_refine', 'pose_init', 'pose_refine']
+    for n, lv in zip(names, outs):
+        for i, t in enumerate(lv):
+            if t is not None:
+                gu.pack(f'out/{n}/{i}', t, data)
+    boxes, labels, extremes, masks, kps, metas = _gt_for(task)
+    kw = dict(gt_bboxes=boxes, gt_labels=labels, img_metas=metas,
+              gt_extremes=extremes if task in ('bbox', 'pose_bbox') else None,
+              gt_keypoints_vs=[k.clone() for k in kps] if 'pose' in task else None,
+              gt_masks=masks if task == 'segm' else None)
+    losses = head.loss(*outs, **kw)
+    total = 0
+    for k, v in losses.items():
+        data[f'loss/{k}'] = np.array([float(x) for x in v], dtype=np.float64)
+        total = total + sum(v)
+    total.backward()
+    for i, f in enumerate(feats):
+        gu.pack(f'grad/feat/{i}', f.grad, data)
+    for name, p in sorted(head.named_parameters()):
+        if p.grad is not None:
+            gu.pack(f'grad/param/{name}', p.grad, data, stride=7)
+    # inference: decode + NMS
+    head.eval()
+    with torch.no_grad():
+        dets = head.get_bboxes(*[[None if t is None else t.detach() for t in lv] for lv in outs], metas)
+    for i, (b, v, l) in enumerate(dets):
+        data[f'det/{i}/bboxes'] = b.numpy()
+        data[f'det/{i}/vectors'] = v.numpy()
+        data[f'det/{i}/labels'] = l.numpy()
+    _save(f'head_{task}', data)
+
+
+def golden_assign():
+    """(6) CentroidAssigner + ATSSAssigner gt indices on the 800x800 grid (13 343 points)."""
+    from mmdet.core import build_assigner
+    from mmdet.core.anchor.point_generator import PointGenerator
+    data = {}
+    strides = [8, 16, 32, 64, 128]
+    sizes = [(-(-800 // s), -(-800 // s)) for s in strides]
+    pg = PointGenerator()
+    pts = torch.cat([pg.grid_points(sz, s, 'cpu') for sz, s in zip(sizes, strides)])
+    init = build_assigner(dict(type='CentroidAssigner', scale=4, pos_num=1, iou_type='center'))
+    cen = build_assigner(dict(type='CentroidAssigner', scale=4, pos_num=3, iou_type='centroid'))
+    atss = build_assigner(dict(type='ATSSAssigner', topk=9))
+    for i in range(2):
+        b, l, e = gu.make_gt(300 + i, 7 + 5 * i, 800, 800)
+        r = init.assign(pts, b, e, None, l)
+        data[f'init/{i}/gt_inds'] = r.gt_inds.numpy().astype(np.int32)
+        data[f'init/{i}/labels'] = r.labels.numpy().astype(np.int32)
+        r = cen.assign(pts, b, e, None, l)
+        data[f'centroid/{i}/gt_inds'] = r.gt_inds.numpy().astype(np.int32)
+        g = gu.gen(400 + i)
+        wh = torch.rand(pts.shape[0], 2, generator=g) * pts[:, 2:3] * 6 + 2
+        ctr = pts[:, :2] + (torch.rand(pts.shape[0], 2, generator=g) - 0.5) * pts[:, 2:3]
+        props = torch.cat([ctr - wh / 2, ctr + wh / 2], 1)
+        r = atss.assign(props, [s[0] * s[1] for s in sizes], b, None, l)
+        data[f'atss/{i}/gt_inds'] = r.gt_inds.numpy().astype(np.int32)
+        gu.pack(f'atss/{i}/max_overlaps', r.max_overlaps, data, stride=5)
+    _save('assign', data)
+
+
+def golden_cross_iou():
+    """(4) cross-IOU value + gradient for the bbox / polygon / keypoint variants, 4096 rows."""
+    from mmdet.models.losses.cross_iou_loss import CrossIOULoss
+    data = {}
+    N = 4096
+    for kind, width, nv in (('bbox', 20, 4), ('polygon', 148, 36), ('keypoint', 72, 17)):
+        g = gu.gen(500 + width)
+        pred = (torch.rand(N, width, generator=g) * 2 + 0.01).requires_grad_()
+        target = torch.rand(N, width, generator=g) * 2
+        pos = torch.rand(N, width // 2, generator=g) > 0.5
+        pos = torch.stack([pos, ~pos], -1).reshape(N, width)
+        target = target * pos            # the inactive half of each pair is 0 before alpha-filling
+        rowpos = torch.rand(N, generator=g) < 0.02
+        target = target * rowpos[:, None]
+        weight = rowpos.float()[:, None].expand(N, width).contiguous()
+        anchor = torch.rand(N, 2, generator=g) * 10
+        lo = torch.rand(N, 2, generator=g) * 5
+        bbox_gt = torch.cat([lo, lo + torch.rand(N, 2, generator=g) * 5 + 0.1], 1)
+        vs = torch.randint(0, 3, (N, nv), generator=g).float()
+        loss_fn = CrossIOULoss(loss_weight=2.0, loss_type=kind)
+        kw = dict(anchor_pts=anchor, pos_inds=pos, bbox_gt=None if kind == 'keypoint' else bbox_gt)
+        if kind == 'keypoint':
+            kw['vs'] = vs.clone()
+        loss = loss_fn(pred, target.clone(), weight, avg_factor=37.0, **kw)
+        loss.backward()
+        data[f'{kind}/loss'] = np.float64(loss.item())
+        gu.pack(f'{kind}/grad', pred.grad, data, stride=3)
+    _save('cross_iou', data)
+
+
+def golden_backbone():
+    """(9) ResNet-50 + FPN forward on a 1x3x128x128 input with name-keyed weights."""
+    import mmcv
+    from mmdet.models import build_backbone, build_neck
+    cfg = mmcv.Config.fromfile('/root/reference/code/configs/lsnet/lsnet_bbox_r50_fpn_1x_coco.py')
+    bb, neck = build_backbone(cfg.model.backbone), build_neck(cfg.model.neck)
+    gu.fill_params(bb, seed=3); gu.fill_params(neck, seed=4)
+    bb.train(); neck.train()
+    x = torch.randn(1, 3, 128, 128, generator=gu.gen(21))
+    data = {}
+    with torch.no_grad():
+        c = bb(x)
+        p = neck(c)
+    for i, t in enumerate(c):
+        gu.pack(f'c/{i}', t, data)
+    for i, t in enumerate(p):
+        gu.pack(f'p/{i}', t, data)
+    _save('backbone_r50_fpn', data)
+
+
+def golden_nms():
+    """(7) multiclass_nms_lsvr keep set on random candidates (the reference's nms_cpu semantics)."""
+    from mmdet.core import multiclass_nms_lsvr
+    g = gu.gen(600)
+    n, C = 1500, 8
+    xy = torch.rand(n, 2, generator=g) * 300
+    wh = torch.rand(n, 2, generator=g) * 80 + 2
+    boxes = torch.cat([xy, xy + wh], 1)
+    pts = torch.rand(n, 8, generator=g) * 300
+    scores = torch.rand(n, C, generator=g) ** 4
+    scores = torch.cat([scores, torch.zeros(n, 1)], 1)
+    import mmcv
+    dets, vec, labels = multiclass_nms_lsvr(boxes, pts, scores, 4, 0.05, mmcv.Config(dict(nms=dict(type='nms', iou_thr=0.6))).nms,
+                                            100)
+    _save('nms_lsvr', dict(dets=dets.numpy(), vectors=vec.numpy(), labels=labels.numpy()))
+
+
+ALL = dict(head_bbox=lambda: golden_head('bbox'), head_segm=lambda: golden_head('segm'),
+           head_pose_bbox=lambda: golden_head('pose_bbox'), head_pose_kbox=lambda: golden_head('pose_kbox'),
+           assign=golden_assign, cross_iou=golden_cross_iou, backbone=golden_backbone, nms=golden_nms)
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--only', default='')
+    args = ap.parse_args()
+    bootstrap.load_reference()
+    torch.set_num_threads(8)
+    for k in (args.only.split(',') if args.only else ALL):
+        ALL[k]()

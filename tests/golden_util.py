@@ -1,0 +1,150 @@
+"""Deterministic inputs / parameter fills / output summaries shared by the golden-vector generator
+(oracle/ref_harness/make_golden.py, runs against the reference in the build container) and by the
+parity tests (which run wherever the fixtures under tests/golden/ are).  Pure torch/numpy on CPU:
+the same code yields bit-identical inputs on both sides."""
+import types
+import zlib
+
+import numpy as np
+import torch
+
+
+def gen(seed):
+    return torch.Generator().manual_seed(int(seed))
+
+
+def fill_params(model, seed=0):
+    """Overwrite every parameter / buffer with values drawn from a generator keyed by its NAME, so
+    two differently-constructed models with the same state-dict keys get identical weights."""
+    with torch.no_grad():
+        for name, p in sorted(model.state_dict().items()):
+            g = gen(zlib.crc32(name.encode()) + seed)
+            if not p.dtype.is_floating_point:
+                continue
+            if name.endswith('running_var'):
+                p.copy_(torch.rand(p.shape, generator=g) * 0.5 + 0.75)
+            elif name.endswith('running_mean'):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.1)
+            elif p.dim() >= 2:
+                fan_in = p[0].numel()
+                scale = 0.3 if 'conv_offset' in name else 1.0
+                p.copy_(torch.randn(p.shape, generator=g) * (scale / fan_in ** 0.5))
+            elif name.endswith('weight'):          # norm scales
+                p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g))
+            else:                                   # biases
+                p.copy_(0.1 * torch.randn(p.shape, generator=g))
+    return model
+
+
+def summary(t, stride=13):
+    """Compact fingerprint of a tensor: strided sample + sums (enough to catch layout, sign and
+    scale errors; 1e-3-level comparison is done on the sample)."""
+    t = t.detach().double().cpu().reshape(-1)
+    return dict(sample=t[::stride].float().numpy(), sum=np.float64(t.sum().item()),
+                abssum=np.float64(t.abs().sum().item()), n=np.int64(t.numel()))
+
+
+def pack(prefix, t, out, stride=13):
+    for k, v in summary(t, stride).items():
+        out[f'{prefix}/{k}'] = v
+
+
+def check(prefix, t, ref, rtol=1e-3, stride=13):
+    """Assert `t` matches the fingerprint stored under `prefix` in the npz `ref`."""
+    s = summary(t, stride)
+    assert int(s['n']) == int(ref[f'{prefix}/n']), (prefix, s['n'], ref[f'{prefix}/n'])
+    want = ref[f'{prefix}/sample']
+    scale = max(float(np.abs(want).max()), 1e-12)
+    err = float(np.abs(s['sample'] - want).max()) / scale
+    assert err < rtol, f'{prefix}: sample rel err {err:.3e}'
+    denom = max(float(ref[f'{prefix}/abssum']), 1e-12)
+    assert abs(float(s['sum']) - float(ref[f'{prefix}/sum'])) / denom < rtol, f'{prefix}: sum mismatch'
+    return err
+
+
+# ---------------------------------------------------------------------------------------------
+# synthetic COCO-shaped ground truth
+# ---------------------------------------------------------------------------------------------
+def make_gt(seed, num, img_h, img_w, num_classes=80, min_size=16., max_size=None):
+    """Boxes with centres uniform over the image and log-uniform sizes, labels, and extreme points
+    [top, left, bottom, right, centre] as (x, y) pairs lying on the respective box edge."""
+    g = gen(seed)
+    max_size = max_size or 0.75 * min(img_h, img_w)
+    cx = torch.rand(num, generator=g) * img_w
+    cy = torch.rand(num, generator=g) * img_h
+    w = torch.exp(torch.rand(num, generator=g) * (np.log(max_size) - np.log(min_size)) + np.log(min_size))
+    h = torch.exp(torch.rand(num, generator=g) * (np.log(max_size) - np.log(min_size)) + np.log(min_size))
+    x1, x2 = (cx - w / 2).clamp(0, img_w - 2), (cx + w / 2).clamp(2, img_w)
+    y1, y2 = (cy - h / 2).clamp(0, img_h - 2), (cy + h / 2).clamp(2, img_h)
+    x2, y2 = torch.max(x2, x1 + 2), torch.max(y2, y1 + 2)
+    boxes = torch.stack([x1, y1, x2, y2], 1)
+    labels = torch.randint(0, num_classes, (num,), generator=g)
+    u = torch.rand(num, 4, generator=g)
+    tx, ly = x1 + u[:, 0] * (x2 - x1), y1 + u[:, 1] * (y2 - y1)
+    bx, ry = x1 + u[:, 2] * (x2 - x1), y1 + u[:, 3] * (y2 - y1)
+    extremes = torch.stack([tx, y1, x1, ly, bx, y2, x2, ry, (x1 + x2) / 2, (y1 + y2) / 2], 1)
+    return boxes, labels, extremes
+
+
+def make_polygons(boxes, nv=36):
+    """nv-vertex clockwise (image coordinates) ellipse inscribed in each box, starting at the vertex
+    nearest the top-centre -- the format the reference's data pipeline emits (loading.py:405-441).
+    Returned as an object with `.masks` (per instance: list with one flat (2*nv,) float array) and
+    `.areas`, which is all LSHead.process_polygons reads."""
+    masks, areas = [], []
+    for b in boxes.tolist():
+        cx, cy, rx, ry = (b[0] + b[2]) / 2, (b[1] + b[3]) / 2, (b[2] - b[0]) / 2, (b[3] - b[1]) / 2
+        ang = -np.pi / 2 + 2 * np.pi * np.arange(nv) / nv      # start at the top, clockwise on screen
+        pts = np.stack([cx + rx * np.cos(ang), cy + ry * np.sin(ang)], 1).astype(np.float32)
+        masks.append([pts.reshape(-1)])
+        areas.append(np.pi * rx * ry)
+    return types.SimpleNamespace(masks=masks, areas=np.asarray(areas, dtype=np.float32))
+
+
+def make_keypoints(seed, boxes, nk=17):
+    """(G, nk*3) [x, y, v] with keypoints uniform inside the box and v in {0,1,2} (p = .3,.2,.5)."""
+    g = gen(seed)
+    G = boxes.shape[0]
+    u = torch.rand(G, nk, 2, generator=g)
+    x = boxes[:, None, 0] + u[..., 0] * (boxes[:, None, 2] - boxes[:, None, 0])
+    y = boxes[:, None, 1] + u[..., 1] * (boxes[:, None, 3] - boxes[:, None, 1])
+    r = torch.rand(G, nk, generator=g)
+    v = (r > 0.3).float() + (r > 0.5).float()
+    v[:, 0] = 2.0   # at least one visible keypoint per instance (kbox needs it)
+    return torch.stack([x, y, v], 2).reshape(G, -1)
+
+
+def head_cfg(task, channels=32, num_classes=8):
+    """A reduced LSHead config (same code paths as configs/lsnet/*, small tensors)."""
+    norm_cfg = dict(type='GN', num_groups=8, requires_grad=True)
+    nv = {'bbox': 4, 'segm': 36, 'pose_bbox': 17, 'pose_kbox': 17}[task]
+    cfg = dict(type='LSHead', task=task, num_vectors=nv, num_classes=num_classes, in_channels=channels,
+               feat_channels=channels, point_feat_channels=channels, stacked_convs=3, num_kernel_points=9,
+               gradient_mul=0.1, point_strides=[8, 16, 32, 64, 128], point_base_scale=4, norm_cfg=norm_cfg,
+               conv_module_type='dcn',
+               loss_cls=dict(type='FocalLoss', use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=1.0))
+    if task in ('bbox', 'pose_bbox'):
+        cfg.update(loss_bbox_init=dict(type='CrossIOULoss', loss_weight=1.0),
+                   loss_bbox_refine=dict(type='CrossIOULoss', loss_weight=2.0))
+    if task == 'segm':
+        cfg.update(loss_segm_init=dict(type='CrossIOULoss', loss_weight=1.0, loss_type='polygon'),
+                   loss_segm_refine=dict(type='CrossIOULoss', loss_weight=2.0, loss_type='polygon'))
+    if task in ('pose_bbox', 'pose_kbox'):
+        cfg.update(loss_pose_init=dict(type='CrossIOULoss', loss_weight=10.0, loss_type='keypoint'),
+                   loss_pose_refine=dict(type='CrossIOULoss', loss_weight=20.0, loss_type='keypoint'))
+    train_cfg = dict(init=dict(assigner=dict(type='CentroidAssigner', scale=4, pos_num=1, iou_type='center'),
+                               allowed_border=-1, pos_weight=-1, debug=False),
+                     refine=dict(assigner=dict(type='ATSSAssigner', topk=9), allowed_border=-1, pos_weight=-1,
+                                 debug=False))
+    test_cfg = dict(nms_pre=1000, min_bbox_size=0, score_thr=0.05, nms=dict(type='nms', iou_thr=0.6),
+                    max_per_img=100)
+    return cfg, train_cfg, test_cfg
+
+
+HEAD_IMG = (384, 512)   # -> grids 48x64, 24x32, 12x16, 6x8, 3x4 (>= 9 cells on every level for ATSS)
+
+
+def head_inputs(seed, channels=32, batch=2):
+    g = gen(seed)
+    h, w = HEAD_IMG
+    return [torch.randn(batch, channels, -(-h // s), -(-w // s), generator=g) for s in (8, 16, 32, 64, 128)]

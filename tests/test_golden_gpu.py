@@ -1,0 +1,37 @@
+"""The golden-vector parity cases on the MI355X: LSHead / losses / assigners / decode / NMS with the
+native ops going through liblsnet_hip.so (both memory formats)."""
+import pytest
+import torch
+
+from tests import golden_cases as gc
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available()
+    return torch.device('cuda:0')
+
+
+@pytest.mark.parametrize('channels_last', [False, True], ids=['nchw', 'nhwc'])
+@pytest.mark.parametrize('task', ['bbox', 'segm', 'pose_bbox', 'pose_kbox'])
+def test_head_forward_loss_backward_decode(task, channels_last):
+    worst = gc.head_case(task, _dev(), channels_last)
+    print(task, 'channels_last' if channels_last else 'contiguous', f'worst sample err {worst:.2e}')
+
+
+def test_assigners_exact():
+    gc.assign_case(_dev())
+
+
+def test_cross_iou_loss():
+    gc.cross_iou_case(_dev())
+
+
+@pytest.mark.parametrize('channels_last', [False, True], ids=['nchw', 'nhwc'])
+def test_backbone_fpn(channels_last):
+    gc.backbone_case(_dev(), channels_last)
+
+
+def test_multiclass_nms_lsvr():
+    gc.nms_lsvr_case(_dev())

@@ -1,0 +1,30 @@
+"""Host-side parity against the reference's golden vectors, on CPU with the oracle registered as
+the 'cpu' backend of the native ops (test infrastructure).  The same cases run on the MI355X
+through the HIP path in tests/test_golden_gpu.py."""
+import pytest
+import torch
+
+from tests import golden_cases as gc
+
+CPU = torch.device('cpu')
+
+
+@pytest.mark.parametrize('task', ['bbox', 'segm', 'pose_bbox', 'pose_kbox'])
+def test_head_forward_loss_backward_decode(task, cpu_oracle_backend):
+    gc.head_case(task, CPU)
+
+
+def test_assigners_exact():
+    gc.assign_case(CPU)
+
+
+def test_cross_iou_loss():
+    gc.cross_iou_case(CPU)
+
+
+def test_backbone_fpn():
+    gc.backbone_case(CPU)
+
+
+def test_multiclass_nms_lsvr(cpu_oracle_backend):
+    gc.nms_lsvr_case(CPU)
