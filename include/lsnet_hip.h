@@ -67,6 +67,10 @@ typedef struct {
     int kh, kw, stride, pad, dil;
     int groups, deformable_groups;
     float scale_h, scale_w;
+    int mask_is_logit; /* 1: `mask` holds raw logits; the kernels apply sigmoid and grad_mask is the
+                        * gradient w.r.t. the logits.  Lets a DCNv2 pack hand its (B, 3*dg*kh*kw, H, W)
+                        * conv_offset output to the op as ONE tensor (offset = first 2/3 of the channels,
+                        * mask = last 1/3, deform_conv.py:527-530) and get ONE gradient tensor back. */
 } lsn_dcn_shape;
 
 /* One (source map, offset field, output) triple of a batched launch.  All levels of a launch

@@ -148,6 +148,7 @@ static int fill_levels(DcnArgs &a, const lsn_dcn_shape &s, int n, const lsn_dcn_
     a.groups = s.groups; a.dg = s.deformable_groups;
     const int Cg = s.C / s.groups, cpdg = s.C / s.deformable_groups;
     a.SL = Cg < cpdg ? Cg : cpdg;
+    a.msig = s.mask_is_logit ? 1 : 0;
     a.w = a.bias = nullptr;
     a.gw = a.gb = nullptr;
     return 0;

@@ -41,6 +41,7 @@ struct DcnArgs {
     float *gw, *gb;
     int C, Co, kh, kw, stride, pad, dil, groups, dg;
     int SL;   // channel segment length = min(C/groups, C/dg): constant (g, dgi) inside a segment
+    int msig; // mask tensor holds logits: apply sigmoid on read, chain it into grad_mask
 };
 
 // One sampling position: the four clamped NHWC element offsets of its bilinear corners (channel 0),
@@ -76,9 +77,10 @@ __device__ __forceinline__ Tap make_tap(const DcnArgs &a, const Lvl &L, int pix,
     const float *op = L.off + (size_t)b * L.osb + (size_t)ho * L.osh + (size_t)wo * L.osw;
     const float oy = op[(size_t)(dgi * 2 * K + 2 * k) * L.osc];
     const float ox = op[(size_t)(dgi * 2 * K + 2 * k + 1) * L.osc];
-    const float m = L.msk ? L.msk[(size_t)b * L.msb + (size_t)(dgi * K + k) * L.msc + (size_t)ho * L.msh +
-                                  (size_t)wo * L.msw]
-                          : 1.f;
+    float m = L.msk ? L.msk[(size_t)b * L.msb + (size_t)(dgi * K + k) * L.msc + (size_t)ho * L.msh +
+                            (size_t)wo * L.msw]
+                    : 1.f;
+    if (a.msig && L.msk) m = 1.f / (1.f + expf(-m));
     const float py = __fadd_rn(__fmul_rn((float)(ho * a.stride - a.pad + i * a.dil), L.sh), oy);
     const float px = __fadd_rn(__fmul_rn((float)(wo * a.stride - a.pad + j * a.dil), L.sw), ox);
     if (py > -1.f && px > -1.f && py < (float)L.H && px < (float)L.W) {
@@ -493,9 +495,14 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_kernel(const DcnArgs a)
             op[(size_t)(dgi * 2 * K + 2 * k) * L.osc] = ga[0];
             op[(size_t)(dgi * 2 * K + 2 * k + 1) * L.osc] = ga[1];
         }
-        if (L.gmsk)
-            L.gmsk[(size_t)b * L.msb + (size_t)(dgi * K + k) * L.msc + (size_t)ho * L.msh + (size_t)wo * L.msw] =
-                ga[2];
+        if (L.gmsk) {
+            float gm = ga[2];
+            if (a.msig) {  // d sigmoid: m (1 - m); out-of-range samples have ga[2] == 0 already
+                const float m = tab[e].m;
+                gm *= m * (1.f - m);
+            }
+            L.gmsk[(size_t)b * L.msb + (size_t)(dgi * K + k) * L.msc + (size_t)ho * L.msh + (size_t)wo * L.msw] = gm;
+        }
     }
 }
 

@@ -55,7 +55,7 @@ class _DCNFunction(Function):
             if tuple(off.shape[2:]) != hw:
                 raise RuntimeError(f'invalid spatial size of offset, expected height: {hw[0]} width: {hw[1]}, '
                                    f'but got height: {off.shape[2]} width: {off.shape[3]}')
-            if off.shape[1] != cfg['dg'] * 2 * weight.shape[2] * weight.shape[3]:
+            if off.shape[1] != cfg['dg'] * (3 if cfg.get('fused_om') else 2) * weight.shape[2] * weight.shape[3]:
                 raise RuntimeError('invalid number of channels of offset')
             out_hw.append(hw)
         ctx.cfg, ctx.n, ctx.backend = cfg, n, backend
@@ -96,12 +96,16 @@ class _DCNFunction(Function):
 
 
 def dcn_multi(inputs, offsets, masks, weight, bias=None, stride=1, padding=0, dilation=1, groups=1,
-              deformable_groups=1, scales=None, pyramid=False):
+              deformable_groups=1, scales=None, pyramid=False, fused_om=False):
     """Batched deformable convolution: out_i = DCN(inputs[i], offsets[i], masks[i]; weight, bias).
 
     masks may be None (DCNv1 / pyramid) or a list with None entries.  scales: per-level
     (scale_h, scale_w) for the pyramid op (default 1).  With pyramid=True the output grid is the
-    offset grid (deform_conv.py:215-217)."""
+    offset grid (deform_conv.py:215-217).
+
+    fused_om=True: `offsets[i]` is the raw (B, 3*dg*kh*kw, H, W) output of a DCNv2 pack's conv_offset
+    (offsets in the first two thirds of the channels, mask LOGITS in the last third); the sigmoid and
+    its derivative are applied inside the kernels and ONE gradient tensor comes back."""
     n = len(inputs)
     if masks is None:
         masks = [None] * n
@@ -112,7 +116,7 @@ def dcn_multi(inputs, offsets, masks, weight, bias=None, stride=1, padding=0, di
             raise ValueError(f'Expected 4D tensor as input, got {x.dim()}D tensor instead.')
     cfg = dict(stride=_same_int(stride, 'stride'), pad=_same_int(padding, 'padding'),
                dil=_same_int(dilation, 'dilation'), groups=int(groups), dg=int(deformable_groups),
-               scales=[(float(a), float(b)) for a, b in scales], pyramid=bool(pyramid))
+               scales=[(float(a), float(b)) for a, b in scales], pyramid=bool(pyramid), fused_om=bool(fused_om))
     return list(_DCNFunction.apply(weight, bias, cfg, n, *inputs, *offsets, *masks))
 
 
@@ -284,14 +288,14 @@ class ModulatedDeformConvPack(ModulatedDeformConv):
         return out[:, :k2], torch.sigmoid(out[:, k2:])
 
     def forward(self, x):
-        offset, mask = self._offset_mask(x)
-        return modulated_deform_conv(x, offset, mask, self.weight, self.bias, self.stride, self.padding,
-                                     self.dilation, self.groups, self.deformable_groups)
+        return self.forward_multi([x])[0]
 
     def forward_multi(self, xs):
-        oms = [self._offset_mask(x) for x in xs]
-        return dcn_multi(list(xs), [o for o, _ in oms], [m for _, m in oms], self.weight, self.bias,
-                         self.stride, self.padding, self.dilation, self.groups, self.deformable_groups)
+        # conv_offset's output goes to the op as ONE tensor (offsets | mask logits): no chunk / cat /
+        # sigmoid kernels and a single dense gradient for conv_offset's backward
+        return dcn_multi(list(xs), [self.conv_offset(x) for x in xs], None, self.weight, self.bias,
+                         self.stride, self.padding, self.dilation, self.groups, self.deformable_groups,
+                         fused_om=True)
 
     def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
                               error_msgs):

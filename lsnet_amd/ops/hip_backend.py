@@ -64,7 +64,13 @@ class HipBackend:
     def _shape(w, cfg):
         Co, Cg, kh, kw = w.shape
         return _lib.DcnShape(0, Cg * cfg['groups'], 0, 0, Co, 0, 0, kh, kw, cfg['stride'], cfg['pad'],
-                             cfg['dil'], cfg['groups'], cfg['dg'], 1.0, 1.0)
+                             cfg['dil'], cfg['groups'], cfg['dg'], 1.0, 1.0, 1 if cfg.get('fused_om') else 0)
+
+    @staticmethod
+    def _mask_view_ptr(om, cfg, kk):
+        """Fused DCNv2 pack: `om` (B, 3*dg*K, H, W) holds offsets in its first 2*dg*K channels and the
+        mask logits in the rest; the mask pointer is the same buffer advanced by 2*dg*K channels."""
+        return ctypes.c_void_p(om.data_ptr() + 2 * cfg['dg'] * kk * om.stride(1) * om.element_size())
 
     def dcn_forward(self, inputs, offsets, masks, weight, bias, cfg, out_hw):
         """inputs/offsets/masks: per-level lists (mask entries may be None); cfg: stride, pad, dil,
@@ -84,7 +90,9 @@ class HipBackend:
             L = levels[i]
             L.input, L.offset, L.mask, L.output = _ptr(xs[i]), _ptr(offs[i]), _ptr(msks[i]), _ptr(out)
             L.off_st = _strides(offs[i])
-            if msks[i] is not None:
+            if cfg.get('fused_om'):
+                L.mask, L.mask_st = self._mask_view_ptr(offs[i], cfg, w.shape[2] * w.shape[3]), _strides(offs[i])
+            elif msks[i] is not None:
                 L.mask_st = _strides(msks[i])
             L.B, L.H, L.W, L.Ho, L.Wo = B, H, W, Ho, Wo
             L.scale_h, L.scale_w = cfg['scales'][i]
@@ -117,7 +125,12 @@ class HipBackend:
             L.input, L.offset, L.mask = _ptr(xs[i]), _ptr(offs[i]), _ptr(msks[i])
             L.grad_output, L.grad_input, L.grad_offset, L.grad_mask = _ptr(go), _ptr(gx), _ptr(goff), _ptr(gmsk)
             L.off_st = _strides(offs[i])
-            if msks[i] is not None:
+            if cfg.get('fused_om'):
+                kk = w.shape[2] * w.shape[3]
+                L.mask, L.mask_st = self._mask_view_ptr(offs[i], cfg, kk), _strides(offs[i])
+                if goff is not None:   # one gradient tensor for offsets + mask logits
+                    L.grad_mask = self._mask_view_ptr(goff, cfg, kk)
+            elif msks[i] is not None:
                 L.mask_st = _strides(msks[i])
             L.B, L.H, L.W, L.Ho, L.Wo = B, H, W, Ho, Wo
             L.scale_h, L.scale_w = cfg['scales'][i]

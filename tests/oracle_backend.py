@@ -10,7 +10,15 @@ from oracle import oracle_py as orc
 class OracleBackend:
     name = 'oracle'
 
+    @staticmethod
+    def _split(om, cfg, weight):
+        k2 = 2 * cfg['dg'] * weight.shape[2] * weight.shape[3]
+        return om[:, :k2].contiguous(), torch.sigmoid(om[:, k2:]).contiguous()
+
     def dcn_forward(self, inputs, offsets, masks, weight, bias, cfg, out_hw):
+        if cfg.get('fused_om'):
+            pairs = [self._split(om, cfg, weight) for om in offsets]
+            offsets, masks = [p[0] for p in pairs], [p[1] for p in pairs]
         outs = []
         for i, x in enumerate(inputs):
             sh, sw = cfg['scales'][i]
@@ -20,6 +28,10 @@ class OracleBackend:
         return outs
 
     def dcn_backward(self, inputs, offsets, masks, weight, grad_outs, cfg, need):
+        fused = cfg.get('fused_om')
+        if fused:
+            pairs = [self._split(om, cfg, weight) for om in offsets]
+            offsets, masks = [p[0] for p in pairs], [p[1] for p in pairs]
         gxs, goffs, gmsks = [], [], []
         gw = torch.zeros_like(weight.detach().float().contiguous())
         gb = torch.zeros(weight.shape[0])
@@ -29,6 +41,9 @@ class OracleBackend:
                                          cfg['pad'], cfg['dil'], cfg['groups'], cfg['dg'], sh, sw)
             gxs.append(g['gx']); goffs.append(g['goff']); gmsks.append(g['gmask'])
             gw += g['gw']; gb += g['gb']
+        if fused:   # one gradient per level: [d offsets | d mask logits]
+            goffs = [torch.cat([go, gm * m * (1 - m)], 1) for go, gm, m in zip(goffs, gmsks, masks)]
+            gmsks = [None] * len(goffs)
         return gxs, goffs, gmsks, gw, gb
 
     def focal_forward(self, logits, targets, gamma, alpha):

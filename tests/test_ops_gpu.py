@@ -274,3 +274,35 @@ def test_nms_bit_exact():
     offs = labels.float() * (boxes.max() + 1)
     ref = orc.nms(torch.cat([boxes + offs[:, None], scores[:, None]], 1), 0.5)
     assert keep_g.cpu().tolist() == ref.tolist()
+
+
+@pytest.mark.parametrize('layout', ['nchw', 'nhwc'])
+def test_dcn_pack_fused_offset_mask_logits(layout):
+    """ModulatedDeformConvPack hands conv_offset's output to the op as one tensor (mask logits ->
+    sigmoid inside the kernels).  Must equal the explicit chunk / sigmoid composition of the
+    reference (deform_conv.py:527-534), forward and all gradients."""
+    from lsnet_amd import ops
+    dev = _dev()
+    torch.manual_seed(3)
+    pack = ops.ModulatedDeformConvPack(32, 48, 3, 1, 1).to(dev)
+    torch.nn.init.normal_(pack.conv_offset.weight, std=0.05)
+    torch.nn.init.normal_(pack.conv_offset.bias, std=0.5)
+    x = torch.randn(2, 32, 17, 23, device=dev)
+    if layout == 'nhwc':
+        pack = pack.to(memory_format=torch.channels_last)
+        x = x.contiguous(memory_format=torch.channels_last)
+    x.requires_grad_()
+    out = pack(x)
+    go = torch.randn_like(out)
+    g1 = torch.autograd.grad(out, [x] + list(pack.parameters()), go)
+    om = pack.conv_offset(x)
+    out2 = ops.modulated_deform_conv(x, om[:, :18], torch.sigmoid(om[:, 18:]), pack.weight, pack.bias, 1, 1, 1)
+    g2 = torch.autograd.grad(out2, [x] + list(pack.parameters()), go)
+    assert _err(out, out2.detach().cpu()) < 1e-6
+    for a, b in zip(g1, g2):
+        assert _err(a, b.detach().cpu()) < 1e-5
+    # and against the oracle
+    omc = om.detach().cpu()
+    ref = orc.deform_conv_forward(x.detach().cpu(), pack.weight.detach().cpu(), pack.bias.detach().cpu(),
+                                  omc[:, :18].contiguous(), torch.sigmoid(omc[:, 18:]).contiguous(), 1, 1, 1)
+    assert _err(out, ref) < TOL
