@@ -1,0 +1,246 @@
+#!/usr/bin/env python
+"""Throughput of the LSNet training hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one full training iteration of LSNet R-50-FPN (bbox task, conv_module_type='dcn') on
+one synthetic COCO-shaped batch of 2 images 3x800x1344 per GPU (BASELINE.json configs[1]):
+backbone + FPN + LSHead forward, target assignment (CentroidAssigner + ATSS), focal + cross-IOU
+losses, backward, RCCL gradient all-reduce (N > 1), clip-grad-norm 35 and the SGD update -- the same
+hooks a real run uses (lsnet_amd/runner).  Inputs are resident in HBM before the timed region.
+
+Prints ONE JSON line (rank 0):  value = total images / s over all N GPUs (weak scaling, 2 img/GPU).
+  roofline     : the dominant hand-written kernel family (fused gather + fp32-MFMA deformable
+                 convolution): algorithmic FLOPs of its launches / their HIP-event time, against the
+                 157.3 TFLOP/s fp32 MFMA peak (MI355X_MICROARCH.md).
+  cpu_baseline : the same training step on the host CPU (this repo's host code with the CPU oracle
+                 standing behind the native ops -- the reference has no CPU path for them), on a
+                 bounded sample, rank 0 at N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, 2.4 GHz x 256 CU
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--task', default='bbox')
+    ap.add_argument('--backbone', default='r50')
+    ap.add_argument('--height', type=int, default=800)
+    ap.add_argument('--width', type=int, default=1344)
+    ap.add_argument('--batch', type=int, default=2, help='images per GPU')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--nchw', action='store_true', help='run in contiguous NCHW memory format (slower)')
+    return ap.parse_args()
+
+
+class KernelTimer:
+    """Brackets every native deformable-conv call with HIP events recorded on the stream the
+    kernels are launched on (torch's current stream is the launch stream, hip_backend._stream)."""
+
+    def __init__(self, backend):
+        self.be, self.on = backend, False
+        self.rec = {'dcn_fwd': [], 'dcn_bwd': []}
+        self._fwd, self._bwd = backend.dcn_forward, backend.dcn_backward
+        backend.dcn_forward, backend.dcn_backward = self.fwd, self.bwd
+
+    @staticmethod
+    def _flops(inputs, weight, outs_hw):
+        co, cg, kh, kw = weight.shape
+        return sum(2.0 * x.shape[0] * h * w * co * cg * kh * kw for x, (h, w) in zip(inputs, outs_hw))
+
+    def fwd(self, inputs, offsets, masks, weight, bias, cfg, out_hw):
+        if not self.on:
+            return self._fwd(inputs, offsets, masks, weight, bias, cfg, out_hw)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        r = self._fwd(inputs, offsets, masks, weight, bias, cfg, out_hw)
+        e.record()
+        self.rec['dcn_fwd'].append((s, e, self._flops(inputs, weight, out_hw)))
+        return r
+
+    def bwd(self, inputs, offsets, masks, weight, grad_outs, cfg, need):
+        if not self.on:
+            return self._bwd(inputs, offsets, masks, weight, grad_outs, cfg, need)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        r = self._bwd(inputs, offsets, masks, weight, grad_outs, cfg, need)
+        e.record()
+        fl = 2.0 * self._flops(inputs, weight, [g.shape[2:] for g in grad_outs])
+        self.rec['dcn_bwd'].append((s, e, fl))
+        return r
+
+    def summary(self):
+        out = {}
+        for k, lst in self.rec.items():
+            if lst:
+                ms = sum(s.elapsed_time(e) for s, e, _ in lst)
+                fl = sum(f for _, _, f in lst)
+                out[k] = dict(launches=len(lst), avg_ms=ms / len(lst), tflops=fl / (ms * 1e-3) / 1e12,
+                              gflop_per_launch=fl / len(lst) / 1e9)
+        return out
+
+
+def build_step(model, cfg):
+    """One training iteration through the runner's own hooks (lr schedule, optimizer hook)."""
+    from lsnet_amd.runner import EpochBasedRunner, build_optimizer
+    opt = build_optimizer(model, cfg.optimizer)
+    runner = EpochBasedRunner(model, optimizer=opt, logger=lambda m: None)
+    runner.register_training_hooks(cfg.lr_config, cfg.optimizer_config, None, dict(interval=10 ** 9, hooks=[]))
+    runner.epoch_len = 10 ** 9
+    runner.call_hook('before_run')
+    runner.call_hook('before_train_epoch')
+
+    def step(data):
+        runner.call_hook('before_train_iter')
+        runner.outputs = model.train_step(data, opt)
+        runner.log_buffer_update(runner.outputs['log_vars'], runner.outputs['num_samples'])
+        runner.call_hook('after_train_iter')
+        runner.iter += 1
+        return runner.outputs
+
+    return step, runner
+
+
+def cpu_baseline(args):
+    """The training step on the host CPU: this repo's host code + the CPU oracle behind the native
+    ops (test infrastructure used as the timed baseline, never as the product path)."""
+    from lsnet_amd.data import synthetic_batch
+    from lsnet_amd.model_zoo import build_lsnet
+    from lsnet_amd.ops import register_backend, unregister_backend
+    from tests.oracle_backend import OracleBackend
+    from oracle import oracle_py
+    h, w, b = 416, 672, 1          # bounded sample: 1 image at ~1/4 of the 800x1344 area
+    cores = os.cpu_count() or 1
+    threads = min(cores, 64)
+    torch.set_num_threads(threads)
+    os.environ.setdefault('OMP_NUM_THREADS', str(threads))
+    register_backend('cpu', OracleBackend())
+    try:
+        torch.manual_seed(0)
+        model, cfg = build_lsnet(args.task, args.backbone)
+        model.train()
+        step, _ = build_step(model, cfg)
+        data = synthetic_batch(args.task, b, h, w, seed=99, device='cpu', channels_last=False)
+        t0 = time.time()
+        out = step(data)
+        loss = float(out['loss'])
+        dt = time.time() - t0
+    finally:
+        unregister_backend('cpu')
+    return dict(value=b / dt, unit='img/s', cores=threads, kind='port',
+                sample=f'1 training step (fwd+bwd+clip+SGD) of the same model on {b} image 3x{h}x{w} '
+                       f'({oracle_py.num_threads()} OpenMP threads in the oracle, {threads} torch threads, '
+                       f'{cores} host cores), {dt:.1f} s, loss {loss:.3f}')
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    assert torch.cuda.is_available(), 'bench.py measures the HIP path: a GPU is required'
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl')
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+
+    from lsnet_amd.data import synthetic_batch
+    from lsnet_amd.model_zoo import build_lsnet
+    from lsnet_amd.ops import get_backend
+    from lsnet_amd.parallel import DataParallelModel
+
+    torch.manual_seed(0)
+    model, cfg = build_lsnet(args.task, args.backbone)
+    model = model.to(dev)
+    if not args.nchw:
+        model = model.to(memory_format=torch.channels_last)
+    model.train()
+    if world > 1:
+        model = DataParallelModel(model)
+    step, runner = build_step(model, cfg)
+    data = synthetic_batch(args.task, args.batch, args.height, args.width, seed=1234 + rank, device=dev,
+                           channels_last=not args.nchw)
+    timer = None if args.no_kernel_timing else KernelTimer(get_backend(data['img']))
+
+    for _ in range(args.warmup):
+        step(data)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    if timer:
+        timer.on = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step(data)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if timer:
+        timer.on = False
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    losses = out['log_vars'].items_as_float() if hasattr(out['log_vars'], 'items_as_float') else {}
+
+    if rank == 0:
+        imgs = args.batch * world * args.steps
+        res = {
+            'metric': 'img/s train LSNet R-50-FPN 1333x800 bs2/GPU',
+            'value': imgs / dt, 'unit': 'img/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'LSNet {args.backbone.upper()}-FPN {args.task} (conv_module_type=dcn), '
+                                   f'{args.batch} img/GPU 3x{args.height}x{args.width} (1333x800 padded to /32), '
+                                   f'7 gt/img, fwd+bwd+RCCL grad all-reduce+clip35+SGD',
+                       'global_batch': args.batch * world, 'parallelism': f'dp{world}',
+                       'memory_format': 'nchw' if args.nchw else 'channels_last'},
+            'loss': {k: round(v, 5) for k, v in losses.items()},
+        }
+        if timer:
+            ks = timer.summary()
+            dom = max(ks, key=lambda k: ks[k]['avg_ms'] * ks[k]['launches']) if ks else None
+            res['kernels'] = ks
+            if 'dcn_fwd' in ks:
+                k = ks['dcn_fwd']
+                res['roofline'] = {'kernel': 'dcn_fwd_kernel<64,256,1,4> (fused bilinear gather + fp32 MFMA GEMM)',
+                                   'bound': 'mfma', 'achieved': k['tflops'], 'peak': FP32_MFMA_PEAK_TFLOPS,
+                                   'unit': 'TFLOP/s', 'frac': k['tflops'] / FP32_MFMA_PEAK_TFLOPS, 'traffic': None,
+                                   'launches_timed': k['launches'], 'avg_launch_ms': k['avg_ms'],
+                                   'gflop_per_launch': k['gflop_per_launch'], 'dominant_family': dom}
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                res['cpu_baseline'] = cpu_baseline(args)
+            except Exception as ex:   # the baseline must never take the bench line down
+                res['cpu_baseline'] = {'value': None, 'unit': 'img/s', 'cores': 0, 'kind': 'port',
+                                       'sample': f'failed: {type(ex).__name__}: {ex}'}
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

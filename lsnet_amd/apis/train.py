@@ -1,0 +1,26 @@
+"""`train_detector` (mmdet/apis/train.py:33-128): wrap the model for data-parallel training, build
+the optimizer and the runner, register the training hooks, run."""
+import torch
+
+from ..parallel import DataParallelModel
+from ..runner import EpochBasedRunner, build_optimizer
+
+
+def train_detector(model, data_loaders, cfg, distributed=False, validate=False, timestamp=None, meta=None,
+                   logger=None, channels_last=True):
+    data_loaders = data_loaders if isinstance(data_loaders, (list, tuple)) else [data_loaders]
+    if torch.cuda.is_available():
+        model = model.cuda()
+        if channels_last:
+            model = model.to(memory_format=torch.channels_last)
+    model = DataParallelModel(model) if distributed else model
+    optimizer = build_optimizer(model, cfg.optimizer)
+    runner = EpochBasedRunner(model, optimizer=optimizer, work_dir=cfg.get('work_dir'), logger=logger, meta=meta)
+    runner.register_training_hooks(cfg.lr_config, cfg.optimizer_config, cfg.get('checkpoint_config'),
+                                   cfg.get('log_config'))
+    if cfg.get('resume_from'):
+        runner.resume(cfg.resume_from)
+    elif cfg.get('load_from'):
+        runner.load_checkpoint(cfg.load_from)
+    runner.run(list(data_loaders), cfg.workflow, cfg.total_epochs)
+    return runner
