@@ -188,6 +188,11 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    markers = os.environ.get('LSNET_PROF_MARKERS') == '1'
+    if markers:   # a recognisable dispatch (lsn::selftest32_kernel) delimits the timed region in rocprof traces
+        mk = torch.ones(32, 32, device=dev)
+        get_backend(mk).selftest_mfma(mk, mk, 0)
+        torch.cuda.synchronize()
     if timer:
         timer.on = True
     t0 = time.perf_counter()
@@ -200,6 +205,9 @@ def main():
     dt = time.perf_counter() - t0
     if timer:
         timer.on = False
+    if markers:
+        get_backend(mk).selftest_mfma(mk, mk, 0)
+        torch.cuda.synchronize()
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -198,6 +198,11 @@ int lsn_nms(const float *dets, const int64_t *order, int n, float iou_thr, int64
             int64_t *num_keep, void *workspace, lsn_stream_t stream);
 
 /* ---- diagnostics ---------------------------------------------------------------------------- */
+/* When set to a device buffer of 512 int64 (NULL disables), thread 0 of workgroup `block` of the
+ * next DCN forward / backward-data launches appends (phase_id << 56 | shader_clock) stamps at its
+ * phase boundaries: a per-chunk cycle anatomy for tuning.  Not thread-safe; profiling only. */
+int lsn_debug_phase_clocks(long long *device_buf_512, int block);
+
 /* D = A(MxK) * B(KxN) through the same MFMA fragment code as the DCN kernels (self-test). */
 int lsn_selftest_mfma(const float *A, const float *B, float *D, int M, int N, int K, int variant,
                       lsn_stream_t stream);

@@ -43,7 +43,7 @@ EXPORTS = [
     'lsn_pyramid_deform_conv_backward_parameters',
     'lsn_sigmoid_focal_loss_forward', 'lsn_sigmoid_focal_loss_backward', 'lsn_sigmoid_focal_loss_sum',
     'lsn_sigmoid_focal_loss_backward_weighted',
-    'lsn_nms_workspace_bytes', 'lsn_nms', 'lsn_selftest_mfma',
+    'lsn_nms_workspace_bytes', 'lsn_nms', 'lsn_selftest_mfma', 'lsn_debug_phase_clocks',
 ]
 
 _lib = None

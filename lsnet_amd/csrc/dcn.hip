@@ -21,6 +21,10 @@ int fail(int code, const char *fmt, ...)
     return code;
 }
 
+// optional phase-clock capture (diagnostics only; see lsn_debug_phase_clocks)
+static long long *g_dbg_buf = nullptr;
+static int g_dbg_block = 0;
+
 // in[b][r][s] -> out[b][s][r]   (NCHW <-> NHWC with r = C, s = H*W; weight OIHW <-> OHWI with
 // b = Co, r = Cg, s = kh*kw).  32x32 tiles through LDS so both sides are coalesced.
 __global__ void permute_rs_kernel(const float *__restrict__ in, float *__restrict__ out, int R, int S)
@@ -149,28 +153,89 @@ static int fill_levels(DcnArgs &a, const lsn_dcn_shape &s, int n, const lsn_dcn_
     const int Cg = s.C / s.groups, cpdg = s.C / s.deformable_groups;
     a.SL = Cg < cpdg ? Cg : cpdg;
     a.msig = s.mask_is_logit ? 1 : 0;
+    a.dbg = g_dbg_buf;
+    a.dbg_block = g_dbg_block;
     a.w = a.bias = nullptr;
     a.gw = a.gb = nullptr;
     return 0;
 }
 
-static int launch_forward(const DcnArgs &a, hipStream_t st)
+// VEC kernels need 16-byte aligned float4 rows: channel counts that are multiples of 4
+static bool vec_ok(const DcnArgs &a)
+{
+    const int Cg = a.C / a.groups, Cog = a.Co / a.groups;
+    return (Cg % 4 == 0) && (Cog % 4 == 0) && (a.Co % 4 == 0) && (a.SL % 4 == 0);
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_forward_t(const DcnArgs &a, hipStream_t st)
 {
     const int Cog = a.Co / a.groups, KD = a.kh * a.kw * a.dg;
-    if (Cog > 64) {
-        constexpr int BM = 64, BN = 256;
-        const size_t lds = (size_t)(BM + BN) * 33 * 4 + (size_t)BM * KD * sizeof(Tap);
-        auto k = dcn_fwd_kernel<BM, BN, 1, 4>;
+    const size_t lds = (size_t)(BM + BN) * 33 * 4 + (size_t)BM * KD * sizeof(Tap);
+    dim3 grid(a.ntiles, cdiv(Cog, BN), a.groups);
+    if (vec_ok(a)) {
+        auto k = dcn_fwd_kernel<BM, BN, WM, WN, true>;
         if (int rc = set_lds(k, lds)) return rc;
-        dim3 grid(a.ntiles, cdiv(Cog, BN), a.groups);
         hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a);
     } else {
-        constexpr int BM = 64, BN = 64;
-        const size_t lds = (size_t)(BM + BN) * 33 * 4 + (size_t)BM * KD * sizeof(Tap);
-        auto k = dcn_fwd_kernel<BM, BN, 2, 2>;
+        auto k = dcn_fwd_kernel<BM, BN, WM, WN, false>;
         if (int rc = set_lds(k, lds)) return rc;
-        dim3 grid(a.ntiles, cdiv(Cog, BN), a.groups);
         hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a);
+    }
+    LSN_HIP(hipGetLastError());
+    return 0;
+}
+
+static size_t pipe_lds_bytes(const DcnArgs &a)
+{
+    return (size_t)2 * (PIPE_BM + PIPE_BN) * PIPE_LDK * 4 + (size_t)PIPE_BM * a.kh * a.kw * a.dg * sizeof(Tap);
+}
+
+// the pipelined kernel needs float4 rows and 32-bit byte offsets into x and w (buffer addressing)
+static bool pipe_ok(const DcnArgs &a)
+{
+    if (a.Co / a.groups <= 64 || !vec_ok(a) || pipe_lds_bytes(a) > 160 * 1024) return false;
+    if ((int64_t)a.Co * a.kh * a.kw * (a.C / a.groups) * 4 >= (int64_t)1 << 31) return false;
+    for (int i = 0; i < a.nlv; ++i)
+        if ((int64_t)a.lv[i].B * a.lv[i].H * a.lv[i].W * a.C * 4 >= (int64_t)1 << 31) return false;
+    return !((g_dbg_block >> 24) & 1);   // bit 24 of the debug word forces the two-workgroup variant (A/B runs)
+}
+
+static int launch_forward(const DcnArgs &a, hipStream_t st)
+{
+    if (a.Co / a.groups <= 64) return launch_forward_t<64, 64, 2, 2>(a, st);
+    if (!pipe_ok(a)) return launch_forward_t<64, 256, 1, 4>(a, st);
+    const size_t lds = pipe_lds_bytes(a);
+    dim3 grid(a.ntiles, cdiv(a.Co / a.groups, PIPE_BN), a.groups);
+    auto go = [&](auto kern) -> int {
+        if (int rc = set_lds(kern, lds)) return rc;
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
+        LSN_HIP(hipGetLastError());
+        return 0;
+    };
+    switch ((g_dbg_block >> 20) & 15) {   // diagnostic ablations (tools/phase_clocks.py); 0 in production
+    case 1: return go(dcn_fwd_pipe_kernel<1>);
+    case 2: return go(dcn_fwd_pipe_kernel<2>);
+    case 3: return go(dcn_fwd_pipe_kernel<3>);
+    case 6: return go(dcn_fwd_pipe_kernel<6>);
+    case 10: return go(dcn_fwd_pipe_kernel<10>);
+    default: return go(dcn_fwd_pipe_kernel<0>);
+    }
+}
+
+template <int RED>
+static int launch_bwd_data_t(const DcnArgs &a, hipStream_t st)
+{
+    const int KD = a.kh * a.kw * a.dg;
+    const size_t lds = (size_t)RED * 32 * 4 + (size_t)BWD_BM * KD * (sizeof(Tap) + 12);
+    if (vec_ok(a)) {
+        auto k = dcn_bwd_data_kernel<RED, true>;
+        if (int rc = set_lds(k, lds)) return rc;
+        hipLaunchKernelGGL(k, dim3(a.ntiles), dim3(256), lds, st, a);
+    } else {
+        auto k = dcn_bwd_data_kernel<RED, false>;
+        if (int rc = set_lds(k, lds)) return rc;
+        hipLaunchKernelGGL(k, dim3(a.ntiles), dim3(256), lds, st, a);
     }
     LSN_HIP(hipGetLastError());
     return 0;
@@ -178,22 +243,7 @@ static int launch_forward(const DcnArgs &a, hipStream_t st)
 
 static int launch_bwd_data(const DcnArgs &a, hipStream_t st)
 {
-    const int Cog = a.Co / a.groups, KD = a.kh * a.kw * a.dg;
-    if (Cog > 64) {
-        constexpr int RED = 256;
-        const size_t lds = (size_t)RED * 32 * 4 + (size_t)BWD_BM * KD * (sizeof(Tap) + 12);
-        auto k = dcn_bwd_data_kernel<RED>;
-        if (int rc = set_lds(k, lds)) return rc;
-        hipLaunchKernelGGL(k, dim3(a.ntiles), dim3(256), lds, st, a);
-    } else {
-        constexpr int RED = 64;
-        const size_t lds = (size_t)RED * 32 * 4 + (size_t)BWD_BM * KD * (sizeof(Tap) + 12);
-        auto k = dcn_bwd_data_kernel<RED>;
-        if (int rc = set_lds(k, lds)) return rc;
-        hipLaunchKernelGGL(k, dim3(a.ntiles), dim3(256), lds, st, a);
-    }
-    LSN_HIP(hipGetLastError());
-    return 0;
+    return (a.Co / a.groups > 64) ? launch_bwd_data_t<256>(a, st) : launch_bwd_data_t<64>(a, st);
 }
 
 static int launch_wgrad(const DcnArgs &a, int nsteps, hipStream_t st)
@@ -208,7 +258,10 @@ static int launch_wgrad(const DcnArgs &a, int nsteps, hipStream_t st)
     const size_t lds = (size_t)WG_BP * (WG_BM + WG_BN) * 4 + 2 * WG_BP * sizeof(Tap);
     LSN_HIP(hipMemsetAsync(a.gw, 0, sizeof(float) * (size_t)a.Co * K * Cg, st));
     if (a.gb) LSN_HIP(hipMemsetAsync(a.gb, 0, sizeof(float) * (size_t)a.Co, st));
-    hipLaunchKernelGGL(dcn_wgrad_kernel, dim3(ncol, splits, nz), dim3(256), lds, st, a, nsteps);
+    if (vec_ok(a))
+        hipLaunchKernelGGL(dcn_wgrad_kernel<true>, dim3(ncol, splits, nz), dim3(256), lds, st, a, nsteps);
+    else
+        hipLaunchKernelGGL(dcn_wgrad_kernel<false>, dim3(ncol, splits, nz), dim3(256), lds, st, a, nsteps);
     LSN_HIP(hipGetLastError());
     return 0;
 }
@@ -387,6 +440,13 @@ using namespace lsn;
 extern "C" {
 
 const char *lsn_last_error(void) { return lsn::err_buf(); }
+
+int lsn_debug_phase_clocks(long long *device_buf_512, int block)
+{
+    lsn::g_dbg_buf = device_buf_512;
+    lsn::g_dbg_block = block;
+    return 0;
+}
 int lsn_version(void) { return 100; }
 
 int lsn_dcn_forward(const lsn_dcn_shape *shape, int n_levels, const lsn_dcn_level *levels, const float *weight,

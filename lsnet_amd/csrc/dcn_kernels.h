@@ -42,6 +42,8 @@ struct DcnArgs {
     int C, Co, kh, kw, stride, pad, dil, groups, dg;
     int SL;   // channel segment length = min(C/groups, C/dg): constant (g, dgi) inside a segment
     int msig; // mask tensor holds logits: apply sigmoid on read, chain it into grad_mask
+    long long *dbg;  // optional phase timestamps of block `dbg_block`, wave 0 (lsn_debug_phase_clocks)
+    int dbg_block;
 };
 
 // One sampling position: the four clamped NHWC element offsets of its bilinear corners (channel 0),
@@ -51,6 +53,14 @@ struct __align__(16) Tap {
     float ly, lx, m;
     int flags;
 };
+
+// phase stamp: thread 0 of the chosen block appends the shader clock (s_memtime) to a.dbg
+#define LSN_STAMP(slot)                                                                  \
+    do {                                                                                 \
+        if (a.dbg != nullptr && blockIdx.x == (unsigned)(a.dbg_block & 0xfffff) && threadIdx.x == 0 && \
+            dbg_n < 512)                                                                 \
+            a.dbg[dbg_n++] = ((long long)(slot) << 56) | (clock64() & 0x00ffffffffffffffll); \
+    } while (0)
 
 __device__ __forceinline__ const Lvl &find_level(const DcnArgs &a, int tile)
 {
@@ -111,6 +121,36 @@ __device__ __forceinline__ void corner_weights(const Tap &t, float &b00, float &
     b11 = (t.flags & 8) ? t.ly * t.lx : 0.f;
 }
 
+
+// Branch-free guarded load of 4 consecutive floats p[0..3] of which the first `rem` (may be <= 0)
+// are valid.  hipcc turns `if (cond) v = *ptr` into a branch with a full vmcnt(0) wait per load
+// (cdna_hip_programming.md section 5, trap (c)), which serialises a staging phase into dependent L2
+// round trips; here every lane always loads from a clamped, valid address and the result is
+// selected afterwards.  VEC: the row is 16-byte aligned and rem is a multiple of 4.
+template <bool VEC>
+__device__ __forceinline__ float4 load4_guarded(const float *row, int off, int rem, bool row_ok)
+{
+    float4 v;
+    if (VEC) {
+        const bool ok = row_ok && rem > 0;
+        v = *reinterpret_cast<const float4 *>(row + (ok ? off : 0));
+        if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+        const int base = (row_ok && rem > 0) ? off : 0;
+        const int n = (row_ok && rem > 0) ? rem : 1;   // n >= 1 valid elements from base
+        const float a = row[base];
+        const float b = row[base + (n > 1 ? 1 : 0)];
+        const float c = row[base + (n > 2 ? 2 : 0)];
+        const float d = row[base + (n > 3 ? 3 : 0)];
+        const bool ok = row_ok && rem > 0;
+        v.x = ok ? a : 0.f;
+        v.y = (ok && rem > 1) ? b : 0.f;
+        v.z = (ok && rem > 2) ? c : 0.f;
+        v.w = (ok && rem > 3) ? d : 0.f;
+    }
+    return v;
+}
+
 // chunk index -> (tap k, channel offset inside the conv group, #valid channels, deformable group)
 struct Chunk {
     int k, c0, nval, dgi;
@@ -118,7 +158,9 @@ struct Chunk {
 template <int CK>
 __device__ __forceinline__ Chunk decode_chunk(const DcnArgs &a, int g, int t, int segs, int ncc)
 {
-    // order: tap-major, then segment, then CK-channel sub-chunk
+    // order: tap-major, then segment, then CK-channel sub-chunk: all chunks of one (tap, deformable
+    // group) are consecutive, so a thread keeps its sampling offsets / weights in registers across them
+    // (measured: the channel-major order bought no L1 reuse)
     Chunk c;
     c.k = t / (segs * ncc);
     const int r = t - c.k * segs * ncc;
@@ -130,6 +172,40 @@ __device__ __forceinline__ Chunk decode_chunk(const DcnArgs &a, int g, int t, in
     return c;
 }
 
+// Walks the chunk sequence of decode_chunk without integer divisions (a division by a runtime value
+// costs ~40 instructions; two decodes per chunk were ~20% of the pipelined kernel's chunk time).
+// `next()` saturates at the last chunk.
+template <int CK>
+struct ChunkIter {
+    int k, seg, cc, t, T, segs, ncc, SL, base_c, cpdg;
+    __device__ __forceinline__ ChunkIter(const DcnArgs &a, int g, int segs_, int ncc_, int T_)
+        : k(0), seg(0), cc(0), t(0), T(T_), segs(segs_), ncc(ncc_), SL(a.SL), base_c(g * (a.C / a.groups)),
+          cpdg(a.C / a.dg) {}
+    __device__ __forceinline__ Chunk get() const
+    {
+        // readfirstlane: the values are wave-uniform by construction; saying so keeps them in SGPRs (without
+        // it hipcc wrapped the weight buffer loads in waterfall loops)
+        Chunk c;
+        c.k = __builtin_amdgcn_readfirstlane(k);
+        c.c0 = __builtin_amdgcn_readfirstlane(seg * SL + cc * CK);
+        c.nval = __builtin_amdgcn_readfirstlane(min(CK, SL - cc * CK));
+        c.dgi = __builtin_amdgcn_readfirstlane((base_c + seg * SL) / cpdg);
+        return c;
+    }
+    __device__ __forceinline__ void next()
+    {
+        if (t + 1 >= T) return;
+        ++t;
+        if (++cc == ncc) {
+            cc = 0;
+            if (++seg == segs) {
+                seg = 0;
+                ++k;
+            }
+        }
+    }
+};
+
 // =============================================================================================
 // Forward:  block = BM output pixels x BN output channels of one conv group; 4 waves (WM x WN),
 // each owning TM x TN accumulator tiles of 32x32 (v_mfma_f32_32x32x2_f32).
@@ -137,7 +213,7 @@ __device__ __forceinline__ Chunk decode_chunk(const DcnArgs &a, int g, int t, in
 //         Bs[BN][33]  weight chunk (co rows, k contiguous);  stride 33 -> conflict-free both ways
 //         tab[BM][K*dg] sampling table built once per block
 // =============================================================================================
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool VEC>
 __global__ __launch_bounds__(256, 2) void dcn_fwd_kernel(const DcnArgs a)
 {
     constexpr int BK = 32, LDK = BK + 1;
@@ -174,7 +250,6 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_kernel(const DcnArgs a)
     constexpr int NPA = BM / 8;
     const int wq = tid & 7, wrow = tid >> 3;   // weights: float4 slot along k, co row (32 rows per pass)
     constexpr int NPB = BN / 32;
-    const bool vec4 = (Cg & 3) == 0;
     float xv[NPA][4];
     float4 wv[NPB];
 
@@ -186,9 +261,14 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_kernel(const DcnArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    const bool abl_no_x = (a.dbg_block >> 21) & 1, abl_no_w = (a.dbg_block >> 20) & 1;  // tuning ablations
     auto load_chunk = [&](int t) {
         const Chunk ch = decode_chunk<BK>(a, g, t, segs, ncc);
         const int c = g * Cg + ch.c0 + (kk < ch.nval ? kk : 0);
+        if (abl_no_x) {
+#pragma unroll
+            for (int ps = 0; ps < NPA; ++ps) xv[ps][0] = xv[ps][1] = xv[ps][2] = xv[ps][3] = 1.f;
+        } else
 #pragma unroll
         for (int ps = 0; ps < NPA; ++ps) {
             const Tap *tp = &tab[(ps * 8 + prow) * KD + ch.dgi * K + ch.k];
@@ -198,23 +278,17 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_kernel(const DcnArgs a)
             xv[ps][2] = L.x[idx.z + c];
             xv[ps][3] = L.x[idx.w + c];
         }
+        const float *wbase = a.w + (size_t)co_base * Kdim + ch.k * Cg + ch.c0;
+        const int rem = ch.nval - wq * 4;
+        if (abl_no_w) {
+#pragma unroll
+            for (int ps = 0; ps < NPB; ++ps) wv[ps] = make_float4(1.f, 1.f, 1.f, 1.f);
+        } else
 #pragma unroll
         for (int ps = 0; ps < NPB; ++ps) {
             const int col = ps * 32 + wrow;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int rem = ch.nval - wq * 4;
-            if (col < nco && rem > 0) {
-                const float *wp = a.w + (size_t)(co_base + col) * Kdim + ch.k * Cg + ch.c0 + wq * 4;
-                if (vec4 && rem >= 4) {
-                    v = *reinterpret_cast<const float4 *>(wp);
-                } else {
-                    v.x = wp[0];
-                    if (rem > 1) v.y = wp[1];
-                    if (rem > 2) v.z = wp[2];
-                    if (rem > 3) v.w = wp[3];
-                }
-            }
-            wv[ps] = v;
+            const bool ok = col < nco;
+            wv[ps] = load4_guarded<VEC>(wbase + (size_t)(ok ? col : 0) * Kdim, wq * 4, rem, ok);
         }
     };
 
@@ -240,12 +314,24 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_kernel(const DcnArgs a)
         }
     };
 
+    int dbg_n = 0;
+    LSN_STAMP(0);
     __syncthreads();  // sampling table complete
+    LSN_STAMP(1);
     load_chunk(0);
     for (int t = 0; t < T; ++t) {
+        LSN_STAMP(2);
+        // staging (VALU / LDS / VMEM issue) gets issue priority over the co-resident block's MFMA
+        // phase: measured on MI355X, a wave in a back-to-back MFMA stream otherwise starves its SIMD
+        // partner's staging (store phase 2.3k -> 5.7k cycles), serialising the two blocks of a CU
+        __builtin_amdgcn_s_setprio(2);
         store_chunk(t);
+        LSN_STAMP(3);
         __syncthreads();
+        LSN_STAMP(4);
         if (t + 1 < T) load_chunk(t + 1);  // in flight during the MFMA phase below
+        __builtin_amdgcn_s_setprio(0);
+        LSN_STAMP(5);
         const float *ap = As + (wm * TM * 32 + (lane & 31)) * LDK + (lane >> 5);
         const float *bp = Bs + (wn * TN * 32 + (lane & 31)) * LDK + (lane >> 5);
 #pragma unroll
@@ -260,7 +346,9 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_kernel(const DcnArgs a)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(af[i], bf[j], acc[i][j]);
         }
+        LSN_STAMP(6);
         __syncthreads();
+        LSN_STAMP(7);
     }
 
     // epilogue: D rows = pixels, D cols = output channels (32 consecutive floats per half-wave)
@@ -280,6 +368,275 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_kernel(const DcnArgs a)
 }
 
 // =============================================================================================
+// Forward, software-pipelined kernel for wide layers (Co/groups > 64, channel counts % 4 == 0).
+//
+// What the measurements on MI355X said (tools/phase_clocks.py, tools/ablate_fwd.py):
+//   * the two-workgroups-per-CU kernel above is NOT memory bound (removing every global load only takes
+//     it from 0.80 to 0.63 ms): its staging phases are instruction/latency bound, and
+//   * they do not overlap the partner workgroup's MFMA phase -- a wave issuing back-to-back fp32 MFMAs
+//     starves its SIMD partner's VALU/LDS issue (staging 2.3k -> 5.7k cycles, s_setprio does not help).
+// A wave's OWN independent instructions do issue in the 64-cycle shadow of its MFMAs.  So: ONE
+// workgroup per CU (one wave per SIMD), double-buffered LDS, and every wave interleaves per k-step
+//     4 MFMAs of chunk t | 1/16 of the staging of chunk t+1 | 1/16 of the loads of chunk t+2
+// with one barrier per chunk; and the staging stream is cut to ~110 instructions per chunk:
+//   * sampling offsets / corner weights of the thread's 8 pixels live in REGISTERS for all chunks of a
+//     tap (no LDS table reads, no address arithmetic in the loop);
+//   * gathers and weight rows are raw buffer loads (32-bit per-lane offset + scalar chunk offset,
+//     hardware bounds check returns 0 for out-of-range rows);
+//   * LDS rows are 36 floats (16-byte aligned): weight rows are written with ds_write_b128, and MFMA
+//     operands are fetched with ds_read_b128 by assigning k = 16*h + s to k-step s of lane-half h
+//     (each lane reads 16 contiguous floats of its row per chunk) -- conflict-free (36*i mod 64 is a
+//     distinct multiple of 4 for the 16 lanes of a b128 group).
+// =============================================================================================
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float buf_load_f32(__amdgpu_buffer_rsrc_t rs, int voff, int soff)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+}
+__device__ __forceinline__ float4 buf_load_f32x4(__amdgpu_buffer_rsrc_t rs, int voff, int soff)
+{
+    // NB: assigning the builtin's result to a 4 x u32 ext-vector and indexing it makes hipcc (ROCm 7.2)
+    // emit buffer_load_dword + splat; copying the 16 bytes out keeps the dwordx4 load.
+    auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+    static_assert(sizeof(v) == 16, "b128");
+    float4 f;
+    __builtin_memcpy(&f, &v, 16);
+    return f;
+}
+
+constexpr int PIPE_BM = 64, PIPE_BN = 256, PIPE_BK = 32, PIPE_LDK = 36;
+
+// ABL (diagnostic builds of the same kernel): bit 0 drops the LDS commits, bit 1 the global-load issues
+template <int ABL>
+__global__ __launch_bounds__(256, 1) void dcn_fwd_pipe_kernel(const DcnArgs a)
+{
+    constexpr int BM = PIPE_BM, BN = PIPE_BN, BK = PIPE_BK, LDK = PIPE_LDK;
+    constexpr int NPA = BM / 8, NPB = BN / 32;   // 8 gather passes, 8 weight passes per thread
+    static_assert(NPA == 8 && NPB == 8, "one pass of each kind per pair of k-steps");
+    extern __shared__ __align__(16) unsigned char smem[];
+    float *As0 = reinterpret_cast<float *>(smem);          // [2][BM][LDK]
+    float *Bs0 = As0 + 2 * BM * LDK;                        // [2][BN][LDK]
+    Tap *tab = reinterpret_cast<Tap *>(Bs0 + 2 * BN * LDK);  // [BM][K*dg]
+
+    const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+    const int K = a.kh * a.kw, KD = K * a.dg;
+    const int Cg = a.C / a.groups, Cog = a.Co / a.groups, Kdim = K * Cg;
+
+    const Lvl &L = find_level(a, blockIdx.x);
+    const int tile_p = (blockIdx.x - L.tile0) * BM;
+    const int g = blockIdx.z;
+    const int co_blk = blockIdx.y * BN;
+    const int nco = min(BN, Cog - co_blk);
+    const int co_base = g * Cog + co_blk;
+
+    for (int e = tid; e < BM * KD; e += 256) {
+        const int pl = e / KD, r = e - pl * KD;
+        const int dgi = r / K, k = r - dgi * K;
+        tab[e] = make_tap(a, L, tile_p + pl, k, dgi);
+    }
+    const int segs = Cg / a.SL, ncc = (a.SL + BK - 1) / BK;
+    const int T = K * segs * ncc;
+    const int kk = tid & 31, prow = tid >> 5;   // gather: channel lane, pixel row
+    const int wq = tid & 7, wrow = tid >> 3;    // weights: float4 slot along k, co row
+
+    const __amdgpu_buffer_rsrc_t xrs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(L.x), 0, L.B * L.H * L.W * a.C * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.w), 0, a.Co * Kdim * 4, 0x00020000);
+
+    int wvoff[NPB];   // byte offset of this thread's float4 inside weight row (co_base + col); OOB if col >= nco
+#pragma unroll
+    for (int ps = 0; ps < NPB; ++ps) {
+        const int col = ps * 32 + wrow;
+        wvoff[ps] = (col < nco) ? ((co_base + col) * Kdim + wq * 4) * 4 : 0x7ffffff0;
+    }
+
+    // per-tap registers: byte offsets of the 4 bilinear corners (issue side) and their weights, already
+    // multiplied by the modulation scalar and zeroed for invalid corners (commit side)
+    int voffI[NPA][4];
+    float wgtC[NPA][4];
+    auto load_offsets = [&](const Chunk &ch) {
+#pragma unroll
+        for (int ps = 0; ps < NPA; ++ps) {
+            const int4 idx = *reinterpret_cast<const int4 *>(&tab[(ps * 8 + prow) * KD + ch.dgi * K + ch.k]);
+            voffI[ps][0] = (idx.x + kk) * 4;
+            voffI[ps][1] = (idx.y + kk) * 4;
+            voffI[ps][2] = (idx.z + kk) * 4;
+            voffI[ps][3] = (idx.w + kk) * 4;
+        }
+    };
+    auto load_weights = [&](const Chunk &ch) {
+#pragma unroll
+        for (int ps = 0; ps < NPA; ++ps) {
+            const Tap tp = tab[(ps * 8 + prow) * KD + ch.dgi * K + ch.k];
+            float b00, b01, b10, b11;
+            corner_weights(tp, b00, b01, b10, b11);
+            wgtC[ps][0] = b00 * tp.m;
+            wgtC[ps][1] = b01 * tp.m;
+            wgtC[ps][2] = b10 * tp.m;
+            wgtC[ps][3] = b11 * tp.m;
+        }
+    };
+
+    float xv[NPA][4];
+    float4 wv[NPB];
+    auto issue_x = [&](const Chunk &ch, int ps) {
+        const int soff = (g * Cg + ch.c0) * 4;
+        xv[ps][0] = buf_load_f32(xrs, voffI[ps][0], soff);
+        xv[ps][1] = buf_load_f32(xrs, voffI[ps][1], soff);
+        xv[ps][2] = buf_load_f32(xrs, voffI[ps][2], soff);
+        xv[ps][3] = buf_load_f32(xrs, voffI[ps][3], soff);
+    };
+    auto issue_w = [&](const Chunk &ch, int ps) { wv[ps] = buf_load_f32x4(wrs, wvoff[ps], (ch.k * Cg + ch.c0) * 4); };
+    auto commit_x = [&](const Chunk &ch, int ps, float *Asb) {
+        if (ABL & 8) {   // diagnostic: LDS write only
+            Asb[(ps * 8 + prow) * LDK + kk] = xv[ps][0];
+            return;
+        }
+        const float v = wgtC[ps][0] * xv[ps][0] + wgtC[ps][1] * xv[ps][1] + wgtC[ps][2] * xv[ps][2] +
+                        wgtC[ps][3] * xv[ps][3];
+        const float r = (kk < ch.nval) ? v : 0.f;
+        if (ABL & 4)     // diagnostic: VALU only
+            asm volatile("" ::"v"(r));
+        else
+            Asb[(ps * 8 + prow) * LDK + kk] = r;
+    };
+    auto commit_w = [&](const Chunk &ch, int ps, float *Bsb) {
+        if (ABL & 8) {
+            *reinterpret_cast<float4 *>(Bsb + (ps * 32 + wrow) * LDK + wq * 4) = wv[ps];
+            return;
+        }
+        const float4 v = (wq * 4 < ch.nval) ? wv[ps] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ABL & 4)
+            asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+        else
+            *reinterpret_cast<float4 *>(Bsb + (ps * 32 + wrow) * LDK + wq * 4) = v;
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    __syncthreads();  // sampling table complete
+    // ---- prologue: chunk 0 -> buffer 0, loads of chunk 1 in flight ----
+    ChunkIter<BK> it1(a, g, segs, ncc, T), it2(a, g, segs, ncc, T);   // chunk t+1 / chunk t+2 walkers
+    Chunk cI = it1.get();   // chunk whose offsets are in voffI
+    Chunk cC = cI;          // chunk whose weights are in wgtC
+    load_offsets(cI);
+    load_weights(cC);
+    {
+#pragma unroll
+        for (int ps = 0; ps < NPA; ++ps) issue_x(cI, ps);
+#pragma unroll
+        for (int ps = 0; ps < NPB; ++ps) issue_w(cI, ps);
+#pragma unroll
+        for (int ps = 0; ps < NPA; ++ps) commit_x(cC, ps, As0);
+#pragma unroll
+        for (int ps = 0; ps < NPB; ++ps) commit_w(cC, ps, Bs0);
+        it1.next();                 // -> chunk 1
+        it2.next();
+        it2.next();                 // -> chunk 2
+        const Chunk c1 = it1.get();
+        if (c1.k != cI.k || c1.dgi != cI.dgi) load_offsets(c1);
+        cI = c1;
+#pragma unroll
+        for (int ps = 0; ps < NPA; ++ps) issue_x(c1, ps);
+#pragma unroll
+        for (int ps = 0; ps < NPB; ++ps) issue_w(c1, ps);
+    }
+    __syncthreads();
+
+    int dbg_n = 0;
+    for (int t = 0; t < T; ++t) {
+        LSN_STAMP(2);
+        const int cur = t & 1;
+        const float *Asc = As0 + cur * BM * LDK, *Bsc = Bs0 + cur * BN * LDK;
+        float *Asn = As0 + (cur ^ 1) * BM * LDK, *Bsn = Bs0 + (cur ^ 1) * BN * LDK;
+        // chunk t+1 is committed, chunk t+2 is issued; indices clamp at the tail (the last iterations redo
+        // harmless staging work instead of branching inside the interleaved block)
+        const Chunk c1 = it1.get();
+        const Chunk c2 = it2.get();
+        it1.next();
+        it2.next();
+        if (c1.k != cC.k || c1.dgi != cC.dgi) load_weights(c1);   // once per (tap, deformable group)
+        cC = c1;
+        // note: the loads of chunk t+1 (issued with the OLD voffI) are already in flight, so the issue
+        // side may move on to the next tap now
+        if (c2.k != cI.k || c2.dgi != cI.dgi) load_offsets(c2);
+        cI = c2;
+
+        // MFMA operands: lane (i = lane & 31, h = lane >> 5) holds k = 16 h + s for k-step s
+        const float *ap = Asc + (lane & 31) * LDK + (lane >> 5) * 16;
+        const float *bp = Bsc + (wn * 64 + (lane & 31)) * LDK + (lane >> 5) * 16;
+        float4 A0[4], A1[4], B0[4], B1[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            A0[q] = *reinterpret_cast<const float4 *>(ap + 4 * q);
+            A1[q] = *reinterpret_cast<const float4 *>(ap + 32 * LDK + 4 * q);
+            B0[q] = *reinterpret_cast<const float4 *>(bp + 4 * q);
+            B1[q] = *reinterpret_cast<const float4 *>(bp + 32 * LDK + 4 * q);
+        }
+        if (a.dbg != nullptr) {
+            __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): diagnostic only
+            LSN_STAMP(5);
+        }
+#pragma unroll
+        for (int s = 0; s < BK / 2; ++s) {
+            const float a0 = reinterpret_cast<const float *>(&A0[s >> 2])[s & 3];
+            const float a1 = reinterpret_cast<const float *>(&A1[s >> 2])[s & 3];
+            const float b0 = reinterpret_cast<const float *>(&B0[s >> 2])[s & 3];
+            const float b1 = reinterpret_cast<const float *>(&B1[s >> 2])[s & 3];
+            // order pinned: MFMA, a slice of staging, MFMA, ... (a wave stalls at an MFMA until the pipe
+            // accepts it, so only what sits BETWEEN two MFMAs issues in their 64-cycle shadow)
+            const int ps = s >> 1;
+            acc[0][0] = mfma32(a0, b0, acc[0][0]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(ABL & 1)) {
+                if ((s & 1) == 0)
+                    commit_x(c1, ps, Asn);   // chunk t+1, loaded one iteration ago
+                else
+                    commit_w(c1, ps, Bsn);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][1] = mfma32(a0, b1, acc[0][1]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(ABL & 2)) {
+                if ((s & 1) == 0)
+                    issue_x(c2, ps);         // chunk t+2 into the registers just consumed
+                else
+                    issue_w(c2, ps);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[1][0] = mfma32(a1, b0, acc[1][0]);
+            acc[1][1] = mfma32(a1, b1, acc[1][1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        LSN_STAMP(6);
+        __syncthreads();  // everyone finished reading buf[cur] and writing buf[cur^1]
+        LSN_STAMP(7);
+    }
+
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = wn * 64 + j * 32 + (lane & 31);
+            if (col >= nco) continue;
+            const float bv = a.bias ? a.bias[co_base + col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int pix = tile_p + i * 32 + mfma32_row(r, lane);
+                if (pix < L.P) L.out[(size_t)pix * a.Co + co_base + col] = acc[i][j][r] + bv;
+            }
+        }
+}
+
+// =============================================================================================
 // Backward-data:  gcol[p][k,ci] = sum_co gout[p][co] * w[co][k,ci]   (never stored), then
 //   grad_input  += bilinear-weighted scatter of gcol*mask            (fp32 atomics, kernel.cu:913-970)
 //   grad_offset  = sum_ci gcol*mask * d(bilinear)/d(py,px)           (kernel.cu:973-1044)
@@ -291,7 +648,7 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_kernel(const DcnArgs a)
 // the 16 channel lanes per (tap, segment) and accumulated in LDS (rows are wave-private).
 // =============================================================================================
 constexpr int BWD_BM = 64;
-template <int RED>
+template <int RED, bool VEC>
 __global__ __launch_bounds__(256, 2) void dcn_bwd_data_kernel(const DcnArgs a)
 {
     constexpr int BK = 32, QR = RED / 4;  // QR reduction indices per lane quarter
@@ -322,8 +679,6 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_kernel(const DcnArgs a)
 
     const int wq = tid & 7, wrow = tid >> 3;  // weight staging: float4 slot along k, 32 rows/pass
     constexpr int NPB = RED / 32;
-    const bool vec4 = (Cg & 3) == 0;
-    const bool avec4 = (a.Co & 3) == 0 && (Cog & 3) == 0;
 
     const int my_pix = tile_p + wave * 16 + j16;  // A operand row (pixel) of this lane
 
@@ -334,21 +689,11 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_kernel(const DcnArgs a)
     // A operand: gout[pix][g*Cog + rb*RED + kq*QR + s], s = 0..QR-1 (this lane's k-quarter)
     auto load_a = [&](int g, int rb) {
         const int cb = rb * RED + kq * QR;
+        const bool pix_ok = my_pix < L.P;
+        const float *grow = L.gout + (size_t)(pix_ok ? my_pix : 0) * a.Co + g * Cog;
 #pragma unroll
         for (int s4 = 0; s4 < QR / 4; ++s4) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int rem = Cog - (cb + s4 * 4);
-            if (my_pix < L.P && rem > 0) {
-                const float *gp = L.gout + (size_t)my_pix * a.Co + g * Cog + cb + s4 * 4;
-                if (avec4 && rem >= 4) {
-                    v = *reinterpret_cast<const float4 *>(gp);
-                } else {
-                    v.x = gp[0];
-                    if (rem > 1) v.y = gp[1];
-                    if (rem > 2) v.z = gp[2];
-                    if (rem > 3) v.w = gp[3];
-                }
-            }
+            const float4 v = load4_guarded<VEC>(grow, cb + s4 * 4, Cog - (cb + s4 * 4), pix_ok);
             areg[s4 * 4 + 0] = v.x;
             areg[s4 * 4 + 1] = v.y;
             areg[s4 * 4 + 2] = v.z;
@@ -358,23 +703,13 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_kernel(const DcnArgs a)
     // weight slab of (chunk t, reduction block rb): rows = output channels, 32 k-columns
     auto load_w = [&](int g, int t, int rb) {
         const Chunk ch = decode_chunk<BK>(a, g, t, segs, ncc);
+        const float *wbase = a.w + (size_t)(g * Cog + rb * RED) * Kdim + ch.k * Cg + ch.c0;
+        const int rem = ch.nval - wq * 4;
 #pragma unroll
         for (int ps = 0; ps < NPB; ++ps) {
             const int row = ps * 32 + wrow;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int rem = ch.nval - wq * 4;
-            if (rb * RED + row < Cog && rem > 0) {
-                const float *wp = a.w + (size_t)(g * Cog + rb * RED + row) * Kdim + ch.k * Cg + ch.c0 + wq * 4;
-                if (vec4 && rem >= 4) {
-                    v = *reinterpret_cast<const float4 *>(wp);
-                } else {
-                    v.x = wp[0];
-                    if (rem > 1) v.y = wp[1];
-                    if (rem > 2) v.z = wp[2];
-                    if (rem > 3) v.w = wp[3];
-                }
-            }
-            wv[ps] = v;
+            const bool ok = rb * RED + row < Cog;
+            wv[ps] = load4_guarded<VEC>(wbase + (size_t)(ok ? row : 0) * Kdim, wq * 4, rem, ok);
         }
     };
     auto store_w = [&]() {
@@ -386,6 +721,7 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_kernel(const DcnArgs a)
         }
     };
 
+    int dbg_n = 0;
     for (int g = 0; g < a.groups; ++g) {
         if (nrb == 1) load_a(g, 0);
         load_w(g, 0, 0);
@@ -394,8 +730,11 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_kernel(const DcnArgs a)
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
             for (int rb = 0; rb < nrb; ++rb) {
                 if (nrb > 1) load_a(g, rb);  // Co/groups > RED: re-read the gout rows per slab
+                LSN_STAMP(2);
                 store_w();
+                LSN_STAMP(3);
                 __syncthreads();
+                LSN_STAMP(4);
                 if (rb + 1 < nrb)
                     load_w(g, t, rb + 1);
                 else if (t + 1 < T)
@@ -412,6 +751,7 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_kernel(const DcnArgs a)
                         acc1 = mfma16(areg[s], b1, acc1);
                     }
                 }
+                LSN_STAMP(5);
                 if (rb + 1 < nrb) __syncthreads();  // slab consumed; next slab may overwrite Bs
             }
 
@@ -475,7 +815,9 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_kernel(const DcnArgs a)
                     }
                 }
             }
+            LSN_STAMP(6);
             __syncthreads();  // Bs free for the next chunk
+            LSN_STAMP(7);
         }
     }
     __syncthreads();
@@ -515,6 +857,7 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_kernel(const DcnArgs a)
 // with fp32 atomics into gw (zero-filled by the launcher).
 // =============================================================================================
 constexpr int WG_BP = 32, WG_BN = 64, WG_BM = 256;
+template <bool VEC>
 __global__ __launch_bounds__(256, 2) void dcn_wgrad_kernel(const DcnArgs a, int nsteps)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -541,7 +884,6 @@ __global__ __launch_bounds__(256, 2) void dcn_wgrad_kernel(const DcnArgs a, int 
     const bool cval = kk < ch.nval;
     const int c = g * Cg + ch.c0 + (cval ? kk : 0);
     const int gq = tid & 63, grow = tid >> 6;  // gout: float4 slot along co, 4 rows per pass
-    const bool avec4 = (a.Co & 3) == 0 && (Cog & 3) == 0;
     const bool do_bias = (a.gb != nullptr) && ch.k == 0 && ch.c0 == 0;
 
     float xv[NPA][4];
@@ -574,23 +916,12 @@ __global__ __launch_bounds__(256, 2) void dcn_wgrad_kernel(const DcnArgs a, int 
             xv[ps][2] = L.x[idx.z + c];
             xv[ps][3] = L.x[idx.w + c];
         }
+        const int rem = nco - gq * 4;
 #pragma unroll
         for (int ps = 0; ps < NPA; ++ps) {
             const int pix = p0 + ps * 4 + grow;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int rem = nco - gq * 4;
-            if (pix < L.P && rem > 0) {
-                const float *gp = L.gout + (size_t)pix * a.Co + co_base + gq * 4;
-                if (avec4 && rem >= 4) {
-                    v = *reinterpret_cast<const float4 *>(gp);
-                } else {
-                    v.x = gp[0];
-                    if (rem > 1) v.y = gp[1];
-                    if (rem > 2) v.z = gp[2];
-                    if (rem > 3) v.w = gp[3];
-                }
-            }
-            gv[ps] = v;
+            const bool ok = pix < L.P;
+            gv[ps] = load4_guarded<VEC>(L.gout + (size_t)(ok ? pix : 0) * a.Co + co_base, gq * 4, rem, ok);
         }
     };
     auto store_step = [&](int buf) {

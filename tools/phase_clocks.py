@@ -1,0 +1,60 @@
+"""Per-chunk cycle anatomy of the DCN forward / backward-data kernels (lsn_debug_phase_clocks)."""
+import sys, os, ctypes
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from lsnet_amd import _lib
+from lsnet_amd.ops import get_backend
+
+dev = torch.device('cuda:0')
+cl = torch.channels_last
+LEVELS = [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)]
+B, C = 2, 256
+torch.manual_seed(0)
+be = get_backend(torch.zeros(1, device=dev))
+lib = _lib.load()
+w = (torch.randn(C, C, 3, 3, device=dev) * 0.02).contiguous(memory_format=cl)
+xs = [torch.randn(B, C, h, ww, device=dev).contiguous(memory_format=cl) for h, ww in LEVELS]
+offs = [(torch.randn(B, 18, h, ww, device=dev) * 0.5).contiguous(memory_format=cl) for h, ww in LEVELS]
+msks = [torch.rand(B, 9, h, ww, device=dev).contiguous(memory_format=cl) for h, ww in LEVELS]
+gos = [torch.randn(B, C, h, ww, device=dev).contiguous(memory_format=cl) for h, ww in LEVELS]
+cfg = dict(stride=1, pad=1, dil=1, groups=1, dg=1, scales=[(1.0, 1.0)] * 5, pyramid=False)
+need = dict(input=[True] * 5, offset=[True] * 5, mask=[True] * 5, weight=False, bias=False)
+NAMES = {0: 'start', 1: 'table+sync', 2: 'loop top', 3: 'store/stage done', 4: 'sync1 done', 5: 'loads issued / mfma done(bwd)',
+         6: 'mfma done / post done(bwd)', 7: 'sync2 done'}
+
+
+def run(fn, block, label, flags=0):
+    buf = torch.zeros(512, dtype=torch.int64, device=dev)
+    for _ in range(3):
+        fn()
+    lib.lsn_debug_phase_clocks(None, flags)
+    for _ in range(2):
+        fn()
+    lib.lsn_debug_phase_clocks(ctypes.c_void_p(buf.data_ptr()), block | flags)
+    fn()
+    torch.cuda.synchronize()
+    lib.lsn_debug_phase_clocks(None, 0)
+    v = buf.cpu().tolist()
+    st = [(x >> 56, x & ((1 << 56) - 1)) for x in v if x != 0]
+    print(f'--- {label}, block {block}: {len(st)} stamps')
+    # per-phase deltas, averaged over chunks 2.. (skip first)
+    from collections import defaultdict
+    acc = defaultdict(list)
+    for (p0, t0), (p1, t1) in zip(st[:-1], st[1:]):
+        acc[(p0, p1)].append(t1 - t0)
+    for k in sorted(acc):
+        d = acc[k]
+        d2 = d[2:] if len(d) > 4 else d
+        print(f'   {NAMES.get(k[0], k[0]):32s} -> {NAMES.get(k[1], k[1]):32s} n={len(d):3d} mean {sum(d2) / len(d2):9.0f} cyc  min {min(d2):7d} max {max(d2):7d}')
+    if len(st) > 2:
+        print(f'   total {st[-1][1] - st[0][1]} cycles for {len(st)} stamps')
+
+
+import sys
+if len(sys.argv) > 1 and sys.argv[1] == 'ablate':
+    for name, fl in (('full', 0), ('no issue', 2 << 20), ('no issue, commit VALU only', 6 << 20), ('no issue, commit LDS only', 10 << 20)):
+        run(lambda: be.dcn_forward(xs, offs, msks, w, None, cfg, LEVELS), 300, 'forward ' + name, fl)
+else:
+    for blk in (0, 300):
+        run(lambda: be.dcn_forward(xs, offs, msks, w, None, cfg, LEVELS), blk, 'forward')
+        run(lambda: be.dcn_backward(xs, offs, msks, w, gos, cfg, need), blk, 'backward-data')
