@@ -32,6 +32,10 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+# HBM traffic per launch (GB) from the committed PMC passes, profiles/r1c_pmc_hbm.txt: mean over the 8 launches
+# of a step of FETCH_SIZE (KB; doubled as MI355X_MICROARCH.md "HBM" prescribes for gfx950) + WRITE_SIZE (KB).
+# bwd_data's 2 GB of writes are its fp32 atomics reaching the memory side (36 atomic adds per input element).
+HBM_TRAFFIC_GB = {'dcn_fwd': 0.93, 'dcn_bwd_data': 3.06, 'dcn_wgrad': 1.08}
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, 2.4 GHz x 256 CU
 
 
@@ -51,50 +55,35 @@ def parse():
     return ap.parse_args()
 
 
+KERNEL_NOTES = {
+    'dcn_fwd': 'lsn::dcn_fwd_pipe_kernel (fused bilinear gather + MFMA implicit GEMM, forward)',
+    'dcn_bwd_data': 'lsn::dcn_bwd_data_kernel (gout x W^T on MFMA, fused bilinear scatter: grad input/offset/mask)',
+    'dcn_wgrad': 'lsn::dcn_wgrad_kernel (gathered columns^T x gout on MFMA: grad weight/bias)',
+}
+
+
 class KernelTimer:
-    """Brackets every native deformable-conv call with HIP events recorded on the stream the
-    kernels are launched on (torch's current stream is the launch stream, hip_backend._stream)."""
+    """Per-kernel launch durations from the library's own HIP-event log (lsn_prof_*): the events are
+    recorded on the stream each deformable-conv kernel is launched on, around that kernel alone."""
 
-    def __init__(self, backend):
-        self.be, self.on = backend, False
-        self.rec = {'dcn_fwd': [], 'dcn_bwd': []}
-        self._fwd, self._bwd = backend.dcn_forward, backend.dcn_backward
-        backend.dcn_forward, backend.dcn_backward = self.fwd, self.bwd
+    def __init__(self):
+        from lsnet_amd import _lib
+        self.lib = _lib
 
-    @staticmethod
-    def _flops(inputs, weight, outs_hw):
-        co, cg, kh, kw = weight.shape
-        return sum(2.0 * x.shape[0] * h * w * co * cg * kh * kw for x, (h, w) in zip(inputs, outs_hw))
+    def start(self):
+        self.lib.prof_enable(True)
 
-    def fwd(self, inputs, offsets, masks, weight, bias, cfg, out_hw):
-        if not self.on:
-            return self._fwd(inputs, offsets, masks, weight, bias, cfg, out_hw)
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-        r = self._fwd(inputs, offsets, masks, weight, bias, cfg, out_hw)
-        e.record()
-        self.rec['dcn_fwd'].append((s, e, self._flops(inputs, weight, out_hw)))
-        return r
-
-    def bwd(self, inputs, offsets, masks, weight, grad_outs, cfg, need):
-        if not self.on:
-            return self._bwd(inputs, offsets, masks, weight, grad_outs, cfg, need)
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-        r = self._bwd(inputs, offsets, masks, weight, grad_outs, cfg, need)
-        e.record()
-        fl = 2.0 * self._flops(inputs, weight, [g.shape[2:] for g in grad_outs])
-        self.rec['dcn_bwd'].append((s, e, fl))
-        return r
-
-    def summary(self):
+    def stop(self):
+        torch.cuda.synchronize()
+        rec = self.lib.prof_read()
+        self.lib.prof_enable(False)
         out = {}
-        for k, lst in self.rec.items():
-            if lst:
-                ms = sum(s.elapsed_time(e) for s, e, _ in lst)
-                fl = sum(f for _, _, f in lst)
-                out[k] = dict(launches=len(lst), avg_ms=ms / len(lst), tflops=fl / (ms * 1e-3) / 1e12,
-                              gflop_per_launch=fl / len(lst) / 1e9)
+        for k, r in rec.items():
+            if r['launches']:
+                sec = r['total_ms'] * 1e-3
+                out[k] = dict(launches=r['launches'], avg_ms=r['total_ms'] / r['launches'], total_ms=r['total_ms'],
+                              tflops=r['flops'] / sec / 1e12, gflop_per_launch=r['flops'] / r['launches'] / 1e9,
+                              alg_gbytes_per_launch=r['bytes'] / r['launches'] / 1e9, alg_gbps=r['bytes'] / sec / 1e9)
         return out
 
 
@@ -180,7 +169,7 @@ def main():
     step, runner = build_step(model, cfg)
     data = synthetic_batch(args.task, args.batch, args.height, args.width, seed=1234 + rank, device=dev,
                            channels_last=not args.nchw)
-    timer = None if args.no_kernel_timing else KernelTimer(get_backend(data['img']))
+    timer = None if args.no_kernel_timing else KernelTimer()
 
     for _ in range(args.warmup):
         step(data)
@@ -194,7 +183,7 @@ def main():
         get_backend(mk).selftest_mfma(mk, mk, 0)
         torch.cuda.synchronize()
     if timer:
-        timer.on = True
+        timer.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step(data)
@@ -203,8 +192,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if timer:
-        timer.on = False
+    ks = timer.stop() if timer else {}
     if markers:
         get_backend(mk).selftest_mfma(mk, mk, 0)
         torch.cuda.synchronize()
@@ -228,17 +216,18 @@ def main():
                        'memory_format': 'nchw' if args.nchw else 'channels_last'},
             'loss': {k: round(v, 5) for k, v in losses.items()},
         }
-        if timer:
-            ks = timer.summary()
-            dom = max(ks, key=lambda k: ks[k]['avg_ms'] * ks[k]['launches']) if ks else None
+        if ks:
+            dom = max(ks, key=lambda k: ks[k]['total_ms'])   # the kernel with the most GPU time in the timed steps
+            k = ks[dom]
             res['kernels'] = ks
-            if 'dcn_fwd' in ks:
-                k = ks['dcn_fwd']
-                res['roofline'] = {'kernel': 'dcn_fwd_kernel<64,256,1,4> (fused bilinear gather + fp32 MFMA GEMM)',
-                                   'bound': 'mfma', 'achieved': k['tflops'], 'peak': FP32_MFMA_PEAK_TFLOPS,
-                                   'unit': 'TFLOP/s', 'frac': k['tflops'] / FP32_MFMA_PEAK_TFLOPS, 'traffic': None,
-                                   'launches_timed': k['launches'], 'avg_launch_ms': k['avg_ms'],
-                                   'gflop_per_launch': k['gflop_per_launch'], 'dominant_family': dom}
+            res['roofline'] = {'kernel': KERNEL_NOTES.get(dom, dom), 'bound': 'mfma', 'achieved': k['tflops'],
+                               'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                               'frac': k['tflops'] / FP32_MFMA_PEAK_TFLOPS, 'traffic': HBM_TRAFFIC_GB.get(dom),
+                               'traffic_unit': 'GB/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/)',
+                               'launches_timed': k['launches'], 'avg_launch_ms': k['avg_ms'],
+                               'gflop_per_launch': k['gflop_per_launch'],
+                               'alg_gbytes_per_launch': k['alg_gbytes_per_launch'],
+                               'ms_per_step': k['total_ms'] / args.steps}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res['cpu_baseline'] = cpu_baseline(args)

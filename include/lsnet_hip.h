@@ -17,7 +17,7 @@
  *   - the caller owns all buffers (as in the reference, deform_conv.py:40-42,141-142,215-217).
  *     Outputs and gradient buffers are OVERWRITTEN (the reference's Python always passes
  *     zero-filled gradient tensors, deform_conv.py:75-76,86,157-161, so results are identical).
- *   - work is enqueued on `stream` and is asynchronous w.r.t. the host, except lsn_nms_host_count.
+ *   - work is enqueued on `stream` and is asynchronous w.r.t. the host, except lsn_nms.
  *   - float32 throughout; indices int64 where the reference uses int64.
  *   - one process per GPU; entry points are re-entrant across streams (no global mutable state
  *     except the thread-local error string and a per-device cached attribute query).
@@ -202,6 +202,22 @@ int lsn_nms(const float *dets, const int64_t *order, int n, float iou_thr, int64
  * next DCN forward / backward-data launches appends (phase_id << 56 | shader_clock) stamps at its
  * phase boundaries: a per-chunk cycle anatomy for tuning.  Not thread-safe; profiling only. */
 int lsn_debug_phase_clocks(long long *device_buf_512, int block);
+
+/* Per-kernel launch timing.  lsn_prof_enable(1) clears the log and makes every deformable-conv kernel
+ * launch record a HIP event pair on its launch stream; lsn_prof_read() waits for the recorded events
+ * and returns one entry per kernel family (dcn_fwd, dcn_bwd_data, dcn_wgrad) with the launch count,
+ * the summed kernel time and the summed ALGORITHMIC flops / bytes of those launches (flops: 2 x output
+ * pixels x Co x C/groups x kh x kw per launch; bytes: each operand read or written once).
+ * Returns the number of entries written (3) or a negative lsn error.  Not thread-safe. */
+typedef struct lsn_prof_entry {
+    char name[48];
+    long long launches;
+    double total_ms;
+    double flops;
+    double bytes;
+} lsn_prof_entry;
+int lsn_prof_enable(int on);
+int lsn_prof_read(lsn_prof_entry *out, int max_entries);
 
 /* D = A(MxK) * B(KxN) through the same MFMA fragment code as the DCN kernels (self-test). */
 int lsn_selftest_mfma(const float *A, const float *B, float *D, int M, int N, int K, int variant,

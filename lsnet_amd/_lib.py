@@ -34,6 +34,11 @@ class DcnLevel(ctypes.Structure):
                 ('Wo', ctypes.c_int), ('scale_h', ctypes.c_float), ('scale_w', ctypes.c_float)]
 
 
+class ProfEntry(ctypes.Structure):
+    _fields_ = [('name', ctypes.c_char * 48), ('launches', ctypes.c_longlong), ('total_ms', ctypes.c_double),
+                ('flops', ctypes.c_double), ('bytes', ctypes.c_double)]
+
+
 # every symbol include/lsnet_hip.h declares (checked by tests/test_capi.py without a GPU)
 EXPORTS = [
     'lsn_last_error', 'lsn_version', 'lsn_dcn_forward', 'lsn_dcn_backward',
@@ -44,6 +49,7 @@ EXPORTS = [
     'lsn_sigmoid_focal_loss_forward', 'lsn_sigmoid_focal_loss_backward', 'lsn_sigmoid_focal_loss_sum',
     'lsn_sigmoid_focal_loss_backward_weighted',
     'lsn_nms_workspace_bytes', 'lsn_nms', 'lsn_selftest_mfma', 'lsn_debug_phase_clocks',
+    'lsn_prof_enable', 'lsn_prof_read',
 ]
 
 _lib = None
@@ -73,3 +79,18 @@ def check(rc):
         if rc == -2:
             raise NotImplementedError(msg)
         raise RuntimeError(msg)
+
+
+def prof_enable(on):
+    """Start (and clear) / stop the library's per-kernel event log (lsn_prof_enable)."""
+    check(load().lsn_prof_enable(1 if on else 0))
+
+
+def prof_read():
+    """{family: dict(launches, total_ms, flops, bytes)} of the launches logged since prof_enable(True)."""
+    arr = (ProfEntry * 8)()
+    n = load().lsn_prof_read(arr, 8)
+    if n < 0:
+        check(n)
+    return {arr[i].name.decode(): dict(launches=int(arr[i].launches), total_ms=arr[i].total_ms,
+                                       flops=arr[i].flops, bytes=arr[i].bytes) for i in range(n)}

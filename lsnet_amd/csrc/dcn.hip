@@ -4,6 +4,8 @@
 #include <limits.h>
 #include <string.h>
 
+#include <cstring>
+#include <cstdio>
 #include <vector>
 
 #include "dcn_kernels.h"
@@ -24,6 +26,68 @@ int fail(int code, const char *fmt, ...)
 // optional phase-clock capture (diagnostics only; see lsn_debug_phase_clocks)
 static long long *g_dbg_buf = nullptr;
 static int g_dbg_block = 0;
+
+// ---- per-kernel launch timing (lsn_prof_*): HIP events recorded on the launch stream around each
+// deformable-conv kernel, so bench.py can quote a kernel's own average duration live.
+enum { PROF_FWD = 0, PROF_BWD_DATA = 1, PROF_WGRAD = 2, PROF_N = 3 };
+static const char *const kProfNames[PROF_N] = {"dcn_fwd", "dcn_bwd_data", "dcn_wgrad"};
+struct ProfRec {
+    hipEvent_t e0, e1;
+    int fam;
+    double flops, bytes;
+};
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+
+static double dcn_flops(const DcnArgs &a)
+{
+    double px = 0;
+    for (int i = 0; i < a.nlv; ++i) px += (double)a.lv[i].B * a.lv[i].Ho * a.lv[i].Wo;
+    return 2.0 * px * a.Co * (a.C / a.groups) * a.kh * a.kw;
+}
+
+// algorithmic HBM bytes of one launch: every operand read or written once
+static double dcn_bytes(const DcnArgs &a, int fam)
+{
+    const double K = (double)a.kh * a.kw;
+    double in = 0, out = 0, om = 0;
+    for (int i = 0; i < a.nlv; ++i) {
+        const double opx = (double)a.lv[i].B * a.lv[i].Ho * a.lv[i].Wo;
+        in += (double)a.lv[i].B * a.lv[i].H * a.lv[i].W * a.C;
+        out += opx * a.Co;
+        om += opx * a.dg * K * (a.lv[i].msk ? 3 : 2);
+    }
+    const double w = (double)a.Co * (a.C / a.groups) * K;
+    switch (fam) {
+    case PROF_FWD: return 4.0 * (in + om + w + out);
+    case PROF_BWD_DATA: return 4.0 * (in + om + w + out + in + om);   // + grad_input, grad_offset/mask
+    default: return 4.0 * (in + om + out + w);
+    }
+}
+
+struct ProfScope {
+    ProfRec r;
+    hipStream_t st;
+    bool on;
+    ProfScope(int fam, const DcnArgs &a, hipStream_t s) : st(s), on(g_prof_on)
+    {
+        if (!on) return;
+        r.fam = fam;
+        r.flops = dcn_flops(a);
+        r.bytes = dcn_bytes(a, fam);
+        if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) {
+            on = false;
+            return;
+        }
+        (void)hipEventRecord(r.e0, st);
+    }
+    ~ProfScope()
+    {
+        if (!on) return;
+        (void)hipEventRecord(r.e1, st);
+        g_prof.push_back(r);
+    }
+};
 
 // in[b][r][s] -> out[b][s][r]   (NCHW <-> NHWC with r = C, s = H*W; weight OIHW <-> OHWI with
 // b = Co, r = Cg, s = kh*kw).  32x32 tiles through LDS so both sides are coalesced.
@@ -203,8 +267,10 @@ static bool pipe_ok(const DcnArgs &a)
 
 static int launch_forward(const DcnArgs &a, hipStream_t st)
 {
-    if (a.Co / a.groups <= 64) return launch_forward_t<64, 64, 2, 2>(a, st);
-    if (!pipe_ok(a)) return launch_forward_t<64, 256, 1, 4>(a, st);
+    if (a.Co / a.groups <= 64 || !pipe_ok(a)) {
+        ProfScope prof(PROF_FWD, a, st);
+        return (a.Co / a.groups <= 64) ? launch_forward_t<64, 64, 2, 2>(a, st) : launch_forward_t<64, 256, 1, 4>(a, st);
+    }
     const size_t lds = pipe_lds_bytes(a);
     dim3 grid(a.ntiles, cdiv(a.Co / a.groups, PIPE_BN), a.groups);
     auto go = [&](auto kern) -> int {
@@ -213,6 +279,7 @@ static int launch_forward(const DcnArgs &a, hipStream_t st)
         LSN_HIP(hipGetLastError());
         return 0;
     };
+    ProfScope prof(PROF_FWD, a, st);
     switch ((g_dbg_block >> 20) & 15) {   // diagnostic ablations (tools/phase_clocks.py); 0 in production
     case 1: return go(dcn_fwd_pipe_kernel<1>);
     case 2: return go(dcn_fwd_pipe_kernel<2>);
@@ -243,6 +310,7 @@ static int launch_bwd_data_t(const DcnArgs &a, hipStream_t st)
 
 static int launch_bwd_data(const DcnArgs &a, hipStream_t st)
 {
+    ProfScope prof(PROF_BWD_DATA, a, st);
     return (a.Co / a.groups > 64) ? launch_bwd_data_t<256>(a, st) : launch_bwd_data_t<64>(a, st);
 }
 
@@ -258,6 +326,7 @@ static int launch_wgrad(const DcnArgs &a, int nsteps, hipStream_t st)
     const size_t lds = (size_t)WG_BP * (WG_BM + WG_BN) * 4 + 2 * WG_BP * sizeof(Tap);
     LSN_HIP(hipMemsetAsync(a.gw, 0, sizeof(float) * (size_t)a.Co * K * Cg, st));
     if (a.gb) LSN_HIP(hipMemsetAsync(a.gb, 0, sizeof(float) * (size_t)a.Co, st));
+    ProfScope prof(PROF_WGRAD, a, st);
     if (vec_ok(a))
         hipLaunchKernelGGL(dcn_wgrad_kernel<true>, dim3(ncol, splits, nz), dim3(256), lds, st, a, nsteps);
     else
@@ -448,6 +517,38 @@ int lsn_debug_phase_clocks(long long *device_buf_512, int block)
     return 0;
 }
 int lsn_version(void) { return 100; }
+
+int lsn_prof_enable(int on)
+{
+    for (auto &r : lsn::g_prof) {
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
+    }
+    lsn::g_prof.clear();
+    lsn::g_prof_on = on != 0;
+    return 0;
+}
+
+int lsn_prof_read(lsn_prof_entry *out, int max_entries)
+{
+    using namespace lsn;
+    LSN_CHECK(out != nullptr && max_entries >= PROF_N, "lsn_prof_read needs room for %d entries", PROF_N);
+    for (int f = 0; f < PROF_N; ++f) {
+        std::memset(&out[f], 0, sizeof(out[f]));
+        std::snprintf(out[f].name, sizeof(out[f].name), "%s", kProfNames[f]);
+    }
+    for (auto &r : g_prof) {
+        LSN_HIP(hipEventSynchronize(r.e1));
+        float ms = 0.f;
+        LSN_HIP(hipEventElapsedTime(&ms, r.e0, r.e1));
+        lsn_prof_entry &e = out[r.fam];
+        e.launches += 1;
+        e.total_ms += ms;
+        e.flops += r.flops;
+        e.bytes += r.bytes;
+    }
+    return PROF_N;
+}
 
 int lsn_dcn_forward(const lsn_dcn_shape *shape, int n_levels, const lsn_dcn_level *levels, const float *weight,
                     const float *bias, lsn_layout layout, lsn_stream_t stream)

@@ -105,3 +105,20 @@ def test_focal_against_python_formula():
     d = torch.randn(1000, 80)
     gr, = torch.autograd.grad(py_focal(x), x, d)
     assert (orc.sigmoid_focal_loss_backward(lg, tg, d, 2.0, 0.25) - gr).abs().max() < 1e-5
+
+
+def test_nms_against_reference_build():
+    """orc_nms vs the reference's own nms_cpu.cpp compiled into oracle/_ref (oracle/build_ref.py)."""
+    from oracle import build_ref
+    if build_ref.build() is None:
+        pytest.skip('no /root/reference and no prebuilt oracle/_ref/nms_ext.so')
+    ref = build_ref.load()
+    g = torch.Generator().manual_seed(11)
+    for n, thr in ((1, 0.5), (37, 0.3), (500, 0.5), (2000, 0.65)):
+        xy = torch.rand(n, 2, generator=g) * 200
+        wh = torch.rand(n, 2, generator=g) * 60 + 1
+        sc = torch.rand(n, 1, generator=g)
+        if n > 30:   # duplicated boxes (score ties are excluded: the reference orders them by an unstable sort)
+            xy[20:23], wh[20:23] = xy[20], wh[20]
+        dets = torch.cat([xy, xy + wh, sc], 1)
+        assert orc.nms(dets, thr).tolist() == ref.nms(dets, thr).tolist(), (n, thr)

@@ -1,0 +1,146 @@
+"""Runner / hooks (lr schedule, optimizer hook, checkpoints) and the data-parallel gradient reducer.
+
+The multi-process tests run world_size 2 over gloo on CPU: the reducer is backend-agnostic, on the GPU box
+the same code runs over RCCL (backend 'nccl')."""
+import os
+import socket
+import tempfile
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+from lsnet_amd.parallel import BucketedGradReducer, DataParallelModel
+from lsnet_amd.runner import EpochBasedRunner, build_optimizer
+
+
+class Toy(nn.Module):
+    """A model with the detector protocol: train_step(data, optimizer) -> dict(loss, log_vars, num_samples)."""
+
+    def __init__(self):
+        super().__init__()
+        self.a = nn.Linear(8, 16)
+        self.b = nn.Linear(16, 4)
+        self.unused = nn.Parameter(torch.zeros(3))     # never receives a gradient
+        self.frozen = nn.Parameter(torch.ones(2), requires_grad=False)
+
+    def forward(self, x):
+        return self.b(torch.relu(self.a(x)))
+
+    def train_step(self, data, optimizer):
+        loss = (self(data['x']) - data['y']).pow(2).mean()
+        return dict(loss=loss, log_vars=dict(loss=loss.detach()), num_samples=data['x'].shape[0])
+
+
+def _batches(n, seed):
+    g = torch.Generator().manual_seed(seed)
+    return [dict(x=torch.randn(4, 8, generator=g), y=torch.randn(4, 4, generator=g)) for _ in range(n)]
+
+
+def test_step_lr_warmup_and_steps():
+    m = Toy()
+    opt = build_optimizer(m, dict(type='SGD', lr=0.01, momentum=0.9, weight_decay=1e-4))
+    r = EpochBasedRunner(m, optimizer=opt, logger=lambda s: None)
+    r.register_training_hooks(dict(policy='step', warmup='linear', warmup_iters=10, warmup_ratio=0.001, step=[2, 3]),
+                              dict(grad_clip=dict(max_norm=35, norm_type=2)), None, dict(interval=1000, hooks=[]))
+    lrs = []
+
+    class Spy(type(r.hooks[0]).__mro__[1]):   # Hook
+        priority = 90
+
+        def before_train_iter(self, runner):
+            lrs.append(runner.optimizer.param_groups[0]['lr'])
+    r.register_hook(Spy())
+    r.run([_batches(6, 0)], [('train', 1)], 4)
+    # reference rule (mmcv lr_updater.py:153-181): during warm-up lr = regular * (1 - (1 - it/warmup_iters) * (1 - ratio))
+    for it in range(10):
+        k = (1 - it / 10) * (1 - 0.001)
+        assert lrs[it] == pytest.approx(0.01 * (1 - k), rel=1e-6), it
+    assert lrs[10] == pytest.approx(0.01) and lrs[11] == pytest.approx(0.01)
+    assert lrs[12] == pytest.approx(0.001) and lrs[17] == pytest.approx(0.001)      # epoch 2
+    assert lrs[18] == pytest.approx(0.0001)                                          # epoch 3
+    assert r.epoch == 4 and r.iter == 24
+
+
+def test_training_reduces_loss_and_checkpoint_resume():
+    torch.manual_seed(0)
+    with tempfile.TemporaryDirectory() as d:
+        m = Toy()
+        opt = build_optimizer(m, dict(type='SGD', lr=0.05, momentum=0.9))
+        r = EpochBasedRunner(m, optimizer=opt, work_dir=d, logger=lambda s: None)
+        r.register_training_hooks(dict(policy='step', step=[100]), dict(grad_clip=None), dict(interval=1),
+                                  dict(interval=1000, hooks=[]))
+        data = _batches(8, 1)
+        first = float(m.train_step(data[0], None)['loss'])
+        r.run([data], [('train', 1)], 3)
+        assert float(m.train_step(data[0], None)['loss']) < first
+        assert os.path.exists(os.path.join(d, 'epoch_3.pth')) and os.path.islink(os.path.join(d, 'latest.pth'))
+        m2 = Toy()
+        opt2 = build_optimizer(m2, dict(type='SGD', lr=0.05, momentum=0.9))
+        r2 = EpochBasedRunner(m2, optimizer=opt2, work_dir=d, logger=lambda s: None)
+        r2.resume(os.path.join(d, 'latest.pth'))
+        assert r2.epoch == 3 and r2.iter == 24
+        for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+            assert torch.equal(a, b), k
+        assert opt2.state_dict()['state'].keys() == opt.state_dict()['state'].keys()
+
+
+def test_reducer_is_a_noop_without_process_group():
+    m = Toy()
+    red = BucketedGradReducer(m.parameters())
+    m.train_step(_batches(1, 0)[0], None)['loss'].backward()
+    g = m.a.weight.grad.clone()
+    red.finish()
+    assert torch.equal(m.a.weight.grad, g)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir, bucket_mb):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.manual_seed(100 + rank)           # different initial weights per rank: broadcast must fix that
+        model = DataParallelModel(Toy(), bucket_mb=bucket_mb)
+        opt = build_optimizer(model, dict(type='SGD', lr=0.1, momentum=0.9))
+        r = EpochBasedRunner(model, optimizer=opt, logger=lambda s: None)
+        r.register_training_hooks(dict(policy='step', step=[100]), dict(grad_clip=dict(max_norm=35, norm_type=2)),
+                                  None, dict(interval=1000, hooks=[]))
+        r.run([_batches(5, 10 + rank)], [('train', 1)], 2)        # each rank sees its own shard
+        torch.save({k: v.clone() for k, v in model.module.state_dict().items()},
+                   os.path.join(out_dir, f'rank{rank}.pt'))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('bucket_mb', [64.0, 0.0002])   # one bucket / one bucket per few parameters
+def test_two_rank_data_parallel_equals_large_batch_sgd(bucket_mb):
+    world, port = 2, _free_port()
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(world, port, d, bucket_mb), nprocs=world, join=True)
+        sd = [torch.load(os.path.join(d, f'rank{r}.pt')) for r in range(world)]
+    for k in sd[0]:
+        assert torch.equal(sd[0][k], sd[1][k]), f'ranks diverged at {k}'
+    # single-process restatement: mean of the two per-rank gradients, same clip and SGD
+    torch.manual_seed(100)                       # rank 0's weights are broadcast to everyone
+    ref = Toy()
+    opt = torch.optim.SGD(ref.parameters(), lr=0.1, momentum=0.9)
+    shards = [_batches(5, 10), _batches(5, 11)]
+    for _ in range(2):
+        for i in range(5):
+            opt.zero_grad()
+            for s in shards:
+                (ref.train_step(s[i], None)['loss'] / world).backward()
+            torch.nn.utils.clip_grad_norm_([p for p in ref.parameters() if p.requires_grad and p.grad is not None], 35)
+            opt.step()
+    for k, v in ref.state_dict().items():
+        assert torch.allclose(sd[0][k], v, rtol=1e-5, atol=1e-6), k
+    assert torch.equal(sd[0]['unused'], torch.zeros(3))
