@@ -122,6 +122,24 @@ __device__ __forceinline__ void corner_weights(const Tap &t, float &b00, float &
 }
 
 
+// Sum over the 16 lanes of a DPP row (lanes 16q..16q+15) without touching the LDS: quad xor 1, quad xor 2,
+// half-row mirror, row mirror.  (__shfl_xor compiles to ds_bpermute_b32 + a wait per step: 84 of them per chunk
+// were the longest dependent chain of the backward-data epilogue.)
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v)
+{
+    const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true);
+    return v + __int_as_float(t);
+}
+__device__ __forceinline__ float row16_sum(float v)
+{
+    v = dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v);   // row_half_mirror
+    v = dpp_add<0x140>(v);   // row_mirror
+    return v;
+}
+
 // Branch-free guarded load of 4 consecutive floats p[0..3] of which the first `rem` (may be <= 0)
 // are valid.  hipcc turns `if (cond) v = *ptr` into a branch with a full vmcnt(0) wait per load
 // (cdna_hip_programming.md section 5, trap (c)), which serialises a staging phase into dependent L2
@@ -675,7 +693,9 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_kernel(const DcnArgs a)
     const int segs = Cg / a.SL, ncc = (a.SL + BK - 1) / BK;
     const int T = K * segs * ncc;
     const int nrb = (Cog + RED - 1) / RED;  // reduction blocks (1 for Co/groups <= RED)
-    const bool want_off = (L.goff != nullptr) || (L.gmsk != nullptr);
+    // bits 26..28 of the debug word: timing ablations (tools/phase_clocks.py bwd); results are wrong when set
+    const bool abl_no_atomic = (a.dbg_block >> 26) & 1, abl_no_xload = (a.dbg_block >> 28) & 1;
+    const bool want_off = ((L.goff != nullptr) || (L.gmsk != nullptr)) && !((a.dbg_block >> 27) & 1);
 
     const int wq = tid & 7, wrow = tid >> 3;  // weight staging: float4 slot along k, 32 rows/pass
     constexpr int NPB = RED / 32;
@@ -725,8 +745,13 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_kernel(const DcnArgs a)
     for (int g = 0; g < a.groups; ++g) {
         if (nrb == 1) load_a(g, 0);
         load_w(g, 0, 0);
+        // offset / mask gradient partial sums of this lane's 4 pixel rows, carried over the chunks of one
+        // (tap, deformable group) and reduced across the 16 channel lanes once, when the tap is finished
+        float sy[4] = {0.f, 0.f, 0.f, 0.f}, sx[4] = {0.f, 0.f, 0.f, 0.f}, sm[4] = {0.f, 0.f, 0.f, 0.f};
         for (int t = 0; t < T; ++t) {
             const Chunk ch = decode_chunk<BK>(a, g, t, segs, ncc);
+            const Chunk chn = decode_chunk<BK>(a, g, min(t + 1, T - 1), segs, ncc);
+            const bool tap_done = (t + 1 == T) || chn.k != ch.k || chn.dgi != ch.dgi;
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
             for (int rb = 0; rb < nrb; ++rb) {
                 if (nrb > 1) load_a(g, rb);  // Co/groups > RED: re-read the gout rows per slab
@@ -762,7 +787,10 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_kernel(const DcnArgs a)
                 const bool cval = cl < ch.nval;
                 const int c = g * Cg + ch.c0 + (cval ? cl : 0);
                 float xv[4][4];
-                if (want_off) {
+                if (want_off && abl_no_xload) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) xv[r][0] = xv[r][1] = xv[r][2] = xv[r][3] = 1.f;
+                } else if (want_off) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const Tap *tp = &tab[(wave * 16 + kq * 4 + r) * KD + ch.dgi * K + ch.k];
@@ -780,11 +808,14 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_kernel(const DcnArgs a)
                     float b00, b01, b10, b11;
                     corner_weights(tp, b00, b01, b10, b11);
                     const float gm = gval * tp.m;
-                    if (L.gx != nullptr && cval) {
-                        if (b00 != 0.f) atomic_add_f32(L.gx + tp.i00 + c, b00 * gm);
-                        if (b01 != 0.f) atomic_add_f32(L.gx + tp.i01 + c, b01 * gm);
-                        if (b10 != 0.f) atomic_add_f32(L.gx + tp.i10 + c, b10 * gm);
-                        if (b11 != 0.f) atomic_add_f32(L.gx + tp.i11 + c, b11 * gm);
+                    if (L.gx != nullptr && cval && tp.flags && !abl_no_atomic) {
+                        // one guard per sample, not per corner: a clamped corner of a border sample gets +0 at
+                        // a valid neighbour address (wholly invalid samples must be skipped: their index is 0
+                        // and thousands of same-address atomics serialise in L2)
+                        atomic_add_f32(L.gx + tp.i00 + c, b00 * gm);
+                        atomic_add_f32(L.gx + tp.i01 + c, b01 * gm);
+                        atomic_add_f32(L.gx + tp.i10 + c, b10 * gm);
+                        atomic_add_f32(L.gx + tp.i11 + c, b11 * gm);
                     }
                     if (want_off) {
                         const float hy = 1.f - tp.ly, hx = 1.f - tp.lx;
@@ -797,22 +828,23 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_kernel(const DcnArgs a)
                         const float dx = hy * (v01 - v00) + tp.ly * (v11 - v10);
                         const float bil =
                             hy * hx * v00 + hy * tp.lx * v01 + tp.ly * hx * v10 + tp.ly * tp.lx * v11;
-                        // reduce over the 16 channel lanes of this k-quarter, park in LDS (row is
-                        // private to this wave, so a plain read-modify-write is race-free)
-                        float vy = gm * dy, vx = gm * dx, vm = gval * bil;
-#pragma unroll
-                        for (int o = 8; o >= 1; o >>= 1) {
-                            vy += __shfl_xor(vy, o);
-                            vx += __shfl_xor(vx, o);
-                            vm += __shfl_xor(vm, o);
-                        }
-                        if (j16 == 0) {
-                            float *ga = gacc + ((wave * 16 + kq * 4 + r) * KD + ch.dgi * K + ch.k) * 3;
-                            ga[0] += vy;
-                            ga[1] += vx;
-                            ga[2] += vm;
-                        }
+                        sy[r] += gm * dy;
+                        sx[r] += gm * dx;
+                        sm[r] += gval * bil;
                     }
+                }
+            }
+            if (want_off && tap_done) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float vy = row16_sum(sy[r]), vx = row16_sum(sx[r]), vm = row16_sum(sm[r]);
+                    if (j16 == 0) {   // the row is private to this wave; conv groups sharing a deformable
+                        float *ga = gacc + ((wave * 16 + kq * 4 + r) * KD + ch.dgi * K + ch.k) * 3;   // group add up
+                        ga[0] += vy;
+                        ga[1] += vx;
+                        ga[2] += vm;
+                    }
+                    sy[r] = sx[r] = sm[r] = 0.f;
                 }
             }
             LSN_STAMP(6);

@@ -51,7 +51,11 @@ def run(fn, block, label, flags=0):
 
 
 import sys
-if len(sys.argv) > 1 and sys.argv[1] == 'ablate':
+if len(sys.argv) > 1 and sys.argv[1] == 'bwd':
+    for name, fl in (('full', 0), ('no atomics', 1 << 26), ('no offset/mask grads', 1 << 27), ('no x loads', 1 << 28),
+                     ('neither atomics nor offset grads', 3 << 26)):
+        run(lambda: be.dcn_backward(xs, offs, msks, w, gos, cfg, need), 300, f'backward-data {name}', fl)
+elif len(sys.argv) > 1 and sys.argv[1] == 'ablate':
     for name, fl in (('full', 0), ('no issue', 2 << 20), ('no issue, commit VALU only', 6 << 20), ('no issue, commit LDS only', 10 << 20)):
         run(lambda: be.dcn_forward(xs, offs, msks, w, None, cfg, LEVELS), 300, 'forward ' + name, fl)
 else:
