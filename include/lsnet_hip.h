@@ -197,6 +197,33 @@ int64_t lsn_nms_workspace_bytes(int n);
 int lsn_nms(const float *dets, const int64_t *order, int n, float iou_thr, int64_t *keep,
             int64_t *num_keep, void *workspace, lsn_stream_t stream);
 
+/* ---- GroupNorm (+ReLU) on channels-last tensors ----------------------------------------------
+ * The reference uses torch.nn.GroupNorm followed by nn.ReLU (ATen kernels; call sites
+ * lsnet_head.py:1830-1849,136-141 and ConvModule in fpn.py:65-156).  These entry points are the fused
+ * channels-last equivalent: y = relu?( (x - mean_g) * rstd_g * gamma_c + beta_c ), statistics per
+ * (image, group) over HW x C/G elements, biased variance, eps inside the square root -- the ATen definition.
+ * Several tensors that share one GroupNorm module (the FPN levels) are processed per call.
+ * x / y / dy / dx: (B, HW, C) channels-last fp32, 16-byte aligned.  Supported: C % 4 == 0, (C/G) % 4 == 0,
+ * 256 % (C/4) == 0 (C = 64 ... 1024); otherwise LSN_ERR_UNSUPPORTED (the caller keeps ATen's GroupNorm).
+ * mean_rstd: (sum of B over levels, G, 2) fp32, written by forward and read by backward.
+ * workspace: lsn_group_norm_workspace_bytes() bytes of device memory, contents undefined.
+ * backward recomputes the ReLU gate from x (y is not needed); grad_gamma / grad_beta (C) are OVERWRITTEN with
+ * the sums over all levels and images and may be NULL. */
+typedef struct lsn_gn_level {
+    const float *x;    /* input                              */
+    float *y;          /* forward: output                    */
+    const float *dy;   /* backward: gradient w.r.t. output   */
+    float *dx;         /* backward: gradient w.r.t. input    */
+    int B, HW;
+} lsn_gn_level;
+int64_t lsn_group_norm_workspace_bytes(int n_levels, const lsn_gn_level *levels, int C, int G);
+int lsn_group_norm_forward(int n_levels, const lsn_gn_level *levels, int C, int G, const float *gamma,
+                           const float *beta, float eps, int relu, float *mean_rstd, void *workspace,
+                           lsn_stream_t stream);
+int lsn_group_norm_backward(int n_levels, const lsn_gn_level *levels, int C, int G, const float *gamma,
+                            const float *beta, int relu, const float *mean_rstd, float *grad_gamma,
+                            float *grad_beta, void *workspace, lsn_stream_t stream);
+
 /* ---- diagnostics ---------------------------------------------------------------------------- */
 /* When set to a device buffer of 512 int64 (NULL disables), thread 0 of workgroup `block` of the
  * next DCN forward / backward-data launches appends (phase_id << 56 | shader_clock) stamps at its

@@ -34,6 +34,11 @@ class DcnLevel(ctypes.Structure):
                 ('Wo', ctypes.c_int), ('scale_h', ctypes.c_float), ('scale_w', ctypes.c_float)]
 
 
+class GnLevel(ctypes.Structure):
+    _fields_ = [('x', ctypes.c_void_p), ('y', ctypes.c_void_p), ('dy', ctypes.c_void_p), ('dx', ctypes.c_void_p),
+                ('B', ctypes.c_int), ('HW', ctypes.c_int)]
+
+
 class ProfEntry(ctypes.Structure):
     _fields_ = [('name', ctypes.c_char * 48), ('launches', ctypes.c_longlong), ('total_ms', ctypes.c_double),
                 ('flops', ctypes.c_double), ('bytes', ctypes.c_double)]
@@ -50,6 +55,7 @@ EXPORTS = [
     'lsn_sigmoid_focal_loss_backward_weighted',
     'lsn_nms_workspace_bytes', 'lsn_nms', 'lsn_selftest_mfma', 'lsn_debug_phase_clocks',
     'lsn_prof_enable', 'lsn_prof_read',
+    'lsn_group_norm_workspace_bytes', 'lsn_group_norm_forward', 'lsn_group_norm_backward',
 ]
 
 _lib = None
@@ -67,6 +73,7 @@ def load():
     lib = ctypes.CDLL(SO_PATH)
     lib.lsn_last_error.restype = ctypes.c_char_p
     lib.lsn_nms_workspace_bytes.restype = ctypes.c_int64
+    lib.lsn_group_norm_workspace_bytes.restype = ctypes.c_int64
     for name in EXPORTS:
         getattr(lib, name)  # AttributeError here means header and library disagree
     _lib = lib

@@ -6,6 +6,7 @@ import warnings
 import torch.nn as nn
 from torch.nn.modules.batchnorm import _BatchNorm
 
+from ..ops.group_norm import GroupNorm
 from .registry import ACTIVATION_LAYERS, CONV_LAYERS, NORM_LAYERS
 
 CONV_LAYERS.register_module('Conv2d', module=nn.Conv2d)
@@ -13,7 +14,7 @@ CONV_LAYERS.register_module('Conv', module=nn.Conv2d)
 NORM_LAYERS.register_module('BN', module=nn.BatchNorm2d)
 NORM_LAYERS.register_module('BN2d', module=nn.BatchNorm2d)
 NORM_LAYERS.register_module('SyncBN', module=nn.SyncBatchNorm)
-NORM_LAYERS.register_module('GN', module=nn.GroupNorm)
+NORM_LAYERS.register_module('GN', module=GroupNorm)
 for _act in (nn.ReLU, nn.LeakyReLU, nn.PReLU, nn.ReLU6, nn.ELU, nn.Sigmoid, nn.Tanh):
     ACTIVATION_LAYERS.register_module(module=_act)
 
@@ -149,6 +150,9 @@ class ConvModule(nn.Module):
             constant_init(self.norm, 1, bias=0)
 
     def forward(self, x, activate=True, norm=True):
+        if (self.order == ('conv', 'norm', 'act') and norm and activate and self.with_norm and self.with_activation
+                and isinstance(self.norm, GroupNorm) and isinstance(self.activate, nn.ReLU)):
+            return self.norm.forward_act(self.conv(x))      # GroupNorm + ReLU in one pass
         for step in self.order:
             if step == 'conv':
                 x = self.conv(x)

@@ -1,0 +1,352 @@
+// GroupNorm (+ optional ReLU) forward / backward on channels-last fp32 tensors, several tensors (FPN levels
+// sharing one GroupNorm module) per launch.
+//
+// The reference calls torch.nn.GroupNorm + nn.ReLU (lsnet_head.py:1830-1849, 136-141; fpn.py:65-156 through
+// ConvModule): three ATen kernels forward, five backward, on NCHW tensors.  On MI355X the hot path keeps
+// activations in NHWC for the deformable-conv gathers; ATen's GroupNorm returns NCHW-contiguous tensors, which
+// cost a layout copy before and after every deformable conv (324 permute launches per training step).  These
+// kernels read and write NHWC directly and fold the ReLU in:
+//   forward : gn_stats_kernel (shifted sums -> fp64 atomics per (image, group)), gn_apply_kernel (y = x*a + b)
+//   backward: gn_bwd_reduce_kernel (per (image, channel) sums of dy and dy*xhat), gn_bwd_apply_kernel,
+//             gn_param_grad_kernel (d gamma, d beta over images and levels)
+// All are HBM-bound streaming kernels: one pixel row (C floats) is read by C/4 lanes as float4.
+// Numerics: variance from shifted sums (shift = the group's first element of the image), accumulated in fp32
+// per thread and in fp64 across threads / blocks -- robust when |mean| >> std.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/lsnet_hip.h"
+#include "common.h"
+
+namespace lsn {
+
+constexpr int GN_MAXLV = 16;
+constexpr int GN_PIX = 128;   // pixels per block
+
+struct GnLvl {
+    const float *x, *dy;
+    float *y, *dx;
+    int B, HW;
+    int tile0;   // first block of this level
+    int img0;    // first (image) slot of this level in the statistics buffers
+};
+struct GnArgs {
+    GnLvl lv[GN_MAXLV];
+    int nlv, C, G, relu;
+    float eps;
+    const float *gamma, *beta;
+    double *sums;      // [images][G][2]   shifted sum, shifted sum of squares   (zero-filled by the launcher)
+    float *mean_rstd;  // [images][G][2]
+    float *ab;         // [images][C][2]   backward: sum dy*xhat, sum dy          (zero-filled by the launcher)
+    float *dgamma, *dbeta;
+};
+
+__device__ __forceinline__ const GnLvl &gn_level(const GnArgs &a, int tile, int &li)
+{
+    li = 0;
+    while (li + 1 < a.nlv && tile >= a.lv[li + 1].tile0) ++li;
+    return a.lv[li];
+}
+
+// block -> (level, image, pixel range); thread -> (channel quad q, row slot)
+struct GnPos {
+    int b, p0, p1, q, row, rows;
+};
+__device__ __forceinline__ GnPos gn_pos(const GnArgs &a, const GnLvl &L)
+{
+    GnPos r;
+    const int tpi = (L.HW + GN_PIX - 1) / GN_PIX;   // tiles per image
+    const int t = blockIdx.x - L.tile0;
+    r.b = t / tpi;
+    r.p0 = (t - r.b * tpi) * GN_PIX;
+    r.p1 = min(r.p0 + GN_PIX, L.HW);
+    const int qn = a.C >> 2;
+    r.q = threadIdx.x % qn;
+    r.row = threadIdx.x / qn;
+    r.rows = 256 / qn;
+    return r;
+}
+
+__global__ __launch_bounds__(256) void gn_stats_kernel(const GnArgs a)
+{
+    int li;
+    const GnLvl &L = gn_level(a, blockIdx.x, li);
+    const GnPos p = gn_pos(a, L);
+    const int cpg = a.C / a.G, g = (p.q * 4) / cpg;
+    const float *xb = L.x + (size_t)p.b * L.HW * a.C;
+    const float K = xb[g * cpg];   // shift: first element of the group in this image
+    float s1 = 0.f, s2 = 0.f;
+    for (int px = p.p0 + p.row; px < p.p1; px += p.rows) {
+        const float4 v = *reinterpret_cast<const float4 *>(xb + (size_t)px * a.C + p.q * 4);
+        const float d0 = v.x - K, d1 = v.y - K, d2 = v.z - K, d3 = v.w - K;
+        s1 += (d0 + d1) + (d2 + d3);
+        s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+    // block reduction per group in fp64 through LDS
+    __shared__ double acc[256 * 2];
+    acc[threadIdx.x * 2] = (double)s1;
+    acc[threadIdx.x * 2 + 1] = (double)s2;
+    __syncthreads();
+    // threads of one group: quads q with (q*4)/cpg == g, all rows.  One thread per group sums them.
+    const int qn = a.C >> 2, qpg = cpg >> 2;
+    if (threadIdx.x < a.G) {
+        double t1 = 0.0, t2 = 0.0;
+        for (int r = 0; r < p.rows; ++r)
+            for (int j = 0; j < qpg; ++j) {
+                const int t = r * qn + threadIdx.x * qpg + j;
+                t1 += acc[t * 2];
+                t2 += acc[t * 2 + 1];
+            }
+        double *dst = a.sums + ((size_t)(L.img0 + p.b) * a.G + threadIdx.x) * 2;
+        unsafeAtomicAdd(dst, t1);
+        unsafeAtomicAdd(dst + 1, t2);
+    }
+}
+
+// mean / rstd of (image, group) from the shifted sums
+__device__ __forceinline__ void gn_moments(const GnArgs &a, const GnLvl &L, int b, int g, float K, float &mean,
+                                           float &rstd)
+{
+    const double n = (double)L.HW * (a.C / a.G);
+    const double *s = a.sums + ((size_t)(L.img0 + b) * a.G + g) * 2;
+    const double m1 = s[0] / n;
+    double var = s[1] / n - m1 * m1;
+    if (var < 0.0) var = 0.0;
+    mean = (float)((double)K + m1);
+    rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a)
+{
+    int li;
+    const GnLvl &L = gn_level(a, blockIdx.x, li);
+    const GnPos p = gn_pos(a, L);
+    const int cpg = a.C / a.G, g = (p.q * 4) / cpg;
+    const float *xb = L.x + (size_t)p.b * L.HW * a.C;
+    float *yb = L.y + (size_t)p.b * L.HW * a.C;
+    float mean, rstd;
+    gn_moments(a, L, p.b, g, xb[g * cpg], mean, rstd);
+    if (p.p0 == 0 && p.row == 0 && (p.q * 4) % cpg == 0) {   // saved for backward
+        float *mr = a.mean_rstd + ((size_t)(L.img0 + p.b) * a.G + g) * 2;
+        mr[0] = mean;
+        mr[1] = rstd;
+    }
+    const float4 ga = *reinterpret_cast<const float4 *>(a.gamma + p.q * 4);
+    const float4 be = *reinterpret_cast<const float4 *>(a.beta + p.q * 4);
+    const float a0 = rstd * ga.x, a1 = rstd * ga.y, a2 = rstd * ga.z, a3 = rstd * ga.w;
+    const float b0 = be.x - mean * a0, b1 = be.y - mean * a1, b2 = be.z - mean * a2, b3 = be.w - mean * a3;
+    for (int px = p.p0 + p.row; px < p.p1; px += p.rows) {
+        const float4 v = *reinterpret_cast<const float4 *>(xb + (size_t)px * a.C + p.q * 4);
+        float4 o = make_float4(v.x * a0 + b0, v.y * a1 + b1, v.z * a2 + b2, v.w * a3 + b3);
+        if (a.relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
+        *reinterpret_cast<float4 *>(yb + (size_t)px * a.C + p.q * 4) = o;
+    }
+}
+
+// per (image, channel): A = sum dy' * xhat, Bc = sum dy'   (dy' = dy gated by the ReLU of the forward)
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const GnArgs a)
+{
+    int li;
+    const GnLvl &L = gn_level(a, blockIdx.x, li);
+    const GnPos p = gn_pos(a, L);
+    const int cpg = a.C / a.G, g = (p.q * 4) / cpg;
+    const float *xb = L.x + (size_t)p.b * L.HW * a.C;
+    const float *db = L.dy + (size_t)p.b * L.HW * a.C;
+    const float *mr = a.mean_rstd + ((size_t)(L.img0 + p.b) * a.G + g) * 2;
+    const float mean = mr[0], rstd = mr[1];
+    const float4 ga = *reinterpret_cast<const float4 *>(a.gamma + p.q * 4);
+    const float4 be = *reinterpret_cast<const float4 *>(a.beta + p.q * 4);
+    const float a0 = rstd * ga.x, a1 = rstd * ga.y, a2 = rstd * ga.z, a3 = rstd * ga.w;
+    const float b0 = be.x - mean * a0, b1 = be.y - mean * a1, b2 = be.z - mean * a2, b3 = be.w - mean * a3;
+    float A[4] = {0.f, 0.f, 0.f, 0.f}, Bc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int px = p.p0 + p.row; px < p.p1; px += p.rows) {
+        const float4 v = *reinterpret_cast<const float4 *>(xb + (size_t)px * a.C + p.q * 4);
+        float4 d = *reinterpret_cast<const float4 *>(db + (size_t)px * a.C + p.q * 4);
+        const float h0 = (v.x - mean) * rstd, h1 = (v.y - mean) * rstd, h2 = (v.z - mean) * rstd,
+                    h3 = (v.w - mean) * rstd;
+        if (a.relu) {   // the forward's own expression, so the gate is bitwise the one that was applied
+            d.x = (v.x * a0 + b0 > 0.f) ? d.x : 0.f;
+            d.y = (v.y * a1 + b1 > 0.f) ? d.y : 0.f;
+            d.z = (v.z * a2 + b2 > 0.f) ? d.z : 0.f;
+            d.w = (v.w * a3 + b3 > 0.f) ? d.w : 0.f;
+        }
+        A[0] += d.x * h0, A[1] += d.y * h1, A[2] += d.z * h2, A[3] += d.w * h3;
+        Bc[0] += d.x, Bc[1] += d.y, Bc[2] += d.z, Bc[3] += d.w;
+    }
+    __shared__ float red[256 * 8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        red[threadIdx.x * 8 + j] = A[j];
+        red[threadIdx.x * 8 + 4 + j] = Bc[j];
+    }
+    __syncthreads();
+    const int qn = a.C >> 2;
+    if (threadIdx.x < qn) {   // row 0 threads sum the rows of their channel quad
+        float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < p.rows; ++r)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] += red[(r * qn + threadIdx.x) * 8 + j];
+        float *dst = a.ab + ((size_t)(L.img0 + p.b) * a.C + threadIdx.x * 4) * 2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            atomic_add_f32(dst + j * 2, s[j]);
+            atomic_add_f32(dst + j * 2 + 1, s[4 + j]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const GnArgs a)
+{
+    int li;
+    const GnLvl &L = gn_level(a, blockIdx.x, li);
+    const GnPos p = gn_pos(a, L);
+    const int cpg = a.C / a.G, g = (p.q * 4) / cpg;
+    const float *xb = L.x + (size_t)p.b * L.HW * a.C;
+    const float *db = L.dy + (size_t)p.b * L.HW * a.C;
+    float *ob = L.dx + (size_t)p.b * L.HW * a.C;
+    const float *mr = a.mean_rstd + ((size_t)(L.img0 + p.b) * a.G + g) * 2;
+    const float mean = mr[0], rstd = mr[1];
+    // group sums S1 = sum_c gamma_c * Bc[c], S2 = sum_c gamma_c * A[c]
+    float S1 = 0.f, S2 = 0.f;
+    const float *ab = a.ab + ((size_t)(L.img0 + p.b) * a.C + g * cpg) * 2;
+    for (int c = 0; c < cpg; ++c) {
+        const float gm = a.gamma[g * cpg + c];
+        S2 += gm * ab[c * 2];
+        S1 += gm * ab[c * 2 + 1];
+    }
+    const float inv_n = 1.f / ((float)L.HW * (float)cpg);
+    const float m1 = S1 * inv_n, m2 = S2 * inv_n;
+    const float4 ga = *reinterpret_cast<const float4 *>(a.gamma + p.q * 4);
+    const float4 be = *reinterpret_cast<const float4 *>(a.beta + p.q * 4);
+    const float a0 = rstd * ga.x, a1 = rstd * ga.y, a2 = rstd * ga.z, a3 = rstd * ga.w;
+    const float b0 = be.x - mean * a0, b1 = be.y - mean * a1, b2 = be.z - mean * a2, b3 = be.w - mean * a3;
+    for (int px = p.p0 + p.row; px < p.p1; px += p.rows) {
+        const float4 v = *reinterpret_cast<const float4 *>(xb + (size_t)px * a.C + p.q * 4);
+        float4 d = *reinterpret_cast<const float4 *>(db + (size_t)px * a.C + p.q * 4);
+        const float h0 = (v.x - mean) * rstd, h1 = (v.y - mean) * rstd, h2 = (v.z - mean) * rstd,
+                    h3 = (v.w - mean) * rstd;
+        if (a.relu) {   // the forward's own expression, so the gate is bitwise the one that was applied
+            d.x = (v.x * a0 + b0 > 0.f) ? d.x : 0.f;
+            d.y = (v.y * a1 + b1 > 0.f) ? d.y : 0.f;
+            d.z = (v.z * a2 + b2 > 0.f) ? d.z : 0.f;
+            d.w = (v.w * a3 + b3 > 0.f) ? d.w : 0.f;
+        }
+        float4 o;
+        o.x = rstd * (ga.x * d.x - m1 - h0 * m2);
+        o.y = rstd * (ga.y * d.y - m1 - h1 * m2);
+        o.z = rstd * (ga.z * d.z - m1 - h2 * m2);
+        o.w = rstd * (ga.w * d.w - m1 - h3 * m2);
+        *reinterpret_cast<float4 *>(ob + (size_t)px * a.C + p.q * 4) = o;
+    }
+}
+
+// d gamma[c] = sum_images A[img][c], d beta[c] = sum_images Bc[img][c]
+__global__ void gn_param_grad_kernel(const GnArgs a, int images)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.C) return;
+    float sa = 0.f, sb = 0.f;
+    for (int i = 0; i < images; ++i) {
+        sa += a.ab[((size_t)i * a.C + c) * 2];
+        sb += a.ab[((size_t)i * a.C + c) * 2 + 1];
+    }
+    if (a.dgamma) a.dgamma[c] = sa;
+    if (a.dbeta) a.dbeta[c] = sb;
+}
+
+static int gn_fill(GnArgs &a, int n, const lsn_gn_level *lv, int C, int G, int *tiles, int *images)
+{
+    LSN_CHECK(n >= 1 && n <= GN_MAXLV, "n_levels must be in [1,%d], got %d", GN_MAXLV, n);
+    LSN_CHECK(C > 0 && G > 0 && C % G == 0, "num_channels %d must be divisible by num_groups %d", C, G);
+    const int qn = C / 4;
+    if (C % 4 != 0 || (C / G) % 4 != 0 || qn > 256 || 256 % qn != 0 || G > 256)
+        return fail(LSN_ERR_UNSUPPORTED, "group norm kernel needs C in {64..1024} with 256 %% (C/4) == 0 and "
+                                         "(C/G) %% 4 == 0, got C=%d G=%d", C, G);
+    int t = 0, im = 0;
+    for (int i = 0; i < n; ++i) {
+        LSN_CHECK(lv[i].B > 0 && lv[i].HW > 0 && lv[i].x != nullptr, "level %d: empty tensor", i);
+        a.lv[i].x = lv[i].x;
+        a.lv[i].y = lv[i].y;
+        a.lv[i].dy = lv[i].dy;
+        a.lv[i].dx = lv[i].dx;
+        a.lv[i].B = lv[i].B;
+        a.lv[i].HW = lv[i].HW;
+        a.lv[i].tile0 = t;
+        a.lv[i].img0 = im;
+        t += lv[i].B * ((lv[i].HW + GN_PIX - 1) / GN_PIX);
+        im += lv[i].B;
+    }
+    a.nlv = n;
+    a.C = C;
+    a.G = G;
+    *tiles = t;
+    *images = im;
+    return 0;
+}
+
+}  // namespace lsn
+
+extern "C" {
+
+int64_t lsn_group_norm_workspace_bytes(int n_levels, const lsn_gn_level *levels, int C, int G)
+{
+    int64_t images = 0;
+    for (int i = 0; i < n_levels; ++i) images += levels[i].B;
+    // forward: sums (double [images][G][2]); backward: ab (float [images][C][2]); sized for the larger
+    const int64_t f = images * G * 2 * (int64_t)sizeof(double), b = images * C * 2 * (int64_t)sizeof(float);
+    return f > b ? f : b;
+}
+
+int lsn_group_norm_forward(int n_levels, const lsn_gn_level *levels, int C, int G, const float *gamma,
+                           const float *beta, float eps, int relu, float *mean_rstd, void *workspace,
+                           lsn_stream_t stream)
+{
+    using namespace lsn;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    GnArgs a = {};
+    int tiles = 0, images = 0;
+    if (int rc = gn_fill(a, n_levels, levels, C, G, &tiles, &images)) return rc;
+    LSN_CHECK(gamma && beta && mean_rstd && workspace, "group norm: NULL argument");
+    for (int i = 0; i < n_levels; ++i) LSN_CHECK(levels[i].y != nullptr, "level %d: output is NULL", i);
+    a.gamma = gamma;
+    a.beta = beta;
+    a.eps = eps;
+    a.relu = relu;
+    a.sums = reinterpret_cast<double *>(workspace);
+    a.mean_rstd = mean_rstd;
+    LSN_HIP(hipMemsetAsync(a.sums, 0, sizeof(double) * (size_t)images * G * 2, st));
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(tiles), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(tiles), dim3(256), 0, st, a);
+    LSN_HIP(hipGetLastError());
+    return 0;
+}
+
+int lsn_group_norm_backward(int n_levels, const lsn_gn_level *levels, int C, int G, const float *gamma,
+                            const float *beta, int relu, const float *mean_rstd, float *grad_gamma,
+                            float *grad_beta, void *workspace, lsn_stream_t stream)
+{
+    using namespace lsn;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    GnArgs a = {};
+    int tiles = 0, images = 0;
+    if (int rc = gn_fill(a, n_levels, levels, C, G, &tiles, &images)) return rc;
+    LSN_CHECK(gamma && beta && mean_rstd && workspace, "group norm: NULL argument");
+    for (int i = 0; i < n_levels; ++i)
+        LSN_CHECK(levels[i].dy != nullptr && levels[i].dx != nullptr, "level %d: dy/dx is NULL", i);
+    a.gamma = gamma;
+    a.beta = beta;
+    a.relu = relu;
+    a.mean_rstd = const_cast<float *>(mean_rstd);
+    a.ab = reinterpret_cast<float *>(workspace);
+    a.dgamma = grad_gamma;
+    a.dbeta = grad_beta;
+    LSN_HIP(hipMemsetAsync(a.ab, 0, sizeof(float) * (size_t)images * C * 2, st));
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(tiles), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(tiles), dim3(256), 0, st, a);
+    if (grad_gamma || grad_beta)
+        hipLaunchKernelGGL(gn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, st, a, images);
+    LSN_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

@@ -25,6 +25,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ...cnn import ConvModule, bias_init_with_prob, kaiming_init, normal_init
+from ...ops.group_norm import GroupNorm
 from ...core import PointGenerator, build_assigner, build_sampler, multiclass_nms_lsvr
 from ...ops import ModulatedDeformConvPack, PyramidDeformConv
 from ..builder import HEADS, build_loss
@@ -40,14 +41,14 @@ class DCNConvModule(nn.Module):
     def __init__(self, in_channels=256, out_channels=256, kernel_size=3, dilation=1, num_groups=1, dcn_pad=1):
         super().__init__()
         self.conv = ModulatedDeformConvPack(in_channels, out_channels, kernel_size, 1, dcn_pad)
-        self.bn = nn.GroupNorm(num_groups, out_channels)
+        self.bn = GroupNorm(num_groups, out_channels)
         self.relu = nn.ReLU(inplace=True)
 
     def forward(self, x):
-        return self.relu(self.bn(self.conv(x)))
+        return self.bn.forward_act(self.conv(x))
 
     def forward_multi(self, xs):
-        return [self.relu(self.bn(y)) for y in self.conv.forward_multi(xs)]
+        return self.bn.forward_multi(self.conv.forward_multi(xs), relu=True)   # all levels: one fused GN+ReLU
 
 
 def _signed_pairs(t, dim):
@@ -135,10 +136,10 @@ class LSHead(nn.Module):
         ng = self.norm_cfg.num_groups if hasattr(self.norm_cfg, 'num_groups') else self.norm_cfg['num_groups']
         self.relu = nn.ReLU(inplace=True)
         self.softplus = nn.Softplus()
-        self.cls_GN = nn.GroupNorm(ng, fc)
+        self.cls_GN = GroupNorm(ng, fc)
         self.cls_convs = self._tower()
         for b in self.branches:
-            setattr(self, f'{b}_GN', nn.GroupNorm(ng, fc))
+            setattr(self, f'{b}_GN', GroupNorm(ng, fc))
             setattr(self, f'{b}_convs', self._tower())
         self.pts_cls_conv = PyramidDeformConv(fc, pc, self.dcn_kernel, 1, self.dcn_pad)
         self.pts_cls_out = nn.Conv2d(pc, self.cls_out_channels, 1, 1, 0)
@@ -277,18 +278,17 @@ class LSHead(nn.Module):
 
         driver = self.branches[-1]
         cls_raw = gather(self.pts_cls_conv, cls_feats, scaled[driver])
-        outs = {'cls': []}
-        for l in range(nl):
-            fused = self.cls_af_dcn_conv(torch.cat(cls_raw[3 * l:3 * l + 3], dim=1)) + self.cls_feat_conv(cls_feats[l])
-            outs['cls'].append(self.pts_cls_out(self.relu(self.cls_GN(fused))))
+        outs = {}
+        fused = [self.cls_af_dcn_conv(torch.cat(cls_raw[3 * l:3 * l + 3], dim=1)) + self.cls_feat_conv(cls_feats[l])
+                 for l in range(nl)]
+        outs['cls'] = [self.pts_cls_out(y) for y in self.cls_GN.forward_multi(fused, relu=True)]
         for b in self.branches:
             raw = gather(getattr(self, f'pts_{b}_refine_conv'), st[b]['feat'], scaled[b])
             af, fc = getattr(self, f'{b}_af_dcn_conv'), getattr(self, f'{b}_feat_conv')
             gn, ro = getattr(self, f'{b}_GN'), getattr(self, f'pts_{b}_refine_out')
-            outs[b] = []
-            for l in range(nl):
-                fused = af(torch.cat(raw[3 * l:3 * l + 3], dim=1)) + fc(st[b]['feat'][l])
-                outs[b].append(self.softplus(ro(self.relu(gn(fused))) + st[b]['sp'][l].detach()))
+            fused = [af(torch.cat(raw[3 * l:3 * l + 3], dim=1)) + fc(st[b]['feat'][l]) for l in range(nl)]
+            outs[b] = [self.softplus(ro(y) + st[b]['sp'][l].detach())
+                       for l, y in enumerate(gn.forward_multi(fused, relu=True))]
 
         none = [None] * nl
         res = [outs['cls']]

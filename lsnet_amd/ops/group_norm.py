@@ -1,0 +1,61 @@
+"""GroupNorm with an optional fused ReLU, channels-last, several tensors per launch.
+
+Stands where the reference uses torch.nn.GroupNorm (+ nn.ReLU): NORM_LAYERS['GN'] of ConvModule
+(mmcv/cnn/bricks/norm.py:70-118), `DCNConvModule.bn` and `LSHead.{cls,bbox,...}_GN`
+(lsnet_head.py:1830-1849, 136-141).  `GroupNorm` subclasses nn.GroupNorm (same parameters, same state-dict
+keys, same definition: biased variance over HW x C/G, eps inside the root).  CUDA channels-last fp32 inputs of a
+supported shape run the HIP kernels of csrc/norm.hip (lsn_group_norm_*), which keep the NHWC layout the deformable
+convolutions want; anything else takes ATen's group_norm -- a different PyTorch operator for a different layout, not
+a CPU fallback of the HIP path."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .backend import get_backend
+
+_CL = torch.channels_last
+
+
+class _GroupNormFn(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, gamma, beta, groups, eps, relu, *xs):
+        be = get_backend(xs[0])
+        ys, mean_rstd = be.group_norm_forward(list(xs), gamma, beta, groups, eps, relu)
+        ctx.save_for_backward(gamma, beta, mean_rstd, *xs)
+        ctx.cfg = (groups, relu)
+        return tuple(ys)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *dys):
+        gamma, beta, mean_rstd, *xs = ctx.saved_tensors
+        groups, relu = ctx.cfg
+        dys = [torch.zeros_like(x) if d is None else d for d, x in zip(dys, xs)]
+        need_p = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        dxs, dg, db = get_backend(xs[0]).group_norm_backward(xs, dys, gamma, beta, groups, relu, mean_rstd, need_p)
+        return (dg if ctx.needs_input_grad[0] else None, db if ctx.needs_input_grad[1] else None, None, None, None,
+                *dxs)
+
+
+def _hip_ok(x, C, G):
+    if not (x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and x.is_contiguous(memory_format=_CL)):
+        return False
+    return get_backend(x).group_norm_supported(C, G)
+
+
+class GroupNorm(nn.GroupNorm):
+
+    def forward_multi(self, xs, relu=False):
+        """[GN(x) (then ReLU)] for tensors that share this module -- one fused launch on the HIP path."""
+        xs = list(xs)
+        if self.affine and all(_hip_ok(x, self.num_channels, self.num_groups) for x in xs):
+            return list(_GroupNormFn.apply(self.weight, self.bias, self.num_groups, self.eps, bool(relu), *xs))
+        ys = [F.group_norm(x, self.num_groups, self.weight, self.bias, self.eps) for x in xs]
+        return [F.relu(y) for y in ys] if relu else ys
+
+    def forward(self, x):
+        return self.forward_multi([x], relu=False)[0]
+
+    def forward_act(self, x):
+        return self.forward_multi([x], relu=True)[0]

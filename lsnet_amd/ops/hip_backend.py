@@ -43,6 +43,54 @@ def _strides(t):
 class HipBackend:
     name = 'hip'
 
+    # ------------------------------------------------------------------ group norm (+ReLU), channels-last
+    @staticmethod
+    def group_norm_supported(C, G):
+        return C % 4 == 0 and C % G == 0 and (C // G) % 4 == 0 and C // 4 <= 256 and 256 % (C // 4) == 0 and G <= 256
+
+    @staticmethod
+    def _gn_levels(xs, ys=None, dys=None, dxs=None):
+        n = len(xs)
+        levels = (_lib.GnLevel * n)()
+        for i, x in enumerate(xs):
+            B, C, H, W = x.shape
+            L = levels[i]
+            L.x = _ptr(x)
+            L.y = _ptr(ys[i]) if ys is not None else None
+            L.dy = _ptr(dys[i]) if dys is not None else None
+            L.dx = _ptr(dxs[i]) if dxs is not None else None
+            L.B, L.HW = B, H * W
+        return levels
+
+    def group_norm_forward(self, xs, gamma, beta, groups, eps, relu):
+        """xs: channels-last (B, C, H, W) tensors sharing gamma/beta.  Returns (ys, mean_rstd)."""
+        lib = _lib.load()
+        n, C = len(xs), xs[0].shape[1]
+        ys = [torch.empty_like(x, memory_format=_CL) for x in xs]
+        levels = self._gn_levels(xs, ys=ys)
+        images = sum(x.shape[0] for x in xs)
+        mean_rstd = torch.empty(images, groups, 2, device=xs[0].device, dtype=torch.float32)
+        ws = torch.empty(lib.lsn_group_norm_workspace_bytes(n, levels, C, groups), device=xs[0].device,
+                         dtype=torch.uint8)
+        _lib.check(lib.lsn_group_norm_forward(n, levels, C, groups, _ptr(gamma), _ptr(beta), ctypes.c_float(eps),
+                                              1 if relu else 0, _ptr(mean_rstd), _ptr(ws), _stream()))
+        return ys, mean_rstd
+
+    def group_norm_backward(self, xs, dys, gamma, beta, groups, relu, mean_rstd, need_params):
+        """Returns (dxs, dgamma, dbeta); dgamma/dbeta are None unless need_params."""
+        lib = _lib.load()
+        n, C = len(xs), xs[0].shape[1]
+        dys = [d.contiguous(memory_format=_CL) for d in dys]
+        dxs = [torch.empty_like(x, memory_format=_CL) for x in xs]
+        levels = self._gn_levels(xs, dys=dys, dxs=dxs)
+        dg = torch.empty_like(gamma) if need_params else None
+        db = torch.empty_like(beta) if need_params else None
+        ws = torch.empty(lib.lsn_group_norm_workspace_bytes(n, levels, C, groups), device=xs[0].device,
+                         dtype=torch.uint8)
+        _lib.check(lib.lsn_group_norm_backward(n, levels, C, groups, _ptr(gamma), _ptr(beta), 1 if relu else 0,
+                                               _ptr(mean_rstd), _ptr(dg), _ptr(db), _ptr(ws), _stream()))
+        return dxs, dg, db
+
     # ------------------------------------------------------------------ deformable conv family
     @staticmethod
     def _prep(inputs, offsets, masks, weight):

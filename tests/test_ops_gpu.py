@@ -8,6 +8,7 @@ import ctypes
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
@@ -306,3 +307,57 @@ def test_dcn_pack_fused_offset_mask_logits(layout):
     ref = orc.deform_conv_forward(x.detach().cpu(), pack.weight.detach().cpu(), pack.bias.detach().cpu(),
                                   omc[:, :18].contiguous(), torch.sigmoid(omc[:, 18:]).contiguous(), 1, 1, 1)
     assert _err(out, ref) < TOL
+
+
+# ---------------------------------------------------------------------------------- group norm (+ReLU)
+@pytest.mark.gpu
+@pytest.mark.parametrize('C,G,relu,shapes', [
+    (256, 32, True, [(2, 25, 42), (2, 13, 21), (2, 7, 11)]),      # LSHead towers: levels share one module
+    (256, 32, False, [(2, 50, 84)]),                               # FPN ConvModule: no activation
+    (64, 8, True, [(3, 9, 5)]),
+    (1024, 32, False, [(1, 6, 7), (2, 3, 3)]),
+    (128, 32, True, [(2, 130, 67)]),                               # HW not a multiple of the block size
+])
+def test_group_norm_matches_torch(C, G, relu, shapes):
+    """fp32 reference: torch.nn.functional.group_norm (+relu) on the same device and on the CPU."""
+    from lsnet_amd.ops.group_norm import GroupNorm
+    torch.manual_seed(5)
+    dev = torch.device('cuda:0')
+    m = GroupNorm(G, C).to(dev)
+    with torch.no_grad():
+        m.weight.copy_(torch.randn(C) * 0.5 + 1.0)
+        m.bias.copy_(torch.randn(C) * 0.3)
+    # large mean / small std in some groups stresses the variance computation
+    xs = [(torch.randn(b, C, h, w) * (0.2 + torch.rand(1, C, 1, 1) * 3) + torch.randn(1, C, 1, 1) * 8).to(dev)
+          .contiguous(memory_format=torch.channels_last).requires_grad_() for b, h, w in shapes]
+    gos = [torch.randn_like(x) for x in xs]
+    ys = m.forward_multi(xs, relu=relu)
+    assert all(y.is_contiguous(memory_format=torch.channels_last) for y in ys)
+    torch.autograd.backward(ys, gos)
+    got = [y.detach().clone() for y in ys], [x.grad.clone() for x in xs], m.weight.grad.clone(), m.bias.grad.clone()
+
+    for where in ('cuda', 'cpu'):
+        w = m.weight.detach().to(where).clone().requires_grad_()
+        b = m.bias.detach().to(where).clone().requires_grad_()
+        xr = [x.detach().to(where).contiguous().requires_grad_() for x in xs]
+        yr = [F.group_norm(x, G, w, b, m.eps) for x in xr]
+        if relu:
+            yr = [F.relu(y) for y in yr]
+        torch.autograd.backward(yr, [g.to(where) for g in gos])
+        for y, r in zip(got[0], yr):
+            assert _err(y, r.detach().to(dev)) < 1e-5
+        for gx, r in zip(got[1], xr):
+            assert _err(gx, r.grad.to(dev)) < 2e-5
+        assert _err(got[2], w.grad.to(dev)) < 2e-5
+        assert _err(got[3], b.grad.to(dev)) < 2e-5
+
+
+@pytest.mark.gpu
+def test_group_norm_unsupported_shape_uses_aten():
+    from lsnet_amd.ops.group_norm import GroupNorm
+    dev = torch.device('cuda:0')
+    m = GroupNorm(3, 6).to(dev)                 # C/G = 2: not a float4 multiple
+    x = torch.randn(2, 6, 5, 5, device=dev).contiguous(memory_format=torch.channels_last)
+    assert torch.allclose(m(x), F.group_norm(x, 3, m.weight, m.bias, m.eps), atol=1e-6)
+    y = GroupNorm(32, 256)(torch.randn(2, 256, 5, 5))      # CPU tensors take ATen's kernel as well
+    assert y.shape == (2, 256, 5, 5)
