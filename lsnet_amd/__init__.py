@@ -4,3 +4,13 @@ The compute path is hand-written HIP in lsnet_amd/csrc (C ABI: include/lsnet_hip
 package is the host-side mirror of the reference's operator / registry interface for that path.
 """
 __version__ = '0.1.0'
+
+import os as _os
+
+# ROCm 7.2 hipGraph workaround.  With the runtime's AQL "graph packet capture" fast path (the default), replaying
+# the captured forward+backward graph (runner/graph_step.py, ~5000 kernel nodes) after eager kernels have written
+# the parameters ends in HSA_STATUS_ERROR_EXCEPTION 0x1016 a few replays later -- reproduced with plain
+# per-tensor torch ops between replays, not reproducible with AMD_SERIALIZE_KERNEL=3, gone with the fast path off
+# (tools/try_capture4.py).  The variable is read when the HIP runtime initialises, i.e. at the first device call,
+# so setting it at import time is early enough; an explicit user setting wins.
+_os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')

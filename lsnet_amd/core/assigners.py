@@ -49,7 +49,7 @@ def bbox_overlaps(bboxes1, bboxes2, mode='iou', is_aligned=False, eps=1e-6):
         union = area1 + area2 - overlap
     else:
         union = area1
-    return overlap / torch.max(union, union.new_tensor([eps]))
+    return overlap / union.clamp(min=eps)
 
 
 @IOU_CALCULATORS.register_module()

@@ -92,7 +92,11 @@ class LSHead(nn.Module):
         assert self.dcn_kernel % 2 == 1, 'The points number should be an odd square number.'
         base = np.arange(-self.dcn_pad, self.dcn_pad + 1).astype(np.float64)
         base_yx = np.stack([np.repeat(base, self.dcn_kernel), np.tile(base, self.dcn_kernel)], axis=1).reshape(-1)
-        self.dcn_base_offset = torch.tensor(base_yx).view(1, -1, 1, 1)   # regular 3x3 grid, (y, x) per tap
+        # regular 3x3 grid, (y, x) per tap.  A non-persistent buffer: it follows the module to the device (an
+        # H2D copy inside forward would break hipGraph capture) and stays out of the state dict like the
+        # reference's plain attribute (lsnet_head.py:84-91)
+        self.register_buffer('dcn_base_offset', torch.tensor(base_yx).view(1, -1, 1, 1), persistent=False)
+        self._consts = {}
 
         self.loss_cls = build_loss(loss_cls)
         loss_cfgs = dict(bbox=(loss_bbox_init, loss_bbox_refine), segm=(loss_segm_init, loss_segm_refine),
@@ -225,6 +229,16 @@ class LSHead(nn.Module):
             out = conv.forward_multi(out)
         return out
 
+    def _scale_const(self, sh, sw, like):
+        """(1, 2*taps, 1, 1) tensor [sh, sw, sh, sw, ...], built once per (scale, device): constants are never
+        uploaded inside the step (no H2D copy in the hot loop, hipGraph-capturable)."""
+        key = (float(sh), float(sw), like.device, like.dtype)
+        t = self._consts.get(key)
+        if t is None:
+            t = like.new_tensor([sh, sw]).repeat(self.num_kernel_points).view(1, -1, 1, 1)
+            self._consts[key] = t
+        return t
+
     @staticmethod
     def _level_list(lvl, num_levels):
         if lvl == 0:
@@ -266,7 +280,7 @@ class LSHead(nn.Module):
             cur = {b: st[b]['off'][l] for b in self.branches}
             for s in self._level_list(l, nl):
                 sh, sw = cls_feats[s].shape[2] / bh, cls_feats[s].shape[3] / bw
-                mult = cur[self.branches[0]].new_tensor([sh, sw]).repeat(self.num_kernel_points).view(1, -1, 1, 1)
+                mult = self._scale_const(sh, sw, cur[self.branches[0]])
                 for b in self.branches:
                     cur[b] = cur[b] * mult
                     scaled[b].append(cur[b])

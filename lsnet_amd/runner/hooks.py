@@ -105,10 +105,11 @@ class OptimizerHook(Hook):
             return torch.nn.utils.clip_grad_norm_(params, **self.grad_clip)   # device scalar, no .item()
 
     def after_train_iter(self, runner):
-        runner.optimizer.zero_grad(set_to_none=True)
-        runner.outputs['loss'].backward()
-        if hasattr(runner.model, 'reduce_gradients'):
-            runner.model.reduce_gradients()
+        if not runner.outputs.get('backward_done'):   # a GraphedForwardBackward step has done all of this
+            runner.optimizer.zero_grad(set_to_none=True)
+            runner.outputs['loss'].backward()
+            if hasattr(runner.model, 'reduce_gradients'):
+                runner.model.reduce_gradients()
         if self.grad_clip is not None:
             norm = self.clip_grads(runner.model.parameters())
             if norm is not None:

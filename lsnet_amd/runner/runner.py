@@ -38,6 +38,7 @@ class EpochBasedRunner:
         self.max_epochs = self.max_iters = None
         self.epoch_len = 0
         self.outputs, self.last_log = None, {}
+        self.graph_step = None     # GraphedForwardBackward when enable_hip_graph() was called
         self._buf = OrderedDict()   # name -> [sum (tensor or float), count]
 
     # ---- log buffer (device-resident sums; averaged on demand) -----------------------------
@@ -57,6 +58,23 @@ class EpochBasedRunner:
             out[k] = float(s) / n
         self._buf.clear()
         return out
+
+    def enable_hip_graph(self, warmup=3, bucket_mb=64.0):
+        """Replay forward + backward of every iteration from one captured hipGraph (runner/graph_step.py).
+        Needs static batch shapes; the data-parallel wrapper's backward hooks are bypassed (its buckets are
+        replaced by the graph step's gradient-view buckets)."""
+        from .graph_step import GraphedForwardBackward
+        if hasattr(self.model, 'reducer'):
+            for h in getattr(self.model.reducer, '_handles', []):
+                h.remove()
+        self.graph_step = GraphedForwardBackward(self.model, bucket_mb=bucket_mb, warmup=warmup)
+        return self.graph_step
+
+    def run_iter(self, batch):
+        """forward (+ backward when graphed) of one iteration; the hooks do the rest."""
+        if self.graph_step is not None:
+            return self.graph_step(batch)
+        return self.model.train_step(batch, self.optimizer)
 
     # ---- hooks -------------------------------------------------------------------------------
     def register_hook(self, hook):
@@ -114,7 +132,7 @@ class EpochBasedRunner:
         for i, batch in enumerate(data_loader):
             self.inner_iter = i
             self.call_hook('before_train_iter')
-            self.outputs = self.model.train_step(batch, self.optimizer)
+            self.outputs = self.run_iter(batch)
             if not isinstance(self.outputs, dict):
                 raise TypeError('model.train_step() must return a dict')
             if 'log_vars' in self.outputs:

@@ -144,3 +144,57 @@ def test_two_rank_data_parallel_equals_large_batch_sgd(bucket_mb):
     for k, v in ref.state_dict().items():
         assert torch.allclose(sd[0][k], v, rtol=1e-5, atol=1e-6), k
     assert torch.equal(sd[0]['unused'], torch.zeros(3))
+
+
+# ---------------------------------------------------------------------------------------------------
+# GraphedForwardBackward: without a GPU it runs its eager path -- gradient-view buckets, in-place accumulation,
+# bucket all-reduce -- which is everything except the hipGraph capture itself (covered by the gpu tests).
+def test_graph_step_matches_plain_training_on_cpu():
+    torch.manual_seed(3)
+    ref, m = Toy(), Toy()
+    m.load_state_dict(ref.state_dict())
+    data = _batches(6, 5)
+    runs = []
+    for model, graphed in ((ref, False), (m, True)):
+        opt = build_optimizer(model, dict(type='SGD', lr=0.05, momentum=0.9, weight_decay=1e-3))
+        r = EpochBasedRunner(model, optimizer=opt, logger=lambda s: None)
+        r.register_training_hooks(dict(policy='step', step=[100]), dict(grad_clip=dict(max_norm=1.0, norm_type=2)),
+                                  None, dict(interval=1000, hooks=[]))
+        if graphed:
+            gs = r.enable_hip_graph(warmup=1, bucket_mb=0.0002)
+            assert len(gs.buckets) > 1
+        r.run([data], [('train', 1)], 2)
+        runs.append(model.state_dict())
+    for k in runs[0]:
+        assert torch.allclose(runs[0][k], runs[1][k], rtol=1e-6, atol=1e-7), k
+
+
+def _graph_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.manual_seed(100 + rank)
+        model = DataParallelModel(Toy())
+        opt = build_optimizer(model, dict(type='SGD', lr=0.1, momentum=0.9))
+        r = EpochBasedRunner(model, optimizer=opt, logger=lambda s: None)
+        r.register_training_hooks(dict(policy='step', step=[100]), dict(grad_clip=dict(max_norm=35, norm_type=2)),
+                                  None, dict(interval=1000, hooks=[]))
+        r.enable_hip_graph(warmup=1)
+        r.run([_batches(5, 10 + rank)], [('train', 1)], 2)
+        torch.save({k: v.clone() for k, v in model.module.state_dict().items()},
+                   os.path.join(out_dir, f'rank{rank}.pt'))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_graph_step_equals_hooked_reducer():
+    """The graph step's bucket all-reduce gives the same training as the hook-driven reducer."""
+    world = 2
+    with tempfile.TemporaryDirectory() as d1, tempfile.TemporaryDirectory() as d2:
+        mp.spawn(_graph_worker, args=(world, _free_port(), d1), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, _free_port(), d2, 64.0), nprocs=world, join=True)
+        a = [torch.load(os.path.join(d1, f'rank{r}.pt')) for r in range(world)]
+        b = torch.load(os.path.join(d2, 'rank0.pt'))
+    for k in b:
+        assert torch.equal(a[0][k], a[1][k]), k
+        assert torch.allclose(a[0][k], b[k], rtol=1e-5, atol=1e-6), k
