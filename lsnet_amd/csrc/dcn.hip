@@ -262,7 +262,7 @@ static bool pipe_ok(const DcnArgs &a)
     if ((int64_t)a.Co * a.kh * a.kw * (a.C / a.groups) * 4 >= (int64_t)1 << 31) return false;
     for (int i = 0; i < a.nlv; ++i)
         if ((int64_t)a.lv[i].B * a.lv[i].H * a.lv[i].W * a.C * 4 >= (int64_t)1 << 31) return false;
-    return !((g_dbg_block >> 24) & 1);   // bit 24 of the debug word forces the two-workgroup variant (A/B runs)
+    return !((g_dbg_block >> 29) & 1);   // bit 29 of the debug word forces the two-workgroup variant (A/B runs)
 }
 
 static int launch_forward(const DcnArgs &a, hipStream_t st)
@@ -308,9 +308,52 @@ static int launch_bwd_data_t(const DcnArgs &a, hipStream_t st)
     return 0;
 }
 
+// windowed-scatter variant: 16x8 output patches (its own tile table), see dcn_kernels.h
+static bool bwd_win_ok(const DcnArgs &a)
+{
+    const int KD = a.kh * a.kw * a.dg, RED = (a.Co / a.groups > 64) ? 256 : 64;
+    if (bwd_win_lds_bytes(RED, KD) > 160 * 1024) return false;
+    for (int i = 0; i < a.nlv; ++i)
+        if (a.lv[i].H > 32767 || a.lv[i].W > 32767) return false;   // 15-bit packed window coordinates
+    if ((g_dbg_block >> 25) & 1) return false;   // bits 25 / 24 of the debug word force one kernel (A/B runs)
+    if ((g_dbg_block >> 24) & 1) return true;
+    // Measured in the LSNet step (profiles/): the windowed kernel wins where samples travel far and converge --
+    // the pyramid op, whose offsets are landmark vectors (3.76 vs 4.23 ms) -- and loses on the tower convolutions,
+    // whose learned offsets stay within a pixel (1.46 vs 1.33 ms: its fixed-point conversions cost more VALU time
+    // than the atomics they save).  A launch is treated as "pyramid" when any level resamples (scale != 1).
+    for (int i = 0; i < a.nlv; ++i)
+        if (a.lv[i].sh != 1.f || a.lv[i].sw != 1.f) return true;
+    return false;
+}
+
+template <int RED>
+static int launch_bwd_data_win_t(DcnArgs a, hipStream_t st)
+{
+    int tiles = 0;
+    for (int i = 0; i < a.nlv; ++i) {
+        a.lv[i].tile0 = tiles;
+        tiles += a.lv[i].B * cdiv(a.lv[i].Ho, BW3_PH) * cdiv(a.lv[i].Wo, BW3_PW);
+    }
+    a.ntiles = tiles;
+    const size_t lds = bwd_win_lds_bytes(RED, a.kh * a.kw * a.dg);
+    if (vec_ok(a)) {
+        auto k = dcn_bwd_data_win_kernel<RED, true>;
+        if (int rc = set_lds(k, lds)) return rc;
+        hipLaunchKernelGGL(k, dim3(tiles), dim3(512), lds, st, a);
+    } else {
+        auto k = dcn_bwd_data_win_kernel<RED, false>;
+        if (int rc = set_lds(k, lds)) return rc;
+        hipLaunchKernelGGL(k, dim3(tiles), dim3(512), lds, st, a);
+    }
+    LSN_HIP(hipGetLastError());
+    return 0;
+}
+
 static int launch_bwd_data(const DcnArgs &a, hipStream_t st)
 {
     ProfScope prof(PROF_BWD_DATA, a, st);
+    if (bwd_win_ok(a))
+        return (a.Co / a.groups > 64) ? launch_bwd_data_win_t<256>(a, st) : launch_bwd_data_win_t<64>(a, st);
     return (a.Co / a.groups > 64) ? launch_bwd_data_t<256>(a, st) : launch_bwd_data_t<64>(a, st);
 }
 

@@ -71,7 +71,8 @@ __device__ __forceinline__ const Lvl &find_level(const DcnArgs &a, int tile)
 
 // Sample position exactly as the oracle / reference compute it:
 //   py = float(ho*stride - pad + i*dil) * scale_h + dy     (kernel.cu:227-228, 281-282, 892-893)
-__device__ __forceinline__ Tap make_tap(const DcnArgs &a, const Lvl &L, int pix, int k, int dgi)
+// yx (optional): clamped corner rows / columns {cy0, cx0, cy1, cx1} of a sample with flags != 0
+__device__ __forceinline__ Tap make_tap_ex(const DcnArgs &a, const Lvl &L, int pix, int k, int dgi, int4 *yx)
 {
     Tap t;
     t.i00 = t.i01 = t.i10 = t.i11 = 0;
@@ -108,8 +109,14 @@ __device__ __forceinline__ Tap make_tap(const DcnArgs &a, const Lvl &L, int pix,
         t.i11 = (r1 + cx1) * a.C;
         t.flags = (int)(vy0 && vx0) | ((int)(vy0 && vx1) << 1) | ((int)(vy1 && vx0) << 2) |
                   ((int)(vy1 && vx1) << 3);
+        if (yx) *yx = make_int4(cy0, cx0, cy1, cx1);
     }
     return t;
+}
+
+__device__ __forceinline__ Tap make_tap(const DcnArgs &a, const Lvl &L, int pix, int k, int dgi)
+{
+    return make_tap_ex(a, L, pix, k, dgi, nullptr);
 }
 
 __device__ __forceinline__ void corner_weights(const Tap &t, float &b00, float &b01, float &b10, float &b11)
@@ -876,6 +883,369 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_kernel(const DcnArgs a)
                 gm *= m * (1.f - m);
             }
             L.gmsk[(size_t)b * L.msb + (size_t)(dgi * K + k) * L.msc + (size_t)ho * L.msh + (size_t)wo * L.msw] = gm;
+        }
+    }
+}
+
+// =============================================================================================
+// Backward-data with a windowed scatter (dcn_bwd_data_win_kernel).
+//
+// Same contraction as dcn_bwd_data_kernel; what changes is where the 36 scatter-adds per input element go.
+// Measured on the first kernel: 2.0 GB of memory-side writes per launch against 0.05 GB of grad_input (every fp32
+// global atomic reaches the fabric), and 13.5k of the 18k cycles of its epilogue are those atomics.  Here
+//   * a tile is a 16x8 PATCH of output pixels (8 waves x 16 pixels, 512 threads, one workgroup per CU), so the
+//     samples of its taps land in a compact window of the input map (20x12 pixels for offsets within +-1);
+//   * chunks run slab-major (all taps of a 32-channel slab, then the next slab) and the scatter of a slab is
+//     accumulated in LDS, in a [256 window pixels][32 ch] buffer of 64-bit FIXED-POINT numbers (2^-32 units) with
+//     ds_add_u64, then flushed to grad_input with one global atomic per touched element and slab: ~9x fewer
+//     global atomics.  Fixed point because LDS float atomics are unusable on gfx950: ds_add_f32 measured 1580
+//     cycles per wave-instruction against 160-180 for ds_add_u32 / ds_add_u64 (tools/ubench/lds_atomics.hip).
+//     Integer addition is also order-independent, so this part of the sum is deterministic.  Resolution 2.3e-10,
+//     range +-2.1e9 per accumulated element;
+//   * the window is the bounding box of the samples actually present (from the tap table): when the box of all
+//     taps exceeds the buffer (large learned offsets; the pyramid op, whose taps point at far-apart landmarks)
+//     each tap gets its own box and is flushed per chunk, and a tap whose own box is too large falls back to
+//     direct global atomics.  All three modes produce the same sums up to rounding.
+// MFMA row -> pixel mapping: the 4 pixels that share one scatter instruction (rows r, r+4, r+8, r+12 of a wave's
+// 16) are x-adjacent in the patch, so their window rows are adjacent and the row-parity swizzle keeps the two
+// 32-lane halves of a ds_add_u64 on disjoint banks.
+// =============================================================================================
+constexpr int BW3_PX = 128, BW3_PW = 16, BW3_PH = 8;   // patch: 16 wide x 8 high
+constexpr int BW3_WIN = 256;                            // window pixels
+constexpr int BW3_WPAR = 8;                             // ints per window descriptor: y0, x0, ww, mode, rows
+constexpr float BW3_SCALE = 4294967296.f, BW3_INV = 1.f / 4294967296.f;
+
+__host__ __device__ inline size_t bwd_win_lds_bytes(int RED, int KD)
+{
+    return (size_t)RED * 32 * 4 + (size_t)BW3_WIN * 32 * 8 + (size_t)BW3_PX * KD * (sizeof(Tap) + 12 + 4) +
+           (size_t)KD * 16 + (size_t)(KD + 1) * BW3_WPAR * 4;
+}
+
+// fp32 -> 2^-32 fixed point (round toward zero; |v| < 2^31)
+__device__ __forceinline__ long long to_fixed(float v)
+{
+    const float t = v * BW3_SCALE;                       // exact: power-of-two scaling
+    const float hi = truncf(t * BW3_INV);                // integer part of v
+    const float lo = t - hi * BW3_SCALE;                 // |lo| < 2^32, exact (Sterbenz-like: same exponent range)
+    return ((long long)(int)hi << 32) + (long long)lo;   // (long long)lo: |lo| < 2^32 fits
+}
+
+template <int RED, bool VEC>
+__global__ __launch_bounds__(512, 1) void dcn_bwd_data_win_kernel(const DcnArgs a)
+{
+    constexpr int BK = 32, QR = RED / 4;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int K = a.kh * a.kw, KD = K * a.dg;
+    float *Bs = reinterpret_cast<float *>(smem);                              // [RED][32] swizzled weight slab
+    unsigned long long *win = reinterpret_cast<unsigned long long *>(Bs + RED * BK);   // [BW3_WIN][32]
+    Tap *tab = reinterpret_cast<Tap *>(win + BW3_WIN * BK);                   // [128][KD]
+    float *gacc = reinterpret_cast<float *>(tab + BW3_PX * KD);               // [128][KD][3]  (dy, dx, mask)
+    int *wb = reinterpret_cast<int *>(gacc + BW3_PX * KD * 3);                // [128][KD] window row | dx<<16 | dy*ww<<17
+    int *bb = wb + BW3_PX * KD;                                               // [KD][4] ymin, xmin, ymax, xmax
+    int *wpar = bb + KD * 4;                                                  // [KD+1][BW3_WPAR]; entry KD = all taps
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j16 = lane & 15, kq = lane >> 4;
+    const int Cg = a.C / a.groups, Cog = a.Co / a.groups, Kdim = K * Cg;
+
+    const Lvl &L = find_level(a, blockIdx.x);
+    const int ntx = (L.Wo + BW3_PW - 1) / BW3_PW, nty = (L.Ho + BW3_PH - 1) / BW3_PH;
+    const int tl = blockIdx.x - L.tile0;
+    const int pb = tl / (ntx * nty);
+    const int trem = tl - pb * ntx * nty;
+    const int pty = trem / ntx, ptx = trem - pty * ntx;
+    // local pixel pl = y * 16 + x of the patch
+    auto pix_of = [&](int pl) {
+        const int ho = pty * BW3_PH + (pl >> 4), wo = ptx * BW3_PW + (pl & 15);
+        return (ho < L.Ho && wo < L.Wo) ? (pb * L.Ho + ho) * L.Wo + wo : L.P;
+    };
+    // MFMA row i (0..15) of wave w  ->  local pixel: x = 4 * (i & 3) + (i >> 2), y = w
+    auto pl_of = [&](int i) { return (wave << 4) + ((i & 3) << 2) + (i >> 2); };
+
+    for (int e = tid; e < KD * 4; e += 512) bb[e] = (e & 3) < 2 ? INT_MAX : INT_MIN;
+    for (int e = tid; e < BW3_WIN * BK; e += 512) win[e] = 0ull;
+    for (int e = tid; e < BW3_PX * KD * 3; e += 512) gacc[e] = 0.f;
+    __syncthreads();
+    for (int e = tid; e < BW3_PX * KD; e += 512) {
+        const int pl = e / KD, r = e - pl * KD;
+        const int dgi = r / K, k = r - dgi * K;
+        int4 yx = make_int4(0, 0, 0, 0);
+        const Tap t = make_tap_ex(a, L, pix_of(pl), k, dgi, &yx);
+        tab[e] = t;
+        wb[e] = (int)((unsigned)yx.x | ((unsigned)yx.y << 15) | ((unsigned)(yx.z - yx.x) << 30) |
+                      ((unsigned)(yx.w - yx.y) << 31));
+        if (t.flags) {
+            atomicMin(&bb[r * 4 + 0], yx.x);
+            atomicMin(&bb[r * 4 + 1], yx.y);
+            atomicMax(&bb[r * 4 + 2], yx.z);
+            atomicMax(&bb[r * 4 + 3], yx.w);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const bool off = (a.dbg_block >> 26) & 1;   // diagnostic: force direct atomics
+        int uy0 = INT_MAX, ux0 = INT_MAX, uy1 = INT_MIN, ux1 = INT_MIN;
+        for (int kd = 0; kd < KD; ++kd) {
+            const int y0 = bb[kd * 4], x0 = bb[kd * 4 + 1], y1 = bb[kd * 4 + 2], x1 = bb[kd * 4 + 3];
+            int *wp = wpar + kd * BW3_WPAR;
+            if (y0 <= y1) {
+                uy0 = min(uy0, y0), ux0 = min(ux0, x0), uy1 = max(uy1, y1), ux1 = max(ux1, x1);
+                const int hh = y1 - y0 + 1, ww = x1 - x0 + 1;
+                const bool fits = (long long)hh * ww <= BW3_WIN && !off;
+                wp[0] = y0, wp[1] = x0, wp[2] = fits ? ww : 1, wp[3] = fits ? 1 : 2, wp[4] = fits ? hh * ww : 0;
+            } else {
+                wp[0] = wp[1] = 0, wp[2] = 1, wp[3] = 1, wp[4] = 0;
+            }
+        }
+        int *up = wpar + KD * BW3_WPAR;
+        if (uy0 > uy1) {
+            up[0] = up[1] = 0, up[2] = 1, up[3] = 1, up[4] = 0;
+        } else {
+            const int hh = uy1 - uy0 + 1, ww = ux1 - ux0 + 1;
+            const bool fits = (long long)hh * ww <= BW3_WIN && !off;
+            up[0] = uy0, up[1] = ux0, up[2] = fits ? ww : 1, up[3] = fits ? 1 : 0, up[4] = fits ? hh * ww : 0;
+        }
+    }
+    __syncthreads();
+    const bool umode = wpar[KD * BW3_WPAR + 3] == 1;   // one window for all taps of a slab
+    for (int e = tid; e < BW3_PX * KD; e += 512) {
+        const int pl = e / KD, r = e - pl * KD;
+        const int *wp = wpar + (umode ? KD : r) * BW3_WPAR;
+        const unsigned v = (unsigned)wb[e];
+        const int cy0 = v & 0x7fff, cx0 = (v >> 15) & 0x7fff, dy = (v >> 30) & 1, dx = v >> 31;
+        int o = 0;
+        if (tab[e].flags && wp[3] == 1) o = ((cy0 - wp[0]) * wp[2] + (cx0 - wp[1])) | (dx << 16) | ((dy * wp[2]) << 17);
+        wb[e] = o;
+    }
+
+    const int segs = Cg / a.SL, ncc = (a.SL + BK - 1) / BK;
+    const int T = K * segs * ncc;
+    const int nrb = (Cog + RED - 1) / RED;  // reduction blocks (1 for Co/groups <= RED)
+    const bool want_off = (L.goff != nullptr) || (L.gmsk != nullptr);
+    const int cpdg = a.C / a.dg;
+
+    const int wq = tid & 7, wrow = tid >> 3;  // weight staging: float4 slot along k, 64 rows/pass
+    constexpr int NPB = (RED + 63) / 64;
+
+    const int my_pix = pix_of(pl_of(j16));  // A operand row (pixel) of this lane
+
+    float areg[QR];
+    float4 wv[NPB];
+    __syncthreads();
+
+    auto load_a = [&](int g, int rb) {
+        const int cb = rb * RED + kq * QR;
+        const bool pix_ok = my_pix < L.P;
+        const float *grow = L.gout + (size_t)(pix_ok ? my_pix : 0) * a.Co + g * Cog;
+#pragma unroll
+        for (int s4 = 0; s4 < QR / 4; ++s4) {
+            const float4 v = load4_guarded<VEC>(grow, cb + s4 * 4, Cog - (cb + s4 * 4), pix_ok);
+            areg[s4 * 4 + 0] = v.x;
+            areg[s4 * 4 + 1] = v.y;
+            areg[s4 * 4 + 2] = v.z;
+            areg[s4 * 4 + 3] = v.w;
+        }
+    };
+    // slab-major chunk walk: tap fastest, then 32-channel sub-chunk, then segment
+    struct Walk {
+        int k, cc, seg;
+    };
+    auto chunk_of = [&](const Walk &w, int g) {
+        Chunk c;
+        c.k = __builtin_amdgcn_readfirstlane(w.k);
+        c.c0 = __builtin_amdgcn_readfirstlane(w.seg * a.SL + w.cc * BK);
+        c.nval = __builtin_amdgcn_readfirstlane(min(BK, a.SL - w.cc * BK));
+        c.dgi = __builtin_amdgcn_readfirstlane((g * Cg + w.seg * a.SL) / cpdg);
+        return c;
+    };
+    auto advance = [&](Walk &w) {
+        if (++w.k == K) {
+            w.k = 0;
+            if (++w.cc == ncc) {
+                w.cc = 0;
+                ++w.seg;
+            }
+        }
+    };
+    auto load_w = [&](int g, const Chunk &ch, int rb) {
+        const float *wbase = a.w + (size_t)(g * Cog + rb * RED) * Kdim + ch.k * Cg + ch.c0;
+        const int rem = ch.nval - wq * 4;
+#pragma unroll
+        for (int ps = 0; ps < NPB; ++ps) {
+            const int row = ps * 64 + wrow;
+            const bool ok = row < RED && rb * RED + row < Cog;
+            wv[ps] = load4_guarded<VEC>(wbase + (size_t)(ok ? row : 0) * Kdim, wq * 4, rem, ok);
+        }
+    };
+    auto store_w = [&]() {
+#pragma unroll
+        for (int ps = 0; ps < NPB; ++ps) {
+            const int row = ps * 64 + wrow;
+            if (row < RED) {
+                const int sw = ((row / QR) & 1) << 4;
+                *reinterpret_cast<float4 *>(Bs + row * BK + ((wq * 4) ^ sw)) = wv[ps];
+            }
+        }
+    };
+    // window -> grad_input: elements that received something are added to global memory and cleared
+    auto flush = [&](const int *wp, int cbase, int nval) {
+        const int nrows = wp[4], ww = wp[2];
+        const int q2 = (tid & 15) * 2;
+        for (int row = tid >> 4; row < nrows; row += 32) {
+            unsigned long long *p = win + row * BK + (q2 ^ ((row & 1) << 4));
+            const long long v0 = (long long)p[0], v1 = (long long)p[1];
+            if ((v0 | v1) != 0) {
+                p[0] = 0ull;
+                p[1] = 0ull;
+                const int wy = row / ww, wx = row - wy * ww;
+                float *gp = L.gx + ((size_t)(pb * L.H + wp[0] + wy) * L.W + wp[1] + wx) * a.C + cbase + q2;
+                if (q2 + 0 < nval && v0 != 0) atomic_add_f32(gp + 0, (float)((double)v0 * (double)BW3_INV));
+                if (q2 + 1 < nval && v1 != 0) atomic_add_f32(gp + 1, (float)((double)v1 * (double)BW3_INV));
+            }
+        }
+    };
+
+    int dbg_n = 0;
+    for (int g = 0; g < a.groups; ++g) {
+        Walk wc = {0, 0, 0}, wn = {0, 0, 0};
+        if (nrb == 1) load_a(g, 0);
+        load_w(g, chunk_of(wn, g), 0);
+        advance(wn);
+        for (int t = 0; t < T; ++t) {
+            const Chunk ch = chunk_of(wc, g);
+            advance(wc);
+            const int kd = ch.dgi * K + ch.k;
+            const int *wp = wpar + (umode ? KD : kd) * BW3_WPAR;
+            const bool use_win = wp[3] == 1;
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            for (int rb = 0; rb < nrb; ++rb) {
+                if (nrb > 1) load_a(g, rb);  // Co/groups > RED: re-read the gout rows per slab
+                LSN_STAMP(2);
+                store_w();
+                LSN_STAMP(3);
+                __syncthreads();
+                LSN_STAMP(4);
+                if (rb + 1 < nrb)
+                    load_w(g, ch, rb + 1);
+                else if (t + 1 < T) {
+                    load_w(g, chunk_of(wn, g), 0);
+                    advance(wn);
+                }
+                {
+                    const int sw = (kq & 1) << 4;
+                    const float *bp = Bs + (kq * QR) * BK;
+                    const int c0i = j16 ^ sw, c1i = (16 + j16) ^ sw;
+#pragma unroll
+                    for (int s = 0; s < QR; ++s) {
+                        const float b0 = bp[s * BK + c0i];
+                        const float b1 = bp[s * BK + c1i];
+                        acc0 = mfma16(areg[s], b0, acc0);
+                        acc1 = mfma16(areg[s], b1, acc1);
+                    }
+                }
+                LSN_STAMP(5);
+                if (rb + 1 < nrb) __syncthreads();  // slab consumed; next slab may overwrite Bs
+            }
+
+            // ---- consume gcol[16 px][32 ch] of this wave: D row = 4*kq + r, col = tn*16 + j16 ----
+            float sy[4] = {0.f, 0.f, 0.f, 0.f}, sx[4] = {0.f, 0.f, 0.f, 0.f}, sm[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) {
+                const int cl = tn * 16 + j16;
+                const bool cval = cl < ch.nval;
+                const int c = g * Cg + ch.c0 + (cval ? cl : 0);
+                float xv[4][4];
+                if (want_off) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const Tap *tp = &tab[pl_of(kq * 4 + r) * KD + kd];
+                        const int4 idx = *reinterpret_cast<const int4 *>(tp);
+                        xv[r][0] = L.x[idx.x + c];
+                        xv[r][1] = L.x[idx.y + c];
+                        xv[r][2] = L.x[idx.z + c];
+                        xv[r][3] = L.x[idx.w + c];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float gval = cval ? (tn == 0 ? acc0[r] : acc1[r]) : 0.f;
+                    const int e = pl_of(kq * 4 + r) * KD + kd;
+                    const Tap tp = tab[e];
+                    float b00, b01, b10, b11;
+                    corner_weights(tp, b00, b01, b10, b11);
+                    const float gm = gval * tp.m;
+                    if (L.gx != nullptr && cval && tp.flags) {
+                        if (use_win) {
+                            const int wv0 = wb[e];
+                            const int w00 = wv0 & 0xffff, dx = (wv0 >> 16) & 1, o10 = wv0 >> 17;
+                            const int w01 = w00 + dx, w10 = w00 + o10, w11 = w10 + dx;
+                            atomicAdd(win + w00 * BK + (cl ^ ((w00 & 1) << 4)), (unsigned long long)to_fixed(b00 * gm));
+                            atomicAdd(win + w01 * BK + (cl ^ ((w01 & 1) << 4)), (unsigned long long)to_fixed(b01 * gm));
+                            atomicAdd(win + w10 * BK + (cl ^ ((w10 & 1) << 4)), (unsigned long long)to_fixed(b10 * gm));
+                            atomicAdd(win + w11 * BK + (cl ^ ((w11 & 1) << 4)), (unsigned long long)to_fixed(b11 * gm));
+                        } else {
+                            atomic_add_f32(L.gx + tp.i00 + c, b00 * gm);
+                            atomic_add_f32(L.gx + tp.i01 + c, b01 * gm);
+                            atomic_add_f32(L.gx + tp.i10 + c, b10 * gm);
+                            atomic_add_f32(L.gx + tp.i11 + c, b11 * gm);
+                        }
+                    }
+                    if (want_off) {
+                        const float hy = 1.f - tp.ly, hx = 1.f - tp.lx;
+                        const float v00 = (tp.flags & 1) ? xv[r][0] : 0.f;
+                        const float v01 = (tp.flags & 2) ? xv[r][1] : 0.f;
+                        const float v10 = (tp.flags & 4) ? xv[r][2] : 0.f;
+                        const float v11 = (tp.flags & 8) ? xv[r][3] : 0.f;
+                        // coordinate weights, kernel.cu:145-188 / 800-845
+                        const float dy = hx * (v10 - v00) + tp.lx * (v11 - v01);
+                        const float dx = hy * (v01 - v00) + tp.ly * (v11 - v10);
+                        const float bil =
+                            hy * hx * v00 + hy * tp.lx * v01 + tp.ly * hx * v10 + tp.ly * tp.lx * v11;
+                        sy[r] += gm * dy;
+                        sx[r] += gm * dx;
+                        sm[r] += gval * bil;
+                    }
+                }
+            }
+            if (want_off) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float vy = row16_sum(sy[r]), vx = row16_sum(sx[r]), vm = row16_sum(sm[r]);
+                    if (j16 == 0) {   // the row is private to this wave: plain read-modify-write
+                        float *ga = gacc + (pl_of(kq * 4 + r) * KD + kd) * 3;
+                        ga[0] += vy;
+                        ga[1] += vx;
+                        ga[2] += vm;
+                    }
+                }
+            }
+            LSN_STAMP(6);
+            __syncthreads();  // Bs free for the next chunk; this chunk's window adds are complete
+            LSN_STAMP(7);
+            if (L.gx != nullptr && use_win && (!umode || ch.k == K - 1)) flush(wp, g * Cg + ch.c0, ch.nval);
+        }
+    }
+    __syncthreads();
+
+    // ---- write grad_offset / grad_mask for this tile ----
+    for (int e = tid; e < BW3_PX * KD; e += 512) {
+        const int pl = e / KD, r = e - pl * KD;
+        const int dgi = r / K, k = r - dgi * K;
+        const int ho = pty * BW3_PH + (pl >> 4), wo = ptx * BW3_PW + (pl & 15);
+        if (ho >= L.Ho || wo >= L.Wo) continue;
+        const float *ga = gacc + e * 3;
+        if (L.goff) {
+            float *op = L.goff + (size_t)pb * L.osb + (size_t)ho * L.osh + (size_t)wo * L.osw;
+            op[(size_t)(dgi * 2 * K + 2 * k) * L.osc] = ga[0];
+            op[(size_t)(dgi * 2 * K + 2 * k + 1) * L.osc] = ga[1];
+        }
+        if (L.gmsk) {
+            float gm = ga[2];
+            if (a.msig) {  // d sigmoid: m (1 - m); out-of-range samples have ga[2] == 0 already
+                const float m = tab[e].m;
+                gm *= m * (1.f - m);
+            }
+            L.gmsk[(size_t)pb * L.msb + (size_t)(dgi * K + k) * L.msc + (size_t)ho * L.msh + (size_t)wo * L.msw] = gm;
         }
     }
 }

@@ -104,9 +104,20 @@ def _to(t, dev, cl):
     return t.contiguous(memory_format=torch.channels_last) if cl else t
 
 
+@pytest.fixture(params=['default', 'bwd_first_kernel', 'bwd_windowed_kernel'])
+def dcn_kernel_choice(request):
+    """The backward-data kernel is picked per launch by a heuristic; the parity cases run under the default choice
+    and with each of the two kernels forced (debug word bits 25 / 24, lsn_debug_phase_clocks)."""
+    from lsnet_amd import _lib
+    flag = {'default': 0, 'bwd_first_kernel': 1 << 25, 'bwd_windowed_kernel': 1 << 24}[request.param]
+    _lib.load().lsn_debug_phase_clocks(None, flag)
+    yield request.param
+    _lib.load().lsn_debug_phase_clocks(None, 0)
+
+
 @pytest.mark.parametrize('layout', ['nchw', 'nhwc'])
 @pytest.mark.parametrize('case', DCN_CASES, ids=[c['name'] for c in DCN_CASES])
-def test_dcn_forward_backward(case, layout):
+def test_dcn_forward_backward(case, layout, dcn_kernel_choice):
     from lsnet_amd import ops
     dev = _dev()
     cl = layout == 'nhwc'
