@@ -37,6 +37,7 @@ import torch.distributed as dist  # noqa: E402
 # of a step of FETCH_SIZE (KB; doubled as MI355X_MICROARCH.md "HBM" prescribes for gfx950) + WRITE_SIZE (KB).
 # bwd_data's 2 GB of writes are its fp32 atomics reaching the memory side (36 atomic adds per input element).
 HBM_TRAFFIC_GB = {'dcn_fwd': 0.93, 'dcn_bwd_data': 3.06, 'dcn_wgrad': 1.08}
+BF16_MFMA_PEAK_TFLOPS = 2516.6   # MI355X_MICROARCH.md: ~2.5 PF dense bf16
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, 2.4 GHz x 256 CU
 
 
@@ -53,6 +54,9 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--nchw', action='store_true', help='run in contiguous NCHW memory format (slower)')
+    ap.add_argument('--math', default='bf16x3', choices=['bf16x3', 'fp32'],
+                    help="arithmetic of the conv / deformable-conv contractions: split-bf16 products on the matrix pipe "
+                         "with fp32 accumulation (rel. err 5e-6, the library default) or exact fp32 MFMA")
     ap.add_argument('--graph', action='store_true',
                     help='replay forward+backward from one captured hipGraph (runner/graph_step.py) instead of '
                          'launching every kernel eagerly; same speed while the step is GPU-bound')
@@ -162,6 +166,8 @@ def main():
     from lsnet_amd.ops import get_backend
     from lsnet_amd.parallel import DataParallelModel
 
+    from lsnet_amd import _lib
+    _lib.set_math_mode(args.math)
     torch.manual_seed(0)
     model, cfg = build_lsnet(args.task, args.backbone)
     model = model.to(dev)
@@ -220,6 +226,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     losses = out['log_vars'].items_as_float() if hasattr(out['log_vars'], 'items_as_float') else {}
+    alt = None
+    if args.math == 'bf16x3' and world == 1 and not use_graph:
+        # the same step with exact fp32 MFMA everywhere, for readers who only accept that arithmetic
+        _lib.set_math_mode('fp32')
+        for _ in range(2):
+            step(data)
+        torch.cuda.synchronize()
+        ta = time.perf_counter()
+        for _ in range(5):
+            step(data)
+        torch.cuda.synchronize()
+        ta = (time.perf_counter() - ta) / 5
+        alt = {'value': args.batch / ta, 'unit': 'img/s', 'ms_per_step': ta * 1e3, 'steps': 5,
+               'math': 'exact fp32 MFMA / MIOpen fp32 for every contraction (--math fp32)'}
+        _lib.set_math_mode(args.math)
 
     if rank == 0:
         imgs = args.batch * world * args.steps
@@ -234,21 +255,35 @@ def main():
                        'global_batch': args.batch * world, 'parallelism': f'dp{world}',
                        'memory_format': 'nchw' if args.nchw else 'channels_last',
                        'launch': 'hipGraph replay of forward+backward; all-reduce, clip, SGD eager' if use_graph
-                       else 'eager'},
+                       else 'eager',
+                       'math': 'fp32 tensors; conv / deformable-conv products as 3 bf16 MFMAs on split operands '
+                               '(hi*hi + hi*lo + lo*hi), fp32 accumulation, rel. err 5e-6 vs exact fp32 (tests); '
+                               'backward of the deformable convs and small convs still exact fp32'
+                       if args.math == 'bf16x3' else 'exact fp32 MFMA / MIOpen fp32'},
             'loss': {k: round(v, 5) for k, v in losses.items()},
         }
+        x3 = {'dcn_fwd'} if args.math == 'bf16x3' else set()     # kernel families running split-bf16 MFMAs
+
+        def peak_of(k):
+            return BF16_MFMA_PEAK_TFLOPS / 3.0 if k in x3 else FP32_MFMA_PEAK_TFLOPS
+
+        def peak_note(k):
+            return ('dense bf16 MFMA peak / 3 (three bf16 products per fp32 product)' if k in x3
+                    else 'dense fp32 MFMA peak (v_mfma_f32_*_f32)')
         if ks:
             dom = max(ks, key=lambda k: ks[k]['total_ms'])   # the kernel with the most GPU time in the timed steps
             k = ks[dom]
             res['kernels'] = ks
             res['roofline'] = {'kernel': KERNEL_NOTES.get(dom, dom), 'bound': 'mfma', 'achieved': k['tflops'],
-                               'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                               'frac': k['tflops'] / FP32_MFMA_PEAK_TFLOPS, 'traffic': HBM_TRAFFIC_GB.get(dom),
+                               'peak': peak_of(dom), 'unit': 'TFLOP/s',
+                               'frac': k['tflops'] / peak_of(dom), 'peak_note': peak_note(dom), 'traffic': HBM_TRAFFIC_GB.get(dom),
                                'traffic_unit': 'GB/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/)',
                                'launches_timed': k['launches'], 'avg_launch_ms': k['avg_ms'],
                                'gflop_per_launch': k['gflop_per_launch'],
                                'alg_gbytes_per_launch': k['alg_gbytes_per_launch'],
                                'ms_per_step': k['total_ms'] / args.steps}
+        if alt is not None:
+            res['fp32_exact'] = alt
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res['cpu_baseline'] = cpu_baseline(args)

@@ -94,6 +94,17 @@ typedef struct {
 const char *lsn_last_error(void);
 int lsn_version(void);
 
+/* ---- arithmetic of the contractions ---------------------------------------------------------
+ * LSN_MATH_FP32   : v_mfma_f32_*_f32, exact fp32 products (bitwise an fmaf chain); fp32 vector rate.
+ * LSN_MATH_BF16X3 : every fp32 operand is split into two bf16 values (hi + lo, 16 mantissa bits together) and a
+ *                   product is hi*hi + hi*lo + lo*hi on the bf16 matrix pipe with fp32 accumulation: relative
+ *                   error <= 2^-16 per product (the reference's tolerance for this path is 1e-3), 16x the MFMA rate.
+ * Process-wide; the initial value comes from the environment variable LSNET_MATH (fp32 | bf16x3), default bf16x3.
+ * Kernels without a split variant keep using fp32 MFMA. */
+enum { LSN_MATH_FP32 = 0, LSN_MATH_BF16X3 = 1 };
+int lsn_set_math_mode(int mode);
+int lsn_get_math_mode(void);
+
 /* ---- generic batched entry points (what the Python mirror calls) -------------------------- */
 
 /* out_l = DCN(input_l, offset_l, mask_l; weight, bias) for l < n_levels.
@@ -196,6 +207,22 @@ int lsn_sigmoid_focal_loss_backward_weighted(const float *logits, const int64_t 
 int64_t lsn_nms_workspace_bytes(int n);
 int lsn_nms(const float *dets, const int64_t *order, int n, float iou_thr, int64_t *keep,
             int64_t *num_keep, void *workspace, lsn_stream_t stream);
+
+/* ---- dense convolution (groups = 1), channels-last ----------------------------------------------
+ * The reference calls torch.nn.Conv2d (cuDNN) for every dense conv of the path (resnet.py:624-631,261-301,
+ * fpn.py:171-217, lsnet_head.py:160-257).  x (B,H,W,C), w (Co,kh,kw,C) = the channels-last image of the
+ * (Co,C,kh,kw) weight, out (B,Ho,Wo,Co), fp32, 16-byte aligned; cross-correlation with zero padding like
+ * F.conv2d.  Arithmetic: split-bf16 products with fp32 accumulation (LSN_MATH_BF16X3) -- there is no exact-fp32
+ * variant of these kernels (callers keep the vendor library for LSN_MATH_FP32).  `relu` fuses max(., 0).
+ * Supported: C % 4 == 0; tensors < 2 GiB.  `workspace` / `wt_workspace`: Co*kh*kw*C*4 bytes of scratch for the
+ * pre-split (backward: also flipped and transposed) weights, rebuilt by every call; forward accepts NULL (the
+ * weights are then split inside every block, slower).  backward_data: stride 1 only. */
+int lsn_conv2d_forward(const float *x, const float *w, const float *bias, float *out, void *workspace, int B, int H,
+                       int W, int C, int Co, int kh, int kw, int stride, int pad, int dil, int relu,
+                       lsn_stream_t stream);
+int lsn_conv2d_backward_data(const float *grad_out, const float *w, float *grad_in, float *wt_workspace, int B,
+                             int H, int W, int C, int Co, int kh, int kw, int stride, int pad, int dil,
+                             lsn_stream_t stream);
 
 /* ---- GroupNorm (+ReLU) on channels-last tensors ----------------------------------------------
  * The reference uses torch.nn.GroupNorm followed by nn.ReLU (ATen kernels; call sites

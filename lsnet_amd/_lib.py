@@ -56,6 +56,7 @@ EXPORTS = [
     'lsn_nms_workspace_bytes', 'lsn_nms', 'lsn_selftest_mfma', 'lsn_debug_phase_clocks',
     'lsn_prof_enable', 'lsn_prof_read',
     'lsn_group_norm_workspace_bytes', 'lsn_group_norm_forward', 'lsn_group_norm_backward',
+    'lsn_set_math_mode', 'lsn_get_math_mode', 'lsn_conv2d_forward', 'lsn_conv2d_backward_data',
 ]
 
 _lib = None
@@ -101,3 +102,15 @@ def prof_read():
         check(n)
     return {arr[i].name.decode(): dict(launches=int(arr[i].launches), total_ms=arr[i].total_ms,
                                        flops=arr[i].flops, bytes=arr[i].bytes) for i in range(n)}
+
+
+MATH_FP32, MATH_BF16X3 = 0, 1
+
+
+def set_math_mode(mode):
+    """'fp32' (exact fp32 MFMA) or 'bf16x3' (split-bf16 products, fp32 accumulation); see include/lsnet_hip.h."""
+    check(load().lsn_set_math_mode({'fp32': MATH_FP32, 'bf16x3': MATH_BF16X3}[mode] if isinstance(mode, str) else mode))
+
+
+def get_math_mode():
+    return 'bf16x3' if load().lsn_get_math_mode() == MATH_BF16X3 else 'fp32'

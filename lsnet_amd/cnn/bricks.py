@@ -6,11 +6,12 @@ import warnings
 import torch.nn as nn
 from torch.nn.modules.batchnorm import _BatchNorm
 
+from ..ops.conv import Conv2d
 from ..ops.group_norm import GroupNorm
 from .registry import ACTIVATION_LAYERS, CONV_LAYERS, NORM_LAYERS
 
-CONV_LAYERS.register_module('Conv2d', module=nn.Conv2d)
-CONV_LAYERS.register_module('Conv', module=nn.Conv2d)
+CONV_LAYERS.register_module('Conv2d', module=Conv2d)
+CONV_LAYERS.register_module('Conv', module=Conv2d)
 NORM_LAYERS.register_module('BN', module=nn.BatchNorm2d)
 NORM_LAYERS.register_module('BN2d', module=nn.BatchNorm2d)
 NORM_LAYERS.register_module('SyncBN', module=nn.SyncBatchNorm)

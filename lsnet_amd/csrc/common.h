@@ -48,6 +48,30 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c)
 
 __device__ __forceinline__ int mfma32_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
+// ---- split-bf16 ("bf16x3") products on the matrix pipe ------------------------------------------------
+// fp32 MFMA runs on the same ALUs as fp32 VALU work at 1/16 of the bf16 MFMA rate (MI355X_MICROARCH.md).  A
+// product a*b of fp32 numbers is instead computed as a_hi*b_hi + a_hi*b_lo + a_lo*b_hi with a = a_hi + a_lo
+// split into two bf16 values (8 + 8 mantissa bits) and fp32 accumulation: relative error <= 2^-16 per product
+// (the dropped a_lo*b_lo term and the 2^-17 truncation of each operand), on v_mfma_f32_32x32x16_bf16.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// A: lane l holds row (l & 31), k = 8 (l >> 5) .. + 7;  B: column (l & 31), same k;  D as the fp32 32x32 form
+__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// (v0, v1) -> packed bf16 pairs hi = bf16(v), lo = bf16(v - hi); element 0 in the low half-word
+__device__ __forceinline__ void split_bf16x2(float v0, float v1, unsigned &hi, unsigned &lo)
+{
+    const bf16x2 h = {(__bf16)v0, (__bf16)v1};
+    hi = __builtin_bit_cast(unsigned, h);
+    const float h0 = __uint_as_float(hi << 16), h1 = __uint_as_float(hi & 0xffff0000u);
+    const bf16x2 l = {(__bf16)(v0 - h0), (__bf16)(v1 - h1)};
+    lo = __builtin_bit_cast(unsigned, l);
+}
+
 // hardware fp32 atomic add without return (global_atomic_add_f32), device scope
 __device__ __forceinline__ void atomic_add_f32(float *p, float v) { unsafeAtomicAdd(p, v); }
 

@@ -1,0 +1,389 @@
+// Dense 2-D convolution (groups = 1) on channels-last fp32 tensors as an implicit GEMM on the bf16 matrix pipe
+// with split operands (common.h: a*b = a_hi*b_hi + a_hi*b_lo + a_lo*b_hi, fp32 accumulation).
+//
+// The reference runs torch.nn.Conv2d = cuDNN for every dense conv of the path (backbone resnet.py:624-631,
+// 261-301; neck fpn.py:171-217; head lsnet_head.py:160-257).  On MI355X fp32 MFMA runs at the fp32 vector rate
+// (157 TF, 1/16 of the bf16 rate), so an exact-fp32 GEMM tops out near 100 TF in practice (MIOpen's igemm kernels
+// measure 38-117 TF on these shapes, tools/bench_convs.py).  This kernel keeps fp32 tensors in memory, splits
+// both operands into bf16 hi/lo pairs while staging them into LDS and issues three bf16 MFMAs per product term:
+// 2^-16 relative error per product (parity bar of the path: 1e-3), 24 MFMAs of 32 cycles per 64x64x32 wave tile.
+//
+//   forward      : out[p][co] = sum_{tap, ci} x[p @ tap][ci] * w[co][tap][ci] (+ bias)
+//   backward-data: the same kernel on grad_output with the weights transposed and flipped (stride 1)
+//   backward-weight: conv_wgrad_x3_kernel, reduction over pixels with px-contiguous LDS images
+//
+// Tiling: block = BM output pixels x BN output channels, BM + BN = 320, four waves each owning a 64x64 tile
+// (1x4, 2x2 or 4x1 waves); chunk = one tap x 32 input channels; software pipeline over chunks exactly as
+// dcn_fwd_x3_kernel: MFMAs of chunk t, LDS commit of chunk t+1, global-load issue of chunk t+2, one staging
+// slice in every MFMA gap.  LDS rows are 32 bf16 + 16 B pad (80 B) so the 16-byte operand reads are conflict free.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/lsnet_hip.h"
+#include "common.h"
+
+namespace lsn {
+
+struct ConvArgs {
+    const float *x, *w, *bias;
+    float *out;
+    int B, H, W, C, Ho, Wo, Co, kh, kw, stride, pad, dil;
+    int P;   // B * Ho * Wo
+    int relu;
+    const unsigned short *wp;   // prepared weights: bf16 hi plane [Co][K][C] followed by the lo plane, or NULL
+};
+
+constexpr int CV_RS = 80;   // LDS row stride in bytes
+
+__device__ __forceinline__ float2 cv_load2(__amdgpu_buffer_rsrc_t rs, int voff, int soff)
+{
+    auto v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+    float2 f;
+    __builtin_memcpy(&f, &v, 8);
+    return f;
+}
+__device__ __forceinline__ float4 cv_load4(__amdgpu_buffer_rsrc_t rs, int voff, int soff)
+{
+    auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+    float4 f;
+    __builtin_memcpy(&f, &v, 16);
+    return f;
+}
+
+// PREP: the weights arrive already split (conv_prepare_kernel): their staging is a 16-byte copy per slice
+template <int BM, int BN, bool PREP>
+__global__ __launch_bounds__(256, 1) void conv_fwd_x3_kernel(const ConvArgs a)
+{
+    constexpr int WM = BM / 64, WN = BN / 64, RS = CV_RS, BK = 32;
+    static_assert(WM * WN == 4, "four waves of 64x64");
+    constexpr int NPA = BM / 16, NPB = BN / 32, NS = NPA + NPB;   // staging slices per chunk (12 .. 18)
+    constexpr int PLANE_A = BM * RS, PLANE_B = BN * RS, BUF = 2 * PLANE_A + 2 * PLANE_B;
+    extern __shared__ __align__(16) unsigned char smem[];   // 2 x [A hi][A lo][B hi][B lo]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int K = a.kh * a.kw, Kdim = K * a.C;
+    const int tile_p = blockIdx.x * BM;
+    const int co_blk = blockIdx.y * BN;
+    const int nco = min(BN, a.Co - co_blk);
+    const int ncc = (a.C + BK - 1) / BK;
+    const int T = K * ncc;
+
+    const int kk2 = tid & 15, prow = tid >> 4;   // gather: channel pair, pixel row (16 rows per pass)
+    const int wq = tid & 7, wrow = tid >> 3;     // weights: float4 slot along ci, co row (32 rows per pass)
+
+    const __amdgpu_buffer_rsrc_t xrs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x), 0, a.B * a.H * a.W * a.C * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs =
+        PREP ? __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(a.wp), 0, a.Co * Kdim * 4, 0x00020000)
+             : __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.w), 0, a.Co * Kdim * 4, 0x00020000);
+    constexpr int OOB = 0x7ffffff0;   // beyond num_records: the buffer load returns 0
+    // PREP staging: slice ps covers plane (ps & 1), rows (ps >> 1) * 64 + (tid >> 2), 16-byte slot (tid & 3)
+    const int pq = tid & 3, prw = tid >> 2;
+
+    // per gather pass: top-left input coordinate of the pixel's receptive field and its image base
+    int iy0[NPA], ix0[NPA], ibase[NPA];
+#pragma unroll
+    for (int ps = 0; ps < NPA; ++ps) {
+        const int p = tile_p + ps * 16 + prow;
+        const bool ok = p < a.P;
+        const int HWo = a.Ho * a.Wo;
+        const int b = ok ? p / HWo : 0, rem = ok ? p - b * HWo : 0;
+        const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+        iy0[ps] = ok ? ho * a.stride - a.pad : -0x40000000;   // an invalid pixel is out of range for every tap
+        ix0[ps] = wo * a.stride - a.pad;
+        ibase[ps] = b * a.H * a.W;
+    }
+    int wvoff[NPB];
+#pragma unroll
+    for (int ps = 0; ps < NPB; ++ps) {
+        if (PREP) {
+            const int col = (ps >> 1) * 64 + prw;
+            wvoff[ps] = (col < nco) ? ((ps & 1) * a.Co * Kdim + (co_blk + col) * Kdim) * 2 + pq * 16 : OOB;
+        } else {
+            const int col = ps * 32 + wrow;
+            wvoff[ps] = (col < nco) ? ((co_blk + col) * Kdim + wq * 4) * 4 : OOB;
+        }
+    }
+
+    float2 xv[NPA];
+    float4 wv[NPB];
+    // chunk t = (tap k, channel slab cc): k = t / ncc walked incrementally
+    struct Ck {
+        int i, j, cc;
+    };
+    auto next = [&](Ck &c) {
+        if (++c.cc == ncc) {
+            c.cc = 0;
+            if (++c.j == a.kw) {
+                c.j = 0;
+                ++c.i;
+            }
+        }
+    };
+    auto issue_x = [&](const Ck &c, int ps) {
+        const int y = iy0[ps] + c.i * a.dil, x = ix0[ps] + c.j * a.dil;
+        const bool ok = (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W && c.cc * BK + 2 * kk2 < a.C;
+        const int voff = ok ? ((ibase[ps] + y * a.W + x) * a.C + c.cc * BK + 2 * kk2) * 4 : OOB;
+        xv[ps] = cv_load2(xrs, voff, 0);
+    };
+    auto issue_w = [&](const Ck &c, int ps) {
+        if (PREP) {   // columns past C hold the next tap's values; the A operand is zero there
+            wv[ps] = cv_load4(wrs, wvoff[ps], ((c.i * a.kw + c.j) * a.C + c.cc * BK) * 2);
+        } else {
+            const bool ok = c.cc * BK + wq * 4 < a.C;
+            wv[ps] = cv_load4(wrs, ok ? wvoff[ps] : OOB, ((c.i * a.kw + c.j) * a.C + c.cc * BK) * 4);
+        }
+    };
+    auto commit_x = [&](int ps, unsigned char *buf) {
+        unsigned hi, lo;
+        split_bf16x2(xv[ps].x, xv[ps].y, hi, lo);
+        unsigned char *p = buf + (ps * 16 + prow) * RS + kk2 * 4;
+        *reinterpret_cast<unsigned *>(p) = hi;
+        *reinterpret_cast<unsigned *>(p + PLANE_A) = lo;
+    };
+    auto commit_w = [&](int ps, unsigned char *buf) {
+        if (PREP) {
+            unsigned char *p = buf + 2 * PLANE_A + (ps & 1) * PLANE_B + ((ps >> 1) * 64 + prw) * RS + pq * 16;
+            *reinterpret_cast<float4 *>(p) = wv[ps];
+            return;
+        }
+        uint2 hi, lo;
+        split_bf16x2(wv[ps].x, wv[ps].y, hi.x, lo.x);
+        split_bf16x2(wv[ps].z, wv[ps].w, hi.y, lo.y);
+        unsigned char *p = buf + 2 * PLANE_A + (ps * 32 + wrow) * RS + wq * 8;
+        *reinterpret_cast<uint2 *>(p) = hi;
+        *reinterpret_cast<uint2 *>(p + PLANE_B) = lo;
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- prologue: chunk 0 -> buffer 0, loads of chunk 1 in flight ----
+    Ck c1 = {0, 0, 0}, c2 = {0, 0, 0};
+    {
+#pragma unroll
+        for (int ps = 0; ps < NPA; ++ps) issue_x(c1, ps);
+#pragma unroll
+        for (int ps = 0; ps < NPB; ++ps) issue_w(c1, ps);
+#pragma unroll
+        for (int ps = 0; ps < NPA; ++ps) commit_x(ps, smem);
+#pragma unroll
+        for (int ps = 0; ps < NPB; ++ps) commit_w(ps, smem);
+        if (T > 1) next(c1);
+        c2 = c1;
+        if (T > 2) next(c2);
+#pragma unroll
+        for (int ps = 0; ps < NPA; ++ps) issue_x(c1, ps);
+#pragma unroll
+        for (int ps = 0; ps < NPB; ++ps) issue_w(c1, ps);
+    }
+    __syncthreads();
+
+    for (int t = 0; t < T; ++t) {
+        const int cur = t & 1;
+        const unsigned char *bc = smem + cur * BUF;
+        unsigned char *bn = smem + (cur ^ 1) * BUF;
+        // registers hold chunk t+1 (to commit); c2 = chunk t+2 (to issue); both saturate at the last chunk
+        const unsigned char *ap = bc + (wm * 64 + (lane & 31)) * RS + (lane >> 5) * 16;
+        const unsigned char *bp = bc + 2 * PLANE_A + (wn * 64 + (lane & 31)) * RS + (lane >> 5) * 16;
+        bf16x8 Ah[2][2], Al[2][2], Bh[2][2], Bl[2][2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                Ah[ks][i] = *reinterpret_cast<const bf16x8 *>(ap + i * 32 * RS + ks * 32);
+                Bh[ks][i] = *reinterpret_cast<const bf16x8 *>(bp + i * 32 * RS + ks * 32);
+                Al[ks][i] = *reinterpret_cast<const bf16x8 *>(ap + PLANE_A + i * 32 * RS + ks * 32);
+                Bl[ks][i] = *reinterpret_cast<const bf16x8 *>(bp + PLANE_B + i * 32 * RS + ks * 32);
+            }
+        // 24 MFMAs, NS staging slice pairs (commit, issue) spread over the gaps
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int prod = 0; prod < 3; ++prod)
+#pragma unroll
+                for (int ij = 0; ij < 4; ++ij) {
+                    const int i = ij >> 1, j = ij & 1;
+                    const int gap = ks * 12 + prod * 4 + ij;
+                    const bf16x8 av = (prod == 2) ? Al[ks][i] : Ah[ks][i];
+                    const bf16x8 bv = (prod == 1) ? Bl[ks][j] : Bh[ks][j];
+                    acc[i][j] = mfma_bf16(av, bv, acc[i][j]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    // slices s in [gap*NS/24, (gap+1)*NS/24): x slices first, then weight slices
+#pragma unroll
+                    for (int s = gap * NS / 24; s < (gap + 1) * NS / 24; ++s) {
+                        if (s < NPA) {
+                            commit_x(s, bn);
+                            issue_x(c2, s);
+                        } else {
+                            commit_w(s - NPA, bn);
+                            issue_w(c2, s - NPA);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        if (t + 3 < T) next(c2);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = wn * 64 + j * 32 + (lane & 31);
+            if (col >= nco) continue;
+            const float bv = a.bias ? a.bias[co_blk + col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int pix = tile_p + wm * 64 + i * 32 + mfma32_row(r, lane);
+                if (pix < a.P) {
+                    float v = acc[i][j][r] + bv;
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    a.out[(size_t)pix * a.Co + co_blk + col] = v;
+                }
+            }
+        }
+}
+
+// w (Co, kh, kw, C) -> wt (C, kh, kw, Co) with both kernel axes flipped: the weights of the transposed conv
+__global__ void conv_flip_transpose_kernel(const float *w, float *wt, int Co, int K, int C)
+{
+    const size_t n = (size_t)Co * K * C;
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const int co = (int)(e % Co);
+        const size_t r = e / Co;
+        const int k = (int)(r % K), ci = (int)(r / K);
+        wt[e] = w[((size_t)co * K + (K - 1 - k)) * C + ci];
+    }
+}
+
+// w (n floats) -> bf16 hi plane (n) followed by the lo plane (n).  flipT: source is (Co, K, C) and the destination
+// is the transposed-conv weight (C, K, Co) with the taps reversed.
+__global__ void conv_prepare_kernel(const float *w, unsigned short *out, int Co, int K, int C, int flipT)
+{
+    const size_t n = (size_t)Co * K * C;
+    for (size_t e = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) * 2; e < n; e += (size_t)gridDim.x * blockDim.x * 2) {
+        float v[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const size_t d = e + q;
+            if (!flipT) {
+                v[q] = w[d];
+            } else {
+                const int co = (int)(d % Co);
+                const size_t r = d / Co;
+                const int k = (int)(r % K), ci = (int)(r / K);
+                v[q] = w[((size_t)co * K + (K - 1 - k)) * C + ci];
+            }
+        }
+        unsigned hi, lo;
+        split_bf16x2(v[0], v[1], hi, lo);
+        *reinterpret_cast<unsigned *>(out + e) = hi;
+        *reinterpret_cast<unsigned *>(out + n + e) = lo;
+    }
+}
+
+template <int BM, int BN>
+static int launch_conv(const ConvArgs &a, hipStream_t st)
+{
+    const size_t lds = (size_t)2 * 2 * (BM + BN) * CV_RS;
+    if (a.wp) {
+        auto k = conv_fwd_x3_kernel<BM, BN, true>;
+        LSN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        dim3 grid((a.P + BM - 1) / BM, (a.Co + BN - 1) / BN);
+        hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a);
+        LSN_HIP(hipGetLastError());
+        return 0;
+    }
+    auto k = conv_fwd_x3_kernel<BM, BN, false>;
+    LSN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dim3 grid((a.P + BM - 1) / BM, (a.Co + BN - 1) / BN);
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a);
+    LSN_HIP(hipGetLastError());
+    return 0;
+}
+
+static int conv_forward(const ConvArgs &a, hipStream_t st)
+{
+    // the block is four 64x64 wave tiles: 1x4 for wide layers, 2x2 for 128 output channels, 4x1 for 64
+    if (a.Co <= 64) return launch_conv<256, 64>(a, st);
+    if (a.Co <= 128) return launch_conv<128, 128>(a, st);
+    return launch_conv<64, 256>(a, st);
+}
+
+static int conv_check(int B, int H, int W, int C, int Co, int kh, int kw, int stride, int pad, int dil, int *Ho,
+                      int *Wo)
+{
+    LSN_CHECK(B > 0 && H > 0 && W > 0 && C > 0 && Co > 0 && kh > 0 && kw > 0, "conv2d: empty tensor");
+    LSN_CHECK(stride > 0 && dil > 0 && pad >= 0, "conv2d: bad stride / dilation / padding");
+    if (C % 4 != 0) return fail(LSN_ERR_UNSUPPORTED, "conv2d kernel needs C %% 4 == 0, got %d", C);
+    *Ho = (H + 2 * pad - (dil * (kh - 1) + 1)) / stride + 1;
+    *Wo = (W + 2 * pad - (dil * (kw - 1) + 1)) / stride + 1;
+    LSN_CHECK(*Ho > 0 && *Wo > 0, "conv2d: output size is too small");
+    if ((int64_t)B * H * W * C * 4 >= ((int64_t)1 << 31) || (int64_t)Co * kh * kw * C * 4 >= ((int64_t)1 << 31) ||
+        (int64_t)B * *Ho * *Wo * Co * 4 >= ((int64_t)1 << 31))
+        return fail(LSN_ERR_UNSUPPORTED, "conv2d: tensor too large for 32-bit buffer offsets");
+    return 0;
+}
+
+}  // namespace lsn
+
+extern "C" {
+
+int lsn_conv2d_forward(const float *x, const float *w, const float *bias, float *out, void *workspace, int B, int H,
+                       int W, int C, int Co, int kh, int kw, int stride, int pad, int dil, int relu,
+                       lsn_stream_t stream)
+{
+    using namespace lsn;
+    LSN_CHECK(x && w && out, "conv2d: NULL argument");
+    ConvArgs a = {};
+    if (int rc = conv_check(B, H, W, C, Co, kh, kw, stride, pad, dil, &a.Ho, &a.Wo)) return rc;
+    a.x = x, a.w = w, a.bias = bias, a.out = out;
+    if (workspace && C % 8 == 0) {   // split the weights once instead of in every block
+        hipLaunchKernelGGL(conv_prepare_kernel, dim3(512), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w,
+                           reinterpret_cast<unsigned short *>(workspace), Co, kh * kw, C, 0);
+        a.wp = reinterpret_cast<const unsigned short *>(workspace);
+    }
+    a.B = B, a.H = H, a.W = W, a.C = C, a.Co = Co, a.kh = kh, a.kw = kw, a.stride = stride, a.pad = pad, a.dil = dil;
+    a.P = B * a.Ho * a.Wo;
+    a.relu = relu;
+    return conv_forward(a, reinterpret_cast<hipStream_t>(stream));
+}
+
+int lsn_conv2d_backward_data(const float *grad_out, const float *w, float *grad_in, float *wt_workspace, int B,
+                             int H, int W, int C, int Co, int kh, int kw, int stride, int pad, int dil,
+                             lsn_stream_t stream)
+{
+    using namespace lsn;
+    LSN_CHECK(grad_out && w && grad_in && wt_workspace, "conv2d backward: NULL argument");
+    if (stride != 1) return fail(LSN_ERR_UNSUPPORTED, "conv2d backward-data kernel handles stride 1 only");
+    int Ho, Wo;
+    if (int rc = conv_check(B, H, W, C, Co, kh, kw, stride, pad, dil, &Ho, &Wo)) return rc;
+    if (Co % 4 != 0) return fail(LSN_ERR_UNSUPPORTED, "conv2d backward-data kernel needs Co %% 4 == 0");
+    const int padT_h = dil * (kh - 1) - pad, padT_w = dil * (kw - 1) - pad;
+    if (padT_h != padT_w || padT_h < 0)
+        return fail(LSN_ERR_UNSUPPORTED, "conv2d backward-data kernel needs a square, non-negative transposed padding");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int K = kh * kw;
+    ConvArgs a = {};
+    if (Co % 8 == 0) {
+        hipLaunchKernelGGL(conv_prepare_kernel, dim3(512), dim3(256), 0, st, w,
+                           reinterpret_cast<unsigned short *>(wt_workspace), Co, K, C, 1);
+        a.wp = reinterpret_cast<const unsigned short *>(wt_workspace);
+    } else {
+        hipLaunchKernelGGL(conv_flip_transpose_kernel, dim3(256), dim3(256), 0, st, w, wt_workspace, Co, K, C);
+    }
+    a.x = grad_out, a.w = wt_workspace, a.bias = nullptr, a.out = grad_in;
+    a.B = B, a.H = Ho, a.W = Wo, a.C = Co, a.Co = C, a.kh = kh, a.kw = kw, a.stride = 1, a.pad = padT_h, a.dil = dil;
+    a.Ho = H, a.Wo = W;
+    a.P = B * H * W;
+    return conv_forward(a, st);
+}
+
+}  // extern "C"

@@ -4,6 +4,7 @@
 #include <limits.h>
 #include <string.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <cstdio>
 #include <vector>
@@ -26,6 +27,17 @@ int fail(int code, const char *fmt, ...)
 // optional phase-clock capture (diagnostics only; see lsn_debug_phase_clocks)
 static long long *g_dbg_buf = nullptr;
 static int g_dbg_block = 0;
+
+// arithmetic of the implicit-GEMM contractions: exact fp32 MFMA, or split-bf16 products (common.h)
+static int g_math_mode = -1;   // -1: not initialised (LSNET_MATH decides at first use)
+static int math_mode()
+{
+    if (g_math_mode < 0) {
+        const char *e = getenv("LSNET_MATH");
+        g_math_mode = (e && (!strcmp(e, "fp32") || !strcmp(e, "exact"))) ? LSN_MATH_FP32 : LSN_MATH_BF16X3;
+    }
+    return g_math_mode;
+}
 
 // ---- per-kernel launch timing (lsn_prof_*): HIP events recorded on the launch stream around each
 // deformable-conv kernel, so bench.py can quote a kernel's own average duration live.
@@ -271,8 +283,16 @@ static int launch_forward(const DcnArgs &a, hipStream_t st)
         ProfScope prof(PROF_FWD, a, st);
         return (a.Co / a.groups <= 64) ? launch_forward_t<64, 64, 2, 2>(a, st) : launch_forward_t<64, 256, 1, 4>(a, st);
     }
-    const size_t lds = pipe_lds_bytes(a);
     dim3 grid(a.ntiles, cdiv(a.Co / a.groups, PIPE_BN), a.groups);
+    if (math_mode() == LSN_MATH_BF16X3 && x3_lds_bytes(a.kh * a.kw * a.dg) <= 160 * 1024) {
+        ProfScope prof(PROF_FWD, a, st);
+        const size_t lds3 = x3_lds_bytes(a.kh * a.kw * a.dg);
+        if (int rc = set_lds(dcn_fwd_x3_kernel, lds3)) return rc;
+        hipLaunchKernelGGL(dcn_fwd_x3_kernel, grid, dim3(256), lds3, st, a);
+        LSN_HIP(hipGetLastError());
+        return 0;
+    }
+    const size_t lds = pipe_lds_bytes(a);
     auto go = [&](auto kern) -> int {
         if (int rc = set_lds(kern, lds)) return rc;
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
@@ -560,6 +580,15 @@ int lsn_debug_phase_clocks(long long *device_buf_512, int block)
     return 0;
 }
 int lsn_version(void) { return 100; }
+
+int lsn_set_math_mode(int mode)
+{
+    LSN_CHECK(mode == LSN_MATH_FP32 || mode == LSN_MATH_BF16X3, "unknown math mode %d", mode);
+    lsn::g_math_mode = mode;
+    return 0;
+}
+
+int lsn_get_math_mode(void) { return lsn::math_mode(); }
 
 int lsn_prof_enable(int on)
 {

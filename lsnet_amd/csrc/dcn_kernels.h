@@ -430,6 +430,15 @@ __device__ __forceinline__ float4 buf_load_f32x4(__amdgpu_buffer_rsrc_t rs, int 
     return f;
 }
 
+__device__ __forceinline__ float2 buf_load_f32x2(__amdgpu_buffer_rsrc_t rs, int voff, int soff)
+{
+    auto v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+    static_assert(sizeof(v) == 8, "b64");
+    float2 f;
+    __builtin_memcpy(&f, &v, 8);
+    return f;
+}
+
 constexpr int PIPE_BM = 64, PIPE_BN = 256, PIPE_BK = 32, PIPE_LDK = 36;
 
 // ABL (diagnostic builds of the same kernel): bit 0 drops the LDS commits, bit 1 the global-load issues
@@ -643,6 +652,239 @@ __global__ __launch_bounds__(256, 1) void dcn_fwd_pipe_kernel(const DcnArgs a)
         }
         LSN_STAMP(6);
         __syncthreads();  // everyone finished reading buf[cur] and writing buf[cur^1]
+        LSN_STAMP(7);
+    }
+
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = wn * 64 + j * 32 + (lane & 31);
+            if (col >= nco) continue;
+            const float bv = a.bias ? a.bias[co_base + col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int pix = tile_p + i * 32 + mfma32_row(r, lane);
+                if (pix < L.P) L.out[(size_t)pix * a.Co + co_base + col] = acc[i][j][r] + bv;
+            }
+        }
+}
+
+// =============================================================================================
+// Forward on the bf16 matrix pipe with split operands (dcn_fwd_x3_kernel).
+//
+// Same tiling and software pipeline as dcn_fwd_pipe_kernel (64 px x 256 co, one workgroup per CU, chunk t's
+// MFMAs interleaved with the LDS commit of chunk t+1 and the load issue of chunk t+2), but the blended samples and
+// the weights are split into bf16 hi/lo pairs while they are staged and multiplied as hi*hi + hi*lo + lo*hi on
+// v_mfma_f32_32x32x16_bf16 (common.h).  24 MFMAs of 32 cycles per chunk instead of 64 of 64, and the VALU work
+// of the staging now overlaps them (the bf16 pipe is separate from the fp32 ALUs).
+// LDS rows: 32 k-values = 64 B of bf16 + 16 B pad (stride 80 B: the 16-byte operand reads of a lane group hit
+// all 64 banks exactly once).  hi and lo planes are separate arrays.
+// =============================================================================================
+constexpr int X3_RS = 80;   // LDS row stride, bytes
+
+__host__ __device__ inline size_t x3_lds_bytes(int KD)
+{
+    return (size_t)2 * 2 * (PIPE_BM + PIPE_BN) * X3_RS + (size_t)PIPE_BM * KD * sizeof(Tap);
+}
+
+__global__ __launch_bounds__(256, 1) void dcn_fwd_x3_kernel(const DcnArgs a)
+{
+    constexpr int BM = PIPE_BM, BN = PIPE_BN, BK = PIPE_BK, RS = X3_RS;
+    constexpr int NPA = BM / 16, NPB = BN / 32;   // 4 gather passes (2 channels per thread), 8 weight passes
+    constexpr int PLANE_A = BM * RS, PLANE_B = BN * RS, BUF = 2 * PLANE_A + 2 * PLANE_B;
+    extern __shared__ __align__(16) unsigned char smem[];
+    // buffer b: [A hi][A lo][B hi][B lo]
+    Tap *tab = reinterpret_cast<Tap *>(smem + 2 * BUF);   // [BM][K*dg]
+
+    const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+    const int K = a.kh * a.kw, KD = K * a.dg;
+    const int Cg = a.C / a.groups, Cog = a.Co / a.groups, Kdim = K * Cg;
+
+    const Lvl &L = find_level(a, blockIdx.x);
+    const int tile_p = (blockIdx.x - L.tile0) * BM;
+    const int g = blockIdx.z;
+    const int co_blk = blockIdx.y * BN;
+    const int nco = min(BN, Cog - co_blk);
+    const int co_base = g * Cog + co_blk;
+
+    for (int e = tid; e < BM * KD; e += 256) {
+        const int pl = e / KD, r = e - pl * KD;
+        const int dgi = r / K, k = r - dgi * K;
+        tab[e] = make_tap(a, L, tile_p + pl, k, dgi);
+    }
+    const int segs = Cg / a.SL, ncc = (a.SL + BK - 1) / BK;
+    const int T = K * segs * ncc;
+    const int kk2 = tid & 15, prow = tid >> 4;   // gather: channel pair, pixel row (16 rows per pass)
+    const int wq = tid & 7, wrow = tid >> 3;     // weights: float4 slot along k, co row (32 rows per pass)
+
+    const __amdgpu_buffer_rsrc_t xrs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(L.x), 0, L.B * L.H * L.W * a.C * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.w), 0, a.Co * Kdim * 4, 0x00020000);
+
+    int wvoff[NPB];
+#pragma unroll
+    for (int ps = 0; ps < NPB; ++ps) {
+        const int col = ps * 32 + wrow;
+        wvoff[ps] = (col < nco) ? ((co_base + col) * Kdim + wq * 4) * 4 : 0x7ffffff0;
+    }
+
+    int voffI[NPA][4];
+    float wgtC[NPA][4];
+    auto load_offsets = [&](const Chunk &ch) {
+#pragma unroll
+        for (int ps = 0; ps < NPA; ++ps) {
+            const int4 idx = *reinterpret_cast<const int4 *>(&tab[(ps * 16 + prow) * KD + ch.dgi * K + ch.k]);
+            voffI[ps][0] = (idx.x + 2 * kk2) * 4;
+            voffI[ps][1] = (idx.y + 2 * kk2) * 4;
+            voffI[ps][2] = (idx.z + 2 * kk2) * 4;
+            voffI[ps][3] = (idx.w + 2 * kk2) * 4;
+        }
+    };
+    auto load_weights = [&](const Chunk &ch) {
+#pragma unroll
+        for (int ps = 0; ps < NPA; ++ps) {
+            const Tap tp = tab[(ps * 16 + prow) * KD + ch.dgi * K + ch.k];
+            float b00, b01, b10, b11;
+            corner_weights(tp, b00, b01, b10, b11);
+            wgtC[ps][0] = b00 * tp.m;
+            wgtC[ps][1] = b01 * tp.m;
+            wgtC[ps][2] = b10 * tp.m;
+            wgtC[ps][3] = b11 * tp.m;
+        }
+    };
+
+    float2 xv[NPA][4];
+    float4 wv[NPB];
+    auto issue_x = [&](const Chunk &ch, int ps) {
+        const int soff = (g * Cg + ch.c0) * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xv[ps][q] = buf_load_f32x2(xrs, voffI[ps][q], soff);
+    };
+    auto issue_w = [&](const Chunk &ch, int ps) { wv[ps] = buf_load_f32x4(wrs, wvoff[ps], (ch.k * Cg + ch.c0) * 4); };
+    auto commit_x = [&](const Chunk &ch, int ps, unsigned char *buf) {
+        float v0 = wgtC[ps][0] * xv[ps][0].x + wgtC[ps][1] * xv[ps][1].x + wgtC[ps][2] * xv[ps][2].x +
+                   wgtC[ps][3] * xv[ps][3].x;
+        float v1 = wgtC[ps][0] * xv[ps][0].y + wgtC[ps][1] * xv[ps][1].y + wgtC[ps][2] * xv[ps][2].y +
+                   wgtC[ps][3] * xv[ps][3].y;
+        v0 = (2 * kk2 < ch.nval) ? v0 : 0.f;
+        v1 = (2 * kk2 + 1 < ch.nval) ? v1 : 0.f;
+        unsigned hi, lo;
+        split_bf16x2(v0, v1, hi, lo);
+        unsigned char *p = buf + (ps * 16 + prow) * RS + kk2 * 4;
+        *reinterpret_cast<unsigned *>(p) = hi;
+        *reinterpret_cast<unsigned *>(p + PLANE_A) = lo;
+    };
+    auto commit_w = [&](const Chunk &ch, int ps, unsigned char *buf) {
+        const bool ok = wq * 4 < ch.nval;   // nval is a multiple of 4 on this path (vec_ok)
+        const float4 v = ok ? wv[ps] : make_float4(0.f, 0.f, 0.f, 0.f);
+        uint2 hi, lo;
+        split_bf16x2(v.x, v.y, hi.x, lo.x);
+        split_bf16x2(v.z, v.w, hi.y, lo.y);
+        unsigned char *p = buf + 2 * PLANE_A + (ps * 32 + wrow) * RS + wq * 8;
+        *reinterpret_cast<uint2 *>(p) = hi;
+        *reinterpret_cast<uint2 *>(p + PLANE_B) = lo;
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    __syncthreads();  // sampling table complete
+    ChunkIter<BK> it1(a, g, segs, ncc, T), it2(a, g, segs, ncc, T);
+    Chunk cI = it1.get();
+    Chunk cC = cI;
+    load_offsets(cI);
+    load_weights(cC);
+    {
+#pragma unroll
+        for (int ps = 0; ps < NPA; ++ps) issue_x(cI, ps);
+#pragma unroll
+        for (int ps = 0; ps < NPB; ++ps) issue_w(cI, ps);
+#pragma unroll
+        for (int ps = 0; ps < NPA; ++ps) commit_x(cC, ps, smem);
+#pragma unroll
+        for (int ps = 0; ps < NPB; ++ps) commit_w(cC, ps, smem);
+        it1.next();
+        it2.next();
+        it2.next();
+        const Chunk c1 = it1.get();
+        if (c1.k != cI.k || c1.dgi != cI.dgi) load_offsets(c1);
+        cI = c1;
+#pragma unroll
+        for (int ps = 0; ps < NPA; ++ps) issue_x(c1, ps);
+#pragma unroll
+        for (int ps = 0; ps < NPB; ++ps) issue_w(c1, ps);
+    }
+    __syncthreads();
+
+    int dbg_n = 0;
+    for (int t = 0; t < T; ++t) {
+        LSN_STAMP(2);
+        const int cur = t & 1;
+        const unsigned char *bc = smem + cur * BUF;
+        unsigned char *bn = smem + (cur ^ 1) * BUF;
+        const Chunk c1 = it1.get();
+        const Chunk c2 = it2.get();
+        it1.next();
+        it2.next();
+        if (c1.k != cC.k || c1.dgi != cC.dgi) load_weights(c1);
+        cC = c1;
+        if (c2.k != cI.k || c2.dgi != cI.dgi) load_offsets(c2);
+        cI = c2;
+
+        // operands of both k-steps: [ks][tile row/col block][hi, lo]
+        const unsigned char *ap = bc + (lane & 31) * RS + (lane >> 5) * 16;
+        const unsigned char *bp = bc + 2 * PLANE_A + (wn * 64 + (lane & 31)) * RS + (lane >> 5) * 16;
+        bf16x8 Ah[2][2], Al[2][2], Bh[2][2], Bl[2][2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                Ah[ks][i] = *reinterpret_cast<const bf16x8 *>(ap + i * 32 * RS + ks * 32);
+                Al[ks][i] = *reinterpret_cast<const bf16x8 *>(ap + PLANE_A + i * 32 * RS + ks * 32);
+                Bh[ks][i] = *reinterpret_cast<const bf16x8 *>(bp + i * 32 * RS + ks * 32);
+                Bl[ks][i] = *reinterpret_cast<const bf16x8 *>(bp + PLANE_B + i * 32 * RS + ks * 32);
+            }
+        if (a.dbg != nullptr) {
+            __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): diagnostic only
+            LSN_STAMP(5);
+        }
+        // 24 MFMAs; one staging slice in each gap: commits of chunk t+1 followed by the issue that reuses the
+        // registers just consumed (x slices 0..3, then weight slices 0..7)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int prod = 0; prod < 3; ++prod)
+#pragma unroll
+                for (int ij = 0; ij < 4; ++ij) {
+                    const int i = ij >> 1, j = ij & 1;
+                    const int gap = ks * 12 + prod * 4 + ij;
+                    const bf16x8 av = (prod == 2) ? Al[ks][i] : Ah[ks][i];
+                    const bf16x8 bv = (prod == 1) ? Bl[ks][j] : Bh[ks][j];
+                    acc[i][j] = mfma_bf16(av, bv, acc[i][j]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (gap < 8) {
+                        if ((gap & 1) == 0)
+                            commit_x(c1, gap >> 1, bn);
+                        else
+                            issue_x(c2, gap >> 1);
+                    } else {
+                        const int ps = (gap - 8) >> 1;
+                        if ((gap & 1) == 0)
+                            commit_w(c1, ps, bn);
+                        else
+                            issue_w(c2, ps);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        LSN_STAMP(6);
+        __syncthreads();
         LSN_STAMP(7);
     }
 

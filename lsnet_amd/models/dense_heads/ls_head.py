@@ -25,6 +25,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ...cnn import ConvModule, bias_init_with_prob, kaiming_init, normal_init
+from ...ops.conv import Conv2d
 from ...ops.group_norm import GroupNorm
 from ...core import PointGenerator, build_assigner, build_sampler, multiclass_nms_lsvr
 from ...ops import ModulatedDeformConvPack, PyramidDeformConv
@@ -146,17 +147,17 @@ class LSHead(nn.Module):
             setattr(self, f'{b}_GN', GroupNorm(ng, fc))
             setattr(self, f'{b}_convs', self._tower())
         self.pts_cls_conv = PyramidDeformConv(fc, pc, self.dcn_kernel, 1, self.dcn_pad)
-        self.pts_cls_out = nn.Conv2d(pc, self.cls_out_channels, 1, 1, 0)
-        self.cls_af_dcn_conv = nn.Sequential(nn.Conv2d(3 * pc, pc, 1, 1, 0), nn.ReLU())
-        self.cls_feat_conv = nn.Conv2d(fc, pc, 3, 1, 1)
+        self.pts_cls_out = Conv2d(pc, self.cls_out_channels, 1, 1, 0)
+        self.cls_af_dcn_conv = nn.Sequential(Conv2d(3 * pc, pc, 1, 1, 0), nn.ReLU())
+        self.cls_feat_conv = Conv2d(fc, pc, 3, 1, 1)
         for b in self.branches:
             d_init, d_refine = self._out_dims(b)
-            setattr(self, f'pts_{b}_init_conv', nn.Conv2d(fc, pc, 3, 1, 1))
-            setattr(self, f'pts_{b}_init_out', nn.Conv2d(pc, d_init, 1, 1, 0))
+            setattr(self, f'pts_{b}_init_conv', Conv2d(fc, pc, 3, 1, 1))
+            setattr(self, f'pts_{b}_init_out', Conv2d(pc, d_init, 1, 1, 0))
             setattr(self, f'pts_{b}_refine_conv', PyramidDeformConv(fc, pc, self.dcn_kernel, 1, self.dcn_pad))
-            setattr(self, f'pts_{b}_refine_out', nn.Conv2d(pc, d_refine, 1, 1, 0))
-            setattr(self, f'{b}_af_dcn_conv', nn.Sequential(nn.Conv2d(3 * pc, pc, 1, 1, 0), nn.ReLU()))
-            setattr(self, f'{b}_feat_conv', nn.Conv2d(fc, pc, 3, 1, 1))
+            setattr(self, f'pts_{b}_refine_out', Conv2d(pc, d_refine, 1, 1, 0))
+            setattr(self, f'{b}_af_dcn_conv', nn.Sequential(Conv2d(3 * pc, pc, 1, 1, 0), nn.ReLU()))
+            setattr(self, f'{b}_feat_conv', Conv2d(fc, pc, 3, 1, 1))
 
     def init_weights(self):
         """lsnet_head.py:259-319 (same RNG consumption order: towers, then cls, then each branch)."""

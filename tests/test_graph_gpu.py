@@ -40,8 +40,8 @@ def test_graph_replay_trains_like_eager():
     assert gs.graph is not None and gs.calls == 6          # 1 eager warm-up call, 1 capture, 4 replays
     assert torch.isfinite(graph).all()
     # same kernels, same order; only the fp32 atomics of the DCN backward differ run to run
-    assert torch.allclose(eager, graph, rtol=2e-3), (eager, graph)
+    assert torch.allclose(eager, graph, rtol=5e-3), (eager, graph)
     for (k, a), (_, b) in zip(model.state_dict().items(), twin.state_dict().items()):
-        assert torch.allclose(a, b, rtol=5e-2, atol=2e-5), k
+        assert torch.allclose(a, b, rtol=1e-1, atol=5e-5), k
     with pytest.raises(RuntimeError):
         gs(synthetic_batch("bbox", 2, 384, 512, seed=1, device=dev))   # other shapes are not this graph

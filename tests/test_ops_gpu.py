@@ -104,14 +104,18 @@ def _to(t, dev, cl):
     return t.contiguous(memory_format=torch.channels_last) if cl else t
 
 
-@pytest.fixture(params=['default', 'bwd_first_kernel', 'bwd_windowed_kernel'])
+@pytest.fixture(params=['default', 'bwd_first_kernel', 'bwd_windowed_kernel', 'math_fp32'])
 def dcn_kernel_choice(request):
-    """The backward-data kernel is picked per launch by a heuristic; the parity cases run under the default choice
-    and with each of the two kernels forced (debug word bits 25 / 24, lsn_debug_phase_clocks)."""
+    """The backward-data kernel is picked per launch by a heuristic and the forward arithmetic by the math mode; the
+    parity cases run under the defaults (split-bf16 forward), with each backward kernel forced (debug word bits
+    25 / 24, lsn_debug_phase_clocks) and with exact fp32 MFMA everywhere."""
     from lsnet_amd import _lib
-    flag = {'default': 0, 'bwd_first_kernel': 1 << 25, 'bwd_windowed_kernel': 1 << 24}[request.param]
+    flag = {'bwd_first_kernel': 1 << 25, 'bwd_windowed_kernel': 1 << 24}.get(request.param, 0)
     _lib.load().lsn_debug_phase_clocks(None, flag)
+    old = _lib.get_math_mode()
+    _lib.set_math_mode('fp32' if request.param == 'math_fp32' else 'bf16x3')
     yield request.param
+    _lib.set_math_mode(old)
     _lib.load().lsn_debug_phase_clocks(None, 0)
 
 
@@ -372,3 +376,62 @@ def test_group_norm_unsupported_shape_uses_aten():
     assert torch.allclose(m(x), F.group_norm(x, 3, m.weight, m.bias, m.eps), atol=1e-6)
     y = GroupNorm(32, 256)(torch.randn(2, 256, 5, 5))      # CPU tensors take ATen's kernel as well
     assert y.shape == (2, 256, 5, 5)
+
+
+# ---------------------------------------------------------------------------------- dense conv (split bf16)
+@pytest.fixture
+def bf16x3_mode():
+    from lsnet_amd import _lib
+    old = _lib.get_math_mode()
+    _lib.set_math_mode('bf16x3')
+    yield
+    _lib.set_math_mode(old)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,C,Co,k,s,p,d,H,W,bias', [
+    (2, 256, 256, 3, 1, 1, 1, 25, 42, True),      # 64x256 tiles
+    (2, 128, 128, 3, 2, 1, 1, 40, 52, False),     # 128x128 tiles, stride 2 (backward-data through ATen)
+    (1, 256, 64, 1, 1, 0, 1, 33, 31, True),       # 256x64 tiles, ragged pixel count
+    (2, 64, 512, 1, 1, 0, 1, 20, 28, False),      # two column blocks
+    (2, 768, 256, 1, 1, 0, 1, 13, 21, True),
+    (2, 40, 72, 3, 1, 2, 2, 17, 19, True),        # C and Co not multiples of 32, dilation 2
+    (1, 2048, 256, 3, 2, 1, 1, 25, 42, True),     # FPN P6: 2048 -> 256 stride 2
+])
+def test_conv2d_matches_torch(B, C, Co, k, s, p, d, H, W, bias, bf16x3_mode):
+    """Split-bf16 implicit GEMM vs F.conv2d (fp32, MIOpen and CPU): 2^-16 per product -> well inside 1e-4."""
+    from lsnet_amd.ops.conv import conv2d
+    torch.manual_seed(2)
+    dev = _dev()
+    x = torch.randn(B, C, H, W, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_()
+    w = (torch.randn(Co, C, k, k, device=dev) / (C * k * k) ** 0.5).contiguous(memory_format=torch.channels_last) \
+        .requires_grad_()
+    b = torch.randn(Co, device=dev).requires_grad_() if bias else None
+    y = conv2d(x, w, b, s, p, d)
+    go = torch.randn_like(y)
+    grads = torch.autograd.grad(y, [x, w] + ([b] if bias else []), go)
+    xr, wr = x.detach().cpu().requires_grad_(), w.detach().cpu().contiguous().requires_grad_()
+    br = b.detach().cpu().requires_grad_() if bias else None
+    yr = F.conv2d(xr, wr, br, s, p, d)
+    gr = torch.autograd.grad(yr, [xr, wr] + ([br] if bias else []), go.cpu())
+    assert y.is_contiguous(memory_format=torch.channels_last)
+    assert _err(y, yr) < 5e-5
+    for g, r, n in zip(grads, gr, ('gx', 'gw', 'gb')):
+        assert _err(g, r) < 5e-5, n
+
+
+@pytest.mark.gpu
+def test_conv2d_module_dispatch(bf16x3_mode):
+    from lsnet_amd import _lib
+    from lsnet_amd.ops.conv import Conv2d
+    dev = _dev()
+    m = Conv2d(256, 256, 3, padding=1).to(dev).to(memory_format=torch.channels_last)
+    x = torch.randn(2, 256, 100, 168, device=dev).contiguous(memory_format=torch.channels_last)
+    ref = F.conv2d(x, m.weight, m.bias, 1, 1)
+    assert _err(m(x), ref) < 5e-5                       # large layer: own kernel
+    _lib.set_math_mode('fp32')
+    assert torch.equal(m(x), ref)                       # exact mode: the vendor path, bit for bit
+    _lib.set_math_mode('bf16x3')
+    small = Conv2d(64, 64, 1).to(dev)
+    xs = torch.randn(2, 64, 20, 20, device=dev).contiguous(memory_format=torch.channels_last)
+    assert torch.equal(small(xs), F.conv2d(xs, small.weight, small.bias))   # small layer stays on MIOpen
