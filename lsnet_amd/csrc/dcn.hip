@@ -390,6 +390,13 @@ static int launch_wgrad(const DcnArgs &a, int nsteps, hipStream_t st)
     LSN_HIP(hipMemsetAsync(a.gw, 0, sizeof(float) * (size_t)a.Co * K * Cg, st));
     if (a.gb) LSN_HIP(hipMemsetAsync(a.gb, 0, sizeof(float) * (size_t)a.Co, st));
     ProfScope prof(PROF_WGRAD, a, st);
+    if (math_mode() == LSN_MATH_BF16X3 && !((g_dbg_block >> 30) & 1)) {   // bit 30: force the fp32 MFMA kernel
+        const size_t lds3 = (size_t)2 * (WG_BM + WG_BN) * 80 + 2 * WG_BP * sizeof(Tap);
+        if (int rc = set_lds(dcn_wgrad_x3_kernel<false>, lds3)) return rc;
+        hipLaunchKernelGGL(dcn_wgrad_x3_kernel<false>, dim3(ncol, splits, nz), dim3(256), lds3, st, a, nsteps);
+        LSN_HIP(hipGetLastError());
+        return 0;
+    }
     if (vec_ok(a))
         hipLaunchKernelGGL(dcn_wgrad_kernel<true>, dim3(ncol, splits, nz), dim3(256), lds, st, a, nsteps);
     else

@@ -1626,4 +1626,174 @@ __global__ __launch_bounds__(256, 2) void dcn_wgrad_kernel(const DcnArgs a, int 
     if (do_bias && tid < nco) atomic_add_f32(a.gb + co_base + tid, bias_acc);
 }
 
+// =============================================================================================
+// Backward-weight on the bf16 matrix pipe with split operands (dcn_wgrad_x3_kernel).
+//
+// Same decomposition as dcn_wgrad_kernel (grid = column blocks x pixel splits x 256-co blocks, 32-pixel steps,
+// fp32 atomics into gw at the end).  The reduction index of this GEMM is the PIXEL, so both LDS images are built
+// pixel-contiguous -- As[co][32 px], Bs[kcol][32 px], bf16 hi and lo planes, 80-byte rows -- to give every lane
+// the 8 consecutive k-values v_mfma_f32_32x32x16_bf16 wants: a thread owns one output channel (gout column) resp.
+// one (channel, 8-pixel group) of the gathered columns, splits its values in registers and writes whole 16-byte
+// row pieces.  24 MFMAs of 32 cycles per step and wave instead of 64 of 64.
+// PLAIN: a dense convolution (no offsets, no mask): one load per sample instead of four corners.
+// =============================================================================================
+template <bool PLAIN>
+__global__ __launch_bounds__(256, 2) void dcn_wgrad_x3_kernel(const DcnArgs a, int nsteps)
+{
+    constexpr int RS = 80, PLANE_A = WG_BM * RS, PLANE_B = WG_BN * RS;
+    extern __shared__ __align__(16) unsigned char smem[];   // [A hi][A lo][B hi][B lo][tab 2 x 32]
+    Tap *tab = reinterpret_cast<Tap *>(smem + 2 * PLANE_A + 2 * PLANE_B);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = a.kh * a.kw;
+    const int Cg = a.C / a.groups, Cog = a.Co / a.groups, Kdim = K * Cg;
+    const int segs = Cg / a.SL, ncc = (a.SL + WG_BN - 1) / WG_BN;
+    const int ncol_g = K * segs * ncc;
+    const int g = blockIdx.x / ncol_g;
+    const Chunk ch = decode_chunk<WG_BN>(a, g, blockIdx.x - g * ncol_g, segs, ncc);
+    const int co_blk = blockIdx.z * WG_BM;
+    const int nco = min(WG_BM, Cog - co_blk);
+    const int co_base = g * Cog + co_blk;
+
+    const int st_begin = (int)((long long)nsteps * blockIdx.y / gridDim.y);
+    const int st_end = (int)((long long)nsteps * (blockIdx.y + 1) / gridDim.y);
+
+    const int kk = tid & 63, pg = tid >> 6;   // gathered columns: channel lane, 8-pixel group
+    const bool cval = kk < ch.nval;
+    const int c = g * Cg + ch.c0 + (cval ? kk : 0);
+    const bool gval = tid < nco;               // gout: this thread's output channel
+    const bool do_bias = (a.gb != nullptr) && ch.k == 0 && ch.c0 == 0;
+
+    constexpr int NX = PLAIN ? 1 : 4;
+    float xv[8][NX];
+    float gv[WG_BP];
+    float bias_acc = 0.f;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto build_tab = [&](int st, int buf) {
+        if (tid < WG_BP) {
+            const Lvl &L = find_level(a, st);
+            tab[buf * WG_BP + tid] = make_tap(a, L, (st - L.tile0) * WG_BP + tid, ch.k, ch.dgi);
+        }
+    };
+    auto load_step = [&](int st, int buf) {
+        const Lvl &L = find_level(a, st);
+        const int p0 = (st - L.tile0) * WG_BP;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const Tap *tp = &tab[buf * WG_BP + pg * 8 + q];
+            if (PLAIN) {
+                xv[q][0] = L.x[tp->i00 + c];
+            } else {
+                const int4 idx = *reinterpret_cast<const int4 *>(tp);
+                xv[q][0] = L.x[idx.x + c];
+                xv[q][1] = L.x[idx.y + c];
+                xv[q][2] = L.x[idx.z + c];
+                xv[q][3] = L.x[idx.w + c];
+            }
+        }
+        const float *gp = L.gout + (size_t)p0 * a.Co + co_base + (gval ? tid : 0);
+        const int npx = L.P - p0;   // valid pixels of this step (>= 1)
+#pragma unroll
+        for (int px = 0; px < WG_BP; ++px) gv[px] = gp[(size_t)(px < npx ? px : 0) * a.Co];
+#pragma unroll
+        for (int px = 0; px < WG_BP; ++px) gv[px] = (gval && px < npx) ? gv[px] : 0.f;
+    };
+    auto store_step = [&](int buf) {
+        // gathered columns: 8 pixels of channel kk -> one 16-byte piece of row kk in each plane
+        unsigned hi[4], lo[4];
+#pragma unroll
+        for (int q2 = 0; q2 < 4; ++q2) {
+            float v[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int q = q2 * 2 + h;
+                const Tap tp = tab[buf * WG_BP + pg * 8 + q];
+                if (PLAIN) {
+                    v[h] = (tp.flags & 1) ? xv[q][0] : 0.f;
+                } else {
+                    float b00, b01, b10, b11;
+                    corner_weights(tp, b00, b01, b10, b11);
+                    v[h] = (b00 * xv[q][0] + b01 * xv[q][1] + b10 * xv[q][2] + b11 * xv[q][3]) * tp.m;
+                }
+                v[h] = cval ? v[h] : 0.f;
+            }
+            split_bf16x2(v[0], v[1], hi[q2], lo[q2]);
+        }
+        unsigned char *bp = smem + 2 * PLANE_A + kk * RS + pg * 16;
+        *reinterpret_cast<uint4 *>(bp) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+        *reinterpret_cast<uint4 *>(bp + PLANE_B) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+        // gout: 32 pixels of output channel tid -> row tid (64 bytes) in each plane
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            unsigned h4[4], l4[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) split_bf16x2(gv[q4 * 8 + 2 * e], gv[q4 * 8 + 2 * e + 1], h4[e], l4[e]);
+            unsigned char *ap = smem + tid * RS + q4 * 16;
+            *reinterpret_cast<uint4 *>(ap) = make_uint4(h4[0], h4[1], h4[2], h4[3]);
+            *reinterpret_cast<uint4 *>(ap + PLANE_A) = make_uint4(l4[0], l4[1], l4[2], l4[3]);
+        }
+        if (do_bias) {
+#pragma unroll
+            for (int px = 0; px < WG_BP; ++px) bias_acc += gv[px];
+        }
+    };
+
+    if (st_begin < st_end) {
+        build_tab(st_begin, 0);
+        __syncthreads();
+        load_step(st_begin, 0);
+        for (int st = st_begin; st < st_end; ++st) {
+            const int buf = (st - st_begin) & 1;
+            store_step(buf);
+            if (st + 1 < st_end) build_tab(st + 1, buf ^ 1);
+            __syncthreads();
+            if (st + 1 < st_end) load_step(st + 1, buf ^ 1);
+            const unsigned char *ap = smem + (wave * 64 + (lane & 31)) * RS + (lane >> 5) * 16;
+            const unsigned char *bp = smem + 2 * PLANE_A + (lane & 31) * RS + (lane >> 5) * 16;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 Ah[2], Al[2], Bh[2], Bl[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    Ah[i] = *reinterpret_cast<const bf16x8 *>(ap + i * 32 * RS + ks * 32);
+                    Al[i] = *reinterpret_cast<const bf16x8 *>(ap + PLANE_A + i * 32 * RS + ks * 32);
+                    Bh[i] = *reinterpret_cast<const bf16x8 *>(bp + i * 32 * RS + ks * 32);
+                    Bl[i] = *reinterpret_cast<const bf16x8 *>(bp + PLANE_B + i * 32 * RS + ks * 32);
+                }
+#pragma unroll
+                for (int prod = 0; prod < 3; ++prod)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = mfma_bf16(prod == 2 ? Al[i] : Ah[i], prod == 1 ? Bl[j] : Bh[j], acc[i][j]);
+            }
+            __syncthreads();
+        }
+    }
+
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = j * 32 + (lane & 31);
+            if (col >= ch.nval) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wave * 64 + i * 32 + mfma32_row(r, lane);
+                if (row < nco)
+                    atomic_add_f32(a.gw + (size_t)(co_base + row) * Kdim + ch.k * Cg + ch.c0 + col, acc[i][j][r]);
+            }
+        }
+    if (do_bias && gval) atomic_add_f32(a.gb + co_base + tid, bias_acc);
+}
+
 }  // namespace lsn
