@@ -251,6 +251,23 @@ int lsn_group_norm_backward(int n_levels, const lsn_gn_level *levels, int C, int
                             const float *beta, int relu, const float *mean_rstd, float *grad_gamma,
                             float *grad_beta, void *workspace, lsn_stream_t stream);
 
+/* ---- BatchNorm with frozen statistics (+ residual add, + ReLU), channels-last ------------------
+ * The LSNet backbones keep every BatchNorm in eval mode while training (norm_eval=True, resnet.py:636-645) but
+ * train its affine parameters; the reference runs F.batch_norm, the residual add and F.relu as separate ATen /
+ * cuDNN kernels (resnet.py:261-301).  Fused equivalents on (N = B*H*W, C) channels-last fp32 tensors:
+ *   forward : y = act( (x - mean_c) / sqrt(var_c + eps) * gamma_c + beta_c (+ residual) )
+ *   backward: dz = grad_y * [y > 0] (when relu);  grad_x = dz * gamma_c / sqrt(var_c + eps);  grad_residual = dz;
+ *             grad_gamma_c = sum dz * (x - mean_c) / sqrt(var_c + eps);  grad_beta_c = sum dz
+ * residual / grad_x / grad_residual / grad_gamma+grad_beta may be NULL (not needed).  grad_gamma / grad_beta are
+ * OVERWRITTEN.  Supported: C % 4 == 0, 256 % (C/4) == 0 (C = 4 ... 1024); else LSN_ERR_UNSUPPORTED. */
+int lsn_bn_eval_act_forward(const float *x, const float *residual, float *y, const float *running_mean,
+                            const float *running_var, const float *gamma, const float *beta, float eps, int relu,
+                            int N, int C, lsn_stream_t stream);
+int lsn_bn_eval_act_backward(const float *grad_y, const float *y, const float *x, const float *running_mean,
+                             const float *running_var, const float *gamma, float eps, int relu, float *grad_x,
+                             float *grad_residual, float *grad_gamma, float *grad_beta, int N, int C,
+                             lsn_stream_t stream);
+
 /* ---- diagnostics ---------------------------------------------------------------------------- */
 /* When set to a device buffer of 512 int64 (NULL disables), thread 0 of workgroup `block` of the
  * next DCN forward / backward-data launches appends (phase_id << 56 | shader_clock) stamps at its

@@ -284,6 +284,109 @@ static int gn_fill(GnArgs &a, int n, const lsn_gn_level *lv, int C, int G, int *
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// BatchNorm with frozen statistics (eval mode: the LSNet backbones train with norm_eval=True, resnet.py:636-645)
+// + optional residual add + optional ReLU, channels-last, one pass each way:
+//   forward : y = act( x * a_c + b_c (+ res) ),  a_c = gamma_c / sqrt(var_c + eps),  b_c = beta_c - mean_c * a_c
+//   backward: dz = dy * [y > 0];  dx = dz * a_c;  dres = dz;  dgamma_c = sum dz * (x - mean_c) * rstd_c;
+//             dbeta_c = sum dz                      (ATen needs three kernels and five tensor reads for this)
+// Pixel rows are C floats; a thread owns a channel quad for a strided set of pixels, block sums go through LDS and
+// end in one fp32 atomic per channel and block.
+// ---------------------------------------------------------------------------------------------------------
+struct BnArgs {
+    const float *x, *res, *dy, *y_in;
+    float *y, *dx, *dres;
+    const float *mean, *var, *gamma, *beta;
+    float *dgamma, *dbeta;   // zero-filled by the launcher
+    float eps;
+    int N, C, relu;          // N = B * H * W pixels
+};
+
+constexpr int BN_PIX = 256;   // pixels per block
+
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const BnArgs a)
+{
+    const int qn = a.C >> 2, q = threadIdx.x % qn, row = threadIdx.x / qn, rows = 256 / qn;
+    const float4 mu = *reinterpret_cast<const float4 *>(a.mean + q * 4);
+    const float4 va = *reinterpret_cast<const float4 *>(a.var + q * 4);
+    const float4 ga = *reinterpret_cast<const float4 *>(a.gamma + q * 4);
+    const float4 be = *reinterpret_cast<const float4 *>(a.beta + q * 4);
+    const float a0 = ga.x * rsqrtf(va.x + a.eps), a1 = ga.y * rsqrtf(va.y + a.eps), a2 = ga.z * rsqrtf(va.z + a.eps),
+                a3 = ga.w * rsqrtf(va.w + a.eps);
+    const float b0 = be.x - mu.x * a0, b1 = be.y - mu.y * a1, b2 = be.z - mu.z * a2, b3 = be.w - mu.w * a3;
+    const int p0 = blockIdx.x * BN_PIX, p1 = min(p0 + BN_PIX, a.N);
+    for (int px = p0 + row; px < p1; px += rows) {
+        const size_t o = (size_t)px * a.C + q * 4;
+        const float4 v = *reinterpret_cast<const float4 *>(a.x + o);
+        float4 r = make_float4(v.x * a0 + b0, v.y * a1 + b1, v.z * a2 + b2, v.w * a3 + b3);
+        if (a.res) {
+            const float4 e = *reinterpret_cast<const float4 *>(a.res + o);
+            r.x += e.x, r.y += e.y, r.z += e.z, r.w += e.w;
+        }
+        if (a.relu) r = make_float4(fmaxf(r.x, 0.f), fmaxf(r.y, 0.f), fmaxf(r.z, 0.f), fmaxf(r.w, 0.f));
+        *reinterpret_cast<float4 *>(a.y + o) = r;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_act_bwd_kernel(const BnArgs a)
+{
+    const int qn = a.C >> 2, q = threadIdx.x % qn, row = threadIdx.x / qn, rows = 256 / qn;
+    const float4 mu = *reinterpret_cast<const float4 *>(a.mean + q * 4);
+    const float4 va = *reinterpret_cast<const float4 *>(a.var + q * 4);
+    const float4 ga = *reinterpret_cast<const float4 *>(a.gamma + q * 4);
+    const float r0 = rsqrtf(va.x + a.eps), r1 = rsqrtf(va.y + a.eps), r2 = rsqrtf(va.z + a.eps),
+                r3 = rsqrtf(va.w + a.eps);
+    const float a0 = ga.x * r0, a1 = ga.y * r1, a2 = ga.z * r2, a3 = ga.w * r3;
+    float sg[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
+    const int p0 = blockIdx.x * BN_PIX, p1 = min(p0 + BN_PIX, a.N);
+    for (int px = p0 + row; px < p1; px += rows) {
+        const size_t o = (size_t)px * a.C + q * 4;
+        float4 d = *reinterpret_cast<const float4 *>(a.dy + o);
+        if (a.relu) {
+            const float4 y = *reinterpret_cast<const float4 *>(a.y_in + o);
+            d.x = y.x > 0.f ? d.x : 0.f, d.y = y.y > 0.f ? d.y : 0.f, d.z = y.z > 0.f ? d.z : 0.f,
+            d.w = y.w > 0.f ? d.w : 0.f;
+        }
+        if (a.dres) *reinterpret_cast<float4 *>(a.dres + o) = d;
+        if (a.dx) *reinterpret_cast<float4 *>(a.dx + o) = make_float4(d.x * a0, d.y * a1, d.z * a2, d.w * a3);
+        if (a.dgamma) {
+            const float4 v = *reinterpret_cast<const float4 *>(a.x + o);
+            sg[0] += d.x * (v.x - mu.x), sg[1] += d.y * (v.y - mu.y), sg[2] += d.z * (v.z - mu.z),
+                sg[3] += d.w * (v.w - mu.w);
+            sb[0] += d.x, sb[1] += d.y, sb[2] += d.z, sb[3] += d.w;
+        }
+    }
+    if (!a.dgamma) return;
+    __shared__ float red[256 * 8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        red[threadIdx.x * 8 + j] = sg[j];
+        red[threadIdx.x * 8 + 4 + j] = sb[j];
+    }
+    __syncthreads();
+    if (threadIdx.x < qn) {
+        float t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < rows; ++r)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] += red[(r * qn + threadIdx.x) * 8 + j];
+        const float rs[4] = {r0, r1, r2, r3};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            atomic_add_f32(a.dgamma + threadIdx.x * 4 + j, t[j] * rs[j]);
+            atomic_add_f32(a.dbeta + threadIdx.x * 4 + j, t[4 + j]);
+        }
+    }
+}
+
+static int bn_check(int N, int C)
+{
+    LSN_CHECK(N > 0 && C > 0, "batch norm: empty tensor");
+    const int qn = C / 4;
+    if (C % 4 != 0 || qn > 256 || 256 % qn != 0)
+        return fail(LSN_ERR_UNSUPPORTED, "batch norm kernel needs C in {4..1024} with 256 %% (C/4) == 0, got %d", C);
+    return 0;
+}
+
 }  // namespace lsn
 
 extern "C" {
@@ -345,6 +448,47 @@ int lsn_group_norm_backward(int n_levels, const lsn_gn_level *levels, int C, int
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(tiles), dim3(256), 0, st, a);
     if (grad_gamma || grad_beta)
         hipLaunchKernelGGL(gn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, st, a, images);
+    LSN_HIP(hipGetLastError());
+    return 0;
+}
+
+int lsn_bn_eval_act_forward(const float *x, const float *residual, float *y, const float *running_mean,
+                            const float *running_var, const float *gamma, const float *beta, float eps, int relu,
+                            int N, int C, lsn_stream_t stream)
+{
+    using namespace lsn;
+    if (int rc = bn_check(N, C)) return rc;
+    LSN_CHECK(x && y && running_mean && running_var && gamma && beta, "batch norm: NULL argument");
+    BnArgs a = {};
+    a.x = x, a.res = residual, a.y = y, a.mean = running_mean, a.var = running_var, a.gamma = gamma, a.beta = beta;
+    a.eps = eps, a.N = N, a.C = C, a.relu = relu;
+    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3((N + BN_PIX - 1) / BN_PIX), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), a);
+    LSN_HIP(hipGetLastError());
+    return 0;
+}
+
+int lsn_bn_eval_act_backward(const float *grad_y, const float *y, const float *x, const float *running_mean,
+                             const float *running_var, const float *gamma, float eps, int relu, float *grad_x,
+                             float *grad_residual, float *grad_gamma, float *grad_beta, int N, int C,
+                             lsn_stream_t stream)
+{
+    using namespace lsn;
+    if (int rc = bn_check(N, C)) return rc;
+    LSN_CHECK(grad_y && running_mean && running_var && gamma, "batch norm: NULL argument");
+    LSN_CHECK(!relu || y, "batch norm backward: the ReLU gate needs y");
+    LSN_CHECK((grad_gamma == nullptr) == (grad_beta == nullptr), "grad_gamma and grad_beta come together");
+    LSN_CHECK(!grad_gamma || x, "batch norm backward: grad_gamma needs x");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    BnArgs a = {};
+    a.dy = grad_y, a.y_in = y, a.x = x, a.mean = running_mean, a.var = running_var, a.gamma = gamma;
+    a.dx = grad_x, a.dres = grad_residual, a.dgamma = grad_gamma, a.dbeta = grad_beta;
+    a.eps = eps, a.N = N, a.C = C, a.relu = relu;
+    if (grad_gamma) {
+        LSN_HIP(hipMemsetAsync(grad_gamma, 0, sizeof(float) * C, st));
+        LSN_HIP(hipMemsetAsync(grad_beta, 0, sizeof(float) * C, st));
+    }
+    hipLaunchKernelGGL(bn_act_bwd_kernel, dim3((N + BN_PIX - 1) / BN_PIX), dim3(256), 0, st, a);
     LSN_HIP(hipGetLastError());
     return 0;
 }

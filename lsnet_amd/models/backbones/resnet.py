@@ -11,7 +11,20 @@ import torch.utils.checkpoint as cp
 from torch.nn.modules.batchnorm import _BatchNorm
 
 from ...cnn import build_conv_layer, build_norm_layer, constant_init, kaiming_init
+from ...ops.batch_norm import bn_act
 from ..builder import BACKBONES
+
+
+def _shortcut(downsample, x):
+    """identity, or the projection shortcut conv -> norm (its norm through the fused kernel as well)."""
+    if downsample is None:
+        return x
+    mods = list(downsample)
+    if isinstance(mods[-1], _BatchNorm):
+        for m in mods[:-1]:
+            x = m(x)
+        return bn_act(mods[-1], x, relu=False)
+    return downsample(x)
 
 
 class BasicBlock(nn.Module):
@@ -35,13 +48,11 @@ class BasicBlock(nn.Module):
     norm2 = property(lambda self: getattr(self, self.norm2_name))
 
     def _body(self, x):
-        out = self.relu(self.norm1(self.conv1(x)))
-        out = self.norm2(self.conv2(out))
-        return out + (x if self.downsample is None else self.downsample(x))
+        out = bn_act(self.norm1, self.conv1(x), relu=True)
+        return bn_act(self.norm2, self.conv2(out), relu=True, residual=_shortcut(self.downsample, x))
 
     def forward(self, x):
-        out = cp.checkpoint(self._body, x) if (self.with_cp and x.requires_grad) else self._body(x)
-        return self.relu(out)
+        return cp.checkpoint(self._body, x) if (self.with_cp and x.requires_grad) else self._body(x)
 
 
 class Bottleneck(nn.Module):
@@ -88,14 +99,13 @@ class Bottleneck(nn.Module):
     norm3 = property(lambda self: getattr(self, self.norm3_name))
 
     def _body(self, x):
-        out = self.relu(self.norm1(self.conv1(x)))
-        out = self.relu(self.norm2(self.conv2(out)))
-        out = self.norm3(self.conv3(out))
-        return out + (x if self.downsample is None else self.downsample(x))
+        out = bn_act(self.norm1, self.conv1(x), relu=True)
+        out = bn_act(self.norm2, self.conv2(out), relu=True)
+        # relu(bn3(conv3) + identity): norm, residual add and activation in one pass (resnet.py:261-301)
+        return bn_act(self.norm3, self.conv3(out), relu=True, residual=_shortcut(self.downsample, x))
 
     def forward(self, x):
-        out = cp.checkpoint(self._body, x) if (self.with_cp and x.requires_grad) else self._body(x)
-        return self.relu(out)
+        return cp.checkpoint(self._body, x) if (self.with_cp and x.requires_grad) else self._body(x)
 
 
 class ResLayer(nn.Sequential):
@@ -222,7 +232,7 @@ class ResNet(nn.Module):
                     constant_init(m.norm2, 0)
 
     def forward(self, x):
-        x = self.maxpool(self.relu(self.norm1(self.conv1(x))))
+        x = self.maxpool(bn_act(self.norm1, self.conv1(x), relu=True))
         outs = []
         for i, name in enumerate(self.res_layers):
             x = getattr(self, name)(x)

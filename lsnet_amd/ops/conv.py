@@ -87,11 +87,11 @@ def hip_conv_ok(x, weight, stride, padding, dilation, groups, padding_mode='zero
 
 def _own_is_faster(pixels, cin, cout, taps):
     """Shape rule from tools/bench_convs_x3.py (MI355X, ROCm 7.2 MIOpen): the split-bf16 kernel wins once its grid
-    fills the chip (>= 192 blocks of 64x256 / 128x128 / 256x64) and the reduction is deep enough to amortise the
+    covers a good part of the chip (>= 100 blocks of 64x256 / 128x128 / 256x64) and the reduction is deep enough to amortise the
     pipeline prologue; MIOpen keeps the small and shallow layers."""
     bm, bn = (256, 64) if cout <= 64 else ((128, 128) if cout <= 128 else (64, 256))
     blocks = -(-pixels // bm) * -(-cout // bn)
-    return blocks >= 192 and cin * taps >= 256 and cin >= 128 and cout >= 128
+    return blocks >= 100 and cin * taps >= 256 and cin >= 128 and cout >= 128
 
 
 def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, relu=False):

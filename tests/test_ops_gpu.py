@@ -435,3 +435,41 @@ def test_conv2d_module_dispatch(bf16x3_mode):
     small = Conv2d(64, 64, 1).to(dev)
     xs = torch.randn(2, 64, 20, 20, device=dev).contiguous(memory_format=torch.channels_last)
     assert torch.equal(small(xs), F.conv2d(xs, small.weight, small.bias))   # small layer stays on MIOpen
+
+
+# ---------------------------------------------------------------------------------- frozen BN + add + ReLU
+@pytest.mark.gpu
+@pytest.mark.parametrize('C,shape,relu,res', [(64, (2, 40, 52), True, False), (256, (2, 25, 42), True, True),
+                                               (1024, (1, 13, 21), False, False), (512, (2, 9, 7), True, True)])
+def test_bn_eval_act_matches_torch(C, shape, relu, res):
+    from lsnet_amd.ops.batch_norm import bn_act
+    torch.manual_seed(4)
+    dev = _dev()
+    bn = torch.nn.BatchNorm2d(C).to(dev)
+    with torch.no_grad():
+        bn.weight.copy_(torch.randn(C) * 0.5 + 1)
+        bn.bias.copy_(torch.randn(C) * 0.2)
+        bn.running_mean.copy_(torch.randn(C))
+        bn.running_var.copy_(torch.rand(C) + 0.3)
+    bn.eval()
+    b, h, w = shape
+    x = torch.randn(b, C, h, w, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_()
+    r = torch.randn(b, C, h, w, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_() if res else None
+    y = bn_act(bn, x, relu=relu, residual=r)
+    go = torch.randn_like(y)
+    ins = [x] + ([r] if res else []) + [bn.weight, bn.bias]
+    got = torch.autograd.grad(y, ins, go)
+    x2 = x.detach().clone().requires_grad_()
+    r2 = r.detach().clone().requires_grad_() if res else None
+    ref = F.batch_norm(x2, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps)
+    if res:
+        ref = ref + r2
+    if relu:
+        ref = F.relu(ref)
+    gref = torch.autograd.grad(ref, [x2] + ([r2] if res else []) + [bn.weight, bn.bias], go)
+    assert _err(y, ref) < 1e-6
+    for g, gr in zip(got, gref):
+        assert _err(g, gr) < 2e-5
+    if C == 64:                     # batch statistics: not this kernel's business (one case is enough: MIOpen's
+        bn.train()                  # training-mode BN segfaults on the 1x1024x13x21 channels-last case here)
+        assert torch.allclose(bn_act(bn, x.detach(), relu=True), F.relu(bn(x.detach())), atol=1e-5)
