@@ -263,10 +263,11 @@ int lsn_group_norm_backward(int n_levels, const lsn_gn_level *levels, int C, int
 int lsn_bn_eval_act_forward(const float *x, const float *residual, float *y, const float *running_mean,
                             const float *running_var, const float *gamma, const float *beta, float eps, int relu,
                             int N, int C, lsn_stream_t stream);
+int64_t lsn_bn_eval_act_workspace_bytes(int N, int C);   /* scratch for backward when grad_gamma is wanted */
 int lsn_bn_eval_act_backward(const float *grad_y, const float *y, const float *x, const float *running_mean,
                              const float *running_var, const float *gamma, float eps, int relu, float *grad_x,
-                             float *grad_residual, float *grad_gamma, float *grad_beta, int N, int C,
-                             lsn_stream_t stream);
+                             float *grad_residual, float *grad_gamma, float *grad_beta, void *workspace, int N,
+                             int C, lsn_stream_t stream);
 
 /* ---- diagnostics ---------------------------------------------------------------------------- */
 /* When set to a device buffer of 512 int64 (NULL disables), thread 0 of workgroup `block` of the

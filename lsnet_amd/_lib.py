@@ -57,7 +57,7 @@ EXPORTS = [
     'lsn_prof_enable', 'lsn_prof_read',
     'lsn_group_norm_workspace_bytes', 'lsn_group_norm_forward', 'lsn_group_norm_backward',
     'lsn_set_math_mode', 'lsn_get_math_mode', 'lsn_conv2d_forward', 'lsn_conv2d_backward_data',
-    'lsn_bn_eval_act_forward', 'lsn_bn_eval_act_backward',
+    'lsn_bn_eval_act_forward', 'lsn_bn_eval_act_backward', 'lsn_bn_eval_act_workspace_bytes',
 ]
 
 _lib = None
@@ -76,6 +76,7 @@ def load():
     lib.lsn_last_error.restype = ctypes.c_char_p
     lib.lsn_nms_workspace_bytes.restype = ctypes.c_int64
     lib.lsn_group_norm_workspace_bytes.restype = ctypes.c_int64
+    lib.lsn_bn_eval_act_workspace_bytes.restype = ctypes.c_int64
     for name in EXPORTS:
         getattr(lib, name)  # AttributeError here means header and library disagree
     _lib = lib

@@ -49,9 +49,12 @@ class _BnActFn(torch.autograd.Function):
         dres = torch.empty_like(x, memory_format=_CL) if need_res else None
         dg = torch.empty_like(gamma) if need_p else None
         db = torch.empty_like(gamma) if need_p else None
-        _lib.check(_lib.load().lsn_bn_eval_act_backward(_p(dy), _p(y), _p(x), _p(mean), _p(var), _p(gamma),
-                                                        ctypes.c_float(eps), 1 if relu else 0, _p(dx), _p(dres), _p(dg),
-                                                        _p(db), B * H * W, C, _stream()))
+        lib = _lib.load()
+        ws = torch.empty(lib.lsn_bn_eval_act_workspace_bytes(B * H * W, C), device=x.device, dtype=torch.uint8) \
+            if need_p else None
+        _lib.check(lib.lsn_bn_eval_act_backward(_p(dy), _p(y), _p(x), _p(mean), _p(var), _p(gamma), ctypes.c_float(eps),
+                                                1 if relu else 0, _p(dx), _p(dres), _p(dg), _p(db), _p(ws), B * H * W, C,
+                                                _stream()))
         return dx, dres, dg if ctx.needs_input_grad[2] else None, db if ctx.needs_input_grad[3] else None, \
             None, None, None, None
 
