@@ -71,6 +71,9 @@ typedef struct {
                         * gradient w.r.t. the logits.  Lets a DCNv2 pack hand its (B, 3*dg*kh*kw, H, W)
                         * conv_offset output to the op as ONE tensor (offset = first 2/3 of the channels,
                         * mask = last 1/3, deform_conv.py:527-530) and get ONE gradient tensor back. */
+    void *workspace;   /* optional device scratch of >= Co*kh*kw*(C/groups)*4 bytes: lsn_dcn_backward in
+                        * LSN_MATH_BF16X3 mode puts the split, transposed weights there and runs the matrix-pipe
+                        * backward-data kernel; NULL keeps the fp32 MFMA kernels.  Contents undefined afterwards. */
 } lsn_dcn_shape;
 
 /* One (source map, offset field, output) triple of a batched launch.  All levels of a launch

@@ -22,7 +22,8 @@ class DcnShape(ctypes.Structure):
                 ('Co', ctypes.c_int), ('Ho', ctypes.c_int), ('Wo', ctypes.c_int),
                 ('kh', ctypes.c_int), ('kw', ctypes.c_int), ('stride', ctypes.c_int), ('pad', ctypes.c_int),
                 ('dil', ctypes.c_int), ('groups', ctypes.c_int), ('deformable_groups', ctypes.c_int),
-                ('scale_h', ctypes.c_float), ('scale_w', ctypes.c_float), ('mask_is_logit', ctypes.c_int)]
+                ('scale_h', ctypes.c_float), ('scale_w', ctypes.c_float), ('mask_is_logit', ctypes.c_int),
+                ('workspace', ctypes.c_void_p)]
 
 
 class DcnLevel(ctypes.Structure):

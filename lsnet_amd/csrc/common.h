@@ -62,6 +62,12 @@ __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c)
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
+// A: lane l holds row (l & 15), k = 8 (l >> 4) .. + 7;  B: column (l & 15), same k;  D as the fp32 16x16 form
+__device__ __forceinline__ f32x4 mfma16_bf16(bf16x8 a, bf16x8 b, f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
 // (v0, v1) -> packed bf16 pairs hi = bf16(v), lo = bf16(v - hi); element 0 in the low half-word
 __device__ __forceinline__ void split_bf16x2(float v0, float v1, unsigned &hi, unsigned &lo)
 {

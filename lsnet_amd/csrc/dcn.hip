@@ -232,6 +232,7 @@ static int fill_levels(DcnArgs &a, const lsn_dcn_shape &s, int n, const lsn_dcn_
     a.dbg = g_dbg_buf;
     a.dbg_block = g_dbg_block;
     a.w = a.bias = nullptr;
+    a.wtp = nullptr;
     a.gw = a.gb = nullptr;
     return 0;
 }
@@ -369,9 +370,25 @@ static int launch_bwd_data_win_t(DcnArgs a, hipStream_t st)
     return 0;
 }
 
+static bool bwd_x3_ok(const DcnArgs &a)
+{
+    if (math_mode() != LSN_MATH_BF16X3 || a.wtp == nullptr || a.groups != 1) return false;
+    if (a.Co > 256 || a.Co % 8 != 0 || a.C % 4 != 0) return false;
+    if ((int64_t)a.kh * a.kw * a.C * a.Co * 4 >= ((int64_t)1 << 31)) return false;
+    if (bwd_x3_lds_bytes(a.kh * a.kw * a.dg) > 80 * 1024) return false;
+    return true;
+}
+
 static int launch_bwd_data(const DcnArgs &a, hipStream_t st)
 {
     ProfScope prof(PROF_BWD_DATA, a, st);
+    if (bwd_x3_ok(a) && !bwd_win_ok(a)) {
+        const size_t lds = bwd_x3_lds_bytes(a.kh * a.kw * a.dg);
+        if (int rc = set_lds(dcn_bwd_data_x3_kernel, lds)) return rc;
+        hipLaunchKernelGGL(dcn_bwd_data_x3_kernel, dim3(a.ntiles), dim3(256), lds, st, a);
+        LSN_HIP(hipGetLastError());
+        return 0;
+    }
     if (bwd_win_ok(a))
         return (a.Co / a.groups > 64) ? launch_bwd_data_win_t<256>(a, st) : launch_bwd_data_win_t<64>(a, st);
     return (a.Co / a.groups > 64) ? launch_bwd_data_t<256>(a, st) : launch_bwd_data_t<64>(a, st);
@@ -503,6 +520,12 @@ static int dcn_backward_impl(const lsn_dcn_shape &s, int n, const lsn_dcn_level 
     if (any_data) {
         for (int i = 0; i < n; ++i)
             if (a.lv[i].gx) LSN_HIP(hipMemsetAsync(a.lv[i].gx, 0, sizeof(float) * n_in(s, lv[i]), st));
+        a.wtp = nullptr;
+        if (s.workspace && math_mode() == LSN_MATH_BF16X3 && s.groups == 1 && s.Co % 2 == 0) {
+            hipLaunchKernelGGL(dcn_prepare_wt_kernel, dim3(512), dim3(256), 0, st, a.w,
+                               reinterpret_cast<unsigned short *>(s.workspace), s.Co, K, s.C);
+            a.wtp = reinterpret_cast<const unsigned short *>(s.workspace);
+        }
         if (int rc = launch_bwd_data(a, st)) return rc;
     }
     if (a.gw) {

@@ -42,6 +42,7 @@ struct DcnArgs {
     int C, Co, kh, kw, stride, pad, dil, groups, dg;
     int SL;   // channel segment length = min(C/groups, C/dg): constant (g, dgi) inside a segment
     int msig; // mask tensor holds logits: apply sigmoid on read, chain it into grad_mask
+    const unsigned short *wtp;   // split-bf16 weights for backward-data: planes hi, lo of [K][C][Co] (co contiguous)
     long long *dbg;  // optional phase timestamps of block `dbg_block`, wave 0 (lsn_debug_phase_clocks)
     int dbg_block;
 };
@@ -1125,6 +1126,266 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_kernel(const DcnArgs a)
                 gm *= m * (1.f - m);
             }
             L.gmsk[(size_t)b * L.msb + (size_t)(dgi * K + k) * L.msc + (size_t)ho * L.msh + (size_t)wo * L.msw] = gm;
+        }
+    }
+}
+
+// =============================================================================================
+// Backward-data on the bf16 matrix pipe (dcn_bwd_data_x3_kernel), groups = 1.
+//
+// dcn_bwd_data_kernel with (1) the column-gradient GEMM as split-bf16 products on v_mfma_f32_16x16x32_bf16 -- the
+// gout rows are split once per tile into bf16 hi/lo registers, the weight slab of a chunk comes from planes that
+// dcn_prepare_wt_kernel has split AND transposed to [tap][ci][co] (co contiguous = the MFMA k index), so its staging
+// is a plain 16-byte copy -- and (2) a scatter that merges before it adds: the 4 pixels a lane owns are x-adjacent,
+// so for smooth offset fields the right corner of one is the left corner of the next; equal addresses are summed in
+// registers and zero contributions (integer offsets) are dropped.  The comparison is uniform over the 16 channel
+// lanes of a pixel group, so every skipped add removes a whole 64-byte atomic transaction.
+// =============================================================================================
+constexpr int BX3_RS = 528;   // bytes per LDS row of the transposed weight slab: 256 co x 2 B + 16 B pad
+
+__host__ __device__ inline size_t bwd_x3_lds_bytes(int KD)
+{
+    return (size_t)2 * 32 * BX3_RS + (size_t)BWD_BM * KD * (sizeof(Tap) + 12);
+}
+
+// w (Co, K, C) fp32 -> hi plane [K][C][Co] bf16, then lo plane
+__global__ void dcn_prepare_wt_kernel(const float *w, unsigned short *out, int Co, int K, int C)
+{
+    const size_t n = (size_t)Co * K * C;
+    for (size_t e = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) * 2; e < n; e += (size_t)gridDim.x * blockDim.x * 2) {
+        // destination index e = (k * C + ci) * Co + co, two consecutive co per thread
+        const int co = (int)(e % Co);
+        const size_t r = e / Co;
+        const int ci = (int)(r % C), k = (int)(r / C);
+        const float v0 = w[((size_t)co * K + k) * C + ci], v1 = w[((size_t)(co + 1) * K + k) * C + ci];
+        unsigned hi, lo;
+        split_bf16x2(v0, v1, hi, lo);
+        *reinterpret_cast<unsigned *>(out + e) = hi;
+        *reinterpret_cast<unsigned *>(out + n + e) = lo;
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void dcn_bwd_data_x3_kernel(const DcnArgs a)
+{
+    constexpr int BK = 32, RED = 256, NS = RED / 32, RS = BX3_RS;
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned char *Bh = smem, *Bl = smem + 32 * RS;                      // [32 ch][RED co] bf16, hi / lo
+    Tap *tab = reinterpret_cast<Tap *>(smem + 2 * 32 * RS);              // [64][K*dg]
+    const int K = a.kh * a.kw, KD = K * a.dg;
+    float *gacc = reinterpret_cast<float *>(tab + BWD_BM * KD);          // [64][KD][3]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j16 = lane & 15, kq = lane >> 4;
+    const int C = a.C, Co = a.Co;   // groups == 1
+
+    const Lvl &L = find_level(a, blockIdx.x);
+    const int tile_p = (blockIdx.x - L.tile0) * BWD_BM;
+
+    for (int e = tid; e < BWD_BM * KD; e += 256) {
+        const int pl = e / KD, r = e - pl * KD;
+        const int dgi = r / K, k = r - dgi * K;
+        tab[e] = make_tap(a, L, tile_p + pl, k, dgi);
+    }
+    for (int e = tid; e < BWD_BM * KD * 3; e += 256) gacc[e] = 0.f;
+
+    const int segs = C / a.SL, ncc = (a.SL + BK - 1) / BK;
+    const int T = K * segs * ncc;
+    const bool want_off = (L.goff != nullptr) || (L.gmsk != nullptr);
+
+    // A operand: gout row of pixel (wave * 16 + j16), k-step s covers co = 32 s + 8 kq .. + 7, split once
+    bf16x8 ah[NS], al[NS];
+    {
+        const int my_pix = tile_p + wave * 16 + j16;
+        const bool pix_ok = my_pix < L.P;
+        const float *grow = L.gout + (size_t)(pix_ok ? my_pix : 0) * Co;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int cb = s * 32 + kq * 8;
+            float v[8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const bool ok = pix_ok && cb + h * 4 < Co;   // Co % 4 == 0 on this path
+                const float4 f = *reinterpret_cast<const float4 *>(grow + (ok ? cb + h * 4 : 0));
+                v[h * 4 + 0] = ok ? f.x : 0.f, v[h * 4 + 1] = ok ? f.y : 0.f, v[h * 4 + 2] = ok ? f.z : 0.f,
+                          v[h * 4 + 3] = ok ? f.w : 0.f;
+            }
+            unsigned hi[4], lo[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) split_bf16x2(v[2 * e], v[2 * e + 1], hi[e], lo[e]);
+            const uint4 H = make_uint4(hi[0], hi[1], hi[2], hi[3]), Lo = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+            __builtin_memcpy(&ah[s], &H, 16);
+            __builtin_memcpy(&al[s], &Lo, 16);
+        }
+    }
+
+    // weight slab staging: plane p, channel row r = tid >> 5 (+ 8 per pass), 16-byte piece tid & 31 of its 512 B
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(a.wtp), 0,
+                                                                         K * C * Co * 4, 0x00020000);
+    const int piece = tid & 31, srow = tid >> 5;
+    float4 wv[8];
+    auto load_w = [&](const Chunk &ch) {
+        const int rowbase = ch.k * C + ch.c0;   // row index into [K*C][Co]
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+            const int plane = ps >> 2, r = (ps & 3) * 8 + srow;
+            const bool ok = piece * 8 < Co && r < ch.nval;
+            const int voff = ok ? (plane * K * C * Co + (rowbase + r) * Co) * 2 + piece * 16 : 0x7ffffff0;
+            auto v = __builtin_amdgcn_raw_buffer_load_b128(wrs, voff, 0, 0);
+            __builtin_memcpy(&wv[ps], &v, 16);
+        }
+    };
+    auto store_w = [&]() {
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+            const int plane = ps >> 2, r = (ps & 3) * 8 + srow;
+            *reinterpret_cast<float4 *>((plane ? Bl : Bh) + r * RS + piece * 16) = wv[ps];
+        }
+    };
+
+    __syncthreads();
+    int dbg_n = 0;
+    load_w(decode_chunk<BK>(a, 0, 0, segs, ncc));
+    float sy[4] = {0.f, 0.f, 0.f, 0.f}, sx[4] = {0.f, 0.f, 0.f, 0.f}, sm[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < T; ++t) {
+        const Chunk ch = decode_chunk<BK>(a, 0, t, segs, ncc);
+        const Chunk chn = decode_chunk<BK>(a, 0, min(t + 1, T - 1), segs, ncc);
+        const bool tap_done = (t + 1 == T) || chn.k != ch.k || chn.dgi != ch.dgi;
+        LSN_STAMP(2);
+        store_w();
+        LSN_STAMP(3);
+        __syncthreads();
+        LSN_STAMP(4);
+        if (t + 1 < T) load_w(chn);
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        {
+            const unsigned char *b0 = Bh + j16 * RS + kq * 16, *b1 = Bh + (16 + j16) * RS + kq * 16;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const bf16x8 h0 = *reinterpret_cast<const bf16x8 *>(b0 + s * 64);
+                const bf16x8 h1 = *reinterpret_cast<const bf16x8 *>(b1 + s * 64);
+                const bf16x8 l0 = *reinterpret_cast<const bf16x8 *>(b0 + 32 * RS + s * 64);
+                const bf16x8 l1 = *reinterpret_cast<const bf16x8 *>(b1 + 32 * RS + s * 64);
+                acc0 = mfma16_bf16(ah[s], h0, acc0);
+                acc1 = mfma16_bf16(ah[s], h1, acc1);
+                acc0 = mfma16_bf16(ah[s], l0, acc0);
+                acc1 = mfma16_bf16(ah[s], l1, acc1);
+                acc0 = mfma16_bf16(al[s], h0, acc0);
+                acc1 = mfma16_bf16(al[s], h1, acc1);
+            }
+        }
+        LSN_STAMP(5);
+
+        // ---- consume gcol[16 px][32 ch] of this wave: D row = 4*kq + r (x-adjacent pixels), col = tn*16 + j16 ----
+        const int kd = ch.dgi * K + ch.k;
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const int cl = tn * 16 + j16;
+            const bool cval = cl < ch.nval;
+            const int c = ch.c0 + (cval ? cl : 0);
+            Tap tp[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tp[r] = tab[(wave * 16 + kq * 4 + r) * KD + kd];
+            float xv[4][4];
+            if (want_off) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    xv[r][0] = L.x[tp[r].i00 + c];
+                    xv[r][1] = L.x[tp[r].i01 + c];
+                    xv[r][2] = L.x[tp[r].i10 + c];
+                    xv[r][3] = L.x[tp[r].i11 + c];
+                }
+            }
+            float gm[4], w00[4], w01[4], w10[4], w11[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float gval = cval ? (tn == 0 ? acc0[r] : acc1[r]) : 0.f;
+                corner_weights(tp[r], w00[r], w01[r], w10[r], w11[r]);
+                gm[r] = gval * tp[r].m;
+                if (want_off) {
+                    const float hy = 1.f - tp[r].ly, hx = 1.f - tp[r].lx;
+                    const float v00 = (tp[r].flags & 1) ? xv[r][0] : 0.f;
+                    const float v01 = (tp[r].flags & 2) ? xv[r][1] : 0.f;
+                    const float v10 = (tp[r].flags & 4) ? xv[r][2] : 0.f;
+                    const float v11 = (tp[r].flags & 8) ? xv[r][3] : 0.f;
+                    const float dy = hx * (v10 - v00) + tp[r].lx * (v11 - v01);
+                    const float dx = hy * (v01 - v00) + tp[r].ly * (v11 - v10);
+                    const float bil = hy * hx * v00 + hy * tp[r].lx * v01 + tp[r].ly * hx * v10 + tp[r].ly * tp[r].lx * v11;
+                    sy[r] += gm[r] * dy;
+                    sx[r] += gm[r] * dx;
+                    sm[r] += gval * bil;
+                }
+            }
+            if (L.gx != nullptr && cval) {
+                // merged scatter, one image row of corners at a time: walk the 4 pixels left to right with a pending
+                // (address, value); a corner equal to the pending address is summed into it, anything else flushes.
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    int pa = -1;
+                    float pv = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int aL = half ? tp[r].i10 : tp[r].i00, aR = half ? tp[r].i11 : tp[r].i01;
+                        const float vL = (half ? w10[r] : w00[r]) * gm[r], vR = (half ? w11[r] : w01[r]) * gm[r];
+                        const bool live = tp[r].flags != 0;   // wholly invalid samples carry index 0: never touch it
+                        if (live && aL == pa) {
+                            pv += vL;
+                        } else {
+                            if (pa >= 0 && pv != 0.f) atomic_add_f32(L.gx + pa + c, pv);
+                            pa = live ? aL : -1;
+                            pv = vL;
+                        }
+                        if (live && aR == pa) {
+                            pv += vR;
+                        } else {
+                            if (pa >= 0 && pv != 0.f) atomic_add_f32(L.gx + pa + c, pv);
+                            pa = live ? aR : -1;
+                            pv = vR;
+                        }
+                    }
+                    if (pa >= 0 && pv != 0.f) atomic_add_f32(L.gx + pa + c, pv);
+                }
+            }
+        }
+        if (want_off && tap_done) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float vy = row16_sum(sy[r]), vx = row16_sum(sx[r]), vm = row16_sum(sm[r]);
+                if (j16 == 0) {
+                    float *ga = gacc + ((wave * 16 + kq * 4 + r) * KD + kd) * 3;
+                    ga[0] += vy;
+                    ga[1] += vx;
+                    ga[2] += vm;
+                }
+                sy[r] = sx[r] = sm[r] = 0.f;
+            }
+        }
+        LSN_STAMP(6);
+        __syncthreads();  // slab free for the next chunk
+        LSN_STAMP(7);
+    }
+    __syncthreads();
+
+    for (int e = tid; e < BWD_BM * KD; e += 256) {
+        const int pl = e / KD, r = e - pl * KD;
+        const int dgi = r / K, k = r - dgi * K;
+        const int pix = tile_p + pl;
+        if (pix >= L.P) continue;
+        const int HWo = L.Ho * L.Wo;
+        const int b = pix / HWo, rem = pix - b * HWo;
+        const int ho = rem / L.Wo, wo = rem - ho * L.Wo;
+        const float *ga = gacc + e * 3;
+        if (L.goff) {
+            float *op = L.goff + (size_t)b * L.osb + (size_t)ho * L.osh + (size_t)wo * L.osw;
+            op[(size_t)(dgi * 2 * K + 2 * k) * L.osc] = ga[0];
+            op[(size_t)(dgi * 2 * K + 2 * k + 1) * L.osc] = ga[1];
+        }
+        if (L.gmsk) {
+            float gmv = ga[2];
+            if (a.msig) {
+                const float m = tab[e].m;
+                gmv *= m * (1.f - m);
+            }
+            L.gmsk[(size_t)b * L.msb + (size_t)(dgi * K + k) * L.msc + (size_t)ho * L.msh + (size_t)wo * L.msw] = gmv;
         }
     }
 }

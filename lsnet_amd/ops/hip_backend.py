@@ -182,6 +182,10 @@ class HipBackend:
                 L.mask_st = _strides(msks[i])
             L.B, L.H, L.W, L.Ho, L.Wo = B, H, W, Ho, Wo
             L.scale_h, L.scale_w = cfg['scales'][i]
+        ws = None
+        if cfg['groups'] == 1 and _lib.get_math_mode() == 'bf16x3':
+            ws = torch.empty(w.numel(), device=w.device, dtype=torch.float32)   # split + transposed weights
+            shape.workspace = ws.data_ptr()
         gw = torch.empty_like(w) if (need['weight'] or need['bias']) else None
         gb = torch.empty(w.shape[0], device=w.device, dtype=torch.float32) if need['bias'] else None
         _lib.check(lib.lsn_dcn_backward(ctypes.byref(shape), n, levels, _ptr(w), _ptr(gw), _ptr(gb),
