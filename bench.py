@@ -64,9 +64,17 @@ def parse():
 
 
 KERNEL_NOTES = {
-    'dcn_fwd': 'lsn::dcn_fwd_pipe_kernel (fused bilinear gather + MFMA implicit GEMM, forward)',
-    'dcn_bwd_data': 'lsn::dcn_bwd_data_kernel (gout x W^T on MFMA, fused bilinear scatter: grad input/offset/mask)',
-    'dcn_wgrad': 'lsn::dcn_wgrad_kernel (gathered columns^T x gout on MFMA: grad weight/bias)',
+    'bf16x3': {
+        'dcn_fwd': 'lsn::dcn_fwd_x3_kernel (fused bilinear gather + split-bf16 MFMA implicit GEMM, forward)',
+        'dcn_bwd_data': 'lsn::dcn_bwd_data_x3_kernel (gout x W^T as split-bf16 MFMA, merged bilinear scatter: grad '
+                        'input/offset/mask)',
+        'dcn_wgrad': 'lsn::dcn_wgrad_x3_kernel (gathered columns^T x gout as split-bf16 MFMA: grad weight/bias)',
+    },
+    'fp32': {
+        'dcn_fwd': 'lsn::dcn_fwd_pipe_kernel (fused bilinear gather + fp32 MFMA implicit GEMM, forward)',
+        'dcn_bwd_data': 'lsn::dcn_bwd_data_kernel / _win_kernel (gout x W^T on fp32 MFMA, fused bilinear scatter)',
+        'dcn_wgrad': 'lsn::dcn_wgrad_kernel (gathered columns^T x gout on fp32 MFMA: grad weight/bias)',
+    },
 }
 
 
@@ -258,11 +266,11 @@ def main():
                        else 'eager',
                        'math': 'fp32 tensors; conv / deformable-conv products as 3 bf16 MFMAs on split operands '
                                '(hi*hi + hi*lo + lo*hi), fp32 accumulation, rel. err 5e-6 vs exact fp32 (tests); '
-                               'backward of the deformable convs and small convs still exact fp32'
+                               'small / grouped / stride-2-backward convs and all conv weight gradients stay on MIOpen fp32'
                        if args.math == 'bf16x3' else 'exact fp32 MFMA / MIOpen fp32'},
             'loss': {k: round(v, 5) for k, v in losses.items()},
         }
-        x3 = {'dcn_fwd'} if args.math == 'bf16x3' else set()     # kernel families running split-bf16 MFMAs
+        x3 = {'dcn_fwd', 'dcn_bwd_data', 'dcn_wgrad'} if args.math == 'bf16x3' else set()   # split-bf16 MFMA kernels
 
         def peak_of(k):
             return BF16_MFMA_PEAK_TFLOPS / 3.0 if k in x3 else FP32_MFMA_PEAK_TFLOPS
@@ -274,10 +282,11 @@ def main():
             dom = max(ks, key=lambda k: ks[k]['total_ms'])   # the kernel with the most GPU time in the timed steps
             k = ks[dom]
             res['kernels'] = ks
-            res['roofline'] = {'kernel': KERNEL_NOTES.get(dom, dom), 'bound': 'mfma', 'achieved': k['tflops'],
+            res['roofline'] = {'kernel': KERNEL_NOTES[args.math].get(dom, dom), 'bound': 'mfma', 'achieved': k['tflops'],
                                'peak': peak_of(dom), 'unit': 'TFLOP/s',
-                               'frac': k['tflops'] / peak_of(dom), 'peak_note': peak_note(dom), 'traffic': HBM_TRAFFIC_GB.get(dom),
-                               'traffic_unit': 'GB/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/)',
+                               'frac': k['tflops'] / peak_of(dom), 'peak_note': peak_note(dom), 'traffic': HBM_TRAFFIC_GB.get(dom) if args.math == 'fp32' else None,
+                               'traffic_unit': 'GB/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE of the fp32 kernels, profiles/r1c_pmc_hbm.txt; '
+                                               'no counter pass exists for the split-bf16 kernels yet)',
                                'launches_timed': k['launches'], 'avg_launch_ms': k['avg_ms'],
                                'gflop_per_launch': k['gflop_per_launch'],
                                'alg_gbytes_per_launch': k['alg_gbytes_per_launch'],

@@ -329,6 +329,15 @@ static int launch_bwd_data_t(const DcnArgs &a, hipStream_t st)
     return 0;
 }
 
+static bool bwd_x3_ok(const DcnArgs &a)
+{
+    if (math_mode() != LSN_MATH_BF16X3 || a.wtp == nullptr || a.groups != 1) return false;
+    if (a.Co > 256 || a.Co % 8 != 0 || a.C % 4 != 0) return false;
+    if ((int64_t)a.kh * a.kw * a.C * a.Co * 4 >= ((int64_t)1 << 31)) return false;
+    if (bwd_x3_lds_bytes(a.kh * a.kw * a.dg) > 80 * 1024) return false;
+    return true;
+}
+
 // windowed-scatter variant: 16x8 output patches (its own tile table), see dcn_kernels.h
 static bool bwd_win_ok(const DcnArgs &a)
 {
@@ -336,12 +345,16 @@ static bool bwd_win_ok(const DcnArgs &a)
     if (bwd_win_lds_bytes(RED, KD) > 160 * 1024) return false;
     for (int i = 0; i < a.nlv; ++i)
         if (a.lv[i].H > 32767 || a.lv[i].W > 32767) return false;   // 15-bit packed window coordinates
+    static const int env_win = [] { const char *e = getenv("LSNET_BWD_WIN"); return e ? atoi(e) : -1; }();
+    if (env_win == 0) return false;   // LSNET_BWD_WIN=0/1: A/B switch for whole-step measurements
+    if (env_win == 1) return true;
     if ((g_dbg_block >> 25) & 1) return false;   // bits 25 / 24 of the debug word force one kernel (A/B runs)
     if ((g_dbg_block >> 24) & 1) return true;
-    // Measured in the LSNet step (profiles/): the windowed kernel wins where samples travel far and converge --
-    // the pyramid op, whose offsets are landmark vectors (3.76 vs 4.23 ms) -- and loses on the tower convolutions,
-    // whose learned offsets stay within a pixel (1.46 vs 1.33 ms: its fixed-point conversions cost more VALU time
-    // than the atomics they save).  A launch is treated as "pyramid" when any level resamples (scale != 1).
+    // Measured in the LSNet step (profiles/): against the first fp32 kernel the windowed one won on the pyramid op
+    // (3.76 vs 4.23 ms) and lost on the tower convolutions (1.46 vs 1.33 ms); the split-bf16 kernel with the merged
+    // scatter beats both (2.7 ms / 1.0 ms), so the windowed kernel is only used when asked for (LSNET_BWD_WIN=1 or
+    // debug bit 24) or when the split kernel does not apply and the launch resamples (scale != 1).
+    if (bwd_x3_ok(a)) return false;
     for (int i = 0; i < a.nlv; ++i)
         if (a.lv[i].sh != 1.f || a.lv[i].sw != 1.f) return true;
     return false;
@@ -370,19 +383,10 @@ static int launch_bwd_data_win_t(DcnArgs a, hipStream_t st)
     return 0;
 }
 
-static bool bwd_x3_ok(const DcnArgs &a)
-{
-    if (math_mode() != LSN_MATH_BF16X3 || a.wtp == nullptr || a.groups != 1) return false;
-    if (a.Co > 256 || a.Co % 8 != 0 || a.C % 4 != 0) return false;
-    if ((int64_t)a.kh * a.kw * a.C * a.Co * 4 >= ((int64_t)1 << 31)) return false;
-    if (bwd_x3_lds_bytes(a.kh * a.kw * a.dg) > 80 * 1024) return false;
-    return true;
-}
-
 static int launch_bwd_data(const DcnArgs &a, hipStream_t st)
 {
     ProfScope prof(PROF_BWD_DATA, a, st);
-    if (bwd_x3_ok(a) && !bwd_win_ok(a)) {
+    if (!bwd_win_ok(a) && bwd_x3_ok(a)) {
         const size_t lds = bwd_x3_lds_bytes(a.kh * a.kw * a.dg);
         if (int rc = set_lds(dcn_bwd_data_x3_kernel, lds)) return rc;
         hipLaunchKernelGGL(dcn_bwd_data_x3_kernel, dim3(a.ntiles), dim3(256), lds, st, a);
