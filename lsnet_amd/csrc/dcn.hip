@@ -288,8 +288,13 @@ static int launch_forward(const DcnArgs &a, hipStream_t st)
     if (math_mode() == LSN_MATH_BF16X3 && x3_lds_bytes(a.kh * a.kw * a.dg) <= 160 * 1024) {
         ProfScope prof(PROF_FWD, a, st);
         const size_t lds3 = x3_lds_bytes(a.kh * a.kw * a.dg);
-        if (int rc = set_lds(dcn_fwd_x3_kernel, lds3)) return rc;
-        hipLaunchKernelGGL(dcn_fwd_x3_kernel, grid, dim3(256), lds3, st, a);
+        if (a.wtp) {
+            if (int rc = set_lds(dcn_fwd_x3_kernel<true>, lds3)) return rc;
+            hipLaunchKernelGGL(dcn_fwd_x3_kernel<true>, grid, dim3(256), lds3, st, a);
+        } else {
+            if (int rc = set_lds(dcn_fwd_x3_kernel<false>, lds3)) return rc;
+            hipLaunchKernelGGL(dcn_fwd_x3_kernel<false>, grid, dim3(256), lds3, st, a);
+        }
         LSN_HIP(hipGetLastError());
         return 0;
     }
@@ -462,6 +467,13 @@ static int dcn_forward_impl(const lsn_dcn_shape &s, int n, const lsn_dcn_level *
         }
     }
     a.bias = bias;
+    a.wtp = nullptr;
+    if (s.workspace && math_mode() == LSN_MATH_BF16X3 && (Cg % 8 == 0) && a.Co / a.groups > 64 && pipe_ok(a)) {
+        const size_t nw = (size_t)s.Co * K * Cg;   // split the weights once instead of in every block
+        hipLaunchKernelGGL(dcn_prepare_w_kernel, dim3(512), dim3(256), 0, st, a.w,
+                           reinterpret_cast<unsigned short *>(s.workspace), nw);
+        a.wtp = reinterpret_cast<const unsigned short *>(s.workspace);
+    }
     if (int rc = launch_forward(a, st)) return rc;
     if (layout == LSN_NCHW)
         for (int i = 0; i < n; ++i)

@@ -689,6 +689,9 @@ __host__ __device__ inline size_t x3_lds_bytes(int KD)
     return (size_t)2 * 2 * (PIPE_BM + PIPE_BN) * X3_RS + (size_t)PIPE_BM * KD * sizeof(Tap);
 }
 
+// PREP: a.wtp holds the weights already split by dcn_prepare_w_kernel (planes hi, lo of [Co][K][C/groups] bf16):
+// their staging is a 16-byte copy per slice instead of ~14 VALU instructions per float4
+template <bool PREP>
 __global__ __launch_bounds__(256, 1) void dcn_fwd_x3_kernel(const DcnArgs a)
 {
     constexpr int BM = PIPE_BM, BN = PIPE_BN, BK = PIPE_BK, RS = X3_RS;
@@ -722,13 +725,21 @@ __global__ __launch_bounds__(256, 1) void dcn_fwd_x3_kernel(const DcnArgs a)
     const __amdgpu_buffer_rsrc_t xrs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(L.x), 0, L.B * L.H * L.W * a.C * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrs =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.w), 0, a.Co * Kdim * 4, 0x00020000);
+        PREP ? __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(a.wtp), 0, a.Co * Kdim * 4, 0x00020000)
+             : __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.w), 0, a.Co * Kdim * 4, 0x00020000);
+    // PREP slices: plane (ps & 1), rows (ps >> 1) * 64 + (tid >> 2), 16-byte slot tid & 3
+    const int pq = tid & 3, prw = tid >> 2;
 
     int wvoff[NPB];
 #pragma unroll
     for (int ps = 0; ps < NPB; ++ps) {
-        const int col = ps * 32 + wrow;
-        wvoff[ps] = (col < nco) ? ((co_base + col) * Kdim + wq * 4) * 4 : 0x7ffffff0;
+        if (PREP) {
+            const int col = (ps >> 1) * 64 + prw;
+            wvoff[ps] = (col < nco) ? ((ps & 1) * a.Co * Kdim + (co_base + col) * Kdim) * 2 + pq * 16 : 0x7ffffff0;
+        } else {
+            const int col = ps * 32 + wrow;
+            wvoff[ps] = (col < nco) ? ((co_base + col) * Kdim + wq * 4) * 4 : 0x7ffffff0;
+        }
     }
 
     int voffI[NPA][4];
@@ -763,7 +774,9 @@ __global__ __launch_bounds__(256, 1) void dcn_fwd_x3_kernel(const DcnArgs a)
 #pragma unroll
         for (int q = 0; q < 4; ++q) xv[ps][q] = buf_load_f32x2(xrs, voffI[ps][q], soff);
     };
-    auto issue_w = [&](const Chunk &ch, int ps) { wv[ps] = buf_load_f32x4(wrs, wvoff[ps], (ch.k * Cg + ch.c0) * 4); };
+    auto issue_w = [&](const Chunk &ch, int ps) {
+        wv[ps] = buf_load_f32x4(wrs, wvoff[ps], (ch.k * Cg + ch.c0) * (PREP ? 2 : 4));
+    };
     auto commit_x = [&](const Chunk &ch, int ps, unsigned char *buf) {
         float v0 = wgtC[ps][0] * xv[ps][0].x + wgtC[ps][1] * xv[ps][1].x + wgtC[ps][2] * xv[ps][2].x +
                    wgtC[ps][3] * xv[ps][3].x;
@@ -778,6 +791,11 @@ __global__ __launch_bounds__(256, 1) void dcn_fwd_x3_kernel(const DcnArgs a)
         *reinterpret_cast<unsigned *>(p + PLANE_A) = lo;
     };
     auto commit_w = [&](const Chunk &ch, int ps, unsigned char *buf) {
+        if (PREP) {   // columns past nval hold neighbouring values; the A operand is zero there
+            unsigned char *p = buf + 2 * PLANE_A + (ps & 1) * PLANE_B + ((ps >> 1) * 64 + prw) * RS + pq * 16;
+            *reinterpret_cast<float4 *>(p) = wv[ps];
+            return;
+        }
         const bool ok = wq * 4 < ch.nval;   // nval is a multiple of 4 on this path (vec_ok)
         const float4 v = ok ? wv[ps] : make_float4(0.f, 0.f, 0.f, 0.f);
         uint2 hi, lo;
@@ -1146,6 +1164,17 @@ constexpr int BX3_RS = 528;   // bytes per LDS row of the transposed weight slab
 __host__ __device__ inline size_t bwd_x3_lds_bytes(int KD)
 {
     return (size_t)2 * 32 * BX3_RS + (size_t)BWD_BM * KD * (sizeof(Tap) + 12);
+}
+
+// w (n floats, any layout) -> bf16 hi plane (n) followed by the lo plane (n), same element order
+__global__ void dcn_prepare_w_kernel(const float *w, unsigned short *out, size_t n)
+{
+    for (size_t e = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) * 2; e < n; e += (size_t)gridDim.x * blockDim.x * 2) {
+        unsigned hi, lo;
+        split_bf16x2(w[e], w[e + 1], hi, lo);
+        *reinterpret_cast<unsigned *>(out + e) = hi;
+        *reinterpret_cast<unsigned *>(out + n + e) = lo;
+    }
 }
 
 // w (Co, K, C) fp32 -> hi plane [K][C][Co] bf16, then lo plane

@@ -145,6 +145,9 @@ class HipBackend:
             L.B, L.H, L.W, L.Ho, L.Wo = B, H, W, Ho, Wo
             L.scale_h, L.scale_w = cfg['scales'][i]
         b = None if bias is None else _f32(bias.contiguous(), 'bias')
+        if _lib.get_math_mode() == 'bf16x3':
+            ws = torch.empty(w.numel(), device=w.device, dtype=torch.float32)   # pre-split weights
+            shape.workspace = ws.data_ptr()
         _lib.check(lib.lsn_dcn_forward(ctypes.byref(shape), n, levels, _ptr(w), _ptr(b), 1 if nhwc else 0,
                                        _stream()))
         return outs
