@@ -99,3 +99,47 @@ def test_focal_and_nms_wrappers(cpu_oracle_backend):
     assert keep.tolist() == [0, 2] and dets.shape == (2, 5)
     dets, keep = ops.batched_nms(boxes, scores, torch.tensor([0, 1, 0]), dict(type='nms', iou_thr=0.5))
     assert keep.tolist() == [0, 1, 2]
+
+
+# ---------------------------------------------------------------------------------------------
+# host-side dispatch of the fused / own-kernel modules: on CPU tensors they are the reference's ATen ops
+def test_conv_bn_gn_modules_are_aten_on_cpu():
+    import torch.nn.functional as F
+    from lsnet_amd.ops.batch_norm import bn_act
+    from lsnet_amd.ops.conv import Conv2d, _own_is_faster, hip_conv_ok
+    from lsnet_amd.ops.group_norm import GroupNorm
+    torch.manual_seed(0)
+    x = torch.randn(2, 32, 9, 11)
+    conv = Conv2d(32, 48, 3, padding=1)
+    assert not hip_conv_ok(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups)
+    assert torch.equal(conv(x), F.conv2d(x, conv.weight, conv.bias, 1, 1))
+    assert set(conv.state_dict()) == {'weight', 'bias'}            # checkpoint keys of nn.Conv2d
+    gn = GroupNorm(8, 32)
+    y = gn.forward_multi([x, x[:, :, :4]], relu=True)
+    assert torch.allclose(y[0], F.relu(F.group_norm(x, 8, gn.weight, gn.bias, gn.eps)))
+    assert y[1].shape == (2, 32, 4, 11)
+    bn = torch.nn.BatchNorm2d(32).eval()
+    r = torch.randn_like(x)
+    assert torch.allclose(bn_act(bn, x, relu=True, residual=r), F.relu(bn(x) + r))
+    # the shape rule: big deep layers go to the split-bf16 kernel, small / shallow ones stay on the vendor library
+    assert _own_is_faster(2 * 100 * 168, 256, 256, 9) and _own_is_faster(2 * 50 * 84, 1024, 256, 1)
+    assert not _own_is_faster(2 * 200 * 336, 64, 64, 9) and not _own_is_faster(2 * 25 * 42, 512, 512, 9)
+    assert not _own_is_faster(2 * 100 * 168, 256, 27, 9)
+
+
+def test_resnet_block_equals_reference_sequence():
+    """Bottleneck with the fused bn_act calls == conv/bn/relu/add written out (CPU: ATen both ways)."""
+    import torch.nn.functional as F
+    from lsnet_amd.models.backbones.resnet import Bottleneck
+    torch.manual_seed(1)
+    ds = torch.nn.Sequential(torch.nn.Conv2d(16, 32, 1, stride=2, bias=False), torch.nn.BatchNorm2d(32))
+    blk = Bottleneck(16, 8, stride=2, downsample=ds).eval()
+    for m in blk.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_()
+            m.running_var.uniform_(0.5, 2)
+    x = torch.randn(2, 16, 12, 10)
+    out = F.relu(blk.norm1(blk.conv1(x)))
+    out = F.relu(blk.norm2(blk.conv2(out)))
+    want = F.relu(blk.norm3(blk.conv3(out)) + ds(x))
+    assert torch.allclose(blk(x), want, atol=1e-6)
