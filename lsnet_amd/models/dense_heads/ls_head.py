@@ -398,8 +398,7 @@ class LSHead(nn.Module):
         for k in per_img[0]:
             if k == 'num_pos':
                 continue
-            stacked = torch.stack([t[k] for t in per_img], 0)
-            out[k] = list(torch.split(stacked, num_level, dim=1))
+            out[k] = torch.stack([t[k] for t in per_img], 0)     # (B, N_all, ...): levels stay concatenated
         return out, num_total_pos
 
     # --------------------------------------------------------------------------------------- loss
@@ -427,17 +426,34 @@ class LSHead(nn.Module):
         act = torch.stack([~nonneg[..., 1], nonneg[..., 1], ~nonneg[..., 0], nonneg[..., 0]], dim=-1)
         return reg.reshape(-1, 4 * m), act.reshape(-1, 4 * m)
 
-    def loss_single(self, cls_score, preds, tg_init, tg_refine, anchor_pts, stride, n_init, n_refine):
-        """One FPN level (lsnet_head.py:1021-1270).  preds: branch -> (init, refine) maps;
-        tg_*: level slices of the target dicts."""
-        labels = tg_refine['labels'].reshape(-1)
-        label_weights = tg_refine['label_weights'].reshape(-1)
-        cls_score = cls_score.permute(0, 2, 3, 1).reshape(-1, self.cls_out_channels)
-        losses = dict(cls=self.loss_cls(cls_score, labels, label_weights, avg_factor=n_refine))
-        anchor = anchor_pts.reshape(-1, 3)
+    def _level_rows(self, num_level, like):
+        """(N_all,) stride of every point's level, built once per grid geometry (constants are not re-created
+        inside the step)."""
+        key = ('strides', tuple(num_level), like.device, like.dtype)
+        t = self._consts.get(key)
+        if t is None:
+            t = torch.cat([like.new_full((n,), float(s)) for n, s in zip(num_level, self.point_strides)])
+            self._consts[key] = t
+        return t
+
+    def loss_levels(self, cls_scores, preds, tg_init, tg_refine, points, num_level, n_init, n_refine):
+        """The per-level losses of the reference's `loss_single` (lsnet_head.py:1021-1270) for ALL levels at once.
+        The regression targets and the cross-IOU terms are row-wise functions of (prediction, target, anchor,
+        stride): they are evaluated once on the concatenation of the levels -- a fifth of the elementwise launches
+        -- and only the final sums are taken per level, so the returned lists hold the same per-level values."""
+        B = cls_scores[0].shape[0]
+        losses = {'cls': []}
+        labels = torch.split(tg_refine['labels'], num_level, dim=1)
+        label_w = torch.split(tg_refine['label_weights'], num_level, dim=1)
+        for lvl, cs in enumerate(cls_scores):
+            cs = cs.permute(0, 2, 3, 1).reshape(-1, self.cls_out_channels)
+            losses['cls'].append(self.loss_cls(cs, labels[lvl].reshape(-1), label_w[lvl].reshape(-1),
+                                               avg_factor=n_refine))
+        stride = self._level_rows(num_level, points[0]).repeat(B).unsqueeze(1)            # (B*N_all, 1)
         norm = self.point_base_scale * stride
+        anchor = torch.cat(points)[None].expand(B, -1, -1).reshape(-1, 3)
         for b in self.branches:
-            for stage, tg, pred, n in (('init', tg_init, preds[b][0], n_init), ('refine', tg_refine, preds[b][1], n_refine)):
+            for stage, tg, plist, n in (('init', tg_init, preds[b][0], n_init), ('refine', tg_refine, preds[b][1], n_refine)):
                 bw = tg['bbox_weights'].reshape(-1, 4)
                 bbox_gt = tg['bboxes_gt'].reshape(-1, 4)
                 if b == 'bbox':
@@ -451,11 +467,14 @@ class LSHead(nn.Module):
                     kw = dict(bbox_gt=None, vs=tg['keypoints_vs'].reshape(-1, self.num_vectors))
                 width = gt_pts.shape[1] * 2
                 weights = bw[:, :1].expand(-1, width)
-                pred = pred.permute(0, 2, 3, 1).reshape(-1, width) * stride
+                pred = torch.cat([p.permute(0, 2, 3, 1).reshape(B, -1, width) for p in plist], dim=1)
+                pred = pred.reshape(-1, width) * stride
                 gt_reg, active = self._gt_reg(gt_pts, anchor, weights)
                 loss_fn = getattr(self, f'loss_{b}_{stage}')
-                losses[f'{b}_{stage}'] = loss_fn(pred / norm, gt_reg / norm, weights, avg_factor=n,
-                                                 anchor_pts=anchor[:, :-1] / norm, pos_inds=active, **kw)
+                rows = loss_fn(pred / norm, gt_reg / norm, weights, reduction_override='none',
+                               anchor_pts=anchor[:, :-1] / norm, pos_inds=active, **kw)   # weighted, per row
+                per_level = torch.split(rows.reshape(B, -1), num_level, dim=1)
+                losses[f'{b}_{stage}'] = [r.sum() / n for r in per_level]
         return losses
 
     def loss(self, cls_scores, bbox_pts_preds_init, bbox_pts_preds_refine, segm_pts_preds_init,
@@ -508,17 +527,12 @@ class LSHead(nn.Module):
         tg_refine, n_refine = self.get_targets([boxes[i] for i in range(num_imgs)], flat_flags, all_valid,
                                                num_level, gt_bboxes, gt_labels, extra, 'refine')
 
-        per_level = []
-        for lvl in range(len(cls_scores)):
-            lv_preds = {b: (preds[b][0][lvl], preds[b][1][lvl]) for b in self.branches}
-            anchor = points[lvl][None].expand(num_imgs, -1, -1)
-            per_level.append(self.loss_single(cls_scores[lvl], lv_preds, {k: v[lvl] for k, v in tg_init.items()},
-                                              {k: v[lvl] for k, v in tg_refine.items()}, anchor,
-                                              self.point_strides[lvl], n_init, n_refine))
-        out = {'loss_cls': [d['cls'] for d in per_level]}
+        lv = self.loss_levels(cls_scores, {b: preds[b] for b in self.branches}, tg_init, tg_refine, points, num_level,
+                              n_init, n_refine)
+        out = {'loss_cls': lv['cls']}
         for b in self.branches:
-            out[f'loss_{b}_init'] = [d[f'{b}_init'] for d in per_level]
-            out[f'loss_{b}_refine'] = [d[f'{b}_refine'] for d in per_level]
+            out[f'loss_{b}_init'] = lv[f'{b}_init']
+            out[f'loss_{b}_refine'] = lv[f'{b}_refine']
         return out
 
     # ----------------------------------------------------------------------------------- decoding
