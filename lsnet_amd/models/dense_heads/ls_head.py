@@ -248,11 +248,32 @@ class LSHead(nn.Module):
             return [lvl, lvl - 1, lvl - 2]
         return [lvl, lvl - 1, lvl + 1]
 
+    @staticmethod
+    def _cat_px(maps):
+        """Per-level maps (B, C, H_l, W_l) -> ONE (B, C, N_all, 1) tensor in channels-last memory (pixel rows of all
+        levels back to back).  1x1 convolutions and pointwise functions do not care where a pixel came from, so the
+        levels share one launch (and one weight-gradient accumulation) instead of five."""
+        B, C = maps[0].shape[:2]
+        x = torch.cat([m.permute(0, 2, 3, 1).reshape(B, -1, C) for m in maps], dim=1)      # (B, N_all, C)
+        return x.unsqueeze(2).permute(0, 3, 1, 2)
+
+    @staticmethod
+    def _split_px(x, shapes):
+        """Inverse of `_cat_px`: per-level (B, C, H_l, W_l) VIEWS of a (B, C, N_all, 1) tensor."""
+        B, C = x.shape[:2]
+        flat = x.permute(0, 2, 3, 1).reshape(B, -1, C)
+        outs, o = [], 0
+        for h, w in shapes:
+            outs.append(flat[:, o:o + h * w].reshape(B, h, w, C).permute(0, 3, 1, 2))
+            o += h * w
+        return outs
+
     def forward(self, feats):
         """feats: tuple of 5 FPN maps.  Returns the reference's 7-tuple of per-level lists
         (cls, bbox_init, bbox_refine, segm_init, segm_refine, pose_init, pose_refine); branches the
         task does not have are lists of None (lsnet_head.py:479-500)."""
         nl = len(feats)
+        shapes = [tuple(f.shape[2:]) for f in feats]
         base_offset = self.dcn_base_offset.type_as(feats[0])
         cls_feats = self._run_tower(self.cls_convs, feats)
         st = {}
@@ -260,15 +281,13 @@ class LSHead(nn.Module):
             tower = self._run_tower(getattr(self, f'{b}_convs'), feats)
             init_conv, init_out = getattr(self, f'pts_{b}_init_conv'), getattr(self, f'pts_{b}_init_out')
             n_sp = self._out_dims(b)[1]
-            sps, offs = [], []
-            for f in tower:
-                raw = init_out(self.relu(init_conv(f)))
-                sp = self.softplus(raw[:, :n_sp])
-                reg = self.get_pred_reg(sp, raw[:, n_sp:] if raw.shape[1] > n_sp else None)
-                reg = (1 - self.gradient_mul) * reg.detach() + self.gradient_mul * reg
-                sps.append(sp)
-                offs.append(reg - base_offset)
-            st[b] = dict(feat=tower, sp=sps, off=offs)
+            # 3x3 conv per level; everything after it is pixel-wise: one pass over the concatenated levels
+            raw = init_out(self.relu(self._cat_px([init_conv(f) for f in tower])))
+            sp = self.softplus(raw[:, :n_sp])
+            reg = self.get_pred_reg(sp, raw[:, n_sp:] if raw.shape[1] > n_sp else None)
+            reg = (1 - self.gradient_mul) * reg.detach() + self.gradient_mul * reg
+            st[b] = dict(feat=tower, sp_all=sp, sp=self._split_px(sp, shapes),
+                         off=self._split_px(reg - base_offset, shapes))
 
         # --- offsets handed to the pyramid convs.  The reference rescales the offset tensor IN PLACE
         # while looping over the three source levels, so the multipliers accumulate:
@@ -296,14 +315,14 @@ class LSHead(nn.Module):
         outs = {}
         fused = [self.cls_af_dcn_conv(torch.cat(cls_raw[3 * l:3 * l + 3], dim=1)) + self.cls_feat_conv(cls_feats[l])
                  for l in range(nl)]
-        outs['cls'] = [self.pts_cls_out(y) for y in self.cls_GN.forward_multi(fused, relu=True)]
+        outs['cls'] = self._split_px(self.pts_cls_out(self._cat_px(self.cls_GN.forward_multi(fused, relu=True))), shapes)
         for b in self.branches:
             raw = gather(getattr(self, f'pts_{b}_refine_conv'), st[b]['feat'], scaled[b])
             af, fc = getattr(self, f'{b}_af_dcn_conv'), getattr(self, f'{b}_feat_conv')
             gn, ro = getattr(self, f'{b}_GN'), getattr(self, f'pts_{b}_refine_out')
             fused = [af(torch.cat(raw[3 * l:3 * l + 3], dim=1)) + fc(st[b]['feat'][l]) for l in range(nl)]
-            outs[b] = [self.softplus(ro(y) + st[b]['sp'][l].detach())
-                       for l, y in enumerate(gn.forward_multi(fused, relu=True))]
+            refine = self.softplus(ro(self._cat_px(gn.forward_multi(fused, relu=True))) + st[b]['sp_all'].detach())
+            outs[b] = self._split_px(refine, shapes)
 
         none = [None] * nl
         res = [outs['cls']]
