@@ -37,6 +37,9 @@ import torch.distributed as dist  # noqa: E402
 # of a step of FETCH_SIZE (KB; doubled as MI355X_MICROARCH.md "HBM" prescribes for gfx950) + WRITE_SIZE (KB).
 # bwd_data's 2 GB of writes are its fp32 atomics reaching the memory side (36 atomic adds per input element).
 HBM_TRAFFIC_GB = {'dcn_fwd': 0.93, 'dcn_bwd_data': 3.06, 'dcn_wgrad': 1.08}
+# split-bf16 kernels, profiles/r1q_pmc_hbm_ops.txt: counters of ONE tower-shaped launch (52.8 GFLOP, i.e. 2/3 of the mean
+# launch of the step, random offsets): FETCH_SIZE x 2 + WRITE_SIZE
+HBM_TRAFFIC_X3_GB = {'dcn_fwd': 2 * 0.443 + 0.045, 'dcn_bwd_data': 2 * 0.503 + 1.461, 'dcn_wgrad': 2 * 0.377 + 0.067}
 BF16_MFMA_PEAK_TFLOPS = 2516.6   # MI355X_MICROARCH.md: ~2.5 PF dense bf16
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, 2.4 GHz x 256 CU
 
@@ -144,16 +147,18 @@ def cpu_baseline(args):
         model.train()
         step, _ = build_step(model, cfg)
         data = synthetic_batch(args.task, b, h, w, seed=99, device='cpu', channels_last=False)
+        nstep = 2
         t0 = time.time()
-        out = step(data)
-        loss = float(out['loss'])
-        dt = time.time() - t0
+        for _ in range(nstep):
+            out = step(data)
+            loss = float(out['loss'])
+        dt = (time.time() - t0) / nstep
     finally:
         unregister_backend('cpu')
     return dict(value=b / dt, unit='img/s', cores=threads, kind='port',
-                sample=f'1 training step (fwd+bwd+clip+SGD) of the same model on {b} image 3x{h}x{w} '
+                sample=f'{nstep} training steps (fwd+bwd+clip+SGD) of the same model on {b} image 3x{h}x{w} '
                        f'({oracle_py.num_threads()} OpenMP threads in the oracle, {threads} torch threads, '
-                       f'{cores} host cores), {dt:.1f} s, loss {loss:.3f}')
+                       f'{cores} host cores), {dt:.1f} s per step, last loss {loss:.3f}')
 
 
 def main():
@@ -284,9 +289,11 @@ def main():
             res['kernels'] = ks
             res['roofline'] = {'kernel': KERNEL_NOTES[args.math].get(dom, dom), 'bound': 'mfma', 'achieved': k['tflops'],
                                'peak': peak_of(dom), 'unit': 'TFLOP/s',
-                               'frac': k['tflops'] / peak_of(dom), 'peak_note': peak_note(dom), 'traffic': HBM_TRAFFIC_GB.get(dom) if args.math == 'fp32' else None,
-                               'traffic_unit': 'GB/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE of the fp32 kernels, profiles/r1c_pmc_hbm.txt; '
-                                               'no counter pass exists for the split-bf16 kernels yet)',
+                               'frac': k['tflops'] / peak_of(dom), 'peak_note': peak_note(dom), 'traffic': (HBM_TRAFFIC_GB if args.math == 'fp32' else HBM_TRAFFIC_X3_GB).get(dom),
+                               'traffic_unit': 'GB/launch, rocprofv3 FETCH_SIZE x2 + WRITE_SIZE: ' + (
+                                   'mean launch of the step, profiles/r1c_pmc_hbm.txt' if args.math == 'fp32' else
+                                   'one 52.8-GFLOP tower launch of the micro-benchmark (the mean launch of the step is '
+                                   '79.3 GFLOP), profiles/r1q_pmc_hbm_ops.txt'),
                                'launches_timed': k['launches'], 'avg_launch_ms': k['avg_ms'],
                                'gflop_per_launch': k['gflop_per_launch'],
                                'alg_gbytes_per_launch': k['alg_gbytes_per_launch'],

@@ -65,6 +65,8 @@ def main():
         t = timeit(bwd, args.iters)
         res[name + '_bwd'] = dict(ms=t * 1e3, tflops=2 * fl / t / 1e12, frac=2 * fl / t / PEAK)
 
+    if args.what == 'dcn_all5':
+        run('dcn_all5', [0, 1, 2, 3, 4])
     if args.what in ('all', 'dcn'):
         run('dcn_p3', [0])
         run('dcn_p4', [1])
