@@ -37,9 +37,9 @@ import torch.distributed as dist  # noqa: E402
 # of a step of FETCH_SIZE (KB; doubled as MI355X_MICROARCH.md "HBM" prescribes for gfx950) + WRITE_SIZE (KB).
 # bwd_data's 2 GB of writes are its fp32 atomics reaching the memory side (36 atomic adds per input element).
 HBM_TRAFFIC_GB = {'dcn_fwd': 0.93, 'dcn_bwd_data': 3.06, 'dcn_wgrad': 1.08}
-# split-bf16 kernels, profiles/r1q_pmc_hbm_ops.txt: counters of ONE tower-shaped launch (52.8 GFLOP, i.e. 2/3 of the mean
+# split-bf16 kernels with the XCD-aware work order, profiles/r1r_pmc_hbm_ops_xcd.txt (before it: r1q_...): counters of ONE tower-shaped launch (52.8 GFLOP, i.e. 2/3 of the mean
 # launch of the step, random offsets): FETCH_SIZE x 2 + WRITE_SIZE
-HBM_TRAFFIC_X3_GB = {'dcn_fwd': 2 * 0.443 + 0.045, 'dcn_bwd_data': 2 * 0.503 + 1.461, 'dcn_wgrad': 2 * 0.377 + 0.067}
+HBM_TRAFFIC_X3_GB = {'dcn_fwd': 2 * 0.057 + 0.045, 'dcn_bwd_data': 2 * 0.187 + 1.461, 'dcn_wgrad': 2 * 0.083 + 0.067}
 BF16_MFMA_PEAK_TFLOPS = 2516.6   # MI355X_MICROARCH.md: ~2.5 PF dense bf16
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, 2.4 GHz x 256 CU
 
@@ -293,7 +293,7 @@ def main():
                                'traffic_unit': 'GB/launch, rocprofv3 FETCH_SIZE x2 + WRITE_SIZE: ' + (
                                    'mean launch of the step, profiles/r1c_pmc_hbm.txt' if args.math == 'fp32' else
                                    'one 52.8-GFLOP tower launch of the micro-benchmark (the mean launch of the step is '
-                                   '79.3 GFLOP), profiles/r1q_pmc_hbm_ops.txt'),
+                                   '79.3 GFLOP), profiles/r1r_pmc_hbm_ops_xcd.txt'),
                                'launches_timed': k['launches'], 'avg_launch_ms': k['avg_ms'],
                                'gflop_per_launch': k['gflop_per_launch'],
                                'alg_gbytes_per_launch': k['alg_gbytes_per_launch'],

@@ -78,6 +78,16 @@ __device__ __forceinline__ void split_bf16x2(float v0, float v1, unsigned &hi, u
     lo = __builtin_bit_cast(unsigned, l);
 }
 
+// XCD-aware work order.  Workgroups are dealt round-robin to the 8 XCDs (linear id b -> XCD b % 8), each with its
+// own 4 MB L2.  Giving XCD x the CONTIGUOUS range of work items [start(x), start(x+1)) instead of every 8th one
+// keeps spatially adjacent tiles -- which sample the same input rows and the same gout rows -- behind one L2
+// (measured before: the forward kernel fetched 443 MB over the fabric for a 46 MB input).  Bijection on [0, total).
+__device__ __forceinline__ int xcd_remap(int b, int total)
+{
+    const int q = total >> 3, r = total & 7, x = b & 7, i = b >> 3;
+    return x * q + min(x, r) + i;
+}
+
 // hardware fp32 atomic add without return (global_atomic_add_f32), device scope
 __device__ __forceinline__ void atomic_add_f32(float *p, float v) { unsafeAtomicAdd(p, v); }
 

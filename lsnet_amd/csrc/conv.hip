@@ -63,8 +63,11 @@ __global__ __launch_bounds__(256, 1) void conv_fwd_x3_kernel(const ConvArgs a)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int K = a.kh * a.kw, Kdim = K * a.C;
-    const int tile_p = blockIdx.x * BM;
-    const int co_blk = blockIdx.y * BN;
+    // XCD-ordered (pixel tile, column block) with the column blocks of a pixel tile adjacent (same input rows)
+    const int work = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int ptile = work / (int)gridDim.y;
+    const int tile_p = ptile * BM;
+    const int co_blk = (work - ptile * (int)gridDim.y) * BN;
     const int nco = min(BN, a.Co - co_blk);
     const int ncc = (a.C + BK - 1) / BK;
     const int T = K * ncc;

@@ -256,8 +256,9 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_kernel(const DcnArgs a)
     const int K = a.kh * a.kw, KD = K * a.dg;
     const int Cg = a.C / a.groups, Cog = a.Co / a.groups, Kdim = K * Cg;
 
-    const Lvl &L = find_level(a, blockIdx.x);
-    const int tile_p = (blockIdx.x - L.tile0) * BM;
+    const int tile = xcd_remap(blockIdx.x, a.ntiles);
+    const Lvl &L = find_level(a, tile);
+    const int tile_p = (tile - L.tile0) * BM;
     const int g = blockIdx.z;
     const int co_blk = blockIdx.y * BN;
     const int nco = min(BN, Cog - co_blk);
@@ -458,8 +459,9 @@ __global__ __launch_bounds__(256, 1) void dcn_fwd_pipe_kernel(const DcnArgs a)
     const int K = a.kh * a.kw, KD = K * a.dg;
     const int Cg = a.C / a.groups, Cog = a.Co / a.groups, Kdim = K * Cg;
 
-    const Lvl &L = find_level(a, blockIdx.x);
-    const int tile_p = (blockIdx.x - L.tile0) * BM;
+    const int tile = xcd_remap(blockIdx.x, a.ntiles);
+    const Lvl &L = find_level(a, tile);
+    const int tile_p = (tile - L.tile0) * BM;
     const int g = blockIdx.z;
     const int co_blk = blockIdx.y * BN;
     const int nco = min(BN, Cog - co_blk);
@@ -705,8 +707,9 @@ __global__ __launch_bounds__(256, 1) void dcn_fwd_x3_kernel(const DcnArgs a)
     const int K = a.kh * a.kw, KD = K * a.dg;
     const int Cg = a.C / a.groups, Cog = a.Co / a.groups, Kdim = K * Cg;
 
-    const Lvl &L = find_level(a, blockIdx.x);
-    const int tile_p = (blockIdx.x - L.tile0) * BM;
+    const int tile = xcd_remap(blockIdx.x, a.ntiles);
+    const Lvl &L = find_level(a, tile);
+    const int tile_p = (tile - L.tile0) * BM;
     const int g = blockIdx.z;
     const int co_blk = blockIdx.y * BN;
     const int nco = min(BN, Cog - co_blk);
@@ -948,8 +951,9 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_kernel(const DcnArgs a)
     const int j16 = lane & 15, kq = lane >> 4;
     const int Cg = a.C / a.groups, Cog = a.Co / a.groups, Kdim = K * Cg;
 
-    const Lvl &L = find_level(a, blockIdx.x);
-    const int tile_p = (blockIdx.x - L.tile0) * BWD_BM;
+    const int tile = xcd_remap(blockIdx.x, a.ntiles);
+    const Lvl &L = find_level(a, tile);
+    const int tile_p = (tile - L.tile0) * BWD_BM;
 
     for (int e = tid; e < BWD_BM * KD; e += 256) {
         const int pl = e / KD, r = e - pl * KD;
@@ -1207,8 +1211,9 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_x3_kernel(const DcnArgs a
     const int j16 = lane & 15, kq = lane >> 4;
     const int C = a.C, Co = a.Co;   // groups == 1
 
-    const Lvl &L = find_level(a, blockIdx.x);
-    const int tile_p = (blockIdx.x - L.tile0) * BWD_BM;
+    const int tile = xcd_remap(blockIdx.x, a.ntiles);
+    const Lvl &L = find_level(a, tile);
+    const int tile_p = (tile - L.tile0) * BWD_BM;
 
     for (int e = tid; e < BWD_BM * KD; e += 256) {
         const int pl = e / KD, r = e - pl * KD;
@@ -1939,14 +1944,19 @@ __global__ __launch_bounds__(256, 2) void dcn_wgrad_x3_kernel(const DcnArgs a, i
     const int Cg = a.C / a.groups, Cog = a.Co / a.groups, Kdim = K * Cg;
     const int segs = Cg / a.SL, ncc = (a.SL + WG_BN - 1) / WG_BN;
     const int ncol_g = K * segs * ncc;
-    const int g = blockIdx.x / ncol_g;
-    const Chunk ch = decode_chunk<WG_BN>(a, g, blockIdx.x - g * ncol_g, segs, ncc);
+    // work item = (pixel split, column block), XCD-ordered with the column blocks of one split adjacent: they
+    // read the same gout rows and the same input rows
+    const int ncol_all = gridDim.x, nsplit = gridDim.y;
+    const int work = xcd_remap(blockIdx.y * ncol_all + blockIdx.x, ncol_all * nsplit);
+    const int bsplit = work / ncol_all, bcol = work - bsplit * ncol_all;
+    const int g = bcol / ncol_g;
+    const Chunk ch = decode_chunk<WG_BN>(a, g, bcol - g * ncol_g, segs, ncc);
     const int co_blk = blockIdx.z * WG_BM;
     const int nco = min(WG_BM, Cog - co_blk);
     const int co_base = g * Cog + co_blk;
 
-    const int st_begin = (int)((long long)nsteps * blockIdx.y / gridDim.y);
-    const int st_end = (int)((long long)nsteps * (blockIdx.y + 1) / gridDim.y);
+    const int st_begin = (int)((long long)nsteps * bsplit / nsplit);
+    const int st_end = (int)((long long)nsteps * (bsplit + 1) / nsplit);
 
     const int kk = tid & 63, pg = tid >> 6;   // gathered columns: channel lane, 8-pixel group
     const bool cval = kk < ch.nval;
