@@ -226,6 +226,9 @@ int lsn_conv2d_forward(const float *x, const float *w, const float *bias, float 
 int lsn_conv2d_backward_data(const float *grad_out, const float *w, float *grad_in, float *wt_workspace, int B,
                              int H, int W, int C, int Co, int kh, int kw, int stride, int pad, int dil,
                              lsn_stream_t stream);
+/* grad_w (Co,kh,kw,C) and optionally grad_bias (Co), both OVERWRITTEN; any stride / padding / dilation. */
+int lsn_conv2d_backward_weight(const float *x, const float *grad_out, float *grad_w, float *grad_bias, int B, int H,
+                               int W, int C, int Co, int kh, int kw, int stride, int pad, int dil, lsn_stream_t stream);
 
 /* ---- GroupNorm (+ReLU) on channels-last tensors ----------------------------------------------
  * The reference uses torch.nn.GroupNorm followed by nn.ReLU (ATen kernels; call sites

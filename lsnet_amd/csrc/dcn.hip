@@ -611,6 +611,32 @@ static int make_single(lsn_dcn_shape &s, lsn_dcn_level &L, int B, int C, int H, 
     return 0;
 }
 
+// weight gradient of a dense convolution through the deformable-conv weight-gradient kernel (PLAIN: no offsets)
+static int conv_wgrad_x3(const float *x, const float *gout, float *gw, float *gb, int B, int H, int W, int C, int Co,
+                         int Ho, int Wo, int kh, int kw, int stride, int pad, int dil, hipStream_t st)
+{
+    DcnArgs a = {};
+    Lvl &L = a.lv[0];
+    L.x = x, L.gout = gout, L.off = nullptr, L.msk = nullptr;
+    L.B = B, L.H = H, L.W = W, L.Ho = Ho, L.Wo = Wo, L.P = B * Ho * Wo, L.tile0 = 0, L.sh = L.sw = 1.f;
+    a.nlv = 1;
+    a.C = C, a.Co = Co, a.kh = kh, a.kw = kw, a.stride = stride, a.pad = pad, a.dil = dil, a.groups = 1, a.dg = 1;
+    a.SL = C;
+    a.gw = gw, a.gb = gb;
+    const int K = kh * kw, nsteps = cdiv(L.P, WG_BP);
+    const int ncc = cdiv(C, WG_BN), ncol = K * ncc, nz = cdiv(Co, WG_BM);
+    int splits = cdiv(1024, ncol * nz);
+    if (splits > nsteps) splits = nsteps;
+    if (splits < 1) splits = 1;
+    LSN_HIP(hipMemsetAsync(gw, 0, sizeof(float) * (size_t)Co * K * C, st));
+    if (gb) LSN_HIP(hipMemsetAsync(gb, 0, sizeof(float) * (size_t)Co, st));
+    const size_t lds3 = (size_t)2 * (WG_BM + WG_BN) * 80 + 2 * WG_BP * sizeof(Tap);
+    if (int rc = set_lds(dcn_wgrad_x3_kernel<true>, lds3)) return rc;
+    hipLaunchKernelGGL(dcn_wgrad_x3_kernel<true>, dim3(ncol, splits, nz), dim3(256), lds3, st, a, nsteps);
+    LSN_HIP(hipGetLastError());
+    return 0;
+}
+
 }  // namespace lsn
 
 using namespace lsn;
@@ -635,6 +661,20 @@ int lsn_set_math_mode(int mode)
 }
 
 int lsn_get_math_mode(void) { return lsn::math_mode(); }
+
+int lsn_conv2d_backward_weight(const float *x, const float *grad_out, float *grad_w, float *grad_bias, int B, int H,
+                               int W, int C, int Co, int kh, int kw, int stride, int pad, int dil, lsn_stream_t stream)
+{
+    LSN_CHECK(x && grad_out && grad_w, "conv2d backward-weight: NULL argument");
+    LSN_CHECK(B > 0 && H > 0 && W > 0 && C > 0 && Co > 0 && kh > 0 && kw > 0 && stride > 0 && dil > 0 && pad >= 0,
+              "conv2d backward-weight: bad shape");
+    const int Ho = (H + 2 * pad - (dil * (kh - 1) + 1)) / stride + 1, Wo = (W + 2 * pad - (dil * (kw - 1) + 1)) / stride + 1;
+    LSN_CHECK(Ho > 0 && Wo > 0, "conv2d backward-weight: output size is too small");
+    if ((int64_t)B * H * W * C >= ((int64_t)1 << 31) || (int64_t)B * Ho * Wo * Co >= ((int64_t)1 << 31))
+        return fail(LSN_ERR_UNSUPPORTED, "conv2d backward-weight: tensor too large for 32-bit indexing");
+    return conv_wgrad_x3(x, grad_out, grad_w, grad_bias, B, H, W, C, Co, Ho, Wo, kh, kw, stride, pad, dil,
+                         reinterpret_cast<hipStream_t>(stream));
+}
 
 int lsn_prof_enable(int on)
 {

@@ -86,9 +86,12 @@ __device__ __forceinline__ Tap make_tap_ex(const DcnArgs &a, const Lvl &L, int p
     const int rem = pix - b * HWo;
     const int ho = rem / L.Wo, wo = rem - ho * L.Wo;
     const int i = k / a.kw, j = k - i * a.kw;
-    const float *op = L.off + (size_t)b * L.osb + (size_t)ho * L.osh + (size_t)wo * L.osw;
-    const float oy = op[(size_t)(dgi * 2 * K + 2 * k) * L.osc];
-    const float ox = op[(size_t)(dgi * 2 * K + 2 * k + 1) * L.osc];
+    float oy = 0.f, ox = 0.f;   // L.off == NULL: a dense convolution (the regular grid)
+    if (L.off) {
+        const float *op = L.off + (size_t)b * L.osb + (size_t)ho * L.osh + (size_t)wo * L.osw;
+        oy = op[(size_t)(dgi * 2 * K + 2 * k) * L.osc];
+        ox = op[(size_t)(dgi * 2 * K + 2 * k + 1) * L.osc];
+    }
     float m = L.msk ? L.msk[(size_t)b * L.msb + (size_t)(dgi * K + k) * L.msc + (size_t)ho * L.msh +
                             (size_t)wo * L.msw]
                     : 1.f;

@@ -61,13 +61,20 @@ class _ConvFn(torch.autograd.Function):
             ws = torch.empty(w.numel(), device=x.device, dtype=torch.float32)
             _lib.check(lib.lsn_conv2d_backward_data(_p(go), _p(w), _p(gx), _p(ws), B, H, W, C, Co, kh, kw, stride, pad,
                                                     dil, _stream()))
-        need_aten = (ctx.needs_input_grad[0] and gx is None, ctx.needs_input_grad[1], False)
+        own_w = ctx.needs_input_grad[1] and Co >= 256 and C >= 256 and C * kh * kw >= 512 and C % 4 == 0
+        if own_w:   # weight gradient (and the bias gradient in the same pass) through the split-bf16 kernel
+            gw = torch.empty_like(w)
+            want_b = has_bias and ctx.needs_input_grad[2]
+            gb = torch.empty(Co, device=x.device, dtype=torch.float32) if want_b else None
+            _lib.check(lib.lsn_conv2d_backward_weight(_p(x), _p(go), _p(gw), _p(gb), B, H, W, C, Co, kh, kw, stride, pad,
+                                                      dil, _stream()))
+        need_aten = (ctx.needs_input_grad[0] and gx is None, ctx.needs_input_grad[1] and not own_w, False)
         if need_aten[0] or need_aten[1]:
             ax, aw, _ = torch.ops.aten.convolution_backward(go, x, w, None, [stride, stride], [pad, pad], [dil, dil],
                                                             False, [0, 0], 1, list(need_aten))
             gx = ax if need_aten[0] else gx
-            gw = aw
-        if has_bias and ctx.needs_input_grad[2]:
+            gw = aw if need_aten[1] else gw
+        if has_bias and ctx.needs_input_grad[2] and gb is None:
             gb = go.sum(dim=(0, 2, 3))
         return gx, gw, gb, None, None, None, None
 
