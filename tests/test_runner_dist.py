@@ -198,3 +198,41 @@ def test_two_rank_graph_step_equals_hooked_reducer():
     for k in b:
         assert torch.equal(a[0][k], a[1][k]), k
         assert torch.allclose(a[0][k], b[k], rtol=1e-5, atol=1e-6), k
+
+
+# ---------------------------------------------------------------------------------------------------
+# the real detector under two ranks (gloo, CPU oracle behind the native ops): fused log-scalar all-reduce,
+# hook-driven gradient buckets, identical parameters on both ranks after the step
+def _lsnet_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from lsnet_amd.data import synthetic_batch
+        from lsnet_amd.model_zoo import build_lsnet
+        from lsnet_amd.ops import register_backend
+        from tests.oracle_backend import OracleBackend
+        register_backend('cpu', OracleBackend())
+        torch.manual_seed(7 + rank)
+        model, cfg = build_lsnet('bbox', 'r50')
+        model = DataParallelModel(model.train())
+        opt = build_optimizer(model, cfg.optimizer)
+        r = EpochBasedRunner(model, optimizer=opt, logger=lambda s: None)
+        r.register_training_hooks(cfg.lr_config, cfg.optimizer_config, None, dict(interval=10 ** 9, hooks=[]))
+        batch = synthetic_batch('bbox', 1, 288, 352, boxes_per_img=3, seed=50 + rank, device='cpu', channels_last=False)
+        r.run([[batch]], [('train', 1)], 1)
+        logs = r.outputs['log_vars']
+        torch.save(dict(loss=float(logs['loss']), w=model.module.bbox_head.pts_cls_out.weight.detach().clone(),
+                        b=model.module.backbone.layer4[0].conv1.weight.detach().clone()),
+                   os.path.join(out_dir, f'rank{rank}.pt'))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_lsnet_step():
+    world = 2
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_lsnet_worker, args=(world, _free_port(), d), nprocs=world, join=True)
+        a, b = (torch.load(os.path.join(d, f'rank{r}.pt')) for r in range(world))
+    assert a['loss'] == b['loss'] and a['loss'] > 0          # the logged loss is the mean over ranks
+    assert torch.equal(a['w'], b['w']) and torch.equal(a['b'], b['b'])
