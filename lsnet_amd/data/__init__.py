@@ -1,3 +1,5 @@
+from .gt_formats import flip_extremes, flip_keypoints, flip_polygons, polygon_landmarks, resample_polygon
 from .synthetic import synthetic_batch
 
-__all__ = ['synthetic_batch']
+__all__ = ['synthetic_batch', 'resample_polygon', 'polygon_landmarks', 'flip_extremes', 'flip_polygons',
+           'flip_keypoints']

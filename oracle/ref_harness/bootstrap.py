@@ -124,6 +124,26 @@ def _install_third_party_shims():
         tt.AsciiTable = type('AsciiTable', (), {'__init__': lambda self, *a, **k: None})
         sys.modules['terminaltables'] = tt
 
+    if 'shapely' not in sys.modules:   # only LinearRing.is_ccw is used (loading.py:403-404): signed shoelace area > 0
+        import numpy as _np
+        sh, geo = types.ModuleType('shapely'), types.ModuleType('shapely.geometry')
+
+        class _Ring:
+            def __init__(self, pts):
+                self.pts = _np.asarray(pts, dtype=_np.float64).reshape(-1, 2)
+
+            @property
+            def is_ccw(self):
+                x, y = self.pts[:, 0], self.pts[:, 1]
+                return float(_np.dot(x, _np.roll(y, -1)) - _np.dot(y, _np.roll(x, -1))) > 0
+
+        class Polygon:
+            def __init__(self, pts):
+                self.exterior = _Ring(pts)
+        geo.Polygon = Polygon
+        sh.geometry = geo
+        sys.modules['shapely'], sys.modules['shapely.geometry'] = sh, geo
+
     for name in ('torchvision', 'torchvision.models'):
         if name not in sys.modules:
             sys.modules[name] = _RaisingModule(name)

@@ -188,7 +188,52 @@ def golden_nms():
     _save('nms_lsvr', dict(dets=dets.numpy(), vectors=vec.numpy(), labels=labels.numpy()))
 
 
-ALL = dict(head_bbox=lambda: golden_head('bbox'), head_segm=lambda: golden_head('segm'),
+def golden_gt_formats():
+    """(f-2) GT formatting of the real-data pipeline: polygon re-sampling / unification (loading.py:314-441) and the
+    flip transforms (core/bbox/transforms.py:30-87) of the reference on random inputs."""
+    from mmdet.core.bbox.transforms import extreme_flip, kps_flip, polygon_flip
+    from mmdet.datasets.pipelines.loading import LoadAnnotations
+    la = LoadAnnotations(with_mask=True, poly2mask=False, spline_num=10, num_contour_points=36)
+    la.spline_poly_num = 36 * 10 if not hasattr(la, 'spline_poly_num') else la.spline_poly_num
+    rng = np.random.RandomState(5)
+    data = {}
+
+    def blob(n, cx, cy, r):   # star-shaped, random orientation
+        ang = np.sort(rng.rand(n)) * 2 * np.pi
+        rad = r * (0.5 + rng.rand(n))
+        pts = np.stack([cx + rad * np.cos(ang), cy + rad * np.sin(ang)], 1)
+        return pts[::-1] if rng.rand() < 0.5 else pts
+    cases = [[blob(4, 50, 60, 20)], [blob(7, 120, 80, 35)], [blob(57, 200, 150, 60)], [blob(400, 300, 200, 90)],
+             [blob(12, 80, 90, 30), blob(5, 90, 95, 0.4)],            # second component is tiny: dropped
+             [blob(3, 10, 10, 0.3)],                                  # everything tiny: box fallback
+             [blob(9, 40, 40, 15), blob(30, 140, 60, 25)]]
+    for i, comps in enumerate(cases):
+        allp = np.concatenate(comps)
+        bbox = np.array([allp[:, 0].min(), allp[:, 1].min(), allp[:, 0].max(), allp[:, 1].max()], dtype=np.float32)
+        out = la.unify_polygons([c.reshape(-1).tolist() for c in comps], bbox)
+        data[f'poly/{i}/n'] = np.array(len(comps))
+        for j, c in enumerate(comps):
+            data[f'poly/{i}/in{j}'] = c
+        data[f'poly/{i}/bbox'] = bbox
+        data[f'poly/{i}/out'] = np.stack(out)
+    for n, m in ((5, 36), (400, 360), (361, 360), (3, 10), (13, 7)):
+        pts = blob(n, 100, 100, 50)
+        data[f'resample/{n}_{m}/in'] = pts
+        data[f'resample/{n}_{m}/out'] = la.uniformsample(pts, m)
+    g = gu.gen(77)
+    shape = (480, 640, 3)
+    ext = torch.rand(6, 16, generator=g) * 400
+    pol = torch.rand(5, 72, generator=g) * 400
+    kps = torch.rand(4, 34, generator=g) * 400
+    data.update(ext=ext.numpy(), pol=pol.numpy(), kps=kps.numpy())
+    for d in ('horizontal', 'vertical'):
+        data[f'flip/{d}/ext'] = extreme_flip(ext, shape, d).numpy()
+        data[f'flip/{d}/pol'] = polygon_flip(pol, shape, d).numpy()
+        data[f'flip/{d}/kps'] = kps_flip(kps, shape, d).numpy()
+    _save('gt_formats', data)
+
+
+ALL = dict(gt_formats=golden_gt_formats, head_bbox=lambda: golden_head('bbox'), head_segm=lambda: golden_head('segm'),
            head_pose_bbox=lambda: golden_head('pose_bbox'), head_pose_kbox=lambda: golden_head('pose_kbox'),
            assign=golden_assign, cross_iou=golden_cross_iou, backbone=golden_backbone, nms=golden_nms)
 
