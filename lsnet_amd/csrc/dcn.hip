@@ -355,11 +355,11 @@ static bool bwd_win_ok(const DcnArgs &a)
     if (env_win == 1) return true;
     if ((g_dbg_block >> 25) & 1) return false;   // bits 25 / 24 of the debug word force one kernel (A/B runs)
     if ((g_dbg_block >> 24) & 1) return true;
-    // Measured in the LSNet step (profiles/): against the first fp32 kernel the windowed one won on the pyramid op
-    // (3.76 vs 4.23 ms) and lost on the tower convolutions (1.46 vs 1.33 ms); the split-bf16 kernel with the merged
-    // scatter beats both (2.7 ms / 1.0 ms), so the windowed kernel is only used when asked for (LSNET_BWD_WIN=1 or
-    // debug bit 24) or when the split kernel does not apply and the launch resamples (scale != 1).
-    if (bwd_x3_ok(a)) return false;
+    // Measured in the LSNet step (profiles/, bench.py kernel timers).  Exact fp32: the windowed kernel beat the first
+    // kernel on the pyramid op (3.76 vs 4.23 ms) and lost on the tower convolutions (1.46 vs 1.33 ms).  Split bf16:
+    // merged-scatter kernel 1.0 ms (towers) / 2.7 ms (pyramid); windowed kernel with the GEMM on the matrix pipe
+    // 1.0 ms / 1.95 ms.  So a launch that resamples (scale != 1: the pyramid op, whose samples travel far and
+    // converge on landmarks) takes the windowed kernel, everything else the merged-scatter kernel.
     for (int i = 0; i < a.nlv; ++i)
         if (a.lv[i].sh != 1.f || a.lv[i].sw != 1.f) return true;
     return false;
@@ -374,6 +374,13 @@ static int launch_bwd_data_win_t(DcnArgs a, hipStream_t st)
         tiles += a.lv[i].B * cdiv(a.lv[i].Ho, BW3_PH) * cdiv(a.lv[i].Wo, BW3_PW);
     }
     a.ntiles = tiles;
+    if (RED == 256 && bwd_x3_ok(a) && bwd_win_x3_lds_bytes(a.kh * a.kw * a.dg) <= 160 * 1024) {
+        const size_t lds3 = bwd_win_x3_lds_bytes(a.kh * a.kw * a.dg);   // GEMM on the bf16 matrix pipe
+        if (int rc = set_lds(dcn_bwd_data_win_x3_kernel, lds3)) return rc;
+        hipLaunchKernelGGL(dcn_bwd_data_win_x3_kernel, dim3(tiles), dim3(512), lds3, st, a);
+        LSN_HIP(hipGetLastError());
+        return 0;
+    }
     const size_t lds = bwd_win_lds_bytes(RED, a.kh * a.kw * a.dg);
     if (vec_ok(a)) {
         auto k = dcn_bwd_data_win_kernel<RED, true>;

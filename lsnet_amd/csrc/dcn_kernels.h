@@ -1470,6 +1470,12 @@ __device__ __forceinline__ long long to_fixed(float v)
     return ((long long)(int)hi << 32) + (long long)lo;   // (long long)lo: |lo| < 2^32 fits
 }
 
+__host__ __device__ inline size_t bwd_win_x3_lds_bytes(int KD)
+{
+    return (size_t)2 * 32 * 528 + (size_t)BW3_WIN * 32 * 8 + (size_t)BW3_PX * KD * (sizeof(Tap) + 12 + 4) +
+           (size_t)KD * 16 + (size_t)(KD + 1) * BW3_WPAR * 4;
+}
+
 template <int RED, bool VEC>
 __global__ __launch_bounds__(512, 1) void dcn_bwd_data_win_kernel(const DcnArgs a)
 {
@@ -1686,6 +1692,329 @@ __global__ __launch_bounds__(512, 1) void dcn_bwd_data_win_kernel(const DcnArgs 
                 LSN_STAMP(5);
                 if (rb + 1 < nrb) __syncthreads();  // slab consumed; next slab may overwrite Bs
             }
+
+            // ---- consume gcol[16 px][32 ch] of this wave: D row = 4*kq + r, col = tn*16 + j16 ----
+            float sy[4] = {0.f, 0.f, 0.f, 0.f}, sx[4] = {0.f, 0.f, 0.f, 0.f}, sm[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) {
+                const int cl = tn * 16 + j16;
+                const bool cval = cl < ch.nval;
+                const int c = g * Cg + ch.c0 + (cval ? cl : 0);
+                float xv[4][4];
+                if (want_off) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const Tap *tp = &tab[pl_of(kq * 4 + r) * KD + kd];
+                        const int4 idx = *reinterpret_cast<const int4 *>(tp);
+                        xv[r][0] = L.x[idx.x + c];
+                        xv[r][1] = L.x[idx.y + c];
+                        xv[r][2] = L.x[idx.z + c];
+                        xv[r][3] = L.x[idx.w + c];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float gval = cval ? (tn == 0 ? acc0[r] : acc1[r]) : 0.f;
+                    const int e = pl_of(kq * 4 + r) * KD + kd;
+                    const Tap tp = tab[e];
+                    float b00, b01, b10, b11;
+                    corner_weights(tp, b00, b01, b10, b11);
+                    const float gm = gval * tp.m;
+                    if (L.gx != nullptr && cval && tp.flags) {
+                        if (use_win) {
+                            const int wv0 = wb[e];
+                            const int w00 = wv0 & 0xffff, dx = (wv0 >> 16) & 1, o10 = wv0 >> 17;
+                            const int w01 = w00 + dx, w10 = w00 + o10, w11 = w10 + dx;
+                            atomicAdd(win + w00 * BK + (cl ^ ((w00 & 1) << 4)), (unsigned long long)to_fixed(b00 * gm));
+                            atomicAdd(win + w01 * BK + (cl ^ ((w01 & 1) << 4)), (unsigned long long)to_fixed(b01 * gm));
+                            atomicAdd(win + w10 * BK + (cl ^ ((w10 & 1) << 4)), (unsigned long long)to_fixed(b10 * gm));
+                            atomicAdd(win + w11 * BK + (cl ^ ((w11 & 1) << 4)), (unsigned long long)to_fixed(b11 * gm));
+                        } else {
+                            atomic_add_f32(L.gx + tp.i00 + c, b00 * gm);
+                            atomic_add_f32(L.gx + tp.i01 + c, b01 * gm);
+                            atomic_add_f32(L.gx + tp.i10 + c, b10 * gm);
+                            atomic_add_f32(L.gx + tp.i11 + c, b11 * gm);
+                        }
+                    }
+                    if (want_off) {
+                        const float hy = 1.f - tp.ly, hx = 1.f - tp.lx;
+                        const float v00 = (tp.flags & 1) ? xv[r][0] : 0.f;
+                        const float v01 = (tp.flags & 2) ? xv[r][1] : 0.f;
+                        const float v10 = (tp.flags & 4) ? xv[r][2] : 0.f;
+                        const float v11 = (tp.flags & 8) ? xv[r][3] : 0.f;
+                        // coordinate weights, kernel.cu:145-188 / 800-845
+                        const float dy = hx * (v10 - v00) + tp.lx * (v11 - v01);
+                        const float dx = hy * (v01 - v00) + tp.ly * (v11 - v10);
+                        const float bil =
+                            hy * hx * v00 + hy * tp.lx * v01 + tp.ly * hx * v10 + tp.ly * tp.lx * v11;
+                        sy[r] += gm * dy;
+                        sx[r] += gm * dx;
+                        sm[r] += gval * bil;
+                    }
+                }
+            }
+            if (want_off) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float vy = row16_sum(sy[r]), vx = row16_sum(sx[r]), vm = row16_sum(sm[r]);
+                    if (j16 == 0) {   // the row is private to this wave: plain read-modify-write
+                        float *ga = gacc + (pl_of(kq * 4 + r) * KD + kd) * 3;
+                        ga[0] += vy;
+                        ga[1] += vx;
+                        ga[2] += vm;
+                    }
+                }
+            }
+            LSN_STAMP(6);
+            __syncthreads();  // Bs free for the next chunk; this chunk's window adds are complete
+            LSN_STAMP(7);
+            if (L.gx != nullptr && use_win && (!umode || ch.k == K - 1)) flush(wp, g * Cg + ch.c0, ch.nval);
+        }
+    }
+    __syncthreads();
+
+    // ---- write grad_offset / grad_mask for this tile ----
+    for (int e = tid; e < BW3_PX * KD; e += 512) {
+        const int pl = e / KD, r = e - pl * KD;
+        const int dgi = r / K, k = r - dgi * K;
+        const int ho = pty * BW3_PH + (pl >> 4), wo = ptx * BW3_PW + (pl & 15);
+        if (ho >= L.Ho || wo >= L.Wo) continue;
+        const float *ga = gacc + e * 3;
+        if (L.goff) {
+            float *op = L.goff + (size_t)pb * L.osb + (size_t)ho * L.osh + (size_t)wo * L.osw;
+            op[(size_t)(dgi * 2 * K + 2 * k) * L.osc] = ga[0];
+            op[(size_t)(dgi * 2 * K + 2 * k + 1) * L.osc] = ga[1];
+        }
+        if (L.gmsk) {
+            float gm = ga[2];
+            if (a.msig) {  // d sigmoid: m (1 - m); out-of-range samples have ga[2] == 0 already
+                const float m = tab[e].m;
+                gm *= m * (1.f - m);
+            }
+            L.gmsk[(size_t)pb * L.msb + (size_t)(dgi * K + k) * L.msc + (size_t)ho * L.msh + (size_t)wo * L.msw] = gm;
+        }
+    }
+}
+
+// The windowed scatter with the GEMM on the bf16 matrix pipe (split operands as in dcn_bwd_data_x3_kernel): the
+// fixed-point conversions and LDS adds of the epilogue then overlap the MFMAs instead of queueing behind them.
+__global__ __launch_bounds__(512, 1) void dcn_bwd_data_win_x3_kernel(const DcnArgs a)
+{
+    constexpr int BK = 32, RED = 256, NS = RED / 32, RS = BX3_RS;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int K = a.kh * a.kw, KD = K * a.dg;
+    unsigned char *Bh = smem, *Bl = smem + 32 * RS;                           // [32 ch][RED co] bf16 planes
+    unsigned long long *win = reinterpret_cast<unsigned long long *>(smem + 2 * 32 * RS);   // [BW3_WIN][32]
+    Tap *tab = reinterpret_cast<Tap *>(win + BW3_WIN * BK);                   // [128][KD]
+    float *gacc = reinterpret_cast<float *>(tab + BW3_PX * KD);               // [128][KD][3]  (dy, dx, mask)
+    int *wb = reinterpret_cast<int *>(gacc + BW3_PX * KD * 3);                // [128][KD] window row | dx<<16 | dy*ww<<17
+    int *bb = wb + BW3_PX * KD;                                               // [KD][4] ymin, xmin, ymax, xmax
+    int *wpar = bb + KD * 4;                                                  // [KD+1][BW3_WPAR]; entry KD = all taps
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j16 = lane & 15, kq = lane >> 4;
+    const int Cg = a.C, C = a.C, Co = a.Co;   // groups == 1
+
+    const Lvl &L = find_level(a, blockIdx.x);
+    const int ntx = (L.Wo + BW3_PW - 1) / BW3_PW, nty = (L.Ho + BW3_PH - 1) / BW3_PH;
+    const int tl = blockIdx.x - L.tile0;
+    const int pb = tl / (ntx * nty);
+    const int trem = tl - pb * ntx * nty;
+    const int pty = trem / ntx, ptx = trem - pty * ntx;
+    // local pixel pl = y * 16 + x of the patch
+    auto pix_of = [&](int pl) {
+        const int ho = pty * BW3_PH + (pl >> 4), wo = ptx * BW3_PW + (pl & 15);
+        return (ho < L.Ho && wo < L.Wo) ? (pb * L.Ho + ho) * L.Wo + wo : L.P;
+    };
+    // MFMA row i (0..15) of wave w  ->  local pixel: x = 4 * (i & 3) + (i >> 2), y = w
+    auto pl_of = [&](int i) { return (wave << 4) + ((i & 3) << 2) + (i >> 2); };
+
+    for (int e = tid; e < KD * 4; e += 512) bb[e] = (e & 3) < 2 ? INT_MAX : INT_MIN;
+    for (int e = tid; e < BW3_WIN * BK; e += 512) win[e] = 0ull;
+    for (int e = tid; e < BW3_PX * KD * 3; e += 512) gacc[e] = 0.f;
+    __syncthreads();
+    for (int e = tid; e < BW3_PX * KD; e += 512) {
+        const int pl = e / KD, r = e - pl * KD;
+        const int dgi = r / K, k = r - dgi * K;
+        int4 yx = make_int4(0, 0, 0, 0);
+        const Tap t = make_tap_ex(a, L, pix_of(pl), k, dgi, &yx);
+        tab[e] = t;
+        wb[e] = (int)((unsigned)yx.x | ((unsigned)yx.y << 15) | ((unsigned)(yx.z - yx.x) << 30) |
+                      ((unsigned)(yx.w - yx.y) << 31));
+        if (t.flags) {
+            atomicMin(&bb[r * 4 + 0], yx.x);
+            atomicMin(&bb[r * 4 + 1], yx.y);
+            atomicMax(&bb[r * 4 + 2], yx.z);
+            atomicMax(&bb[r * 4 + 3], yx.w);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const bool off = (a.dbg_block >> 26) & 1;   // diagnostic: force direct atomics
+        int uy0 = INT_MAX, ux0 = INT_MAX, uy1 = INT_MIN, ux1 = INT_MIN;
+        for (int kd = 0; kd < KD; ++kd) {
+            const int y0 = bb[kd * 4], x0 = bb[kd * 4 + 1], y1 = bb[kd * 4 + 2], x1 = bb[kd * 4 + 3];
+            int *wp = wpar + kd * BW3_WPAR;
+            if (y0 <= y1) {
+                uy0 = min(uy0, y0), ux0 = min(ux0, x0), uy1 = max(uy1, y1), ux1 = max(ux1, x1);
+                const int hh = y1 - y0 + 1, ww = x1 - x0 + 1;
+                const bool fits = (long long)hh * ww <= BW3_WIN && !off;
+                wp[0] = y0, wp[1] = x0, wp[2] = fits ? ww : 1, wp[3] = fits ? 1 : 2, wp[4] = fits ? hh * ww : 0;
+            } else {
+                wp[0] = wp[1] = 0, wp[2] = 1, wp[3] = 1, wp[4] = 0;
+            }
+        }
+        int *up = wpar + KD * BW3_WPAR;
+        if (uy0 > uy1) {
+            up[0] = up[1] = 0, up[2] = 1, up[3] = 1, up[4] = 0;
+        } else {
+            const int hh = uy1 - uy0 + 1, ww = ux1 - ux0 + 1;
+            const bool fits = (long long)hh * ww <= BW3_WIN && !off;
+            up[0] = uy0, up[1] = ux0, up[2] = fits ? ww : 1, up[3] = fits ? 1 : 0, up[4] = fits ? hh * ww : 0;
+        }
+    }
+    __syncthreads();
+    const bool umode = wpar[KD * BW3_WPAR + 3] == 1;   // one window for all taps of a slab
+    for (int e = tid; e < BW3_PX * KD; e += 512) {
+        const int pl = e / KD, r = e - pl * KD;
+        const int *wp = wpar + (umode ? KD : r) * BW3_WPAR;
+        const unsigned v = (unsigned)wb[e];
+        const int cy0 = v & 0x7fff, cx0 = (v >> 15) & 0x7fff, dy = (v >> 30) & 1, dx = v >> 31;
+        int o = 0;
+        if (tab[e].flags && wp[3] == 1) o = ((cy0 - wp[0]) * wp[2] + (cx0 - wp[1])) | (dx << 16) | ((dy * wp[2]) << 17);
+        wb[e] = o;
+    }
+
+    const int segs = Cg / a.SL, ncc = (a.SL + BK - 1) / BK;
+    const int T = K * segs * ncc;
+    const bool want_off = (L.goff != nullptr) || (L.gmsk != nullptr);
+    const int cpdg = a.C / a.dg;
+
+    // A operand: gout row of pixel pl_of(j16), k-step s covers co = 32 s + 8 kq .. + 7, split once
+    bf16x8 ah[NS], al[NS];
+    {
+        const int my_pix = pix_of(pl_of(j16));
+        const bool pix_ok = my_pix < L.P;
+        const float *grow = L.gout + (size_t)(pix_ok ? my_pix : 0) * Co;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int cb = s * 32 + kq * 8;
+            float v[8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const bool ok = pix_ok && cb + h * 4 < Co;
+                const float4 f = *reinterpret_cast<const float4 *>(grow + (ok ? cb + h * 4 : 0));
+                v[h * 4 + 0] = ok ? f.x : 0.f, v[h * 4 + 1] = ok ? f.y : 0.f, v[h * 4 + 2] = ok ? f.z : 0.f,
+                          v[h * 4 + 3] = ok ? f.w : 0.f;
+            }
+            unsigned hi[4], lo[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) split_bf16x2(v[2 * e], v[2 * e + 1], hi[e], lo[e]);
+            const uint4 H = make_uint4(hi[0], hi[1], hi[2], hi[3]), Lo = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+            __builtin_memcpy(&ah[s], &H, 16);
+            __builtin_memcpy(&al[s], &Lo, 16);
+        }
+    }
+    // slab-major chunk walk: tap fastest, then 32-channel sub-chunk, then segment
+    struct Walk {
+        int k, cc, seg;
+    };
+    auto chunk_of = [&](const Walk &w) {
+        Chunk c;
+        c.k = __builtin_amdgcn_readfirstlane(w.k);
+        c.c0 = __builtin_amdgcn_readfirstlane(w.seg * a.SL + w.cc * BK);
+        c.nval = __builtin_amdgcn_readfirstlane(min(BK, a.SL - w.cc * BK));
+        c.dgi = __builtin_amdgcn_readfirstlane((w.seg * a.SL) / cpdg);
+        return c;
+    };
+    auto advance = [&](Walk &w) {
+        if (++w.k == K) {
+            w.k = 0;
+            if (++w.cc == ncc) {
+                w.cc = 0;
+                ++w.seg;
+            }
+        }
+    };
+    // weight slab staging from the prepared [K][C][Co] planes: 512 threads = 2 planes x 8 rows x 32 pieces per pass
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(a.wtp), 0,
+                                                                         K * C * Co * 4, 0x00020000);
+    const int piece = tid & 31, srow = (tid >> 5) & 7, plane = tid >> 8;
+    float4 wv[4];
+    auto load_w = [&](const Chunk &ch) {
+        const int rowbase = ch.k * C + ch.c0;
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int r = ps * 8 + srow;
+            const bool ok = piece * 8 < Co && r < ch.nval;
+            const int voff = ok ? (plane * K * C * Co + (rowbase + r) * Co) * 2 + piece * 16 : 0x7ffffff0;
+            auto v = __builtin_amdgcn_raw_buffer_load_b128(wrs, voff, 0, 0);
+            __builtin_memcpy(&wv[ps], &v, 16);
+        }
+    };
+    auto store_w = [&]() {
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps)
+            *reinterpret_cast<float4 *>((plane ? Bl : Bh) + (ps * 8 + srow) * RS + piece * 16) = wv[ps];
+    };
+    // window -> grad_input: elements that received something are added to global memory and cleared
+    auto flush = [&](const int *wp, int cbase, int nval) {
+        const int nrows = wp[4], ww = wp[2];
+        const int q2 = (tid & 15) * 2;
+        for (int row = tid >> 4; row < nrows; row += 32) {
+            unsigned long long *p = win + row * BK + (q2 ^ ((row & 1) << 4));
+            const long long v0 = (long long)p[0], v1 = (long long)p[1];
+            if ((v0 | v1) != 0) {
+                p[0] = 0ull;
+                p[1] = 0ull;
+                const int wy = row / ww, wx = row - wy * ww;
+                float *gp = L.gx + ((size_t)(pb * L.H + wp[0] + wy) * L.W + wp[1] + wx) * a.C + cbase + q2;
+                if (q2 + 0 < nval && v0 != 0) atomic_add_f32(gp + 0, (float)((double)v0 * (double)BW3_INV));
+                if (q2 + 1 < nval && v1 != 0) atomic_add_f32(gp + 1, (float)((double)v1 * (double)BW3_INV));
+            }
+        }
+    };
+
+    int dbg_n = 0;
+    __syncthreads();
+    {
+        const int g = 0;
+        Walk wc = {0, 0, 0}, wn = {0, 0, 0};
+        load_w(chunk_of(wn));
+        advance(wn);
+        for (int t = 0; t < T; ++t) {
+            const Chunk ch = chunk_of(wc);
+            advance(wc);
+            const int kd = ch.dgi * K + ch.k;
+            const int *wp = wpar + (umode ? KD : kd) * BW3_WPAR;
+            const bool use_win = wp[3] == 1;
+            LSN_STAMP(2);
+            store_w();
+            LSN_STAMP(3);
+            __syncthreads();
+            LSN_STAMP(4);
+            if (t + 1 < T) {
+                load_w(chunk_of(wn));
+                advance(wn);
+            }
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            {
+                const unsigned char *b0 = Bh + j16 * RS + kq * 16, *b1 = Bh + (16 + j16) * RS + kq * 16;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const bf16x8 h0 = *reinterpret_cast<const bf16x8 *>(b0 + s * 64);
+                    const bf16x8 h1 = *reinterpret_cast<const bf16x8 *>(b1 + s * 64);
+                    const bf16x8 l0 = *reinterpret_cast<const bf16x8 *>(b0 + 32 * RS + s * 64);
+                    const bf16x8 l1 = *reinterpret_cast<const bf16x8 *>(b1 + 32 * RS + s * 64);
+                    acc0 = mfma16_bf16(ah[s], h0, acc0);
+                    acc1 = mfma16_bf16(ah[s], h1, acc1);
+                    acc0 = mfma16_bf16(ah[s], l0, acc0);
+                    acc1 = mfma16_bf16(ah[s], l1, acc1);
+                    acc0 = mfma16_bf16(al[s], h0, acc0);
+                    acc1 = mfma16_bf16(al[s], h1, acc1);
+                }
+            }
+            LSN_STAMP(5);
 
             // ---- consume gcol[16 px][32 ch] of this wave: D row = 4*kq + r, col = tn*16 + j16 ----
             float sy[4] = {0.f, 0.f, 0.f, 0.f}, sx[4] = {0.f, 0.f, 0.f, 0.f}, sm[4] = {0.f, 0.f, 0.f, 0.f};
