@@ -12,9 +12,11 @@ losses, backward, RCCL gradient all-reduce (N > 1), clip-grad-norm 35 and the SG
 hooks a real run uses (lsnet_amd/runner).  Inputs are resident in HBM before the timed region.
 
 Prints ONE JSON line (rank 0):  value = total images / s over all N GPUs (weak scaling, 2 img/GPU).
-  roofline     : the dominant hand-written kernel family (fused gather + fp32-MFMA deformable
-                 convolution): algorithmic FLOPs of its launches / their HIP-event time, against the
-                 157.3 TFLOP/s fp32 MFMA peak (MI355X_MICROARCH.md).
+  roofline     : the hand-written kernel family with the most GPU time in the timed steps (a deformable-convolution
+                 kernel): algorithmic FLOPs of its launches / their HIP-event time (events recorded by the library
+                 around each kernel on its launch stream), against the MFMA peak of its arithmetic -- 2516 / 3 TFLOP/s
+                 for split-bf16 products, 157.3 for exact fp32 (MI355X_MICROARCH.md); `traffic` from rocprofv3 counters.
+  fp32_exact   : the same step with --math fp32 (exact fp32 MFMA kernels, MIOpen fp32 convolutions), 5 steps.
   cpu_baseline : the same training step on the host CPU (this repo's host code with the CPU oracle
                  standing behind the native ops -- the reference has no CPU path for them), on a
                  bounded sample, rank 0 at N=1 only.

@@ -6,8 +6,8 @@
  *   mmdet/ops/dcn/src/deform_conv_ext.cpp:227-250      pybind module `deform_conv_ext` (8 functions)
  *   mmdet/ops/sigmoid_focal_loss/src/sigmoid_focal_loss_ext.cpp:19-57   `sigmoid_focal_loss_ext`
  *   mmdet/ops/nms/src/nms_ext.cpp:18-49                 `nms_ext.nms`
- * plus fused device kernels for work the reference does as chains of small torch kernels
- * (cross-IOU loss, group-norm + ReLU, softplus heads) -- those are marked [fused] below.
+ * plus device kernels for work the reference gets from PyTorch (dense convolution, GroupNorm + ReLU, frozen
+ * BatchNorm + add + ReLU, weighted focal-loss sums) -- marked [fused] or described in their sections below.
  *
  * Conventions
  *   - plain C: raw device pointers, int sizes, an explicit hipStream_t.  No torch types.
@@ -18,9 +18,11 @@
  *     Outputs and gradient buffers are OVERWRITTEN (the reference's Python always passes
  *     zero-filled gradient tensors, deform_conv.py:75-76,86,157-161, so results are identical).
  *   - work is enqueued on `stream` and is asynchronous w.r.t. the host, except lsn_nms.
- *   - float32 throughout; indices int64 where the reference uses int64.
- *   - one process per GPU; entry points are re-entrant across streams (no global mutable state
- *     except the thread-local error string and a per-device cached attribute query).
+ *   - float32 tensors throughout; indices int64 where the reference uses int64.  The arithmetic of the
+ *     contractions is selected by lsn_set_math_mode (split-bf16 products with fp32 accumulation, or exact fp32).
+ *   - one process per GPU; entry points are re-entrant across streams.  Process-wide mutable state: the math
+ *     mode, the kernel-timing log (lsn_prof_*) and the tuning word (lsn_debug_phase_clocks) -- set them from one
+ *     thread; plus the thread-local error string.
  *
  * Activation layout.  `layout` selects how 4-D activation tensors (input, output, their grads)
  * and the weight tensor are laid out in memory:
