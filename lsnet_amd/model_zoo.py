@@ -12,7 +12,8 @@ NORM_GN = dict(type='GN', num_groups=32, requires_grad=True)
 
 
 def backbone_cfg(name='r50'):
-    """r50 / r101 (lsnet_bbox_r50_fpn_1x_coco.py:9-18), x101 = ResNeXt-101-64x4d
+    """r50 / r101 (lsnet_bbox_r50_fpn_1x_coco.py:9-18), res2-101 = Res2Net-101 26w x 4s
+    (lsnet_segm_res2_101_fpn_dconv_c3-c5_mstrain_30e_coco.py:6-14), x101 = ResNeXt-101-64x4d
     (lsnet_bbox_x101_fpn_mstrain_2x_coco.py), `-dcn` suffix = DCNv2 in c3-c5
     (lsnet_bbox_x101_fpn_dconv_c3-c5_mstrain_2x_coco.py.py:4-17)."""
     dcn = name.endswith('-dcn')
@@ -23,12 +24,14 @@ def backbone_cfg(name='r50'):
         cfg = dict(type='ResNet', depth=int(base[1:]), **common)
     elif base == 'x101':
         cfg = dict(type='ResNeXt', depth=101, groups=64, base_width=4, **common)
+    elif base in ('res2-50', 'res2-101'):   # lsnet_*_res2_101_fpn_dconv_c3-c5_*: 26w x 4s, always with `-dcn`
+        cfg = dict(type='Res2Net', depth=int(base.split('-')[1]), scales=4, base_width=26, **common)
     else:
         raise KeyError(base)
     if dcn:
         cfg.update(dcn=dict(type='DCNv2', deformable_groups=1, fallback_on_stride=False),
                    stage_with_dcn=(False, True, True, True))
-        if base == 'x101':
+        if base in ('x101', 'res2-50', 'res2-101'):
             cfg['with_cp'] = True
     return cfg
 

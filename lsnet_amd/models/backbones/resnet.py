@@ -152,8 +152,6 @@ class ResNet(nn.Module):
         super().__init__()
         if depth not in self.arch_settings:
             raise KeyError(f'invalid depth {depth} for resnet')
-        if deep_stem:
-            raise NotImplementedError('deep_stem (ResNetV1d) is outside the LSNet hot path')
         assert 1 <= num_stages <= 4
         assert len(strides) == len(dilations) == num_stages
         assert max(out_indices) < num_stages
@@ -161,17 +159,25 @@ class ResNet(nn.Module):
             assert len(stage_with_dcn) == num_stages
         self.depth, self.stem_channels, self.base_channels = depth, stem_channels, base_channels
         self.num_stages, self.strides, self.dilations = num_stages, strides, dilations
-        self.out_indices, self.style, self.avg_down = out_indices, style, avg_down
+        self.out_indices, self.style, self.avg_down, self.deep_stem = out_indices, style, avg_down, deep_stem
         self.frozen_stages, self.conv_cfg, self.norm_cfg = frozen_stages, conv_cfg, norm_cfg
         self.with_cp, self.norm_eval, self.dcn, self.stage_with_dcn = with_cp, norm_eval, dcn, stage_with_dcn
         self.zero_init_residual = zero_init_residual
         self.block, stage_blocks = self.arch_settings[depth]
         self.stage_blocks = stage_blocks[:num_stages]
 
-        self.conv1 = build_conv_layer(conv_cfg, in_channels, stem_channels, kernel_size=7, stride=2, padding=3,
-                                      bias=False)
-        self.norm1_name, norm1 = build_norm_layer(norm_cfg, stem_channels, postfix=1)
-        self.add_module(self.norm1_name, norm1)
+        if deep_stem:   # ResNetV1d / Res2Net stem: three 3x3 convs (resnet.py:521-556), module name `stem`
+            half = stem_channels // 2
+            mods = []
+            for cin, cout, st in ((in_channels, half, 2), (half, half, 1), (half, stem_channels, 1)):
+                mods += [build_conv_layer(conv_cfg, cin, cout, kernel_size=3, stride=st, padding=1, bias=False),
+                         build_norm_layer(norm_cfg, cout)[1], nn.ReLU(inplace=True)]
+            self.stem = nn.Sequential(*mods)
+        else:
+            self.conv1 = build_conv_layer(conv_cfg, in_channels, stem_channels, kernel_size=7, stride=2, padding=3,
+                                          bias=False)
+            self.norm1_name, norm1 = build_norm_layer(norm_cfg, stem_channels, postfix=1)
+            self.add_module(self.norm1_name, norm1)
         self.relu = nn.ReLU(inplace=True)
         self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
 
@@ -198,8 +204,12 @@ class ResNet(nn.Module):
         """Stem (frozen_stages >= 0) and the first `frozen_stages` stages: eval mode, no grads."""
         frozen = []
         if self.frozen_stages >= 0:
-            self.norm1.eval()
-            frozen += [self.conv1, self.norm1]
+            if self.deep_stem:
+                self.stem.eval()
+                frozen.append(self.stem)
+            else:
+                self.norm1.eval()
+                frozen += [self.conv1, self.norm1]
         for i in range(1, self.frozen_stages + 1):
             m = getattr(self, f'layer{i}')
             m.eval()
@@ -232,7 +242,8 @@ class ResNet(nn.Module):
                     constant_init(m.norm2, 0)
 
     def forward(self, x):
-        x = self.maxpool(bn_act(self.norm1, self.conv1(x), relu=True))
+        x = self.stem(x) if self.deep_stem else bn_act(self.norm1, self.conv1(x), relu=True)
+        x = self.maxpool(x)
         outs = []
         for i, name in enumerate(self.res_layers):
             x = getattr(self, name)(x)

@@ -171,6 +171,25 @@ def golden_backbone():
     _save('backbone_r50_fpn', data)
 
 
+def golden_res2net():
+    """(f-3) Res2Net-50 (26w x 4s, DCNv2 in c3-c5: the structure of the headline res2_101 configs at a testable
+    depth) forward on a 1x3x96x128 input with name-keyed weights, plus the sorted state-dict keys."""
+    from mmdet.models import build_backbone
+    bb = build_backbone(dict(type='Res2Net', depth=50, scales=4, base_width=26, num_stages=4, out_indices=(0, 1, 2, 3),
+                             frozen_stages=1, norm_cfg=dict(type='BN', requires_grad=True), norm_eval=True,
+                             dcn=dict(type='DCNv2', deformable_groups=1, fallback_on_stride=False),
+                             stage_with_dcn=(False, True, True, True)))
+    gu.fill_params(bb, seed=8)
+    bb.train()
+    x = torch.randn(1, 3, 96, 128, generator=gu.gen(31))
+    data = {'keys': np.array(sorted(bb.state_dict().keys())),
+            'nparams': np.array(sum(p.numel() for p in bb.parameters()))}
+    with torch.no_grad():
+        for i, t in enumerate(bb(x)):
+            gu.pack(f'c/{i}', t, data)
+    _save('res2net50_dcn', data)
+
+
 def golden_nms():
     """(7) multiclass_nms_lsvr keep set on random candidates (the reference's nms_cpu semantics)."""
     from mmdet.core import multiclass_nms_lsvr
@@ -233,7 +252,7 @@ def golden_gt_formats():
     _save('gt_formats', data)
 
 
-ALL = dict(gt_formats=golden_gt_formats, head_bbox=lambda: golden_head('bbox'), head_segm=lambda: golden_head('segm'),
+ALL = dict(gt_formats=golden_gt_formats, res2net=golden_res2net, head_bbox=lambda: golden_head('bbox'), head_segm=lambda: golden_head('segm'),
            head_pose_bbox=lambda: golden_head('pose_bbox'), head_pose_kbox=lambda: golden_head('pose_kbox'),
            assign=golden_assign, cross_iou=golden_cross_iou, backbone=golden_backbone, nms=golden_nms)
 

@@ -33,5 +33,10 @@ def test_backbone_fpn(channels_last):
     gc.backbone_case(_dev(), channels_last)
 
 
+@pytest.mark.parametrize('channels_last', [False, True], ids=['nchw', 'nhwc'])
+def test_res2net_dcn_backbone(channels_last):
+    gc.res2net_case(_dev(), channels_last)
+
+
 def test_multiclass_nms_lsvr():
     gc.nms_lsvr_case(_dev())

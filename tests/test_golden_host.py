@@ -26,5 +26,9 @@ def test_backbone_fpn():
     gc.backbone_case(CPU)
 
 
+def test_res2net_dcn_backbone(cpu_oracle_backend):
+    gc.res2net_case(CPU)
+
+
 def test_multiclass_nms_lsvr(cpu_oracle_backend):
     gc.nms_lsvr_case(CPU)
