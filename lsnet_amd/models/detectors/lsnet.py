@@ -2,8 +2,10 @@
 detectors/lsnet.py:12-100): backbone -> neck -> LSHead; training returns the head's loss dict,
 `simple_test` returns per-class lists of boxes and landmark vectors."""
 import numpy as np
+import torch
 import torch.nn as nn
 
+from ...core.vote import remove_boxes, vote_merge
 from ..builder import DETECTORS, build_backbone, build_head, build_neck
 from .base import BaseDetector
 
@@ -89,3 +91,32 @@ class LSDetector(SingleStageDetector):
                 out.append((b[big], v[big], l[big]))
             return out
         return dets
+
+    def aug_test(self, imgs, img_metas, rescale=False, show=False, out_dir=False):
+        """Multi-scale / flip testing by instance voting (lsnet.py:301-417, `test_cfg.method == 'vote'`): every view
+        is decoded with NMS, filtered to the box sizes its scale is trusted for (`test_cfg.scale_ranges[i // 2]`, views
+        come in (plain, flipped) pairs), mapped back to the original image and merged per class by `instances_vote`."""
+        cfg = self.test_cfg
+        if cfg.get('method', 'simple') != 'vote':
+            raise NotImplementedError("only test_cfg.method='vote' is implemented for multi-view testing")
+        head = self.bbox_head
+        boxes, vecs, labels = [], [], []
+        for i, (img, meta) in enumerate(zip(imgs, img_metas)):
+            b, v, l = head.get_bboxes(*head(self.extract_feat(img)), meta, cfg, False, True)[0]
+            keep = remove_boxes(b, cfg.scale_ranges[i // 2][0], cfg.scale_ranges[i // 2][1])
+            boxes.append(b[keep])
+            vecs.append(v[keep])
+            labels.append(l[keep])
+        det_b, det_v, det_l = vote_merge(boxes, vecs, labels, img_metas, head.task, head.num_classes, head.num_vectors)
+        if not rescale:
+            sf = torch.as_tensor(np.asarray(img_metas[0][0]['scale_factor'], dtype=np.float32), device=det_b.device)
+            det_b = det_b.clone()
+            det_b[:, :4] *= sf
+            det_v = det_v * sf[:2].repeat(det_v.shape[1] // 2)
+        if head.task == 'bbox':
+            return bbox_extreme2result(det_b, det_v, det_l, head.num_classes)
+        if head.task in ('pose_bbox', 'pose_kbox') and not (show or out_dir):
+            big = (det_b[:, 2] - det_b[:, 0]) * (det_b[:, 3] - det_b[:, 1]) > 1024
+            det_b, det_v, det_l = det_b[big], det_v[big], det_l[big]
+        return bbox_poly2result(det_b, det_v, det_l, head.num_classes, head.num_vectors)
+

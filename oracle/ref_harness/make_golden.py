@@ -190,6 +190,32 @@ def golden_res2net():
     _save('res2net50_dcn', data)
 
 
+def golden_vote():
+    """(f-3) instances_vote of the reference detector (lsnet.py:229-299) on random multi-scale-like detections: clusters
+    of jittered copies of a few boxes plus isolated ones."""
+    from mmdet.models.detectors.lsnet import LSDetector
+    g = gu.gen(91)
+    data = {}
+    real_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self          # the reference ends with .cuda(); there is no GPU here
+    try:
+        for case, (nbase, ncopy, nv) in enumerate(((6, 7, 8), (15, 4, 72), (1, 1, 34), (3, 12, 34))):
+            base = torch.rand(nbase, 2, generator=g) * 300
+            wh = torch.rand(nbase, 2, generator=g) * 120 + 10
+            b0 = torch.cat([base, base + wh], 1).repeat_interleave(ncopy, 0)
+            boxes = b0 + torch.randn(b0.shape, generator=g) * 4
+            vectors = torch.rand(boxes.shape[0], nv, generator=g) * 300
+            scores = torch.rand(boxes.shape[0], generator=g)
+            ob, ov, os_ = LSDetector.instances_vote(None, boxes.clone(), vectors.clone(), scores.clone())
+            data[f'{case}/boxes'], data[f'{case}/vectors'], data[f'{case}/scores'] = boxes.numpy(), vectors.numpy(), scores.numpy()
+            data[f'{case}/out_boxes'] = np.asarray(ob if isinstance(ob, np.ndarray) else ob.numpy(), dtype=np.float32).reshape(-1, 4)
+            data[f'{case}/out_vectors'] = np.asarray(ov if isinstance(ov, np.ndarray) else ov.numpy(), dtype=np.float32).reshape(-1, nv)
+            data[f'{case}/out_scores'] = np.asarray(os_ if isinstance(os_, np.ndarray) else os_.numpy(), dtype=np.float32).reshape(-1)
+    finally:
+        torch.Tensor.cuda = real_cuda
+    _save('vote', data)
+
+
 def golden_nms():
     """(7) multiclass_nms_lsvr keep set on random candidates (the reference's nms_cpu semantics)."""
     from mmdet.core import multiclass_nms_lsvr
@@ -252,7 +278,7 @@ def golden_gt_formats():
     _save('gt_formats', data)
 
 
-ALL = dict(gt_formats=golden_gt_formats, res2net=golden_res2net, head_bbox=lambda: golden_head('bbox'), head_segm=lambda: golden_head('segm'),
+ALL = dict(gt_formats=golden_gt_formats, res2net=golden_res2net, vote=golden_vote, head_bbox=lambda: golden_head('bbox'), head_segm=lambda: golden_head('segm'),
            head_pose_bbox=lambda: golden_head('pose_bbox'), head_pose_kbox=lambda: golden_head('pose_kbox'),
            assign=golden_assign, cross_iou=golden_cross_iou, backbone=golden_backbone, nms=golden_nms)
 
