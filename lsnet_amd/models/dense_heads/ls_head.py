@@ -22,7 +22,6 @@ import math
 import numpy as np
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from ...cnn import ConvModule, bias_init_with_prob, kaiming_init, normal_init
 from ...ops.conv import Conv2d

@@ -1,5 +1,4 @@
 """Sigmoid focal loss op -- mirror of mmdet/ops/sigmoid_focal_loss/sigmoid_focal_loss.py:8-54."""
-import torch
 import torch.nn as nn
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable

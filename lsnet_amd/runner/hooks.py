@@ -5,7 +5,6 @@ timer, text logger and epoch checkpoints.
 By design nothing here forces a device->host synchronisation per iteration: the gradient norm and
 the loss scalars stay on the device and are only read when the logger prints (every `interval`
 iterations); the reference reads them every iteration (hooks/optimizer.py:22-27, base.py:202-207)."""
-import os
 import time
 
 import torch

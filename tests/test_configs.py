@@ -1,10 +1,8 @@
 """Config machinery, model zoo vs the reference's config files, registry build of every LSNet variant."""
-import copy
 import glob
 import os
 
 import pytest
-import torch
 
 from lsnet_amd.model_zoo import build_lsnet, lsnet_config
 from lsnet_amd.utils import Config
