@@ -3,7 +3,7 @@ the optimizer and the runner, register the training hooks, run."""
 import torch
 
 from ..parallel import DataParallelModel
-from ..runner import EpochBasedRunner, build_optimizer
+from ..runner import DistSamplerSeedHook, EpochBasedRunner, build_optimizer
 
 
 def train_detector(model, data_loaders, cfg, distributed=False, validate=False, timestamp=None, meta=None,
@@ -18,6 +18,8 @@ def train_detector(model, data_loaders, cfg, distributed=False, validate=False, 
     runner = EpochBasedRunner(model, optimizer=optimizer, work_dir=cfg.get('work_dir'), logger=logger, meta=meta)
     runner.register_training_hooks(cfg.lr_config, cfg.optimizer_config, cfg.get('checkpoint_config'),
                                    cfg.get('log_config'))
+    if distributed:
+        runner.register_hook(DistSamplerSeedHook())
     if cfg.get('resume_from'):
         runner.resume(cfg.resume_from)
     elif cfg.get('load_from'):

@@ -53,3 +53,33 @@ class DistributedGroupSampler(Sampler):
         order = [order[j] for b in batches for j in range(b * self.samples_per_gpu, (b + 1) * self.samples_per_gpu)]
         start = self.num_samples * self.rank
         return iter(order[start:start + self.num_samples])
+
+
+class GroupSampler(Sampler):
+    """Single-process variant (group_sampler.py:10-57): every group shuffled with `np.random`, padded to a whole
+    number of mini-batches by random re-draws, mini-batches then permuted.  Same `np.random` call sequence as the
+    reference, so a seeded run yields the same order."""
+
+    def __init__(self, dataset, samples_per_gpu=1):
+        assert hasattr(dataset, 'flag')
+        self.dataset, self.samples_per_gpu = dataset, samples_per_gpu
+        self.flag = np.asarray(dataset.flag).astype(np.int64)
+        self.group_sizes = np.bincount(self.flag)
+        self.num_samples = sum(int(np.ceil(s / samples_per_gpu)) * samples_per_gpu for s in self.group_sizes)
+
+    def __len__(self):
+        return self.num_samples
+
+    def __iter__(self):
+        spg, parts = self.samples_per_gpu, []
+        for gid, size in enumerate(self.group_sizes):
+            if size == 0:
+                continue
+            members = np.where(self.flag == gid)[0]
+            np.random.shuffle(members)
+            extra = int(np.ceil(size / spg)) * spg - len(members)
+            parts.append(np.concatenate([members, np.random.choice(members, extra)]))
+        flat = np.concatenate(parts)
+        flat = np.concatenate([flat[b * spg:(b + 1) * spg] for b in np.random.permutation(range(len(flat) // spg))])
+        assert len(flat) == self.num_samples
+        return iter(flat.astype(np.int64).tolist())

@@ -34,6 +34,16 @@ class Hook:
 
 
 @HOOKS.register_module()
+class DistSamplerSeedHook(Hook):
+    """mmcv/runner/hooks/sampler_seed.py:6-10: a new shuffle of the distributed sampler every epoch."""
+
+    def before_train_epoch(self, runner):
+        sampler = getattr(getattr(runner, 'data_loader', None), 'sampler', None)
+        if hasattr(sampler, 'set_epoch'):
+            sampler.set_epoch(runner.epoch)
+
+
+@HOOKS.register_module()
 class StepLrUpdaterHook(Hook):
     """lr = base * gamma^(#passed steps); linear warm-up from warmup_ratio*lr over warmup_iters
     (hooks/lr_updater.py:83-92, 123-141, 153-181)."""

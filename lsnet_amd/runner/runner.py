@@ -8,6 +8,7 @@ from collections import OrderedDict
 import torch
 import torch.distributed as dist
 
+from ..parallel.data_container import DataContainer, scatter
 from .checkpoint import load_checkpoint, save_checkpoint
 from .hooks import (CheckpointHook, Hook, IterTimerHook, OptimizerHook, StepLrUpdaterHook, TextLoggerHook,
                     build_hook)
@@ -71,7 +72,12 @@ class EpochBasedRunner:
         return self.graph_step
 
     def run_iter(self, batch):
-        """forward (+ backward when graphed) of one iteration; the hooks do the rest."""
+        """forward (+ backward when graphed) of one iteration; the hooks do the rest.  A batch collated from the
+        data pipeline still holds DataContainers: unwrap it onto this process's device first (what the reference's
+        MMDistributedDataParallel.train_step does with `scatter`, mmcv/parallel/distributed.py:21-35)."""
+        if isinstance(batch, dict) and any(isinstance(v, DataContainer) for v in batch.values()):
+            p = next(self.model.parameters())
+            batch = scatter(batch, p.device, channels_last=p.device.type == 'cuda')
         if self.graph_step is not None:
             return self.graph_step(batch)
         return self.model.train_step(batch, self.optimizer)
@@ -127,6 +133,7 @@ class EpochBasedRunner:
     # ---- main loop ---------------------------------------------------------------------------
     def train(self, data_loader):
         self.model.train()
+        self.data_loader = data_loader
         self.epoch_len = len(data_loader)
         self.call_hook('before_train_epoch')
         for i, batch in enumerate(data_loader):

@@ -278,7 +278,176 @@ def golden_gt_formats():
     _save('gt_formats', data)
 
 
-ALL = dict(gt_formats=golden_gt_formats, res2net=golden_res2net, vote=golden_vote, head_bbox=lambda: golden_head('bbox'), head_segm=lambda: golden_head('segm'),
+def tiny_coco(seed=3):
+    """A small COCO-format annotation dict exercising every branch of the reference's annotation parser: polygon
+    (one and several components, tiny components), crowd (run-length) and ignored instances, boxes outside the
+    image / thinner than a pixel / of zero area, an unknown category, an image without annotations and one below
+    the minimum size.  Carries both LSNet extras: `extreme_points` (10) and `keypoints` (51)."""
+    rng = np.random.RandomState(seed)
+    images = [dict(id=11, file_name='000011.jpg', width=97, height=64), dict(id=5, file_name='000005.jpg', width=60, height=90),
+              dict(id=7, file_name='000007.jpg', width=40, height=36), dict(id=9, file_name='000009.jpg', width=20, height=200),
+              dict(id=2, file_name='000002.jpg', width=128, height=96)]
+    cats = [dict(id=1, name='person', supercategory='person'), dict(id=2, name='bicycle', supercategory='vehicle'),
+            dict(id=18, name='dog', supercategory='animal'), dict(id=99, name='unicorn', supercategory='animal')]
+    anns, aid = [], 100
+
+    def star(n, cx, cy, r):
+        ang = np.sort(rng.rand(n)) * 2 * np.pi
+        rad = r * (0.5 + rng.rand(n))
+        pts = np.stack([cx + rad * np.cos(ang), cy + rad * np.sin(ang)], 1)
+        return (pts[::-1] if rng.rand() < 0.5 else pts).round(2)
+
+    def add(img, cat, comps, crowd=0, ignore=None, bbox=None, area=None):
+        nonlocal aid
+        allp = np.concatenate(comps)
+        x1, y1, x2, y2 = allp[:, 0].min(), allp[:, 1].min(), allp[:, 0].max(), allp[:, 1].max()
+        box = [float(x1), float(y1), float(x2 - x1), float(y2 - y1)] if bbox is None else bbox
+        k = np.concatenate([rng.rand(17, 2) * [x2 - x1, y2 - y1] + [x1, y1], rng.randint(0, 3, (17, 1))], 1).round(1)
+        ex = np.array([[allp[allp[:, 1].argmin(), 0], y1], [x1, allp[allp[:, 0].argmin(), 1]],
+                       [allp[allp[:, 1].argmax(), 0], y2], [x2, allp[allp[:, 0].argmax(), 1]],
+                       [(x1 + x2) / 2, (y1 + y2) / 2]])
+        seg = [c.reshape(-1).tolist() for c in comps]
+        if crowd:
+            seg = dict(size=[img['height'], img['width']], counts=[37, 120, int(img['height'] * img['width']) - 157])
+        a = dict(id=aid, image_id=img['id'], category_id=cat, bbox=box, area=float(box[2] * box[3] * 0.6) if area is None else area,
+                 iscrowd=crowd, segmentation=seg, extreme_points=ex.reshape(-1).round(2).tolist(),
+                 keypoints=k.reshape(-1).tolist(), num_keypoints=int((k[:, 2] > 0).sum()))
+        if ignore is not None:
+            a['ignore'] = ignore
+        anns.append(a)
+        aid += 1
+    im11, im5, im2 = images[0], images[1], images[4]
+    add(im2, 1, [star(9, 40, 40, 18)])
+    add(im11, 18, [star(7, 30, 30, 15)])
+    add(im11, 1, [star(12, 60, 35, 20), star(5, 70, 40, 0.4)])
+    add(im5, 2, [star(30, 30, 45, 22)])
+    add(im11, 1, [star(6, 50, 30, 10)], crowd=1)
+    add(im5, 1, [star(6, 20, 20, 8)], ignore=True)
+    add(im5, 99, [star(6, 25, 60, 8)])
+    add(im2, 1, [star(5, 64, 48, 12)], bbox=[200.0, 10.0, 20.0, 20.0])           # outside the image
+    add(im2, 2, [star(5, 64, 48, 12)], bbox=[30.0, 30.0, 0.5, 20.0])             # thinner than a pixel
+    add(im2, 18, [star(5, 64, 48, 12)], area=0.0)
+    add(im2, 18, [star(40, 80, 50, 30), star(8, 20, 70, 9)])
+    add(im2, 1, [star(3, 100, 20, 0.3)])                                         # all components tiny: box fallback
+    add(im5, 1, [star(10, 35, 70, 14)])
+    return dict(images=images, categories=cats, annotations=anns, info=dict(description='synthetic'), licenses=[])
+
+
+def golden_data_pipeline():
+    """(f-2) annotation parsing (datasets/coco.py:120-185, coco_pose.py:110-172) and the per-image pipeline
+    (pipelines/loading.py LoadAnnotations, transforms.py Resize / RandomFlip / Pad, formating.py) of the reference on
+    tests/golden/coco_tiny.json.  cv2 is absent from this image: its four calls behind mmcv (resize, cvtColor,
+    subtract, multiply) are stood in by numpy here, so image PIXELS are not part of this fixture -- only shapes,
+    meta data and every ground-truth field."""
+    import json
+    import types
+
+    import cv2
+    from lsnet_amd.data import geometry as G
+    from mmdet.datasets.coco import CocoDataset
+    from mmdet.datasets.coco_pose import CocoPoseDataset
+    from mmdet.datasets.pipelines import Compose
+    cv2.resize = lambda img, size, dst=None, interpolation=None: G.imresize(img, size)
+
+    def _cvt(src, code, dst=None):
+        dst[...] = src[..., ::-1].copy()
+        return dst
+    cv2.cvtColor, cv2.COLOR_BGR2RGB = _cvt, 4
+
+    def _sub(a, b, dst=None):
+        dst[...] = a - b.astype(np.float32)
+        return dst
+
+    def _mul(a, b, dst=None):
+        dst[...] = a * b.astype(np.float32)
+        return dst
+    cv2.subtract, cv2.multiply = _sub, _mul
+
+    coco = tiny_coco()
+    with open(os.path.join(OUT, 'coco_tiny.json'), 'w') as f:
+        json.dump(coco, f)
+    data = {}
+    norm = dict(mean=[123.675, 116.28, 103.53], std=[58.395, 57.12, 57.375], to_rgb=True)
+    loaders = dict(bbox=(CocoDataset, dict(with_bbox=True, with_extreme=True), ['gt_bboxes', 'gt_labels', 'gt_extremes']),
+                   segm=(CocoDataset, dict(with_bbox=True, with_mask=True, poly2mask=False, spline_num=10, num_contour_points=36),
+                         ['gt_bboxes', 'gt_labels', 'gt_masks']),
+                   pose=(CocoPoseDataset, dict(with_bbox=True, with_keypoint=True), ['gt_bboxes', 'gt_labels', 'gt_keypoints']))
+    names = {c['id']: c['name'] for c in coco['categories']}
+    for task, (cls, load_kw, keys) in loaders.items():
+        classes = CocoDataset.CLASSES if cls is CocoDataset else ['person']
+        cat_ids = [c['id'] for c in coco['categories'] if c['name'] in classes]
+        stub = types.SimpleNamespace(cat_ids=cat_ids, cat2label={c: i for i, c in enumerate(cat_ids)})
+        for img in coco['images']:
+            info = dict(img, filename=img['file_name'])
+            anns = [a for a in coco['annotations'] if a['image_id'] == img['id']]
+            parsed = cls._parse_ann_info(stub, info, copy.deepcopy(anns))
+            base = f'{task}/{img["id"]}'
+            for k in ('bboxes', 'labels', 'bboxes_ignore', 'extremes', 'keypoints'):
+                if k in parsed:
+                    data[f'{base}/ann/{k}'] = np.asarray(parsed[k])
+            data[f'{base}/ann/num_masks'] = np.array(len(parsed['masks']))
+            if img['height'] < 32 or img['width'] < 32:
+                continue
+            for flip, direction in ((False, 'horizontal'), (True, 'horizontal'), (True, 'vertical')):
+                pipe = Compose([dict(type='LoadAnnotations', **load_kw), dict(type='Resize', img_scale=(200, 120), keep_ratio=True),
+                                dict(type='RandomFlip', flip_ratio=0.5), dict(type='Normalize', **norm), dict(type='Pad', size_divisor=32),
+                                dict(type='DefaultFormatBundle'), dict(type='Collect', keys=['img'] + keys)])
+                rng = np.random.RandomState(img['id'])
+                pixels = rng.randint(0, 256, (img['height'], img['width'], 3)).astype(np.uint8)
+                results = dict(img_info=info, ann_info=copy.deepcopy(parsed), img=pixels, img_shape=pixels.shape, ori_shape=pixels.shape,
+                               img_fields=['img'], filename=info['filename'], ori_filename=info['filename'], flip=flip,
+                               flip_direction=direction, bbox_fields=[], extreme_fields=[], mask_fields=[], seg_fields=[],
+                               keypoint_fields=[], img_prefix=None, seg_prefix=None, proposal_file=None)
+                tag = f'{base}/{"flip_" + direction if flip else "plain"}'
+                try:
+                    out = pipe(results)
+                except ValueError:            # the reference cannot mirror an EMPTY keypoint array (transforms.py:398)
+                    assert task == 'pose' and len(parsed['keypoints']) == 0
+                    data[f'{tag}/reference_raises'] = np.array(1)
+                    continue
+                meta = out['img_metas'].data
+                data[f'{tag}/img_shape'] = np.array(meta['img_shape'])
+                data[f'{tag}/pad_shape'] = np.array(meta['pad_shape'])
+                data[f'{tag}/scale_factor'] = np.asarray(meta['scale_factor'])
+                data[f'{tag}/img_tensor_shape'] = np.array(out['img'].data.shape)
+                for k in keys:
+                    v = out[k].data
+                    if k == 'gt_masks':
+                        data[f'{tag}/gt_masks/hw'] = np.array([v.height, v.width])
+                        data[f'{tag}/gt_masks/ncomp'] = np.array([len(m) for m in v.masks])
+                        flat = [c for m in v.masks for c in m]
+                        data[f'{tag}/gt_masks/polys'] = np.stack(flat) if flat else np.zeros((0, 72))
+                    else:
+                        data[f'{tag}/{k}'] = v.numpy()
+    # stride-8 semantic targets of the CPV variant (loading_reppointsv2.py:24-46)
+    from mmdet.datasets.pipelines.loading_reppointsv2 import LoadRPDV2Annotations
+    rng = np.random.RandomState(4)
+    xy = rng.rand(12, 2) * [100, 70]
+    boxes = np.concatenate([xy, xy + rng.rand(12, 2) * [60, 50] + 1], 1).astype(np.float32)
+    boxes[:, 0::2] = boxes[:, 0::2].clip(0, 127)
+    boxes[:, 1::2] = boxes[:, 1::2].clip(0, 95)
+    labels = rng.randint(0, 5, 12).astype(np.int64)
+    res = LoadRPDV2Annotations(num_classes=5)(dict(gt_bboxes=boxes, gt_labels=labels, pad_shape=(96, 128, 3)))
+    data.update({'rpdv2/boxes': boxes, 'rpdv2/labels': labels, 'rpdv2/sem': res['gt_sem_map'], 'rpdv2/weights': res['gt_sem_weights']})
+    # extreme points of tools/gen_coco_lsvr.py:16-75 on the polygon annotations and on random contours
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('gen_coco_lsvr_ref', os.path.join(bootstrap.REF_ROOT, 'tools', 'gen_coco_lsvr.py'))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    rng = np.random.RandomState(9)
+    contours = [np.array([v for c in a['segmentation'] for v in c]).reshape(-1, 2) for a in coco['annotations']
+                if isinstance(a['segmentation'], list)]
+    for i in range(40):
+        pts = (rng.rand(rng.randint(3, 40), 2) * rng.randint(5, 300)).round(rng.randint(0, 3))
+        contours.append(pts.astype(np.int32) if i % 3 == 0 else pts)
+    data['extreme/n'] = np.array(len(contours))
+    for i, c in enumerate(contours):
+        data[f'extreme/{i}/in'] = c
+        data[f'extreme/{i}/out'] = tool._get_extreme_points(c)
+    _save('data_pipeline', data)
+
+
+ALL = dict(data_pipeline=golden_data_pipeline, gt_formats=golden_gt_formats, res2net=golden_res2net, vote=golden_vote, head_bbox=lambda: golden_head('bbox'), head_segm=lambda: golden_head('segm'),
            head_pose_bbox=lambda: golden_head('pose_bbox'), head_pose_kbox=lambda: golden_head('pose_kbox'),
            assign=golden_assign, cross_iou=golden_cross_iou, backbone=golden_backbone, nms=golden_nms)
 

@@ -79,3 +79,23 @@ def test_registry_builds_every_variant(task, backbone, params_m):
         assert k in keys, k
     frozen = [n_ for n_, p in model.named_parameters() if not p.requires_grad]
     assert any(n_.startswith('backbone.layer1') for n_ in frozen) and not any('layer2' in n_ for n_ in frozen)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_CFG), reason='reference configs are not on this machine')
+def test_data_sections_of_reference_configs_build():
+    """Every `data.train/val/test` pipeline of configs/lsnet/*.py is made of stages this package registers, with the
+    arguments those files pass (the dataset classes themselves need the annotation files, so only the type is checked)."""
+    from lsnet_amd.data import DATASETS, Compose
+    from lsnet_amd.utils import Config
+    seen = set()
+    for f in sorted(os.listdir(REF_CFG)):
+        cfg = Config.fromfile(os.path.join(REF_CFG, f))
+        for split in ('train', 'val', 'test'):
+            d = cfg.data[split]
+            assert d['type'] in DATASETS, (f, d['type'])
+            pipe = Compose(d['pipeline'])
+            seen |= {type(t).__name__ for t in pipe.transforms}
+            assert repr(pipe)
+        assert cfg.data.samples_per_gpu in (2, 6)                 # 6 for the pose configs
+    assert {'LoadImageFromFile', 'LoadAnnotations', 'Resize', 'RandomFlip', 'Normalize', 'Pad', 'DefaultFormatBundle',
+            'Collect', 'MultiScaleFlipAug'} <= seen
