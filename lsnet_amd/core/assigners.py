@@ -134,6 +134,97 @@ class CentroidAssigner:
         return torch.stack([cx, cy], dim=-1)
 
 
+def gaussian_radius(det_size, min_overlap):
+    """CornerNet's radius: the largest corner displacement that still leaves IoU >= min_overlap with the gt box, the
+    minimum over its three cases (point_hm_assigner.py:148-166)."""
+    height, width = det_size
+    b1 = height + width
+    c1 = width * height * (1 - min_overlap) / (1 + min_overlap)
+    r1 = (b1 - torch.sqrt(b1 ** 2 - 4 * c1)) / 2
+    b2 = 2 * (height + width)
+    c2 = (1 - min_overlap) * width * height
+    r2 = (b2 - torch.sqrt(b2 ** 2 - 16 * c2)) / 8
+    a3 = 4 * min_overlap
+    b3 = -2 * min_overlap * (height + width)
+    c3 = (min_overlap - 1) * width * height
+    r3 = (b3 + torch.sqrt(b3 ** 2 - 4 * a3 * c3)) / (2 * a3)
+    return torch.min(torch.stack([r1, r2, r3], dim=1), dim=1)[0]
+
+
+@BBOX_ASSIGNERS.register_module()
+class PointHMAssigner:
+    """Corner heat-map targets of the corner-point-verification head (point_hm_assigner.py:8-146).  For the top-left
+    and the bottom-right corner of every gt box, on EVERY level: the grid point nearest to the corner is a positive
+    (target 1) and carries the sub-cell offset (corner - point) / stride; with `gaussian_bump` every point within the
+    gt's Gaussian radius of a corner gets exp(-d^2 / 2 sigma^2), the maximum over gts.
+
+    `assign_dense` is the form the head uses: targets and a positive MASK, no index lists, no host reads when the
+    level strides are passed in.  `assign` is the reference's interface on top of it.  Where several gts pick the
+    same point the last gt's offset stays, as with the reference's sequential CPU indexing."""
+
+    def __init__(self, gaussian_bump=False, gaussian_iou=0.7):
+        self.gaussian_bump, self.gaussian_iou = gaussian_bump, gaussian_iou
+
+    def _corner(self, xy, lvl, levels, corner, radius, sigma, dtype):
+        INF = 1e8
+        P, G = xy.shape[0], corner.shape[0]
+        dist = (xy[:, None, :] - corner[None, :, :]).norm(dim=2)                 # (P, G)
+        if self.gaussian_bump:
+            g = torch.exp(-torch.pow(dist, 2) / (2 * sigma * sigma)[None, :])
+            g = torch.where(dist >= radius[None, :], g.new_full((), -INF), g).max(dim=1)[0]
+            hm = torch.where(g != -INF, g, torch.zeros_like(g))
+        else:
+            hm = xy.new_zeros((P,), dtype=dtype)
+        offset = xy.new_zeros((P + 1, 2), dtype=torch.float32)                   # row P: sink for empty levels
+        winner = torch.full((P + 1,), -1, dtype=torch.long, device=xy.device)
+        order = torch.arange(G, device=xy.device)
+        for l in levels:
+            on = lvl == l
+            d = torch.where(on[:, None], dist, dist.new_full((), float('inf')))
+            best_d, best_p = d.min(dim=0)                                        # (G,)
+            best_p = torch.where(torch.isfinite(best_d), best_p, torch.full_like(best_p, P))
+            winner.zero_().sub_(1)
+            winner.scatter_reduce_(0, best_p, order, 'amax')                     # last gt wins a shared point
+            keep = winner[best_p] == order
+            tgt = torch.where(keep, best_p, torch.full_like(best_p, P))
+            val = (corner - xy[best_p.clamp(max=P - 1)]) / float(2 ** int(l))
+            offset[tgt] = val
+            pos = torch.zeros(P + 1, dtype=torch.bool, device=xy.device)
+            pos[best_p] = True
+            hm = torch.where(pos[:P], torch.ones_like(hm), hm)
+        return hm, offset[:P]
+
+    def assign_dense(self, points, gt_bboxes, strides=None):
+        """-> (hm_tl (P,), offset_tl (P, 2), hm_br, offset_br); positives are hm == 1, negatives hm < 1."""
+        P, G = points.shape[0], gt_bboxes.shape[0]
+        dtype = torch.float32 if self.gaussian_bump else torch.long
+        if P == 0 or G == 0:
+            z = points.new_zeros
+            return z((P,), dtype=dtype), z((P, 2), dtype=torch.float32), z((P,), dtype=dtype), z((P, 2), dtype=torch.float32)
+        xy = points[:, :2]
+        lvl = torch.log2(points[:, 2]).int()
+        if strides is None:
+            levels = range(int(lvl.min()), int(lvl.max()) + 1)
+        else:
+            import math
+            levels = [int(math.log2(s)) for s in strides]
+        radius = sigma = None
+        if self.gaussian_bump:
+            w, h = gt_bboxes[:, 2] - gt_bboxes[:, 0], gt_bboxes[:, 3] - gt_bboxes[:, 1]
+            radius = gaussian_radius((h, w), self.gaussian_iou)
+            sigma = (2 * radius + 1) / 6
+        hm_tl, off_tl = self._corner(xy, lvl, levels, gt_bboxes[:, :2], radius, sigma, dtype)
+        hm_br, off_br = self._corner(xy, lvl, levels, gt_bboxes[:, 2:], radius, sigma, dtype)
+        return hm_tl, off_tl, hm_br, off_br
+
+    def assign(self, points, gt_bboxes, gt_labels=None):
+        hm_tl, off_tl, hm_br, off_br = self.assign_dense(points, gt_bboxes)
+
+        def inds(mask):
+            return torch.nonzero(mask, as_tuple=False).squeeze(-1)
+        return (hm_tl, off_tl, inds(hm_tl == 1), inds(hm_tl < 1), hm_br, off_br, inds(hm_br == 1), inds(hm_br < 1))
+
+
 @BBOX_ASSIGNERS.register_module()
 class ATSSAssigner:
     """Adaptive training sample selection: per level the `topk` boxes whose centres are nearest to

@@ -29,3 +29,10 @@ def multiclass_nms_lsvr(multi_bboxes, multi_pts, multi_scores, npts, score_thr, 
     if max_num > 0:
         dets, keep = dets[:max_num], keep[:max_num]
     return dets, pts[keep], labels[keep]
+
+
+def multiclass_nms(multi_bboxes, multi_scores, score_thr, nms_cfg, max_num=-1, score_factors=None):
+    """The box-only form (bbox_nms.py:7-57), used by the corner-point-verification head: (dets (k,5), labels (k,))."""
+    dets, _, labels = multiclass_nms_lsvr(multi_bboxes, multi_bboxes.new_zeros((multi_bboxes.shape[0], 0)), multi_scores,
+                                          0, score_thr, nms_cfg, max_num, score_factors)
+    return dets, labels

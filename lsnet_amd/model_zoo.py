@@ -39,6 +39,17 @@ def backbone_cfg(name='r50'):
 def head_cfg(task='bbox', conv_module_type='dcn'):
     """bbox: lsnet_bbox_r50_fpn_1x_coco.py:27-47; segm: lsnet_segm_r50_fpn_1x_coco.py:40-59;
     pose_bbox / pose_kbox: lsnet_pose_bbox_r50_fpn_1x_coco.py:27-46."""
+    if task == 'bbox_cpv':     # lsnet_bbox_cpv_x101_fpn_dconv_c3-c5_mstrain_2x_coco.py:20-56
+        return dict(type='LSCPVHead', num_classes=80, in_channels=256, feat_channels=256, point_feat_channels=256,
+                    stacked_convs=3, shared_stacked_convs=1, first_kernel_size=3, kernel_size=1, corner_dim=64,
+                    num_points=9, gradient_mul=0.1, point_strides=[8, 16, 32, 64, 128], point_base_scale=4,
+                    norm_cfg=NORM_GN, conv_module_type=conv_module_type,
+                    loss_cls=dict(type='FocalLoss', use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=1.0),
+                    loss_bbox_init=dict(type='CrossIOULoss', loss_weight=1.0),
+                    loss_bbox_refine=dict(type='CrossIOULoss', loss_weight=2.0),
+                    loss_heatmap=dict(type='GaussianFocalLoss', alpha=2.0, gamma=4.0, loss_weight=0.25),
+                    loss_offset=dict(type='SmoothL1Loss', beta=1.0 / 9.0, loss_weight=1.0),
+                    loss_sem=dict(type='SEPFocalLoss', gamma=2.0, alpha=0.25, loss_weight=0.1))
     nv = {'bbox': 4, 'segm': 36, 'pose_bbox': 17, 'pose_kbox': 17}[task]
     cfg = dict(type='LSHead', task=task, num_vectors=nv, num_classes=80 if 'pose' not in task else 1,
                in_channels=256, feat_channels=256, point_feat_channels=256, stacked_convs=3, num_kernel_points=9,
@@ -61,7 +72,8 @@ def head_cfg(task='bbox', conv_module_type='dcn'):
 
 
 def lsnet_config(task='bbox', backbone='r50', conv_module_type='dcn', lr=0.01, max_per_img=None):
-    model = dict(type='LSDetector', pretrained=None, backbone=backbone_cfg(backbone),
+    cpv = task == 'bbox_cpv'
+    model = dict(type='LSCPVDetector' if cpv else 'LSDetector', pretrained=None, backbone=backbone_cfg(backbone),
                  neck=dict(type='FPN', in_channels=[256, 512, 1024, 2048], out_channels=256, start_level=1,
                            add_extra_convs='on_input', num_outs=5, norm_cfg=NORM_GN),
                  bbox_head=head_cfg(task, conv_module_type))
@@ -69,6 +81,9 @@ def lsnet_config(task='bbox', backbone='r50', conv_module_type='dcn', lr=0.01, m
                                allowed_border=-1, pos_weight=-1, debug=False),
                      refine=dict(assigner=dict(type='ATSSAssigner', topk=9), allowed_border=-1, pos_weight=-1,
                                  debug=False))
+    if cpv:                    # lsnet_bbox_cpv_x101_*.py:58-73
+        train_cfg['heatmap'] = dict(assigner=dict(type='PointHMAssigner', gaussian_bump=True, gaussian_iou=0.7),
+                                    allowed_border=-1, pos_weight=-1, debug=False)
     pose = 'pose' in task
     test_cfg = dict(nms_pre=100 if pose else 1000, min_bbox_size=0, score_thr=0.05,
                     nms=dict(type='nms', iou_thr=0.6), max_per_img=max_per_img or (20 if pose else 100))

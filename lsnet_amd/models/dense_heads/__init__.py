@@ -1,3 +1,4 @@
 from .ls_head import DCNConvModule, LSHead
+from .lscpv_head import LSCPVHead
 
-__all__ = ['LSHead', 'DCNConvModule']
+__all__ = ['LSHead', 'LSCPVHead', 'DCNConvModule']

@@ -92,6 +92,51 @@ def golden_head(task):
     _save(f'head_{task}', data)
 
 
+def golden_head_cpv():
+    """(f-4) LSCPVHead.forward + loss (+ gradients) and get_bboxes, reference code end to end
+    (mmdet/models/dense_heads/lscpvnet_head.py)."""
+    import mmcv
+    from mmdet.models import build_head
+    cfg, train_cfg, test_cfg = gu.cpv_head_cfg()
+    cfg = mmcv.Config(copy.deepcopy(cfg))._cfg_dict
+    cfg.update(train_cfg=mmcv.Config(train_cfg), test_cfg=mmcv.Config(test_cfg))
+    head = build_head(cfg)
+    gu.fill_params(head, seed=7)
+    head.train()
+    feats = [f.requires_grad_() for f in gu.head_inputs(11)]
+    outs = head(feats)
+    data = {}
+    names = ['cls', 'bbox_init', 'bbox_refine', 'hm_score', 'hm_offset', 'sem']
+    for n, lv in zip(names, outs):
+        for i, t in enumerate(lv):
+            gu.pack(f'out/{n}/{i}', t, data)
+    boxes, labels, extremes, _, _, metas = _gt_for('bbox')
+    sem, wts = gu.make_sem_maps(boxes, labels, *gu.HEAD_IMG, 8)
+    losses = head.loss(*outs, boxes, extremes, sem, wts, labels, metas)
+    total = 0
+    for k, v in losses.items():
+        v = v if isinstance(v, (list, tuple)) else [v]
+        data[f'loss/{k}'] = np.array([float(x) for x in v], dtype=np.float64)
+        total = total + sum(v)
+    total.backward()
+    for i, f in enumerate(feats):
+        gu.pack(f'grad/feat/{i}', f.grad, data)
+    for name, p in sorted(head.named_parameters()):
+        if p.grad is not None:
+            gu.pack(f'grad/param/{name}', p.grad, data, stride=7)
+    head.eval()
+    with torch.no_grad():
+        dets = head.get_bboxes(*[[t.detach() for t in lv] for lv in outs], metas)
+        raw = head.get_bboxes(*[[t.detach() for t in lv] for lv in outs], metas, nms=False)
+    for i, (b, l) in enumerate(dets):
+        data[f'det/{i}/bboxes'] = b.numpy()
+        data[f'det/{i}/labels'] = l.numpy()
+        gu.pack(f'raw/{i}/bboxes', raw[i][0], data)
+    data['keys'] = np.array(sorted(head.state_dict().keys()))
+    data['shapes'] = np.array([str(tuple(v.shape)) for _, v in sorted(head.state_dict().items())])
+    _save('head_cpv', data)
+
+
 def golden_assign():
     """(6) CentroidAssigner + ATSSAssigner gt indices on the 800x800 grid (13 343 points)."""
     from mmdet.core import build_assigner
@@ -447,7 +492,7 @@ def golden_data_pipeline():
     _save('data_pipeline', data)
 
 
-ALL = dict(data_pipeline=golden_data_pipeline, gt_formats=golden_gt_formats, res2net=golden_res2net, vote=golden_vote, head_bbox=lambda: golden_head('bbox'), head_segm=lambda: golden_head('segm'),
+ALL = dict(head_cpv=golden_head_cpv, data_pipeline=golden_data_pipeline, gt_formats=golden_gt_formats, res2net=golden_res2net, vote=golden_vote, head_bbox=lambda: golden_head('bbox'), head_segm=lambda: golden_head('segm'),
            head_pose_bbox=lambda: golden_head('pose_bbox'), head_pose_kbox=lambda: golden_head('pose_kbox'),
            assign=golden_assign, cross_iou=golden_cross_iou, backbone=golden_backbone, nms=golden_nms)
 

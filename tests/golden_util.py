@@ -160,3 +160,37 @@ def head_inputs(seed, channels=32, batch=2):
     g = gen(seed)
     h, w = HEAD_IMG
     return [torch.randn(batch, channels, -(-h // s), -(-w // s), generator=g) for s in (8, 16, 32, 64, 128)]
+
+
+def cpv_head_cfg(channels=32, num_classes=8):
+    """A reduced LSCPVHead config (same code paths as configs/lsnet/lsnet_bbox_cpv_*, small tensors)."""
+    norm_cfg = dict(type='GN', num_groups=8, requires_grad=True)
+    cfg = dict(type='LSCPVHead', num_classes=num_classes, in_channels=channels, feat_channels=channels,
+               point_feat_channels=channels, stacked_convs=3, shared_stacked_convs=1, first_kernel_size=3, kernel_size=1,
+               corner_dim=16, num_points=9, gradient_mul=0.1, point_strides=[8, 16, 32, 64, 128], point_base_scale=4,
+               norm_cfg=norm_cfg, conv_module_type='dcn',
+               loss_cls=dict(type='FocalLoss', use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=1.0),
+               loss_bbox_init=dict(type='CrossIOULoss', loss_weight=1.0),
+               loss_bbox_refine=dict(type='CrossIOULoss', loss_weight=2.0),
+               loss_heatmap=dict(type='GaussianFocalLoss', alpha=2.0, gamma=4.0, loss_weight=0.25),
+               loss_offset=dict(type='SmoothL1Loss', beta=1.0 / 9.0, loss_weight=1.0),
+               loss_sem=dict(type='SEPFocalLoss', gamma=2.0, alpha=0.25, loss_weight=0.1))
+    _, train_cfg, test_cfg = head_cfg('bbox', channels, num_classes)
+    train_cfg['heatmap'] = dict(assigner=dict(type='PointHMAssigner', gaussian_bump=True, gaussian_iou=0.7),
+                                allowed_border=-1, pos_weight=-1, debug=False)
+    return cfg, train_cfg, test_cfg
+
+
+def make_sem_maps(boxes_list, labels_list, img_h, img_w, num_classes):
+    """Stride-8 box-level class maps and 1/area weights, (B, C, H/8, W/8) each -- the inputs LSCPVHead.loss gets from
+    the data pipeline (painted from the largest box to the smallest)."""
+    h, w = img_h // 8, img_w // 8
+    sem = torch.zeros(len(boxes_list), num_classes, h, w)
+    wts = torch.zeros(len(boxes_list), num_classes, h, w)
+    for i, (boxes, labels) in enumerate(zip(boxes_list, labels_list)):
+        area = (boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1])
+        for j in torch.argsort(area, descending=True).tolist():
+            x1, y1, x2, y2 = (int(v / 8) for v in boxes[j].tolist())
+            sem[i, labels[j], y1:y2 + 1, x1:x2 + 1] = 1
+            wts[i, labels[j], y1:y2 + 1, x1:x2 + 1] = 1 / float(area[j])
+    return sem, wts

@@ -43,6 +43,7 @@ def test_all_reference_lsnet_configs_load():
     ('lsnet_pose_bbox_r50_fpn_1x_coco.py', 'pose_bbox', 'r50'),
     ('lsnet_bbox_x101_fpn_dconv_c3-c5_mstrain_2x_coco.py.py', 'bbox', 'x101-dcn'),
     ('lsnet_segm_res2_101_fpn_dconv_c3-c5_mstrain_30e_coco.py', 'segm', 'res2-101-dcn'),
+    ('lsnet_bbox_cpv_x101_fpn_dconv_c3-c5_mstrain_2x_coco.py', 'bbox_cpv', 'x101-dcn'),
 ])
 def test_model_zoo_equals_reference_config(fname, task, backbone):
     """The zoo is what bench.py uses on the GPU box (no config files there): same model dicts."""

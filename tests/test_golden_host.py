@@ -32,3 +32,7 @@ def test_res2net_dcn_backbone(cpu_oracle_backend):
 
 def test_multiclass_nms_lsvr(cpu_oracle_backend):
     gc.nms_lsvr_case(CPU)
+
+
+def test_cpv_head_forward_loss_backward_decode(cpu_oracle_backend):
+    gc.cpv_head_case(CPU)
