@@ -1,4 +1,5 @@
-"""Builds liblsnet_hip.so (gfx950) in-tree with hipcc.  No torch dependency: plain HIP + C ABI."""
+"""Builds liblsnet_hip.so (gfx950) in-tree with hipcc, and liblsnet_host.so (host-side evaluation helpers, g++).
+No torch dependency: plain HIP / C++ behind C ABIs (include/lsnet_hip.h, include/lsnet_host.h)."""
 import os
 import shutil
 import subprocess
@@ -37,5 +38,26 @@ def build(force=False, verbose=False):
     return SO
 
 
+HOST_SO = os.path.join(HERE, 'liblsnet_host.so')
+HOST_SOURCES = [os.path.join('host', 'rle.cpp')]
+HOST_HEADERS = [os.path.join('..', '..', 'include', 'lsnet_host.h')]
+
+
+def build_host(force=False, verbose=False):
+    deps = [os.path.join(HERE, f) for f in HOST_SOURCES + HOST_HEADERS]
+    if not force and os.path.exists(HOST_SO) and all(os.path.getmtime(d) <= os.path.getmtime(HOST_SO) for d in deps):
+        return HOST_SO
+    cxx = shutil.which('g++') or shutil.which('c++')
+    if cxx is None:
+        raise RuntimeError('g++ not found: liblsnet_host.so cannot be built')
+    cmd = [cxx, '-O2', '-std=c++17', '-fPIC', '-shared', '-Wall', '-ffp-contract=off'] + \
+        [os.path.join(HERE, s) for s in HOST_SOURCES] + ['-o', HOST_SO]
+    if verbose:
+        print(' '.join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd, cwd=HERE)
+    return HOST_SO
+
+
 if __name__ == '__main__':
     print(build(force='--force' in sys.argv, verbose=True))
+    print(build_host(force='--force' in sys.argv, verbose=True))

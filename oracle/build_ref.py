@@ -6,7 +6,13 @@ Buildable: the CPU NMS extension (mmdet/ops/nms/src/nms_ext.cpp + src/cpu/nms_cp
 Unbuildable here (recorded in DESIGN.md): the DCN / pyramid-DCN / focal-loss extensions -- CUDA-only
 sources that include THC headers removed from current torch, no CPU branch, no nvcc.
 
-Used by tests/test_oracle.py to pin oracle `orc_nms` against the reference's own greedy NMS.
+Also buildable: the vendored COCO mask API (cocoapi/pycocotools/common/maskApi.c, one C file) -> maskapi.so, bound
+with ctypes by oracle/ref_harness/pycoco_mask.py so that the reference's own pycocotools (coco.py / cocoeval.py, pure
+Python) runs here as the checker of lsnet_amd/evaluation (its Cython binding `_mask.pyx` is not built: that would
+mean running the reference's build system).
+
+Used by tests/test_oracle.py to pin oracle `orc_nms` against the reference's own greedy NMS, and by
+tests/test_evaluation.py / make_golden.py for the evaluation fixtures.
 """
 import importlib.util
 import os
@@ -44,6 +50,22 @@ def build(force=False):
     return SO
 
 
+REF_MASK = '/root/reference/code/cocoapi/pycocotools/common'
+MASK_SO = os.path.join(OUT, 'maskapi.so')
+
+
+def build_maskapi(force=False):
+    """gcc on the reference's maskApi.c where it lies -> oracle/_ref/maskapi.so (plain C ABI, no Python)."""
+    src = os.path.join(REF_MASK, 'maskApi.c')
+    if not os.path.exists(src):
+        return MASK_SO if os.path.exists(MASK_SO) else None
+    if os.path.exists(MASK_SO) and not force and os.path.getmtime(MASK_SO) >= os.path.getmtime(src):
+        return MASK_SO
+    os.makedirs(OUT, exist_ok=True)
+    subprocess.check_call(['gcc', '-O2', '-std=c99', '-fPIC', '-shared', '-w', f'-I{REF_MASK}', src, '-lm', '-o', MASK_SO])
+    return MASK_SO
+
+
 def load():
     """The reference's compiled `nms_ext` module (nms / soft_nms / nms_match), or None."""
     if not available():
@@ -57,3 +79,4 @@ def load():
 
 if __name__ == '__main__':
     print(build(force='--force' in sys.argv))
+    print(build_maskapi(force='--force' in sys.argv))

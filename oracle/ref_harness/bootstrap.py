@@ -147,12 +147,35 @@ def _install_third_party_shims():
     for name in ('torchvision', 'torchvision.models'):
         if name not in sys.modules:
             sys.modules[name] = _RaisingModule(name)
-    for name in ('pycocotools', 'pycocotools.mask', 'pycocotools.coco', 'pycocotools.cocoeval',
-                 'lvis'):
-        if name not in sys.modules:
+    _install_pycocotools()
+    if 'lvis' not in sys.modules:
+        sys.modules['lvis'] = _RaisingModule('lvis')
+
+
+def _install_pycocotools():
+    """The reference vendors the COCO api (code/cocoapi/pycocotools): its pure-Python modules are imported from
+    there; its Cython module `_mask` is replaced by the ctypes binding of the reference's own maskApi.c
+    (pycoco_mask.py over oracle/_ref/maskapi.so).  Without that library (or the vendored tree) stubs remain."""
+    if 'pycocotools' in sys.modules:
+        return
+    pkg_dir = os.path.join(REF_ROOT, 'cocoapi', 'pycocotools', 'pycocotools')
+    from oracle import build_ref
+    so = build_ref.build_maskapi() if os.path.isdir(pkg_dir) else None
+    if so is None:
+        for name in ('pycocotools', 'pycocotools.mask', 'pycocotools.coco', 'pycocotools.cocoeval'):
             sys.modules[name] = _RaisingModule(name)
-    sys.modules['pycocotools.coco'].COCO = type('COCO', (), {})
-    sys.modules['pycocotools.cocoeval'].COCOeval = type('COCOeval', (), {})
+        sys.modules['pycocotools.coco'].COCO = type('COCO', (), {})
+        sys.modules['pycocotools.cocoeval'].COCOeval = type('COCOeval', (), {})
+        return
+    import numpy as np
+    if not hasattr(np, 'float'):          # cocoeval.py:317 uses the alias numpy removed in 1.24
+        np.float = float
+    pkg = types.ModuleType('pycocotools')
+    pkg.__path__ = [pkg_dir]
+    sys.modules['pycocotools'] = pkg
+    from oracle.ref_harness import pycoco_mask
+    sys.modules['pycocotools._mask'] = pycoco_mask
+    pkg._mask = pycoco_mask
 
 
 _EXT_STUBS = [
