@@ -59,6 +59,12 @@ void lsn_rle_decode(const uint32_t *counts, size_t m, uint8_t *mask, size_t hw);
 size_t lsn_rle_to_string(const uint32_t *counts, size_t m, char *s, size_t cap);
 size_t lsn_rle_from_string(const char *s, uint32_t *counts, size_t cap);
 
+/* cocoeval.py:212-247 (COCOeval.evaluateImg, the matching loops): greedy assignment of detections (rows of `ious`,
+ * D x G row-major, sorted by descending score) to ground truths (columns, non-ignored first) for T IoU thresholds.
+ * dt_match[t*D + d] = matched column or -1; gt_match[t*G + g] = matching row or -1. */
+void lsn_coco_match(const double *ious, size_t D, size_t G, const uint8_t *gt_ignore, const uint8_t *gt_crowd,
+                    const double *thrs, size_t T, int64_t *dt_match, int64_t *gt_match);
+
 #ifdef __cplusplus
 }
 #endif

@@ -34,8 +34,7 @@ class CocoIndex:
                 self.cat_img_map[ann['category_id']].append(ann['image_id'])
 
     def get_cat_ids(self, cat_names=()):
-        if isinstance(cat_names, str):
-            cat_names = [cat_names]
+        # a bare string is matched by substring (`name in 'person'`), exactly what the COCO api does with it
         cats = self.dataset.get('categories', [])
         if len(cat_names):
             cats = [c for c in cats if c['name'] in cat_names]

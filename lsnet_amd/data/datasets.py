@@ -206,30 +206,144 @@ class CocoDataset(CustomDataset):
         return {'bboxes': boxes, 'labels': labels, 'bboxes_ignore': ignored, 'masks': masks, key: extra,
                 'seg_map': img_info['filename'].replace('jpg', 'png')}
 
-    # ---- detections -> COCO result records (coco.py:187-330) ---------------------------------------------
+    # ---- detections -> COCO result records -> metrics (coco.py:187-507) -----------------------------------
     @staticmethod
     def xyxy2xywh(bbox):
         b = bbox.tolist()
         return [b[0], b[1], b[2] - b[0], b[3] - b[1]]
 
-    def det2json(self, results):
-        """`results[i]` = per-class list of (n, 5) arrays `[x1, y1, x2, y2, score]` of image i."""
+    def _records(self, results, pick_boxes, extra=None):
         out = []
         for idx in range(len(self)):
             img_id = self.img_ids[idx]
-            for label, dets in enumerate(results[idx]):
-                for d in dets:
-                    out.append(dict(image_id=img_id, bbox=self.xyxy2xywh(d), score=float(d[4]),
-                                    category_id=self.cat_ids[label]))
+            per_class = pick_boxes(results[idx])
+            for label, dets in enumerate(per_class):
+                for i in range(dets.shape[0]):
+                    rec = dict(image_id=img_id, bbox=self.xyxy2xywh(dets[i]), score=float(dets[i][4]),
+                               category_id=self.cat_ids[label])
+                    if extra is not None:
+                        rec.update(extra(results[idx], label, i))
+                    out.append(rec)
+        return out
+
+    def _det2json(self, results):
+        """`results[i]` = per-class list of (n, 5) arrays `[x1, y1, x2, y2, score]` of image i."""
+        return self._records(results, lambda r: r)
+
+    def _segm2json(self, results):
+        """`results[i]` = (per-class boxes, per-class lists of RLE dicts)."""
+        def seg(r, label, i):
+            rle = dict(r[1][label][i])
+            if isinstance(rle['counts'], bytes):
+                rle['counts'] = rle['counts'].decode()
+            return dict(segmentation=rle)
+        return self._records(results, lambda r: r[0]), self._records(results, lambda r: r[0], seg)
+
+    def results2json(self, results, outfile_prefix):
+        import json
+        files = {}
+
+        def dump(records, kind, suffix):
+            files[kind] = f'{outfile_prefix}.{suffix}.json'
+            with open(files[kind], 'w') as f:
+                json.dump(records, f)
+        if isinstance(results[0], list):
+            dump(self._det2json(results), 'bbox', 'bbox')
+            files['proposal'] = files['bbox']
+        elif isinstance(results[0], tuple):
+            boxes, segms = self._segm2json(results)
+            dump(boxes, 'bbox', 'bbox')
+            files['proposal'] = files['bbox']
+            dump(segms, 'segm', 'segm')
+        else:
+            raise TypeError('invalid type of results')
+        return files
+
+    def format_results(self, results, jsonfile_prefix=None, **kwargs):
+        import tempfile
+        assert isinstance(results, list), 'results must be a list'
+        assert len(results) == len(self), f'The length of results is not equal to the dataset len: {len(results)} != {len(self)}'
+        tmp_dir = None
+        if jsonfile_prefix is None:
+            tmp_dir = tempfile.TemporaryDirectory()
+            jsonfile_prefix = osp.join(tmp_dir.name, 'results')
+        return self.results2json(results, jsonfile_prefix), tmp_dir
+
+    ALLOWED_METRICS = ('bbox', 'segm')
+
+    def evaluate(self, results, metric='bbox', logger=None, jsonfile_prefix=None, classwise=False, **kwargs):
+        """COCO AP / AR of `results` (one entry per image, test-mode order) -> {'bbox_mAP': ..., 'bbox_mAP_50': ...}.
+        Metrics: 'bbox', 'segm' (and 'keypoints' on CocoPoseDataset); the proposal metrics of two-stage detectors are
+        not on the LSNet path."""
+        from ..evaluation.coco_eval import CocoEval, load_results
+        log = logger if callable(logger) else (lambda s: None)
+        metrics = metric if isinstance(metric, list) else [metric]
+        for m in metrics:
+            if m not in self.ALLOWED_METRICS:
+                raise KeyError(f'metric {m} is not supported')
+        files, tmp_dir = self.format_results(results, jsonfile_prefix)
+        out = {}
+        for m in metrics:
+            log(f'Evaluating {m}...')
+            if m not in files:
+                raise KeyError(f'{m} is not in results')
+            try:
+                dt = load_results(self.coco, files[m])
+            except IndexError:
+                log('The testing results of the whole dataset is empty.')
+                break
+            ev = CocoEval(self.coco, dt, m)
+            ev.params.cat_ids, ev.params.img_ids = self.cat_ids, self.img_ids
+            ev.evaluate()
+            ev.accumulate()
+            ev.summarize(printer=log)
+            if classwise:
+                prec = ev.eval['precision']
+                assert len(self.cat_ids) == prec.shape[2]
+                per_class = {}
+                for k, cat_id in enumerate(self.cat_ids):
+                    pk = prec[:, :, k, 0, -1]
+                    pk = pk[pk > -1]
+                    per_class[self.coco.load_cats([cat_id])[0]['name']] = float(np.mean(pk)) if pk.size else float('nan')
+                out[f'{m}_classwise_AP'] = per_class
+            for i, item in enumerate(('mAP', 'mAP_50', 'mAP_75', 'mAP_s', 'mAP_m', 'mAP_l')):
+                out[f'{m}_{item}'] = float(f'{ev.stats[i]:.3f}')
+            out[f'{m}_mAP_copypaste'] = ' '.join(f'{v:.3f}' for v in ev.stats[:6])
+        if tmp_dir is not None:
+            tmp_dir.cleanup()
         return out
 
 
 @DATASETS.register_module()
 class CocoPoseDataset(CocoDataset):
-    """coco_pose.py:19-172 (there CLASSES is the bare string 'person', which the COCO api wraps into ['person'])."""
+    """coco_pose.py:19-172.  There CLASSES is the bare string 'person'; the COCO api takes a string for a sequence and
+    keeps the categories whose name is a SUBSTRING of it -- in COCO files that is the person category alone."""
 
     CLASSES = ('person',)
     INSTANCE_FIELD = ('keypoints', 'keypoints', 51)
+    ALLOWED_METRICS = ('bbox', 'segm', 'keypoints')
+
+    def _det2json(self, results):
+        """`results[i]` = [per-class boxes, per-class (n, 34) keypoint arrays] (coco_pose.py:209-224)."""
+        return self._records(results, lambda r: r[0])
+
+    def _kps2json(self, results):
+        """coco_pose.py:226-247: every keypoint is reported as labelled and visible (v = 1)."""
+        def kps(r, label, i):
+            k = np.concatenate([r[1][label][i].reshape(-1, 2), np.ones((17, 1), dtype=np.float32)], axis=1)
+            return dict(keypoints=k.reshape(51).tolist())
+        return self._records(results, lambda r: r[0], kps)
+
+    def results2json(self, results, outfile_prefix):
+        import json
+        if not (isinstance(results[0], list) and len(results[0]) == 2 and isinstance(results[0][0], list)):
+            return super().results2json(results, outfile_prefix)
+        files = {'bbox': f'{outfile_prefix}.bbox.json', 'keypoints': f'{outfile_prefix}.kps.json'}
+        files['proposal'] = files['bbox']
+        for kind, records in (('bbox', self._det2json(results)), ('keypoints', self._kps2json(results))):
+            with open(files[kind], 'w') as f:
+                json.dump(records, f)
+        return files
 
 
 @DATASETS.register_module()

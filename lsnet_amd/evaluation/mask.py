@@ -15,7 +15,8 @@ _lib = None
 _u32p, _f64p, _szp, _u8p = C.POINTER(C.c_uint32), C.POINTER(C.c_double), C.POINTER(C.c_size_t), C.POINTER(C.c_uint8)
 
 EXPORTS = ('lsn_rle_from_polygon', 'lsn_rle_from_bbox', 'lsn_rle_merge', 'lsn_rle_area', 'lsn_rle_to_bbox',
-           'lsn_rle_iou', 'lsn_bbox_iou', 'lsn_rle_encode', 'lsn_rle_decode', 'lsn_rle_to_string', 'lsn_rle_from_string')
+           'lsn_rle_iou', 'lsn_bbox_iou', 'lsn_rle_encode', 'lsn_rle_decode', 'lsn_rle_to_string', 'lsn_rle_from_string',
+           'lsn_coco_match')
 
 
 def lib():
@@ -46,6 +47,9 @@ def lib():
         L.lsn_rle_to_string.argtypes = [_u32p, C.c_size_t, C.c_char_p, C.c_size_t]
         L.lsn_rle_from_string.restype = C.c_size_t
         L.lsn_rle_from_string.argtypes = [C.c_char_p, _u32p, C.c_size_t]
+        L.lsn_coco_match.restype = None
+        L.lsn_coco_match.argtypes = [_f64p, C.c_size_t, C.c_size_t, _u8p, _u8p, _f64p, C.c_size_t, C.POINTER(C.c_int64),
+                                     C.POINTER(C.c_int64)]
         _lib = L
     return _lib
 

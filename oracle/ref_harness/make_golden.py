@@ -137,6 +137,53 @@ def golden_head_cpv():
     _save('head_cpv', data)
 
 
+def golden_coco_eval():
+    """(f-4) COCO metrics of the reference's vendored evaluator (cocoapi/pycocotools: coco.py loadRes, cocoeval.py, its
+    maskApi.c bound by pycoco_mask.py) on gu.synthetic_eval_case: boxes, masks (polygons -> RLE), keypoints; also with
+    `useCats = 0` and other detection budgets (the proposal-style use of mmdet/datasets/coco.py:430-445)."""
+    import contextlib
+    import io
+
+    import pycocotools.mask as mask_util
+    from pycocotools.coco import COCO
+    from pycocotools.cocoeval import COCOeval
+    gt_dict, boxes, polys, kpts = gu.synthetic_eval_case()
+    data = {}
+    sizes = {im['id']: (im['height'], im['width']) for im in gt_dict['images']}
+
+    def run(kind, records, tweak=None):
+        with contextlib.redirect_stdout(io.StringIO()):
+            gt = COCO()
+            gt.dataset = copy.deepcopy(gt_dict)
+            gt.createIndex()
+            dt = gt.loadRes(copy.deepcopy(records))
+            ev = COCOeval(gt, dt, kind)
+            if tweak:
+                tweak(ev.params)
+            ev.evaluate()
+            ev.accumulate()
+            ev.summarize()
+        return ev
+    segm = []
+    for r in polys:
+        h, w = sizes[r['image_id']]
+        rle = mask_util.merge(mask_util.frPyObjects([r['polygon']], h, w))
+        rle['counts'] = rle['counts'].decode()
+        segm.append(dict(image_id=r['image_id'], category_id=r['category_id'], score=r['score'], segmentation=rle))
+    data['segm/rle0'] = np.array(segm[0]['segmentation']['counts'])
+    cases = dict(bbox=('bbox', boxes, None), segm=('segm', segm, None), keypoints=('keypoints', kpts, None),
+                 bbox_nocat=('bbox', boxes, lambda p: (setattr(p, 'useCats', 0), setattr(p, 'maxDets', [3, 30, 300]))),
+                 bbox_subset=('bbox', boxes, lambda p: (setattr(p, 'catIds', [1, 17]),
+                                                        setattr(p, 'imgIds', [im['id'] for im in gt_dict['images'][:9]]))))
+    for name, (kind, recs, tweak) in cases.items():
+        ev = run(kind, recs, tweak)
+        data[f'{name}/stats'] = np.asarray(ev.stats)
+        data[f'{name}/precision'] = ev.eval['precision']
+        data[f'{name}/recall'] = ev.eval['recall']
+        data[f'{name}/scores'] = ev.eval['scores']
+    _save('coco_eval', data)
+
+
 def golden_assign():
     """(6) CentroidAssigner + ATSSAssigner gt indices on the 800x800 grid (13 343 points)."""
     from mmdet.core import build_assigner
@@ -492,7 +539,7 @@ def golden_data_pipeline():
     _save('data_pipeline', data)
 
 
-ALL = dict(head_cpv=golden_head_cpv, data_pipeline=golden_data_pipeline, gt_formats=golden_gt_formats, res2net=golden_res2net, vote=golden_vote, head_bbox=lambda: golden_head('bbox'), head_segm=lambda: golden_head('segm'),
+ALL = dict(coco_eval=golden_coco_eval, head_cpv=golden_head_cpv, data_pipeline=golden_data_pipeline, gt_formats=golden_gt_formats, res2net=golden_res2net, vote=golden_vote, head_bbox=lambda: golden_head('bbox'), head_segm=lambda: golden_head('segm'),
            head_pose_bbox=lambda: golden_head('pose_bbox'), head_pose_kbox=lambda: golden_head('pose_kbox'),
            assign=golden_assign, cross_iou=golden_cross_iou, backbone=golden_backbone, nms=golden_nms)
 

@@ -194,3 +194,76 @@ def make_sem_maps(boxes_list, labels_list, img_h, img_w, num_classes):
             sem[i, labels[j], y1:y2 + 1, x1:x2 + 1] = 1
             wts[i, labels[j], y1:y2 + 1, x1:x2 + 1] = 1 / float(area[j])
     return sem, wts
+
+
+def synthetic_eval_case(seed=0, num_images=14):
+    """A COCO-format ground truth (3 categories, polygons, crowd regions as run-length masks, keypoints, an image without
+    objects, an unlabelled-keypoint person) and detection records of the three kinds (boxes, polygons, keypoints) that
+    hit, miss, duplicate and hallucinate objects -- inputs of the evaluation fixtures.  Pure numpy; returns plain
+    python structures (json-serialisable)."""
+    import numpy as np
+    rng = np.random.RandomState(seed)
+    cats = [dict(id=1, name='person', supercategory='person'), dict(id=3, name='car', supercategory='vehicle'),
+            dict(id=17, name='cat', supercategory='animal')]
+    images, anns = [], []
+    aid = 1
+
+    def star(n, cx, cy, r):
+        ang = np.sort(rng.rand(n)) * 2 * np.pi
+        rad = r * (0.6 + 0.4 * rng.rand(n))
+        return np.stack([cx + rad * np.cos(ang), cy + rad * np.sin(ang)], 1)
+    for i in range(num_images):
+        w, h = int(rng.randint(120, 400)), int(rng.randint(120, 400))
+        img_id = 100 - 3 * i if i % 2 else 7 + i          # unsorted, unique ids
+        images.append(dict(id=img_id, file_name=f'{img_id:06d}.jpg', width=w, height=h))
+        if i == 3:
+            continue                                      # an image without annotations
+        for _ in range(int(rng.randint(1, 7))):
+            r = float(rng.choice([6, 14, 30, 70]))
+            cx, cy = float(rng.uniform(r, w - r)), float(rng.uniform(r, h - r))
+            pts = star(int(rng.randint(5, 14)), cx, cy, r).clip([0, 0], [w - 1, h - 1]).round(2)
+            x1, y1, x2, y2 = pts[:, 0].min(), pts[:, 1].min(), pts[:, 0].max(), pts[:, 1].max()
+            crowd = int(rng.rand() < 0.12)
+            shoelace = 0.5 * abs(np.dot(pts[:, 0], np.roll(pts[:, 1], 1)) - np.dot(pts[:, 1], np.roll(pts[:, 0], 1)))
+            kp = np.concatenate([rng.uniform([x1, y1], [x2, y2], (17, 2)), rng.randint(0, 3, (17, 1))], 1).round(1)
+            if rng.rand() < 0.15:
+                kp[:, 2] = 0
+            seg = [pts.reshape(-1).tolist()]
+            if crowd:                                     # crowd regions come as uncompressed run-length masks
+                a, b = int(x1) * h + int(y1), int((x2 - x1) * h * 0.5)
+                seg = dict(size=[h, w], counts=[a, max(b, 1), h * w - a - max(b, 1)])
+            anns.append(dict(id=aid, image_id=img_id, category_id=int(rng.choice([1, 1, 3, 17])), iscrowd=crowd,
+                             bbox=[float(x1), float(y1), float(x2 - x1), float(y2 - y1)], area=float(shoelace),
+                             segmentation=seg, keypoints=kp.reshape(-1).tolist(), num_keypoints=int((kp[:, 2] > 0).sum())))
+            aid += 1
+    gt = dict(images=images, categories=cats, annotations=anns)
+    boxes, polys, kpts = [], [], []
+    for a in anns:
+        if rng.rand() < 0.15:
+            continue                                      # missed object
+        for rep in range(1 + int(rng.rand() < 0.3)):      # sometimes detected twice
+            x, y, w, h = a['bbox']
+            jit = rng.normal(0, 0.08 + 0.15 * rep, 4) * [w, h, w, h]
+            bb = [x + jit[0], y + jit[1], max(w + jit[2], 1.0), max(h + jit[3], 1.0)]
+            score = float(np.clip(rng.beta(5, 2) - 0.2 * rep, 0.01, 0.999))
+            cat = a['category_id'] if rng.rand() > 0.1 else int(rng.choice([1, 3, 17]))
+            boxes.append(dict(image_id=a['image_id'], category_id=cat, bbox=[float(v) for v in bb], score=score))
+            if isinstance(a['segmentation'], list):
+                p = np.array(a['segmentation'][0]).reshape(-1, 2)
+            else:
+                p = np.array([[x, y], [x + w, y], [x + w, y + h], [x, y + h]])
+            p = p + rng.normal(0, 0.06 * (1 + rep), p.shape) * [w, h]
+            polys.append(dict(image_id=a['image_id'], category_id=cat, score=score, polygon=p.reshape(-1).round(2).tolist()))
+            k = np.array(a['keypoints']).reshape(17, 3).copy()
+            k[:, :2] += rng.normal(0, 0.05 * (1 + rep), (17, 2)) * [w, h]
+            k[:, 2] = 1
+            kpts.append(dict(image_id=a['image_id'], category_id=1, score=score, keypoints=k.reshape(-1).round(2).tolist(),
+                             bbox=[float(v) for v in bb]))
+    for _ in range(25):                                   # hallucinations
+        im = images[int(rng.randint(len(images)))]
+        w, h = rng.uniform(5, 80, 2)
+        x, y = rng.uniform(0, im['width'] - w), rng.uniform(0, im['height'] - h)
+        rec = dict(image_id=im['id'], category_id=int(rng.choice([1, 3, 17])), score=float(rng.uniform(0.01, 0.6)))
+        boxes.append(dict(rec, bbox=[float(x), float(y), float(w), float(h)]))
+        polys.append(dict(rec, polygon=[float(x), float(y), float(x + w), float(y), float(x + w), float(y + h), float(x), float(y + h)]))
+    return gt, boxes, polys, kpts

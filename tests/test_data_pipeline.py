@@ -377,3 +377,34 @@ def test_cpv_semantic_targets_equal_reference_fixture():
     assert np.array_equal(res['gt_sem_weights'], gold['rpdv2/weights'])
     bundle = build_from_cfg(dict(type='RPDV2FormatBundle'), PIPELINES)(dict(res, img=np.zeros((96, 128, 3), np.float32)))
     assert bundle['gt_sem_map'].stack and bundle['gt_sem_map'].data.shape == (5, 12, 16) and bundle['img'].data.shape == (3, 96, 128)
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/code/cocoapi'), reason='the reference tree is not on this machine')
+@pytest.mark.parametrize('test_mode', [False, True])
+def test_datasets_equal_reference_datasets(test_mode):
+    """The reference's own CocoDataset / CocoPoseDataset over its vendored COCO api (oracle/ref_harness) list the same
+    images in the same order with the same group flags, categories and parsed annotations."""
+    import contextlib
+    import io
+    os.environ['PYTHONDONTWRITEBYTECODE'] = '1'
+    from oracle.ref_harness import bootstrap
+    bootstrap.load_reference()
+    from mmdet.datasets import CocoDataset as RefCoco
+    from mmdet.datasets import CocoPoseDataset as RefPose
+    for ours_cls, ref_cls in ((CocoDataset, RefCoco), (CocoPoseDataset, RefPose)):
+        with contextlib.redirect_stdout(io.StringIO()):
+            ref = ref_cls(TINY, pipeline=[], test_mode=test_mode)
+        ours = ours_cls(TINY, pipeline=[], test_mode=test_mode)
+        assert [d['id'] for d in ours.data_infos] == [d['id'] for d in ref.data_infos]
+        assert ours.cat_ids == ref.cat_ids and ours.cat2label == ref.cat2label and ours.img_ids == ref.img_ids
+        if not test_mode:
+            assert np.array_equal(ours.flag, ref.flag)
+        for idx in range(len(ours)):
+            a, b = ours.get_ann_info(idx), ref.get_ann_info(idx)
+            assert sorted(a) == sorted(b)
+            for k in a:
+                if isinstance(a[k], np.ndarray):
+                    assert a[k].dtype == b[k].dtype and np.array_equal(a[k], b[k]), (idx, k)
+                else:
+                    assert a[k] == b[k], (idx, k)
+            assert ours.get_cat_ids(idx) == ref.get_cat_ids(idx)
