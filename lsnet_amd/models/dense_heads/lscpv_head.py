@@ -80,6 +80,10 @@ class LSCPVHead(LSHead):
         self.hem_tl = TLPool(fc, self.conv_cfg, self.norm_cfg, **pool_kw)
         self.hem_br = BRPool(fc, self.conv_cfg, self.norm_cfg, **pool_kw)
         gather_in = fc + 6                                   # features + 2 corner scores + 4 corner offsets
+        # The matrix-pipe kernels step through channels in eights: the gathered maps get zero channels up to the next
+        # multiple of 8 and the four weights that read them a matching zero-padded VIEW per step (parameters keep the
+        # reference's shapes: 262 input channels for feat_channels = 256).
+        self.gather_pad = (-gather_in) % 8
         self.pts_cls_conv = PyramidDeformConv(gather_in, pc, self.dcn_kernel, 1, self.dcn_pad)
         self.pts_cls_out = Conv2d(pc, self.cls_out_channels, 1, 1, 0)
         self.pts_bbox_init_conv = Conv2d(fc, pc, 3, 1, 1)
@@ -143,8 +147,11 @@ class LSCPVHead(LSHead):
             hem_offsets.append(offset)
             bbox_feat = bbox_tower[l] + sem
             init_feats.append(self.pts_bbox_init_conv(bbox_feat))
-            cls_feats.append(torch.cat([cls_tower[l] + sem, score, offset], dim=1))
-            bbox_feats.append(torch.cat([bbox_feat, score, offset], dim=1))
+            extra = [score, offset]
+            if self.gather_pad:
+                extra.append(score.new_zeros(score.shape[0], self.gather_pad, *score.shape[2:]))
+            cls_feats.append(torch.cat([cls_tower[l] + sem] + extra, dim=1))
+            bbox_feats.append(torch.cat([bbox_feat] + extra, dim=1))
 
         raw = self.pts_bbox_init_out(self.relu(self._cat_px(init_feats)))          # pixel-wise from here: all levels
         sp_all = self.softplus(raw[:, :20])
@@ -164,12 +171,18 @@ class LSCPVHead(LSHead):
                 scaled.append(cur)
                 pairs.append((l, s, sh, sw))
         scales = [(p[2], p[3]) for p in pairs]
-        cls_raw = self.pts_cls_conv.forward_multi([cls_feats[p[1]] for p in pairs], scaled, scales)
-        box_raw = self.pts_bbox_refine_conv.forward_multi([bbox_feats[p[1]] for p in pairs], scaled, scales)
-        cls_fused = [self.cls_af_dcn_conv(torch.cat(cls_raw[3 * l:3 * l + 3], dim=1)) + self.cls_feat_conv(cls_feats[l])
-                     for l in range(nl)]
-        box_fused = [self.bbox_af_dcn_conv(torch.cat(box_raw[3 * l:3 * l + 3], dim=1)) + self.bbox_feat_conv(bbox_feats[l])
-                     for l in range(nl)]
+
+        def wide(w):                                           # (Co, C, kh, kw) -> (Co, C + pad, kh, kw)
+            return F.pad(w, (0, 0, 0, 0, 0, self.gather_pad)) if self.gather_pad else w
+        cls_raw = self.pts_cls_conv.forward_multi([cls_feats[p[1]] for p in pairs], scaled, scales,
+                                                  weight=wide(self.pts_cls_conv.weight))
+        box_raw = self.pts_bbox_refine_conv.forward_multi([bbox_feats[p[1]] for p in pairs], scaled, scales,
+                                                          weight=wide(self.pts_bbox_refine_conv.weight))
+        w_cls, w_box = wide(self.cls_feat_conv.weight), wide(self.bbox_feat_conv.weight)
+        cls_fused = [self.cls_af_dcn_conv(torch.cat(cls_raw[3 * l:3 * l + 3], dim=1)) +
+                     self.cls_feat_conv(cls_feats[l], weight=w_cls) for l in range(nl)]
+        box_fused = [self.bbox_af_dcn_conv(torch.cat(box_raw[3 * l:3 * l + 3], dim=1)) +
+                     self.bbox_feat_conv(bbox_feats[l], weight=w_box) for l in range(nl)]
         cls_out = self._split_px(self.pts_cls_out(self._cat_px(self.cls_GN.forward_multi(cls_fused, relu=True))), shapes)
         refine = self.pts_bbox_refine_out(self._cat_px(self.bbox_GN.forward_multi(box_fused, relu=True)))
         refine_sp = self._split_px(self.softplus(refine + sp_all.detach()), shapes)

@@ -107,12 +107,19 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, relu=False):
 
 class Conv2d(nn.Conv2d):
 
-    def forward(self, x):
-        if hip_conv_ok(x, self.weight, self.stride, self.padding, self.dilation, self.groups, self.padding_mode):
-            Co, C, kh, kw = self.weight.shape
+    def forward(self, x, weight=None):
+        """`weight`: use this tensor instead of the module's parameter (a zero-padded view of it, for inputs whose
+        channel count was rounded up to the kernels' granularity)."""
+        if weight is not None:
+            return self._run(x, weight)
+        return self._run(x, self.weight)
+
+    def _run(self, x, w):
+        if hip_conv_ok(x, w, self.stride, self.padding, self.dilation, self.groups, self.padding_mode):
+            Co, C, kh, kw = w.shape
             s, p, d = self.stride[0], self.padding[0], self.dilation[0]
             ho = (x.shape[2] + 2 * p - (d * (kh - 1) + 1)) // s + 1
             wo = (x.shape[3] + 2 * p - (d * (kw - 1) + 1)) // s + 1
             if _own_is_faster(x.shape[0] * ho * wo, C, Co, kh * kw):
-                return _ConvFn.apply(x, self.weight, self.bias, s, p, d, False)
-        return F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
+                return _ConvFn.apply(x, w, self.bias, s, p, d, False)
+        return F.conv2d(x, w, self.bias, self.stride, self.padding, self.dilation, self.groups)

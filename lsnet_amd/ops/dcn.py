@@ -340,9 +340,11 @@ class PyramidDeformConv(nn.Module):
     def forward(self, x, offset, scale_h, scale_w):
         return self.forward_multi([x], [offset], [(scale_h, scale_w)])[0]
 
-    def forward_multi(self, xs, offsets, scales):
+    def forward_multi(self, xs, offsets, scales, weight=None):
+        """`weight`: a zero-padded view of `self.weight` for sources whose channels were rounded up."""
         prepped = [self._pad_small(x, o) for x, o in zip(xs, offsets)]
-        outs = dcn_multi([p[0] for p in prepped], [p[1] for p in prepped], None, self.weight, None, self.stride,
+        outs = dcn_multi([p[0] for p in prepped], [p[1] for p in prepped], None,
+                         self.weight if weight is None else weight, None, self.stride,
                          self.padding, self.dilation, self.groups, self.deformable_groups,
                          scales=[_pair(s) for s in scales], pyramid=True)
         res = []
