@@ -65,6 +65,20 @@ size_t lsn_rle_from_string(const char *s, uint32_t *counts, size_t cap);
 void lsn_coco_match(const double *ious, size_t D, size_t G, const uint8_t *gt_ignore, const uint8_t *gt_crowd,
                     const double *thrs, size_t T, int64_t *dt_match, int64_t *gt_match);
 
+/* Image preparation of the data pipeline; the reference reaches OpenCV for these through mmcv
+ * (mmcv/image/geometric.py:26-56 imresize, photometric.py:8-41 imnormalize).  Images are interleaved h x w x c.
+ * Bilinear resize with cv2.INTER_LINEAR's sampling (pixel centres at half-integers, no antialiasing); 8-bit images
+ * use its 11-bit fixed-point weights and two-pass rounding, float images plain float32.  Return 0, or 1 on a
+ * non-positive size. */
+int lsn_image_resize_bilinear_u8(const uint8_t *src, int sh, int sw, int c, uint8_t *dst, int dh, int dw);
+int lsn_image_resize_bilinear_f32(const float *src, int sh, int sw, int c, float *dst, int dh, int dw);
+
+/* dst = (src - mean) * inv_std per channel in float32, optionally reading the channels in reverse order (BGR -> RGB). */
+void lsn_image_normalize_u8(const uint8_t *src, size_t pixels, int c, const float *mean, const float *inv_std,
+                            int reverse_channels, float *dst);
+void lsn_image_normalize_f32(const float *src, size_t pixels, int c, const float *mean, const float *inv_std,
+                             int reverse_channels, float *dst);
+
 #ifdef __cplusplus
 }
 #endif

@@ -39,7 +39,8 @@ def build(force=False, verbose=False):
 
 
 HOST_SO = os.path.join(HERE, 'liblsnet_host.so')
-HOST_SOURCES = [os.path.join('host', 'rle.cpp'), os.path.join('host', 'coco_match.cpp')]
+HOST_SOURCES = [os.path.join('host', 'rle.cpp'), os.path.join('host', 'coco_match.cpp'),
+                os.path.join('host', 'image.cpp')]
 HOST_HEADERS = [os.path.join('..', '..', 'include', 'lsnet_host.h')]
 
 
@@ -50,7 +51,7 @@ def build_host(force=False, verbose=False):
     cxx = shutil.which('g++') or shutil.which('c++')
     if cxx is None:
         raise RuntimeError('g++ not found: liblsnet_host.so cannot be built')
-    cmd = [cxx, '-O2', '-std=c++17', '-fPIC', '-shared', '-Wall', '-ffp-contract=off'] + \
+    cmd = [cxx, '-O3', '-std=c++17', '-fPIC', '-shared', '-Wall', '-ffp-contract=off'] + \
         [os.path.join(HERE, s) for s in HOST_SOURCES] + ['-o', HOST_SO]
     if verbose:
         print(' '.join(cmd), file=sys.stderr)

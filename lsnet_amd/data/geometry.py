@@ -6,9 +6,23 @@ io.py:140-190).  Images are HxWxC numpy arrays in BGR order, like the reference'
 fixed-point weights, the two-pass rounding of `HResizeLinear`/`VResizeLinear` -- so that a checkpoint trained on
 cv2-resized images sees the same pixels; float images are interpolated in float32.  (cv2 is absent from this image, so
 the 8-bit path is pinned by its own properties in tests/test_data_pipeline.py, not against cv2 itself.)"""
+import ctypes as C
 import io
+import os
 
 import numpy as np
+
+
+def _native():
+    """liblsnet_host.so (csrc/host/image.cpp: the same arithmetic, compiled), or None -- then the numpy formulation
+    below runs (also with LSNET_NUMPY_IMAGE=1, which the tests use to compare the two)."""
+    if os.environ.get('LSNET_NUMPY_IMAGE') == '1':
+        return None
+    try:
+        from ..evaluation.mask import lib
+        return lib()
+    except (RuntimeError, OSError):
+        return None
 
 
 def rescale_size(old_size, scale, return_scale=False):
@@ -37,6 +51,23 @@ def _linear_taps(dst, src):
     hi = s >= src - 1
     f[hi], s[hi] = 0.0, src - 1
     return s, np.minimum(s + 1, src - 1), f
+
+
+def _resize_linear_native(img, w, h):
+    L = _native()
+    if L is None or img.dtype not in (np.uint8, np.float32):
+        return None
+    sh, sw = img.shape[:2]
+    src = np.ascontiguousarray(img)
+    c = int(src.size // (sh * sw))
+    dst = np.empty((h, w) + img.shape[2:], dtype=img.dtype)
+    if img.dtype == np.uint8:
+        t = C.POINTER(C.c_uint8)
+        rc = L.lsn_image_resize_bilinear_u8(src.ctypes.data_as(t), sh, sw, c, dst.ctypes.data_as(t), h, w)
+    else:
+        t = C.POINTER(C.c_float)
+        rc = L.lsn_image_resize_bilinear_f32(src.ctypes.data_as(t), sh, sw, c, dst.ctypes.data_as(t), h, w)
+    return dst if rc == 0 else None
 
 
 def _resize_linear_u8(img, w, h):
@@ -81,10 +112,10 @@ def imresize(img, size, return_scale=False, interpolation='bilinear'):
     elif interpolation == 'bilinear':
         if (w, h) == (sw, sh):
             out = img.copy()
-        elif img.dtype == np.uint8:
-            out = _resize_linear_u8(img, w, h)
         else:
-            out = _resize_linear_f32(img, w, h)
+            out = _resize_linear_native(img, w, h)
+            if out is None:
+                out = _resize_linear_u8(img, w, h) if img.dtype == np.uint8 else _resize_linear_f32(img, w, h)
     else:
         raise ValueError(f'interpolation {interpolation!r} is not on the LSNet path')
     return (out, w / sw, h / sh) if return_scale else out
@@ -122,12 +153,24 @@ def impad_to_multiple(img, divisor, pad_val=0):
 
 def imnormalize(img, mean, std, to_rgb=True):
     """float32 `(img[..., ::-1 if to_rgb] - mean) * (1 / std)`; the reciprocal is formed in double as in the reference."""
+    mean32 = np.ascontiguousarray(np.asarray(mean, dtype=np.float64).reshape(-1).astype(np.float32))
+    inv32 = np.ascontiguousarray((1.0 / np.asarray(std, dtype=np.float64).reshape(-1)).astype(np.float32))
+    L = _native()
+    if L is not None and img.ndim == 3 and img.dtype in (np.uint8, np.float32) and img.shape[2] == mean32.size:
+        src = np.ascontiguousarray(img)
+        dst = np.empty(img.shape, dtype=np.float32)
+        f32p = C.POINTER(C.c_float)
+        args = (img.shape[0] * img.shape[1], img.shape[2], mean32.ctypes.data_as(f32p), inv32.ctypes.data_as(f32p),
+                int(bool(to_rgb)), dst.ctypes.data_as(f32p))
+        if img.dtype == np.uint8:
+            L.lsn_image_normalize_u8(src.ctypes.data_as(C.POINTER(C.c_uint8)), *args)
+        else:
+            L.lsn_image_normalize_f32(src.ctypes.data_as(f32p), *args)
+        return dst
     out = img.astype(np.float32)
     if to_rgb:
         out = out[..., ::-1]
-    mean32 = np.asarray(mean, dtype=np.float64).reshape(1, -1).astype(np.float32)
-    inv32 = (1.0 / np.asarray(std, dtype=np.float64).reshape(1, -1)).astype(np.float32)
-    return np.ascontiguousarray((out - mean32) * inv32)
+    return np.ascontiguousarray((out - mean32.reshape(1, -1)) * inv32.reshape(1, -1))
 
 
 def imfrombytes(content, flag='color'):

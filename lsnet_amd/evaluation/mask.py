@@ -16,7 +16,8 @@ _u32p, _f64p, _szp, _u8p = C.POINTER(C.c_uint32), C.POINTER(C.c_double), C.POINT
 
 EXPORTS = ('lsn_rle_from_polygon', 'lsn_rle_from_bbox', 'lsn_rle_merge', 'lsn_rle_area', 'lsn_rle_to_bbox',
            'lsn_rle_iou', 'lsn_bbox_iou', 'lsn_rle_encode', 'lsn_rle_decode', 'lsn_rle_to_string', 'lsn_rle_from_string',
-           'lsn_coco_match')
+           'lsn_coco_match', 'lsn_image_resize_bilinear_u8', 'lsn_image_resize_bilinear_f32', 'lsn_image_normalize_u8',
+           'lsn_image_normalize_f32')
 
 
 def lib():
@@ -50,6 +51,15 @@ def lib():
         L.lsn_coco_match.restype = None
         L.lsn_coco_match.argtypes = [_f64p, C.c_size_t, C.c_size_t, _u8p, _u8p, _f64p, C.c_size_t, C.POINTER(C.c_int64),
                                      C.POINTER(C.c_int64)]
+        f32p = C.POINTER(C.c_float)
+        L.lsn_image_resize_bilinear_u8.restype = C.c_int
+        L.lsn_image_resize_bilinear_u8.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int, C.c_int]
+        L.lsn_image_resize_bilinear_f32.restype = C.c_int
+        L.lsn_image_resize_bilinear_f32.argtypes = [f32p, C.c_int, C.c_int, C.c_int, f32p, C.c_int, C.c_int]
+        L.lsn_image_normalize_u8.restype = None
+        L.lsn_image_normalize_u8.argtypes = [_u8p, C.c_size_t, C.c_int, f32p, f32p, C.c_int, f32p]
+        L.lsn_image_normalize_f32.restype = None
+        L.lsn_image_normalize_f32.argtypes = [f32p, C.c_size_t, C.c_int, f32p, f32p, C.c_int, f32p]
         _lib = L
     return _lib
 

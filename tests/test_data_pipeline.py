@@ -408,3 +408,31 @@ def test_datasets_equal_reference_datasets(test_mode):
                 else:
                     assert a[k] == b[k], (idx, k)
             assert ours.get_cat_ids(idx) == ref.get_cat_ids(idx)
+
+
+def test_native_image_ops_equal_numpy_formulation(monkeypatch):
+    """liblsnet_host.so (csrc/host/image.cpp) and the numpy statement of the same arithmetic in data/geometry.py return
+    identical arrays: 8-bit fixed-point and float32 bilinear resize, normalisation with / without channel reversal."""
+    rng = np.random.RandomState(0)
+    cases = []
+    for i in range(30):
+        sh, sw, dh, dw = int(rng.randint(2, 90)), int(rng.randint(2, 90)), int(rng.randint(1, 200)), int(rng.randint(1, 200))
+        img = rng.randint(0, 256, (sh, sw) + [(), (1,), (3,), (4,)][i % 4]).astype(np.uint8)
+        cases.append((img, (dw, dh)))
+    cases.append((rng.randint(0, 256, (480, 640, 3)).astype(np.uint8), (1067, 800)))
+    native = [(G.imresize(im, sz), G.imresize(im.astype(np.float32), sz)) for im, sz in cases]
+    mean, std = np.array(NORM['mean'], np.float32), np.array(NORM['std'], np.float32)
+    big = cases[-1][0]
+    native_norm = [G.imnormalize(big, mean, std, True), G.imnormalize(big, mean, std, False),
+                   G.imnormalize(big.astype(np.float32), mean, std, True)]
+    assert G._native() is not None, 'liblsnet_host.so did not load'
+    monkeypatch.setenv('LSNET_NUMPY_IMAGE', '1')
+    assert G._native() is None
+    for (im, sz), (a, af) in zip(cases, native):
+        b, bf = G.imresize(im, sz), G.imresize(im.astype(np.float32), sz)
+        assert a.dtype == b.dtype == np.uint8 and a.shape == b.shape and np.array_equal(a, b), (im.shape, sz)
+        assert af.dtype == bf.dtype == np.float32 and np.array_equal(af, bf), (im.shape, sz)
+    ref_norm = [G.imnormalize(big, mean, std, True), G.imnormalize(big, mean, std, False),
+                G.imnormalize(big.astype(np.float32), mean, std, True)]
+    for a, b in zip(native_norm, ref_norm):
+        assert a.dtype == b.dtype and a.flags['C_CONTIGUOUS'] and np.array_equal(a, b)
