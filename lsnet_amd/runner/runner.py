@@ -10,8 +10,7 @@ import torch.distributed as dist
 
 from ..parallel.data_container import DataContainer, scatter
 from .checkpoint import load_checkpoint, save_checkpoint
-from .hooks import (CheckpointHook, Hook, IterTimerHook, OptimizerHook, StepLrUpdaterHook, TextLoggerHook,
-                    build_hook)
+from .hooks import CheckpointHook, Hook, IterTimerHook, OptimizerHook, StepLrUpdaterHook, build_hook
 
 
 def build_optimizer(model, cfg):

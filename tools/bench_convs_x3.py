@@ -1,5 +1,5 @@
 """Own split-bf16 conv kernels vs MIOpen on the ResNet-50 / FPN / head shapes: accuracy and time."""
-import sys, os, time
+import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import torch.nn.functional as F

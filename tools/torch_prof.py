@@ -5,7 +5,6 @@ import torch
 from torch.profiler import profile, ProfilerActivity
 from lsnet_amd.data import synthetic_batch
 from lsnet_amd.model_zoo import build_lsnet
-from lsnet_amd.runner import EpochBasedRunner, build_optimizer
 sys.argv = sys.argv[:1]
 import bench
 
