@@ -1,19 +1,12 @@
 """LSCPVHead on the MI355X against the reference fixture (head_cpv.npz): the `feat_channels + 6`-channel pyramid
 gathers, corner pooling, corner verification at decode.  (File name sorts last: this widening row runs after every
-hot-path test.)
-
-Written after round 1's GPU budget was spent, so it has not run on the device yet: opt-in with LSNET_CPV_GPU_TEST=1
-until it has (the CPU case, tests/test_golden_host.py, runs always)."""
-import os
-
+hot-path test.)"""
 import pytest
 import torch
 
 from tests import golden_cases as gc
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get('LSNET_CPV_GPU_TEST') != '1', reason='not yet verified on the device: '
-                                 'set LSNET_CPV_GPU_TEST=1')]
+pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize('channels_last', [False, True], ids=['nchw', 'nhwc'])
