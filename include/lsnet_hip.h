@@ -303,6 +303,20 @@ int lsn_prof_read(lsn_prof_entry *out, int max_entries);
 int lsn_selftest_mfma(const float *A, const float *B, float *D, int M, int N, int K, int variant,
                       lsn_stream_t stream);
 
+/* ---- input preparation (csrc/image.hip) --------------------------------------------------------------------
+ * The reference prepares images on the CPU: Resize / RandomFlip / Normalize / Pad of
+ * mmdet/datasets/pipelines/transforms.py:184-207, 409-432, 484-495, 550-565 and the zero-padding of
+ * mmcv/parallel/collate.py:34-64.  One launch does the same for one uploaded 8-bit image:
+ *   src   device pointer, h x w x c interleaved uint8 as decoded (c <= 4);
+ *   dh,dw size after the resize (cv2.INTER_LINEAR rule, bit-identical to the host implementation);
+ *   flip  mirror the RESIZED image horizontally / vertically;  reverse_channels: BGR -> RGB;
+ *   mean, inv_std  host pointers, c floats each, in OUTPUT channel order;
+ *   dst   device pointer to this image's slot: out_h x out_w x c float32 (channels-last), everything outside
+ *         dh x dw is set to pad_val. */
+int lsn_image_prep_u8(const uint8_t *src, int sh, int sw, int c, int dh, int dw, int flip_h, int flip_v,
+                      const float *mean, const float *inv_std, int reverse_channels, float pad_val, float *dst,
+                      int out_h, int out_w, lsn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -53,8 +53,10 @@ class Compose:
 class LoadImageFromFile:
     """loading.py:12-77."""
 
-    def __init__(self, to_float32=False, color_type='color', file_client_args=None):
-        self.to_float32, self.color_type = to_float32, color_type
+    def __init__(self, to_float32=False, color_type='color', file_client_args=None, defer_to_device=False):
+        """`defer_to_device`: keep the decoded 8-bit image untouched through Resize / RandomFlip / Normalize / Pad (they
+        only record what they would do) and let `data.device_prep.prepare_batch` make the network input on the device."""
+        self.to_float32, self.color_type, self.defer_to_device = to_float32, color_type, defer_to_device
         if file_client_args not in (None, dict(backend='disk')):
             raise ValueError('only the disk backend exists here')
 
@@ -66,6 +68,9 @@ class LoadImageFromFile:
             img = img.astype(np.float32)
         results.update(filename=filename, ori_filename=name, img=img, img_shape=img.shape, ori_shape=img.shape,
                        img_fields=['img'])
+        if self.defer_to_device:
+            assert img.dtype == np.uint8 and img.ndim == 3
+            results['img_deferred'] = True
         return results
 
     def __repr__(self):
@@ -178,6 +183,14 @@ class Resize:
             assert 'scale_factor' not in results, 'scale and scale_factor cannot be both set.'
         for key in results.get('img_fields', ['img']):
             h, w = results[key].shape[:2]
+            if results.get('img_deferred'):                    # sizes only; the pixels are resized on the device
+                new_w, new_h = G.rescale_size((w, h), results['scale']) if self.keep_ratio else results['scale']
+                shape = (int(new_h), int(new_w)) + tuple(results[key].shape[2:])
+                w_scale, h_scale = new_w / w, new_h / h
+                results['img_shape'] = results['pad_shape'] = shape
+                results['scale_factor'] = np.array([w_scale, h_scale, w_scale, h_scale], dtype=np.float32)
+                results['keep_ratio'] = self.keep_ratio
+                continue
             if self.keep_ratio:
                 img = G.imrescale(results[key], results['scale'])
                 w_scale, h_scale = img.shape[1] / w, img.shape[0] / h
@@ -285,7 +298,8 @@ class RandomFlip:
         if results['flip']:
             d, shape = results['flip_direction'], results['img_shape']
             for key in results.get('img_fields', ['img']):
-                results[key] = G.imflip(results[key], d)
+                if not results.get('img_deferred'):
+                    results[key] = G.imflip(results[key], d)
             for key in results.get('bbox_fields', []):
                 results[key] = self.bbox_flip(results[key], shape, d)
             for key in results.get('extreme_fields', []):
@@ -310,7 +324,8 @@ class Normalize:
 
     def __call__(self, results):
         for key in results.get('img_fields', ['img']):
-            results[key] = G.imnormalize(results[key], self.mean, self.std, self.to_rgb)
+            if not results.get('img_deferred'):
+                results[key] = G.imnormalize(results[key], self.mean, self.std, self.to_rgb)
         results['img_norm_cfg'] = dict(mean=self.mean, std=self.std, to_rgb=self.to_rgb)
         return results
 
@@ -327,11 +342,20 @@ class Pad:
         self.size, self.size_divisor, self.pad_val = size, size_divisor, pad_val
 
     def __call__(self, results):
-        for key in results.get('img_fields', ['img']):
-            padded = (G.impad(results[key], self.size, self.pad_val) if self.size is not None
-                      else G.impad_to_multiple(results[key], self.size_divisor, self.pad_val))
-            results[key] = padded
-        results['pad_shape'] = padded.shape
+        if results.get('img_deferred'):
+            assert self.pad_val == 0, 'the device path pads with zeros'
+            h, w = results['img_shape'][:2]
+            if self.size is not None:
+                ph, pw = self.size
+            else:
+                ph, pw = (int(np.ceil(v / self.size_divisor)) * self.size_divisor for v in (h, w))
+            results['pad_shape'] = (ph, pw) + tuple(results['img_shape'][2:])
+        else:
+            for key in results.get('img_fields', ['img']):
+                padded = (G.impad(results[key], self.size, self.pad_val) if self.size is not None
+                          else G.impad_to_multiple(results[key], self.size_divisor, self.pad_val))
+                results[key] = padded
+            results['pad_shape'] = padded.shape
         results['pad_fixed_size'], results['pad_size_divisor'] = self.size, self.size_divisor
         for key in results.get('mask_fields', []):
             results[key] = results[key].pad(results['pad_shape'][:2], pad_val=self.pad_val)
@@ -408,7 +432,10 @@ class DefaultFormatBundle:
             nch = 1 if img.ndim < 3 else img.shape[2]
             results.setdefault('img_norm_cfg', dict(mean=np.zeros(nch, dtype=np.float32),
                                                     std=np.ones(nch, dtype=np.float32), to_rgb=False))
-            results['img'] = DC(to_tensor(_chw(img)), stack=True)
+            if results.get('img_deferred'):        # decoded HxWxC bytes; batched and prepared by prepare_batch
+                results['img'] = DC(to_tensor(np.ascontiguousarray(img)), stack=False)
+            else:
+                results['img'] = DC(to_tensor(_chw(img)), stack=True)
         for key in self.TENSOR_KEYS:
             if key in results:
                 results[key] = DC(to_tensor(results[key]))

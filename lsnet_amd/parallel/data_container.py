@@ -108,7 +108,17 @@ def scatter(data, device=None, group=0, channels_last=False):
     if isinstance(data, torch.Tensor):
         return _to_device(data, device, channels_last)
     if isinstance(data, Mapping):
-        return {k: scatter(v, device, group, channels_last) for k, v in data.items()}
+        out = {k: scatter(v, device, group, channels_last) for k, v in data.items() if k != 'img'}
+        if 'img' in data:
+            img = data['img']
+            deferred = (isinstance(img, DataContainer) and not img.stack and not img.cpu_only and len(img.data[group])
+                        and isinstance(img.data[group][0], torch.Tensor) and img.data[group][0].dtype == torch.uint8)
+            if deferred:      # decoded 8-bit images + recorded plans -> the float batch, made on the target device
+                from ..data.device_prep import prepare_batch
+                out['img'] = prepare_batch(img.data[group], out['img_metas'], device)
+            else:
+                out['img'] = scatter(img, device, group, channels_last)
+        return out
     if isinstance(data, (list, tuple)) and not isinstance(data, (str, bytes)):
         return type(data)(scatter(v, device, group, channels_last) for v in data)
     return data

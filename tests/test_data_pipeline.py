@@ -436,3 +436,33 @@ def test_native_image_ops_equal_numpy_formulation(monkeypatch):
                 G.imnormalize(big.astype(np.float32), mean, std, True)]
     for a, b in zip(native_norm, ref_norm):
         assert a.dtype == b.dtype and a.flags['C_CONTIGUOUS'] and np.array_equal(a, b)
+
+
+def test_deferred_pipeline_equals_eager_pipeline(tmp_path):
+    """`LoadImageFromFile(defer_to_device=True)`: the stages only record what they would do to the pixels; `scatter`
+    then builds the batch (host library on a CPU target) -- same tensors, same ground truth, same meta data as the eager
+    pipeline, flips and batch padding included."""
+    ann = _write_images(str(tmp_path))
+    cls, load_kw, keys = TASKS['segm']
+
+    def make(defer):
+        return build_dataset(dict(type='CocoDataset', ann_file=ann, img_prefix=str(tmp_path), pipeline=[
+            dict(type='LoadImageFromFile', defer_to_device=defer)] + _pipeline(load_kw, keys, scale=(333, 200))))
+    eager, deferred = make(False), make(True)
+    flips = set()
+    for seed in (0, 1, 2):
+        runs = []
+        for ds in (eager, deferred):
+            np.random.seed(seed)
+            runs.append([scatter(b, 'cpu') for b in build_dataloader(ds, 2, 0, dist=False, shuffle=True, seed=seed)])
+        assert len(runs[0]) == len(runs[1]) == 2
+        for x, y in zip(*runs):
+            assert x['img'].dtype == y['img'].dtype == torch.float32 and torch.equal(x['img'], y['img'])
+            assert all(torch.equal(p, q) for p, q in zip(x['gt_bboxes'], y['gt_bboxes']))
+            for m, n in zip(x['img_metas'], y['img_metas']):
+                assert m['flip'] == n['flip'] and tuple(m['img_shape']) == tuple(n['img_shape'])
+                assert tuple(m['pad_shape']) == tuple(n['pad_shape']) and np.array_equal(m['scale_factor'], n['scale_factor'])
+                flips.add(m['flip'])
+            for p, q in zip(x['gt_masks'], y['gt_masks']):
+                assert all(np.array_equal(a, b) for oa, ob in zip(p.masks, q.masks) for a, b in zip(oa, ob))
+    assert flips == {False, True}
