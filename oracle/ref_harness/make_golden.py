@@ -184,6 +184,58 @@ def golden_coco_eval():
     _save('coco_eval', data)
 
 
+CURVE_ITERS, CURVE_HW = 12, (288, 352)
+
+
+def curve_cfg():
+    """Model / schedule of the training-curve fixture: configs/lsnet/lsnet_bbox_r50_fpn_1x_coco.py with the warm-up
+    shortened to 6 iterations so that 12 iterations reach the full learning rate."""
+    from lsnet_amd.model_zoo import lsnet_config
+    cfg = lsnet_config('bbox', 'r50')
+    cfg.lr_config = dict(policy='step', warmup='linear', warmup_iters=6, warmup_ratio=0.001, step=[8, 11])
+    return cfg
+
+
+def golden_train_curve():
+    """(8d) loss parity over an SGD run: the REFERENCE's detector, losses, optimizer hook (grad clip 35), SGD and
+    step-LR warm-up hooks (mmcv runner, mmcv/runner/hooks/{optimizer,lr_updater}.py) for 12 iterations on one
+    seeded synthetic batch per iteration, native ops backed by the CPU oracle.  Stores the loss curves, the learning
+    rates and fingerprints of two weights after the run."""
+    import logging
+
+    import mmcv
+    from mmcv.runner import EpochBasedRunner
+    from mmdet.models import build_detector
+    from lsnet_amd.data import synthetic_batch
+    cfg = curve_cfg()
+    model_cfg = mmcv.Config(copy.deepcopy(cfg.model.to_dict() if hasattr(cfg.model, 'to_dict') else dict(cfg.model)))._cfg_dict
+    model = build_detector(model_cfg, train_cfg=mmcv.Config(dict(cfg.train_cfg)), test_cfg=mmcv.Config(dict(cfg.test_cfg)))
+    gu.fill_params(model, seed=11)
+    model.train()
+    opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=0.0001)
+    logger = logging.getLogger('curve')
+    logger.setLevel(logging.ERROR)
+    runner = EpochBasedRunner(model, optimizer=opt, work_dir=None, logger=logger)
+    runner.register_training_hooks(dict(cfg.lr_config), dict(cfg.optimizer_config), None, dict(interval=10 ** 9, hooks=[]))
+    batches = [synthetic_batch('bbox', 1, *CURVE_HW, boxes_per_img=3, num_classes=80, seed=900 + i, device='cpu',
+                               channels_last=False) for i in range(CURVE_ITERS)]
+    curves = {k: [] for k in ('loss', 'loss_cls', 'loss_bbox_init', 'loss_bbox_refine', 'lr')}
+
+    class Tap(mmcv.runner.Hook):
+        def after_train_iter(self, r):
+            for k in curves:
+                if k != 'lr':
+                    curves[k].append(float(r.outputs['log_vars'][k]))
+            curves['lr'].append(float(r.current_lr()[0]))
+    runner.register_hook(Tap(), priority='VERY_LOW')
+    runner.run([batches], [('train', 1)], 1)
+    data = {f'curve/{k}': np.array(v, dtype=np.float64) for k, v in curves.items()}
+    sd = model.state_dict()
+    for name in ('bbox_head.pts_cls_out.weight', 'backbone.layer4.0.conv1.weight', 'neck.fpn_convs.0.conv.weight'):
+        gu.pack(f'weight/{name}', sd[name], data, stride=211)
+    _save('train_curve', data)
+
+
 def golden_assign():
     """(6) CentroidAssigner + ATSSAssigner gt indices on the 800x800 grid (13 343 points)."""
     from mmdet.core import build_assigner
@@ -539,7 +591,7 @@ def golden_data_pipeline():
     _save('data_pipeline', data)
 
 
-ALL = dict(coco_eval=golden_coco_eval, head_cpv=golden_head_cpv, data_pipeline=golden_data_pipeline, gt_formats=golden_gt_formats, res2net=golden_res2net, vote=golden_vote, head_bbox=lambda: golden_head('bbox'), head_segm=lambda: golden_head('segm'),
+ALL = dict(train_curve=golden_train_curve, coco_eval=golden_coco_eval, head_cpv=golden_head_cpv, data_pipeline=golden_data_pipeline, gt_formats=golden_gt_formats, res2net=golden_res2net, vote=golden_vote, head_bbox=lambda: golden_head('bbox'), head_segm=lambda: golden_head('segm'),
            head_pose_bbox=lambda: golden_head('pose_bbox'), head_pose_kbox=lambda: golden_head('pose_kbox'),
            assign=golden_assign, cross_iou=golden_cross_iou, backbone=golden_backbone, nms=golden_nms)
 

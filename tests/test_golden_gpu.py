@@ -40,3 +40,18 @@ def test_res2net_dcn_backbone(channels_last):
 
 def test_multiclass_nms_lsvr():
     gc.nms_lsvr_case(_dev())
+
+
+@pytest.mark.parametrize('math', ['bf16x3', 'fp32'])
+def test_training_curve_follows_reference_runner(math):
+    """12 SGD iterations on the device against the curve of the reference's detector + mmcv runner on CPU
+    (SURVEY.md 8d).  Measured on the MI355X (profiles/r1y_train_curve_gpu.log): <= 1.5e-4 relative over the first six
+    iterations, <= 1e-2 afterwards, in both arithmetic modes."""
+    from lsnet_amd import _lib
+    before = _lib.get_math_mode()
+    _lib.set_math_mode(math)
+    try:
+        worst = gc.train_curve_case(_dev(), early_tol=2e-3, late_tol=0.15, rtol_weight=5e-2, channels_last=True)
+    finally:
+        _lib.set_math_mode(before)
+    print(math, f'worst relative loss deviation {worst:.2e}')

@@ -36,3 +36,9 @@ def test_multiclass_nms_lsvr(cpu_oracle_backend):
 
 def test_cpv_head_forward_loss_backward_decode(cpu_oracle_backend):
     gc.cpv_head_case(CPU)
+
+
+def test_training_curve_follows_reference_runner(cpu_oracle_backend):
+    torch.set_num_threads(8)
+    worst = gc.train_curve_case(CPU, early_tol=1e-4, late_tol=0.15, rtol_weight=5e-2)
+    print(f'worst relative loss deviation over 12 iterations: {worst:.2e}')
