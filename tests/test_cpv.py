@@ -180,3 +180,43 @@ def test_cpv_detector_trains_and_tests_from_coco_files(tmp_path, cpu_oracle_back
     assert (allb[:, :4] >= -1e-3).all() and (allb[:, [0, 2]] <= w + 1e-3).all() and (allb[:, [1, 3]] <= h + 1e-3).all()
     assert json.dumps([len(r) for r in voted])
     assert scatter is not None
+
+
+@pytest.mark.skipif(not HAVE_REF, reason='the reference tree is not on this machine')
+@pytest.mark.parametrize('kind', ['bbox', 'cpv'])
+def test_image_without_ground_truth_equals_reference(kind, cpu_oracle_backend):
+    """Edge case of the target builders: one image of the batch has no objects.  Both heads against the reference's,
+    run live in the harness on the same weights and inputs."""
+    import copy
+
+    import mmcv
+    _ref()
+    from mmdet.models import build_head as ref_build
+    from lsnet_amd.models import build_head
+    from lsnet_amd.utils import ConfigDict
+    cfg, tr, te = gu.cpv_head_cfg() if kind == 'cpv' else gu.head_cfg('bbox')
+    rc = mmcv.Config(copy.deepcopy(cfg))._cfg_dict
+    rc.update(train_cfg=mmcv.Config(tr), test_cfg=mmcv.Config(te))
+    mc = ConfigDict(copy.deepcopy(cfg))
+    mc.update(train_cfg=ConfigDict(tr), test_cfg=ConfigDict(te))
+    heads = [gu.fill_params(ref_build(rc), seed=7).train(), gu.fill_params(build_head(mc), seed=7).train()]
+    h, w = gu.HEAD_IMG
+    b0, l0, e0 = gu.make_gt(100, 4, h, w, num_classes=8)
+    boxes, labels, ext = [b0, b0[:0]], [l0, l0[:0]], [e0, e0[:0]]
+    metas = [dict(pad_shape=(h, w, 3), img_shape=(h, w, 3), scale_factor=1.0) for _ in range(2)]
+    sem, wts = gu.make_sem_maps(boxes, labels, h, w, 8)
+    got = []
+    for i, head in enumerate(heads):
+        outs = head([f.clone() for f in gu.head_inputs(11)])
+        if kind == 'cpv':
+            losses = head.loss(*outs, boxes, ext, sem, wts, labels, metas)
+        elif i == 0:
+            losses = head.loss(*outs, gt_bboxes=boxes, gt_extremes=ext, gt_keypoints_vs=None, gt_masks=None,
+                               gt_labels=labels, img_metas=metas)
+        else:
+            losses = head.loss(*outs, boxes, ext, None, None, labels, metas)
+        got.append({k: np.array([float(x) for x in (v if isinstance(v, (list, tuple)) else [v])]) for k, v in losses.items()})
+    assert sorted(got[0]) == sorted(got[1])
+    for k in got[0]:
+        assert np.allclose(got[0][k], got[1][k], rtol=1e-4, atol=1e-6), (k, got[0][k], got[1][k])
+        assert np.isfinite(got[1][k]).all()
