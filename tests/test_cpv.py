@@ -188,9 +188,8 @@ def test_image_without_ground_truth_equals_reference(kind, cpu_oracle_backend):
     """Edge case of the target builders: one image of the batch has no objects.  Both heads against the reference's,
     run live in the harness on the same weights and inputs."""
     import copy
-
-    import mmcv
     _ref()
+    import mmcv
     from mmdet.models import build_head as ref_build
     from lsnet_amd.models import build_head
     from lsnet_amd.utils import ConfigDict
