@@ -183,10 +183,12 @@ def test_cpv_detector_trains_and_tests_from_coco_files(tmp_path, cpu_oracle_back
 
 
 @pytest.mark.skipif(not HAVE_REF, reason='the reference tree is not on this machine')
+@pytest.mark.parametrize('case', ['empty', 'ragged'])
 @pytest.mark.parametrize('kind', ['bbox', 'cpv'])
-def test_image_without_ground_truth_equals_reference(kind, cpu_oracle_backend):
-    """Edge case of the target builders: one image of the batch has no objects.  Both heads against the reference's,
-    run live in the harness on the same weights and inputs."""
+def test_target_edge_cases_equal_reference(kind, case, cpu_oracle_backend):
+    """Edge cases of the target builders: one image of the batch has no objects ('empty'); one image is smaller than
+    the padded batch, so part of every level's grid lies outside it and is masked out ('ragged').  Both heads against
+    the reference's, run live in the harness on the same weights and inputs."""
     import copy
     _ref()
     import mmcv
@@ -201,8 +203,15 @@ def test_image_without_ground_truth_equals_reference(kind, cpu_oracle_backend):
     heads = [gu.fill_params(ref_build(rc), seed=7).train(), gu.fill_params(build_head(mc), seed=7).train()]
     h, w = gu.HEAD_IMG
     b0, l0, e0 = gu.make_gt(100, 4, h, w, num_classes=8)
-    boxes, labels, ext = [b0, b0[:0]], [l0, l0[:0]], [e0, e0[:0]]
-    metas = [dict(pad_shape=(h, w, 3), img_shape=(h, w, 3), scale_factor=1.0) for _ in range(2)]
+    if case == 'empty':
+        boxes, labels, ext = [b0, b0[:0]], [l0, l0[:0]], [e0, e0[:0]]
+        small = (h, w)
+    else:
+        small = (384, 400)                                 # >= 9 cells on the coarsest level, as ATSS needs
+        b1, l1, e1 = gu.make_gt(101, 3, *small, num_classes=8)
+        boxes, labels, ext = [b0, b1], [l0, l1], [e0, e1]
+    metas = [dict(pad_shape=(h, w, 3), img_shape=(h, w, 3), scale_factor=1.0),
+             dict(pad_shape=small + (3,), img_shape=small + (3,), scale_factor=1.0)]
     sem, wts = gu.make_sem_maps(boxes, labels, h, w, 8)
     got = []
     for i, head in enumerate(heads):
