@@ -71,3 +71,46 @@ def test_image_without_instances_raises_as_reference(task, cpu_oracle_backend):
     ref, ours = _run(task, _heads(task), [b0, b0[:0]], [l0, l0[:0]], [e0, e0[:0]], metas)
     assert isinstance(ref, Exception) and isinstance(ours, Exception), (ref, ours)
     assert type(ref) is type(ours) and str(ref)[:40] == str(ours)[:40]
+
+
+@pytest.mark.parametrize('task', ['bbox', 'segm', 'pose_bbox', 'pose_kbox'])
+def test_decode_with_rescale_equals_reference(task, cpu_oracle_backend):
+    """`get_bboxes(rescale=True)` with a per-axis scale factor and an image smaller than its padded shape: boxes and
+    landmark vectors are clamped to the image and mapped back to the original scale as the reference does."""
+    h, w = gu.HEAD_IMG
+    ref, ours = _heads(task)
+    ref.eval(), ours.eval()
+    sf = np.array([1.25, 1.3, 1.25, 1.3], dtype=np.float32)
+    metas = [dict(pad_shape=(h, w, 3), img_shape=(h - 20, w - 30, 3), scale_factor=sf),
+             dict(pad_shape=(h, w, 3), img_shape=(h, w, 3), scale_factor=sf)]
+    with torch.no_grad():
+        a = ref.get_bboxes(*ref(gu.head_inputs(11)), metas, rescale=True)
+        b = ours.get_bboxes(*ours(gu.head_inputs(11)), metas, rescale=True)
+    for (ab, av, al), (bb, bv, bl) in zip(a, b):
+        assert len(ab) > 10 and torch.equal(al, bl)
+        assert torch.allclose(ab, bb, rtol=1e-4, atol=1e-3) and torch.allclose(av, bv, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize('name', ['r101', 'x101-dcn'])
+def test_other_backbones_equal_reference(name, cpu_oracle_backend):
+    """ResNet-101 and ResNeXt-101-64x4d with DCNv2 in c3-c5 (the backbones of the other BASELINE configurations): same
+    state-dict keys, same features on the same weights."""
+    os.environ['PYTHONDONTWRITEBYTECODE'] = '1'
+    from oracle.ref_harness import bootstrap
+    bootstrap.load_reference()
+    import mmcv
+    from mmdet.models import build_backbone as ref_build
+    from lsnet_amd.model_zoo import backbone_cfg
+    from lsnet_amd.models import build_backbone
+    cfg = backbone_cfg(name)
+    cfg.pop('with_cp', None)
+    ref = ref_build(mmcv.Config(copy.deepcopy(cfg))._cfg_dict)
+    ours = build_backbone(copy.deepcopy(cfg))
+    assert sorted(ref.state_dict()) == sorted(ours.state_dict())
+    gu.fill_params(ref, seed=3).train(), gu.fill_params(ours, seed=3).train()
+    x = torch.randn(1, 3, 96, 96, generator=gu.gen(5))
+    with torch.no_grad():
+        fa, fb = ref(x), ours(x)
+    assert [tuple(t.shape) for t in fa] == [tuple(t.shape) for t in fb]
+    for p, q in zip(fa, fb):
+        assert float((p - q).abs().max()) <= 1e-5 * float(p.abs().max())
