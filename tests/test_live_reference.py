@@ -160,3 +160,33 @@ def test_whole_detector_from_reference_config_equals_reference(fname, task, cpu_
         for ca, cb in zip(pa, pb):
             assert ca.shape == cb.shape and np.allclose(ca, cb, rtol=1e-4, atol=1e-3)
     assert sum(len(c) for c in ra[0]) > 0
+
+
+def test_assigner_variants_equal_reference():
+    """CentroidAssigner with `iou_type='centroid'` (the extreme-point quadrilateral's centroid) and several positives
+    per object, ATSS with other top-k values: gt indices identical to the reference's classes."""
+    os.environ['PYTHONDONTWRITEBYTECODE'] = '1'
+    from oracle.ref_harness import bootstrap
+    bootstrap.load_reference()
+    from mmdet.core.bbox.assigners import ATSSAssigner as RefATSS
+    from mmdet.core.bbox.assigners import CentroidAssigner as RefCentroid
+    from lsnet_amd.core import ATSSAssigner, CentroidAssigner, PointGenerator
+    h, w = 384, 512
+    sizes = [(-(-h // s), -(-w // s)) for s in (8, 16, 32, 64, 128)]
+    pts = torch.cat([PointGenerator().grid_points(sz, s, 'cpu') for sz, s in zip(sizes, (8, 16, 32, 64, 128))])
+    num_level = [a * b for a, b in sizes]
+    for seed, n in ((1, 3), (2, 11), (3, 25)):
+        boxes, labels, ext = gu.make_gt(seed, n, h, w, num_classes=8)
+        for iou_type in ('center', 'centroid'):
+            for pos_num in (1, 3):
+                a = RefCentroid(scale=4, pos_num=pos_num, iou_type=iou_type).assign(pts, boxes, ext, None, labels)
+                b = CentroidAssigner(scale=4, pos_num=pos_num, iou_type=iou_type).assign(pts, boxes, ext, None, labels)
+                assert torch.equal(a.gt_inds, b.gt_inds) and torch.equal(a.labels, b.labels), (seed, iou_type, pos_num)
+        g = gu.gen(seed)
+        centre = pts[:, :2].repeat(1, 2)
+        cand = centre + torch.cat([-torch.rand(len(pts), 2, generator=g), torch.rand(len(pts), 2, generator=g)], 1) * pts[:, 2:3] * 4
+        for topk in (5, 9):
+            a = RefATSS(topk=topk).assign(cand, num_level, boxes, None, labels)
+            b = ATSSAssigner(topk=topk).assign(cand, num_level, boxes, None, labels)
+            assert torch.equal(a.gt_inds, b.gt_inds) and torch.equal(a.labels, b.labels), (seed, topk)
+            assert torch.allclose(a.max_overlaps, b.max_overlaps, atol=1e-6)
