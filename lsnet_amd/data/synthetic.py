@@ -59,8 +59,18 @@ def synthetic_batch(task='bbox', batch=2, height=800, width=1344, boxes_per_img=
         img = img.contiguous(memory_format=torch.channels_last)
     data = dict(img=img, img_metas=metas, gt_bboxes=[b.to(device) for b in gt_b],
                 gt_labels=[l.to(device) for l in gt_l])
-    if task in ('bbox', 'pose_bbox'):
+    if task in ('bbox', 'pose_bbox', 'bbox_cpv'):
         data['gt_extremes'] = [_extremes(g, b).to(device) for b in gt_b]
+    if task == 'bbox_cpv':      # stride-8 box-level class maps + 1/area weights (pipelines.LoadRPDV2Annotations)
+        sem = torch.zeros(batch, num_classes, height // 8, width // 8)
+        wts = torch.zeros_like(sem)
+        for i, (b, l) in enumerate(zip(gt_b, gt_l)):
+            area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+            for j in torch.argsort(area, descending=True).tolist():
+                x1, y1, x2, y2 = (int(v / 8) for v in b[j].tolist())
+                sem[i, l[j], y1:y2 + 1, x1:x2 + 1] = 1
+                wts[i, l[j], y1:y2 + 1, x1:x2 + 1] = 1 / float(area[j])
+        data['gt_sem_map'], data['gt_sem_weights'] = sem.to(device), wts.to(device)
     if task == 'segm':
         data['gt_masks'] = [_polygons(b) for b in gt_b]
     if 'pose' in task:

@@ -228,3 +228,11 @@ def test_target_edge_cases_equal_reference(kind, case, cpu_oracle_backend):
     for k in got[0]:
         assert np.allclose(got[0][k], got[1][k], rtol=1e-4, atol=1e-6), (k, got[0][k], got[1][k])
         assert np.isfinite(got[1][k]).all()
+
+
+def test_synthetic_cpv_batch_has_the_semantic_maps():
+    from lsnet_amd.data import synthetic_batch
+    d = synthetic_batch('bbox_cpv', 2, 288, 352, boxes_per_img=3, device='cpu', channels_last=False)
+    assert d['gt_sem_map'].shape == d['gt_sem_weights'].shape == (2, 80, 36, 44)
+    assert d['gt_sem_map'].sum() > 0 and ((d['gt_sem_weights'] > 0) == (d['gt_sem_map'] > 0)).all()
+    assert d['gt_extremes'][0].shape == (3, 10)
