@@ -190,3 +190,42 @@ def test_assigner_variants_equal_reference():
             b = ATSSAssigner(topk=topk).assign(cand, num_level, boxes, None, labels)
             assert torch.equal(a.gt_inds, b.gt_inds) and torch.equal(a.labels, b.labels), (seed, topk)
             assert torch.allclose(a.max_overlaps, b.max_overlaps, atol=1e-6)
+
+
+@pytest.mark.skipif(os.environ.get('LSNET_SLOW_TESTS') != '1', reason='2 minutes on CPU: set LSNET_SLOW_TESTS=1')
+def test_whole_cpv_detector_equals_reference(cpu_oracle_backend):
+    """LSCPVDetector with an R-50 backbone (the reference's CPV configs use X-101 / Res2Net-101: too slow for a CPU
+    check), both sides built from the same model dict: equal training losses (six terms), equal per-class test boxes."""
+    os.environ['PYTHONDONTWRITEBYTECODE'] = '1'
+    from oracle.ref_harness import bootstrap
+    bootstrap.load_reference()
+    import mmcv
+    from mmdet.models import build_detector as ref_build
+    from lsnet_amd.data import synthetic_batch
+    from lsnet_amd.model_zoo import lsnet_config
+    from lsnet_amd.models import build_detector
+    cfg = lsnet_config('bbox_cpv', 'r50')
+    rc = mmcv.Config(dict(model=copy.deepcopy(dict(cfg.model)), train_cfg=copy.deepcopy(dict(cfg.train_cfg)),
+                          test_cfg=copy.deepcopy(dict(cfg.test_cfg))))
+    ref = ref_build(rc.model, train_cfg=rc.train_cfg, test_cfg=rc.test_cfg)
+    ours = build_detector(copy.deepcopy(cfg.model), train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg)
+    assert sorted(ref.state_dict()) == sorted(ours.state_dict())
+    gu.fill_params(ref, seed=5), gu.fill_params(ours, seed=5)
+    torch.set_num_threads(8)
+    data = synthetic_batch('bbox_cpv', 1, 288, 352, boxes_per_img=3, num_classes=80, seed=77, device='cpu', channels_last=False)
+    data['img_metas'][0]['scale_factor'] = np.array([1.1, 1.2, 1.1, 1.2], dtype=np.float32)
+    ref.train(), ours.train()
+    la, lb = ref(**copy.deepcopy(data)), ours(**copy.deepcopy(data))
+
+    def vals(v):
+        return [float(x) for x in (v if isinstance(v, (list, tuple)) else [v])]
+    assert sorted(la) == sorted(lb) and len(la) == 6
+    for k in la:
+        assert np.allclose(vals(la[k]), vals(lb[k]), rtol=1e-4, atol=1e-6), k
+    ref.eval(), ours.eval()
+    with torch.no_grad():
+        ra = ref(img=[data['img']], img_metas=[data['img_metas']], return_loss=False, rescale=True)
+        rb = ours(img=[data['img']], img_metas=[data['img_metas']], return_loss=False, rescale=True)
+    assert len(ra) == len(rb) == 80 and sum(len(c) for c in ra) > 0
+    for ca, cb in zip(ra, rb):
+        assert ca.shape == cb.shape and np.allclose(ca, cb, rtol=1e-4, atol=1e-3)
