@@ -92,13 +92,33 @@ class LSDetector(SingleStageDetector):
             return out
         return dets
 
+    def aug_test_simple(self, imgs, img_metas, rescale=False):
+        """`test_cfg.method == 'simple'` (lsnet.py:27-135): every view decoded without NMS, boxes mapped back to the
+        original image, ONE multi-class NMS over all of them; like the reference this returns per-class BOXES only
+        (the landmark vectors are dropped by the merge)."""
+        from ...core import multiclass_nms
+        from .lscpv import bbox2result, bbox_mapping_back
+        head, cfg = self.bbox_head, self.test_cfg
+        boxes, scores = [], []
+        for img, meta in zip(imgs, img_metas):
+            b, _, s = head.get_bboxes(*head(self.extract_feat(img)), meta, cfg, False, False)[0]
+            m = meta[0]
+            boxes.append(bbox_mapping_back(b, m['img_shape'], m['scale_factor'], m['flip'],
+                                           m.get('flip_direction', 'horizontal')))
+            scores.append(s)
+        det_b, det_l = multiclass_nms(torch.cat(boxes), torch.cat(scores), cfg.score_thr, cfg.nms, cfg.max_per_img)
+        if not rescale:
+            det_b = det_b.clone()
+            det_b[:, :4] *= det_b.new_tensor(np.asarray(img_metas[0][0]['scale_factor'], dtype=np.float32))
+        return bbox2result(det_b, det_l, head.num_classes)
+
     def aug_test(self, imgs, img_metas, rescale=False, show=False, out_dir=False):
         """Multi-scale / flip testing by instance voting (lsnet.py:301-417, `test_cfg.method == 'vote'`): every view
         is decoded with NMS, filtered to the box sizes its scale is trusted for (`test_cfg.scale_ranges[i // 2]`, views
         come in (plain, flipped) pairs), mapped back to the original image and merged per class by `instances_vote`."""
         cfg = self.test_cfg
         if cfg.get('method', 'simple') != 'vote':
-            raise NotImplementedError("only test_cfg.method='vote' is implemented for multi-view testing")
+            return self.aug_test_simple(imgs, img_metas, rescale)
         head = self.bbox_head
         boxes, vecs, labels = [], [], []
         for i, (img, meta) in enumerate(zip(imgs, img_metas)):

@@ -68,3 +68,7 @@ def test_detector_aug_test_vote_runs(cpu_oracle_backend):
     assert len(boxes) == len(vectors) == 80
     n = sum(b.shape[0] for b in boxes)
     assert n > 0 and all(b.shape[1] == 5 for b in boxes) and all(v.shape[1] == 8 for v in vectors)
+    model.test_cfg.method = 'simple'                       # all views merged by ONE NMS: per-class boxes only
+    with torch.no_grad():
+        merged = model(imgs, metas, return_loss=False, rescale=True)
+    assert len(merged) == 80 and all(b.shape[1] == 5 for b in merged) and 0 < sum(len(b) for b in merged) <= 20
