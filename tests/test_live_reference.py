@@ -229,3 +229,35 @@ def test_whole_cpv_detector_equals_reference(cpu_oracle_backend):
     assert len(ra) == len(rb) == 80 and sum(len(c) for c in ra) > 0
     for ca, cb in zip(ra, rb):
         assert ca.shape == cb.shape and np.allclose(ca, cb, rtol=1e-4, atol=1e-3)
+
+
+def test_random_draws_of_the_pipeline_equal_reference():
+    """Multi-scale training (`Resize` with a scale range / a list of scales / a ratio range) and `RandomFlip` consume
+    `np.random` exactly as the reference's stages do: the same seed gives the same scales and flips."""
+    os.environ['PYTHONDONTWRITEBYTECODE'] = '1'
+    from oracle.ref_harness import bootstrap
+    bootstrap.load_reference()
+    from mmdet.datasets.pipelines import RandomFlip as RefFlip
+    from mmdet.datasets.pipelines import Resize as RefResize
+    from lsnet_amd.data.pipelines import RandomFlip, Resize
+    cases = [dict(img_scale=[(1333, 480), (1333, 960)], multiscale_mode='range', keep_ratio=True),
+             dict(img_scale=[(1333, 640), (1333, 800), (1000, 600)], multiscale_mode='value', keep_ratio=True),
+             dict(img_scale=(1333, 800), ratio_range=(0.8, 1.2), keep_ratio=True),
+             dict(img_scale=(1333, 800), keep_ratio=False)]
+    for kw in cases:
+        a, b = RefResize(**kw), Resize(**kw)
+        for seed in range(5):
+            ra, rb = {}, {}
+            np.random.seed(seed)
+            a._random_scale(ra)
+            np.random.seed(seed)
+            b._random_scale(rb)
+            assert ra == rb, (kw, seed, ra, rb)
+    fa, fb = RefFlip(flip_ratio=0.5), RandomFlip(flip_ratio=0.5)
+    base = dict(img=np.zeros((4, 6, 3), np.uint8), img_shape=(4, 6, 3), img_fields=['img'], bbox_fields=[], extreme_fields=[],
+                keypoint_fields=[], mask_fields=[], seg_fields=[])
+    np.random.seed(3)
+    want = [fa(dict(base))['flip'] for _ in range(20)]
+    np.random.seed(3)
+    got = [fb(dict(base))['flip'] for _ in range(20)]
+    assert want == got and True in got and False in got
