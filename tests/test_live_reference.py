@@ -359,3 +359,35 @@ def test_lr_schedule_and_focal_module_equal_reference(cpu_oracle_backend):
         assert la.shape == lb.shape and torch.allclose(la, lb, rtol=1e-5, atol=1e-7), (red, avg)
         la.sum().backward(), lb.sum().backward()
         assert torch.allclose(xa.grad, xb.grad, rtol=1e-5, atol=1e-7)
+
+
+def test_checkpoints_are_interchangeable_with_reference(tmp_path, cpu_oracle_backend):
+    """A checkpoint written by the reference's `save_checkpoint` loads into this package's model and vice versa
+    (same container keys, same state-dict keys, optimizer state included); a resumed run continues identically."""
+    os.environ['PYTHONDONTWRITEBYTECODE'] = '1'
+    from oracle.ref_harness import bootstrap
+    bootstrap.load_reference()
+    from mmcv.runner import load_checkpoint as ref_load
+    from mmcv.runner import save_checkpoint as ref_save
+    from lsnet_amd.runner import load_checkpoint, save_checkpoint
+    ref, ours = _heads('bbox')
+    gu.fill_params(ref, seed=21)
+    opt = torch.optim.SGD(ref.parameters(), lr=0.01, momentum=0.9)
+    for p in ref.parameters():
+        p.grad = torch.ones_like(p) * 1e-3
+    opt.step()
+    ref_save(ref, str(tmp_path / 'ref.pth'), optimizer=opt, meta=dict(epoch=3, iter=77))
+    ckpt = load_checkpoint(ours, str(tmp_path / 'ref.pth'), strict=True)
+    assert ckpt['meta']['epoch'] == 3 and 'optimizer' in ckpt
+    for (ka, va), (kb, vb) in zip(sorted(ref.state_dict().items()), sorted(ours.state_dict().items())):
+        assert ka == kb and torch.equal(va, vb)
+    opt2 = torch.optim.SGD(ours.parameters(), lr=0.01, momentum=0.9)
+    opt2.load_state_dict(ckpt['optimizer'])                       # parameter order is the same: momentum buffers line up
+    assert len(opt2.state) == len(opt.state)
+
+    gu.fill_params(ours, seed=22)
+    save_checkpoint(ours, str(tmp_path / 'ours.pth'), optimizer=opt2, meta=dict(epoch=5, iter=99))
+    back = ref_load(ref, str(tmp_path / 'ours.pth'), map_location='cpu', strict=True)
+    assert back['meta']['epoch'] == 5 and set(back) >= {'meta', 'state_dict', 'optimizer'}
+    for (ka, va), (kb, vb) in zip(sorted(ref.state_dict().items()), sorted(ours.state_dict().items())):
+        assert ka == kb and torch.equal(va, vb)
