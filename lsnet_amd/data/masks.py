@@ -82,6 +82,17 @@ class PolygonMasks:
             return p
         return self._map(f, np.maximum(y2 - y1, 1), np.maximum(x2 - x1, 1))
 
+    def to_ndarray(self):
+        """(N, h, w) uint8 bitmaps by COCO's rasterisation rule (structures.py:548-556: frPyObjects + merge + decode)."""
+        from ..evaluation import mask as mask_util
+        if len(self.masks) == 0:
+            return np.empty((0, self.height, self.width), dtype=np.uint8)
+        out = []
+        for obj in self.masks:
+            rles = mask_util.frPyObjects([np.asarray(p, dtype=np.float64).tolist() for p in obj], self.height, self.width)
+            out.append(mask_util.decode(mask_util.merge(rles)))
+        return np.stack(out).reshape(-1, self.height, self.width)
+
     @property
     def areas(self):
         out = []

@@ -1,0 +1,79 @@
+"""Known-answer vectors held by the reference's OWN tests for pieces of this path (data: inputs and expected outputs),
+checked against this package's implementations:
+
+  * corner pooling      -- tests/test_ops/test_corner_pool.py:21-58 of the reference;
+  * polygon masks       -- tests/test_masks.py:330-478, 531-546: rescale / resize / crop with their rasterised truth
+                           bitmaps (these pin COCO's polygon rasterisation in liblsnet_host.so independently of the
+                           reference-built maskapi.so), areas;
+  * NMS                 -- tests/test_ops/test_nms.py:18-24 lives in tests/test_oracle.py / test_ops_gpu.py."""
+import numpy as np
+import pytest
+import torch
+
+from lsnet_amd.data import PolygonMasks
+from lsnet_amd.ops.corner_pool import CornerPool
+
+
+def test_corner_pool_known_answers():
+    with pytest.raises(AssertionError):
+        CornerPool('corner')
+    lr = torch.tensor([[[[0, 0, 0, 0, 0], [2, 1, 3, 0, 2], [5, 4, 1, 1, 6], [0, 0, 0, 0, 0], [0, 0, 0, 0, 0]]]])
+    tb = torch.tensor([[[[0, 3, 1, 0, 0], [0, 1, 1, 0, 0], [0, 3, 4, 0, 0], [0, 2, 2, 0, 0], [0, 0, 2, 0, 0]]]])
+    answers = dict(
+        left=(lr, [[0, 0, 0, 0, 0], [3, 3, 3, 2, 2], [6, 6, 6, 6, 6], [0, 0, 0, 0, 0], [0, 0, 0, 0, 0]]),
+        right=(lr, [[0, 0, 0, 0, 0], [2, 2, 3, 3, 3], [5, 5, 5, 5, 6], [0, 0, 0, 0, 0], [0, 0, 0, 0, 0]]),
+        top=(tb, [[0, 3, 4, 0, 0], [0, 3, 4, 0, 0], [0, 3, 4, 0, 0], [0, 2, 2, 0, 0], [0, 0, 2, 0, 0]]),
+        bottom=(tb, [[0, 3, 1, 0, 0], [0, 3, 1, 0, 0], [0, 3, 4, 0, 0], [0, 3, 4, 0, 0], [0, 3, 4, 0, 0]]))
+    for mode, (x, want) in answers.items():
+        got = CornerPool(mode)(x)
+        assert got.type() == x.type() and torch.equal(got, torch.tensor([[want]])), mode
+
+
+PENTAGON = np.array([1, 1, 3, 1, 4, 3, 2, 4, 1, 3], dtype=np.float64)
+TRUTH_10 = np.array([[0, 0, 0, 0, 0, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 0, 0, 0, 0, 0], [0, 0, 1, 1, 1, 1, 0, 0, 0, 0],
+                     [0, 0, 1, 1, 1, 1, 1, 0, 0, 0], [0, 0, 1, 1, 1, 1, 1, 0, 0, 0], [0, 0, 1, 1, 1, 1, 1, 1, 0, 0],
+                     [0, 0, 0, 1, 1, 1, 1, 0, 0, 0], [0, 0, 0, 0, 1, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 0, 0, 0, 0, 0],
+                     [0, 0, 0, 0, 0, 0, 0, 0, 0, 0]], np.uint8)
+TRUTH_6 = np.array([[0, 1, 0, 0, 0, 0], [0, 0, 0, 0, 0, 0], [0, 0, 1, 1, 0, 0], [0, 0, 1, 1, 0, 0], [0, 0, 0, 0, 0, 0],
+                    [0, 0, 0, 0, 0, 0]], np.uint8)
+
+
+def test_polygon_mask_known_answers():
+    empty = PolygonMasks([], 28, 28)
+    r = empty.rescale((56, 72))
+    assert (len(r), r.height, r.width) == (0, 56, 56) and r.to_ndarray().shape == (0, 56, 56)
+    r = empty.resize((56, 72))
+    assert (len(r), r.height, r.width) == (0, 56, 72) and r.to_ndarray().shape == (0, 56, 72)
+    assert empty.flip('horizontal').to_ndarray().shape == (0, 28, 28)
+    c = empty.crop(np.array([0, 10, 10, 27]))
+    assert (len(c), c.height, c.width) == (0, 17, 10)
+
+    one = PolygonMasks([[PENTAGON.copy()]], 5, 5)
+    r = one.rescale((12, 10))
+    assert (len(r), r.height, r.width) == (1, 10, 10) and (r.to_ndarray() == TRUTH_10).all()
+    assert (one.resize((10, 10)).to_ndarray() == TRUTH_10).all()
+    parts = [[np.array([0., 0., 1., 0., 1., 1.]), np.array([1., 1., 2., 1., 2., 2., 1., 2.])]]
+    two = PolygonMasks(parts, 3, 3).resize((6, 6))
+    assert (two.height, two.width) == (6, 6) and (two.to_ndarray() == TRUTH_6).all()
+    both = PolygonMasks([[PENTAGON.copy()], parts[0]], 5, 5).resize((10, 10))
+    assert (both.to_ndarray() == np.stack([TRUTH_10, np.pad(TRUTH_6, ((0, 4), (0, 4)), 'constant')])).all()
+
+    crop = PolygonMasks([[np.array([1., 3., 5., 1., 5., 6., 1, 6])]], 7, 7).crop(np.array([0, 0, 3, 4]))
+    assert (crop.height, crop.width) == (4, 3)
+    assert (crop.to_ndarray() == np.array([[0, 0, 0], [0, 0, 0], [0, 0, 1], [0, 1, 1]])).all()
+    with pytest.raises(AssertionError):
+        PolygonMasks([[PENTAGON.copy()]], 5, 5).crop(np.array([[0, 0, 1, 1]]))       # a 2-D box
+
+    rng = np.random.RandomState(0)
+    three = PolygonMasks([[rng.rand(10) * 28] for _ in range(3)], 28, 28)
+    for d in ('horizontal', 'vertical'):
+        back = three.flip(d).flip(d)
+        assert (three.to_ndarray() == back.to_ndarray()).all() and three.flip(d).to_ndarray().shape == (3, 28, 28)
+    padded = three.pad((56, 56))
+    assert (padded.height, padded.width) == (56, 56) and padded.to_ndarray().shape == (3, 56, 56)
+
+    # areas: shoelace, summed over the parts of an object (test_masks.py:531-546)
+    assert PolygonMasks([], 28, 28).areas.shape == (0,)
+    square = PolygonMasks([[np.array([1., 1., 5., 1., 5., 5., 1., 5.])]], 7, 7)
+    assert square.areas[0] == 16 and square.areas.shape == (1,)
+    assert abs(square.to_ndarray().sum() - 16) <= 9          # the bitmap agrees with the polygon up to its border
