@@ -77,3 +77,31 @@ def test_polygon_mask_known_answers():
     square = PolygonMasks([[np.array([1., 1., 5., 1., 5., 5., 1., 5.])]], 7, 7)
     assert square.areas[0] == 16 and square.areas.shape == (1,)
     assert abs(square.to_ndarray().sum() - 16) <= 9          # the bitmap agrees with the polygon up to its border
+
+
+def test_dataset_wrappers_index_as_the_reference_expects():
+    """The index arithmetic the reference's tests/test_dataset.py:89-127 checks on ConcatDataset / RepeatDataset."""
+    from lsnet_amd.data import ConcatDataset, RepeatDataset
+
+    class Stub:
+        CLASSES = ('a',)
+
+        def __init__(self, n, seed):
+            rng = np.random.RandomState(seed)
+            self.cats = [rng.randint(0, 80, k).tolist() for k in rng.randint(1, 20, n)]
+
+        def __len__(self):
+            return len(self.cats)
+
+        def __getitem__(self, i):
+            return i
+
+        def get_cat_ids(self, i):
+            return self.cats[i]
+    a, b = Stub(10, 0), Stub(20, 1)
+    cat = ConcatDataset([a, b])
+    assert cat[5] == 5 and cat[25] == 15 and len(cat) == 30
+    assert cat.get_cat_ids(5) == a.cats[5] and cat.get_cat_ids(25) == b.cats[15] and cat.get_cat_ids(-1) == b.cats[19]
+    rep = RepeatDataset(a, 10)
+    assert rep[5] == 5 and rep[15] == 5 and rep[27] == 7 and len(rep) == 100
+    assert rep.get_cat_ids(15) == a.cats[5] and rep.get_cat_ids(27) == a.cats[7]
