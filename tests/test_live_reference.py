@@ -391,3 +391,77 @@ def test_checkpoints_are_interchangeable_with_reference(tmp_path, cpu_oracle_bac
     assert back['meta']['epoch'] == 5 and set(back) >= {'meta', 'state_dict', 'optimizer'}
     for (ka, va), (kb, vb) in zip(sorted(ref.state_dict().items()), sorted(ours.state_dict().items())):
         assert ka == kb and torch.equal(va, vb)
+
+
+def test_fpn_variants_equal_reference():
+    """Every FPN option the reference's tests/test_necks.py exercises (extra-level sources, no extra convs, lateral
+    norm, bilinear / scale-factor upsampling, end_level, ReLU before the extra convs): same keys, same outputs, same
+    constructor errors."""
+    os.environ['PYTHONDONTWRITEBYTECODE'] = '1'
+    from oracle.ref_harness import bootstrap
+    bootstrap.load_reference()
+    from mmdet.models.necks import FPN as Ref
+    from lsnet_amd.models.necks.fpn import FPN
+    inc, s = [8, 16, 32, 64], 64
+    feats = [torch.rand(1, inc[i], s // 2 ** i, s // 2 ** i, generator=gu.gen(i)) for i in range(4)]
+    variants = [dict(start_level=1, add_extra_convs=True, num_outs=5), dict(start_level=1, add_extra_convs=False, num_outs=5),
+                dict(start_level=1, add_extra_convs=True, norm_cfg=dict(type='BN', requires_grad=True), num_outs=5),
+                dict(start_level=1, add_extra_convs=True, upsample_cfg=dict(mode='bilinear', align_corners=True), num_outs=5),
+                dict(start_level=1, add_extra_convs=True, upsample_cfg=dict(scale_factor=2), num_outs=5),
+                dict(start_level=1, add_extra_convs='on_input', num_outs=5), dict(start_level=1, add_extra_convs='on_lateral', num_outs=5),
+                dict(start_level=1, add_extra_convs='on_output', num_outs=5),
+                dict(start_level=1, add_extra_convs=True, extra_convs_on_inputs=False, num_outs=5),
+                dict(start_level=0, end_level=3, num_outs=3),
+                dict(start_level=1, add_extra_convs='on_input', relu_before_extra_convs=True, num_outs=5),
+                dict(start_level=1, add_extra_convs='on_input', norm_cfg=dict(type='GN', num_groups=4, requires_grad=True), num_outs=5)]
+    for kw in variants:
+        r, m = Ref(in_channels=inc, out_channels=8, **copy.deepcopy(kw)), FPN(in_channels=inc, out_channels=8, **copy.deepcopy(kw))
+        assert sorted(r.state_dict()) == sorted(m.state_dict()), kw
+        assert r.add_extra_convs == m.add_extra_convs
+        gu.fill_params(r, seed=2).train(), gu.fill_params(m, seed=2).train()
+        a, b = r(feats), m(feats)
+        assert len(a) == len(b) == kw['num_outs']
+        for x, y in zip(a, b):
+            assert x.shape == y.shape and torch.allclose(x, y, rtol=1e-5, atol=1e-6), kw
+    for bad in (dict(start_level=1, num_outs=2), dict(start_level=1, end_level=4, num_outs=2),
+                dict(start_level=1, end_level=3, num_outs=1), dict(start_level=1, add_extra_convs='on_xxx', num_outs=5)):
+        for cls in (Ref, FPN):
+            with pytest.raises(AssertionError):
+                cls(in_channels=inc, out_channels=8, **bad)
+
+
+def test_backbone_variants_equal_reference(cpu_oracle_backend):
+    """ResNet-18/34/50 options of the reference's tests/test_backbone.py (caffe style, deep stem + average-pool
+    shortcuts, frozen stages, fewer stages, checkpointing, DCN v1 / v2 stages, GN), ResNeXt-50 32x4d, Res2Net-50:
+    same keys, same frozen parameters, same features."""
+    os.environ['PYTHONDONTWRITEBYTECODE'] = '1'
+    from oracle.ref_harness import bootstrap
+    bootstrap.load_reference()
+    from mmdet.models.backbones import Res2Net as R2
+    from mmdet.models.backbones import ResNet as RR
+    from mmdet.models.backbones import ResNeXt as RX
+    from lsnet_amd.models.backbones import Res2Net, ResNet, ResNeXt
+    x = torch.randn(1, 3, 64, 64, generator=gu.gen(1))
+    dcn = dict(type='DCNv2', deformable_groups=1, fallback_on_stride=False)
+    variants = [(RR, ResNet, dict(depth=18)), (RR, ResNet, dict(depth=34)), (RR, ResNet, dict(depth=50, style='caffe')),
+                (RR, ResNet, dict(depth=50, deep_stem=True, avg_down=True)),
+                (RR, ResNet, dict(depth=50, frozen_stages=2, norm_eval=True)),
+                (RR, ResNet, dict(depth=50, num_stages=3, strides=(1, 2, 2), dilations=(1, 1, 1), out_indices=(0, 1, 2))),
+                (RR, ResNet, dict(depth=50, with_cp=True)),
+                (RR, ResNet, dict(depth=50, dcn=dcn, stage_with_dcn=(False, True, True, True))),
+                (RR, ResNet, dict(depth=50, dcn=dict(type='DCN', deformable_groups=1, fallback_on_stride=False),
+                                  stage_with_dcn=(False, False, True, True))),
+                (RR, ResNet, dict(depth=50, norm_cfg=dict(type='GN', num_groups=32, requires_grad=True))),
+                (RX, ResNeXt, dict(depth=50, groups=32, base_width=4)), (R2, Res2Net, dict(depth=50, scales=4, base_width=26))]
+    for ref_cls, cls, kw in variants:
+        r, m = ref_cls(**copy.deepcopy(kw)), cls(**copy.deepcopy(kw))
+        assert sorted(r.state_dict()) == sorted(m.state_dict()), kw
+        assert [n for n, p in r.named_parameters() if not p.requires_grad] == \
+               [n for n, p in m.named_parameters() if not p.requires_grad], kw
+        gu.fill_params(r, seed=3).train(), gu.fill_params(m, seed=3).train()
+        assert {n for n, mod in r.named_modules() if not mod.training} == {n for n, mod in m.named_modules() if not mod.training}
+        with torch.no_grad():
+            a, b = r(x), m(x)
+        assert len(a) == len(b)
+        for p, q in zip(a, b):
+            assert p.shape == q.shape and torch.allclose(p, q, rtol=1e-4, atol=1e-5), kw
