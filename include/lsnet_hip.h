@@ -317,6 +317,20 @@ int lsn_image_prep_u8(const uint8_t *src, int sh, int sw, int c, int dh, int dw,
                       const float *mean, const float *inv_std, int reverse_channels, float pad_val, float *dst,
                       int out_h, int out_w, lsn_stream_t stream);
 
+/* ---- fused cross-IOU loss of the bbox task (csrc/loss.hip) ---------------------------------------------------
+ * mmdet/models/losses/cross_iou_loss.py:10-33, 61-132 with loss_type='bbox' for n points in one launch:
+ *   pred, target  (n, 20) float32, 16-byte aligned rows: 5 landmarks x [y_up, y_down, x_left, x_right];
+ *   active        (n, 20) bytes: non-zero where a component carries the ground truth (the reference's `pos_inds`);
+ *   anchor (n, 2), bbox_gt (n, 4); weight (n) or NULL;
+ * forward : loss_rows[i] = weight[i] * loss_i  (reduction 'none');
+ * backward: grad_pred[i, :] = grad_rows[i] * weight[i] * d loss_i / d pred[i, :]. */
+int lsn_cross_iou_bbox_forward(const float *pred, const float *target, const uint8_t *active, const float *anchor,
+                               const float *bbox_gt, const float *weight, int64_t n, float alpha, float eps,
+                               float *loss_rows, lsn_stream_t stream);
+int lsn_cross_iou_bbox_backward(const float *pred, const float *target, const uint8_t *active, const float *anchor,
+                                const float *bbox_gt, const float *weight, const float *grad_rows, int64_t n,
+                                float alpha, float eps, float *grad_pred, lsn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,8 +7,8 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.path.join(HERE, 'liblsnet_hip.so')
-SOURCES = ['dcn.hip', 'misc.hip', 'norm.hip', 'conv.hip', 'image.hip']
-HEADERS = ['common.h', 'dcn_kernels.h', os.path.join('..', '..', 'include', 'lsnet_hip.h')]
+SOURCES = ['dcn.hip', 'misc.hip', 'norm.hip', 'conv.hip', 'image.hip', 'loss.hip']
+HEADERS = ['common.h', 'dcn_kernels.h', 'cross_iou_row.h', os.path.join('..', '..', 'include', 'lsnet_hip.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=fast',
          '-Wno-unused-result']
 

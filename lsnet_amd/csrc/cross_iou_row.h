@@ -1,0 +1,88 @@
+// One row of the cross-IOU loss of the bbox task (5 landmarks x [y_up, y_down, x_left, x_right] = 20 components)
+// and its gradient with respect to the prediction -- the arithmetic of lsnet_amd/models/losses/cross_iou_loss.py
+// (reference: mmdet/models/losses/cross_iou_loss.py:10-33, 61-132), written once for the device kernel
+// (csrc/loss.hip) and, compiled by a host compiler, for the CPU check of the hand-derived gradient against autograd
+// (tests/test_fused_cross_iou.py).
+//
+//   target'      : the inactive half of every (neg, pos) pair is alpha x the active half
+//   overlap      : sum(min(p, t')) / sum(max(p, t'))
+//   box(p)       : [x_left-lm, y_top-lm, x_right-lm, y_bottom-lm] + anchor, each landmark coordinate the signed
+//                  combination of its pair (pos if pos > neg else -neg)
+//   loss         : 1 - (overlap - (rho^2 / c^2 + v^2 / (1 - overlap + v)))     (centre distance + aspect terms)
+// Ties follow ATen: max / min split the gradient 0.5 / 0.5, clamp(min=0) passes the gradient at 0.
+#pragma once
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define LSN_HD __host__ __device__ __forceinline__
+#else
+#define LSN_HD static inline
+#endif
+
+struct CrossIouRow {
+    float loss;        // unweighted
+    float grad[20];    // d loss / d pred
+};
+
+LSN_HD float ciou_signed(float neg, float pos) { return pos > neg ? pos : -neg; }
+
+// active[c] != 0: component c carries the ground truth; want_grad = 0 skips the gradient
+LSN_HD void cross_iou_bbox_row(const float *p, const float *t, const unsigned char *active, const float *anchor,
+                               const float *gt, float alpha, float eps, int want_grad, CrossIouRow *out)
+{
+    float tt[20];
+    float smin = 0.f, smax = 0.f;
+    for (int j = 0; j < 10; ++j) {
+        const float act = active[2 * j] ? t[2 * j] : t[2 * j + 1];
+        tt[2 * j] = active[2 * j] ? t[2 * j] : alpha * act;
+        tt[2 * j + 1] = active[2 * j + 1] ? t[2 * j + 1] : alpha * act;
+    }
+    for (int c = 0; c < 20; ++c) {
+        smin += fminf(p[c], tt[c]);
+        smax += fmaxf(p[c], tt[c]);
+    }
+    const float ov = smin / smax;
+    // landmark k: y = signed(p[4k], p[4k+1]), x = signed(p[4k+2], p[4k+3]); box = [x1, y0, x3, y2] + anchor
+    const float bx0 = ciou_signed(p[6], p[7]) + anchor[0], by0 = ciou_signed(p[0], p[1]) + anchor[1];
+    const float bx1 = ciou_signed(p[14], p[15]) + anchor[0], by1 = ciou_signed(p[8], p[9]) + anchor[1];
+    const float ew_raw = fmaxf(bx1, gt[2]) - fminf(bx0, gt[0]), eh_raw = fmaxf(by1, gt[3]) - fminf(by0, gt[1]);
+    const float ew = fmaxf(ew_raw, 0.f), eh = fmaxf(eh_raw, 0.f);
+    const float c2 = ew * ew + eh * eh + eps;
+    const float w1 = bx1 - bx0, h1 = by1 - by0 + eps;
+    const float w2 = gt[2] - gt[0], h2 = gt[3] - gt[1] + eps;
+    const float dxs = (gt[0] + gt[2]) - (bx0 + bx1), dys = (gt[1] + gt[3]) - (by0 + by1);
+    const float rho2 = dxs * dxs / 4 + dys * dys / 4;
+    const float kv = 4.f / (3.14159265358979323846f * 3.14159265358979323846f);
+    const float da = atanf(w2 / h2) - atanf(w1 / h1);
+    const float v = kv * da * da;
+    const float D = 1.f - ov + v;
+    out->loss = 1.f - (ov - (rho2 / c2 + v * v / D));
+    if (!want_grad) return;
+
+    const float dL_dov = -1.f + v * v / (D * D);
+    const float dL_dv = (2.f * v * D - v * v) / (D * D);
+    const float dL_drho2 = 1.f / c2, dL_dc2 = -rho2 / (c2 * c2);
+    // aspect term: v = kv (A2 - A1)^2, A1 = atan(w1 / h1)
+    const float r = w1 / h1, dA1 = 1.f / (1.f + r * r);
+    const float dv_dw1 = kv * 2.f * da * (-dA1 / h1), dv_dh1 = kv * 2.f * da * (dA1 * w1 / (h1 * h1));
+    // enclosing box: max / min against the ground truth (ties 0.5), clamp at 0 passes the gradient when >= 0
+    const float cw = ew_raw >= 0.f ? 1.f : 0.f, ch = eh_raw >= 0.f ? 1.f : 0.f;
+    const float mx1 = bx1 > gt[2] ? 1.f : (bx1 == gt[2] ? .5f : 0.f), mn0 = bx0 < gt[0] ? 1.f : (bx0 == gt[0] ? .5f : 0.f);
+    const float my1 = by1 > gt[3] ? 1.f : (by1 == gt[3] ? .5f : 0.f), my0 = by0 < gt[1] ? 1.f : (by0 == gt[1] ? .5f : 0.f);
+    const float g_bx0 = dL_drho2 * (-dxs / 2) + dL_dc2 * 2.f * ew * cw * (-mn0) + dL_dv * dv_dw1 * (-1.f);
+    const float g_bx1 = dL_drho2 * (-dxs / 2) + dL_dc2 * 2.f * ew * cw * mx1 + dL_dv * dv_dw1;
+    const float g_by0 = dL_drho2 * (-dys / 2) + dL_dc2 * 2.f * eh * ch * (-my0) + dL_dv * dv_dh1 * (-1.f);
+    const float g_by1 = dL_drho2 * (-dys / 2) + dL_dc2 * 2.f * eh * ch * my1 + dL_dv * dv_dh1;
+    for (int c = 0; c < 20; ++c) {
+        const float dmin = p[c] < tt[c] ? 1.f : (p[c] == tt[c] ? .5f : 0.f);
+        const float dmax = p[c] > tt[c] ? 1.f : (p[c] == tt[c] ? .5f : 0.f);
+        out->grad[c] = dL_dov * (dmin / smax - smin / (smax * smax) * dmax);
+    }
+    // box coordinates -> the selected half of their pair: (neg, pos) at (c, c + 1); pos > neg selects +pos else -neg
+    const int pair_of[4] = {6, 0, 14, 8};                    // bx0 <- x of lm 1, by0 <- y of lm 0, bx1 <- x of lm 3, by1 <- y of lm 2
+    const float g_box[4] = {g_bx0, g_by0, g_bx1, g_by1};
+    for (int q = 0; q < 4; ++q) {
+        const int c = pair_of[q];
+        if (p[c + 1] > p[c]) out->grad[c + 1] += g_box[q]; else out->grad[c] -= g_box[q];
+    }
+}

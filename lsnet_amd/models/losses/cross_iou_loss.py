@@ -98,6 +98,12 @@ class CrossIOULoss(nn.Module):
         if weight is not None and weight.dim() > 1:
             assert weight.shape == pred.shape
             weight = weight.mean(-1)
+        from ...ops import cross_iou as fused
+        if fused.enabled() and fused.usable(pred, target, self.loss_type) and kwargs.get('pos_inds') is not None:
+            from .utils import weight_reduce_loss
+            rows = fused.cross_iou_bbox_rows(pred, target, kwargs['pos_inds'], kwargs['anchor_pts'], kwargs['bbox_gt'],
+                                             weight, self.alpha, self.eps)      # already weighted
+            return self.loss_weight * weight_reduce_loss(rows, None, reduction, avg_factor)
         return self.loss_weight * cross_iou_loss(pred, target, weight, loss_type=self.loss_type, eps=self.eps,
                                                  reduction=reduction, avg_factor=avg_factor, alpha=self.alpha,
                                                  stride=self.stride, **kwargs)

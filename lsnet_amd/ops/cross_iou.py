@@ -1,0 +1,60 @@
+"""Fused cross-IOU loss of the bbox task (csrc/loss.hip, lsn_cross_iou_bbox_forward / _backward): the per-point loss and
+its gradient in one launch each, instead of the ~60 elementwise launches of the torch formulation
+(models/losses/cross_iou_loss.py).  Opt-in -- `LSNET_FUSED_CIOU=1` -- until it has been measured in the training step."""
+import ctypes
+import os
+
+import torch
+
+from .. import _lib
+
+
+def enabled():
+    return os.environ.get('LSNET_FUSED_CIOU') == '1'
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _CrossIouBbox(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, pred, target, active, anchor, bbox_gt, weight, alpha, eps):
+        pred, target = pred.contiguous(), target.contiguous()
+        active = active.to(torch.uint8).contiguous()
+        anchor, bbox_gt = anchor.contiguous(), bbox_gt.contiguous()
+        weight = None if weight is None else weight.contiguous()
+        loss = torch.empty(pred.shape[0], dtype=torch.float32, device=pred.device)
+        _lib.check(_lib.load().lsn_cross_iou_bbox_forward(_p(pred), _p(target), _p(active), _p(anchor), _p(bbox_gt), _p(weight),
+                                                          ctypes.c_int64(pred.shape[0]), ctypes.c_float(alpha),
+                                                          ctypes.c_float(eps), _p(loss), _stream()))
+        ctx.save_for_backward(pred, target, active, anchor, bbox_gt, *([weight] if weight is not None else []))
+        ctx.cfg = (alpha, eps, weight is not None)
+        return loss
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_rows):
+        alpha, eps, has_w = ctx.cfg
+        pred, target, active, anchor, bbox_gt, *rest = ctx.saved_tensors
+        weight = rest[0] if has_w else None
+        grad = torch.empty_like(pred)
+        _lib.check(_lib.load().lsn_cross_iou_bbox_backward(_p(pred), _p(target), _p(active), _p(anchor), _p(bbox_gt), _p(weight),
+                                                           _p(grad_rows.contiguous()), ctypes.c_int64(pred.shape[0]),
+                                                           ctypes.c_float(alpha), ctypes.c_float(eps), _p(grad), _stream()))
+        return grad, None, None, None, None, None, None, None
+
+
+def usable(pred, target, loss_type):
+    return (loss_type == 'bbox' and pred.is_cuda and pred.dtype == torch.float32 and pred.dim() == 2
+            and pred.shape[1] == 20 and not target.requires_grad)
+
+
+def cross_iou_bbox_rows(pred, target, active, anchor, bbox_gt, weight=None, alpha=0.2, eps=1e-6):
+    """(n,) weighted loss rows (reduction 'none') of the bbox cross-IOU loss; gradient flows to `pred` only."""
+    return _CrossIouBbox.apply(pred, target, active, anchor, bbox_gt, weight, float(alpha), float(eps))

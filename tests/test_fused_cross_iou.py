@@ -1,0 +1,78 @@
+"""The hand-derived row function of the fused cross-IOU kernel (lsnet_amd/csrc/cross_iou_row.h, shared by the device
+kernel in csrc/loss.hip) against the torch formulation and its autograd gradient (models/losses/cross_iou_loss.py).
+The header is compiled here with g++ into a scratch library: the same source the GPU runs."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from lsnet_amd.models.losses.cross_iou_loss import cross_iou_loss
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DRIVER = r'''
+#include "cross_iou_row.h"
+extern "C" void rows(const float *p, const float *t, const unsigned char *a, const float *anchor, const float *gt, int n,
+                     float alpha, float eps, float *loss, float *grad) {
+    for (int i = 0; i < n; ++i) {
+        CrossIouRow r;
+        cross_iou_bbox_row(p + 20 * i, t + 20 * i, a + 20 * i, anchor + 2 * i, gt + 4 * i, alpha, eps, 1, &r);
+        loss[i] = r.loss;
+        for (int c = 0; c < 20; ++c) grad[20 * i + c] = r.grad[c];
+    }
+}
+'''
+
+
+@pytest.fixture(scope='module')
+def rowlib(tmp_path_factory):
+    d = tmp_path_factory.mktemp('ciou')
+    src = d / 'driver.cpp'
+    src.write_text(DRIVER)
+    so = d / 'ciou.so'
+    subprocess.check_call(['g++', '-O2', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off',
+                           f'-I{os.path.join(ROOT, "lsnet_amd", "csrc")}', str(src), '-o', str(so)])
+    return ctypes.CDLL(str(so))
+
+
+def _case(seed, n=400):
+    g = torch.Generator().manual_seed(seed)
+    pred = torch.rand(n, 20, generator=g) * 3 + 0.01
+    mag = torch.rand(n, 10, generator=g) * 3 + 0.01
+    pos = torch.rand(n, 10, generator=g) > 0.5
+    target = torch.zeros(n, 20)
+    target[:, 0::2] = torch.where(pos, torch.zeros_like(mag), mag)
+    target[:, 1::2] = torch.where(pos, mag, torch.zeros_like(mag))
+    active = torch.zeros(n, 20, dtype=torch.bool)
+    active[:, 0::2], active[:, 1::2] = ~pos, pos
+    anchor = torch.rand(n, 2, generator=g) * 10
+    c = anchor + torch.randn(n, 2, generator=g)
+    wh = torch.rand(n, 2, generator=g) * 4 + 0.2
+    gt = torch.cat([c - wh, c + wh], 1)
+    target[::17] = 0                                             # rows without an object: zero targets
+    pred[5, 3] = target[5, 3] = 1.25                             # an exact tie of max / min
+    return pred, target, active, anchor, gt
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2])
+def test_row_function_matches_torch_and_autograd(rowlib, seed):
+    pred, target, active, anchor, gt = _case(seed)
+    p = pred.clone().requires_grad_()
+    want = cross_iou_loss(p, target, None, reduction='none', loss_type='bbox', anchor_pts=anchor, bbox_gt=gt, pos_inds=active)
+    up = torch.rand(len(pred), generator=torch.Generator().manual_seed(9))
+    (want * up).sum().backward()
+    n = len(pred)
+    loss, grad = np.zeros(n, np.float32), np.zeros((n, 20), np.float32)
+    f32, u8 = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_ubyte)
+    arrs = [np.ascontiguousarray(x.numpy(), dtype=np.float32) for x in (pred, target, anchor, gt)]
+    act = np.ascontiguousarray(active.numpy().astype(np.uint8))
+    rowlib.rows(arrs[0].ctypes.data_as(f32), arrs[1].ctypes.data_as(f32), act.ctypes.data_as(u8), arrs[2].ctypes.data_as(f32),
+                arrs[3].ctypes.data_as(f32), n, ctypes.c_float(0.2), ctypes.c_float(1e-6), loss.ctypes.data_as(f32),
+                grad.ctypes.data_as(f32))
+    np.testing.assert_allclose(loss, want.detach().numpy(), rtol=2e-5, atol=2e-6)
+    got = grad * up.numpy()[:, None]
+    ref = p.grad.numpy()
+    scale = np.abs(ref).max(1, keepdims=True) + 1e-6
+    assert (np.abs(got - ref) / scale).max() < 2e-4, float((np.abs(got - ref) / scale).max())
