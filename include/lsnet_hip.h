@@ -331,6 +331,17 @@ int lsn_cross_iou_bbox_backward(const float *pred, const float *target, const ui
                                 const float *bbox_gt, const float *weight, const float *grad_rows, int64_t n,
                                 float alpha, float eps, float *grad_pred, lsn_stream_t stream);
 
+/* The whole bbox regression stage of LSHead.loss_single for n points (lsnet_head.py:402-427, 1066-1101): pred_raw (n, 20)
+ * in stride units; gt_pts (n, 10) extreme points + centre as (x, y); anchor3 (n, 3) = (x, y, stride); bbox_gt (n, 4);
+ * weight (n): 0 for points without an object.  Scaling to pixels, normalisation by base_scale * stride, target and
+ * active-half construction and the cross-IOU row happen in registers. */
+int lsn_cross_iou_bbox_stage_forward(const float *pred_raw, const float *gt_pts, const float *anchor3, const float *bbox_gt,
+                                     const float *weight, int64_t n, float base_scale, float alpha, float eps,
+                                     float *loss_rows, lsn_stream_t stream);
+int lsn_cross_iou_bbox_stage_backward(const float *pred_raw, const float *gt_pts, const float *anchor3, const float *bbox_gt,
+                                      const float *weight, const float *grad_rows, int64_t n, float base_scale, float alpha,
+                                      float eps, float *grad_raw, lsn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -86,3 +86,31 @@ LSN_HD void cross_iou_bbox_row(const float *p, const float *t, const unsigned ch
         if (p[c + 1] > p[c]) out->grad[c + 1] += g_box[q]; else out->grad[c] -= g_box[q];
     }
 }
+
+// The whole bbox regression stage of one point (lsnet_head.py:1066-1101 via LSHead.loss_levels): prediction in stride
+// units -> pixels -> normalised by base_scale * stride; ground-truth extreme points (5 x (x, y)) -> the four-component
+// regression target and the active-half mask (lsnet_head.py:402-427: `offset >= 0` selects the positive half; points
+// without an object get zero targets); anchor and ground-truth box normalised the same way; then the row loss above.
+// out->grad is d loss / d (raw prediction).
+LSN_HD void cross_iou_bbox_stage_row(const float *pred_raw, const float *gt_pts, const float *anchor3, const float *gt_box,
+                                     int has_object, float base_scale, float alpha, float eps, int want_grad,
+                                     CrossIouRow *out)
+{
+    const float stride = anchor3[2], norm = base_scale * stride;
+    float p[20], t[20], an[2], gb[4];
+    unsigned char act[20];
+    for (int c = 0; c < 20; ++c) p[c] = pred_raw[c] * stride / norm;
+    for (int k = 0; k < 5; ++k) {
+        const float dx = gt_pts[2 * k] - anchor3[0], dy = gt_pts[2 * k + 1] - anchor3[1];
+        const float mx = has_object ? fabsf(dx) : 0.f, my = has_object ? fabsf(dy) : 0.f;
+        const bool px = dx >= 0.f, py = dy >= 0.f;
+        t[4 * k] = (py ? 0.f : my) / norm;   t[4 * k + 1] = (py ? my : 0.f) / norm;
+        t[4 * k + 2] = (px ? 0.f : mx) / norm; t[4 * k + 3] = (px ? mx : 0.f) / norm;
+        act[4 * k] = !py; act[4 * k + 1] = py; act[4 * k + 2] = !px; act[4 * k + 3] = px;
+    }
+    an[0] = anchor3[0] / norm; an[1] = anchor3[1] / norm;
+    for (int q = 0; q < 4; ++q) gb[q] = gt_box[q] / norm;
+    cross_iou_bbox_row(p, t, act, an, gb, alpha, eps, want_grad, out);
+    if (want_grad)
+        for (int c = 0; c < 20; ++c) out->grad[c] = out->grad[c] * stride / norm;
+}

@@ -47,6 +47,42 @@ __global__ void cross_iou_bbox_kernel(CiouArgs a)
     }
 }
 
+// the whole regression stage per point: raw prediction + extreme points + anchor (x, y, stride) + box -> weighted row
+struct CiouStageArgs {
+    const float *raw, *gt_pts, *anchor3, *gt_box, *weight, *grad_rows;
+    float *loss, *grad_raw;
+    long long n;
+    float base, alpha, eps;
+};
+
+template <bool BWD>
+__global__ void cross_iou_bbox_stage_kernel(CiouStageArgs a)
+{
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < a.n; i += (long long)gridDim.x * blockDim.x) {
+        float p[20], g[10];
+        const float4 *p4 = reinterpret_cast<const float4 *>(a.raw + 20 * i);
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            const float4 x = p4[q];
+            p[4 * q] = x.x; p[4 * q + 1] = x.y; p[4 * q + 2] = x.z; p[4 * q + 3] = x.w;
+        }
+#pragma unroll
+        for (int c = 0; c < 10; ++c) g[c] = a.gt_pts[10 * i + c];
+        const float w = a.weight[i];
+        CrossIouRow r;
+        cross_iou_bbox_stage_row(p, g, a.anchor3 + 3 * i, a.gt_box + 4 * i, w > 0.f, a.base, a.alpha, a.eps, BWD ? 1 : 0, &r);
+        if (!BWD) {
+            a.loss[i] = r.loss * w;
+        } else {
+            const float s = a.grad_rows[i] * w;
+            float4 *o = reinterpret_cast<float4 *>(a.grad_raw + 20 * i);
+#pragma unroll
+            for (int q = 0; q < 5; ++q)
+                o[q] = make_float4(r.grad[4 * q] * s, r.grad[4 * q + 1] * s, r.grad[4 * q + 2] * s, r.grad[4 * q + 3] * s);
+        }
+    }
+}
+
 static int launch(const CiouArgs &a, bool bwd, hipStream_t st)
 {
     if (a.n == 0) return 0;
@@ -85,6 +121,39 @@ int lsn_cross_iou_bbox_backward(const float *pred, const float *target, const ui
               "pred / target / grad rows must be 16-byte aligned");
     CiouArgs a = {pred, target, anchor, bbox_gt, weight, grad_rows, active, nullptr, grad_pred, (long long)n, alpha, eps};
     return launch(a, true, static_cast<hipStream_t>(stream));
+}
+
+int lsn_cross_iou_bbox_stage_forward(const float *pred_raw, const float *gt_pts, const float *anchor3, const float *bbox_gt,
+                                     const float *weight, int64_t n, float base_scale, float alpha, float eps,
+                                     float *loss_rows, lsn_stream_t stream)
+{
+    using namespace lsn;
+    LSN_CHECK(n >= 0, "invalid number of rows %lld", (long long)n);
+    if (n == 0) return 0;
+    LSN_CHECK(pred_raw && gt_pts && anchor3 && bbox_gt && weight && loss_rows, "lsn_cross_iou_bbox_stage_forward: null pointer");
+    LSN_CHECK((uintptr_t)pred_raw % 16 == 0, "prediction rows must be 16-byte aligned");
+    CiouStageArgs a = {pred_raw, gt_pts, anchor3, bbox_gt, weight, nullptr, loss_rows, nullptr, (long long)n, base_scale, alpha, eps};
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(cross_iou_bbox_stage_kernel<false>, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    LSN_HIP(hipGetLastError());
+    return 0;
+}
+
+int lsn_cross_iou_bbox_stage_backward(const float *pred_raw, const float *gt_pts, const float *anchor3, const float *bbox_gt,
+                                      const float *weight, const float *grad_rows, int64_t n, float base_scale, float alpha,
+                                      float eps, float *grad_raw, lsn_stream_t stream)
+{
+    using namespace lsn;
+    LSN_CHECK(n >= 0, "invalid number of rows %lld", (long long)n);
+    if (n == 0) return 0;
+    LSN_CHECK(pred_raw && gt_pts && anchor3 && bbox_gt && weight && grad_rows && grad_raw,
+              "lsn_cross_iou_bbox_stage_backward: null pointer");
+    LSN_CHECK((uintptr_t)pred_raw % 16 == 0 && (uintptr_t)grad_raw % 16 == 0, "prediction / gradient rows must be 16-byte aligned");
+    CiouStageArgs a = {pred_raw, gt_pts, anchor3, bbox_gt, weight, grad_rows, nullptr, grad_raw, (long long)n, base_scale, alpha, eps};
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(cross_iou_bbox_stage_kernel<true>, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    LSN_HIP(hipGetLastError());
+    return 0;
 }
 
 }  // extern "C"

@@ -28,6 +28,7 @@ from ...ops.conv import Conv2d
 from ...ops.group_norm import GroupNorm
 from ...core import PointGenerator, build_assigner, build_sampler, multiclass_nms_lsvr
 from ...ops import ModulatedDeformConvPack, PyramidDeformConv
+from ...ops import cross_iou as fused_ciou
 from ..builder import HEADS, build_loss
 
 # regression branches of each task; the LAST branch's offsets also drive the classification
@@ -486,9 +487,18 @@ class LSHead(nn.Module):
                 width = gt_pts.shape[1] * 2
                 weights = bw[:, :1].expand(-1, width)
                 pred = torch.cat([p.permute(0, 2, 3, 1).reshape(B, -1, width) for p in plist], dim=1)
+                loss_fn = getattr(self, f'loss_{b}_{stage}')
+                if (b == 'bbox' and width == 20 and fused_ciou.enabled() and pred.is_cuda and pred.dtype == torch.float32
+                        and getattr(loss_fn, 'loss_type', None) == 'bbox'):
+                    # opt-in (LSNET_FUSED_CIOU=1): scaling, normalisation, target construction and the loss in one launch
+                    rows = loss_fn.loss_weight * fused_ciou.cross_iou_bbox_stage_rows(
+                        pred.reshape(-1, width), gt_pts, anchor, bbox_gt, bw[:, 0], self.point_base_scale, loss_fn.alpha,
+                        loss_fn.eps)
+                    per_level = torch.split(rows.reshape(B, -1), num_level, dim=1)
+                    losses[f'{b}_{stage}'] = [r.sum() / n for r in per_level]
+                    continue
                 pred = pred.reshape(-1, width) * stride
                 gt_reg, active = self._gt_reg(gt_pts, anchor, weights)
-                loss_fn = getattr(self, f'loss_{b}_{stage}')
                 rows = loss_fn(pred / norm, gt_reg / norm, weights, reduction_override='none',
                                anchor_pts=anchor[:, :-1] / norm, pos_inds=active, **kw)   # weighted, per row
                 per_level = torch.split(rows.reshape(B, -1), num_level, dim=1)

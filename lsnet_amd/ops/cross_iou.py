@@ -58,3 +58,36 @@ def usable(pred, target, loss_type):
 def cross_iou_bbox_rows(pred, target, active, anchor, bbox_gt, weight=None, alpha=0.2, eps=1e-6):
     """(n,) weighted loss rows (reduction 'none') of the bbox cross-IOU loss; gradient flows to `pred` only."""
     return _CrossIouBbox.apply(pred, target, active, anchor, bbox_gt, weight, float(alpha), float(eps))
+
+
+class _CrossIouBboxStage(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, raw, gt_pts, anchor3, bbox_gt, weight, base, alpha, eps):
+        raw, gt_pts, anchor3 = raw.contiguous(), gt_pts.contiguous(), anchor3.contiguous()
+        bbox_gt, weight = bbox_gt.contiguous(), weight.contiguous()
+        loss = torch.empty(raw.shape[0], dtype=torch.float32, device=raw.device)
+        _lib.check(_lib.load().lsn_cross_iou_bbox_stage_forward(_p(raw), _p(gt_pts), _p(anchor3), _p(bbox_gt), _p(weight),
+                                                                ctypes.c_int64(raw.shape[0]), ctypes.c_float(base),
+                                                                ctypes.c_float(alpha), ctypes.c_float(eps), _p(loss), _stream()))
+        ctx.save_for_backward(raw, gt_pts, anchor3, bbox_gt, weight)
+        ctx.cfg = (base, alpha, eps)
+        return loss
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_rows):
+        base, alpha, eps = ctx.cfg
+        raw, gt_pts, anchor3, bbox_gt, weight = ctx.saved_tensors
+        grad = torch.empty_like(raw)
+        _lib.check(_lib.load().lsn_cross_iou_bbox_stage_backward(_p(raw), _p(gt_pts), _p(anchor3), _p(bbox_gt), _p(weight),
+                                                                 _p(grad_rows.contiguous()), ctypes.c_int64(raw.shape[0]),
+                                                                 ctypes.c_float(base), ctypes.c_float(alpha), ctypes.c_float(eps),
+                                                                 _p(grad), _stream()))
+        return grad, None, None, None, None, None, None, None
+
+
+def cross_iou_bbox_stage_rows(pred_raw, gt_pts, anchor3, bbox_gt, weight, base_scale, alpha=0.2, eps=1e-6):
+    """The bbox regression stage of LSHead for n points in one launch (see lsn_cross_iou_bbox_stage_forward): weighted
+    loss rows; gradient flows to `pred_raw`."""
+    return _CrossIouBboxStage.apply(pred_raw, gt_pts, anchor3, bbox_gt, weight, float(base_scale), float(alpha), float(eps))

@@ -23,6 +23,15 @@ extern "C" void rows(const float *p, const float *t, const unsigned char *a, con
         for (int c = 0; c < 20; ++c) grad[20 * i + c] = r.grad[c];
     }
 }
+extern "C" void stage_rows(const float *p, const float *g, const float *anchor3, const float *gt, const unsigned char *obj,
+                           int n, float base, float alpha, float eps, float *loss, float *grad) {
+    for (int i = 0; i < n; ++i) {
+        CrossIouRow r;
+        cross_iou_bbox_stage_row(p + 20 * i, g + 10 * i, anchor3 + 3 * i, gt + 4 * i, obj[i], base, alpha, eps, 1, &r);
+        loss[i] = r.loss;
+        for (int c = 0; c < 20; ++c) grad[20 * i + c] = r.grad[c];
+    }
+}
 '''
 
 
@@ -76,3 +85,44 @@ def test_row_function_matches_torch_and_autograd(rowlib, seed):
     ref = p.grad.numpy()
     scale = np.abs(ref).max(1, keepdims=True) + 1e-6
     assert (np.abs(got - ref) / scale).max() < 2e-4, float((np.abs(got - ref) / scale).max())
+
+
+@pytest.mark.parametrize('seed', [3, 4])
+def test_stage_row_matches_head_formulation(rowlib, seed):
+    """prediction in stride units + extreme points + anchors  ->  rows, as LSHead.loss_levels composes them
+    (`_gt_reg`, normalisation by 4 * stride, cross_iou_loss) and its autograd gradient w.r.t. the raw prediction."""
+    from lsnet_amd.models.dense_heads.ls_head import LSHead
+    g = torch.Generator().manual_seed(seed)
+    n = 600
+    stride = torch.tensor([8., 16., 32., 64., 128.])[torch.randint(0, 5, (n,), generator=g)]
+    anchor = torch.cat([torch.floor(torch.rand(n, 2, generator=g) * 20) * stride[:, None], stride[:, None]], 1)
+    raw = torch.rand(n, 20, generator=g) * 2 + 0.01
+    centre = anchor[:, :2] + torch.randn(n, 2, generator=g) * stride[:, None] * 2
+    half = (torch.rand(n, 2, generator=g) * 3 + 0.3) * stride[:, None]
+    box = torch.cat([centre - half, centre + half], 1)
+    ext = torch.stack([centre[:, 0], box[:, 1], box[:, 0], centre[:, 1], centre[:, 0], box[:, 3], box[:, 2], centre[:, 1],
+                       centre[:, 0], centre[:, 1]], 1) + torch.randn(n, 10, generator=g)
+    ext[3, 0] = anchor[3, 0]                                     # dx == 0 exactly: the ">= 0" side
+    obj = torch.rand(n, generator=g) > 0.25
+    weights = obj.float()[:, None].expand(-1, 20)
+    ext_in = torch.where(obj[:, None], ext, torch.zeros_like(ext))       # the target builder zeroes rows without object
+    box_in = torch.where(obj[:, None], box, torch.zeros_like(box))
+    p = raw.clone().requires_grad_()
+    norm = 4 * stride[:, None]
+    reg, active = LSHead._gt_reg(ext_in, anchor, weights)
+    want = cross_iou_loss(p * stride[:, None] / norm, reg / norm, weights.mean(-1), reduction='none', loss_type='bbox',
+                          anchor_pts=anchor[:, :2] / norm, bbox_gt=box_in / norm, pos_inds=active)
+    up = torch.rand(n, generator=g)
+    (want * up).sum().backward()
+    loss, grad = np.zeros(n, np.float32), np.zeros((n, 20), np.float32)
+    f32, u8 = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_ubyte)
+    arrs = [np.ascontiguousarray(x.numpy(), dtype=np.float32) for x in (raw, ext_in, anchor, box_in)]
+    ob = np.ascontiguousarray(obj.numpy().astype(np.uint8))
+    rowlib.stage_rows(arrs[0].ctypes.data_as(f32), arrs[1].ctypes.data_as(f32), arrs[2].ctypes.data_as(f32),
+                      arrs[3].ctypes.data_as(f32), ob.ctypes.data_as(u8), n, ctypes.c_float(4.0), ctypes.c_float(0.2),
+                      ctypes.c_float(1e-6), loss.ctypes.data_as(f32), grad.ctypes.data_as(f32))
+    w = obj.float().numpy()
+    np.testing.assert_allclose(loss * w, want.detach().numpy(), rtol=5e-5, atol=5e-6)
+    got, ref = grad * (up.numpy() * w)[:, None], p.grad.numpy()
+    scale = np.abs(ref).max(1, keepdims=True) + 1e-6
+    assert (np.abs(got - ref) / scale).max() < 5e-4, float((np.abs(got - ref) / scale).max())

@@ -32,3 +32,10 @@ def test_fused_rows_and_gradient_equal_torch(seed, monkeypatch):
     assert torch.allclose(r0, r1, rtol=1e-4, atol=1e-5) and torch.allclose(t0, t1, rtol=1e-4)
     scale = g0.abs().amax(1, keepdim=True) + 1e-6
     assert float(((g0 - g1).abs() / scale).max()) < 1e-3
+
+
+def test_head_with_fused_stage_equals_reference_fixture(monkeypatch):
+    """LSHead (bbox) with the fused regression stage switched on against the same reference fixture as the default path."""
+    from tests import golden_cases as gc
+    monkeypatch.setenv('LSNET_FUSED_CIOU', '1')
+    gc.head_case('bbox', torch.device('cuda:0'), channels_last=True)
