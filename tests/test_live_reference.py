@@ -75,7 +75,10 @@ def test_image_without_instances_raises_as_reference(task, cpu_oracle_backend):
     assert type(ref) is type(ours) and str(ref)[:40] == str(ours)[:40]
 
 
-@pytest.mark.parametrize('task', ['bbox', 'segm', 'pose_bbox', 'pose_kbox'])
+SLOW = pytest.mark.skipif(os.environ.get('LSNET_SLOW_TESTS') != '1', reason='set LSNET_SLOW_TESTS=1')
+
+
+@pytest.mark.parametrize('task', ['bbox', pytest.param('segm', marks=SLOW), pytest.param('pose_bbox', marks=SLOW), 'pose_kbox'])
 def test_decode_with_rescale_equals_reference(task, cpu_oracle_backend):
     """`get_bboxes(rescale=True)` with a per-axis scale factor and an image smaller than its padded shape: boxes and
     landmark vectors are clamped to the image and mapped back to the original scale as the reference does."""
