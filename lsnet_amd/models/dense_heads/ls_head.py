@@ -342,7 +342,14 @@ class LSHead(nn.Module):
     # ------------------------------------------------------------------------------------ targets
     def get_points(self, featmap_sizes, img_metas, device):
         """Per-level grid points (shared by all images) and, per image, the flags of the cells that
-        lie inside the padded image (lsnet_head.py:757-794)."""
+        lie inside the padded image (lsnet_head.py:757-794).  Both depend only on the grid geometry and the padded
+        shapes: built once per geometry and reused (they are read-only downstream), so a training step with a
+        constant input shape creates none of these ~50 small tensors again."""
+        key = ('points', tuple(tuple(s) for s in featmap_sizes), tuple(tuple(m['pad_shape'][:2]) for m in img_metas),
+               str(device))
+        hit = self._consts.get(key)
+        if hit is not None:
+            return hit
         points = [self.point_generators[i].grid_points(featmap_sizes[i], self.point_strides[i], device)
                   for i in range(len(featmap_sizes))]
         flags, all_valid = [], True
@@ -355,6 +362,9 @@ class LSHead(nn.Module):
                 all_valid = all_valid and vh == fh and vw == fw
                 per_level.append(self.point_generators[i].valid_flags((fh, fw), (vh, vw), device))
             flags.append(per_level)
+        if len(self._consts) > 64:            # multi-scale training visits many geometries: keep the table small
+            self._consts.clear()
+        self._consts[key] = (points, flags, all_valid)
         return points, flags, all_valid
 
     def _dense_targets(self, gt_inds, gt_labels, gt_bboxes, extra):
