@@ -374,13 +374,13 @@ class LSHead(nn.Module):
         pos = gt_inds > 0
         idx = (gt_inds - 1).clamp(min=0)
         posf = pos.unsqueeze(1)
-        out = dict(bboxes_gt=torch.where(posf, gt_bboxes[idx], gt_bboxes.new_zeros(())),
+        out = dict(bboxes_gt=torch.where(posf, gt_bboxes[idx], 0.0),          # python scalars: no tensor is made for them
                    bbox_weights=posf.to(gt_bboxes.dtype).expand(-1, 4),
                    labels=torch.where(pos, gt_labels[idx] if gt_labels is not None else torch.ones_like(idx),
-                                      idx.new_full((), self.background_label)),
+                                      self.background_label),
                    label_weights=torch.ones_like(pos, dtype=gt_bboxes.dtype), num_pos=pos.sum())
         for k, v in extra.items():
-            out[k] = torch.where(posf, v[idx], v.new_zeros(()))
+            out[k] = torch.where(posf, v[idx], 0.0)
         return out
 
     def _assign_image(self, stage, proposals, flags, all_valid, num_level, gt_bboxes, gt_labels, extra):
