@@ -78,7 +78,7 @@ def _labels_of(gt_inds, gt_labels):
     if gt_labels is None:
         return None
     pos = gt_inds > 0
-    return torch.where(pos, gt_labels[(gt_inds - 1).clamp(min=0)], gt_inds.new_full((), -1))
+    return torch.where(pos, gt_labels[(gt_inds - 1).clamp(min=0)], -1)
 
 
 def _empty_assignment(ref, num_gts, num_preds, gt_labels, with_overlaps):
@@ -111,11 +111,11 @@ class CentroidAssigner:
         gt_lvl = ((torch.log2(wh[:, 0] / self.scale) + torch.log2(wh[:, 1] / self.scale)) / 2).int()
         gt_lvl = torch.clamp(gt_lvl, min=lvl_min, max=lvl_max)
         dist = ((xy[:, None, :] - centers[None, :, :]) / wh[None, :, :]).norm(dim=2)
-        dist = torch.where(lvl[:, None] != gt_lvl[None, :], dist.new_full((), INF), dist)
+        dist = torch.where(lvl[:, None] != gt_lvl[None, :], INF, dist)
         near_d, near_i = torch.topk(dist, self.pos_num, dim=0, largest=False)
         claimed = torch.full_like(dist, INF).scatter_(0, near_i, near_d)
         best_d, best_gt = claimed.min(dim=1)
-        gt_inds = torch.where(best_d != INF, best_gt + 1, torch.zeros_like(best_gt))
+        gt_inds = torch.where(best_d != INF, best_gt + 1, 0)
         return AssignResult(num_gts, gt_inds, None, labels=_labels_of(gt_inds, gt_labels))
 
     @staticmethod
@@ -171,7 +171,7 @@ class PointHMAssigner:
         dist = (xy[:, None, :] - corner[None, :, :]).norm(dim=2)                 # (P, G)
         if self.gaussian_bump:
             g = torch.exp(-torch.pow(dist, 2) / (2 * sigma * sigma)[None, :])
-            g = torch.where(dist >= radius[None, :], g.new_full((), -INF), g).max(dim=1)[0]
+            g = torch.where(dist >= radius[None, :], -INF, g).max(dim=1)[0]
             hm = torch.where(g != -INF, g, torch.zeros_like(g))
         else:
             hm = xy.new_zeros((P,), dtype=dtype)
@@ -180,7 +180,7 @@ class PointHMAssigner:
         order = torch.arange(G, device=xy.device)
         for l in levels:
             on = lvl == l
-            d = torch.where(on[:, None], dist, dist.new_full((), float('inf')))
+            d = torch.where(on[:, None], dist, float('inf'))
             best_d, best_p = d.min(dim=0)                                        # (G,)
             best_p = torch.where(torch.isfinite(best_d), best_p, torch.full_like(best_p, P))
             winner.zero_().sub_(1)
@@ -269,9 +269,9 @@ class ATSSAssigner:
         chosen = torch.zeros(num_gt * num_bboxes, dtype=torch.bool, device=bboxes.device)
         chosen[flat] = is_pos.view(-1)
         iou_t = overlaps.t().contiguous().view(-1)
-        table = torch.where(chosen, iou_t, iou_t.new_full((), -INF))
+        table = torch.where(chosen, iou_t, -INF)
         max_overlaps, argmax = table.view(num_gt, -1).t().max(dim=1)
-        gt_inds = torch.where(max_overlaps != -INF, argmax + 1, torch.zeros_like(argmax))
+        gt_inds = torch.where(max_overlaps != -INF, argmax + 1, 0)
         return AssignResult(num_gt, gt_inds, max_overlaps, labels=_labels_of(gt_inds, gt_labels))
 
 
