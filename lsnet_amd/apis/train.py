@@ -3,7 +3,7 @@ the optimizer and the runner, register the training hooks, run."""
 import torch
 
 from ..parallel import DataParallelModel
-from ..runner import DistSamplerSeedHook, EpochBasedRunner, build_optimizer
+from ..runner import DistEvalHook, DistSamplerSeedHook, EpochBasedRunner, EvalHook, build_optimizer
 
 
 def train_detector(model, data_loaders, cfg, distributed=False, validate=False, timestamp=None, meta=None,
@@ -20,6 +20,13 @@ def train_detector(model, data_loaders, cfg, distributed=False, validate=False, 
                                    cfg.get('log_config'))
     if distributed:
         runner.register_hook(DistSamplerSeedHook())
+    if validate:                                   # mmdet/apis/train.py:112-122
+        from ..data import build_dataloader, build_dataset
+        val = build_dataset(cfg.data.val, dict(test_mode=True))
+        loader = build_dataloader(val, samples_per_gpu=1, workers_per_gpu=cfg.data.get('workers_per_gpu', 0),
+                                  dist=distributed, shuffle=False)
+        hook = DistEvalHook if distributed else EvalHook
+        runner.register_hook(hook(loader, **dict(cfg.get('evaluation', {}))))
     if cfg.get('resume_from'):
         runner.resume(cfg.resume_from)
     elif cfg.get('load_from'):

@@ -163,6 +163,47 @@ class TextLoggerHook(Hook):
 
 
 @HOOKS.register_module()
+class EvalHook(Hook):
+    """Evaluate on the validation loader every `interval` epochs and log the metrics
+    (mmdet/core/evaluation/eval_hooks.py:7-42).  The metrics of the last evaluation stay in `runner.eval_results`."""
+    priority = 85
+
+    def __init__(self, dataloader, interval=1, bbox_head=None, **eval_kwargs):
+        from torch.utils.data import DataLoader
+        if not isinstance(dataloader, DataLoader):
+            raise TypeError(f'dataloader must be a pytorch DataLoader, but got {type(dataloader)}')
+        self.dataloader, self.interval, self.eval_kwargs = dataloader, interval, eval_kwargs
+
+    def _results(self, runner):
+        from ..apis.test import single_gpu_test
+        return single_gpu_test(runner.model, self.dataloader)
+
+    def after_train_epoch(self, runner):
+        if not self.every_n_epochs(runner, self.interval):
+            return
+        results = self._results(runner)
+        runner.model.train()
+        if results is None:                       # not rank 0 of a distributed evaluation
+            return
+        res = self.dataloader.dataset.evaluate(results, logger=runner.logger, **self.eval_kwargs)
+        runner.eval_results = res
+        runner.logger('Epoch(val) [%d]\t' % (runner.epoch + 1) +
+                      ', '.join(f'{k}: {v}' for k, v in res.items() if not isinstance(v, dict)))
+
+
+@HOOKS.register_module()
+class DistEvalHook(EvalHook):
+    """eval_hooks.py:45-98: every rank tests its share (DistributedSampler without shuffle), rank 0 gathers and scores."""
+
+    def __init__(self, dataloader, interval=1, bbox_head=None, gpu_collect=False, **eval_kwargs):
+        super().__init__(dataloader, interval, bbox_head, **eval_kwargs)
+
+    def _results(self, runner):
+        from ..apis.test import multi_gpu_test
+        return multi_gpu_test(runner.model, self.dataloader)
+
+
+@HOOKS.register_module()
 class CheckpointHook(Hook):
     """Rank-0 checkpoint every `interval` epochs: epoch_N.pth + latest.pth
     (hooks/checkpoint.py:43-52)."""

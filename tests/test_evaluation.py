@@ -310,3 +310,42 @@ def test_test_loop_and_evaluate(tmp_path, task, cpu_oracle_backend):
         assert rles[k][0]['size'] == [info['height'], info['width']] and len(rles[k]) == len(boxes[k])
         out = ds.evaluate(results, metric=['bbox', 'segm'])
         assert -1 <= out['segm_mAP'] <= 1 and 'bbox_mAP' in out
+
+
+def test_train_detector_with_validation(tmp_path, cpu_oracle_backend):
+    """`train_detector(validate=True)`: the EvalHook tests the model on `cfg.data.val` after the epoch and scores it
+    with `cfg.evaluation` (mmdet/apis/train.py:112-122, core/evaluation/eval_hooks.py)."""
+    from lsnet_amd.apis import train_detector
+    from lsnet_amd.data import build_dataloader, build_dataset
+    from lsnet_amd.data.datasets import COCO_CLASSES
+    from lsnet_amd.model_zoo import build_lsnet
+    from tests.test_data_pipeline import NORM, TASKS, _pipeline, _write_images
+    ann = _write_images(str(tmp_path))
+    with open(ann) as f:
+        coco = json.load(f)
+    have = {c['name'] for c in coco['categories']}
+    coco['categories'] += [dict(id=200 + i, name=n, supercategory='x') for i, n in enumerate(COCO_CLASSES) if n not in have]
+    with open(ann, 'w') as f:
+        json.dump(coco, f)
+    cls, load_kw, keys = TASKS['bbox']
+    train = build_dataset(dict(type='CocoDataset', ann_file=ann, img_prefix=str(tmp_path),
+                               pipeline=[dict(type='LoadImageFromFile')] + _pipeline(load_kw, keys, scale=(480, 384))))
+    torch.manual_seed(1)
+    torch.set_num_threads(8)
+    model, cfg = build_lsnet('bbox', 'r50')
+    model.test_cfg.nms_pre, model.test_cfg.max_per_img, model.test_cfg.score_thr = 20, 10, 0.0
+    cfg.total_epochs, cfg.workflow, cfg.checkpoint_config = 1, [('train', 1)], None
+    cfg.log_config = dict(interval=10 ** 9, hooks=[])
+    cfg.data.workers_per_gpu = 0
+    cfg.data.val = dict(type='CocoDataset', ann_file=ann, img_prefix=str(tmp_path), pipeline=[
+        dict(type='LoadImageFromFile'),
+        dict(type='MultiScaleFlipAug', img_scale=(480, 384), flip=False, transforms=[
+            dict(type='Resize', keep_ratio=True), dict(type='RandomFlip'), dict(type='Normalize', **NORM),
+            dict(type='Pad', size_divisor=32), dict(type='ImageToTensor', keys=['img']), dict(type='Collect', keys=['img'])])])
+    cfg.evaluation = dict(interval=1, metric=['bbox'])
+    lines = []
+    runner = train_detector(model, [build_dataloader(train, 1, 0, dist=False, shuffle=True, seed=0)], cfg, distributed=False,
+                            validate=True, logger=lines.append, channels_last=False)
+    assert runner.epoch == 1 and -1 <= runner.eval_results['bbox_mAP'] <= 1
+    assert any('Epoch(val) [1]' in str(s) and 'bbox_mAP' in str(s) for s in lines)
+    assert model.training
