@@ -306,33 +306,7 @@ def test_single_process_group_sampler_equals_reference():
         assert ours == list(Ref(ds, spg)) and len(ours) % spg == 0
 
 
-def test_train_detector_from_coco_files(tmp_path):
-    """COCO json + image files -> CocoDataset -> pipeline -> loader -> train_detector: two optimizer steps of the real
-    LSNet (R-50, bbox task) on CPU, native ops served by the oracle backend (test infrastructure)."""
-    from lsnet_amd.apis import train_detector
-    from lsnet_amd.model_zoo import build_lsnet
-    from lsnet_amd.ops import register_backend
-    from tests.oracle_backend import OracleBackend
-    register_backend('cpu', OracleBackend())
-    ann = _write_images(str(tmp_path))
-    cls, load_kw, keys = TASKS['bbox']
-    ds = build_dataset(dict(type='CocoDataset', ann_file=ann, img_prefix=str(tmp_path),
-                            pipeline=[dict(type='LoadImageFromFile')] + _pipeline(load_kw, keys, scale=(480, 384))))
-    loader = build_dataloader(ds, samples_per_gpu=1, workers_per_gpu=0, dist=False, shuffle=True, seed=0)
-    torch.manual_seed(3)
-    torch.set_num_threads(8)
-    model, cfg = build_lsnet('bbox', 'r50')
-    cfg.total_epochs, cfg.workflow = 1, [('train', 1)]
-    cfg.log_config = dict(interval=1, hooks=[dict(type='TextLoggerHook')])
-    cfg.checkpoint_config = None
-    lines = []
-    before = model.bbox_head.pts_cls_out.weight.detach().clone()
-    runner = train_detector(model, [loader], cfg, distributed=False, logger=lines.append, channels_last=False)
-    assert runner.iter == len(loader) == 3 and runner.epoch == 1
-    assert not torch.equal(before, model.bbox_head.pts_cls_out.weight)
-    loss = float(runner.outputs['log_vars']['loss'])
-    assert np.isfinite(loss) and loss > 0
-    assert any('loss_bbox_refine' in str(s) for s in lines)
+# (training from COCO files end to end, with validation: tests/test_evaluation.py::test_train_detector_with_validation)
 
 
 def test_extreme_points_equal_reference_fixture_and_tool(tmp_path):
