@@ -233,7 +233,7 @@ class LSCPVHead(LSHead):
         points, flags, all_valid = self.get_points(featmap_sizes, img_metas, device)
         num_level = [p.shape[0] for p in points]
         tg, n_tl, n_br = self.get_hm_targets(torch.cat(points), [torch.cat(f) for f in flags], all_valid, gt_bboxes)
-        B = cls_scores[0].shape[0]
+        assert cls_scores[0].shape[0] == gt_sem_map.shape[0] == len(gt_bboxes)
 
         def levels(t):
             return torch.split(t, num_level, dim=1)
@@ -255,7 +255,6 @@ class LSCPVHead(LSHead):
         sem_gt = torch.cat([F.interpolate(gt_sem_map, s.shape[-2:]).reshape(-1) for s in sem_scores])
         sem_w = torch.cat([F.interpolate(gt_sem_weights, s.shape[-2:]).reshape(-1) for s in sem_scores])
         out['loss_sem'] = self.loss_sem(sem_pred, sem_gt, sem_w, avg_factor=(sem_gt > 0).sum())
-        assert B == gt_sem_map.shape[0]
         return out
 
     # ----------------------------------------------------------------------------------- decoding
