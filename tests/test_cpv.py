@@ -161,7 +161,7 @@ def test_cpv_detector_trains_and_tests_from_coco_files(tmp_path, cpu_oracle_back
     model.test_cfg.nms_pre, model.test_cfg.max_per_img, model.test_cfg.score_thr = 30, 20, 0.0
     test_ds = build_dataset(dict(type='CocoDataset', ann_file=ann, img_prefix=str(tmp_path), test_mode=True, pipeline=[
         dict(type='LoadImageFromFile'),
-        dict(type='MultiScaleFlipAug', img_scale=[(480, 384)], flip=True, transforms=[
+        dict(type='MultiScaleFlipAug', img_scale=[(240, 192)], flip=True, transforms=[
             dict(type='Resize', keep_ratio=True), dict(type='RandomFlip'), dict(type='Normalize', **NORM),
             dict(type='Pad', size_divisor=32), dict(type='ImageToTensor', keys=['img']), dict(type='Collect', keys=['img'])])]))
     item = test_ds[0]

@@ -40,5 +40,5 @@ def test_cpv_head_forward_loss_backward_decode(cpu_oracle_backend):
 
 def test_training_curve_follows_reference_runner(cpu_oracle_backend):
     torch.set_num_threads(8)
-    worst = gc.train_curve_case(CPU, early_tol=1e-4, late_tol=0.15, rtol_weight=5e-2)
-    print(f'worst relative loss deviation over 12 iterations: {worst:.2e}')
+    worst = gc.train_curve_case(CPU, early_tol=1e-4, late_tol=0.15, rtol_weight=5e-2, iters=8)   # the GPU test runs all 12
+    print(f'worst relative loss deviation over 8 iterations: {worst:.2e}')
