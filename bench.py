@@ -153,7 +153,7 @@ def cpu_baseline(args):
         t0 = time.time()
         for _ in range(nstep):
             out = step(data)
-            loss = float(out['loss'])
+            loss = float(out['loss'].detach())
         dt = (time.time() - t0) / nstep
     finally:
         unregister_backend('cpu')
