@@ -276,7 +276,7 @@ class CocoDataset(CustomDataset):
         Metrics: 'bbox', 'segm' (and 'keypoints' on CocoPoseDataset); the proposal metrics of two-stage detectors are
         not on the LSNet path."""
         from ..evaluation.coco_eval import CocoEval, load_results
-        log = logger if callable(logger) else (lambda s: None)
+        log = logger if callable(logger) else (logger.info if hasattr(logger, 'info') else (lambda s: None))
         metrics = metric if isinstance(metric, list) else [metric]
         for m in metrics:
             if m not in self.ALLOWED_METRICS:
