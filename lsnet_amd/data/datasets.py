@@ -414,7 +414,8 @@ def build_dataloader(dataset, samples_per_gpu, workers_per_gpu, num_gpus=1, dist
                      rank=None, world_size=None, **kwargs):
     """builder.py:60-125.  Distributed: this process loads `samples_per_gpu` images per step for its own GPU, indices
     from DistributedGroupSampler (shuffled, one aspect-ratio group per mini-batch, padded so every rank runs the same
-    number of steps).  `pin_memory` defaults on: `scatter` then copies asynchronously."""
+    number of steps).  `pin_memory` stays off as in the reference (the loader's pinning thread does not look inside
+    DataContainers); `scatter` pins what it uploads through torch's caching host allocator and copies asynchronously."""
     if rank is None or world_size is None:
         import torch.distributed as td
         ok = td.is_available() and td.is_initialized()
