@@ -79,6 +79,15 @@ void lsn_image_normalize_u8(const uint8_t *src, size_t pixels, int c, const floa
 void lsn_image_normalize_f32(const float *src, size_t pixels, int c, const float *mean, const float *inv_std,
                              int reverse_channels, float *dst);
 
+/* The two host-only members of the reference's `nms_ext` module (mmdet/ops/nms/src/nms_ext.cpp:29-43, cpu/nms_cpu.cpp:
+ * 63-258); `dets` is (n, 5) float32 [x1, y1, x2, y2, score].
+ * lsn_soft_nms: method 1 linear, 2 gaussian, other = hard; out has room for n rows [x1, y1, x2, y2, score, index];
+ *               returns the number of rows written.
+ * lsn_nms_match: `order` = box indices by descending score; flat (n) receives the groups back to back (keeper first),
+ *               group_start (n + 1) their boundaries; returns the number of groups. */
+size_t lsn_soft_nms(const float *dets, size_t n, float iou_thr, int method, float sigma, float min_score, float *out);
+size_t lsn_nms_match(const float *dets, const int64_t *order, size_t n, float iou_thr, int64_t *flat, int64_t *group_start);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,7 +40,7 @@ def build(force=False, verbose=False):
 
 HOST_SO = os.path.join(HERE, 'liblsnet_host.so')
 HOST_SOURCES = [os.path.join('host', 'rle.cpp'), os.path.join('host', 'coco_match.cpp'),
-                os.path.join('host', 'image.cpp')]
+                os.path.join('host', 'image.cpp'), os.path.join('host', 'nms_host.cpp')]
 HOST_HEADERS = [os.path.join('..', '..', 'include', 'lsnet_host.h')]
 
 

@@ -42,3 +42,50 @@ def batched_nms(bboxes, scores, inds, nms_cfg, class_agnostic=False):
         raise NotImplementedError(f'nms type {nms_type!r} is outside the LSNet hot path')
     dets, keep = nms(torch.cat([boxes_for_nms, scores[:, None]], -1), **cfg)
     return torch.cat([bboxes[keep], dets[:, -1:]], -1), keep
+
+
+def _host():
+    from ..evaluation.mask import lib
+    return lib()
+
+
+def soft_nms(dets, iou_thr, method='linear', sigma=0.5, min_score=1e-3):
+    """Soft NMS on the host (nms_wrapper.py:62-116; the reference has no device version either): returns
+    (new_dets (k, 5), inds (k,)) in the type of the input."""
+    import ctypes as C
+    if isinstance(dets, torch.Tensor):
+        is_tensor, arr = True, dets.detach().cpu().numpy()
+    elif isinstance(dets, np.ndarray):
+        is_tensor, arr = False, dets
+    else:
+        raise TypeError(f'dets must be either a Tensor or numpy array, but got {type(dets)}')
+    codes = {'linear': 1, 'gaussian': 2}
+    if method not in codes:
+        raise ValueError(f'Invalid method for SoftNMS: {method}')
+    a = np.ascontiguousarray(arr, dtype=np.float32).reshape(-1, 5)
+    out = np.zeros((len(a), 6), dtype=np.float32)
+    f32 = C.POINTER(C.c_float)
+    k = _host().lsn_soft_nms(a.ctypes.data_as(f32), len(a), float(iou_thr), codes[method], float(sigma), float(min_score),
+                             out.ctypes.data_as(f32)) if len(a) else 0
+    new_dets, inds = out[:k, :5], out[:k, 5].astype(np.int64)
+    if is_tensor:
+        return torch.from_numpy(new_dets).to(device=dets.device, dtype=dets.dtype), torch.from_numpy(inds).to(dets.device)
+    return new_dets.astype(arr.dtype), inds
+
+
+def nms_match(dets, thresh):
+    """Groups of boxes that NMS would merge (nms_wrapper.py:160-191): one index array per kept box, the keeper first."""
+    import ctypes as C
+    if dets.shape[0] == 0:
+        return []
+    assert dets.shape[-1] == 5, f'inputs dets.shape should be (N, 5), but get {dets.shape}'
+    is_tensor = isinstance(dets, torch.Tensor)
+    t = dets.detach().cpu().float() if is_tensor else torch.from_numpy(np.ascontiguousarray(dets, dtype=np.float32))
+    order = t[:, 4].sort(0, descending=True)[1].contiguous().numpy()
+    a = np.ascontiguousarray(t.numpy())
+    flat, start = np.zeros(len(a), np.int64), np.zeros(len(a) + 1, np.int64)
+    i64 = C.POINTER(C.c_int64)
+    g = _host().lsn_nms_match(a.ctypes.data_as(C.POINTER(C.c_float)), order.ctypes.data_as(i64), len(a), float(thresh),
+                              flat.ctypes.data_as(i64), start.ctypes.data_as(i64))
+    groups = [flat[start[k]:start[k + 1]].copy() for k in range(g)]
+    return [dets.new_tensor(m, dtype=torch.long) for m in groups] if is_tensor else groups

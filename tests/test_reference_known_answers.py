@@ -105,3 +105,45 @@ def test_dataset_wrappers_index_as_the_reference_expects():
     rep = RepeatDataset(a, 10)
     assert rep[5] == 5 and rep[15] == 5 and rep[27] == 7 and len(rep) == 100
     assert rep.get_cat_ids(15) == a.cats[5] and rep.get_cat_ids(27) == a.cats[7]
+
+
+def test_soft_nms_and_nms_match_known_answers_and_reference_library():
+    """The reference's doctest vector for soft NMS (mmdet/ops/nms/nms_wrapper.py:78-87) and its tests/test_ops/
+    test_nms.py:86-108 / test_soft_nms.py expectations; where oracle/_ref/nms_ext.so (built from the reference's
+    nms_cpu.cpp) exists, random boxes index for index against it, all three decay methods."""
+    from lsnet_amd.ops import nms_match, soft_nms
+    dets = np.array([[4., 3., 5., 3., 0.9], [4., 3., 5., 4., 0.9], [3., 1., 3., 1., 0.5], [3., 1., 3., 1., 0.5],
+                     [3., 1., 3., 1., 0.4], [3., 1., 3., 1., 0.0]], dtype=np.float32)
+    new_dets, inds = soft_nms(dets, 0.6, sigma=0.5)
+    assert len(inds) == len(new_dets) == 5 and new_dets.dtype == np.float32 and inds.dtype == np.int64
+    t_dets, t_inds = soft_nms(torch.from_numpy(dets), 0.6, method='gaussian')
+    assert isinstance(t_dets, torch.Tensor) and t_inds.dtype == torch.long and len(t_inds) == len(t_dets)
+    with pytest.raises(ValueError):
+        soft_nms(dets, 0.6, method='cubic')
+    assert nms_match(np.zeros((0, 5), np.float32), 0.5) == []
+    boxes = np.array([[49.1, 32.4, 51.0, 35.9, 0.9], [49.3, 32.9, 51.0, 35.3, 0.9], [35.3, 11.5, 39.9, 14.5, 0.4],
+                      [35.2, 11.7, 39.7, 15.7, 0.3]], dtype=np.float32)       # test_nms.py's boxes
+    groups = nms_match(boxes, 0.1)
+    assert sorted(int(i) for g in groups for i in g) == [0, 1, 2, 3] and all(len(g) == 2 for g in groups)
+    tg = nms_match(torch.from_numpy(boxes), 0.1)
+    assert all(isinstance(g, torch.Tensor) and g.dtype == torch.long for g in tg)
+
+    from oracle import build_ref
+    ref = build_ref.load() if build_ref.available() else None
+    if ref is None:
+        return
+    rng = np.random.RandomState(0)
+    for n in (1, 7, 60, 300):
+        xy = rng.rand(n, 2) * 60
+        wh = rng.rand(n, 2) * 30 + 1
+        d = np.concatenate([xy, xy + wh, rng.rand(n, 1)], 1).astype(np.float32)
+        for method, code in (('linear', 1), ('gaussian', 2)):
+            want = ref.soft_nms(torch.from_numpy(d), 0.5, code, 0.5, 0.05)
+            got_d, got_i = soft_nms(d, 0.5, method=method, sigma=0.5, min_score=0.05)
+            assert np.array_equal(want[:, 5].numpy().astype(np.int64), got_i), (n, method)
+            np.testing.assert_allclose(got_d, want[:, :5].numpy(), rtol=1e-6, atol=1e-7)
+        scores_unique = d.copy()
+        scores_unique[:, 4] = rng.permutation(n) / n                          # no ties: the sort order is unambiguous
+        want = ref.nms_match(torch.from_numpy(scores_unique), 0.3)
+        got = nms_match(scores_unique, 0.3)
+        assert [list(map(int, g)) for g in got] == [list(g) for g in want], n
