@@ -38,9 +38,10 @@ def batched_nms(bboxes, scores, inds, nms_cfg, class_agnostic=False):
         offsets = inds.to(bboxes) * (max_coordinate + 1)
         boxes_for_nms = bboxes + offsets[:, None]
     nms_type = cfg.pop('type', 'nms')
-    if nms_type != 'nms':
-        raise NotImplementedError(f'nms type {nms_type!r} is outside the LSNet hot path')
-    dets, keep = nms(torch.cat([boxes_for_nms, scores[:, None]], -1), **cfg)
+    if nms_type not in ('nms', 'soft_nms'):
+        raise NotImplementedError(f'nms type {nms_type!r} is not one of nms_wrapper.py\'s operators')
+    op = nms if nms_type == 'nms' else soft_nms            # soft_nms runs on the host, as in the reference
+    dets, keep = op(torch.cat([boxes_for_nms, scores[:, None]], -1), **cfg)
     return torch.cat([bboxes[keep], dets[:, -1:]], -1), keep
 
 
