@@ -12,14 +12,16 @@ losses, backward, RCCL gradient all-reduce (N > 1), clip-grad-norm 35 and the SG
 hooks a real run uses (lsnet_amd/runner).  Inputs are resident in HBM before the timed region.
 
 Prints ONE JSON line (rank 0):  value = total images / s over all N GPUs (weak scaling, 2 img/GPU).
-  roofline     : the hand-written kernel family with the most GPU time in the timed steps (a deformable-convolution
-                 kernel): algorithmic FLOPs of its launches / their HIP-event time (events recorded by the library
-                 around each kernel on its launch stream), against the MFMA peak of its arithmetic -- 2516 / 3 TFLOP/s
-                 for split-bf16 products, 157.3 for exact fp32 (MI355X_MICROARCH.md); `traffic` from rocprofv3 counters.
-  fp32_exact   : the same step with --math fp32 (exact fp32 MFMA kernels, MIOpen fp32 convolutions), 5 steps.
-  cpu_baseline : the same training step on the host CPU (this repo's host code with the CPU oracle
-                 standing behind the native ops -- the reference has no CPU path for them), on a
-                 bounded sample, rank 0 at N=1 only.
+  value        : at the library's default arithmetic 'bf16x6' = fp32-equivalent (include/lsnet_hip.h).
+  roofline     : the hand-written kernel family with the most GPU time in the step (a deformable-convolution family):
+                 algorithmic FLOPs of its launches / their HIP-event time (events recorded by the library around each
+                 family's kernels on the launch stream, over the timed steps), against the MFMA
+                 peak of its arithmetic -- 2516 / 6 TFLOP/s for 'bf16x6', 157.3 for exact fp32 (MI355X_MICROARCH.md);
+                 `traffic`: HBM bytes of this step's own launch shapes from committed rocprofv3 counter passes.
+  extra        : the same step in the other arithmetic modes (bf16x3: 3-term split; fp32: exact fp32 MFMA + MIOpen),
+                 5 steps each, and BASELINE config 5 (pose-head inference, bs 4).
+  cpu_baseline : BASELINE config 1 (2 x 3x800x800) on the host CPU: this repo's host code with the CPU oracle standing
+                 behind the native ops -- the reference has no CPU path for them -- rank 0 at N=1 only.
 """
 import argparse
 import json
@@ -35,15 +37,13 @@ os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')   # ROCm 7.2 hipGra
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-# HBM traffic per launch (GB) from the committed PMC passes, profiles/r1c_pmc_hbm.txt: mean over the 8 launches
-# of a step of FETCH_SIZE (KB; doubled as MI355X_MICROARCH.md "HBM" prescribes for gfx950) + WRITE_SIZE (KB).
-# bwd_data's 2 GB of writes are its fp32 atomics reaching the memory side (36 atomic adds per input element).
-HBM_TRAFFIC_GB = {'dcn_fwd': 0.93, 'dcn_bwd_data': 3.06, 'dcn_wgrad': 1.08}
-# split-bf16 kernels with the XCD-aware work order, profiles/r1r_pmc_hbm_ops_xcd.txt (before it: r1q_...): counters of ONE tower-shaped launch (52.8 GFLOP, i.e. 2/3 of the mean
-# launch of the step, random offsets): FETCH_SIZE x 2 + WRITE_SIZE
-HBM_TRAFFIC_X3_GB = {'dcn_fwd': 2 * 0.057 + 0.045, 'dcn_bwd_data': 2 * 0.187 + 1.461, 'dcn_wgrad': 2 * 0.083 + 0.067}
 BF16_MFMA_PEAK_TFLOPS = 2516.6   # MI355X_MICROARCH.md: ~2.5 PF dense bf16
-FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, 2.4 GHz x 256 CU
+FP32_MFMA_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, 2.4 GHz x 256 CU
+PRODUCTS = {'bf16x6': 6, 'bf16x3': 3}
+# HBM traffic of the deformable-conv launches of THIS step (tower launch over 5 levels, pyramid launch over 15 pairs),
+# written by tools/pmc_step_shapes.sh from rocprofv3 FETCH_SIZE / WRITE_SIZE passes (separate passes; FETCH doubled as
+# MI355X_MICROARCH.md prescribes for gfx950) and committed with the round's profiles
+TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'r2_hbm_traffic.json')
 
 
 def parse():
@@ -59,9 +59,11 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--nchw', action='store_true', help='run in contiguous NCHW memory format (slower)')
-    ap.add_argument('--math', default='bf16x3', choices=['bf16x3', 'fp32'],
-                    help="arithmetic of the conv / deformable-conv contractions: split-bf16 products on the matrix pipe "
-                         "with fp32 accumulation (rel. err 5e-6, the library default) or exact fp32 MFMA")
+    ap.add_argument('--math', default='bf16x6', choices=['bf16x6', 'bf16x3', 'fp32'],
+                    help="arithmetic of the conv / deformable-conv contractions: 'bf16x6' = fp32-equivalent (exact 3-way "
+                         "bf16 split of every operand, 6 product terms, fp32 accumulation; the library default), "
+                         "'bf16x3' = 2-way split, 3 terms (rel. err 5e-6), 'fp32' = exact fp32 MFMA")
+    ap.add_argument('--no-extra', action='store_true', help='skip the extra legs (other arithmetic modes, inference)')
     ap.add_argument('--graph', action='store_true',
                     help='replay forward+backward from one captured hipGraph (runner/graph_step.py) instead of '
                          'launching every kernel eagerly; same speed while the step is GPU-bound')
@@ -69,17 +71,26 @@ def parse():
 
 
 KERNEL_NOTES = {
-    'bf16x3': {
-        'dcn_fwd': 'lsn::dcn_fwd_x3_kernel (fused bilinear gather + split-bf16 MFMA implicit GEMM, forward)',
-        'dcn_bwd_data': 'lsn::dcn_bwd_data_x3_kernel (gout x W^T as split-bf16 MFMA, merged bilinear scatter: grad '
-                        'input/offset/mask)',
-        'dcn_wgrad': 'lsn::dcn_wgrad_x3_kernel (gathered columns^T x gout as split-bf16 MFMA: grad weight/bias)',
+    'split': {
+        'dcn_fwd': 'lsn::dcn_fwd_xn_kernel (fused bilinear gather + split-bf16 MFMA implicit GEMM, forward)',
+        'dcn_bwd_data': 'lsn::dcn_bwd_data_xn_kernel + dcn_gather_kernel (gout x W^T as split-bf16 MFMA -> grad offset/mask '
+                        'and mask-weighted column gradients; grad input by an atomic-free gather over per-anchor sample '
+                        'lists: dcn_bin / scan / fill / sort_lists kernels, all inside the timed bracket)',
+        'dcn_wgrad': 'lsn::dcn_wgrad_xn_kernel (gathered columns^T x gout as split-bf16 MFMA: grad weight/bias)',
     },
     'fp32': {
         'dcn_fwd': 'lsn::dcn_fwd_pipe_kernel (fused bilinear gather + fp32 MFMA implicit GEMM, forward)',
         'dcn_bwd_data': 'lsn::dcn_bwd_data_kernel / _win_kernel (gout x W^T on fp32 MFMA, fused bilinear scatter)',
         'dcn_wgrad': 'lsn::dcn_wgrad_kernel (gathered columns^T x gout on fp32 MFMA: grad weight/bias)',
     },
+}
+MATH_NOTES = {
+    'bf16x6': 'fp32 tensors; every conv / deformable-conv product a*b evaluated as 6 bf16 MFMA terms of the EXACT 3-way '
+              'bf16 splits a = h+m+l, b = h+m+l (hh+hm+mh+mm+hl+lh; dropped terms <= 2^-25 relative, below the 2^-24 '
+              'rounding of an fp32 product), fp32 accumulation: fp32-equivalent, <= 1e-6 of the output range against the '
+              'exact-fp32 MFMA kernels (tests/test_ops_gpu.py::test_split6_matches_exact_fp32)',
+    'bf16x3': 'fp32 tensors; products as 3 bf16 MFMA terms of 2-way splits (hh+hl+lh), fp32 accumulation, rel. err 5e-6',
+    'fp32': 'exact fp32 MFMA for the deformable family, MIOpen fp32 for dense convolutions',
 }
 
 
@@ -130,18 +141,18 @@ def build_step(model, cfg):
 
 
 def cpu_baseline(args):
-    """The training step on the host CPU: this repo's host code + the CPU oracle behind the native
-    ops (test infrastructure used as the timed baseline, never as the product path)."""
+    """BASELINE config 1 on the host: the training step of the same model on 2 images 3x800x800 with this repo's host
+    code and the CPU oracle behind the native ops (the reference has no CPU path for them: SURVEY.md section 0.2), all
+    host cores, one warm-up step excluded.  Test infrastructure used as the timed baseline, never as the product."""
     from lsnet_amd.data import synthetic_batch
     from lsnet_amd.model_zoo import build_lsnet
     from lsnet_amd.ops import register_backend, unregister_backend
     from tests.oracle_backend import OracleBackend
     from oracle import oracle_py
-    h, w, b = 416, 672, 1          # bounded sample: 1 image at ~1/4 of the 800x1344 area
+    h, w, b = 800, 800, 2
     cores = os.cpu_count() or 1
-    threads = min(cores, 64)
-    torch.set_num_threads(threads)
-    os.environ.setdefault('OMP_NUM_THREADS', str(threads))
+    torch.set_num_threads(cores)
+    os.environ.setdefault('OMP_NUM_THREADS', str(cores))
     register_backend('cpu', OracleBackend())
     try:
         torch.manual_seed(0)
@@ -149,7 +160,10 @@ def cpu_baseline(args):
         model.train()
         step, _ = build_step(model, cfg)
         data = synthetic_batch(args.task, b, h, w, seed=99, device='cpu', channels_last=False)
-        nstep = 2
+        t0 = time.time()
+        step(data)                                   # warm-up (allocations, thread pools), not timed
+        warm = time.time() - t0
+        nstep = 3 if warm < 25 else 1                # keep the whole bench run inside a few minutes
         t0 = time.time()
         for _ in range(nstep):
             out = step(data)
@@ -157,10 +171,70 @@ def cpu_baseline(args):
         dt = (time.time() - t0) / nstep
     finally:
         unregister_backend('cpu')
-    return dict(value=b / dt, unit='img/s', cores=threads, kind='port',
-                sample=f'{nstep} training steps (fwd+bwd+clip+SGD) of the same model on {b} image 3x{h}x{w} '
-                       f'({oracle_py.num_threads()} OpenMP threads in the oracle, {threads} torch threads, '
-                       f'{cores} host cores), {dt:.1f} s per step, last loss {loss:.3f}')
+    return dict(value=b / dt, unit='img/s', cores=cores, kind='port',
+                sample=f'BASELINE config 1: {nstep} timed training step(s) (fwd+bwd+clip+SGD; 1 warm-up step of '
+                       f'{warm:.1f} s excluded) of LSNet {args.backbone.upper()}-FPN {args.task} on {b} images 3x{h}x{w}, '
+                       f'torch.set_num_threads({cores}), {oracle_py.num_threads()} OpenMP threads in the oracle, '
+                       f'{dt:.1f} s per step, last loss {loss:.3f}')
+
+
+def infer_leg(dev):
+    """BASELINE config 5: LSNet R-50-FPN pose head (17 keypoints), 4 images 3x800x1344, forward + decode + NMS on the
+    device (the reference's tools/benchmark.py:63-89 times the same region at batch 1)."""
+    from lsnet_amd.model_zoo import build_lsnet
+    B, H, W = 4, 800, 1344
+    torch.manual_seed(0)
+    model, _ = build_lsnet('pose_kbox', 'r50')
+    model = model.to(dev).to(memory_format=torch.channels_last).eval()
+    with torch.no_grad():
+        # random-init classification logits sit at -4.6 (bias init) and nothing would pass score_thr = 0.05: shift the
+        # bias so that a realistic share of the points survives and the decode / NMS stages do real work
+        model.bbox_head.pts_cls_out.bias.add_(2.0)
+    img = torch.randn(B, 3, H, W, device=dev).contiguous(memory_format=torch.channels_last)
+    metas = [dict(pad_shape=(H, W, 3), img_shape=(H, W, 3), scale_factor=1.0, ori_shape=(H, W, 3), flip=False)] * B
+    with torch.no_grad():
+        for _ in range(2):
+            dets = model.simple_test_batch(img, metas)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 5
+        for _ in range(n):
+            dets = model.simple_test_batch(img, metas)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+    return dict(metric='inference latency LSNet R-50-FPN pose head (17 kps), bs 4, 3x800x1344, decode + NMS included',
+                ms_per_batch=dt * 1e3, img_per_s=B / dt, detections_img0=int(dets[0][0].shape[0]))
+
+
+def timed_steps(step, data, n, warm):
+    for _ in range(warm):
+        step(data)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step(data)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+def allreduce_probe(model, dev, world, reps=5):
+    """Stand-alone time of one gradient all-reduce of the step (all buckets, back to back, nothing to overlap with)."""
+    flats = [b['flat'] for b in model.reducer.buckets]
+    for _ in range(2):
+        for f in flats:
+            dist.all_reduce(f)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        works = [dist.all_reduce(f, async_op=True) for f in flats]
+        for w in works:
+            w.wait()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    nbytes = sum(f.numel() * 4 for f in flats)
+    return dict(allreduce_ms_per_step_standalone=dt * 1e3, allreduce_mbytes=nbytes / 1e6, buckets=len(flats),
+                allreduce_algbw_gbps=nbytes / dt / 1e9)
 
 
 def main():
@@ -216,7 +290,7 @@ def main():
         get_backend(mk).selftest_mfma(mk, mk, 0)
         torch.cuda.synchronize()
     if timer and not use_graph:
-        timer.start()
+        timer.start()      # HIP events around every deformable-conv family launch of the timed steps
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step(data)
@@ -226,13 +300,6 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ks = timer.stop() if (timer and not use_graph) else {}
-    if timer and use_graph:
-        # HIP events cannot bracket kernels inside a graph replay: the same kernels on the same tensors are
-        # launched eagerly for a few forward+backward passes right after the timed region and timed there
-        timer.start()
-        for _ in range(min(args.steps, 5)):
-            gs._fwd_bwd(data)
-        ks = timer.stop()
     if markers:
         get_backend(mk).selftest_mfma(mk, mk, 0)
         torch.cuda.synchronize()
@@ -241,67 +308,89 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     losses = out['log_vars'].items_as_float() if hasattr(out['log_vars'], 'items_as_float') else {}
-    alt = None
-    if args.math == 'bf16x3' and world == 1 and not use_graph:
-        # the same step with exact fp32 MFMA everywhere, for readers who only accept that arithmetic
-        _lib.set_math_mode('fp32')
-        for _ in range(2):
-            step(data)
-        torch.cuda.synchronize()
-        ta = time.perf_counter()
-        for _ in range(5):
-            step(data)
-        torch.cuda.synchronize()
-        ta = (time.perf_counter() - ta) / 5
-        alt = {'value': args.batch / ta, 'unit': 'img/s', 'ms_per_step': ta * 1e3, 'steps': 5,
-               'math': 'exact fp32 MFMA / MIOpen fp32 for every contraction (--math fp32)'}
+
+    nk = args.steps
+    if timer and use_graph:
+        # HIP events cannot bracket kernels inside a graph replay: the same kernels on the same tensors are launched
+        # eagerly for a few forward+backward passes right after the timed region and timed there
+        nk = min(args.steps, 5)
+        timer.start()
+        for _ in range(nk):
+            gs._fwd_bwd(data)
+        ks = timer.stop()
+    comm = allreduce_probe(model, dev, world) if world > 1 else None
+
+    extra = {}
+    if world == 1 and not use_graph and not args.no_extra:
+        for mode in ('bf16x3', 'fp32'):
+            if mode == args.math:
+                continue
+            _lib.set_math_mode(mode)
+            ta = timed_steps(step, data, 5, 2)
+            extra[mode] = {'value': args.batch / ta, 'unit': 'img/s', 'ms_per_step': ta * 1e3, 'steps': 5,
+                           'math': MATH_NOTES[mode]}
         _lib.set_math_mode(args.math)
+        try:
+            extra['infer_pose_bs4'] = infer_leg(dev)
+        except Exception as ex:   # an extra leg must never take the bench line down
+            extra['infer_pose_bs4'] = {'error': f'{type(ex).__name__}: {ex}'}
 
     if rank == 0:
         imgs = args.batch * world * args.steps
+        np_ = PRODUCTS.get(args.math, 0)
         res = {
             'metric': 'img/s train LSNet R-50-FPN 1333x800 bs2/GPU',
             'value': imgs / dt, 'unit': 'img/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'vs_baseline': None,
+            'dtype': {'bf16x6': 'f32 (fp32-equivalent: 6 bf16 MFMA terms per product on exact 3-way operand splits, '
+                                'fp32 accumulate)',
+                      'bf16x3': 'f32 tensors, bf16x3 split products (16 mantissa bits per operand)',
+                      'fp32': 'f32'}[args.math],
+            'data': 'synthetic',
             'config': {'workload': f'LSNet {args.backbone.upper()}-FPN {args.task} (conv_module_type=dcn), '
                                    f'{args.batch} img/GPU 3x{args.height}x{args.width} (1333x800 padded to /32), '
                                    f'7 gt/img, fwd+bwd+RCCL grad all-reduce+clip35+SGD',
-                       'global_batch': args.batch * world, 'parallelism': f'dp{world}',
+                       'global_batch': args.batch * world, 'parallelism': f'dp{world}', 'world_size': world,
                        'memory_format': 'nchw' if args.nchw else 'channels_last',
                        'launch': 'hipGraph replay of forward+backward; all-reduce, clip, SGD eager' if use_graph
                        else 'eager',
-                       'math': 'fp32 tensors; conv / deformable-conv products as 3 bf16 MFMAs on split operands '
-                               '(hi*hi + hi*lo + lo*hi), fp32 accumulation, rel. err 5e-6 vs exact fp32 (tests); '
-                               'small / grouped / stride-2-backward convs and all conv weight gradients stay on MIOpen fp32'
-                       if args.math == 'bf16x3' else 'exact fp32 MFMA / MIOpen fp32'},
+                       'math': MATH_NOTES[args.math]},
             'loss': {k: round(v, 5) for k, v in losses.items()},
         }
-        x3 = {'dcn_fwd', 'dcn_bwd_data', 'dcn_wgrad'} if args.math == 'bf16x3' else set()   # split-bf16 MFMA kernels
+        if world > 1:
+            try:
+                res['config']['rccl_version'] = '.'.join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:
+                res['config']['rccl_version'] = 'unknown'
+            res['config'].update(comm)
 
-        def peak_of(k):
-            return BF16_MFMA_PEAK_TFLOPS / 3.0 if k in x3 else FP32_MFMA_PEAK_TFLOPS
-
-        def peak_note(k):
-            return ('dense bf16 MFMA peak / 3 (three bf16 products per fp32 product)' if k in x3
-                    else 'dense fp32 MFMA peak (v_mfma_f32_*_f32)')
+        peak = BF16_MFMA_PEAK_TFLOPS / np_ if np_ else FP32_MFMA_PEAK_TFLOPS
+        peak_note = (f'dense bf16 MFMA peak / {np_} ({np_} bf16 products per fp32 product)' if np_
+                     else 'dense fp32 MFMA peak (v_mfma_f32_*_f32)')
         if ks:
-            dom = max(ks, key=lambda k: ks[k]['total_ms'])   # the kernel with the most GPU time in the timed steps
+            dom = max(ks, key=lambda k: ks[k]['total_ms'])   # the kernel family with the most GPU time
             k = ks[dom]
             res['kernels'] = ks
-            res['roofline'] = {'kernel': KERNEL_NOTES[args.math].get(dom, dom), 'bound': 'mfma', 'achieved': k['tflops'],
-                               'peak': peak_of(dom), 'unit': 'TFLOP/s',
-                               'frac': k['tflops'] / peak_of(dom), 'peak_note': peak_note(dom), 'traffic': (HBM_TRAFFIC_GB if args.math == 'fp32' else HBM_TRAFFIC_X3_GB).get(dom),
-                               'traffic_unit': 'GB/launch, rocprofv3 FETCH_SIZE x2 + WRITE_SIZE: ' + (
-                                   'mean launch of the step, profiles/r1c_pmc_hbm.txt' if args.math == 'fp32' else
-                                   'one 52.8-GFLOP tower launch of the micro-benchmark (the mean launch of the step is '
-                                   '79.3 GFLOP), profiles/r1r_pmc_hbm_ops_xcd.txt'),
+            traffic, traffic_note = None, 'not measured'
+            try:
+                with open(TRAFFIC_FILE) as f:
+                    tf = json.load(f)
+                if tf.get('math') == args.math and dom in tf.get('kernels', {}):
+                    e = tf['kernels'][dom]
+                    traffic = e['gbytes_per_mean_launch']
+                    traffic_note = e['note']
+            except (OSError, ValueError, KeyError):
+                pass
+            res['roofline'] = {'kernel': KERNEL_NOTES['split' if np_ else 'fp32'].get(dom, dom), 'bound': 'mfma',
+                               'achieved': k['tflops'], 'peak': peak, 'unit': 'TFLOP/s', 'frac': k['tflops'] / peak,
+                               'peak_note': peak_note, 'traffic': traffic, 'traffic_unit': 'GB per mean launch: ' + traffic_note,
                                'launches_timed': k['launches'], 'avg_launch_ms': k['avg_ms'],
                                'gflop_per_launch': k['gflop_per_launch'],
                                'alg_gbytes_per_launch': k['alg_gbytes_per_launch'],
-                               'ms_per_step': k['total_ms'] / args.steps}
-        if alt is not None:
-            res['fp32_exact'] = alt
+                               'ms_per_step': k['total_ms'] / max(nk, 1)}
+        if extra:
+            res['extra'] = extra
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res['cpu_baseline'] = cpu_baseline(args)

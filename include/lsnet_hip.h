@@ -73,9 +73,12 @@ typedef struct {
                         * gradient w.r.t. the logits.  Lets a DCNv2 pack hand its (B, 3*dg*kh*kw, H, W)
                         * conv_offset output to the op as ONE tensor (offset = first 2/3 of the channels,
                         * mask = last 1/3, deform_conv.py:527-530) and get ONE gradient tensor back. */
-    void *workspace;   /* optional device scratch of >= Co*kh*kw*(C/groups)*4 bytes: lsn_dcn_backward in
-                        * LSN_MATH_BF16X3 mode puts the split, transposed weights there and runs the matrix-pipe
-                        * backward-data kernel; NULL keeps the fp32 MFMA kernels.  Contents undefined afterwards. */
+    void *workspace;   /* optional device scratch of >= Co*kh*kw*(C/groups)*8 bytes: in the split-bf16 math modes
+                        * the pre-split (backward: also transposed) weight planes go there and the matrix-pipe
+                        * kernels run; NULL: weights are split inside every block (forward) / the fp32 MFMA
+                        * backward-data kernel runs.  Contents undefined afterwards. */
+    void *gather_workspace;          /* optional device scratch for lsn_dcn_backward's atomic-free grad_input path */
+    int64_t gather_workspace_bytes;  /* (>= lsn_dcn_backward_workspace_bytes()); NULL / too small: fp32 atomics.   */
 } lsn_dcn_shape;
 
 /* One (source map, offset field, output) triple of a batched launch.  All levels of a launch
@@ -101,12 +104,16 @@ int lsn_version(void);
 
 /* ---- arithmetic of the contractions ---------------------------------------------------------
  * LSN_MATH_FP32   : v_mfma_f32_*_f32, exact fp32 products (bitwise an fmaf chain); fp32 vector rate.
- * LSN_MATH_BF16X3 : every fp32 operand is split into two bf16 values (hi + lo, 16 mantissa bits together) and a
- *                   product is hi*hi + hi*lo + lo*hi on the bf16 matrix pipe with fp32 accumulation: relative
- *                   error <= 2^-16 per product (the reference's tolerance for this path is 1e-3), 16x the MFMA rate.
- * Process-wide; the initial value comes from the environment variable LSNET_MATH (fp32 | bf16x3), default bf16x3.
+ * LSN_MATH_BF16X6 : (default) fp32-EQUIVALENT.  Every fp32 operand is split exactly into three bf16 values
+ *                   (h + m + l, 24 mantissa bits) and a product is h*h + h*m + m*h + m*m + h*l + l*h on the bf16
+ *                   matrix pipe with fp32 accumulation; the dropped terms are <= 2^-25 relative, below the 2^-24
+ *                   rounding of an fp32 product, so results differ from LSN_MATH_FP32 by summation order only
+ *                   (tests: <= 1e-6 of the output range).  2516 / 6 = 419 TFLOP/s peak against 157 for fp32 MFMA.
+ * LSN_MATH_BF16X3 : two bf16 values per operand (16 mantissa bits), products h*h + h*l + l*h: relative error
+ *                   <= 2^-16 per product (the reference's tolerance for this path is 1e-3).  Opt-in.
+ * Process-wide; the initial value comes from the environment variable LSNET_MATH (fp32 | bf16x3 | bf16x6).
  * Kernels without a split variant keep using fp32 MFMA. */
-enum { LSN_MATH_FP32 = 0, LSN_MATH_BF16X3 = 1 };
+enum { LSN_MATH_FP32 = 0, LSN_MATH_BF16X3 = 1, LSN_MATH_BF16X6 = 2 };
 int lsn_set_math_mode(int mode);
 int lsn_get_math_mode(void);
 
@@ -122,6 +129,12 @@ int lsn_dcn_forward(const lsn_dcn_shape *shape, int n_levels, const lsn_dcn_leve
 int lsn_dcn_backward(const lsn_dcn_shape *shape, int n_levels, const lsn_dcn_level *levels,
                      const float *weight, float *grad_weight, float *grad_bias, lsn_layout layout,
                      lsn_stream_t stream);
+
+/* Bytes of `gather_workspace` that let lsn_dcn_backward form grad_input without atomics (per-anchor sample lists +
+ * a column-gradient buffer of sum(B*Ho*Wo) * kh*kw * C floats, written and read once); 0 when that path does not
+ * apply to the shape (groups > 1, Co > 256, exact-fp32 mode, no grad_input requested).  Levels whose grad_input
+ * pointers are EQUAL accumulate into that one buffer (several offset fields sampling one source map). */
+int64_t lsn_dcn_backward_workspace_bytes(const lsn_dcn_shape *shape, int n_levels, const lsn_dcn_level *levels);
 
 /* ---- one-to-one replacements of the reference extension's functions ----------------------- */
 /* Each takes contiguous NCHW tensors like the reference and the same scalar arguments in the

@@ -23,7 +23,8 @@ class DcnShape(ctypes.Structure):
                 ('kh', ctypes.c_int), ('kw', ctypes.c_int), ('stride', ctypes.c_int), ('pad', ctypes.c_int),
                 ('dil', ctypes.c_int), ('groups', ctypes.c_int), ('deformable_groups', ctypes.c_int),
                 ('scale_h', ctypes.c_float), ('scale_w', ctypes.c_float), ('mask_is_logit', ctypes.c_int),
-                ('workspace', ctypes.c_void_p)]
+                ('workspace', ctypes.c_void_p), ('gather_workspace', ctypes.c_void_p),
+                ('gather_workspace_bytes', ctypes.c_int64)]
 
 
 class DcnLevel(ctypes.Structure):
@@ -47,7 +48,7 @@ class ProfEntry(ctypes.Structure):
 
 # every symbol include/lsnet_hip.h declares (checked by tests/test_capi.py without a GPU)
 EXPORTS = [
-    'lsn_last_error', 'lsn_version', 'lsn_dcn_forward', 'lsn_dcn_backward',
+    'lsn_last_error', 'lsn_version', 'lsn_dcn_forward', 'lsn_dcn_backward', 'lsn_dcn_backward_workspace_bytes',
     'lsn_deform_conv_forward', 'lsn_deform_conv_backward_input', 'lsn_deform_conv_backward_parameters',
     'lsn_modulated_deform_conv_forward', 'lsn_modulated_deform_conv_backward',
     'lsn_pyramid_deform_conv_forward', 'lsn_pyramid_deform_conv_backward_input',
@@ -80,6 +81,7 @@ def load():
     lib.lsn_nms_workspace_bytes.restype = ctypes.c_int64
     lib.lsn_group_norm_workspace_bytes.restype = ctypes.c_int64
     lib.lsn_bn_eval_act_workspace_bytes.restype = ctypes.c_int64
+    lib.lsn_dcn_backward_workspace_bytes.restype = ctypes.c_int64
     for name in EXPORTS:
         getattr(lib, name)  # AttributeError here means header and library disagree
     _lib = lib
@@ -109,13 +111,21 @@ def prof_read():
                                        flops=arr[i].flops, bytes=arr[i].bytes) for i in range(n)}
 
 
-MATH_FP32, MATH_BF16X3 = 0, 1
+MATH_FP32, MATH_BF16X3, MATH_BF16X6 = 0, 1, 2
+_MODES = {'fp32': MATH_FP32, 'bf16x3': MATH_BF16X3, 'bf16x6': MATH_BF16X6}
 
 
 def set_math_mode(mode):
-    """'fp32' (exact fp32 MFMA) or 'bf16x3' (split-bf16 products, fp32 accumulation); see include/lsnet_hip.h."""
-    check(load().lsn_set_math_mode({'fp32': MATH_FP32, 'bf16x3': MATH_BF16X3}[mode] if isinstance(mode, str) else mode))
+    """'bf16x6' (fp32-equivalent split products, the default), 'bf16x3' or 'fp32' (exact fp32 MFMA);
+    see include/lsnet_hip.h."""
+    check(load().lsn_set_math_mode(_MODES[mode] if isinstance(mode, str) else mode))
 
 
 def get_math_mode():
-    return 'bf16x3' if load().lsn_get_math_mode() == MATH_BF16X3 else 'fp32'
+    m = load().lsn_get_math_mode()
+    return {v: k for k, v in _MODES.items()}[m]
+
+
+def split_math():
+    """True when the contractions run as split-bf16 products on the matrix pipe (either split mode)."""
+    return get_math_mode() != 'fp32'

@@ -78,6 +78,52 @@ __device__ __forceinline__ void split_bf16x2(float v0, float v1, unsigned &hi, u
     lo = __builtin_bit_cast(unsigned, l);
 }
 
+// ---- fp32-equivalent products on the matrix pipe ("bf16x6") -------------------------------------------
+// a = a_h + a_m + a_l with three bf16 values (8 + 8 + 8 mantissa bits: the split is EXACT for every fp32 number
+// whose exponent leaves room for the low part, i.e. all but subnormal-scale values) and
+//   a*b = h*h + h*m + m*h + m*m + h*l + l*h          (dropped: m*l, l*m, l*l <= 2^-25 relative)
+// six bf16 MFMAs with fp32 accumulation: the per-product error is below fp32's own product rounding (2^-24),
+// so a contraction differs from an fmaf chain only by summation order.  Peak: 2516 / 6 = 419 TFLOP/s of
+// algorithmic flops, 2.7x the fp32 MFMA pipe.
+__device__ __forceinline__ void split3_bf16x2(float v0, float v1, unsigned &hi, unsigned &mid, unsigned &lo)
+{
+    const bf16x2 h = {(__bf16)v0, (__bf16)v1};
+    hi = __builtin_bit_cast(unsigned, h);
+    const float r0 = v0 - __uint_as_float(hi << 16), r1 = v1 - __uint_as_float(hi & 0xffff0000u);
+    const bf16x2 m = {(__bf16)r0, (__bf16)r1};
+    mid = __builtin_bit_cast(unsigned, m);
+    const float s0 = r0 - __uint_as_float(mid << 16), s1 = r1 - __uint_as_float(mid & 0xffff0000u);
+    const bf16x2 l = {(__bf16)s0, (__bf16)s1};
+    lo = __builtin_bit_cast(unsigned, l);
+}
+
+// NP = number of bf16 products per fp32 product (3: "bf16x3", 6: "bf16x6"); planes per operand and the
+// (A plane, B plane) of product q.  Small terms are issued last so that a consumer may stop early.
+template <int NP> struct SplitCfg;
+template <> struct SplitCfg<3> {
+    static constexpr int NPL = 2;
+    __host__ __device__ static constexpr int pa(int q) { return q == 2 ? 1 : 0; }
+    __host__ __device__ static constexpr int pb(int q) { return q == 1 ? 1 : 0; }
+};
+template <> struct SplitCfg<6> {
+    static constexpr int NPL = 3;
+    //            q:  0      1      2      3      4      5
+    //            A:  h      h      m      m      h      l
+    //            B:  h      m      h      m      l      h
+    __host__ __device__ static constexpr int pa(int q) { return q == 0 ? 0 : q == 1 ? 0 : q == 2 ? 1 : q == 3 ? 1 : q == 4 ? 0 : 2; }
+    __host__ __device__ static constexpr int pb(int q) { return q == 0 ? 0 : q == 1 ? 1 : q == 2 ? 0 : q == 3 ? 1 : q == 4 ? 2 : 0; }
+};
+
+// (v0, v1) -> NPL packed bf16 pairs
+template <int NPL>
+__device__ __forceinline__ void split_planes(float v0, float v1, unsigned (&p)[NPL])
+{
+    if constexpr (NPL == 2)
+        split_bf16x2(v0, v1, p[0], p[1]);
+    else
+        split3_bf16x2(v0, v1, p[0], p[1], p[2]);
+}
+
 // XCD-aware work order.  Workgroups are dealt round-robin to the 8 XCDs (linear id b -> XCD b % 8), each with its
 // own 4 MB L2.  Giving XCD x the CONTIGUOUS range of work items [start(x), start(x+1)) instead of every 8th one
 // keeps spatially adjacent tiles -- which sample the same input rows and the same gout rows -- behind one L2

@@ -50,15 +50,19 @@ __device__ __forceinline__ float4 cv_load4(__amdgpu_buffer_rsrc_t rs, int voff, 
     return f;
 }
 
-// PREP: the weights arrive already split (conv_prepare_kernel): their staging is a 16-byte copy per slice
-template <int BM, int BN, bool PREP>
-__global__ __launch_bounds__(256, 1) void conv_fwd_x3_kernel(const ConvArgs a)
+// PREP: the weights arrive already split (conv_prepare_kernel): their staging is a 16-byte copy per slice.
+// NP: bf16 products per fp32 product (common.h): 3 on two planes, or 6 on three planes (fp32-equivalent).
+template <int BM, int BN, bool PREP, int NP>
+__global__ __launch_bounds__(256, 1) void conv_fwd_xn_kernel(const ConvArgs a)
 {
+    using SC = SplitCfg<NP>;
+    constexpr int NPL = SC::NPL;
     constexpr int WM = BM / 64, WN = BN / 64, RS = CV_RS, BK = 32;
     static_assert(WM * WN == 4, "four waves of 64x64");
-    constexpr int NPA = BM / 16, NPB = BN / 32, NS = NPA + NPB;   // staging slices per chunk (12 .. 18)
-    constexpr int PLANE_A = BM * RS, PLANE_B = BN * RS, BUF = 2 * PLANE_A + 2 * PLANE_B;
-    extern __shared__ __align__(16) unsigned char smem[];   // 2 x [A hi][A lo][B hi][B lo]
+    constexpr int NPA = BM / 16, NPB = PREP ? NPL * (BN / 64) : BN / 32, NS = NPA + NPB;   // staging slices per chunk
+    constexpr int PLANE_A = BM * RS, PLANE_B = BN * RS, BUF = NPL * (PLANE_A + PLANE_B);
+    constexpr int NGAP = 2 * NP * 4;
+    extern __shared__ __align__(16) unsigned char smem[];   // 2 x [A planes][B planes]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -78,10 +82,10 @@ __global__ __launch_bounds__(256, 1) void conv_fwd_x3_kernel(const ConvArgs a)
     const __amdgpu_buffer_rsrc_t xrs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x), 0, a.B * a.H * a.W * a.C * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrs =
-        PREP ? __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(a.wp), 0, a.Co * Kdim * 4, 0x00020000)
+        PREP ? __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(a.wp), 0, a.Co * Kdim * 2 * NPL, 0x00020000)
              : __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.w), 0, a.Co * Kdim * 4, 0x00020000);
     constexpr int OOB = 0x7ffffff0;   // beyond num_records: the buffer load returns 0
-    // PREP staging: slice ps covers plane (ps & 1), rows (ps >> 1) * 64 + (tid >> 2), 16-byte slot (tid & 3)
+    // PREP staging: slice ps covers plane ps % NPL, rows (ps / NPL) * 64 + (tid >> 2), 16-byte slot (tid & 3)
     const int pq = tid & 3, prw = tid >> 2;
 
     // per gather pass: top-left input coordinate of the pixel's receptive field and its image base
@@ -101,8 +105,8 @@ __global__ __launch_bounds__(256, 1) void conv_fwd_x3_kernel(const ConvArgs a)
 #pragma unroll
     for (int ps = 0; ps < NPB; ++ps) {
         if (PREP) {
-            const int col = (ps >> 1) * 64 + prw;
-            wvoff[ps] = (col < nco) ? ((ps & 1) * a.Co * Kdim + (co_blk + col) * Kdim) * 2 + pq * 16 : OOB;
+            const int col = (ps / NPL) * 64 + prw;
+            wvoff[ps] = (col < nco) ? ((ps % NPL) * a.Co * Kdim + (co_blk + col) * Kdim) * 2 + pq * 16 : OOB;
         } else {
             const int col = ps * 32 + wrow;
             wvoff[ps] = (col < nco) ? ((co_blk + col) * Kdim + wq * 4) * 4 : OOB;
@@ -139,24 +143,24 @@ __global__ __launch_bounds__(256, 1) void conv_fwd_x3_kernel(const ConvArgs a)
         }
     };
     auto commit_x = [&](int ps, unsigned char *buf) {
-        unsigned hi, lo;
-        split_bf16x2(xv[ps].x, xv[ps].y, hi, lo);
+        unsigned pl[NPL];
+        split_planes<NPL>(xv[ps].x, xv[ps].y, pl);
         unsigned char *p = buf + (ps * 16 + prow) * RS + kk2 * 4;
-        *reinterpret_cast<unsigned *>(p) = hi;
-        *reinterpret_cast<unsigned *>(p + PLANE_A) = lo;
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) *reinterpret_cast<unsigned *>(p + q * PLANE_A) = pl[q];
     };
     auto commit_w = [&](int ps, unsigned char *buf) {
         if (PREP) {
-            unsigned char *p = buf + 2 * PLANE_A + (ps & 1) * PLANE_B + ((ps >> 1) * 64 + prw) * RS + pq * 16;
+            unsigned char *p = buf + NPL * PLANE_A + (ps % NPL) * PLANE_B + ((ps / NPL) * 64 + prw) * RS + pq * 16;
             *reinterpret_cast<float4 *>(p) = wv[ps];
             return;
         }
-        uint2 hi, lo;
-        split_bf16x2(wv[ps].x, wv[ps].y, hi.x, lo.x);
-        split_bf16x2(wv[ps].z, wv[ps].w, hi.y, lo.y);
-        unsigned char *p = buf + 2 * PLANE_A + (ps * 32 + wrow) * RS + wq * 8;
-        *reinterpret_cast<uint2 *>(p) = hi;
-        *reinterpret_cast<uint2 *>(p + PLANE_B) = lo;
+        unsigned p0[NPL], p1[NPL];
+        split_planes<NPL>(wv[ps].x, wv[ps].y, p0);
+        split_planes<NPL>(wv[ps].z, wv[ps].w, p1);
+        unsigned char *p = buf + NPL * PLANE_A + (ps * 32 + wrow) * RS + wq * 8;
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) *reinterpret_cast<uint2 *>(p + q * PLANE_B) = make_uint2(p0[q], p1[q]);
     };
 
     f32x16 acc[2][2];
@@ -194,33 +198,31 @@ __global__ __launch_bounds__(256, 1) void conv_fwd_x3_kernel(const ConvArgs a)
         unsigned char *bn = smem + (cur ^ 1) * BUF;
         // registers hold chunk t+1 (to commit); c2 = chunk t+2 (to issue); both saturate at the last chunk
         const unsigned char *ap = bc + (wm * 64 + (lane & 31)) * RS + (lane >> 5) * 16;
-        const unsigned char *bp = bc + 2 * PLANE_A + (wn * 64 + (lane & 31)) * RS + (lane >> 5) * 16;
-        bf16x8 Ah[2][2], Al[2][2], Bh[2][2], Bl[2][2];
+        const unsigned char *bp = bc + NPL * PLANE_A + (wn * 64 + (lane & 31)) * RS + (lane >> 5) * 16;
+        bf16x8 Af[2][2][NPL], Bf[2][2][NPL];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                Ah[ks][i] = *reinterpret_cast<const bf16x8 *>(ap + i * 32 * RS + ks * 32);
-                Bh[ks][i] = *reinterpret_cast<const bf16x8 *>(bp + i * 32 * RS + ks * 32);
-                Al[ks][i] = *reinterpret_cast<const bf16x8 *>(ap + PLANE_A + i * 32 * RS + ks * 32);
-                Bl[ks][i] = *reinterpret_cast<const bf16x8 *>(bp + PLANE_B + i * 32 * RS + ks * 32);
-            }
-        // 24 MFMAs, NS staging slice pairs (commit, issue) spread over the gaps
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) {
+                    Af[ks][i][q] = *reinterpret_cast<const bf16x8 *>(ap + q * PLANE_A + i * 32 * RS + ks * 32);
+                    Bf[ks][i][q] = *reinterpret_cast<const bf16x8 *>(bp + q * PLANE_B + i * 32 * RS + ks * 32);
+                }
+        // NGAP MFMAs, NS staging slice pairs (commit, issue) spread over the gaps
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int prod = 0; prod < 3; ++prod)
+            for (int prod = 0; prod < NP; ++prod)
 #pragma unroll
                 for (int ij = 0; ij < 4; ++ij) {
                     const int i = ij >> 1, j = ij & 1;
-                    const int gap = ks * 12 + prod * 4 + ij;
-                    const bf16x8 av = (prod == 2) ? Al[ks][i] : Ah[ks][i];
-                    const bf16x8 bv = (prod == 1) ? Bl[ks][j] : Bh[ks][j];
-                    acc[i][j] = mfma_bf16(av, bv, acc[i][j]);
+                    const int gap = (ks * NP + prod) * 4 + ij;
+                    acc[i][j] = mfma_bf16(Af[ks][i][SC::pa(prod)], Bf[ks][j][SC::pb(prod)], acc[i][j]);
                     __builtin_amdgcn_sched_barrier(0);
-                    // slices s in [gap*NS/24, (gap+1)*NS/24): x slices first, then weight slices
+                    // slices s in [gap*NS/NGAP, (gap+1)*NS/NGAP): x slices first, then weight slices
 #pragma unroll
-                    for (int s = gap * NS / 24; s < (gap + 1) * NS / 24; ++s) {
+                    for (int s = gap * NS / NGAP; s < (gap + 1) * NS / NGAP; ++s) {
                         if (s < NPA) {
                             commit_x(s, bn);
                             issue_x(c2, s);
@@ -266,8 +268,9 @@ __global__ void conv_flip_transpose_kernel(const float *w, float *wt, int Co, in
     }
 }
 
-// w (n floats) -> bf16 hi plane (n) followed by the lo plane (n).  flipT: source is (Co, K, C) and the destination
+// w (n floats) -> NPL bf16 planes of n values each.  flipT: source is (Co, K, C) and the destination
 // is the transposed-conv weight (C, K, Co) with the taps reversed.
+template <int NPL>
 __global__ void conv_prepare_kernel(const float *w, unsigned short *out, int Co, int K, int C, int flipT)
 {
     const size_t n = (size_t)Co * K * C;
@@ -285,31 +288,46 @@ __global__ void conv_prepare_kernel(const float *w, unsigned short *out, int Co,
                 v[q] = w[((size_t)co * K + (K - 1 - k)) * C + ci];
             }
         }
-        unsigned hi, lo;
-        split_bf16x2(v[0], v[1], hi, lo);
-        *reinterpret_cast<unsigned *>(out + e) = hi;
-        *reinterpret_cast<unsigned *>(out + n + e) = lo;
+        unsigned pl[NPL];
+        split_planes<NPL>(v[0], v[1], pl);
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) *reinterpret_cast<unsigned *>(out + q * n + e) = pl[q];
     }
+}
+
+int split_np();   // dcn.hip: bf16 products per fp32 product of the current math mode (0: exact fp32)
+static int conv_np() { return split_np() == 3 ? 3 : 6; }   // these kernels have no fp32-MFMA variant: exact mode gets x6
+
+template <int BM, int BN, int NP>
+static int launch_conv_np(const ConvArgs &a, hipStream_t st)
+{
+    const size_t lds = (size_t)2 * SplitCfg<NP>::NPL * (BM + BN) * CV_RS;
+    dim3 grid((a.P + BM - 1) / BM, (a.Co + BN - 1) / BN);
+    if (a.wp) {
+        auto k = conv_fwd_xn_kernel<BM, BN, true, NP>;
+        LSN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a);
+    } else {
+        auto k = conv_fwd_xn_kernel<BM, BN, false, NP>;
+        LSN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a);
+    }
+    LSN_HIP(hipGetLastError());
+    return 0;
 }
 
 template <int BM, int BN>
 static int launch_conv(const ConvArgs &a, hipStream_t st)
 {
-    const size_t lds = (size_t)2 * 2 * (BM + BN) * CV_RS;
-    if (a.wp) {
-        auto k = conv_fwd_x3_kernel<BM, BN, true>;
-        LSN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        dim3 grid((a.P + BM - 1) / BM, (a.Co + BN - 1) / BN);
-        hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a);
-        LSN_HIP(hipGetLastError());
-        return 0;
-    }
-    auto k = conv_fwd_x3_kernel<BM, BN, false>;
-    LSN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    dim3 grid((a.P + BM - 1) / BM, (a.Co + BN - 1) / BN);
-    hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a);
-    LSN_HIP(hipGetLastError());
-    return 0;
+    return conv_np() == 3 ? launch_conv_np<BM, BN, 3>(a, st) : launch_conv_np<BM, BN, 6>(a, st);
+}
+
+static void conv_prepare(const float *w, unsigned short *out, int Co, int K, int C, int flipT, hipStream_t st)
+{
+    if (conv_np() == 3)
+        hipLaunchKernelGGL(conv_prepare_kernel<2>, dim3(512), dim3(256), 0, st, w, out, Co, K, C, flipT);
+    else
+        hipLaunchKernelGGL(conv_prepare_kernel<3>, dim3(512), dim3(256), 0, st, w, out, Co, K, C, flipT);
 }
 
 static int conv_forward(const ConvArgs &a, hipStream_t st)
@@ -349,8 +367,7 @@ int lsn_conv2d_forward(const float *x, const float *w, const float *bias, float 
     if (int rc = conv_check(B, H, W, C, Co, kh, kw, stride, pad, dil, &a.Ho, &a.Wo)) return rc;
     a.x = x, a.w = w, a.bias = bias, a.out = out;
     if (workspace && C % 8 == 0) {   // split the weights once instead of in every block
-        hipLaunchKernelGGL(conv_prepare_kernel, dim3(512), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w,
-                           reinterpret_cast<unsigned short *>(workspace), Co, kh * kw, C, 0);
+        conv_prepare(w, reinterpret_cast<unsigned short *>(workspace), Co, kh * kw, C, 0, reinterpret_cast<hipStream_t>(stream));
         a.wp = reinterpret_cast<const unsigned short *>(workspace);
     }
     a.B = B, a.H = H, a.W = W, a.C = C, a.Co = Co, a.kh = kh, a.kw = kw, a.stride = stride, a.pad = pad, a.dil = dil;
@@ -376,8 +393,7 @@ int lsn_conv2d_backward_data(const float *grad_out, const float *w, float *grad_
     const int K = kh * kw;
     ConvArgs a = {};
     if (Co % 8 == 0) {
-        hipLaunchKernelGGL(conv_prepare_kernel, dim3(512), dim3(256), 0, st, w,
-                           reinterpret_cast<unsigned short *>(wt_workspace), Co, K, C, 1);
+        conv_prepare(w, reinterpret_cast<unsigned short *>(wt_workspace), Co, K, C, 1, st);
         a.wp = reinterpret_cast<const unsigned short *>(wt_workspace);
     } else {
         hipLaunchKernelGGL(conv_flip_transpose_kernel, dim3(256), dim3(256), 0, st, w, wt_workspace, Co, K, C);

@@ -9,6 +9,8 @@
 #include <cstdio>
 #include <vector>
 
+#include <rocprim/rocprim.hpp>
+
 #include "dcn_kernels.h"
 
 namespace lsn {
@@ -34,10 +36,15 @@ static int math_mode()
 {
     if (g_math_mode < 0) {
         const char *e = getenv("LSNET_MATH");
-        g_math_mode = (e && (!strcmp(e, "fp32") || !strcmp(e, "exact"))) ? LSN_MATH_FP32 : LSN_MATH_BF16X3;
+        g_math_mode = (e && (!strcmp(e, "fp32") || !strcmp(e, "exact"))) ? LSN_MATH_FP32
+                      : (e && !strcmp(e, "bf16x3"))                       ? LSN_MATH_BF16X3
+                                                                          : LSN_MATH_BF16X6;
     }
     return g_math_mode;
 }
+// bf16 products per fp32 product of the current mode (0: exact fp32 MFMA)
+static int math_np() { return math_mode() == LSN_MATH_BF16X6 ? 6 : (math_mode() == LSN_MATH_BF16X3 ? 3 : 0); }
+int split_np() { return math_np(); }
 
 // ---- per-kernel launch timing (lsn_prof_*): HIP events recorded on the launch stream around each
 // deformable-conv kernel, so bench.py can quote a kernel's own average duration live.
@@ -285,18 +292,18 @@ static int launch_forward(const DcnArgs &a, hipStream_t st)
         return (a.Co / a.groups <= 64) ? launch_forward_t<64, 64, 2, 2>(a, st) : launch_forward_t<64, 256, 1, 4>(a, st);
     }
     dim3 grid(a.ntiles, cdiv(a.Co / a.groups, PIPE_BN), a.groups);
-    if (math_mode() == LSN_MATH_BF16X3 && x3_lds_bytes(a.kh * a.kw * a.dg) <= 160 * 1024) {
+    const int np = math_np(), KDf = a.kh * a.kw * a.dg;
+    if (np && (np == 6 ? xn_lds_bytes<6>(KDf) : xn_lds_bytes<3>(KDf)) <= 160 * 1024) {
         ProfScope prof(PROF_FWD, a, st);
-        const size_t lds3 = x3_lds_bytes(a.kh * a.kw * a.dg);
-        if (a.wtp) {
-            if (int rc = set_lds(dcn_fwd_x3_kernel<true>, lds3)) return rc;
-            hipLaunchKernelGGL(dcn_fwd_x3_kernel<true>, grid, dim3(256), lds3, st, a);
-        } else {
-            if (int rc = set_lds(dcn_fwd_x3_kernel<false>, lds3)) return rc;
-            hipLaunchKernelGGL(dcn_fwd_x3_kernel<false>, grid, dim3(256), lds3, st, a);
-        }
-        LSN_HIP(hipGetLastError());
-        return 0;
+        const size_t ldsn = np == 6 ? xn_lds_bytes<6>(KDf) : xn_lds_bytes<3>(KDf);
+        auto gox = [&](auto kern) -> int {
+            if (int rc = set_lds(kern, ldsn)) return rc;
+            hipLaunchKernelGGL(kern, grid, dim3(256), ldsn, st, a);
+            LSN_HIP(hipGetLastError());
+            return 0;
+        };
+        if (np == 6) return a.wtp ? gox(dcn_fwd_xn_kernel<true, 6>) : gox(dcn_fwd_xn_kernel<false, 6>);
+        return a.wtp ? gox(dcn_fwd_xn_kernel<true, 3>) : gox(dcn_fwd_xn_kernel<false, 3>);
     }
     const size_t lds = pipe_lds_bytes(a);
     auto go = [&](auto kern) -> int {
@@ -336,10 +343,10 @@ static int launch_bwd_data_t(const DcnArgs &a, hipStream_t st)
 
 static bool bwd_x3_ok(const DcnArgs &a)
 {
-    if (math_mode() != LSN_MATH_BF16X3 || a.wtp == nullptr || a.groups != 1) return false;
+    if (math_np() == 0 || a.wtp == nullptr || a.groups != 1) return false;
     if (a.Co > 256 || a.Co % 8 != 0 || a.C % 4 != 0) return false;
-    if ((int64_t)a.kh * a.kw * a.C * a.Co * 4 >= ((int64_t)1 << 31)) return false;
-    if (bwd_x3_lds_bytes(a.kh * a.kw * a.dg) > 80 * 1024) return false;
+    if ((int64_t)a.kh * a.kw * a.C * a.Co * 6 >= ((int64_t)1 << 31)) return false;
+    if (bwd_xn_lds_bytes(math_np(), a.kh * a.kw * a.dg) > 80 * 1024) return false;
     return true;
 }
 
@@ -374,7 +381,7 @@ static int launch_bwd_data_win_t(DcnArgs a, hipStream_t st)
         tiles += a.lv[i].B * cdiv(a.lv[i].Ho, BW3_PH) * cdiv(a.lv[i].Wo, BW3_PW);
     }
     a.ntiles = tiles;
-    if (RED == 256 && bwd_x3_ok(a) && bwd_win_x3_lds_bytes(a.kh * a.kw * a.dg) <= 160 * 1024) {
+    if (RED == 256 && math_np() == 3 && bwd_x3_ok(a) && bwd_win_x3_lds_bytes(a.kh * a.kw * a.dg) <= 160 * 1024) {
         const size_t lds3 = bwd_win_x3_lds_bytes(a.kh * a.kw * a.dg);   // GEMM on the bf16 matrix pipe
         if (int rc = set_lds(dcn_bwd_data_win_x3_kernel, lds3)) return rc;
         hipLaunchKernelGGL(dcn_bwd_data_win_x3_kernel, dim3(tiles), dim3(512), lds3, st, a);
@@ -395,15 +402,132 @@ static int launch_bwd_data_win_t(DcnArgs a, hipStream_t st)
     return 0;
 }
 
-static int launch_bwd_data(const DcnArgs &a, hipStream_t st)
+// ---- atomic-free grad_input: workspace plan of the bin / scan / fill / sort / gather sequence (dcn_kernels.h) ----
+struct GatherPlan {
+    bool ok = false;
+    int nsamples = 0, nanchors = 0;
+    size_t scan_tmp = 0;
+    size_t o_gcol = 0, o_cnt = 0, o_start = 0, o_anchor = 0, o_rank = 0, o_frac = 0, o_ent = 0, o_tmp = 0, bytes = 0;
+    GatherArgs ga;
+};
+
+static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+// Fills prow0 / abase of the levels and the plan.  gx pointers: levels with the same grad_input share an anchor grid.
+static void gather_plan(DcnArgs &a, GatherPlan &pl)
+{
+    pl.ok = false;
+    const int K = a.kh * a.kw, KD = K * a.dg;
+    int64_t prow = 0, anchors = 0, Q = 0;
+    GatherArgs &ga = pl.ga;
+    ga.ng = 0;
+    bool any = false;
+    for (int i = 0; i < a.nlv; ++i) {
+        Lvl &L = a.lv[i];
+        L.prow0 = (int)prow;
+        prow += L.P;
+        L.abase = 0;
+        if (!L.gx) continue;
+        any = true;
+        int gi = -1;
+        for (int j = 0; j < ga.ng; ++j)
+            if (ga.g[j].gx == L.gx) gi = j;
+        if (gi < 0) {
+            gi = ga.ng++;
+            GatherGrp &G = ga.g[gi];
+            G.gx = L.gx, G.B = L.B, G.H = L.H, G.W = L.W;
+            G.abase = (int)anchors, G.q0 = (int)Q;
+            anchors += (int64_t)L.B * (L.H + 1) * (L.W + 1);
+            Q += (int64_t)L.B * L.H * L.W;
+        } else if (ga.g[gi].B != L.B || ga.g[gi].H != L.H || ga.g[gi].W != L.W) {
+            return;   // one buffer, two shapes: not a valid call for this path
+        }
+        L.abase = ga.g[gi].abase;
+    }
+    if (!any) return;
+    if (prow * KD >= ((int64_t)1 << 30) || anchors >= ((int64_t)1 << 30) || Q >= ((int64_t)1 << 30)) return;
+    if (a.C % 4 != 0 || (a.C / a.dg) % 4 != 0) return;
+    pl.nsamples = (int)(prow * KD);
+    pl.nanchors = (int)anchors;
+    ga.Q = (int)Q;
+    ga.C = a.C, ga.K = K, ga.KD = KD, ga.dg = a.dg;
+    size_t tmp = 0;
+    if (rocprim::exclusive_scan((void *)nullptr, tmp, (int *)nullptr, (int *)nullptr, 0, (size_t)pl.nanchors + 1,
+                                rocprim::plus<int>(), (hipStream_t)0) != hipSuccess)
+        return;
+    pl.scan_tmp = tmp;
+    size_t o = 0;
+    pl.o_gcol = o, o = align256(o + (size_t)prow * K * a.C * sizeof(float));
+    pl.o_cnt = o, o = align256(o + ((size_t)pl.nanchors + 1) * sizeof(int));
+    pl.o_start = o, o = align256(o + ((size_t)pl.nanchors + 1) * sizeof(int));
+    pl.o_anchor = o, o = align256(o + (size_t)pl.nsamples * sizeof(int));
+    pl.o_rank = o, o = align256(o + (size_t)pl.nsamples * sizeof(int));
+    pl.o_frac = o, o = align256(o + (size_t)pl.nsamples * sizeof(float2));
+    pl.o_ent = o, o = align256(o + (size_t)pl.nsamples * sizeof(GEntry));
+    pl.o_tmp = o, o = align256(o + tmp + 256);
+    pl.bytes = o;
+    pl.ok = true;
+}
+
+static bool bwd_colbuf_env()
+{
+    static const int v = [] { const char *e = getenv("LSNET_BWD_GATHER"); return e ? atoi(e) : 1; }();
+    if ((g_dbg_block >> 23) & 1) return false;   // bit 23 of the debug word forces the atomic scatter kernels (tests)
+    return v != 0;   // LSNET_BWD_GATHER=0: keep the atomic scatter kernels (A/B runs)
+}
+
+template <int NP>
+static int launch_bwd_colbuf(DcnArgs &a, GatherPlan &pl, unsigned char *ws, hipStream_t st)
+{
+    a.gcol = reinterpret_cast<float *>(ws + pl.o_gcol);
+    int *cnt = reinterpret_cast<int *>(ws + pl.o_cnt), *start = reinterpret_cast<int *>(ws + pl.o_start);
+    int *sanchor = reinterpret_cast<int *>(ws + pl.o_anchor), *srank = reinterpret_cast<int *>(ws + pl.o_rank);
+    float2 *sfrac = reinterpret_cast<float2 *>(ws + pl.o_frac);
+    GEntry *ent = reinterpret_cast<GEntry *>(ws + pl.o_ent);
+    LSN_HIP(hipMemsetAsync(cnt, 0, ((size_t)pl.nanchors + 1) * sizeof(int), st));
+    hipLaunchKernelGGL(dcn_bin_kernel, dim3(cdiv(pl.nsamples, 256)), dim3(256), 0, st, a, pl.nsamples, cnt, sanchor,
+                       srank, sfrac);
+    size_t tmp = pl.scan_tmp;
+    LSN_HIP(rocprim::exclusive_scan(ws + pl.o_tmp, tmp, cnt, start, 0, (size_t)pl.nanchors + 1, rocprim::plus<int>(), st));
+    hipLaunchKernelGGL(dcn_fill_kernel, dim3(cdiv(pl.nsamples, 256)), dim3(256), 0, st, pl.nsamples, start, sanchor,
+                       srank, sfrac, ent);
+    int sort_blocks = cdiv(pl.nanchors, 4);
+    if (sort_blocks > 4096) sort_blocks = 4096;
+    hipLaunchKernelGGL(dcn_sort_lists_kernel, dim3(sort_blocks), dim3(256), 0, st, pl.nanchors, start, ent);
+    const size_t lds = bwd_xn_lds_bytes(NP, a.kh * a.kw * a.dg);
+    if (int rc = set_lds(dcn_bwd_data_xn_kernel<NP, true>, lds)) return rc;
+    hipLaunchKernelGGL((dcn_bwd_data_xn_kernel<NP, true>), dim3(a.ntiles), dim3(256), lds, st, a);
+    pl.ga.gcol = a.gcol, pl.ga.start = start, pl.ga.ent = ent;
+    hipLaunchKernelGGL(dcn_gather_kernel, dim3(cdiv(pl.ga.Q, 4)), dim3(256), 0, st, pl.ga);
+    LSN_HIP(hipGetLastError());
+    return 0;
+}
+
+// gather_ws: device scratch of >= the plan's byte count for the atomic-free path, or NULL
+static int launch_bwd_data(DcnArgs &a, void *gather_ws, size_t gather_ws_bytes, hipStream_t st)
 {
     ProfScope prof(PROF_BWD_DATA, a, st);
-    if (!bwd_win_ok(a) && bwd_x3_ok(a)) {
-        const size_t lds = bwd_x3_lds_bytes(a.kh * a.kw * a.dg);
-        if (int rc = set_lds(dcn_bwd_data_x3_kernel, lds)) return rc;
-        hipLaunchKernelGGL(dcn_bwd_data_x3_kernel, dim3(a.ntiles), dim3(256), lds, st, a);
-        LSN_HIP(hipGetLastError());
-        return 0;
+    const int np = math_np();
+    if (bwd_x3_ok(a) && gather_ws && bwd_colbuf_env()) {
+        GatherPlan pl;
+        gather_plan(a, pl);
+        if (pl.ok && pl.bytes <= gather_ws_bytes)
+            return np == 6 ? launch_bwd_colbuf<6>(a, pl, reinterpret_cast<unsigned char *>(gather_ws), st)
+                           : launch_bwd_colbuf<3>(a, pl, reinterpret_cast<unsigned char *>(gather_ws), st);
+    }
+    a.gcol = nullptr;
+    for (int i = 0; i < a.nlv; ++i)   // the scatter kernels accumulate: start from zero (once per buffer is enough)
+        if (a.lv[i].gx)
+            LSN_HIP(hipMemsetAsync(a.lv[i].gx, 0, sizeof(float) * (size_t)a.lv[i].B * a.lv[i].H * a.lv[i].W * a.C, st));
+    if (bwd_x3_ok(a) && (np == 6 || !bwd_win_ok(a))) {
+        const size_t lds = bwd_xn_lds_bytes(np, a.kh * a.kw * a.dg);
+        auto gox = [&](auto kern) -> int {
+            if (int rc = set_lds(kern, lds)) return rc;
+            hipLaunchKernelGGL(kern, dim3(a.ntiles), dim3(256), lds, st, a);
+            LSN_HIP(hipGetLastError());
+            return 0;
+        };
+        return np == 6 ? gox(dcn_bwd_data_xn_kernel<6, false>) : gox(dcn_bwd_data_xn_kernel<3, false>);
     }
     if (bwd_win_ok(a))
         return (a.Co / a.groups > 64) ? launch_bwd_data_win_t<256>(a, st) : launch_bwd_data_win_t<64>(a, st);
@@ -423,10 +547,16 @@ static int launch_wgrad(const DcnArgs &a, int nsteps, hipStream_t st)
     LSN_HIP(hipMemsetAsync(a.gw, 0, sizeof(float) * (size_t)a.Co * K * Cg, st));
     if (a.gb) LSN_HIP(hipMemsetAsync(a.gb, 0, sizeof(float) * (size_t)a.Co, st));
     ProfScope prof(PROF_WGRAD, a, st);
-    if (math_mode() == LSN_MATH_BF16X3 && !((g_dbg_block >> 30) & 1)) {   // bit 30: force the fp32 MFMA kernel
-        const size_t lds3 = (size_t)2 * (WG_BM + WG_BN) * 80 + 2 * WG_BP * sizeof(Tap);
-        if (int rc = set_lds(dcn_wgrad_x3_kernel<false>, lds3)) return rc;
-        hipLaunchKernelGGL(dcn_wgrad_x3_kernel<false>, dim3(ncol, splits, nz), dim3(256), lds3, st, a, nsteps);
+    if (math_np() && !((g_dbg_block >> 30) & 1)) {   // bit 30: force the fp32 MFMA kernel
+        if (math_np() == 6) {
+            const size_t ldsn = wgrad_xn_lds_bytes<6>();
+            if (int rc = set_lds(dcn_wgrad_xn_kernel<false, 6>, ldsn)) return rc;
+            hipLaunchKernelGGL((dcn_wgrad_xn_kernel<false, 6>), dim3(ncol, splits, nz), dim3(256), ldsn, st, a, nsteps);
+        } else {
+            const size_t ldsn = wgrad_xn_lds_bytes<3>();
+            if (int rc = set_lds(dcn_wgrad_xn_kernel<false, 3>, ldsn)) return rc;
+            hipLaunchKernelGGL((dcn_wgrad_xn_kernel<false, 3>), dim3(ncol, splits, nz), dim3(256), ldsn, st, a, nsteps);
+        }
         LSN_HIP(hipGetLastError());
         return 0;
     }
@@ -475,10 +605,14 @@ static int dcn_forward_impl(const lsn_dcn_shape &s, int n, const lsn_dcn_level *
     }
     a.bias = bias;
     a.wtp = nullptr;
-    if (s.workspace && math_mode() == LSN_MATH_BF16X3 && (Cg % 8 == 0) && a.Co / a.groups > 64 && pipe_ok(a)) {
+    if (s.workspace && math_np() && (Cg % 8 == 0) && a.Co / a.groups > 64 && pipe_ok(a)) {
         const size_t nw = (size_t)s.Co * K * Cg;   // split the weights once instead of in every block
-        hipLaunchKernelGGL(dcn_prepare_w_kernel, dim3(512), dim3(256), 0, st, a.w,
-                           reinterpret_cast<unsigned short *>(s.workspace), nw);
+        if (math_np() == 6)
+            hipLaunchKernelGGL(dcn_prepare_w_kernel<3>, dim3(512), dim3(256), 0, st, a.w,
+                               reinterpret_cast<unsigned short *>(s.workspace), nw);
+        else
+            hipLaunchKernelGGL(dcn_prepare_w_kernel<2>, dim3(512), dim3(256), 0, st, a.w,
+                               reinterpret_cast<unsigned short *>(s.workspace), nw);
         a.wtp = reinterpret_cast<const unsigned short *>(s.workspace);
     }
     if (int rc = launch_forward(a, st)) return rc;
@@ -541,15 +675,26 @@ static int dcn_backward_impl(const lsn_dcn_shape &s, int n, const lsn_dcn_level 
     a.gb = grad_bias;
 
     if (any_data) {
-        for (int i = 0; i < n; ++i)
-            if (a.lv[i].gx) LSN_HIP(hipMemsetAsync(a.lv[i].gx, 0, sizeof(float) * n_in(s, lv[i]), st));
         a.wtp = nullptr;
-        if (s.workspace && math_mode() == LSN_MATH_BF16X3 && s.groups == 1 && s.Co % 2 == 0) {
-            hipLaunchKernelGGL(dcn_prepare_wt_kernel, dim3(512), dim3(256), 0, st, a.w,
-                               reinterpret_cast<unsigned short *>(s.workspace), s.Co, K, s.C);
+        a.gcol = nullptr;
+        if (s.workspace && math_np() && s.groups == 1 && s.Co % 2 == 0) {
+            if (math_np() == 6)
+                hipLaunchKernelGGL(dcn_prepare_wt_kernel<3>, dim3(512), dim3(256), 0, st, a.w,
+                                   reinterpret_cast<unsigned short *>(s.workspace), s.Co, K, s.C);
+            else
+                hipLaunchKernelGGL(dcn_prepare_wt_kernel<2>, dim3(512), dim3(256), 0, st, a.w,
+                                   reinterpret_cast<unsigned short *>(s.workspace), s.Co, K, s.C);
             a.wtp = reinterpret_cast<const unsigned short *>(s.workspace);
         }
-        if (int rc = launch_bwd_data(a, st)) return rc;
+        void *gws = s.gather_workspace;
+        size_t gws_bytes = (size_t)(s.gather_workspace_bytes > 0 ? s.gather_workspace_bytes : 0);
+        if (!gws && layout == LSN_NCHW && a.wtp && bwd_colbuf_env()) {   // reference-layout entry points: own scratch
+            GatherPlan pl;
+            DcnArgs probe = a;
+            gather_plan(probe, pl);
+            if (pl.ok && (gws = ws.get(pl.bytes / 4 + 64)) != nullptr) gws_bytes = pl.bytes;
+        }
+        if (int rc = launch_bwd_data(a, gws, gws_bytes, st)) return rc;
     }
     if (a.gw) {
         DcnArgs w = a;  // same levels, step (32-pixel) indexing
@@ -637,9 +782,15 @@ static int conv_wgrad_x3(const float *x, const float *gout, float *gw, float *gb
     if (splits < 1) splits = 1;
     LSN_HIP(hipMemsetAsync(gw, 0, sizeof(float) * (size_t)Co * K * C, st));
     if (gb) LSN_HIP(hipMemsetAsync(gb, 0, sizeof(float) * (size_t)Co, st));
-    const size_t lds3 = (size_t)2 * (WG_BM + WG_BN) * 80 + 2 * WG_BP * sizeof(Tap);
-    if (int rc = set_lds(dcn_wgrad_x3_kernel<true>, lds3)) return rc;
-    hipLaunchKernelGGL(dcn_wgrad_x3_kernel<true>, dim3(ncol, splits, nz), dim3(256), lds3, st, a, nsteps);
+    if (math_np() == 3) {
+        const size_t ldsn = wgrad_xn_lds_bytes<3>();
+        if (int rc = set_lds(dcn_wgrad_xn_kernel<true, 3>, ldsn)) return rc;
+        hipLaunchKernelGGL((dcn_wgrad_xn_kernel<true, 3>), dim3(ncol, splits, nz), dim3(256), ldsn, st, a, nsteps);
+    } else {   // the fp32-equivalent split is also what an exact-mode caller gets: there is no fp32-MFMA dense wgrad
+        const size_t ldsn = wgrad_xn_lds_bytes<6>();
+        if (int rc = set_lds(dcn_wgrad_xn_kernel<true, 6>, ldsn)) return rc;
+        hipLaunchKernelGGL((dcn_wgrad_xn_kernel<true, 6>), dim3(ncol, splits, nz), dim3(256), ldsn, st, a, nsteps);
+    }
     LSN_HIP(hipGetLastError());
     return 0;
 }
@@ -660,9 +811,24 @@ int lsn_debug_phase_clocks(long long *device_buf_512, int block)
 }
 int lsn_version(void) { return 100; }
 
+int64_t lsn_dcn_backward_workspace_bytes(const lsn_dcn_shape *shape, int n_levels, const lsn_dcn_level *levels)
+{
+    using namespace lsn;
+    if (!shape || !levels || math_np() == 0 || shape->groups != 1 || !bwd_colbuf_env()) return 0;
+    if (check_shape(*shape) != 0) return 0;
+    DcnArgs a;
+    if (fill_levels(a, *shape, n_levels, levels, BWD_BM) != 0) return 0;
+    for (int i = 0; i < n_levels; ++i) a.lv[i].gx = levels[i].grad_input;
+    a.wtp = reinterpret_cast<const unsigned short *>(shape);   // any non-NULL value: the caller passes `workspace` too
+    if (!bwd_x3_ok(a)) return 0;
+    GatherPlan pl;
+    gather_plan(a, pl);
+    return pl.ok ? (int64_t)pl.bytes : 0;
+}
+
 int lsn_set_math_mode(int mode)
 {
-    LSN_CHECK(mode == LSN_MATH_FP32 || mode == LSN_MATH_BF16X3, "unknown math mode %d", mode);
+    LSN_CHECK(mode == LSN_MATH_FP32 || mode == LSN_MATH_BF16X3 || mode == LSN_MATH_BF16X6, "unknown math mode %d", mode);
     lsn::g_math_mode = mode;
     return 0;
 }

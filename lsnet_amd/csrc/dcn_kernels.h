@@ -32,6 +32,8 @@ struct Lvl {
     float sh, sw;
     int osb, osc, osh, osw;  // offset (and grad_offset) element strides
     int msb, msc, msh, msw;  // mask (and grad_mask) element strides
+    int prow0;  // first pixel row of this level in the launch-wide numbering (backward: column-gradient buffer)
+    int abase;  // first anchor of the grad_input buffer this level scatters into (levels may share one)
 };
 
 struct DcnArgs {
@@ -42,7 +44,8 @@ struct DcnArgs {
     int C, Co, kh, kw, stride, pad, dil, groups, dg;
     int SL;   // channel segment length = min(C/groups, C/dg): constant (g, dgi) inside a segment
     int msig; // mask tensor holds logits: apply sigmoid on read, chain it into grad_mask
-    const unsigned short *wtp;   // split-bf16 weights for backward-data: planes hi, lo of [K][C][Co] (co contiguous)
+    const unsigned short *wtp;   // pre-split bf16 weight planes (forward: [Co][K][Cg]; backward-data: [K][C][Co])
+    float *gcol;   // backward-data: mask-weighted column gradients [(prow0 + pix) * K + k][C] for the gather pass
     long long *dbg;  // optional phase timestamps of block `dbg_block`, wave 0 (lsn_debug_phase_clocks)
     int dbg_block;
 };
@@ -677,33 +680,43 @@ __global__ __launch_bounds__(256, 1) void dcn_fwd_pipe_kernel(const DcnArgs a)
 }
 
 // =============================================================================================
-// Forward on the bf16 matrix pipe with split operands (dcn_fwd_x3_kernel).
+// Forward on the bf16 matrix pipe with split operands (dcn_fwd_xn_kernel<PREP, NP>).
 //
 // Same tiling and software pipeline as dcn_fwd_pipe_kernel (64 px x 256 co, one workgroup per CU, chunk t's
 // MFMAs interleaved with the LDS commit of chunk t+1 and the load issue of chunk t+2), but the blended samples and
-// the weights are split into bf16 hi/lo pairs while they are staged and multiplied as hi*hi + hi*lo + lo*hi on
-// v_mfma_f32_32x32x16_bf16 (common.h).  24 MFMAs of 32 cycles per chunk instead of 64 of 64, and the VALU work
-// of the staging now overlaps them (the bf16 pipe is separate from the fp32 ALUs).
-// LDS rows: 32 k-values = 64 B of bf16 + 16 B pad (stride 80 B: the 16-byte operand reads of a lane group hit
-// all 64 banks exactly once).  hi and lo planes are separate arrays.
+// the weights are split into bf16 planes while they are staged (common.h: NP = 3 products on 2 planes, or NP = 6
+// products on 3 planes = fp32-equivalent) and multiplied on v_mfma_f32_32x32x16_bf16.  4 NP MFMAs of 32 cycles per
+// k-step instead of 64 of 64 cycles per chunk, and the VALU work of the staging overlaps them (the bf16 pipe is
+// separate from the fp32 ALUs).
+// LDS rows: 32 k-values = 64 B of bf16, no padding; the four 16-byte slots of row r are stored at slot ^ ((r >> 2) & 3),
+// which makes the 16-byte operand reads of every ds_read_b128 lane group cover all 64 banks exactly once (rows with
+// equal r & 3 inside a group differ in (r >> 2) & 3).  One plane per array: buffer b = [A planes][B planes].
 // =============================================================================================
-constexpr int X3_RS = 80;   // LDS row stride, bytes
+constexpr int XN_RS = 64;   // LDS row stride, bytes
 
-__host__ __device__ inline size_t x3_lds_bytes(int KD)
+template <int NP>
+__host__ __device__ inline size_t xn_lds_bytes(int KD)
 {
-    return (size_t)2 * 2 * (PIPE_BM + PIPE_BN) * X3_RS + (size_t)PIPE_BM * KD * sizeof(Tap);
+    return (size_t)2 * SplitCfg<NP>::NPL * (PIPE_BM + PIPE_BN) * XN_RS + (size_t)PIPE_BM * KD * sizeof(Tap);
 }
 
-// PREP: a.wtp holds the weights already split by dcn_prepare_w_kernel (planes hi, lo of [Co][K][C/groups] bf16):
+// byte offset of 16-byte slot `slot` of row `row` inside a plane
+__device__ __forceinline__ int xn_slot(int row, int slot) { return row * XN_RS + ((slot ^ ((row >> 2) & 3)) << 4); }
+
+// PREP: a.wtp holds the weights already split by dcn_prepare_w_kernel (NPL planes of [Co][K][C/groups] bf16):
 // their staging is a 16-byte copy per slice instead of ~14 VALU instructions per float4
-template <bool PREP>
-__global__ __launch_bounds__(256, 1) void dcn_fwd_x3_kernel(const DcnArgs a)
+template <bool PREP, int NP>
+__global__ __launch_bounds__(256, 1) void dcn_fwd_xn_kernel(const DcnArgs a)
 {
-    constexpr int BM = PIPE_BM, BN = PIPE_BN, BK = PIPE_BK, RS = X3_RS;
-    constexpr int NPA = BM / 16, NPB = BN / 32;   // 4 gather passes (2 channels per thread), 8 weight passes
-    constexpr int PLANE_A = BM * RS, PLANE_B = BN * RS, BUF = 2 * PLANE_A + 2 * PLANE_B;
+    using SC = SplitCfg<NP>;
+    constexpr int NPL = SC::NPL;
+    constexpr int BM = PIPE_BM, BN = PIPE_BN, BK = PIPE_BK, RS = XN_RS;
+    constexpr int NPA = BM / 16;                       // 4 gather passes (2 channels per thread)
+    constexpr int NPB = PREP ? NPL * (BN / 64) : BN / 32;   // weight slices of 256 threads x 16 B
+    constexpr int PLANE_A = BM * RS, PLANE_B = BN * RS, BUF = NPL * (PLANE_A + PLANE_B);
+    constexpr int NGAP = 2 * NP * 4, NSLOT = 2 * (NPA + NPB);
+    static_assert(NSLOT <= NGAP, "one staging slot per MFMA gap at most");
     extern __shared__ __align__(16) unsigned char smem[];
-    // buffer b: [A hi][A lo][B hi][B lo]
     Tap *tab = reinterpret_cast<Tap *>(smem + 2 * BUF);   // [BM][K*dg]
 
     const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
@@ -731,22 +744,25 @@ __global__ __launch_bounds__(256, 1) void dcn_fwd_x3_kernel(const DcnArgs a)
     const __amdgpu_buffer_rsrc_t xrs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(L.x), 0, L.B * L.H * L.W * a.C * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrs =
-        PREP ? __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(a.wtp), 0, a.Co * Kdim * 4, 0x00020000)
+        PREP ? __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(a.wtp), 0, a.Co * Kdim * 2 * NPL, 0x00020000)
              : __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.w), 0, a.Co * Kdim * 4, 0x00020000);
-    // PREP slices: plane (ps & 1), rows (ps >> 1) * 64 + (tid >> 2), 16-byte slot tid & 3
+    // PREP slices: plane ps % NPL, rows (ps / NPL) * 64 + (tid >> 2), 16-byte slot tid & 3
     const int pq = tid & 3, prw = tid >> 2;
 
     int wvoff[NPB];
 #pragma unroll
     for (int ps = 0; ps < NPB; ++ps) {
         if (PREP) {
-            const int col = (ps >> 1) * 64 + prw;
-            wvoff[ps] = (col < nco) ? ((ps & 1) * a.Co * Kdim + (co_base + col) * Kdim) * 2 + pq * 16 : 0x7ffffff0;
+            const int col = (ps / NPL) * 64 + prw;
+            wvoff[ps] = (col < nco) ? ((ps % NPL) * a.Co * Kdim + (co_base + col) * Kdim) * 2 + pq * 16 : 0x7ffffff0;
         } else {
             const int col = ps * 32 + wrow;
             wvoff[ps] = (col < nco) ? ((co_base + col) * Kdim + wq * 4) * 4 : 0x7ffffff0;
         }
     }
+    // LDS commit addresses of this thread (the row swizzle depends on the thread's row only)
+    const int xcommit = xn_slot(prow, kk2 >> 2) + (kk2 & 3) * 4;                    // + ps * 16 * RS
+    const int wcommit = PREP ? xn_slot(prw, pq) : xn_slot(wrow, wq >> 1) + (wq & 1) * 8;   // + row block
 
     int voffI[NPA][4];
     float wgtC[NPA][4];
@@ -790,26 +806,42 @@ __global__ __launch_bounds__(256, 1) void dcn_fwd_x3_kernel(const DcnArgs a)
                    wgtC[ps][3] * xv[ps][3].y;
         v0 = (2 * kk2 < ch.nval) ? v0 : 0.f;
         v1 = (2 * kk2 + 1 < ch.nval) ? v1 : 0.f;
-        unsigned hi, lo;
-        split_bf16x2(v0, v1, hi, lo);
-        unsigned char *p = buf + (ps * 16 + prow) * RS + kk2 * 4;
-        *reinterpret_cast<unsigned *>(p) = hi;
-        *reinterpret_cast<unsigned *>(p + PLANE_A) = lo;
+        unsigned pl[NPL];
+        split_planes<NPL>(v0, v1, pl);
+        unsigned char *p = buf + ps * 16 * RS + xcommit;
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) *reinterpret_cast<unsigned *>(p + q * PLANE_A) = pl[q];
     };
     auto commit_w = [&](const Chunk &ch, int ps, unsigned char *buf) {
         if (PREP) {   // columns past nval hold neighbouring values; the A operand is zero there
-            unsigned char *p = buf + 2 * PLANE_A + (ps & 1) * PLANE_B + ((ps >> 1) * 64 + prw) * RS + pq * 16;
+            unsigned char *p = buf + NPL * PLANE_A + (ps % NPL) * PLANE_B + (ps / NPL) * 64 * RS + wcommit;
             *reinterpret_cast<float4 *>(p) = wv[ps];
             return;
         }
         const bool ok = wq * 4 < ch.nval;   // nval is a multiple of 4 on this path (vec_ok)
         const float4 v = ok ? wv[ps] : make_float4(0.f, 0.f, 0.f, 0.f);
-        uint2 hi, lo;
-        split_bf16x2(v.x, v.y, hi.x, lo.x);
-        split_bf16x2(v.z, v.w, hi.y, lo.y);
-        unsigned char *p = buf + 2 * PLANE_A + (ps * 32 + wrow) * RS + wq * 8;
-        *reinterpret_cast<uint2 *>(p) = hi;
-        *reinterpret_cast<uint2 *>(p + PLANE_B) = lo;
+        unsigned p0[NPL], p1[NPL];
+        split_planes<NPL>(v.x, v.y, p0);
+        split_planes<NPL>(v.z, v.w, p1);
+        unsigned char *p = buf + NPL * PLANE_A + ps * 32 * RS + wcommit;
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) *reinterpret_cast<uint2 *>(p + q * PLANE_B) = make_uint2(p0[q], p1[q]);
+    };
+    // staging slot s of a chunk: x slices first (commit, then the issue that reuses the registers just consumed),
+    // then the weight slices
+    auto staging_slot = [&](int s, const Chunk &c1, const Chunk &c2, unsigned char *bn) {
+        if (s < 2 * NPA) {
+            if ((s & 1) == 0)
+                commit_x(c1, s >> 1, bn);
+            else
+                issue_x(c2, s >> 1);
+        } else {
+            const int ps = (s - 2 * NPA) >> 1;
+            if ((s & 1) == 0)
+                commit_w(c1, ps, bn);
+            else
+                issue_w(c2, ps);
+        }
     };
 
     f32x16 acc[2][2];
@@ -848,6 +880,10 @@ __global__ __launch_bounds__(256, 1) void dcn_fwd_x3_kernel(const DcnArgs a)
     }
     __syncthreads();
 
+    // operand read offsets: row (lane & 31) of a 32-row block, k-half (lane >> 5), k-step ks: slot (lane >> 5) + 2 ks
+    const int rsw = (lane >> 2) & 3;
+    const int ro0 = (lane & 31) * RS + ((((lane >> 5)) ^ rsw) << 4), ro1 = ro0 ^ 32;
+
     int dbg_n = 0;
     for (int t = 0; t < T; ++t) {
         LSN_STAMP(2);
@@ -863,49 +899,37 @@ __global__ __launch_bounds__(256, 1) void dcn_fwd_x3_kernel(const DcnArgs a)
         if (c2.k != cI.k || c2.dgi != cI.dgi) load_offsets(c2);
         cI = c2;
 
-        // operands of both k-steps: [ks][tile row/col block][hi, lo]
-        const unsigned char *ap = bc + (lane & 31) * RS + (lane >> 5) * 16;
-        const unsigned char *bp = bc + 2 * PLANE_A + (wn * 64 + (lane & 31)) * RS + (lane >> 5) * 16;
-        bf16x8 Ah[2][2], Al[2][2], Bh[2][2], Bl[2][2];
+        // operands of both k-steps: [ks][tile row/col block][plane]
+        const unsigned char *ap = bc;
+        const unsigned char *bp = bc + NPL * PLANE_A + wn * 64 * RS;
+        bf16x8 Af[2][2][NPL], Bf[2][2][NPL];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                Ah[ks][i] = *reinterpret_cast<const bf16x8 *>(ap + i * 32 * RS + ks * 32);
-                Al[ks][i] = *reinterpret_cast<const bf16x8 *>(ap + PLANE_A + i * 32 * RS + ks * 32);
-                Bh[ks][i] = *reinterpret_cast<const bf16x8 *>(bp + i * 32 * RS + ks * 32);
-                Bl[ks][i] = *reinterpret_cast<const bf16x8 *>(bp + PLANE_B + i * 32 * RS + ks * 32);
-            }
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) {
+                    const int ro = ks ? ro1 : ro0;
+                    Af[ks][i][q] = *reinterpret_cast<const bf16x8 *>(ap + q * PLANE_A + i * 32 * RS + ro);
+                    Bf[ks][i][q] = *reinterpret_cast<const bf16x8 *>(bp + q * PLANE_B + i * 32 * RS + ro);
+                }
         if (a.dbg != nullptr) {
             __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): diagnostic only
             LSN_STAMP(5);
         }
-        // 24 MFMAs; one staging slice in each gap: commits of chunk t+1 followed by the issue that reuses the
-        // registers just consumed (x slices 0..3, then weight slices 0..7)
+        // NGAP MFMAs; the staging slots of chunk t+1 / t+2 are spread over the gaps between them
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int prod = 0; prod < 3; ++prod)
+            for (int prod = 0; prod < NP; ++prod)
 #pragma unroll
                 for (int ij = 0; ij < 4; ++ij) {
                     const int i = ij >> 1, j = ij & 1;
-                    const int gap = ks * 12 + prod * 4 + ij;
-                    const bf16x8 av = (prod == 2) ? Al[ks][i] : Ah[ks][i];
-                    const bf16x8 bv = (prod == 1) ? Bl[ks][j] : Bh[ks][j];
-                    acc[i][j] = mfma_bf16(av, bv, acc[i][j]);
+                    const int gap = (ks * NP + prod) * 4 + ij;
+                    acc[i][j] = mfma_bf16(Af[ks][i][SC::pa(prod)], Bf[ks][j][SC::pb(prod)], acc[i][j]);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (gap < 8) {
-                        if ((gap & 1) == 0)
-                            commit_x(c1, gap >> 1, bn);
-                        else
-                            issue_x(c2, gap >> 1);
-                    } else {
-                        const int ps = (gap - 8) >> 1;
-                        if ((gap & 1) == 0)
-                            commit_w(c1, ps, bn);
-                        else
-                            issue_w(c2, ps);
-                    }
+#pragma unroll
+                    for (int s = gap * NSLOT / NGAP; s < (gap + 1) * NSLOT / NGAP; ++s) staging_slot(s, c1, c2, bn);
                     __builtin_amdgcn_sched_barrier(0);
                 }
         LSN_STAMP(6);
@@ -1168,23 +1192,25 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_kernel(const DcnArgs a)
 // =============================================================================================
 constexpr int BX3_RS = 528;   // bytes per LDS row of the transposed weight slab: 256 co x 2 B + 16 B pad
 
-__host__ __device__ inline size_t bwd_x3_lds_bytes(int KD)
+__host__ __device__ inline size_t bwd_xn_lds_bytes(int np, int KD)
 {
-    return (size_t)2 * 32 * BX3_RS + (size_t)BWD_BM * KD * (sizeof(Tap) + 12);
+    return (size_t)(np == 6 ? 3 : 2) * 32 * BX3_RS + (size_t)BWD_BM * KD * (sizeof(Tap) + 12);
 }
 
-// w (n floats, any layout) -> bf16 hi plane (n) followed by the lo plane (n), same element order
+// w (n floats, any layout) -> NPL bf16 planes of n values each (hi, [mid,] lo), same element order
+template <int NPL>
 __global__ void dcn_prepare_w_kernel(const float *w, unsigned short *out, size_t n)
 {
     for (size_t e = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) * 2; e < n; e += (size_t)gridDim.x * blockDim.x * 2) {
-        unsigned hi, lo;
-        split_bf16x2(w[e], w[e + 1], hi, lo);
-        *reinterpret_cast<unsigned *>(out + e) = hi;
-        *reinterpret_cast<unsigned *>(out + n + e) = lo;
+        unsigned pl[NPL];
+        split_planes<NPL>(w[e], w[e + 1], pl);
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) *reinterpret_cast<unsigned *>(out + q * n + e) = pl[q];
     }
 }
 
-// w (Co, K, C) fp32 -> hi plane [K][C][Co] bf16, then lo plane
+// w (Co, K, C) fp32 -> NPL planes [K][C][Co] bf16
+template <int NPL>
 __global__ void dcn_prepare_wt_kernel(const float *w, unsigned short *out, int Co, int K, int C)
 {
     const size_t n = (size_t)Co * K * C;
@@ -1194,19 +1220,26 @@ __global__ void dcn_prepare_wt_kernel(const float *w, unsigned short *out, int C
         const size_t r = e / Co;
         const int ci = (int)(r % C), k = (int)(r / C);
         const float v0 = w[((size_t)co * K + k) * C + ci], v1 = w[((size_t)(co + 1) * K + k) * C + ci];
-        unsigned hi, lo;
-        split_bf16x2(v0, v1, hi, lo);
-        *reinterpret_cast<unsigned *>(out + e) = hi;
-        *reinterpret_cast<unsigned *>(out + n + e) = lo;
+        unsigned pl[NPL];
+        split_planes<NPL>(v0, v1, pl);
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) *reinterpret_cast<unsigned *>(out + q * n + e) = pl[q];
     }
 }
 
-__global__ __launch_bounds__(256, 2) void dcn_bwd_data_x3_kernel(const DcnArgs a)
+// NP: bf16 products per fp32 product (common.h).  COLBUF: instead of scattering into grad_input with atomics the
+// mask-weighted column gradients go to a.gcol (one 64-byte run per pixel and half-slab), and grad_input is formed by
+// dcn_gather_kernel from per-anchor sample lists: no atomics, each grad_input element written once, fixed summation
+// order.  grad_offset / grad_mask are produced here in both variants.
+template <int NP, bool COLBUF>
+__global__ __launch_bounds__(256, 2) void dcn_bwd_data_xn_kernel(const DcnArgs a)
 {
+    using SC = SplitCfg<NP>;
+    constexpr int NPL = SC::NPL;
     constexpr int BK = 32, RED = 256, NS = RED / 32, RS = BX3_RS;
     extern __shared__ __align__(16) unsigned char smem[];
-    unsigned char *Bh = smem, *Bl = smem + 32 * RS;                      // [32 ch][RED co] bf16, hi / lo
-    Tap *tab = reinterpret_cast<Tap *>(smem + 2 * 32 * RS);              // [64][K*dg]
+    unsigned char *Bp = smem;                                            // [NPL][32 ch][RED co] bf16 planes
+    Tap *tab = reinterpret_cast<Tap *>(smem + NPL * 32 * RS);            // [64][K*dg]
     const int K = a.kh * a.kw, KD = K * a.dg;
     float *gacc = reinterpret_cast<float *>(tab + BWD_BM * KD);          // [64][KD][3]
 
@@ -1228,9 +1261,10 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_x3_kernel(const DcnArgs a
     const int segs = C / a.SL, ncc = (a.SL + BK - 1) / BK;
     const int T = K * segs * ncc;
     const bool want_off = (L.goff != nullptr) || (L.gmsk != nullptr);
+    const bool want_gx = COLBUF ? (a.gcol != nullptr && L.gx != nullptr) : (L.gx != nullptr);
 
     // A operand: gout row of pixel (wave * 16 + j16), k-step s covers co = 32 s + 8 kq .. + 7, split once
-    bf16x8 ah[NS], al[NS];
+    bf16x8 af[NS][NPL];
     {
         const int my_pix = tile_p + wave * 16 + j16;
         const bool pix_ok = my_pix < L.P;
@@ -1246,24 +1280,26 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_x3_kernel(const DcnArgs a
                 v[h * 4 + 0] = ok ? f.x : 0.f, v[h * 4 + 1] = ok ? f.y : 0.f, v[h * 4 + 2] = ok ? f.z : 0.f,
                           v[h * 4 + 3] = ok ? f.w : 0.f;
             }
-            unsigned hi[4], lo[4];
+            unsigned pl[4][NPL];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) split_bf16x2(v[2 * e], v[2 * e + 1], hi[e], lo[e]);
-            const uint4 H = make_uint4(hi[0], hi[1], hi[2], hi[3]), Lo = make_uint4(lo[0], lo[1], lo[2], lo[3]);
-            __builtin_memcpy(&ah[s], &H, 16);
-            __builtin_memcpy(&al[s], &Lo, 16);
+            for (int e = 0; e < 4; ++e) split_planes<NPL>(v[2 * e], v[2 * e + 1], pl[e]);
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) {
+                const uint4 U = make_uint4(pl[0][q], pl[1][q], pl[2][q], pl[3][q]);
+                __builtin_memcpy(&af[s][q], &U, 16);
+            }
         }
     }
 
     // weight slab staging: plane p, channel row r = tid >> 5 (+ 8 per pass), 16-byte piece tid & 31 of its 512 B
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(a.wtp), 0,
-                                                                         K * C * Co * 4, 0x00020000);
+                                                                         K * C * Co * 2 * NPL, 0x00020000);
     const int piece = tid & 31, srow = tid >> 5;
-    float4 wv[8];
+    float4 wv[4 * NPL];
     auto load_w = [&](const Chunk &ch) {
         const int rowbase = ch.k * C + ch.c0;   // row index into [K*C][Co]
 #pragma unroll
-        for (int ps = 0; ps < 8; ++ps) {
+        for (int ps = 0; ps < 4 * NPL; ++ps) {
             const int plane = ps >> 2, r = (ps & 3) * 8 + srow;
             const bool ok = piece * 8 < Co && r < ch.nval;
             const int voff = ok ? (plane * K * C * Co + (rowbase + r) * Co) * 2 + piece * 16 : 0x7ffffff0;
@@ -1273,9 +1309,9 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_x3_kernel(const DcnArgs a
     };
     auto store_w = [&]() {
 #pragma unroll
-        for (int ps = 0; ps < 8; ++ps) {
+        for (int ps = 0; ps < 4 * NPL; ++ps) {
             const int plane = ps >> 2, r = (ps & 3) * 8 + srow;
-            *reinterpret_cast<float4 *>((plane ? Bl : Bh) + r * RS + piece * 16) = wv[ps];
+            *reinterpret_cast<float4 *>(Bp + plane * 32 * RS + r * RS + piece * 16) = wv[ps];
         }
     };
 
@@ -1295,19 +1331,20 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_x3_kernel(const DcnArgs a
         if (t + 1 < T) load_w(chn);
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
         {
-            const unsigned char *b0 = Bh + j16 * RS + kq * 16, *b1 = Bh + (16 + j16) * RS + kq * 16;
+            const unsigned char *b0 = Bp + j16 * RS + kq * 16, *b1 = Bp + (16 + j16) * RS + kq * 16;
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
-                const bf16x8 h0 = *reinterpret_cast<const bf16x8 *>(b0 + s * 64);
-                const bf16x8 h1 = *reinterpret_cast<const bf16x8 *>(b1 + s * 64);
-                const bf16x8 l0 = *reinterpret_cast<const bf16x8 *>(b0 + 32 * RS + s * 64);
-                const bf16x8 l1 = *reinterpret_cast<const bf16x8 *>(b1 + 32 * RS + s * 64);
-                acc0 = mfma16_bf16(ah[s], h0, acc0);
-                acc1 = mfma16_bf16(ah[s], h1, acc1);
-                acc0 = mfma16_bf16(ah[s], l0, acc0);
-                acc1 = mfma16_bf16(ah[s], l1, acc1);
-                acc0 = mfma16_bf16(al[s], h0, acc0);
-                acc1 = mfma16_bf16(al[s], h1, acc1);
+                bf16x8 w0[NPL], w1[NPL];
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) {
+                    w0[q] = *reinterpret_cast<const bf16x8 *>(b0 + q * 32 * RS + s * 64);
+                    w1[q] = *reinterpret_cast<const bf16x8 *>(b1 + q * 32 * RS + s * 64);
+                }
+#pragma unroll
+                for (int prod = 0; prod < NP; ++prod) {
+                    acc0 = mfma16_bf16(af[s][SC::pa(prod)], w0[SC::pb(prod)], acc0);
+                    acc1 = mfma16_bf16(af[s][SC::pa(prod)], w1[SC::pb(prod)], acc1);
+                }
             }
         }
         LSN_STAMP(5);
@@ -1352,7 +1389,16 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_x3_kernel(const DcnArgs a
                     sm[r] += gval * bil;
                 }
             }
-            if (L.gx != nullptr && cval) {
+            if (COLBUF) {
+                if (want_gx && cval) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (tp[r].flags != 0) {   // samples outside the map are in no list
+                            const size_t row = (size_t)(L.prow0 + tile_p + wave * 16 + kq * 4 + r) * K + ch.k;
+                            a.gcol[row * C + c] = gm[r];
+                        }
+                }
+            } else if (want_gx && cval) {
                 // merged scatter, one image row of corners at a time: walk the 4 pixels left to right with a pending
                 // (address, value); a corner equal to the pending address is summed into it, anything else flushes.
 #pragma unroll
@@ -1423,6 +1469,189 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_x3_kernel(const DcnArgs a
                 gmv *= m * (1.f - m);
             }
             L.gmsk[(size_t)b * L.msb + (size_t)(dgi * K + k) * L.msc + (size_t)ho * L.msh + (size_t)wo * L.msw] = gmv;
+        }
+    }
+}
+
+// =============================================================================================
+// grad_input without atomics: anchor lists + gather (the COLBUF path of dcn_bwd_data_xn_kernel).
+//
+// A sample (pixel, tap[, deformable group]) at position (py, px) touches the four input pixels around its
+// ANCHOR (y0, x0) = floor(py, px), y0 in [-1, H-1], x0 in [-1, W-1].  Input pixel q = (y, x) therefore receives
+//   from anchor (y, x)     the (1-ly)(1-lx) corner,   from (y, x-1)   the (1-ly) lx corner,
+//   from anchor (y-1, x)   the ly (1-lx) corner,      from (y-1, x-1) the ly lx corner
+// of every sample anchored there.  dcn_bin_kernel counts the samples of every anchor (integer atomics, 1 per sample
+// against 4 x C float atomics per sample before) and records each sample's rank; a single-block scan turns the counts
+// into list offsets; dcn_fill_kernel writes {sample, ly, lx} entries; dcn_sort_lists_kernel orders each list by sample
+// id (so that the summation order is fixed); dcn_gather_kernel walks the four lists of every input pixel, reads the
+// mask-weighted column-gradient rows (C contiguous floats each) and writes grad_input once.
+// Levels that scatter into the same grad_input buffer (the pyramid op: one source map for several destination
+// levels) share one anchor grid, so their contributions are summed here instead of by separate tensor adds.
+// =============================================================================================
+struct __align__(16) GEntry {
+    int s;        // sample id = (prow0 + pix) * KD + dgi * K + k
+    int pad;
+    float ly, lx;
+};
+
+struct GatherGrp {
+    float *gx;
+    int B, H, W;
+    int abase;   // first anchor id: anchors (B, H+1, W+1), (y0+1, x0+1) row-major
+    int q0;      // first input pixel of this group in the launch-wide numbering
+};
+struct GatherArgs {
+    GatherGrp g[MAXLV];
+    int ng, Q;          // groups, total input pixels
+    int C, K, KD, dg;
+    const float *gcol;
+    const int *start;   // [anchors + 1]
+    const GEntry *ent;
+};
+
+__device__ __forceinline__ const Lvl &find_level_by_row(const DcnArgs &a, int prow)
+{
+    int li = 0;
+    while (li + 1 < a.nlv && prow >= a.lv[li + 1].prow0) ++li;
+    return a.lv[li];
+}
+
+// one thread per sample: anchor, rank inside the anchor's list, fractions
+__global__ void dcn_bin_kernel(const DcnArgs a, int nsamples, int *__restrict__ cnt, int *__restrict__ sanchor,
+                               int *__restrict__ srank, float2 *__restrict__ sfrac)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nsamples) return;
+    const int K = a.kh * a.kw, KD = K * a.dg;
+    const int prow = s / KD, kd = s - prow * KD;
+    const int dgi = kd / K, k = kd - dgi * K;
+    const Lvl &L = find_level_by_row(a, prow);
+    int anchor = -1, rank = 0;
+    float2 fr = make_float2(0.f, 0.f);
+    if (L.gx != nullptr) {
+        int4 yx = make_int4(0, 0, 0, 0);
+        const Tap t = make_tap_ex(a, L, prow - L.prow0, k, dgi, &yx);
+        if (t.flags) {
+            const int y0 = (t.flags & 3) ? yx.x : -1, x0 = (t.flags & 5) ? yx.y : -1;   // unclamped floor(py), floor(px)
+            const int HWo = L.Ho * L.Wo;
+            const int b = (prow - L.prow0) / HWo;
+            anchor = L.abase + (b * (L.H + 1) + y0 + 1) * (L.W + 1) + x0 + 1;
+            rank = atomicAdd(&cnt[anchor], 1);
+            fr = make_float2(t.ly, t.lx);
+        }
+    }
+    sanchor[s] = anchor;
+    srank[s] = rank;
+    sfrac[s] = fr;
+}
+
+// exclusive prefix sum of cnt[0..n) into start[0..n], one workgroup of 1024 threads
+__global__ __launch_bounds__(1024) void dcn_scan_kernel(const int *__restrict__ cnt, int *__restrict__ start, int n)
+{
+    __shared__ int part[1024];
+    const int tid = threadIdx.x;
+    const int per = (n + 1023) / 1024;
+    const int b = min(tid * per, n), e = min(b + per, n);
+    int sum = 0;
+    for (int i = b; i < e; ++i) sum += cnt[i];
+    part[tid] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {   // Hillis-Steele inclusive scan
+        const int v = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = part[tid] - sum;
+    for (int i = b; i < e; ++i) {
+        start[i] = run;
+        run += cnt[i];
+    }
+    if (tid == 1023) start[n] = part[1023];
+}
+
+__global__ void dcn_fill_kernel(int nsamples, const int *__restrict__ start, const int *__restrict__ sanchor,
+                                const int *__restrict__ srank, const float2 *__restrict__ sfrac, GEntry *__restrict__ ent)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nsamples) return;
+    const int an = sanchor[s];
+    if (an < 0) return;
+    GEntry e;
+    e.s = s, e.pad = 0;
+    const float2 f = sfrac[s];
+    e.ly = f.x, e.lx = f.y;
+    ent[start[an] + srank[s]] = e;
+}
+
+// one wave per anchor list: lists of 2..64 entries are rewritten in ascending sample order (longer lists, hundreds of
+// samples converging on one landmark in the pyramid op, keep their arrival order)
+__global__ __launch_bounds__(256) void dcn_sort_lists_kernel(int nanchors, const int *__restrict__ start, GEntry *__restrict__ ent)
+{
+    const int lane = threadIdx.x & 63;
+    const int wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+    for (int an = wid; an < nanchors; an += nw) {
+        const int b = start[an], n = start[an + 1] - b;
+        if (n < 2 || n > 64) continue;
+        GEntry e = {};
+        if (lane < n) e = ent[b + lane];
+        const int key = lane < n ? e.s : 0x7fffffff;
+        int rank = 0;
+        for (int j = 0; j < n; ++j) rank += (__builtin_amdgcn_readlane(key, j) < key) ? 1 : 0;   // sample ids are distinct
+        if (lane < n) ent[b + rank] = e;
+    }
+}
+
+// one wave per input pixel (4 pixels per workgroup pass); lane = 4 consecutive channels
+__global__ __launch_bounds__(256) void dcn_gather_kernel(const GatherArgs ga)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int C = ga.C, K = ga.K, KD = ga.KD;
+    const int cpdg = C / ga.dg;
+    const int nq = gridDim.x * 4;
+    for (int qi = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave; qi < ga.Q; qi += nq) {
+        int gi = 0;
+        while (gi + 1 < ga.ng && qi >= ga.g[gi + 1].q0) ++gi;
+        const GatherGrp &G = ga.g[gi];
+        const int q = qi - G.q0;
+        const int HW = G.H * G.W;
+        const int b = q / HW, rem = q - b * HW;
+        const int y = rem / G.W, x = rem - y * G.W;
+        for (int cb = 0; cb < C; cb += 256) {
+            const int c = cb + lane * 4;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int corner = 0; corner < 4; ++corner) {
+                const int dy = corner >> 1, dx = corner & 1;
+                const int an = G.abase + (b * (G.H + 1) + y - dy + 1) * (G.W + 1) + x - dx + 1;
+                const int lb = __builtin_amdgcn_readfirstlane(ga.start[an]);
+                const int le = __builtin_amdgcn_readfirstlane(ga.start[an + 1]);
+                for (int base = lb; base < le; base += 64) {
+                    const int n = min(64, le - base);
+                    GEntry e = {};
+                    if (lane < n) e = ga.ent[base + lane];
+#pragma unroll 4
+                    for (int j = 0; j < n; ++j) {
+                        const int s = __builtin_amdgcn_readlane(e.s, j);
+                        const float ly = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e.ly), j));
+                        const float lx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e.lx), j));
+                        const float wy = dy ? ly : 1.f - ly, wx = dx ? lx : 1.f - lx;
+                        const float w = wy * wx;
+                        int row = s, c_lo = 0, c_hi = C;
+                        if (ga.dg > 1) {
+                            const int prow = s / KD, kd = s - prow * KD;
+                            const int dgi = kd / K;
+                            row = prow * K + (kd - dgi * K);
+                            c_lo = dgi * cpdg, c_hi = c_lo + cpdg;
+                        }
+                        if (c < c_hi && c >= c_lo) {
+                            const float4 v = *reinterpret_cast<const float4 *>(ga.gcol + (size_t)row * C + c);
+                            acc.x += w * v.x, acc.y += w * v.y, acc.z += w * v.z, acc.w += w * v.w;
+                        }
+                    }
+                }
+            }
+            if (c < C) *reinterpret_cast<float4 *>(G.gx + (size_t)q * C + c) = acc;
         }
     }
 }
@@ -2254,7 +2483,7 @@ __global__ __launch_bounds__(256, 2) void dcn_wgrad_kernel(const DcnArgs a, int 
 }
 
 // =============================================================================================
-// Backward-weight on the bf16 matrix pipe with split operands (dcn_wgrad_x3_kernel).
+// Backward-weight on the bf16 matrix pipe with split operands (dcn_wgrad_xn_kernel).
 //
 // Same decomposition as dcn_wgrad_kernel (grid = column blocks x pixel splits x 256-co blocks, 32-pixel steps,
 // fp32 atomics into gw at the end).  The reduction index of this GEMM is the PIXEL, so both LDS images are built
@@ -2264,12 +2493,20 @@ __global__ __launch_bounds__(256, 2) void dcn_wgrad_kernel(const DcnArgs a, int 
 // row pieces.  24 MFMAs of 32 cycles per step and wave instead of 64 of 64.
 // PLAIN: a dense convolution (no offsets, no mask): one load per sample instead of four corners.
 // =============================================================================================
-template <bool PLAIN>
-__global__ __launch_bounds__(256, 2) void dcn_wgrad_x3_kernel(const DcnArgs a, int nsteps)
+template <int NP>
+__host__ __device__ inline size_t wgrad_xn_lds_bytes()
 {
+    return (size_t)SplitCfg<NP>::NPL * (WG_BM + WG_BN) * 80 + 2 * WG_BP * sizeof(Tap);
+}
+
+template <bool PLAIN, int NP>
+__global__ __launch_bounds__(256, 2) void dcn_wgrad_xn_kernel(const DcnArgs a, int nsteps)
+{
+    using SC = SplitCfg<NP>;
+    constexpr int NPL = SC::NPL;
     constexpr int RS = 80, PLANE_A = WG_BM * RS, PLANE_B = WG_BN * RS;
-    extern __shared__ __align__(16) unsigned char smem[];   // [A hi][A lo][B hi][B lo][tab 2 x 32]
-    Tap *tab = reinterpret_cast<Tap *>(smem + 2 * PLANE_A + 2 * PLANE_B);
+    extern __shared__ __align__(16) unsigned char smem[];   // [A planes][B planes][tab 2 x 32]
+    Tap *tab = reinterpret_cast<Tap *>(smem + NPL * PLANE_A + NPL * PLANE_B);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = a.kh * a.kw;
@@ -2340,7 +2577,7 @@ __global__ __launch_bounds__(256, 2) void dcn_wgrad_x3_kernel(const DcnArgs a, i
     };
     auto store_step = [&](int buf) {
         // gathered columns: 8 pixels of channel kk -> one 16-byte piece of row kk in each plane
-        unsigned hi[4], lo[4];
+        unsigned cp[4][NPL];
 #pragma unroll
         for (int q2 = 0; q2 < 4; ++q2) {
             float v[2];
@@ -2357,20 +2594,22 @@ __global__ __launch_bounds__(256, 2) void dcn_wgrad_x3_kernel(const DcnArgs a, i
                 }
                 v[h] = cval ? v[h] : 0.f;
             }
-            split_bf16x2(v[0], v[1], hi[q2], lo[q2]);
+            split_planes<NPL>(v[0], v[1], cp[q2]);
         }
-        unsigned char *bp = smem + 2 * PLANE_A + kk * RS + pg * 16;
-        *reinterpret_cast<uint4 *>(bp) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-        *reinterpret_cast<uint4 *>(bp + PLANE_B) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+        unsigned char *bp = smem + NPL * PLANE_A + kk * RS + pg * 16;
+#pragma unroll
+        for (int q = 0; q < NPL; ++q)
+            *reinterpret_cast<uint4 *>(bp + q * PLANE_B) = make_uint4(cp[0][q], cp[1][q], cp[2][q], cp[3][q]);
         // gout: 32 pixels of output channel tid -> row tid (64 bytes) in each plane
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
-            unsigned h4[4], l4[4];
+            unsigned gp4[4][NPL];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) split_bf16x2(gv[q4 * 8 + 2 * e], gv[q4 * 8 + 2 * e + 1], h4[e], l4[e]);
+            for (int e = 0; e < 4; ++e) split_planes<NPL>(gv[q4 * 8 + 2 * e], gv[q4 * 8 + 2 * e + 1], gp4[e]);
             unsigned char *ap = smem + tid * RS + q4 * 16;
-            *reinterpret_cast<uint4 *>(ap) = make_uint4(h4[0], h4[1], h4[2], h4[3]);
-            *reinterpret_cast<uint4 *>(ap + PLANE_A) = make_uint4(l4[0], l4[1], l4[2], l4[3]);
+#pragma unroll
+            for (int q = 0; q < NPL; ++q)
+                *reinterpret_cast<uint4 *>(ap + q * PLANE_A) = make_uint4(gp4[0][q], gp4[1][q], gp4[2][q], gp4[3][q]);
         }
         if (do_bias) {
 #pragma unroll
@@ -2389,24 +2628,24 @@ __global__ __launch_bounds__(256, 2) void dcn_wgrad_x3_kernel(const DcnArgs a, i
             __syncthreads();
             if (st + 1 < st_end) load_step(st + 1, buf ^ 1);
             const unsigned char *ap = smem + (wave * 64 + (lane & 31)) * RS + (lane >> 5) * 16;
-            const unsigned char *bp = smem + 2 * PLANE_A + (lane & 31) * RS + (lane >> 5) * 16;
+            const unsigned char *bp = smem + NPL * PLANE_A + (lane & 31) * RS + (lane >> 5) * 16;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 Ah[2], Al[2], Bh[2], Bl[2];
+                bf16x8 Af[2][NPL], Bf[2][NPL];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    Ah[i] = *reinterpret_cast<const bf16x8 *>(ap + i * 32 * RS + ks * 32);
-                    Al[i] = *reinterpret_cast<const bf16x8 *>(ap + PLANE_A + i * 32 * RS + ks * 32);
-                    Bh[i] = *reinterpret_cast<const bf16x8 *>(bp + i * 32 * RS + ks * 32);
-                    Bl[i] = *reinterpret_cast<const bf16x8 *>(bp + PLANE_B + i * 32 * RS + ks * 32);
-                }
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int prod = 0; prod < 3; ++prod)
+                    for (int q = 0; q < NPL; ++q) {
+                        Af[i][q] = *reinterpret_cast<const bf16x8 *>(ap + q * PLANE_A + i * 32 * RS + ks * 32);
+                        Bf[i][q] = *reinterpret_cast<const bf16x8 *>(bp + q * PLANE_B + i * 32 * RS + ks * 32);
+                    }
+#pragma unroll
+                for (int prod = 0; prod < NP; ++prod)
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
                         for (int j = 0; j < 2; ++j)
-                            acc[i][j] = mfma_bf16(prod == 2 ? Al[i] : Ah[i], prod == 1 ? Bl[j] : Bh[j], acc[i][j]);
+                            acc[i][j] = mfma_bf16(Af[i][SC::pa(prod)], Bf[j][SC::pb(prod)], acc[i][j]);
             }
             __syncthreads();
         }

@@ -78,7 +78,8 @@ class BaseDetector(nn.Module):
                 raise TypeError(f'{name} is not a tensor or list of tensors')
         loss = sum(v for k, v in log_vars.items() if 'loss' in k)
         log_vars['loss'] = loss
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and not capturing:
             packed = torch.stack([v.detach().reshape(()) for v in log_vars.values()])
             dist.all_reduce(packed.div_(dist.get_world_size()))   # one collective for all scalars
             for i, k in enumerate(list(log_vars.keys())):

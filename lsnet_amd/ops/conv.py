@@ -3,7 +3,7 @@ mmcv/cnn/bricks/conv.py:11-43 `build_conv_layer`).
 
 `Conv2d` subclasses nn.Conv2d (same parameters and state-dict keys).  CUDA channels-last fp32 inputs of a
 supported shape run the split-bf16 implicit-GEMM kernels of csrc/conv.hip when the library's math mode is
-'bf16x3'; everything else -- exact-fp32 mode, grouped / strided-backward / odd shapes, CPU tensors -- goes to
+'bf16x6' (fp32-equivalent, the default) or 'bf16x3'; everything else -- exact-fp32 mode, grouped / odd shapes, CPU tensors -- goes to
 ATen's convolution (MIOpen), which is a different vendor operator, not a fallback of the HIP path."""
 import ctypes
 
@@ -35,7 +35,7 @@ class _ConvFn(torch.autograd.Function):
         Wo = (W + 2 * pad - (dil * (kw - 1) + 1)) // stride + 1
         w = w.contiguous(memory_format=_CL)
         out = torch.empty((B, Co, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=_CL)
-        ws = torch.empty(w.numel(), device=x.device, dtype=torch.float32)
+        ws = torch.empty(2 * w.numel(), device=x.device, dtype=torch.float32)
         _lib.check(lib.lsn_conv2d_forward(_p(x), _p(w), _p(bias), _p(out), _p(ws), B, H, W, C, Co, kh, kw, stride, pad,
                                           dil, 1 if relu else 0, _stream()))
         ctx.save_for_backward(x, w, out if relu else None)
@@ -58,7 +58,7 @@ class _ConvFn(torch.autograd.Function):
                     and _own_is_faster(B * H * W, Co, C, kh * kw))
         if ctx.needs_input_grad[0] and own_data:
             gx = torch.empty_like(x, memory_format=_CL)
-            ws = torch.empty(w.numel(), device=x.device, dtype=torch.float32)
+            ws = torch.empty(2 * w.numel(), device=x.device, dtype=torch.float32)
             _lib.check(lib.lsn_conv2d_backward_data(_p(go), _p(w), _p(gx), _p(ws), B, H, W, C, Co, kh, kw, stride, pad,
                                                     dil, _stream()))
         own_w = ctx.needs_input_grad[1] and Co >= 256 and C >= 256 and C * kh * kw >= 512 and C % 4 == 0
@@ -89,7 +89,7 @@ def hip_conv_ok(x, weight, stride, padding, dilation, groups, padding_mode='zero
     C = x.shape[1]
     if C % 4 != 0 or C < 16 or x.numel() * 4 >= 2 ** 31 or weight.numel() * 4 >= 2 ** 31:
         return False
-    return _lib.get_math_mode() == 'bf16x3'
+    return _lib.split_math()
 
 
 def _own_is_faster(pixels, cin, cout, taps):

@@ -145,8 +145,8 @@ class HipBackend:
             L.B, L.H, L.W, L.Ho, L.Wo = B, H, W, Ho, Wo
             L.scale_h, L.scale_w = cfg['scales'][i]
         b = None if bias is None else _f32(bias.contiguous(), 'bias')
-        if _lib.get_math_mode() == 'bf16x3':
-            ws = torch.empty(w.numel(), device=w.device, dtype=torch.float32)   # pre-split weights
+        if _lib.split_math():
+            ws = torch.empty(2 * w.numel(), device=w.device, dtype=torch.float32)   # pre-split weight planes
             shape.workspace = ws.data_ptr()
         _lib.check(lib.lsn_dcn_forward(ctypes.byref(shape), n, levels, _ptr(w), _ptr(b), 1 if nhwc else 0,
                                        _stream()))
@@ -161,17 +161,24 @@ class HipBackend:
         shape = self._shape(w, cfg)
         levels = (_lib.DcnLevel * n)()
         gxs, goffs, gmsks, keep = [], [], [], []
+        shared = {}   # levels sampling ONE source map (pyramid op) accumulate into one grad_input buffer
         for i in range(n):
             B, C, H, W = xs[i].shape
             go = grad_outs[i]
             go = go.contiguous(memory_format=_CL) if nhwc else go.contiguous()
             keep.append(go)
             Ho, Wo = go.shape[2], go.shape[3]
-            gx = torch.empty_like(xs[i]) if need['input'][i] else None
+            gx = gx_ret = None
+            if need['input'][i]:
+                key = (xs[i].data_ptr(), tuple(xs[i].shape)) if nhwc else i
+                if key in shared:
+                    gx = shared[key]            # the first level of the group returns the buffer, the others None
+                else:
+                    gx = gx_ret = shared[key] = torch.empty_like(xs[i])
             want_om = need['offset'][i] or (msks[i] is not None and need['mask'][i])
             goff = torch.empty_like(offs[i]) if want_om else None
             gmsk = torch.empty_like(msks[i]) if (want_om and msks[i] is not None) else None
-            gxs.append(gx); goffs.append(goff); gmsks.append(gmsk)
+            gxs.append(gx_ret); goffs.append(goff); gmsks.append(gmsk)
             L = levels[i]
             L.input, L.offset, L.mask = _ptr(xs[i]), _ptr(offs[i]), _ptr(msks[i])
             L.grad_output, L.grad_input, L.grad_offset, L.grad_mask = _ptr(go), _ptr(gx), _ptr(goff), _ptr(gmsk)
@@ -185,10 +192,14 @@ class HipBackend:
                 L.mask_st = _strides(msks[i])
             L.B, L.H, L.W, L.Ho, L.Wo = B, H, W, Ho, Wo
             L.scale_h, L.scale_w = cfg['scales'][i]
-        ws = None
-        if cfg['groups'] == 1 and _lib.get_math_mode() == 'bf16x3':
-            ws = torch.empty(w.numel(), device=w.device, dtype=torch.float32)   # split + transposed weights
+        ws = gws = None
+        if cfg['groups'] == 1 and _lib.split_math():
+            ws = torch.empty(2 * w.numel(), device=w.device, dtype=torch.float32)   # split + transposed weight planes
             shape.workspace = ws.data_ptr()
+            nbytes = int(lib.lsn_dcn_backward_workspace_bytes(ctypes.byref(shape), n, levels))
+            if nbytes > 0:   # column-gradient buffer + anchor lists of the atomic-free grad_input path
+                gws = torch.empty(nbytes, device=w.device, dtype=torch.uint8)
+                shape.gather_workspace, shape.gather_workspace_bytes = gws.data_ptr(), nbytes
         gw = torch.empty_like(w) if (need['weight'] or need['bias']) else None
         gb = torch.empty(w.shape[0], device=w.device, dtype=torch.float32) if need['bias'] else None
         _lib.check(lib.lsn_dcn_backward(ctypes.byref(shape), n, levels, _ptr(w), _ptr(gw), _ptr(gb),

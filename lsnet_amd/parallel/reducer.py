@@ -6,9 +6,10 @@ Takes the place of the reference's `MMDistributedDataParallel` = torch DDP over 
     backbone, the order backward produces them); xGMI is point-to-point (7 links x ~153 GB/s), so a
     ring all-reduce is bound by one link: large buckets amortise latency, and 154 MB of fp32 grads
     (R-50) takes ~2 ms per step, far below the compute time -- it only has to start early;
+  * `p.grad` is a VIEW into its bucket, so backward writes the communication buffers directly (no copies);
   * a bucket's all-reduce is launched (async, on RCCL's own stream) the moment its last gradient
     has been accumulated, from `register_post_accumulate_grad_hook`, so it overlaps the rest of
-    backward; `finish()` waits, averages and scatters the results back before clip-grad / SGD.
+    backward; `finish()` waits and averages in place before clip-grad / SGD.
 Works with any torch.distributed backend ('nccl' = RCCL on ROCm; 'gloo' in the CPU tests)."""
 import os
 
@@ -29,12 +30,22 @@ def init_dist(backend='nccl', **kwargs):
 
 
 class BucketedGradReducer:
+    """Gradient-VIEW buckets: every `p.grad` is a view (in the parameter's own memory layout) into one of a few flat
+    tensors, so backward accumulates straight into the communication buffers -- no gradient -> bucket -> gradient
+    copies, one fill per bucket to zero them, one all-reduce per bucket.
+
+    Buckets are all-reduced strictly in index order (the order backward completes them: head -> neck -> backbone):
+    a bucket is launched from the grad-ready hook only when every earlier bucket has been launched, everything else
+    in `finish()`.  All ranks therefore issue the same collectives in the same order whatever subset of parameters
+    received a gradient.  Parameters without a gradient in a step keep zeros in their slot (with torch DDP they would
+    keep `grad=None`; every trainable LSNet parameter gets a gradient in every step, frozen ones have
+    requires_grad=False and are not bucketed)."""
 
     def __init__(self, params, bucket_mb=64.0, process_group=None):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.params = [p for p in params if p.requires_grad]
-        self.buckets = []          # dict(flat, params, offsets, pending, work)
+        self.buckets = []          # dict(flat, params, views, pending, work)
         cap = int(bucket_mb * 1024 * 1024 / 4)
         cur, size = [], 0
         for p in reversed(self.params):
@@ -56,47 +67,70 @@ class BucketedGradReducer:
     def _close(self, plist):
         n = sum(p.numel() for p in plist)
         flat = torch.zeros(n, dtype=plist[0].dtype, device=plist[0].device)
-        offs, o = [], 0
+        views, o = [], 0
         for p in plist:
-            offs.append(o)
+            seg = flat[o:o + p.numel()]
+            # same memory layout as the parameter (channels-last conv weights): autograd then adds in place
+            dense = p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))
+            views.append(seg.as_strided(p.shape, p.stride()) if dense else seg.view_as(p))
             o += p.numel()
-        self.buckets.append(dict(flat=flat, params=list(plist), offsets=offs, pending=0, work=None))
+        self.buckets.append(dict(flat=flat, params=list(plist), views=views, pending=0, work=None))
 
     def reset(self):
+        self._next = 0            # first bucket not yet launched
         for b in self.buckets:
             b['pending'] = len(b['params'])
             b['work'] = None
 
+    @staticmethod
+    def _is_view(g, v):
+        return g is v or (g is not None and g.data_ptr() == v.data_ptr() and g.stride() == v.stride())
+
+    def zero_grad(self):
+        """Replaces optimizer.zero_grad(): one fill per bucket, and p.grad (re)pointed at its bucket view."""
+        for b in self.buckets:
+            b['flat'].zero_()
+            for p, v in zip(b['params'], b['views']):
+                if not self._is_view(p.grad, v):
+                    p.grad = v
+
+    def _launch_ready(self):
+        while self._next < len(self.buckets) and self.buckets[self._next]['pending'] == 0:
+            b = self.buckets[self._next]
+            b['work'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._next += 1
+
     def _on_grad(self, p):
         bi, pi = self._where[p]
         b = self.buckets[bi]
-        o = b['offsets'][pi]
-        b['flat'][o:o + p.numel()].copy_(p.grad.reshape(-1))
+        v = b['views'][pi]
+        if not self._is_view(p.grad, v):   # the gradient was not preset (zero_grad() skipped): move it into the bucket
+            v.copy_(p.grad)
+            p.grad = v
         b['pending'] -= 1
+        if b['pending'] < 0:
+            raise RuntimeError('BucketedGradReducer: a second backward() before finish() -- gradient accumulation '
+                               'over several backward passes is not supported')
         if b['pending'] == 0:
-            b['work'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._launch_ready()
 
     def finish(self):
-        """Wait for all buckets, write the averaged gradients back.  Parameters that received no
-        gradient this step contribute zeros (every rank launches every bucket, so the collective
-        sequence is identical on all ranks)."""
+        """Launch what the hooks could not (in order), wait, average."""
         if self.world == 1:
             return
-        for b in self.buckets:
-            if b['work'] is None:      # some parameter produced no grad: fill the holes, reduce now
-                for p, o in zip(b['params'], b['offsets']):
-                    if p.grad is None:
-                        b['flat'][o:o + p.numel()].zero_()
-                b['work'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        while self._next < len(self.buckets):
+            b = self.buckets[self._next]
+            for p, v in zip(b['params'], b['views']):
+                if p.grad is None:
+                    p.grad = v    # zeros unless zero_grad() was skipped (then: stale values are cleared here)
+                elif not self._is_view(p.grad, v):
+                    v.copy_(p.grad)
+                    p.grad = v
+            b['pending'] = 0
+            self._launch_ready()
         for b in self.buckets:
             b['work'].wait()
             b['flat'].div_(self.world)
-            for p, o in zip(b['params'], b['offsets']):
-                g = b['flat'][o:o + p.numel()].view_as(p)
-                if p.grad is None:
-                    p.grad = g.clone()
-                else:
-                    p.grad.copy_(g)
         self.reset()
 
 
@@ -122,6 +156,10 @@ class DataParallelModel(nn.Module):
 
     def val_step(self, *args, **kwargs):
         return self.module.val_step(*args, **kwargs)
+
+    def zero_grad_buckets(self):
+        """Called by OptimizerHook instead of optimizer.zero_grad() (one fill per bucket)."""
+        self.reducer.zero_grad()
 
     def reduce_gradients(self):
         self.reducer.finish()

@@ -128,6 +128,16 @@ class GraphedForwardBackward:
         self.reduce_gradients()
         out = dict(out)
         out['backward_done'] = True
+        if self.world > 1 and hasattr(out.get('log_vars'), 'keys'):
+            # no collective is captured (base.py skips it while capturing): the log scalars are averaged here
+            lv = out['log_vars']
+            keys = list(lv.keys())
+            packed = torch.stack([lv[k].detach().reshape(()) for k in keys]).div_(self.world)
+            dist.all_reduce(packed, group=self.group)
+            avg = type(lv)()
+            for i, k in enumerate(keys):
+                avg[k] = packed[i]
+            out['log_vars'] = avg
         return out
 
     def reduce_gradients(self):

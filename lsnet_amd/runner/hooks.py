@@ -115,7 +115,10 @@ class OptimizerHook(Hook):
 
     def after_train_iter(self, runner):
         if not runner.outputs.get('backward_done'):   # a GraphedForwardBackward step has done all of this
-            runner.optimizer.zero_grad(set_to_none=True)
+            if hasattr(runner.model, 'zero_grad_buckets'):
+                runner.model.zero_grad_buckets()     # data parallel: gradients live in the all-reduce buckets
+            else:
+                runner.optimizer.zero_grad(set_to_none=True)
             runner.outputs['loss'].backward()
             if hasattr(runner.model, 'reduce_gradients'):
                 runner.model.reduce_gradients()
@@ -150,9 +153,15 @@ class TextLoggerHook(Hook):
     def __init__(self, interval=50, by_epoch=True, **kwargs):
         self.interval = interval
 
+    def after_train_epoch(self, runner):
+        runner.log_buffer_average()           # windows do not span epochs (hooks/logger/base.py:158-163)
+
     def after_train_iter(self, runner):
-        if self.every_n_iters(runner, self.interval):
+        if (runner.inner_iter + 1) % self.interval == 0:      # every_n_inner_iters, hooks/logger/base.py:142-150
             avg = runner.log_buffer_average()
+            if getattr(runner, 'rank', 0) != 0:                # only rank 0 prints (text.py:100-130 via master_only)
+                runner.last_log = avg
+                return
             lr = runner.optimizer.param_groups[0]['lr']
             msg = ', '.join(f'{k}: {v:.4f}' for k, v in avg.items())
             line = f'Epoch [{runner.epoch + 1}][{runner.inner_iter + 1}/{runner.epoch_len}]\tlr: {lr:.5f}, {msg}'

@@ -42,7 +42,7 @@ def test_multiclass_nms_lsvr():
     gc.nms_lsvr_case(_dev())
 
 
-@pytest.mark.parametrize('math', ['bf16x3', 'fp32'])
+@pytest.mark.parametrize('math', ['bf16x6', 'bf16x3', 'fp32'])
 def test_training_curve_follows_reference_runner(math):
     """12 SGD iterations on the device against the curve of the reference's detector + mmcv runner on CPU
     (SURVEY.md 8d).  Measured on the MI355X (profiles/r1y_train_curve_gpu.log): <= 1.5e-4 relative over the first six

@@ -1,17 +1,13 @@
 """Fused cross-IOU kernels (csrc/loss.hip) against the torch formulation on the device: loss rows and gradient.
 The row function itself is checked against autograd on the CPU (tests/test_fused_cross_iou.py); this test covers the
-launch, the C ABI and the autograd binding.  Written after round 1's GPU budget was spent: opt-in with
-LSNET_UNVERIFIED_GPU=1 until it has run on the device once (the path it tests is itself opt-in: LSNET_FUSED_CIOU=1)."""
-import os
-
+launch, the C ABI and the autograd binding."""
 import pytest
 import torch
 
 from lsnet_amd.models.losses import CrossIOULoss
 from tests.test_fused_cross_iou import _case
 
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get('LSNET_UNVERIFIED_GPU') != '1',
-                                                  reason='not yet run on the device: set LSNET_UNVERIFIED_GPU=1')]
+pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize('seed', [0, 1])
