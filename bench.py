@@ -63,6 +63,7 @@ def parse():
                     help="arithmetic of the conv / deformable-conv contractions: 'bf16x6' = fp32-equivalent (exact 3-way "
                          "bf16 split of every operand, 6 product terms, fp32 accumulation; the library default), "
                          "'bf16x3' = 2-way split, 3 terms (rel. err 5e-6), 'fp32' = exact fp32 MFMA")
+    ap.add_argument('--cpu-baseline-worker', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--no-extra', action='store_true', help='skip the extra legs (other arithmetic modes, inference)')
     ap.add_argument('--graph', action='store_true',
                     help='replay forward+backward from one captured hipGraph (runner/graph_step.py) instead of '
@@ -140,42 +141,66 @@ def build_step(model, cfg):
     return step, runner
 
 
-def cpu_baseline(args):
-    """BASELINE config 1 on the host: the training step of the same model on 2 images 3x800x800 with this repo's host
-    code and the CPU oracle behind the native ops (the reference has no CPU path for them: SURVEY.md section 0.2), all
-    host cores, one warm-up step excluded.  Test infrastructure used as the timed baseline, never as the product."""
+CPU_BASELINE_THREADS = 64     # more threads were slower on the 256-core host of the GPU box (a 256-thread run of this
+                              # leg did not finish one step in 15 minutes: oversubscribed OpenMP team + torch pool)
+CPU_BASELINE_LIMIT_S = 300    # hard wall-clock limit of the leg (it runs in a child process)
+
+
+def cpu_baseline_worker(args):
+    """Child process: BASELINE config 1 on the host CPU.  Prints one JSON line."""
     from lsnet_amd.data import synthetic_batch
     from lsnet_amd.model_zoo import build_lsnet
-    from lsnet_amd.ops import register_backend, unregister_backend
+    from lsnet_amd.ops import register_backend
     from tests.oracle_backend import OracleBackend
     from oracle import oracle_py
     h, w, b = 800, 800, 2
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
-    os.environ.setdefault('OMP_NUM_THREADS', str(cores))
+    threads = min(cores, CPU_BASELINE_THREADS)
+    torch.set_num_threads(threads)
     register_backend('cpu', OracleBackend())
+    torch.manual_seed(0)
+    model, cfg = build_lsnet(args.task, args.backbone)
+    model.train()
+    step, _ = build_step(model, cfg)
+    data = synthetic_batch(args.task, b, h, w, seed=99, device='cpu', channels_last=False)
+    t0 = time.time()
+    step(data)                                   # warm-up (allocations, thread pools), not timed
+    warm = time.time() - t0
+    nstep = 3 if warm < 20 else 1                # keep the whole bench run inside a few minutes
+    t0 = time.time()
+    for _ in range(nstep):
+        out = step(data)
+        loss = float(out['loss'].detach())
+    dt = (time.time() - t0) / nstep
+    print(json.dumps(dict(
+        value=b / dt, unit='img/s', cores=threads, kind='port',
+        sample=f'BASELINE config 1: {nstep} timed training step(s) (fwd+bwd+clip+SGD; 1 warm-up step of {warm:.1f} s '
+               f'excluded) of LSNet {args.backbone.upper()}-FPN {args.task} on {b} images 3x{h}x{w}; '
+               f'torch.set_num_threads({threads}), {oracle_py.num_threads()} OpenMP threads in the oracle, host has '
+               f'{cores} cores; {dt:.1f} s per step, last loss {loss:.3f}')))
+
+
+def cpu_baseline(args):
+    """BASELINE config 1 (2 images 3x800x800) on the host: the training step of the same model with this repo's host
+    code and the CPU oracle behind the native ops (the reference has no CPU path for them: SURVEY.md section 0.2), in a
+    child process with a hard time limit.  Test infrastructure used as the timed baseline, never as the product."""
+    import subprocess
+    cores = os.cpu_count() or 1
+    threads = min(cores, CPU_BASELINE_THREADS)
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES='',
+               CUDA_VISIBLE_DEVICES='')
+    cmd = [sys.executable, os.path.abspath(__file__), '--cpu-baseline-worker', '--task', args.task, '--backbone',
+           args.backbone]
     try:
-        torch.manual_seed(0)
-        model, cfg = build_lsnet(args.task, args.backbone)
-        model.train()
-        step, _ = build_step(model, cfg)
-        data = synthetic_batch(args.task, b, h, w, seed=99, device='cpu', channels_last=False)
-        t0 = time.time()
-        step(data)                                   # warm-up (allocations, thread pools), not timed
-        warm = time.time() - t0
-        nstep = 3 if warm < 25 else 1                # keep the whole bench run inside a few minutes
-        t0 = time.time()
-        for _ in range(nstep):
-            out = step(data)
-            loss = float(out['loss'].detach())
-        dt = (time.time() - t0) / nstep
-    finally:
-        unregister_backend('cpu')
-    return dict(value=b / dt, unit='img/s', cores=cores, kind='port',
-                sample=f'BASELINE config 1: {nstep} timed training step(s) (fwd+bwd+clip+SGD; 1 warm-up step of '
-                       f'{warm:.1f} s excluded) of LSNet {args.backbone.upper()}-FPN {args.task} on {b} images 3x{h}x{w}, '
-                       f'torch.set_num_threads({cores}), {oracle_py.num_threads()} OpenMP threads in the oracle, '
-                       f'{dt:.1f} s per step, last loss {loss:.3f}')
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=CPU_BASELINE_LIMIT_S)
+    except subprocess.TimeoutExpired:
+        return {'value': None, 'unit': 'img/s', 'cores': threads, 'kind': 'port',
+                'sample': f'BASELINE config 1 (2 x 3x800x800) did not finish within {CPU_BASELINE_LIMIT_S} s'}
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
+    if p.returncode != 0 or not lines:
+        return {'value': None, 'unit': 'img/s', 'cores': threads, 'kind': 'port',
+                'sample': 'failed: ' + (p.stderr.strip().splitlines() or ['no output'])[-1][:300]}
+    return json.loads(lines[-1])
 
 
 def infer_leg(dev):
@@ -239,6 +264,8 @@ def allreduce_probe(model, dev, world, reps=5):
 
 def main():
     args = parse()
+    if args.cpu_baseline_worker:
+        return cpu_baseline_worker(args)
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))

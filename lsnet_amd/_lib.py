@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, 'csrc', 'liblsnet_hip.so')
+SO_PATH = os.environ.get('LSNET_HIP_SO') or os.path.join(_HERE, 'csrc', 'liblsnet_hip.so')   # env: diagnostic builds
 
 c_float_p = ctypes.POINTER(ctypes.c_float)
 c_i64_p = ctypes.POINTER(ctypes.c_int64)

@@ -9,8 +9,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.path.join(HERE, 'liblsnet_hip.so')
 SOURCES = ['dcn.hip', 'misc.hip', 'norm.hip', 'conv.hip', 'image.hip', 'loss.hip']
 HEADERS = ['common.h', 'dcn_kernels.h', 'cross_iou_row.h', os.path.join('..', '..', 'include', 'lsnet_hip.h')]
+# -fno-slp-vectorize: hipcc (ROCm 7.2) packs adjacent scalar fp32 adds / fmas into v_pk_add_f32 / v_pk_fma_f32.  In the
+# backward-data kernels the HIGH dword of such packed accumulators came back wrong for the last 16 lanes of a wave in
+# 0.7 % of the cases, differently on every run, whenever two workgroups shared a CU (tools/dbg_goff.py on the MI355X:
+# 100x168 maps; exact with one workgroup per CU, exact without SLP packing, never caught by the small parity cases).
+# Packed fp32 VALU beside MFMAs is also slower than the scalar form (cdna_hip_programming.md, price of one filler).
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=fast',
-         '-Wno-unused-result']
+         '-fno-slp-vectorize', '-Wno-unused-result']
 
 
 def _hipcc():

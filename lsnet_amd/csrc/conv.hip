@@ -163,13 +163,15 @@ __global__ __launch_bounds__(256, 1) void conv_fwd_xn_kernel(const ConvArgs a)
         for (int q = 0; q < NPL; ++q) *reinterpret_cast<uint2 *>(p + q * PLANE_B) = make_uint2(p0[q], p1[q]);
     };
 
-    f32x16 acc[2][2];
+    // leading product h*h in acc, the small products in accl (added once at the end): the fp32 rounding of the large
+    // running sum is then paid once per 16 k-values, not once per product term
+    f32x16 acc[2][2], accl[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = accl[i][j][r] = 0.f;
 
     // ---- prologue: chunk 0 -> buffer 0, loads of chunk 1 in flight ----
     Ck c1 = {0, 0, 0}, c2 = {0, 0, 0};
@@ -218,7 +220,10 @@ __global__ __launch_bounds__(256, 1) void conv_fwd_xn_kernel(const ConvArgs a)
                 for (int ij = 0; ij < 4; ++ij) {
                     const int i = ij >> 1, j = ij & 1;
                     const int gap = (ks * NP + prod) * 4 + ij;
-                    acc[i][j] = mfma_bf16(Af[ks][i][SC::pa(prod)], Bf[ks][j][SC::pb(prod)], acc[i][j]);
+                    if (prod == 0)
+                        acc[i][j] = mfma_bf16(Af[ks][i][0], Bf[ks][j][0], acc[i][j]);
+                    else
+                        accl[i][j] = mfma_bf16(Af[ks][i][SC::pa(prod)], Bf[ks][j][SC::pb(prod)], accl[i][j]);
                     __builtin_amdgcn_sched_barrier(0);
                     // slices s in [gap*NS/NGAP, (gap+1)*NS/NGAP): x slices first, then weight slices
 #pragma unroll
@@ -248,7 +253,7 @@ __global__ __launch_bounds__(256, 1) void conv_fwd_xn_kernel(const ConvArgs a)
             for (int r = 0; r < 16; ++r) {
                 const int pix = tile_p + wm * 64 + i * 32 + mfma32_row(r, lane);
                 if (pix < a.P) {
-                    float v = acc[i][j][r] + bv;
+                    float v = (acc[i][j][r] + accl[i][j][r]) + bv;
                     if (a.relu) v = fmaxf(v, 0.f);
                     a.out[(size_t)pix * a.Co + co_blk + col] = v;
                 }

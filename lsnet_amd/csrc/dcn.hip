@@ -494,7 +494,8 @@ static int launch_bwd_colbuf(DcnArgs &a, GatherPlan &pl, unsigned char *ws, hipS
     int sort_blocks = cdiv(pl.nanchors, 4);
     if (sort_blocks > 4096) sort_blocks = 4096;
     hipLaunchKernelGGL(dcn_sort_lists_kernel, dim3(sort_blocks), dim3(256), 0, st, pl.nanchors, start, ent);
-    const size_t lds = bwd_xn_lds_bytes(NP, a.kh * a.kw * a.dg);
+    size_t lds = bwd_xn_lds_bytes(NP, a.kh * a.kw * a.dg);
+    if ((g_dbg_block >> 22) & 1) lds = 100 * 1024;   // diagnostic: one workgroup per CU
     if (int rc = set_lds(dcn_bwd_data_xn_kernel<NP, true>, lds)) return rc;
     hipLaunchKernelGGL((dcn_bwd_data_xn_kernel<NP, true>), dim3(a.ntiles), dim3(256), lds, st, a);
     pl.ga.gcol = a.gcol, pl.ga.start = start, pl.ga.ent = ent;

@@ -139,20 +139,26 @@ __device__ __forceinline__ void corner_weights(const Tap &t, float &b00, float &
 // Sum over the 16 lanes of a DPP row (lanes 16q..16q+15) without touching the LDS: quad xor 1, quad xor 2,
 // half-row mirror, row mirror.  (__shfl_xor compiles to ds_bpermute_b32 + a wait per step: 84 of them per chunk
 // were the longest dependent chain of the backward-data epilogue.)
-template <int CTRL>
-__device__ __forceinline__ float dpp_add(float v)
-{
-    const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true);
-    return v + __int_as_float(t);
-}
+//
+// Written as inline assembly with its own wait states between a step and whatever produced its input (the operands of
+// an asm statement cannot be SLP-packed into v_pk_* registers; see the note on -fno-slp-vectorize in build.py).
+#define LSN_DPP_ADD(nops, ctrl_text)                                                                       \
+    asm("s_nop " nops "\n\tv_add_f32_dpp %0, %1, %1 " ctrl_text " row_mask:0xf bank_mask:0xf bound_ctrl:1" \
+        : "=&v"(r)                                                                                        \
+        : "v"(v))
 __device__ __forceinline__ float row16_sum(float v)
 {
-    v = dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
-    v = dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
-    v = dpp_add<0x141>(v);   // row_half_mirror
-    v = dpp_add<0x140>(v);   // row_mirror
-    return v;
+    float r;
+    LSN_DPP_ADD("7", "quad_perm:[1,0,3,2]");   // the input may come from a packed op: eight wait states
+    v = r;
+    LSN_DPP_ADD("4", "quad_perm:[2,3,0,1]");
+    v = r;
+    LSN_DPP_ADD("4", "row_half_mirror");
+    v = r;
+    LSN_DPP_ADD("4", "row_mirror");
+    return r;
 }
+#undef LSN_DPP_ADD
 
 // Branch-free guarded load of 4 consecutive floats p[0..3] of which the first `rem` (may be <= 0)
 // are valid.  hipcc turns `if (cond) v = *ptr` into a branch with a full vmcnt(0) wait per load
@@ -844,13 +850,15 @@ __global__ __launch_bounds__(256, 1) void dcn_fwd_xn_kernel(const DcnArgs a)
         }
     };
 
-    f32x16 acc[2][2];
+    // leading product h*h in acc, the small products in accl (added once at the end): the fp32 rounding of the large
+    // running sum is then paid once per 16 k-values, not once per product term
+    f32x16 acc[2][2], accl[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = accl[i][j][r] = 0.f;
 
     __syncthreads();  // sampling table complete
     ChunkIter<BK> it1(a, g, segs, ncc, T), it2(a, g, segs, ncc, T);
@@ -926,7 +934,10 @@ __global__ __launch_bounds__(256, 1) void dcn_fwd_xn_kernel(const DcnArgs a)
                 for (int ij = 0; ij < 4; ++ij) {
                     const int i = ij >> 1, j = ij & 1;
                     const int gap = (ks * NP + prod) * 4 + ij;
-                    acc[i][j] = mfma_bf16(Af[ks][i][SC::pa(prod)], Bf[ks][j][SC::pb(prod)], acc[i][j]);
+                    if (prod == 0)
+                        acc[i][j] = mfma_bf16(Af[ks][i][0], Bf[ks][j][0], acc[i][j]);
+                    else
+                        accl[i][j] = mfma_bf16(Af[ks][i][SC::pa(prod)], Bf[ks][j][SC::pb(prod)], accl[i][j]);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int s = gap * NSLOT / NGAP; s < (gap + 1) * NSLOT / NGAP; ++s) staging_slot(s, c1, c2, bn);
@@ -947,7 +958,7 @@ __global__ __launch_bounds__(256, 1) void dcn_fwd_xn_kernel(const DcnArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int pix = tile_p + i * 32 + mfma32_row(r, lane);
-                if (pix < L.P) L.out[(size_t)pix * a.Co + co_base + col] = acc[i][j][r] + bv;
+                if (pix < L.P) L.out[(size_t)pix * a.Co + co_base + col] = (acc[i][j][r] + accl[i][j][r]) + bv;
             }
         }
 }
@@ -1192,10 +1203,7 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_kernel(const DcnArgs a)
 // =============================================================================================
 constexpr int BX3_RS = 528;   // bytes per LDS row of the transposed weight slab: 256 co x 2 B + 16 B pad
 
-__host__ __device__ inline size_t bwd_xn_lds_bytes(int np, int KD)
-{
-    return (size_t)(np == 6 ? 3 : 2) * 32 * BX3_RS + (size_t)BWD_BM * KD * (sizeof(Tap) + 12);
-}
+
 
 // w (n floats, any layout) -> NPL bf16 planes of n values each (hi, [mid,] lo), same element order
 template <int NPL>
@@ -1231,15 +1239,30 @@ __global__ void dcn_prepare_wt_kernel(const float *w, unsigned short *out, int C
 // mask-weighted column gradients go to a.gcol (one 64-byte run per pixel and half-slab), and grad_input is formed by
 // dcn_gather_kernel from per-anchor sample lists: no atomics, each grad_input element written once, fixed summation
 // order.  grad_offset / grad_mask are produced here in both variants.
+//
+// Weight slab [NPL planes][32 channel rows][256 co] bf16: loaded global -> LDS directly (buffer_load ... lds, no staging
+// registers, no ds_write pass).  Rows are 512 B without padding; 16-byte slot u of row r lives at slot u ^ (r & 15)
+// (applied on the SOURCE address of the load and on the read), which spreads the 16 rows x 4 k-quarters of every
+// ds_read_b128 lane group over all 64 banks.  Per chunk: wait for the slab, MFMAs, barrier, issue the next slab's
+// loads, epilogue (the loads land meanwhile).
+// Accumulation: the leading product h*h and the five small products go to separate accumulators that are added once
+// per chunk, so the fp32 rounding of the running sum is not paid once per small term.
+constexpr int BXN_ROW = 512;   // bytes per LDS row of the transposed weight slab (256 co x 2 B)
+
+__host__ __device__ inline size_t bwd_xn_lds_bytes(int np, int KD)
+{
+    return (size_t)(np == 6 ? 3 : 2) * 32 * BXN_ROW + (size_t)BWD_BM * KD * (sizeof(Tap) + 12);
+}
+
 template <int NP, bool COLBUF>
 __global__ __launch_bounds__(256, 2) void dcn_bwd_data_xn_kernel(const DcnArgs a)
 {
     using SC = SplitCfg<NP>;
     constexpr int NPL = SC::NPL;
-    constexpr int BK = 32, RED = 256, NS = RED / 32, RS = BX3_RS;
+    constexpr int BK = 32, RED = 256, NS = RED / 32, ROW = BXN_ROW, PLANE = 32 * ROW;
     extern __shared__ __align__(16) unsigned char smem[];
-    unsigned char *Bp = smem;                                            // [NPL][32 ch][RED co] bf16 planes
-    Tap *tab = reinterpret_cast<Tap *>(smem + NPL * 32 * RS);            // [64][K*dg]
+    unsigned char *Bp = smem;                                            // [NPL][32 ch][RED co] bf16 planes, swizzled
+    Tap *tab = reinterpret_cast<Tap *>(smem + NPL * PLANE);              // [64][K*dg]
     const int K = a.kh * a.kw, KD = K * a.dg;
     float *gacc = reinterpret_cast<float *>(tab + BWD_BM * KD);          // [64][KD][3]
 
@@ -1291,63 +1314,63 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_xn_kernel(const DcnArgs a
         }
     }
 
-    // weight slab staging: plane p, channel row r = tid >> 5 (+ 8 per pass), 16-byte piece tid & 31 of its 512 B
+    // weight slab: pass ps = (plane, 8-row group); thread = (row tid >> 5 of the group, 16-byte LDS slot tid & 31).
+    // The LDS destination of a wave is its 1 KB piece of the pass (lane-linear); LDS slot t of row r receives the
+    // source slot t ^ (r & 15).  Rows past nval and co slots past Co read a valid neighbour instead (their products
+    // meet a zero A operand resp. an ignored output column), so every LDS byte is (re)written with finite data.
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(a.wtp), 0,
                                                                          K * C * Co * 2 * NPL, 0x00020000);
-    const int piece = tid & 31, srow = tid >> 5;
-    float4 wv[4 * NPL];
-    auto load_w = [&](const Chunk &ch) {
+    const int co_slots = Co >> 3;   // Co % 8 == 0 on this path
+    auto issue_w = [&](const Chunk &ch) {
         const int rowbase = ch.k * C + ch.c0;   // row index into [K*C][Co]
 #pragma unroll
         for (int ps = 0; ps < 4 * NPL; ++ps) {
-            const int plane = ps >> 2, r = (ps & 3) * 8 + srow;
-            const bool ok = piece * 8 < Co && r < ch.nval;
-            const int voff = ok ? (plane * K * C * Co + (rowbase + r) * Co) * 2 + piece * 16 : 0x7ffffff0;
-            auto v = __builtin_amdgcn_raw_buffer_load_b128(wrs, voff, 0, 0);
-            __builtin_memcpy(&wv[ps], &v, 16);
-        }
-    };
-    auto store_w = [&]() {
-#pragma unroll
-        for (int ps = 0; ps < 4 * NPL; ++ps) {
-            const int plane = ps >> 2, r = (ps & 3) * 8 + srow;
-            *reinterpret_cast<float4 *>(Bp + plane * 32 * RS + r * RS + piece * 16) = wv[ps];
+            const int plane = ps >> 2, r = (ps & 3) * 8 + (tid >> 5);
+            const int u = (tid & 31) ^ (r & 15);
+            const int voff = (plane * K * C * Co + (rowbase + min(r, ch.nval - 1)) * Co) * 2 + min(u, co_slots - 1) * 16;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                wrs, (__attribute__((address_space(3))) void *)(Bp + plane * PLANE + (ps & 3) * 4096 + wave * 1024), 16,
+                voff, 0, 0, 0);
         }
     };
 
     __syncthreads();
     int dbg_n = 0;
-    load_w(decode_chunk<BK>(a, 0, 0, segs, ncc));
+    issue_w(decode_chunk<BK>(a, 0, 0, segs, ncc));
     float sy[4] = {0.f, 0.f, 0.f, 0.f}, sx[4] = {0.f, 0.f, 0.f, 0.f}, sm[4] = {0.f, 0.f, 0.f, 0.f};
+    // operand reads: row j16 (channel cl = j16) and row 16 + j16, source slot 4 s + kq -> LDS slot (4 s + kq) ^ j16
+    const unsigned char *b0 = Bp + j16 * ROW, *b1 = Bp + (16 + j16) * ROW;
     for (int t = 0; t < T; ++t) {
         const Chunk ch = decode_chunk<BK>(a, 0, t, segs, ncc);
         const Chunk chn = decode_chunk<BK>(a, 0, min(t + 1, T - 1), segs, ncc);
         const bool tap_done = (t + 1 == T) || chn.k != ch.k || chn.dgi != ch.dgi;
         LSN_STAMP(2);
-        store_w();
-        LSN_STAMP(3);
-        __syncthreads();
+        __syncthreads();   // every wave's slab loads have landed (the barrier's fence waits for this wave's vmcnt)
         LSN_STAMP(4);
-        if (t + 1 < T) load_w(chn);
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        {
-            const unsigned char *b0 = Bp + j16 * RS + kq * 16, *b1 = Bp + (16 + j16) * RS + kq * 16;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, lo0 = {0.f, 0.f, 0.f, 0.f}, lo1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                bf16x8 w0[NPL], w1[NPL];
+        for (int s = 0; s < NS; ++s) {
+            const int so = (((s << 2) | kq) ^ j16) << 4;
+            bf16x8 w0[NPL], w1[NPL];
 #pragma unroll
-                for (int q = 0; q < NPL; ++q) {
-                    w0[q] = *reinterpret_cast<const bf16x8 *>(b0 + q * 32 * RS + s * 64);
-                    w1[q] = *reinterpret_cast<const bf16x8 *>(b1 + q * 32 * RS + s * 64);
-                }
+            for (int q = 0; q < NPL; ++q) {
+                w0[q] = *reinterpret_cast<const bf16x8 *>(b0 + q * PLANE + so);
+                w1[q] = *reinterpret_cast<const bf16x8 *>(b1 + q * PLANE + so);
+            }
+            acc0 = mfma16_bf16(af[s][0], w0[0], acc0);
+            acc1 = mfma16_bf16(af[s][0], w1[0], acc1);
 #pragma unroll
-                for (int prod = 0; prod < NP; ++prod) {
-                    acc0 = mfma16_bf16(af[s][SC::pa(prod)], w0[SC::pb(prod)], acc0);
-                    acc1 = mfma16_bf16(af[s][SC::pa(prod)], w1[SC::pb(prod)], acc1);
-                }
+            for (int prod = 1; prod < NP; ++prod) {
+                lo0 = mfma16_bf16(af[s][SC::pa(prod)], w0[SC::pb(prod)], lo0);
+                lo1 = mfma16_bf16(af[s][SC::pa(prod)], w1[SC::pb(prod)], lo1);
             }
         }
+        float g0[4], g1[4];   // scalar adds: a vector-typed add would be lowered to v_pk_add_f32 (build.py note)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) g0[r] = acc0[r] + lo0[r], g1[r] = acc1[r] + lo1[r];
         LSN_STAMP(5);
+        __syncthreads();   // slab consumed by every wave: the next one may land
+        if (t + 1 < T) issue_w(chn);
 
         // ---- consume gcol[16 px][32 ch] of this wave: D row = 4*kq + r (x-adjacent pixels), col = tn*16 + j16 ----
         const int kd = ch.dgi * K + ch.k;
@@ -1372,7 +1395,7 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_xn_kernel(const DcnArgs a
             float gm[4], w00[4], w01[4], w10[4], w11[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float gval = cval ? (tn == 0 ? acc0[r] : acc1[r]) : 0.f;
+                const float gval = cval ? (tn == 0 ? g0[r] : g1[r]) : 0.f;
                 corner_weights(tp[r], w00[r], w01[r], w10[r], w11[r]);
                 gm[r] = gval * tp[r].m;
                 if (want_off) {
@@ -1429,7 +1452,7 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_xn_kernel(const DcnArgs a
                 }
             }
         }
-        if (want_off && tap_done) {
+        if (want_off && (tap_done || ((a.dbg_block >> 21) & 1))) {   // bit 21: reduce after every chunk (diagnostic)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float vy = row16_sum(sy[r]), vx = row16_sum(sx[r]), vm = row16_sum(sm[r]);
@@ -1443,8 +1466,6 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_xn_kernel(const DcnArgs a
             }
         }
         LSN_STAMP(6);
-        __syncthreads();  // slab free for the next chunk
-        LSN_STAMP(7);
     }
     __syncthreads();
 
@@ -1630,7 +1651,6 @@ __global__ __launch_bounds__(256) void dcn_gather_kernel(const GatherArgs ga)
                     const int n = min(64, le - base);
                     GEntry e = {};
                     if (lane < n) e = ga.ent[base + lane];
-#pragma unroll 4
                     for (int j = 0; j < n; ++j) {
                         const int s = __builtin_amdgcn_readlane(e.s, j);
                         const float ly = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e.ly), j));

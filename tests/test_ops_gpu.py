@@ -513,28 +513,49 @@ def _dcn_all(ops, x, w, b, off, mask, go, cfg, dev, cl=True):
     return res
 
 
+def _dcn_fp64(x, w, b, off, mask, go, cfg):
+    """fp64 evaluation (tests/torch_dcn_ref.py, autograd) at the kernels' own fp32 sampling positions."""
+    from tests.torch_dcn_ref import torch_dcn
+    xd, wd = x.double().requires_grad_(), w.double().requires_grad_()
+    od = off.float().requires_grad_()        # positions (and therefore the bilinear fractions) stay fp32
+    md = None if mask is None else mask.double().requires_grad_()
+    bd = None if b is None else b.double().requires_grad_()
+    out = torch_dcn(xd, od, md, wd, bd, cfg['stride'], cfg['pad'], cfg['dil'], cfg['groups'], cfg['dg'], cfg['sh'], cfg['sw'])
+    wrt = [t for t in (xd, od, md, wd, bd) if t is not None]
+    grads = torch.autograd.grad(out, wrt, go.double())
+    names = ['gx', 'goff'] + (['gmask'] if md is not None else []) + ['gw'] + (['gb'] if bd is not None else [])
+    res = {'out': out.detach()}
+    res.update({n: g.detach().double() for n, g in zip(names, grads)})
+    return res
+
+
 @pytest.mark.parametrize('case', [c for c in DCN_CASES if c['name'] in ('v2_head_p6', 'pyr_head', 'r101_l3', 'v2_c40_co72')],
                          ids=lambda c: c['name'])
 def test_split6_matches_exact_fp32(case):
-    """'bf16x6' is the library's fp32-equivalent arithmetic: every output of the deformable family equals the exact
-    fp32 MFMA kernels' to 1e-6 of the output range (both differ from an fp64 evaluation by fp32 rounding only)."""
+    """'bf16x6' is the library's fp32-equivalent arithmetic.  Measured against an fp64 evaluation, every output of the
+    deformable family is at least as accurate as the exact fp32 MFMA kernels' (whose error is the rounding of an fp32
+    fmaf chain over the 2304-term reduction), and the two agree to a few 1e-6 of the output range -- the sum of their
+    own rounding errors; the 3-product mode is an order of magnitude off."""
     from lsnet_amd import _lib, ops
     dev = _dev()
     x, w, b, off, mask, go, cfg = _make(case, dev, seed=11)
+    truth = _dcn_fp64(x, w, b, off, mask, go, cfg)
     old = _lib.get_math_mode()
+    got = {}
     try:
-        _lib.set_math_mode('fp32')
-        exact = _dcn_all(ops, x, w, b, off, mask, go, cfg, dev)
-        _lib.set_math_mode('bf16x6')
-        six = _dcn_all(ops, x, w, b, off, mask, go, cfg, dev)
-        _lib.set_math_mode('bf16x3')
-        three = _dcn_all(ops, x, w, b, off, mask, go, cfg, dev)
+        for mode in ('fp32', 'bf16x6', 'bf16x3'):
+            _lib.set_math_mode(mode)
+            got[mode] = _dcn_all(ops, x, w, b, off, mask, go, cfg, dev)
     finally:
         _lib.set_math_mode(old)
-    e6 = {k: _err(six[k], exact[k].cpu()) for k in exact}
-    e3 = {k: _err(three[k], exact[k].cpu()) for k in exact}
-    print(case['name'], 'x6 vs fp32', {k: f'{v:.1e}' for k, v in e6.items()}, '| x3 vs fp32', {k: f'{v:.1e}' for k, v in e3.items()})
-    assert all(v <= 1e-6 for v in e6.values()), e6
+    err = {m: {k: _err(v[k].double(), truth[k]) for k in truth} for m, v in got.items()}
+    for m in err:
+        print(case['name'], m, 'vs fp64', {k: f'{v:.1e}' for k, v in err[m].items()})
+    cross = {k: _err(got['bf16x6'][k], got['fp32'][k].cpu()) for k in truth}
+    print(case['name'], 'x6 vs fp32 kernels', {k: f'{v:.1e}' for k, v in cross.items()})
+    for k in truth:
+        assert err['bf16x6'][k] <= 1.25 * err['fp32'][k] + 2e-7, (k, err['bf16x6'][k], err['fp32'][k])
+        assert cross[k] <= 5e-6, (k, cross[k])
 
 
 @pytest.mark.parametrize('B,C,Co,k,s,p,d,H,W', [(2, 256, 256, 3, 1, 1, 1, 50, 84), (2, 1024, 512, 1, 1, 0, 1, 25, 42),
@@ -567,15 +588,17 @@ def test_conv_split6_matches_fp64(B, C, Co, k, s, p, d, H, W):
     ref = [yr.detach()] + list(torch.autograd.grad(yr, [xr, wr], go.double().cpu()))
     errs = {m: [(_err(a.double(), r)) for a, r in zip(v, ref)] for m, v in res.items()}
     print((B, C, Co, k, s), {m: [f'{e:.1e}' for e in v] for m, v in errs.items()})
+    # fp32 accumulation noise grows with the reduction length (MIOpen blocks its sums; a plain fmaf chain does not)
+    floor = max(1e-6, 2e-8 * (C * k * k) ** 0.5)
     for e6, em in zip(errs['bf16x6'], errs['miopen']):
-        assert e6 <= max(2e-6, 3 * em), errs
+        assert e6 <= max(floor, 2 * em), errs
 
 
 # ---------------------------------------------------------------------------------- bench-shaped launches
 FPN_SIZES = [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)]   # 800 x 1344 input, strides 8 .. 128
 
 
-@pytest.mark.parametrize('choice', ['default', 'x6_atomic', 'x3_windowed_kernel'])
+@pytest.mark.parametrize('choice', list(KERNEL_CHOICES))
 def test_tower_launch_at_bench_shape(choice):
     """The LSHead tower call of BASELINE config 2: DCNv2 256 -> 256 over all five FPN levels (B = 2) in ONE launch,
     forward and every gradient against the oracle.  These sizes take the multi-wave tile counts, the XCD remap and the
@@ -622,7 +645,7 @@ def test_tower_launch_at_bench_shape(choice):
     assert all(e < TOL for e in errs.values()), errs
 
 
-@pytest.mark.parametrize('choice', ['default', 'x6_atomic'])
+@pytest.mark.parametrize('choice', ['default', 'x6_atomic', 'x3_gather', 'x3_windowed_kernel'])
 def test_pyramid_launch_at_bench_shape(choice):
     """One PyramidDeformConv of LSHead.forward_single2 (lsnet_head.py:600-755) at BASELINE config 2: the 15 (level,
     source) pairs in ONE launch; sources are shared by several pairs, so their gradients accumulate in one buffer."""
