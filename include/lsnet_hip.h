@@ -227,17 +227,26 @@ int lsn_nms(const float *dets, const int64_t *order, int n, float iou_thr, int64
             int64_t *num_keep, void *workspace, lsn_stream_t stream);
 
 /* ---- dense convolution (groups = 1), channels-last ----------------------------------------------
- * The reference calls torch.nn.Conv2d (cuDNN) for every dense conv of the path (resnet.py:624-631,261-301,
+ * The reference runs torch.nn.Conv2d (cuDNN) for every dense conv of the path (resnet.py:624-631,261-301,
  * fpn.py:171-217, lsnet_head.py:160-257).  x (B,H,W,C), w (Co,kh,kw,C) = the channels-last image of the
  * (Co,C,kh,kw) weight, out (B,Ho,Wo,Co), fp32, 16-byte aligned; cross-correlation with zero padding like
- * F.conv2d.  Arithmetic: split-bf16 products with fp32 accumulation (LSN_MATH_BF16X3) -- there is no exact-fp32
- * variant of these kernels (callers keep the vendor library for LSN_MATH_FP32).  `relu` fuses max(., 0).
- * Supported: C % 4 == 0; tensors < 2 GiB.  `workspace` / `wt_workspace`: Co*kh*kw*C*4 bytes of scratch for the
- * pre-split (backward: also flipped and transposed) weights, rebuilt by every call; forward accepts NULL (the
- * weights are then split inside every block, slower).  backward_data: stride 1 only. */
+ * F.conv2d.  Arithmetic: split-bf16 products with fp32 accumulation -- LSN_MATH_BF16X6 (fp32-equivalent) unless the
+ * mode is LSN_MATH_BF16X3; there is no fp32-MFMA variant of these kernels (in LSN_MATH_FP32 the Python mirror keeps
+ * the vendor library).  `relu` fuses max(., 0).  Supported: C % 4 == 0; tensors < 2 GiB.
+ * `workspace` / `wt_workspace`: Co*kh*kw*C*8 bytes of scratch for the pre-split (backward: also flipped and
+ * transposed) weight planes, rebuilt by every call; forward accepts NULL (the weights are then split inside every
+ * block, slower).
+ * backward_data: any stride -- every residue class (y mod stride, x mod stride) of input pixels is computed as its own
+ * stride-1 convolution of grad_out over the taps that reach it; needs Co % 8 == 0 (pad grad_out and w with zero filters).
+ * forward_pitched: the row-merged form for shallow inputs (the 7x7 stem on 3(+1) channels): `xpitch` floats separate
+ * adjacent pixels while a tap spans C = n * xpitch consecutive floats (n pixels of the same row), kw = 1, pad = 0;
+ * w is (Co, kh, 1, C) = the memory image of a (Co, kh, n, xpitch) weight.  The caller pads the image spatially. */
 int lsn_conv2d_forward(const float *x, const float *w, const float *bias, float *out, void *workspace, int B, int H,
                        int W, int C, int Co, int kh, int kw, int stride, int pad, int dil, int relu,
                        lsn_stream_t stream);
+int lsn_conv2d_forward_pitched(const float *x, const float *w, const float *bias, float *out, void *workspace, int B,
+                               int H, int W, int C, int xpitch, int Co, int kh, int kw, int stride, int pad, int dil,
+                               int relu, lsn_stream_t stream);
 int lsn_conv2d_backward_data(const float *grad_out, const float *w, float *grad_in, float *wt_workspace, int B,
                              int H, int W, int C, int Co, int kh, int kw, int stride, int pad, int dil,
                              lsn_stream_t stream);

@@ -27,10 +27,15 @@ namespace lsn {
 struct ConvArgs {
     const float *x, *w, *bias;
     float *out;
-    int B, H, W, C, Ho, Wo, Co, kh, kw, stride, pad, dil;
+    int B, H, W, C, Ho, Wo, Co, kh, kw, stride, pad_h, pad_w, dil;
+    int xpitch;   // floats between horizontally adjacent input pixels (= C, except for the row-merged stem form)
     int P;   // B * Ho * Wo
     int relu;
-    const unsigned short *wp;   // prepared weights: bf16 hi plane [Co][K][C] followed by the lo plane, or NULL
+    const unsigned short *wp;   // prepared weights: NPL bf16 planes [Co][K][C], or NULL
+    // output placement: pixel (b, ho, wo) of the (Ho, Wo) grid is stored at (b, oy0 + ho * ostep, ox0 + wo * ostep) of an
+    // (OH, OW) map.  ostep = 0: the dense case (OH = Ho, OW = Wo).  Used by the strided backward-data pass, which
+    // computes each residue class of input pixels as its own stride-1 convolution over a subset of the taps.
+    int ostep, oy0, ox0, OH, OW;
 };
 
 constexpr int CV_RS = 80;   // LDS row stride in bytes
@@ -80,7 +85,7 @@ __global__ __launch_bounds__(256, 1) void conv_fwd_xn_kernel(const ConvArgs a)
     const int wq = tid & 7, wrow = tid >> 3;     // weights: float4 slot along ci, co row (32 rows per pass)
 
     const __amdgpu_buffer_rsrc_t xrs =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x), 0, a.B * a.H * a.W * a.C * 4, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x), 0, a.B * a.H * a.W * a.xpitch * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrs =
         PREP ? __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(a.wp), 0, a.Co * Kdim * 2 * NPL, 0x00020000)
              : __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.w), 0, a.Co * Kdim * 4, 0x00020000);
@@ -97,8 +102,8 @@ __global__ __launch_bounds__(256, 1) void conv_fwd_xn_kernel(const ConvArgs a)
         const int HWo = a.Ho * a.Wo;
         const int b = ok ? p / HWo : 0, rem = ok ? p - b * HWo : 0;
         const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
-        iy0[ps] = ok ? ho * a.stride - a.pad : -0x40000000;   // an invalid pixel is out of range for every tap
-        ix0[ps] = wo * a.stride - a.pad;
+        iy0[ps] = ok ? ho * a.stride - a.pad_h : -0x40000000;   // an invalid pixel is out of range for every tap
+        ix0[ps] = wo * a.stride - a.pad_w;
         ibase[ps] = b * a.H * a.W;
     }
     int wvoff[NPB];
@@ -131,7 +136,7 @@ __global__ __launch_bounds__(256, 1) void conv_fwd_xn_kernel(const ConvArgs a)
     auto issue_x = [&](const Ck &c, int ps) {
         const int y = iy0[ps] + c.i * a.dil, x = ix0[ps] + c.j * a.dil;
         const bool ok = (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W && c.cc * BK + 2 * kk2 < a.C;
-        const int voff = ok ? ((ibase[ps] + y * a.W + x) * a.C + c.cc * BK + 2 * kk2) * 4 : OOB;
+        const int voff = ok ? ((ibase[ps] + y * a.W + x) * a.xpitch + c.cc * BK + 2 * kk2) * 4 : OOB;
         xv[ps] = cv_load2(xrs, voff, 0);
     };
     auto issue_w = [&](const Ck &c, int ps) {
@@ -255,7 +260,14 @@ __global__ __launch_bounds__(256, 1) void conv_fwd_xn_kernel(const ConvArgs a)
                 if (pix < a.P) {
                     float v = (acc[i][j][r] + accl[i][j][r]) + bv;
                     if (a.relu) v = fmaxf(v, 0.f);
-                    a.out[(size_t)pix * a.Co + co_blk + col] = v;
+                    size_t opix = pix;
+                    if (a.ostep) {
+                        const int HWo = a.Ho * a.Wo;
+                        const int b = pix / HWo, rem = pix - b * HWo;
+                        const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+                        opix = ((size_t)b * a.OH + a.oy0 + ho * a.ostep) * a.OW + a.ox0 + wo * a.ostep;
+                    }
+                    a.out[opix * a.Co + co_blk + col] = v;
                 }
             }
         }
@@ -273,12 +285,19 @@ __global__ void conv_flip_transpose_kernel(const float *w, float *wt, int Co, in
     }
 }
 
-// w (n floats) -> NPL bf16 planes of n values each.  flipT: source is (Co, K, C) and the destination
-// is the transposed-conv weight (C, K, Co) with the taps reversed.
+// Tap subset of a transposed convolution: taps i = i0 + m * istep (m < ni), j likewise.
+struct TapSub {
+    int i0, istep, ni, j0, jstep, nj, kw;
+};
+
+// w -> NPL bf16 planes.  flipT = 0: same element order (n = Co*K*C values).  flipT = 1: the source is (Co, K, C) and
+// the destination the transposed-conv weight (C, K', Co) over the tap subset `ts` with the taps reversed:
+//   dst[ci][m' * nj + n'][co] = w[co][(i0 + (ni-1-m') istep) * kw + j0 + (nj-1-n') jstep][ci]
 template <int NPL>
-__global__ void conv_prepare_kernel(const float *w, unsigned short *out, int Co, int K, int C, int flipT)
+__global__ void conv_prepare_kernel(const float *w, unsigned short *out, int Co, int K, int C, int flipT, TapSub ts)
 {
-    const size_t n = (size_t)Co * K * C;
+    const int Kd = flipT ? ts.ni * ts.nj : K;
+    const size_t n = (size_t)Co * Kd * C;
     for (size_t e = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) * 2; e < n; e += (size_t)gridDim.x * blockDim.x * 2) {
         float v[2];
 #pragma unroll
@@ -289,8 +308,10 @@ __global__ void conv_prepare_kernel(const float *w, unsigned short *out, int Co,
             } else {
                 const int co = (int)(d % Co);
                 const size_t r = d / Co;
-                const int k = (int)(r % K), ci = (int)(r / K);
-                v[q] = w[((size_t)co * K + (K - 1 - k)) * C + ci];
+                const int k = (int)(r % Kd), ci = (int)(r / Kd);
+                const int m = k / ts.nj, nn = k - m * ts.nj;
+                const int i = ts.i0 + (ts.ni - 1 - m) * ts.istep, j = ts.j0 + (ts.nj - 1 - nn) * ts.jstep;
+                v[q] = w[((size_t)co * K + i * ts.kw + j) * C + ci];
             }
         }
         unsigned pl[NPL];
@@ -327,12 +348,15 @@ static int launch_conv(const ConvArgs &a, hipStream_t st)
     return conv_np() == 3 ? launch_conv_np<BM, BN, 3>(a, st) : launch_conv_np<BM, BN, 6>(a, st);
 }
 
-static void conv_prepare(const float *w, unsigned short *out, int Co, int K, int C, int flipT, hipStream_t st)
+static void conv_prepare(const float *w, unsigned short *out, int Co, int K, int C, int flipT, const TapSub &ts,
+                         hipStream_t st)
 {
+    const size_t n = (size_t)Co * (flipT ? ts.ni * ts.nj : K) * C;
+    const int blocks = (int)((n / 2 + 255) / 256 < 512 ? (n / 2 + 255) / 256 : 512);
     if (conv_np() == 3)
-        hipLaunchKernelGGL(conv_prepare_kernel<2>, dim3(512), dim3(256), 0, st, w, out, Co, K, C, flipT);
+        hipLaunchKernelGGL(conv_prepare_kernel<2>, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, st, w, out, Co, K, C, flipT, ts);
     else
-        hipLaunchKernelGGL(conv_prepare_kernel<3>, dim3(512), dim3(256), 0, st, w, out, Co, K, C, flipT);
+        hipLaunchKernelGGL(conv_prepare_kernel<3>, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, st, w, out, Co, K, C, flipT, ts);
 }
 
 static int conv_forward(const ConvArgs &a, hipStream_t st)
@@ -362,23 +386,40 @@ static int conv_check(int B, int H, int W, int C, int Co, int kh, int kw, int st
 
 extern "C" {
 
+int lsn_conv2d_forward_pitched(const float *x, const float *w, const float *bias, float *out, void *workspace, int B,
+                               int H, int W, int C, int xpitch, int Co, int kh, int kw, int stride, int pad, int dil,
+                               int relu, lsn_stream_t stream)
+{
+    using namespace lsn;
+    LSN_CHECK(x && w && out, "conv2d: NULL argument");
+    LSN_CHECK(xpitch > 0 && xpitch % 2 == 0, "conv2d: the pixel pitch must be an even number of floats, got %d", xpitch);
+    ConvArgs a = {};
+    if (int rc = conv_check(B, H, W, C, Co, kh, kw, stride, pad, dil, &a.Ho, &a.Wo)) return rc;
+    if (xpitch != C) {
+        // row-merged form: the C "channels" of a tap are C / xpitch horizontally adjacent pixels; they must stay inside
+        // the row (the caller pads the image), and the output grid follows the REAL pixels
+        LSN_CHECK(kw == 1 && pad == 0 && dil == 1 && C % xpitch == 0, "conv2d: row-merged form needs kw = 1, pad = 0, dil = 1");
+        a.Wo = (W - C / xpitch) / stride + 1;
+        LSN_CHECK(a.Wo > 0, "conv2d: output size is too small");
+    }
+    a.x = x, a.w = w, a.bias = bias, a.out = out;
+    if (workspace && C % 8 == 0) {   // split the weights once instead of in every block
+        conv_prepare(w, reinterpret_cast<unsigned short *>(workspace), Co, kh * kw, C, 0, TapSub{},
+                     reinterpret_cast<hipStream_t>(stream));
+        a.wp = reinterpret_cast<const unsigned short *>(workspace);
+    }
+    a.B = B, a.H = H, a.W = W, a.C = C, a.Co = Co, a.kh = kh, a.kw = kw, a.stride = stride, a.pad_h = a.pad_w = pad, a.dil = dil;
+    a.xpitch = xpitch;
+    a.P = B * a.Ho * a.Wo;
+    a.relu = relu;
+    return conv_forward(a, reinterpret_cast<hipStream_t>(stream));
+}
+
 int lsn_conv2d_forward(const float *x, const float *w, const float *bias, float *out, void *workspace, int B, int H,
                        int W, int C, int Co, int kh, int kw, int stride, int pad, int dil, int relu,
                        lsn_stream_t stream)
 {
-    using namespace lsn;
-    LSN_CHECK(x && w && out, "conv2d: NULL argument");
-    ConvArgs a = {};
-    if (int rc = conv_check(B, H, W, C, Co, kh, kw, stride, pad, dil, &a.Ho, &a.Wo)) return rc;
-    a.x = x, a.w = w, a.bias = bias, a.out = out;
-    if (workspace && C % 8 == 0) {   // split the weights once instead of in every block
-        conv_prepare(w, reinterpret_cast<unsigned short *>(workspace), Co, kh * kw, C, 0, reinterpret_cast<hipStream_t>(stream));
-        a.wp = reinterpret_cast<const unsigned short *>(workspace);
-    }
-    a.B = B, a.H = H, a.W = W, a.C = C, a.Co = Co, a.kh = kh, a.kw = kw, a.stride = stride, a.pad = pad, a.dil = dil;
-    a.P = B * a.Ho * a.Wo;
-    a.relu = relu;
-    return conv_forward(a, reinterpret_cast<hipStream_t>(stream));
+    return lsn_conv2d_forward_pitched(x, w, bias, out, workspace, B, H, W, C, C, Co, kh, kw, stride, pad, dil, relu, stream);
 }
 
 int lsn_conv2d_backward_data(const float *grad_out, const float *w, float *grad_in, float *wt_workspace, int B,
@@ -387,27 +428,85 @@ int lsn_conv2d_backward_data(const float *grad_out, const float *w, float *grad_
 {
     using namespace lsn;
     LSN_CHECK(grad_out && w && grad_in && wt_workspace, "conv2d backward: NULL argument");
-    if (stride != 1) return fail(LSN_ERR_UNSUPPORTED, "conv2d backward-data kernel handles stride 1 only");
     int Ho, Wo;
     if (int rc = conv_check(B, H, W, C, Co, kh, kw, stride, pad, dil, &Ho, &Wo)) return rc;
-    if (Co % 4 != 0) return fail(LSN_ERR_UNSUPPORTED, "conv2d backward-data kernel needs Co %% 4 == 0");
-    const int padT_h = dil * (kh - 1) - pad, padT_w = dil * (kw - 1) - pad;
-    if (padT_h != padT_w || padT_h < 0)
-        return fail(LSN_ERR_UNSUPPORTED, "conv2d backward-data kernel needs a square, non-negative transposed padding");
+    if (Co % 8 != 0) return fail(LSN_ERR_UNSUPPORTED, "conv2d backward-data kernel needs Co %% 8 == 0");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int K = kh * kw;
-    ConvArgs a = {};
-    if (Co % 8 == 0) {
-        conv_prepare(w, reinterpret_cast<unsigned short *>(wt_workspace), Co, K, C, 1, st);
-        a.wp = reinterpret_cast<const unsigned short *>(wt_workspace);
-    } else {
-        hipLaunchKernelGGL(conv_flip_transpose_kernel, dim3(256), dim3(256), 0, st, w, wt_workspace, Co, K, C);
+    const int K = kh * kw, s = stride;
+    // grad_in[y, x] = sum over taps (i, j) with (y + pad - i dil) % s == 0 (same for x) of
+    //                 grad_out[(y + pad - i dil) / s, (x + pad - j dil) / s] . w[:, i, j, :]
+    // Each residue class (y % s, x % s) of input pixels is a stride-1 convolution of grad_out with its own subset of
+    // the taps (an arithmetic progression): no zero-stuffed samples, no wasted products.  Classes without a tap, and
+    // input rows / columns the forward pass never read, keep the zeros of the memset.
+    bool need_zero = false;
+    struct Cls {
+        TapSub ts;
+        int py, px, Hc, Wc, pad_h, pad_w, dstep;
+    } cls[64];
+    int ncls = 0;
+    if (s * s > 64) return fail(LSN_ERR_UNSUPPORTED, "conv2d backward-data: stride %d is not supported", s);
+    auto taps_of = [&](int p, int k, int &t0, int &tstep, int &nt) {
+        t0 = -1, tstep = 1, nt = 0;
+        int prev = -1;
+        for (int t = 0; t < k; ++t)
+            if (((p + pad - t * dil) % s + s) % s == 0) {
+                if (nt == 0) t0 = t;
+                if (nt == 1) tstep = t - prev;
+                prev = t;
+                ++nt;
+            }
+    };
+    for (int py = 0; py < s; ++py)
+        for (int px = 0; px < s; ++px) {
+            Cls c;
+            c.py = py, c.px = px;
+            c.Hc = py < H ? (H - py + s - 1) / s : 0;
+            c.Wc = px < W ? (W - px + s - 1) / s : 0;
+            if (c.Hc == 0 || c.Wc == 0) continue;
+            taps_of(py, kh, c.ts.i0, c.ts.istep, c.ts.ni);
+            taps_of(px, kw, c.ts.j0, c.ts.jstep, c.ts.nj);
+            c.ts.kw = kw;
+            if (c.ts.ni == 0 || c.ts.nj == 0) {
+                need_zero = true;
+                continue;
+            }
+            // y_in = yy + q0 - m d' (m-th tap of the subset), d' = istep dil / s; as a correlation over the reversed
+            // subset: y_in = yy - P + m' d' with P = (ni - 1) d' - q0
+            const int dstep_h = c.ts.istep * dil / s, dstep_w = c.ts.jstep * dil / s;
+            if (c.ts.ni > 1 && c.ts.nj > 1 && dstep_h != dstep_w)
+                return fail(LSN_ERR_UNSUPPORTED, "conv2d backward-data: unequal tap spacing");
+            c.dstep = c.ts.ni > 1 ? dstep_h : (c.ts.nj > 1 ? dstep_w : 1);
+            if ((c.ts.ni > 1 && c.ts.istep * dil % s != 0) || (c.ts.nj > 1 && c.ts.jstep * dil % s != 0))
+                return fail(LSN_ERR_UNSUPPORTED, "conv2d backward-data: stride / dilation combination");
+            const int q0h = (py + pad - c.ts.i0 * dil) / s, q0w = (px + pad - c.ts.j0 * dil) / s;
+            c.pad_h = (c.ts.ni - 1) * c.dstep - q0h;
+            c.pad_w = (c.ts.nj - 1) * c.dstep - q0w;
+            cls[ncls++] = c;
+        }
+    if (s > 1) {
+        // rows / columns beyond the last receptive field are only reached through out-of-range grad_out samples: the
+        // kernel yields 0 for them, so only tap-less classes need the memset
+        if (need_zero) LSN_HIP(hipMemsetAsync(grad_in, 0, sizeof(float) * (size_t)B * H * W * C, st));
     }
-    a.x = grad_out, a.w = wt_workspace, a.bias = nullptr, a.out = grad_in;
-    a.B = B, a.H = Ho, a.W = Wo, a.C = Co, a.Co = C, a.kh = kh, a.kw = kw, a.stride = 1, a.pad = padT_h, a.dil = dil;
-    a.Ho = H, a.Wo = W;
-    a.P = B * H * W;
-    return conv_forward(a, st);
+    size_t ws_off = 0;   // every class gets its own slice of the workspace (the launches are asynchronous)
+    for (int ci = 0; ci < ncls; ++ci) {
+        const Cls &c = cls[ci];
+        const int Kc = c.ts.ni * c.ts.nj;
+        unsigned short *wp = reinterpret_cast<unsigned short *>(wt_workspace) + ws_off;
+        conv_prepare(w, wp, Co, K, C, 1, c.ts, st);
+        ws_off += (size_t)3 * Co * Kc * C;
+        ConvArgs a = {};
+        a.wp = wp;
+        a.x = grad_out, a.w = nullptr, a.bias = nullptr, a.out = grad_in;
+        a.B = B, a.H = Ho, a.W = Wo, a.C = Co, a.Co = C, a.kh = c.ts.ni, a.kw = c.ts.nj, a.stride = 1;
+        a.xpitch = Co;
+        a.pad_h = c.pad_h, a.pad_w = c.pad_w, a.dil = c.dstep;
+        a.Ho = c.Hc, a.Wo = c.Wc;
+        a.P = B * c.Hc * c.Wc;
+        if (s > 1) a.ostep = s, a.oy0 = c.py, a.ox0 = c.px, a.OH = H, a.OW = W;
+        if (int rc = conv_forward(a, st)) return rc;
+    }
+    return 0;
 }
 
 }  // extern "C"

@@ -1,10 +1,11 @@
 """Dense convolution behind CONV_LAYERS['Conv2d'] (the reference: torch.nn.Conv2d through
 mmcv/cnn/bricks/conv.py:11-43 `build_conv_layer`).
 
-`Conv2d` subclasses nn.Conv2d (same parameters and state-dict keys).  CUDA channels-last fp32 inputs of a
-supported shape run the split-bf16 implicit-GEMM kernels of csrc/conv.hip when the library's math mode is
-'bf16x6' (fp32-equivalent, the default) or 'bf16x3'; everything else -- exact-fp32 mode, grouped / odd shapes, CPU tensors -- goes to
-ATen's convolution (MIOpen), which is a different vendor operator, not a fallback of the HIP path."""
+`Conv2d` subclasses nn.Conv2d (same parameters and state-dict keys).  Every dense (groups = 1) convolution of a CUDA
+channels-last fp32 tensor -- forward, data gradient (any stride), weight and bias gradient -- runs the split-bf16
+implicit-GEMM kernels of csrc/conv.hip in the library's math modes 'bf16x6' (fp32-equivalent, the default) and
+'bf16x3'; exact-fp32 mode, grouped convolutions and CPU tensors go to ATen's convolution (MIOpen), which is a
+different vendor operator, not a fallback of the HIP path."""
 import ctypes
 
 import torch
@@ -24,7 +25,16 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _pad_channels(t, c_to):
+    """Zero-pad dim 1 of a 4-D tensor to `c_to` channels, keeping channels-last memory."""
+    out = t.new_zeros((t.shape[0], c_to, t.shape[2], t.shape[3])).contiguous(memory_format=_CL)
+    out[:, :t.shape[1]] = t
+    return out
+
+
 class _ConvFn(torch.autograd.Function):
+    """Forward, data gradient (any stride: residue classes of the transposed convolution), weight and bias gradient:
+    all through liblsnet_hip.so.  Needs C % 4 == 0 (`conv2d` pads the 3-channel stem input)."""
 
     @staticmethod
     def forward(ctx, x, w, bias, stride, pad, dil, relu):
@@ -54,54 +64,76 @@ class _ConvFn(torch.autograd.Function):
         B, C, H, W = x.shape
         Co, _, kh, kw = w.shape
         gx = gw = gb = None
-        own_data = (stride == 1 and Co % 4 == 0 and dil * (kh - 1) - pad == dil * (kw - 1) - pad >= 0
-                    and _own_is_faster(B * H * W, Co, C, kh * kw))
-        if ctx.needs_input_grad[0] and own_data:
+        if ctx.needs_input_grad[0]:
+            go8, w8, Co8 = go, w, Co
+            if Co % 8:    # the transposed convolution reads grad_output in 8-channel pieces: zero filters are free
+                Co8 = (Co + 7) // 8 * 8
+                go8 = _pad_channels(go, Co8)
+                w8 = w.new_zeros((Co8, C, kh, kw)).contiguous(memory_format=_CL)
+                w8[:Co] = w
             gx = torch.empty_like(x, memory_format=_CL)
-            ws = torch.empty(2 * w.numel(), device=x.device, dtype=torch.float32)
-            _lib.check(lib.lsn_conv2d_backward_data(_p(go), _p(w), _p(gx), _p(ws), B, H, W, C, Co, kh, kw, stride, pad,
+            ws = torch.empty(2 * w8.numel(), device=x.device, dtype=torch.float32)
+            _lib.check(lib.lsn_conv2d_backward_data(_p(go8), _p(w8), _p(gx), _p(ws), B, H, W, C, Co8, kh, kw, stride, pad,
                                                     dil, _stream()))
-        own_w = ctx.needs_input_grad[1] and Co >= 256 and C >= 256 and C * kh * kw >= 512 and C % 4 == 0
-        if own_w:   # weight gradient (and the bias gradient in the same pass) through the split-bf16 kernel
+        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+            # weight gradient and the bias gradient in one pass over grad_output
             gw = torch.empty_like(w)
             want_b = has_bias and ctx.needs_input_grad[2]
             gb = torch.empty(Co, device=x.device, dtype=torch.float32) if want_b else None
             _lib.check(lib.lsn_conv2d_backward_weight(_p(x), _p(go), _p(gw), _p(gb), B, H, W, C, Co, kh, kw, stride, pad,
                                                       dil, _stream()))
-        need_aten = (ctx.needs_input_grad[0] and gx is None, ctx.needs_input_grad[1] and not own_w, False)
-        if need_aten[0] or need_aten[1]:
-            ax, aw, _ = torch.ops.aten.convolution_backward(go, x, w, None, [stride, stride], [pad, pad], [dil, dil],
-                                                            False, [0, 0], 1, list(need_aten))
-            gx = ax if need_aten[0] else gx
-            gw = aw if need_aten[1] else gw
-        if has_bias and ctx.needs_input_grad[2] and gb is None:
-            gb = go.sum(dim=(0, 2, 3))
+            if not ctx.needs_input_grad[1]:
+                gw = None
         return gx, gw, gb, None, None, None, None
 
 
 def hip_conv_ok(x, weight, stride, padding, dilation, groups, padding_mode='zeros'):
+    """The own kernels take every dense (groups = 1) fp32 channels-last convolution on the device in the split math
+    modes; exact-fp32 mode keeps the vendor library (there is no fp32-MFMA dense conv kernel)."""
     if not (x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and x.is_contiguous(memory_format=_CL)):
         return False
     if groups != 1 or padding_mode != 'zeros' or isinstance(padding, str):
         return False
     if stride[0] != stride[1] or padding[0] != padding[1] or dilation[0] != dilation[1]:
         return False
-    C = x.shape[1]
-    if C % 4 != 0 or C < 16 or x.numel() * 4 >= 2 ** 31 or weight.numel() * 4 >= 2 ** 31:
+    if x.numel() * 4 >= 2 ** 31 or weight.numel() * 8 >= 2 ** 31:
         return False
     return _lib.split_math()
 
 
-def _own_is_faster(pixels, cin, cout, taps):
-    """Shape rule from tools/bench_convs_x3.py (MI355X, ROCm 7.2 MIOpen): the split-bf16 kernel wins once its grid
-    covers a good part of the chip (>= 100 blocks of 64x256 / 128x128 / 256x64) and the reduction is deep enough to amortise the
-    pipeline prologue; MIOpen keeps the small and shallow layers."""
-    bm, bn = (256, 64) if cout <= 64 else ((128, 128) if cout <= 128 else (64, 256))
-    blocks = -(-pixels // bm) * -(-cout // bn)
-    return blocks >= 100 and cin * taps >= 256 and cin >= 128 and cout >= 128
+def _stem_forward(x, weight, bias, stride, pad, relu):
+    """Forward of a shallow wide-kernel convolution (the 7x7 stem on the 3-channel image) in the row-merged form of
+    lsn_conv2d_forward_pitched: the image is zero-padded (space: `pad`, channels: to 4) once, then a tap row of kw
+    pixels x 4 channels is ONE contiguous 4 kw-float "channel" run -- kh chunks of the implicit GEMM instead of kh * kw
+    chunks that are 1/8 full.  No gradient (the stem is frozen in every LSNet config)."""
+    lib = _lib.load()
+    B, C, H, W = x.shape
+    Co, _, kh, kw = weight.shape
+    C4 = (C + 3) // 4 * 4
+    xp = x.new_zeros((B, C4, H + 2 * pad, W + 2 * pad)).contiguous(memory_format=_CL)
+    xp[:, :C, pad:pad + H, pad:pad + W] = x
+    w4 = weight.new_zeros((Co, C4, kh, kw)).contiguous(memory_format=_CL)     # memory (Co, kh, kw, C4) = (Co, kh, 1, kw C4)
+    w4[:, :C] = weight
+    Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+    out = torch.empty((B, Co, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=_CL)
+    ws = torch.empty(2 * w4.numel(), device=x.device, dtype=torch.float32)
+    _lib.check(lib.lsn_conv2d_forward_pitched(_p(xp), _p(w4), _p(bias), _p(out), _p(ws), B, H + 2 * pad, W + 2 * pad,
+                                              kw * C4, C4, Co, kh, 1, stride, 0, 1, 1 if relu else 0, _stream()))
+    return out
 
 
 def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, relu=False):
+    C = x.shape[1]
+    no_grad = not (torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or
+                                                (bias is not None and bias.requires_grad)))
+    if C < 8 and weight.shape[3] > 1 and int(dilation) == 1 and no_grad:
+        return _stem_forward(x, weight, bias, int(stride), int(padding), bool(relu))
+    if C % 4:    # the 3-channel image of the stem: one zero channel (and a zero column of taps)
+        C4 = (C + 3) // 4 * 4
+        x = _pad_channels(x, C4)
+        w4 = weight.new_zeros((weight.shape[0], C4, weight.shape[2], weight.shape[3])).contiguous(memory_format=_CL)
+        w4[:, :C] = weight
+        weight = w4
     return _ConvFn.apply(x, weight, bias, int(stride), int(padding), int(dilation), bool(relu))
 
 
@@ -116,10 +148,5 @@ class Conv2d(nn.Conv2d):
 
     def _run(self, x, w):
         if hip_conv_ok(x, w, self.stride, self.padding, self.dilation, self.groups, self.padding_mode):
-            Co, C, kh, kw = w.shape
-            s, p, d = self.stride[0], self.padding[0], self.dilation[0]
-            ho = (x.shape[2] + 2 * p - (d * (kh - 1) + 1)) // s + 1
-            wo = (x.shape[3] + 2 * p - (d * (kw - 1) + 1)) // s + 1
-            if _own_is_faster(x.shape[0] * ho * wo, C, Co, kh * kw):
-                return _ConvFn.apply(x, w, self.bias, s, p, d, False)
+            return conv2d(x, w, self.bias, self.stride[0], self.padding[0], self.dilation[0], False)
         return F.conv2d(x, w, self.bias, self.stride, self.padding, self.dilation, self.groups)

@@ -1,6 +1,7 @@
 """Fused cross-IOU loss of the bbox task (csrc/loss.hip, lsn_cross_iou_bbox_forward / _backward): the per-point loss and
 its gradient in one launch each, instead of the ~60 elementwise launches of the torch formulation
-(models/losses/cross_iou_loss.py).  Opt-in -- `LSNET_FUSED_CIOU=1` -- until it has been measured in the training step."""
+(models/losses/cross_iou_loss.py).  On by default for device tensors (verified on the MI355X against the torch
+formulation and the reference fixture: tests/test_zz_fused_ciou_gpu.py); `LSNET_FUSED_CIOU=0` keeps the torch formulation."""
 import ctypes
 import os
 
@@ -10,7 +11,7 @@ from .. import _lib
 
 
 def enabled():
-    return os.environ.get('LSNET_FUSED_CIOU') == '1'
+    return os.environ.get('LSNET_FUSED_CIOU', '1') != '0'
 
 
 def _p(t):

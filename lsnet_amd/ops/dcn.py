@@ -21,6 +21,7 @@ from torch.nn.modules.utils import _pair, _single
 
 from ..cnn.registry import CONV_LAYERS
 from .backend import get_backend
+from .conv import Conv2d
 
 
 def _conv_out(size, k, stride, pad, dil):
@@ -194,7 +195,7 @@ class DeformConvPack(DeformConv):
 
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
-        self.conv_offset = nn.Conv2d(self.in_channels,
+        self.conv_offset = Conv2d(self.in_channels,
                                      self.deformable_groups * 2 * self.kernel_size[0] * self.kernel_size[1],
                                      kernel_size=self.kernel_size, stride=_pair(self.stride),
                                      padding=_pair(self.padding), dilation=_pair(self.dilation), bias=True)
@@ -269,7 +270,7 @@ class ModulatedDeformConvPack(ModulatedDeformConv):
 
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
-        self.conv_offset = nn.Conv2d(self.in_channels,
+        self.conv_offset = Conv2d(self.in_channels,
                                      self.deformable_groups * 3 * self.kernel_size[0] * self.kernel_size[1],
                                      kernel_size=self.kernel_size, stride=_pair(self.stride),
                                      padding=_pair(self.padding), dilation=_pair(self.dilation), bias=True)

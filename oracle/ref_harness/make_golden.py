@@ -334,6 +334,39 @@ def golden_res2net():
     _save('res2net50_dcn', data)
 
 
+def golden_backbones_dcn():
+    """BASELINE configs 3 / 4: ResNet-101 and ResNeXt-101-64x4d with DCNv2 in c3-c5 (g = 1 resp. g = 64, the first block
+    of a stage with stride 2), full depth, 1x3x96x128 input, name-keyed weights: the four feature maps, and the
+    gradients of a fixed random projection of them w.r.t. the input image and a few parameters of every stage (the
+    backward of the grouped / strided deformable convs inside a real network)."""
+    import copy
+    import mmcv
+    from mmdet.models import build_backbone
+    sys.path.insert(0, '/root/repo')
+    from lsnet_amd.model_zoo import backbone_cfg
+    for name, fixture in (('r101-dcn', 'backbone_r101_dcn'), ('x101-dcn', 'backbone_x101_dcn')):
+        cfg = backbone_cfg(name)
+        cfg.pop('with_cp', None)
+        bb = build_backbone(mmcv.Config(copy.deepcopy(cfg))._cfg_dict)
+        gu.fill_params(bb, seed=13)
+        bb.train()
+        x = torch.randn(1, 3, 96, 128, generator=gu.gen(41)).requires_grad_()
+        data = {'keys': np.array(sorted(bb.state_dict().keys())),
+                'nparams': np.array(sum(p.numel() for p in bb.parameters()))}
+        feats = bb(x)
+        proj = sum((f * torch.randn(f.shape, generator=gu.gen(50 + i))).sum() / f.numel() ** 0.5 for i, f in enumerate(feats))
+        names = gu.backbone_grad_names(bb)
+        params = dict(bb.named_parameters())
+        grads = torch.autograd.grad(proj, [x] + [params[n] for n in names])
+        for i, t in enumerate(feats):
+            gu.pack(f'c/{i}', t, data)
+        gu.pack('gx', grads[0], data)
+        for n, g in zip(names, grads[1:]):
+            gu.pack(f'g/{n}', g, data, stride=257)
+        data['grad_names'] = np.array(names)
+        _save(fixture, data)
+
+
 def golden_vote():
     """(f-3) instances_vote of the reference detector (lsnet.py:229-299) on random multi-scale-like detections: clusters
     of jittered copies of a few boxes plus isolated ones."""
@@ -591,7 +624,7 @@ def golden_data_pipeline():
     _save('data_pipeline', data)
 
 
-ALL = dict(train_curve=golden_train_curve, coco_eval=golden_coco_eval, head_cpv=golden_head_cpv, data_pipeline=golden_data_pipeline, gt_formats=golden_gt_formats, res2net=golden_res2net, vote=golden_vote, head_bbox=lambda: golden_head('bbox'), head_segm=lambda: golden_head('segm'),
+ALL = dict(backbones_dcn=golden_backbones_dcn, train_curve=golden_train_curve, coco_eval=golden_coco_eval, head_cpv=golden_head_cpv, data_pipeline=golden_data_pipeline, gt_formats=golden_gt_formats, res2net=golden_res2net, vote=golden_vote, head_bbox=lambda: golden_head('bbox'), head_segm=lambda: golden_head('segm'),
            head_pose_bbox=lambda: golden_head('pose_bbox'), head_pose_kbox=lambda: golden_head('pose_kbox'),
            assign=golden_assign, cross_iou=golden_cross_iou, backbone=golden_backbone, nms=golden_nms)
 

@@ -267,3 +267,18 @@ def synthetic_eval_case(seed=0, num_images=14):
         boxes.append(dict(rec, bbox=[float(x), float(y), float(w), float(h)]))
         polys.append(dict(rec, polygon=[float(x), float(y), float(x + w), float(y), float(x + w), float(y + h), float(x), float(y + h)]))
     return gt, boxes, polys, kpts
+
+
+def backbone_grad_names(bb):
+    """A few parameters of every stage whose gradients the DCN-backbone fixtures pin: the deformable conv2 (weight and
+    offset conv) of the first (strided) and the last block of layers 2-4, and the first trainable 1x1 conv."""
+    names = []
+    params = dict(bb.named_parameters())
+    for li in (2, 3, 4):
+        layer = getattr(bb, f'layer{li}')
+        for bi in (0, len(layer) - 1):
+            for leaf in ('conv2.weight', 'conv2.conv_offset.weight', 'conv2.conv_offset.bias', 'conv3.weight'):
+                n = f'layer{li}.{bi}.{leaf}'
+                if n in params and params[n].requires_grad:
+                    names.append(n)
+    return names

@@ -38,6 +38,12 @@ def test_res2net_dcn_backbone(channels_last):
     gc.res2net_case(_dev(), channels_last)
 
 
+@pytest.mark.parametrize('channels_last', [False, True], ids=['nchw', 'nhwc'])
+@pytest.mark.parametrize('name', ['r101-dcn', 'x101-dcn'])
+def test_dcn_backbones_of_configs_3_and_4(name, channels_last):
+    gc.backbone_dcn_case(name, _dev(), channels_last)
+
+
 def test_multiclass_nms_lsvr():
     gc.nms_lsvr_case(_dev())
 

@@ -30,6 +30,11 @@ def test_res2net_dcn_backbone(cpu_oracle_backend):
     gc.res2net_case(CPU)
 
 
+@pytest.mark.parametrize('name', ['r101-dcn', 'x101-dcn'])
+def test_dcn_backbones_of_configs_3_and_4(name, cpu_oracle_backend):
+    gc.backbone_dcn_case(name, CPU)
+
+
 def test_multiclass_nms_lsvr(cpu_oracle_backend):
     gc.nms_lsvr_case(CPU)
 

@@ -400,30 +400,46 @@ def test_group_norm_unsupported_shape_uses_aten():
 
 
 # ---------------------------------------------------------------------------------- dense conv (split bf16)
-@pytest.fixture
-def bf16x3_mode():
+@pytest.fixture(params=['bf16x6', 'bf16x3'])
+def split_mode(request):
     from lsnet_amd import _lib
     old = _lib.get_math_mode()
-    _lib.set_math_mode('bf16x3')
-    yield
+    _lib.set_math_mode(request.param)
+    yield request.param
     _lib.set_math_mode(old)
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize('B,C,Co,k,s,p,d,H,W,bias', [
+CONV_CASES = [
+    # B, C, Co, k, s, p, d, H, W, bias
     (2, 256, 256, 3, 1, 1, 1, 25, 42, True),      # 64x256 tiles
-    (2, 128, 128, 3, 2, 1, 1, 40, 52, False),     # 128x128 tiles, stride 2 (backward-data through ATen)
+    (2, 128, 128, 3, 2, 1, 1, 40, 52, False),     # 128x128 tiles, stride 2: backward-data by residue classes
     (1, 256, 64, 1, 1, 0, 1, 33, 31, True),       # 256x64 tiles, ragged pixel count
     (2, 64, 512, 1, 1, 0, 1, 20, 28, False),      # two column blocks
     (2, 768, 256, 1, 1, 0, 1, 13, 21, True),
     (2, 40, 72, 3, 1, 2, 2, 17, 19, True),        # C and Co not multiples of 32, dilation 2
     (1, 2048, 256, 3, 2, 1, 1, 25, 42, True),     # FPN P6: 2048 -> 256 stride 2
-])
-def test_conv2d_matches_torch(B, C, Co, k, s, p, d, H, W, bias, bf16x3_mode):
-    """Split-bf16 implicit GEMM vs F.conv2d (fp32, MIOpen and CPU): 2^-16 per product -> well inside 1e-4."""
+    (2, 64, 64, 1, 1, 0, 1, 50, 84, False),       # layer1-like shallow 1x1 (was MIOpen in round 1)
+    (2, 256, 27, 3, 1, 1, 1, 25, 42, True),       # a DCNv2 pack's conv_offset: Co % 8 != 0
+    (2, 256, 20, 1, 1, 0, 1, 13, 21, True),       # refine_out
+    (2, 256, 512, 1, 2, 0, 1, 51, 85, False),     # a ResNet downsample: 1x1 stride 2, odd map (tap-less residue classes)
+    (2, 64, 128, 3, 2, 1, 1, 27, 41, True),       # 3x3 stride 2, odd map
+    (1, 32, 48, 3, 3, 1, 1, 20, 23, True),        # stride 3
+    (1, 32, 48, 5, 2, 2, 1, 19, 22, False),       # 5x5 stride 2: 3- and 2-tap residue classes
+    (1, 16, 24, 3, 2, 2, 2, 21, 26, True),        # stride 2 with dilation 2 (one residue class per axis has all taps)
+    (2, 3, 64, 7, 2, 3, 1, 64, 96, False),        # the ResNet stem WITH gradients (generic path on 4 padded channels)
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,C,Co,k,s,p,d,H,W,bias', CONV_CASES)
+def test_conv2d_matches_torch(B, C, Co, k, s, p, d, H, W, bias, split_mode):
+    """Split-bf16 implicit GEMM -- forward, data gradient (any stride), weight and bias gradient, no vendor kernel
+    involved -- against an fp64 evaluation of F.conv2d: 3e-6 of the output range in the fp32-equivalent mode
+    (fp32 accumulation noise), 5e-5 in the 3-product mode."""
     from lsnet_amd.ops.conv import conv2d
     torch.manual_seed(2)
     dev = _dev()
+    tol = 3e-6 if split_mode == 'bf16x6' else 5e-5
     x = torch.randn(B, C, H, W, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_()
     w = (torch.randn(Co, C, k, k, device=dev) / (C * k * k) ** 0.5).contiguous(memory_format=torch.channels_last) \
         .requires_grad_()
@@ -431,31 +447,51 @@ def test_conv2d_matches_torch(B, C, Co, k, s, p, d, H, W, bias, bf16x3_mode):
     y = conv2d(x, w, b, s, p, d)
     go = torch.randn_like(y)
     grads = torch.autograd.grad(y, [x, w] + ([b] if bias else []), go)
-    xr, wr = x.detach().cpu().requires_grad_(), w.detach().cpu().contiguous().requires_grad_()
-    br = b.detach().cpu().requires_grad_() if bias else None
+    xr, wr = x.detach().double().cpu().requires_grad_(), w.detach().double().cpu().contiguous().requires_grad_()
+    br = b.detach().double().cpu().requires_grad_() if bias else None
     yr = F.conv2d(xr, wr, br, s, p, d)
-    gr = torch.autograd.grad(yr, [xr, wr] + ([br] if bias else []), go.cpu())
+    gr = torch.autograd.grad(yr, [xr, wr] + ([br] if bias else []), go.double().cpu())
     assert y.is_contiguous(memory_format=torch.channels_last)
-    assert _err(y, yr) < 5e-5
+    assert _err(y.double(), yr) < tol
     for g, r, n in zip(grads, gr, ('gx', 'gw', 'gb')):
-        assert _err(g, r) < 5e-5, n
+        assert _err(g.double(), r) < tol, (n, _err(g.double(), r))
 
 
 @pytest.mark.gpu
-def test_conv2d_module_dispatch(bf16x3_mode):
+def test_stem_row_merged_forward(split_mode):
+    """The frozen 7x7 stride-2 stem on the 3-channel image: row-merged form (lsn_conv2d_forward_pitched)."""
+    from lsnet_amd.ops.conv import Conv2d
+    torch.manual_seed(3)
+    dev = _dev()
+    m = Conv2d(3, 64, 7, stride=2, padding=3, bias=False).to(dev).to(memory_format=torch.channels_last)
+    for p_ in m.parameters():
+        p_.requires_grad_(False)
+    for hw in ((64, 96), (75, 101)):
+        x = torch.randn(2, 3, *hw, device=dev).contiguous(memory_format=torch.channels_last)
+        ref = F.conv2d(x.double().cpu(), m.weight.double().cpu(), None, 2, 3)
+        assert _err(m(x).double(), ref) < (3e-6 if split_mode == 'bf16x6' else 5e-5)
+
+
+@pytest.mark.gpu
+def test_conv2d_module_dispatch():
     from lsnet_amd import _lib
     from lsnet_amd.ops.conv import Conv2d
     dev = _dev()
-    m = Conv2d(256, 256, 3, padding=1).to(dev).to(memory_format=torch.channels_last)
-    x = torch.randn(2, 256, 100, 168, device=dev).contiguous(memory_format=torch.channels_last)
-    ref = F.conv2d(x, m.weight, m.bias, 1, 1)
-    assert _err(m(x), ref) < 5e-5                       # large layer: own kernel
-    _lib.set_math_mode('fp32')
-    assert torch.equal(m(x), ref)                       # exact mode: the vendor path, bit for bit
-    _lib.set_math_mode('bf16x3')
-    small = Conv2d(64, 64, 1).to(dev)
-    xs = torch.randn(2, 64, 20, 20, device=dev).contiguous(memory_format=torch.channels_last)
-    assert torch.equal(small(xs), F.conv2d(xs, small.weight, small.bias))   # small layer stays on MIOpen
+    old = _lib.get_math_mode()
+    try:
+        _lib.set_math_mode('bf16x6')
+        m = Conv2d(256, 256, 3, padding=1).to(dev).to(memory_format=torch.channels_last)
+        x = torch.randn(2, 256, 100, 168, device=dev).contiguous(memory_format=torch.channels_last)
+        ref = F.conv2d(x, m.weight, m.bias, 1, 1)
+        assert _err(m(x), ref) < 5e-6                       # own kernel (different summation order than MIOpen)
+        assert not torch.equal(m(x), ref)
+        small = Conv2d(64, 64, 1).to(dev).to(memory_format=torch.channels_last)
+        xs = torch.randn(2, 64, 20, 20, device=dev).contiguous(memory_format=torch.channels_last)
+        assert _err(small(xs), F.conv2d(xs, small.weight, small.bias)) < 5e-6   # small layers too: no vendor kernels
+        _lib.set_math_mode('fp32')
+        assert torch.equal(m(x), ref)                       # exact mode: the vendor path, bit for bit
+    finally:
+        _lib.set_math_mode(old)
 
 
 # ---------------------------------------------------------------------------------- frozen BN + add + ReLU

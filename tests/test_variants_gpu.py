@@ -1,10 +1,8 @@
-"""One training step of the other BASELINE configurations on the GPU: R-101-DCN bbox (DCNv2 in the backbone),
-X-101-64x4d-DCN segm (grouped DCNv2 + activation checkpointing), R-50 pose head, Res2Net-101-DCN.
-
-Opt-in (LSNET_SLOW_TESTS=1): each case spends about a minute in MIOpen's first-call kernel search.  State at the end of
-round 1: the R-101-DCN case ran forward, backward and the optimizer step on an MI355X; its first version then failed
-on an over-strict "90 % of all parameters moved" check (with zero-initialised last norms the residual branches get
-exactly zero gradient at the first iteration) -- relaxed below to the head's parameters, not re-run since (GPU budget)."""
+"""One training step of the other BASELINE configurations on the GPU: R-101-DCN bbox (config 3: DCNv2 in the backbone)
+and X-101-64x4d-DCN segm (config 4: grouped DCNv2 + activation checkpointing) run by default; R-50 pose head and
+Res2Net-101-DCN are opt-in (LSNET_SLOW_TESTS=1).  Loss finite, the head's parameters move, the backbone's deformable
+convs receive finite gradients.  (Feature / gradient parity of these backbones against the reference:
+tests/test_golden_gpu.py::test_dcn_backbones_of_configs_3_and_4.)"""
 import os
 
 import pytest
@@ -15,10 +13,13 @@ from lsnet_amd.model_zoo import build_lsnet
 from lsnet_amd.runner import EpochBasedRunner, build_optimizer
 
 
+SLOW = pytest.mark.skipif(os.environ.get('LSNET_SLOW_TESTS') != '1', reason='opt-in: LSNET_SLOW_TESTS=1')
+
+
 @pytest.mark.gpu
-@pytest.mark.skipif(os.environ.get('LSNET_SLOW_TESTS') != '1', reason='slow (MIOpen kernel search per new shape); LSNET_SLOW_TESTS=1')
-@pytest.mark.parametrize('task,backbone', [('bbox', 'r101-dcn'), ('segm', 'x101-dcn'), ('pose_bbox', 'r50'),
-                                           ('bbox', 'res2-101-dcn')])
+@pytest.mark.parametrize('task,backbone', [('bbox', 'r101-dcn'), ('segm', 'x101-dcn'),
+                                           pytest.param('pose_bbox', 'r50', marks=SLOW),
+                                           pytest.param('bbox', 'res2-101-dcn', marks=SLOW)])
 def test_one_training_step(task, backbone):
     dev = torch.device('cuda:0')
     torch.manual_seed(0)
