@@ -244,6 +244,22 @@ int lsn_nms(const float *dets, const int64_t *order, int n, float iou_thr, int64
 int lsn_conv2d_forward(const float *x, const float *w, const float *bias, float *out, void *workspace, int B, int H,
                        int W, int C, int Co, int kh, int kw, int stride, int pad, int dil, int relu,
                        lsn_stream_t stream);
+/* Batched forms: up to 8 input maps of different sizes that share one weight (the FPN levels under LSHead's shared
+ * convolutions, lsnet_head.py:502-513) in ONE launch each way.  forward: x -> out.  backward_data: x = grad_out
+ * (B,Ho,Wo,Co), out = grad_in (B,H,W,C), and B/H/W are the forward INPUT sizes; stride 1 when n_levels > 1.
+ * backward_weight: x = forward input, grad_out; the weight / bias gradients are summed over the levels. */
+typedef struct lsn_conv_level {
+    const float *x;
+    float *out;
+    const float *grad_out;   /* backward_weight only */
+    int B, H, W;
+} lsn_conv_level;
+int lsn_conv2d_forward_multi(int n_levels, const lsn_conv_level *levels, const float *w, const float *bias, void *workspace,
+                             int C, int Co, int kh, int kw, int stride, int pad, int dil, int relu, lsn_stream_t stream);
+int lsn_conv2d_backward_data_multi(int n_levels, const lsn_conv_level *levels, const float *w, float *wt_workspace, int C,
+                                   int Co, int kh, int kw, int stride, int pad, int dil, lsn_stream_t stream);
+int lsn_conv2d_backward_weight_multi(int n_levels, const lsn_conv_level *levels, float *grad_w, float *grad_bias, int C,
+                                     int Co, int kh, int kw, int stride, int pad, int dil, lsn_stream_t stream);
 int lsn_conv2d_forward_pitched(const float *x, const float *w, const float *bias, float *out, void *workspace, int B,
                                int H, int W, int C, int xpitch, int Co, int kh, int kw, int stride, int pad, int dil,
                                int relu, lsn_stream_t stream);

@@ -36,6 +36,11 @@ class DcnLevel(ctypes.Structure):
                 ('Wo', ctypes.c_int), ('scale_h', ctypes.c_float), ('scale_w', ctypes.c_float)]
 
 
+class ConvLevel(ctypes.Structure):
+    _fields_ = [('x', ctypes.c_void_p), ('out', ctypes.c_void_p), ('grad_out', ctypes.c_void_p),
+                ('B', ctypes.c_int), ('H', ctypes.c_int), ('W', ctypes.c_int)]
+
+
 class GnLevel(ctypes.Structure):
     _fields_ = [('x', ctypes.c_void_p), ('y', ctypes.c_void_p), ('dy', ctypes.c_void_p), ('dx', ctypes.c_void_p),
                 ('B', ctypes.c_int), ('HW', ctypes.c_int)]
@@ -58,7 +63,8 @@ EXPORTS = [
     'lsn_nms_workspace_bytes', 'lsn_nms', 'lsn_selftest_mfma', 'lsn_debug_phase_clocks',
     'lsn_prof_enable', 'lsn_prof_read',
     'lsn_group_norm_workspace_bytes', 'lsn_group_norm_forward', 'lsn_group_norm_backward',
-    'lsn_set_math_mode', 'lsn_get_math_mode', 'lsn_conv2d_forward', 'lsn_conv2d_forward_pitched', 'lsn_conv2d_backward_data', 'lsn_conv2d_backward_weight',
+    'lsn_set_math_mode', 'lsn_get_math_mode', 'lsn_conv2d_forward', 'lsn_conv2d_forward_pitched', 'lsn_conv2d_backward_data',
+    'lsn_conv2d_forward_multi', 'lsn_conv2d_backward_data_multi', 'lsn_conv2d_backward_weight_multi', 'lsn_conv2d_backward_weight',
     'lsn_bn_eval_act_forward', 'lsn_bn_eval_act_backward', 'lsn_bn_eval_act_workspace_bytes',
     'lsn_image_prep_u8', 'lsn_cross_iou_bbox_forward', 'lsn_cross_iou_bbox_backward',
     'lsn_cross_iou_bbox_stage_forward', 'lsn_cross_iou_bbox_stage_backward',

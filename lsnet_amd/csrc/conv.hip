@@ -24,13 +24,27 @@
 
 namespace lsn {
 
-struct ConvArgs {
-    const float *x, *w, *bias;
+constexpr int CV_MAXLV = 8;
+
+// One input map of a batched launch: the FPN levels that share a convolution's weights (LSHead) go into ONE launch,
+// so that the small levels do not each pay a launch whose duration is set by the depth of the reduction.
+struct ConvLvl {
+    const float *x;
     float *out;
-    int B, H, W, C, Ho, Wo, Co, kh, kw, stride, pad_h, pad_w, dil;
+    int B, H, W, Ho, Wo;
+    int P;       // B * Ho * Wo
+    int tile0;   // first pixel tile of this level
+};
+
+struct ConvArgs {
+    ConvLvl lv[CV_MAXLV];
+    int nlv, ntiles;
+    const float *w, *bias;
+    int C, Co, kh, kw, stride, pad_h, pad_w, dil;
     int xpitch;   // floats between horizontally adjacent input pixels (= C, except for the row-merged stem form)
-    int P;   // B * Ho * Wo
     int relu;
+    int ksplit;   // > 1: the chunk range is divided over blockIdx.z and the partial sums are added atomically into a
+                  // zero-filled output (few pixels, deep reduction: FPN P6 / P7); bias by split 0, no ReLU
     const unsigned short *wp;   // prepared weights: NPL bf16 planes [Co][K][C], or NULL
     // output placement: pixel (b, ho, wo) of the (Ho, Wo) grid is stored at (b, oy0 + ho * ostep, ox0 + wo * ostep) of an
     // (OH, OW) map.  ostep = 0: the dense case (OH = Ho, OW = Wo).  Used by the strided backward-data pass, which
@@ -75,17 +89,23 @@ __global__ __launch_bounds__(256, 1) void conv_fwd_xn_kernel(const ConvArgs a)
     // XCD-ordered (pixel tile, column block) with the column blocks of a pixel tile adjacent (same input rows)
     const int work = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
     const int ptile = work / (int)gridDim.y;
-    const int tile_p = ptile * BM;
+    int li = 0;
+    while (li + 1 < a.nlv && ptile >= a.lv[li + 1].tile0) ++li;
+    const ConvLvl &L = a.lv[li];
+    const int tile_p = (ptile - L.tile0) * BM;
     const int co_blk = (work - ptile * (int)gridDim.y) * BN;
     const int nco = min(BN, a.Co - co_blk);
     const int ncc = (a.C + BK - 1) / BK;
-    const int T = K * ncc;
+    const int Tall = K * ncc;
+    // split-K: this block reduces chunks [t_begin, t_begin + T)
+    const int t_begin = (int)((long long)Tall * blockIdx.z / gridDim.z);
+    const int T = (int)((long long)Tall * (blockIdx.z + 1) / gridDim.z) - t_begin;
 
     const int kk2 = tid & 15, prow = tid >> 4;   // gather: channel pair, pixel row (16 rows per pass)
     const int wq = tid & 7, wrow = tid >> 3;     // weights: float4 slot along ci, co row (32 rows per pass)
 
     const __amdgpu_buffer_rsrc_t xrs =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x), 0, a.B * a.H * a.W * a.xpitch * 4, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(L.x), 0, L.B * L.H * L.W * a.xpitch * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrs =
         PREP ? __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(a.wp), 0, a.Co * Kdim * 2 * NPL, 0x00020000)
              : __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.w), 0, a.Co * Kdim * 4, 0x00020000);
@@ -98,13 +118,13 @@ __global__ __launch_bounds__(256, 1) void conv_fwd_xn_kernel(const ConvArgs a)
 #pragma unroll
     for (int ps = 0; ps < NPA; ++ps) {
         const int p = tile_p + ps * 16 + prow;
-        const bool ok = p < a.P;
-        const int HWo = a.Ho * a.Wo;
+        const bool ok = p < L.P;
+        const int HWo = L.Ho * L.Wo;
         const int b = ok ? p / HWo : 0, rem = ok ? p - b * HWo : 0;
-        const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+        const int ho = rem / L.Wo, wo = rem - ho * L.Wo;
         iy0[ps] = ok ? ho * a.stride - a.pad_h : -0x40000000;   // an invalid pixel is out of range for every tap
         ix0[ps] = wo * a.stride - a.pad_w;
-        ibase[ps] = b * a.H * a.W;
+        ibase[ps] = b * L.H * L.W;
     }
     int wvoff[NPB];
 #pragma unroll
@@ -135,8 +155,8 @@ __global__ __launch_bounds__(256, 1) void conv_fwd_xn_kernel(const ConvArgs a)
     };
     auto issue_x = [&](const Ck &c, int ps) {
         const int y = iy0[ps] + c.i * a.dil, x = ix0[ps] + c.j * a.dil;
-        const bool ok = (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W && c.cc * BK + 2 * kk2 < a.C;
-        const int voff = ok ? ((ibase[ps] + y * a.W + x) * a.xpitch + c.cc * BK + 2 * kk2) * 4 : OOB;
+        const bool ok = (unsigned)y < (unsigned)L.H && (unsigned)x < (unsigned)L.W && c.cc * BK + 2 * kk2 < a.C;
+        const int voff = ok ? ((ibase[ps] + y * L.W + x) * a.xpitch + c.cc * BK + 2 * kk2) * 4 : OOB;
         xv[ps] = cv_load2(xrs, voff, 0);
     };
     auto issue_w = [&](const Ck &c, int ps) {
@@ -178,8 +198,15 @@ __global__ __launch_bounds__(256, 1) void conv_fwd_xn_kernel(const ConvArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = accl[i][j][r] = 0.f;
 
-    // ---- prologue: chunk 0 -> buffer 0, loads of chunk 1 in flight ----
-    Ck c1 = {0, 0, 0}, c2 = {0, 0, 0};
+    // ---- prologue: first chunk -> buffer 0, loads of the second in flight ----
+    Ck c1;
+    {
+        const int k0 = t_begin / ncc;
+        c1.cc = t_begin - k0 * ncc;
+        c1.i = k0 / a.kw;
+        c1.j = k0 - c1.i * a.kw;
+    }
+    Ck c2 = c1;
     {
 #pragma unroll
         for (int ps = 0; ps < NPA; ++ps) issue_x(c1, ps);
@@ -253,21 +280,25 @@ __global__ __launch_bounds__(256, 1) void conv_fwd_xn_kernel(const ConvArgs a)
         for (int j = 0; j < 2; ++j) {
             const int col = wn * 64 + j * 32 + (lane & 31);
             if (col >= nco) continue;
-            const float bv = a.bias ? a.bias[co_blk + col] : 0.f;
+            const float bv = (a.bias && blockIdx.z == 0) ? a.bias[co_blk + col] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int pix = tile_p + wm * 64 + i * 32 + mfma32_row(r, lane);
-                if (pix < a.P) {
+                if (pix < L.P) {
                     float v = (acc[i][j][r] + accl[i][j][r]) + bv;
                     if (a.relu) v = fmaxf(v, 0.f);
                     size_t opix = pix;
                     if (a.ostep) {
-                        const int HWo = a.Ho * a.Wo;
+                        const int HWo = L.Ho * L.Wo;
                         const int b = pix / HWo, rem = pix - b * HWo;
-                        const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+                        const int ho = rem / L.Wo, wo = rem - ho * L.Wo;
                         opix = ((size_t)b * a.OH + a.oy0 + ho * a.ostep) * a.OW + a.ox0 + wo * a.ostep;
                     }
-                    a.out[opix * a.Co + co_blk + col] = v;
+                    float *dst = L.out + opix * a.Co + co_blk + col;
+                    if (a.ksplit > 1)
+                        atomic_add_f32(dst, v);
+                    else
+                        *dst = v;
                 }
             }
         }
@@ -325,10 +356,31 @@ int split_np();   // dcn.hip: bf16 products per fp32 product of the current math
 static int conv_np() { return split_np() == 3 ? 3 : 6; }   // these kernels have no fp32-MFMA variant: exact mode gets x6
 
 template <int BM, int BN, int NP>
-static int launch_conv_np(const ConvArgs &a, hipStream_t st)
+static int launch_conv_np(ConvArgs &a, hipStream_t st)
 {
     const size_t lds = (size_t)2 * SplitCfg<NP>::NPL * (BM + BN) * CV_RS;
-    dim3 grid((a.P + BM - 1) / BM, (a.Co + BN - 1) / BN);
+    int tiles = 0;
+    for (int i = 0; i < a.nlv; ++i) {
+        a.lv[i].tile0 = tiles;
+        tiles += (a.lv[i].P + BM - 1) / BM;
+    }
+    a.ntiles = tiles;
+    const int ncol = (a.Co + BN - 1) / BN;
+    // few pixel tiles and a deep reduction (FPN P6 / P7, 1x1 convs on 2048 channels at the smallest maps): split the
+    // chunk range over blockIdx.z until the grid covers the chip; partial sums meet in a zero-filled output
+    const int Tall = a.kh * a.kw * ((a.C + 31) / 32);
+    int ks = 1;
+    if (!a.relu && !a.ostep && tiles * ncol < 128 && Tall >= 16) {
+        ks = 256 / (tiles * ncol);
+        if (ks > Tall / 8) ks = Tall / 8;
+        if (ks > 16) ks = 16;
+        if (ks < 1) ks = 1;
+    }
+    a.ksplit = ks;
+    if (ks > 1)
+        for (int i = 0; i < a.nlv; ++i)
+            LSN_HIP(hipMemsetAsync(a.lv[i].out, 0, sizeof(float) * (size_t)a.lv[i].P * a.Co, st));
+    dim3 grid(tiles, ncol, ks);
     if (a.wp) {
         auto k = conv_fwd_xn_kernel<BM, BN, true, NP>;
         LSN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -343,7 +395,7 @@ static int launch_conv_np(const ConvArgs &a, hipStream_t st)
 }
 
 template <int BM, int BN>
-static int launch_conv(const ConvArgs &a, hipStream_t st)
+static int launch_conv(ConvArgs &a, hipStream_t st)
 {
     return conv_np() == 3 ? launch_conv_np<BM, BN, 3>(a, st) : launch_conv_np<BM, BN, 6>(a, st);
 }
@@ -359,7 +411,7 @@ static void conv_prepare(const float *w, unsigned short *out, int Co, int K, int
         hipLaunchKernelGGL(conv_prepare_kernel<3>, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, st, w, out, Co, K, C, flipT, ts);
 }
 
-static int conv_forward(const ConvArgs &a, hipStream_t st)
+static int conv_forward(ConvArgs &a, hipStream_t st)
 {
     // the block is four 64x64 wave tiles: 1x4 for wide layers, 2x2 for 128 output channels, 4x1 for 64
     if (a.Co <= 64) return launch_conv<256, 64>(a, st);
@@ -367,14 +419,16 @@ static int conv_forward(const ConvArgs &a, hipStream_t st)
     return launch_conv<64, 256>(a, st);
 }
 
+static int conv_out_size(int in, int k, int stride, int pad, int dil) { return (in + 2 * pad - (dil * (k - 1) + 1)) / stride + 1; }
+
 static int conv_check(int B, int H, int W, int C, int Co, int kh, int kw, int stride, int pad, int dil, int *Ho,
                       int *Wo)
 {
     LSN_CHECK(B > 0 && H > 0 && W > 0 && C > 0 && Co > 0 && kh > 0 && kw > 0, "conv2d: empty tensor");
     LSN_CHECK(stride > 0 && dil > 0 && pad >= 0, "conv2d: bad stride / dilation / padding");
     if (C % 4 != 0) return fail(LSN_ERR_UNSUPPORTED, "conv2d kernel needs C %% 4 == 0, got %d", C);
-    *Ho = (H + 2 * pad - (dil * (kh - 1) + 1)) / stride + 1;
-    *Wo = (W + 2 * pad - (dil * (kw - 1) + 1)) / stride + 1;
+    *Ho = conv_out_size(H, kh, stride, pad, dil);
+    *Wo = conv_out_size(W, kw, stride, pad, dil);
     LSN_CHECK(*Ho > 0 && *Wo > 0, "conv2d: output size is too small");
     if ((int64_t)B * H * W * C * 4 >= ((int64_t)1 << 31) || (int64_t)Co * kh * kw * C * 4 >= ((int64_t)1 << 31) ||
         (int64_t)B * *Ho * *Wo * Co * 4 >= ((int64_t)1 << 31))
@@ -382,69 +436,65 @@ static int conv_check(int B, int H, int W, int C, int Co, int kh, int kw, int st
     return 0;
 }
 
-}  // namespace lsn
-
-extern "C" {
-
-int lsn_conv2d_forward_pitched(const float *x, const float *w, const float *bias, float *out, void *workspace, int B,
-                               int H, int W, int C, int xpitch, int Co, int kh, int kw, int stride, int pad, int dil,
-                               int relu, lsn_stream_t stream)
+static int conv_forward_impl(int n, const lsn_conv_level *lv, const float *w, const float *bias, void *workspace, int C,
+                             int xpitch, int Co, int kh, int kw, int stride, int pad, int dil, int relu, hipStream_t st)
 {
-    using namespace lsn;
-    LSN_CHECK(x && w && out, "conv2d: NULL argument");
+    LSN_CHECK(n >= 1 && n <= CV_MAXLV && lv && w, "conv2d: bad level list");
     LSN_CHECK(xpitch > 0 && xpitch % 2 == 0, "conv2d: the pixel pitch must be an even number of floats, got %d", xpitch);
     ConvArgs a = {};
-    if (int rc = conv_check(B, H, W, C, Co, kh, kw, stride, pad, dil, &a.Ho, &a.Wo)) return rc;
-    if (xpitch != C) {
-        // row-merged form: the C "channels" of a tap are C / xpitch horizontally adjacent pixels; they must stay inside
-        // the row (the caller pads the image), and the output grid follows the REAL pixels
-        LSN_CHECK(kw == 1 && pad == 0 && dil == 1 && C % xpitch == 0, "conv2d: row-merged form needs kw = 1, pad = 0, dil = 1");
-        a.Wo = (W - C / xpitch) / stride + 1;
-        LSN_CHECK(a.Wo > 0, "conv2d: output size is too small");
+    a.nlv = n;
+    for (int i = 0; i < n; ++i) {
+        ConvLvl &L = a.lv[i];
+        LSN_CHECK(lv[i].x && lv[i].out, "conv2d: NULL tensor in level %d", i);
+        if (int rc = conv_check(lv[i].B, lv[i].H, lv[i].W, C, Co, kh, kw, stride, pad, dil, &L.Ho, &L.Wo)) return rc;
+        if (xpitch != C) {
+            // row-merged form: the C "channels" of a tap are C / xpitch horizontally adjacent pixels; they must stay
+            // inside the row (the caller pads the image), and the output grid follows the REAL pixels
+            LSN_CHECK(kw == 1 && pad == 0 && dil == 1 && C % xpitch == 0, "conv2d: row-merged form needs kw = 1, pad = 0, dil = 1");
+            L.Wo = (lv[i].W - C / xpitch) / stride + 1;
+            LSN_CHECK(L.Wo > 0, "conv2d: output size is too small");
+        }
+        L.x = lv[i].x, L.out = lv[i].out, L.B = lv[i].B, L.H = lv[i].H, L.W = lv[i].W;
+        L.P = L.B * L.Ho * L.Wo;
     }
-    a.x = x, a.w = w, a.bias = bias, a.out = out;
+    a.w = w, a.bias = bias;
     if (workspace && C % 8 == 0) {   // split the weights once instead of in every block
-        conv_prepare(w, reinterpret_cast<unsigned short *>(workspace), Co, kh * kw, C, 0, TapSub{},
-                     reinterpret_cast<hipStream_t>(stream));
+        conv_prepare(w, reinterpret_cast<unsigned short *>(workspace), Co, kh * kw, C, 0, TapSub{}, st);
         a.wp = reinterpret_cast<const unsigned short *>(workspace);
     }
-    a.B = B, a.H = H, a.W = W, a.C = C, a.Co = Co, a.kh = kh, a.kw = kw, a.stride = stride, a.pad_h = a.pad_w = pad, a.dil = dil;
+    a.C = C, a.Co = Co, a.kh = kh, a.kw = kw, a.stride = stride, a.pad_h = a.pad_w = pad, a.dil = dil;
     a.xpitch = xpitch;
-    a.P = B * a.Ho * a.Wo;
     a.relu = relu;
-    return conv_forward(a, reinterpret_cast<hipStream_t>(stream));
+    return conv_forward(a, st);
 }
 
-int lsn_conv2d_forward(const float *x, const float *w, const float *bias, float *out, void *workspace, int B, int H,
-                       int W, int C, int Co, int kh, int kw, int stride, int pad, int dil, int relu,
-                       lsn_stream_t stream)
+// grad_in of every level (B, H, W, C) from grad_out (B, Ho, Wo, Co): lv[i].x = grad_out, lv[i].out = grad_in, and
+// lv[i].B / H / W are the INPUT sizes of the forward convolution
+static int conv_backward_data_impl(int n, const lsn_conv_level *lv, const float *w, float *wt_workspace, int C, int Co,
+                                   int kh, int kw, int stride, int pad, int dil, hipStream_t st)
 {
-    return lsn_conv2d_forward_pitched(x, w, bias, out, workspace, B, H, W, C, C, Co, kh, kw, stride, pad, dil, relu, stream);
-}
-
-int lsn_conv2d_backward_data(const float *grad_out, const float *w, float *grad_in, float *wt_workspace, int B,
-                             int H, int W, int C, int Co, int kh, int kw, int stride, int pad, int dil,
-                             lsn_stream_t stream)
-{
-    using namespace lsn;
-    LSN_CHECK(grad_out && w && grad_in && wt_workspace, "conv2d backward: NULL argument");
-    int Ho, Wo;
-    if (int rc = conv_check(B, H, W, C, Co, kh, kw, stride, pad, dil, &Ho, &Wo)) return rc;
+    LSN_CHECK(n >= 1 && n <= CV_MAXLV && lv && w && wt_workspace, "conv2d backward: bad arguments");
     if (Co % 8 != 0) return fail(LSN_ERR_UNSUPPORTED, "conv2d backward-data kernel needs Co %% 8 == 0");
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int K = kh * kw, s = stride;
+    int Ho[CV_MAXLV], Wo[CV_MAXLV];
+    for (int i = 0; i < n; ++i) {
+        LSN_CHECK(lv[i].x && lv[i].out, "conv2d backward: NULL tensor in level %d", i);
+        if (int rc = conv_check(lv[i].B, lv[i].H, lv[i].W, C, Co, kh, kw, stride, pad, dil, &Ho[i], &Wo[i])) return rc;
+    }
+    if (s > 1 && n > 1) return fail(LSN_ERR_UNSUPPORTED, "conv2d backward-data: strided convolutions take one level per call");
     // grad_in[y, x] = sum over taps (i, j) with (y + pad - i dil) % s == 0 (same for x) of
     //                 grad_out[(y + pad - i dil) / s, (x + pad - j dil) / s] . w[:, i, j, :]
     // Each residue class (y % s, x % s) of input pixels is a stride-1 convolution of grad_out with its own subset of
-    // the taps (an arithmetic progression): no zero-stuffed samples, no wasted products.  Classes without a tap, and
-    // input rows / columns the forward pass never read, keep the zeros of the memset.
+    // the taps (an arithmetic progression): no zero-stuffed samples, no wasted products.  Classes without a tap keep
+    // the zeros of the memset.
+    if (s * s > 64) return fail(LSN_ERR_UNSUPPORTED, "conv2d backward-data: stride %d is not supported", s);
+    const int H = lv[0].H, W = lv[0].W, B = lv[0].B;
     bool need_zero = false;
     struct Cls {
         TapSub ts;
         int py, px, Hc, Wc, pad_h, pad_w, dstep;
     } cls[64];
     int ncls = 0;
-    if (s * s > 64) return fail(LSN_ERR_UNSUPPORTED, "conv2d backward-data: stride %d is not supported", s);
     auto taps_of = [&](int p, int k, int &t0, int &tstep, int &nt) {
         t0 = -1, tstep = 1, nt = 0;
         int prev = -1;
@@ -462,7 +512,7 @@ int lsn_conv2d_backward_data(const float *grad_out, const float *w, float *grad_
             c.py = py, c.px = px;
             c.Hc = py < H ? (H - py + s - 1) / s : 0;
             c.Wc = px < W ? (W - px + s - 1) / s : 0;
-            if (c.Hc == 0 || c.Wc == 0) continue;
+            if (s > 1 && (c.Hc == 0 || c.Wc == 0)) continue;
             taps_of(py, kh, c.ts.i0, c.ts.istep, c.ts.ni);
             taps_of(px, kw, c.ts.j0, c.ts.jstep, c.ts.nj);
             c.ts.kw = kw;
@@ -483,11 +533,7 @@ int lsn_conv2d_backward_data(const float *grad_out, const float *w, float *grad_
             c.pad_w = (c.ts.nj - 1) * c.dstep - q0w;
             cls[ncls++] = c;
         }
-    if (s > 1) {
-        // rows / columns beyond the last receptive field are only reached through out-of-range grad_out samples: the
-        // kernel yields 0 for them, so only tap-less classes need the memset
-        if (need_zero) LSN_HIP(hipMemsetAsync(grad_in, 0, sizeof(float) * (size_t)B * H * W * C, st));
-    }
+    if (need_zero) LSN_HIP(hipMemsetAsync(lv[0].out, 0, sizeof(float) * (size_t)B * H * W * C, st));
     size_t ws_off = 0;   // every class gets its own slice of the workspace (the launches are asynchronous)
     for (int ci = 0; ci < ncls; ++ci) {
         const Cls &c = cls[ci];
@@ -497,16 +543,66 @@ int lsn_conv2d_backward_data(const float *grad_out, const float *w, float *grad_
         ws_off += (size_t)3 * Co * Kc * C;
         ConvArgs a = {};
         a.wp = wp;
-        a.x = grad_out, a.w = nullptr, a.bias = nullptr, a.out = grad_in;
-        a.B = B, a.H = Ho, a.W = Wo, a.C = Co, a.Co = C, a.kh = c.ts.ni, a.kw = c.ts.nj, a.stride = 1;
+        a.nlv = n;
+        for (int i = 0; i < n; ++i) {
+            ConvLvl &L = a.lv[i];
+            L.x = lv[i].x, L.out = lv[i].out;
+            L.B = lv[i].B, L.H = Ho[i], L.W = Wo[i];
+            L.Ho = s > 1 ? c.Hc : lv[i].H, L.Wo = s > 1 ? c.Wc : lv[i].W;
+            L.P = L.B * L.Ho * L.Wo;
+        }
+        a.C = Co, a.Co = C, a.kh = c.ts.ni, a.kw = c.ts.nj, a.stride = 1;
         a.xpitch = Co;
         a.pad_h = c.pad_h, a.pad_w = c.pad_w, a.dil = c.dstep;
-        a.Ho = c.Hc, a.Wo = c.Wc;
-        a.P = B * c.Hc * c.Wc;
         if (s > 1) a.ostep = s, a.oy0 = c.py, a.ox0 = c.px, a.OH = H, a.OW = W;
         if (int rc = conv_forward(a, st)) return rc;
     }
     return 0;
+}
+
+}  // namespace lsn
+
+extern "C" {
+
+int lsn_conv2d_forward_multi(int n_levels, const lsn_conv_level *levels, const float *w, const float *bias, void *workspace,
+                             int C, int Co, int kh, int kw, int stride, int pad, int dil, int relu, lsn_stream_t stream)
+{
+    return lsn::conv_forward_impl(n_levels, levels, w, bias, workspace, C, C, Co, kh, kw, stride, pad, dil, relu,
+                                  reinterpret_cast<hipStream_t>(stream));
+}
+
+int lsn_conv2d_backward_data_multi(int n_levels, const lsn_conv_level *levels, const float *w, float *wt_workspace, int C,
+                                   int Co, int kh, int kw, int stride, int pad, int dil, lsn_stream_t stream)
+{
+    return lsn::conv_backward_data_impl(n_levels, levels, w, wt_workspace, C, Co, kh, kw, stride, pad, dil,
+                                        reinterpret_cast<hipStream_t>(stream));
+}
+
+int lsn_conv2d_forward_pitched(const float *x, const float *w, const float *bias, float *out, void *workspace, int B,
+                               int H, int W, int C, int xpitch, int Co, int kh, int kw, int stride, int pad, int dil,
+                               int relu, lsn_stream_t stream)
+{
+    lsn_conv_level L = {};
+    L.x = x, L.out = out, L.B = B, L.H = H, L.W = W;
+    return lsn::conv_forward_impl(1, &L, w, bias, workspace, C, xpitch, Co, kh, kw, stride, pad, dil, relu,
+                                  reinterpret_cast<hipStream_t>(stream));
+}
+
+int lsn_conv2d_forward(const float *x, const float *w, const float *bias, float *out, void *workspace, int B, int H,
+                       int W, int C, int Co, int kh, int kw, int stride, int pad, int dil, int relu,
+                       lsn_stream_t stream)
+{
+    return lsn_conv2d_forward_pitched(x, w, bias, out, workspace, B, H, W, C, C, Co, kh, kw, stride, pad, dil, relu, stream);
+}
+
+int lsn_conv2d_backward_data(const float *grad_out, const float *w, float *grad_in, float *wt_workspace, int B,
+                             int H, int W, int C, int Co, int kh, int kw, int stride, int pad, int dil,
+                             lsn_stream_t stream)
+{
+    lsn_conv_level L = {};
+    L.x = grad_out, L.out = grad_in, L.B = B, L.H = H, L.W = W;
+    return lsn::conv_backward_data_impl(1, &L, w, wt_workspace, C, Co, kh, kw, stride, pad, dil,
+                                        reinterpret_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -764,36 +764,53 @@ static int make_single(lsn_dcn_shape &s, lsn_dcn_level &L, int B, int C, int H, 
     return 0;
 }
 
-// weight gradient of a dense convolution through the deformable-conv weight-gradient kernel (PLAIN: no offsets)
-static int conv_wgrad_x3(const float *x, const float *gout, float *gw, float *gb, int B, int H, int W, int C, int Co,
-                         int Ho, int Wo, int kh, int kw, int stride, int pad, int dil, hipStream_t st)
+// weight gradient of a dense convolution through the deformable-conv weight-gradient kernel (PLAIN: no offsets), summed
+// over up to MAXLV input maps that share the weight
+template <int NP, int BMW>
+static int conv_wgrad_launch(const DcnArgs &a, int nsteps, int C, int Co, int K, hipStream_t st)
 {
+    const int ncc = cdiv(C, WG_BN), ncol = K * ncc, nz = cdiv(Co, BMW);
+    int splits = cdiv(BMW == 256 ? 1024 : 2048, ncol * nz);
+    if (splits > nsteps) splits = nsteps;
+    if (splits < 1) splits = 1;
+    if (splits > 65535) splits = 65535;
+    const size_t ldsn = wgrad_xn_lds_bytes<NP, BMW>();
+    auto k = dcn_wgrad_xn_kernel<true, NP, BMW>;
+    if (int rc = set_lds(k, ldsn)) return rc;
+    hipLaunchKernelGGL(k, dim3(ncol, splits, nz), dim3(256), ldsn, st, a, nsteps);
+    LSN_HIP(hipGetLastError());
+    return 0;
+}
+
+static int conv_wgrad_xn(int n, const lsn_conv_level *lv, float *gw, float *gb, int C, int Co, int kh, int kw, int stride,
+                         int pad, int dil, hipStream_t st)
+{
+    LSN_CHECK(n >= 1 && n <= MAXLV && lv && gw, "conv2d backward-weight: bad arguments");
     DcnArgs a = {};
-    Lvl &L = a.lv[0];
-    L.x = x, L.gout = gout, L.off = nullptr, L.msk = nullptr;
-    L.B = B, L.H = H, L.W = W, L.Ho = Ho, L.Wo = Wo, L.P = B * Ho * Wo, L.tile0 = 0, L.sh = L.sw = 1.f;
-    a.nlv = 1;
+    int steps = 0;
+    for (int i = 0; i < n; ++i) {
+        Lvl &L = a.lv[i];
+        const int B = lv[i].B, H = lv[i].H, W = lv[i].W;
+        LSN_CHECK(lv[i].x && lv[i].grad_out && B > 0 && H > 0 && W > 0, "conv2d backward-weight: bad level %d", i);
+        const int Ho = (H + 2 * pad - (dil * (kh - 1) + 1)) / stride + 1, Wo = (W + 2 * pad - (dil * (kw - 1) + 1)) / stride + 1;
+        LSN_CHECK(Ho > 0 && Wo > 0, "conv2d backward-weight: output size is too small");
+        if ((int64_t)B * H * W * C >= ((int64_t)1 << 31) || (int64_t)B * Ho * Wo * Co >= ((int64_t)1 << 31))
+            return fail(LSN_ERR_UNSUPPORTED, "conv2d backward-weight: tensor too large for 32-bit indexing");
+        L.x = lv[i].x, L.gout = lv[i].grad_out, L.off = nullptr, L.msk = nullptr;
+        L.B = B, L.H = H, L.W = W, L.Ho = Ho, L.Wo = Wo, L.P = B * Ho * Wo, L.sh = L.sw = 1.f;
+        L.tile0 = steps;
+        steps += cdiv(L.P, WG_BP);
+    }
+    a.nlv = n;
     a.C = C, a.Co = Co, a.kh = kh, a.kw = kw, a.stride = stride, a.pad = pad, a.dil = dil, a.groups = 1, a.dg = 1;
     a.SL = C;
     a.gw = gw, a.gb = gb;
-    const int K = kh * kw, nsteps = cdiv(L.P, WG_BP);
-    const int ncc = cdiv(C, WG_BN), ncol = K * ncc, nz = cdiv(Co, WG_BM);
-    int splits = cdiv(1024, ncol * nz);
-    if (splits > nsteps) splits = nsteps;
-    if (splits < 1) splits = 1;
+    const int K = kh * kw;
     LSN_HIP(hipMemsetAsync(gw, 0, sizeof(float) * (size_t)Co * K * C, st));
     if (gb) LSN_HIP(hipMemsetAsync(gb, 0, sizeof(float) * (size_t)Co, st));
-    if (math_np() == 3) {
-        const size_t ldsn = wgrad_xn_lds_bytes<3>();
-        if (int rc = set_lds(dcn_wgrad_xn_kernel<true, 3>, ldsn)) return rc;
-        hipLaunchKernelGGL((dcn_wgrad_xn_kernel<true, 3>), dim3(ncol, splits, nz), dim3(256), ldsn, st, a, nsteps);
-    } else {   // the fp32-equivalent split is also what an exact-mode caller gets: there is no fp32-MFMA dense wgrad
-        const size_t ldsn = wgrad_xn_lds_bytes<6>();
-        if (int rc = set_lds(dcn_wgrad_xn_kernel<true, 6>, ldsn)) return rc;
-        hipLaunchKernelGGL((dcn_wgrad_xn_kernel<true, 6>), dim3(ncol, splits, nz), dim3(256), ldsn, st, a, nsteps);
-    }
-    LSN_HIP(hipGetLastError());
-    return 0;
+    const bool x3 = math_np() == 3;   // exact-mode callers get the fp32-equivalent split: there is no fp32-MFMA dense wgrad
+    if (Co <= 64) return x3 ? conv_wgrad_launch<3, 64>(a, steps, C, Co, K, st) : conv_wgrad_launch<6, 64>(a, steps, C, Co, K, st);
+    return x3 ? conv_wgrad_launch<3, 256>(a, steps, C, Co, K, st) : conv_wgrad_launch<6, 256>(a, steps, C, Co, K, st);
 }
 
 }  // namespace lsn
@@ -836,18 +853,20 @@ int lsn_set_math_mode(int mode)
 
 int lsn_get_math_mode(void) { return lsn::math_mode(); }
 
+int lsn_conv2d_backward_weight_multi(int n_levels, const lsn_conv_level *levels, float *grad_w, float *grad_bias, int C,
+                                     int Co, int kh, int kw, int stride, int pad, int dil, lsn_stream_t stream)
+{
+    LSN_CHECK(C > 0 && Co > 0 && kh > 0 && kw > 0 && stride > 0 && dil > 0 && pad >= 0, "conv2d backward-weight: bad shape");
+    return conv_wgrad_xn(n_levels, levels, grad_w, grad_bias, C, Co, kh, kw, stride, pad, dil,
+                         reinterpret_cast<hipStream_t>(stream));
+}
+
 int lsn_conv2d_backward_weight(const float *x, const float *grad_out, float *grad_w, float *grad_bias, int B, int H,
                                int W, int C, int Co, int kh, int kw, int stride, int pad, int dil, lsn_stream_t stream)
 {
-    LSN_CHECK(x && grad_out && grad_w, "conv2d backward-weight: NULL argument");
-    LSN_CHECK(B > 0 && H > 0 && W > 0 && C > 0 && Co > 0 && kh > 0 && kw > 0 && stride > 0 && dil > 0 && pad >= 0,
-              "conv2d backward-weight: bad shape");
-    const int Ho = (H + 2 * pad - (dil * (kh - 1) + 1)) / stride + 1, Wo = (W + 2 * pad - (dil * (kw - 1) + 1)) / stride + 1;
-    LSN_CHECK(Ho > 0 && Wo > 0, "conv2d backward-weight: output size is too small");
-    if ((int64_t)B * H * W * C >= ((int64_t)1 << 31) || (int64_t)B * Ho * Wo * Co >= ((int64_t)1 << 31))
-        return fail(LSN_ERR_UNSUPPORTED, "conv2d backward-weight: tensor too large for 32-bit indexing");
-    return conv_wgrad_x3(x, grad_out, grad_w, grad_bias, B, H, W, C, Co, Ho, Wo, kh, kw, stride, pad, dil,
-                         reinterpret_cast<hipStream_t>(stream));
+    lsn_conv_level L = {};
+    L.x = x, L.grad_out = grad_out, L.B = B, L.H = H, L.W = W;
+    return lsn_conv2d_backward_weight_multi(1, &L, grad_w, grad_bias, C, Co, kh, kw, stride, pad, dil, stream);
 }
 
 int lsn_prof_enable(int on)

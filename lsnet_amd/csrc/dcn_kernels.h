@@ -2513,18 +2513,23 @@ __global__ __launch_bounds__(256, 2) void dcn_wgrad_kernel(const DcnArgs a, int 
 // row pieces.  24 MFMAs of 32 cycles per step and wave instead of 64 of 64.
 // PLAIN: a dense convolution (no offsets, no mask): one load per sample instead of four corners.
 // =============================================================================================
-template <int NP>
+template <int NP, int BMW = WG_BM>
 __host__ __device__ inline size_t wgrad_xn_lds_bytes()
 {
-    return (size_t)SplitCfg<NP>::NPL * (WG_BM + WG_BN) * 80 + 2 * WG_BP * sizeof(Tap);
+    return (size_t)SplitCfg<NP>::NPL * (BMW + WG_BN) * 80 + 2 * WG_BP * sizeof(Tap);
 }
 
-template <bool PLAIN, int NP>
+// BMW: output channels per block.  256 (four waves x 64 co x 64 columns) for the wide layers; 64 (four waves x 32 x 32)
+// for convolutions with few output channels (a DCNv2 pack's 27-channel offset conv, the 64-channel stem stage), whose
+// weight gradient would otherwise spend 3/4 .. 9/10 of its MFMAs and of its gout staging on rows that do not exist.
+template <bool PLAIN, int NP, int BMW = WG_BM>
 __global__ __launch_bounds__(256, 2) void dcn_wgrad_xn_kernel(const DcnArgs a, int nsteps)
 {
+    static_assert(BMW == 256 || BMW == 64, "co tile");
+    constexpr int TI = BMW == 256 ? 2 : 1;   // 32x32 accumulator tiles per wave: TI x TI
     using SC = SplitCfg<NP>;
     constexpr int NPL = SC::NPL;
-    constexpr int RS = 80, PLANE_A = WG_BM * RS, PLANE_B = WG_BN * RS;
+    constexpr int RS = 80, PLANE_A = BMW * RS, PLANE_B = WG_BN * RS;
     extern __shared__ __align__(16) unsigned char smem[];   // [A planes][B planes][tab 2 x 32]
     Tap *tab = reinterpret_cast<Tap *>(smem + NPL * PLANE_A + NPL * PLANE_B);
 
@@ -2540,9 +2545,10 @@ __global__ __launch_bounds__(256, 2) void dcn_wgrad_xn_kernel(const DcnArgs a, i
     const int bsplit = work / ncol_all, bcol = work - bsplit * ncol_all;
     const int g = bcol / ncol_g;
     const Chunk ch = decode_chunk<WG_BN>(a, g, bcol - g * ncol_g, segs, ncc);
-    const int co_blk = blockIdx.z * WG_BM;
-    const int nco = min(WG_BM, Cog - co_blk);
+    const int co_blk = blockIdx.z * BMW;
+    const int nco = min(BMW, Cog - co_blk);
     const int co_base = g * Cog + co_blk;
+    const int row0 = BMW == 256 ? wave * 64 : (wave >> 1) * 32, col0 = BMW == 256 ? 0 : (wave & 1) * 32;
 
     const int st_begin = (int)((long long)nsteps * bsplit / nsplit);
     const int st_end = (int)((long long)nsteps * (bsplit + 1) / nsplit);
@@ -2558,11 +2564,11 @@ __global__ __launch_bounds__(256, 2) void dcn_wgrad_xn_kernel(const DcnArgs a, i
     float gv[WG_BP];
     float bias_acc = 0.f;
 
-    f32x16 acc[2][2];
+    f32x16 acc[TI][TI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TI; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -2588,12 +2594,14 @@ __global__ __launch_bounds__(256, 2) void dcn_wgrad_xn_kernel(const DcnArgs a, i
                 xv[q][3] = L.x[idx.w + c];
             }
         }
-        const float *gp = L.gout + (size_t)p0 * a.Co + co_base + (gval ? tid : 0);
-        const int npx = L.P - p0;   // valid pixels of this step (>= 1)
+        if (BMW == 256 || tid < BMW) {   // (wave-uniform: BMW = 64 is the first wave)
+            const float *gp = L.gout + (size_t)p0 * a.Co + co_base + (gval ? tid : 0);
+            const int npx = L.P - p0;   // valid pixels of this step (>= 1)
 #pragma unroll
-        for (int px = 0; px < WG_BP; ++px) gv[px] = gp[(size_t)(px < npx ? px : 0) * a.Co];
+            for (int px = 0; px < WG_BP; ++px) gv[px] = gp[(size_t)(px < npx ? px : 0) * a.Co];
 #pragma unroll
-        for (int px = 0; px < WG_BP; ++px) gv[px] = (gval && px < npx) ? gv[px] : 0.f;
+            for (int px = 0; px < WG_BP; ++px) gv[px] = (gval && px < npx) ? gv[px] : 0.f;
+        }
     };
     auto store_step = [&](int buf) {
         // gathered columns: 8 pixels of channel kk -> one 16-byte piece of row kk in each plane
@@ -2621,6 +2629,7 @@ __global__ __launch_bounds__(256, 2) void dcn_wgrad_xn_kernel(const DcnArgs a, i
         for (int q = 0; q < NPL; ++q)
             *reinterpret_cast<uint4 *>(bp + q * PLANE_B) = make_uint4(cp[0][q], cp[1][q], cp[2][q], cp[3][q]);
         // gout: 32 pixels of output channel tid -> row tid (64 bytes) in each plane
+        if (tid < BMW)
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
             unsigned gp4[4][NPL];
@@ -2647,13 +2656,13 @@ __global__ __launch_bounds__(256, 2) void dcn_wgrad_xn_kernel(const DcnArgs a, i
             if (st + 1 < st_end) build_tab(st + 1, buf ^ 1);
             __syncthreads();
             if (st + 1 < st_end) load_step(st + 1, buf ^ 1);
-            const unsigned char *ap = smem + (wave * 64 + (lane & 31)) * RS + (lane >> 5) * 16;
-            const unsigned char *bp = smem + NPL * PLANE_A + (lane & 31) * RS + (lane >> 5) * 16;
+            const unsigned char *ap = smem + (row0 + (lane & 31)) * RS + (lane >> 5) * 16;
+            const unsigned char *bp = smem + NPL * PLANE_A + (col0 + (lane & 31)) * RS + (lane >> 5) * 16;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 Af[2][NPL], Bf[2][NPL];
+                bf16x8 Af[TI][NPL], Bf[TI][NPL];
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < TI; ++i)
 #pragma unroll
                     for (int q = 0; q < NPL; ++q) {
                         Af[i][q] = *reinterpret_cast<const bf16x8 *>(ap + q * PLANE_A + i * 32 * RS + ks * 32);
@@ -2662,9 +2671,9 @@ __global__ __launch_bounds__(256, 2) void dcn_wgrad_xn_kernel(const DcnArgs a, i
 #pragma unroll
                 for (int prod = 0; prod < NP; ++prod)
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
+                    for (int i = 0; i < TI; ++i)
 #pragma unroll
-                        for (int j = 0; j < 2; ++j)
+                        for (int j = 0; j < TI; ++j)
                             acc[i][j] = mfma_bf16(Af[i][SC::pa(prod)], Bf[j][SC::pb(prod)], acc[i][j]);
             }
             __syncthreads();
@@ -2672,14 +2681,14 @@ __global__ __launch_bounds__(256, 2) void dcn_wgrad_xn_kernel(const DcnArgs a, i
     }
 
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = j * 32 + (lane & 31);
+        for (int j = 0; j < TI; ++j) {
+            const int col = col0 + j * 32 + (lane & 31);
             if (col >= ch.nval) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = wave * 64 + i * 32 + mfma32_row(r, lane);
+                const int row = row0 + i * 32 + mfma32_row(r, lane);
                 if (row < nco)
                     atomic_add_f32(a.gw + (size_t)(co_base + row) * Kdim + ch.k * Cg + ch.c0 + col, acc[i][j][r]);
             }

@@ -282,7 +282,7 @@ class LSHead(nn.Module):
             init_conv, init_out = getattr(self, f'pts_{b}_init_conv'), getattr(self, f'pts_{b}_init_out')
             n_sp = self._out_dims(b)[1]
             # 3x3 conv per level; everything after it is pixel-wise: one pass over the concatenated levels
-            raw = init_out(self.relu(self._cat_px([init_conv(f) for f in tower])))
+            raw = init_out(self.relu(self._cat_px(init_conv.forward_multi(tower))))
             sp = self.softplus(raw[:, :n_sp])
             reg = self.get_pred_reg(sp, raw[:, n_sp:] if raw.shape[1] > n_sp else None)
             reg = (1 - self.gradient_mul) * reg.detach() + self.gradient_mul * reg
@@ -313,14 +313,20 @@ class LSHead(nn.Module):
         driver = self.branches[-1]
         cls_raw = gather(self.pts_cls_conv, cls_feats, scaled[driver])
         outs = {}
-        fused = [self.cls_af_dcn_conv(torch.cat(cls_raw[3 * l:3 * l + 3], dim=1)) + self.cls_feat_conv(cls_feats[l])
-                 for l in range(nl)]
+        def fuse(af, fc, raw, feat):
+            # relu(1x1 over the three gathered maps of a level) + 3x3 over the level's tower output: each of the two
+            # convolutions runs over all levels in one launch
+            a = af[0].forward_multi([torch.cat(raw[3 * l:3 * l + 3], dim=1) for l in range(nl)], relu=True)
+            f = fc.forward_multi(feat)
+            return [x + y for x, y in zip(a, f)]
+
+        fused = fuse(self.cls_af_dcn_conv, self.cls_feat_conv, cls_raw, cls_feats)
         outs['cls'] = self._split_px(self.pts_cls_out(self._cat_px(self.cls_GN.forward_multi(fused, relu=True))), shapes)
         for b in self.branches:
             raw = gather(getattr(self, f'pts_{b}_refine_conv'), st[b]['feat'], scaled[b])
             af, fc = getattr(self, f'{b}_af_dcn_conv'), getattr(self, f'{b}_feat_conv')
             gn, ro = getattr(self, f'{b}_GN'), getattr(self, f'pts_{b}_refine_out')
-            fused = [af(torch.cat(raw[3 * l:3 * l + 3], dim=1)) + fc(st[b]['feat'][l]) for l in range(nl)]
+            fused = fuse(af, fc, raw, st[b]['feat'])
             refine = self.softplus(ro(self._cat_px(gn.forward_multi(fused, relu=True))) + st[b]['sp_all'].detach())
             outs[b] = self._split_px(refine, shapes)
 

@@ -87,6 +87,82 @@ class _ConvFn(torch.autograd.Function):
         return gx, gw, gb, None, None, None, None
 
 
+class _ConvMultiFn(torch.autograd.Function):
+    """Several input maps of different sizes under ONE weight (the FPN levels of LSHead's shared convolutions):
+    forward, data gradients and the weight / bias gradient (summed over the maps) in one launch each.  Stride 1."""
+
+    @staticmethod
+    def forward(ctx, w, bias, cfg, *xs):
+        lib = _lib.load()
+        pad, dil, relu = cfg
+        Co, C, kh, kw = w.shape
+        w = w.contiguous(memory_format=_CL)
+        n = len(xs)
+        levels = (_lib.ConvLevel * n)()
+        outs = []
+        for i, x in enumerate(xs):
+            B, _, H, W = x.shape
+            Ho, Wo = H + 2 * pad - (dil * (kh - 1) + 1) + 1, W + 2 * pad - (dil * (kw - 1) + 1) + 1
+            out = torch.empty((B, Co, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=_CL)
+            outs.append(out)
+            L = levels[i]
+            L.x, L.out, L.B, L.H, L.W = _p(x), _p(out), B, H, W
+        ws = torch.empty(2 * w.numel(), device=w.device, dtype=torch.float32)
+        _lib.check(lib.lsn_conv2d_forward_multi(n, levels, _p(w), _p(bias), _p(ws), C, Co, kh, kw, 1, pad, dil,
+                                                1 if relu else 0, _stream()))
+        ctx.save_for_backward(w, *xs, *(outs if relu else []))
+        ctx.cfg, ctx.n, ctx.has_bias = cfg, n, bias is not None
+        return tuple(outs)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *gos):
+        lib = _lib.load()
+        pad, dil, relu = ctx.cfg
+        n = ctx.n
+        saved = ctx.saved_tensors
+        w, xs = saved[0], saved[1:1 + n]
+        outs = saved[1 + n:] if relu else None
+        Co, C, kh, kw = w.shape
+        gos = [g.contiguous(memory_format=_CL) for g in gos]
+        if relu:
+            gos = [g * (o > 0) for g, o in zip(gos, outs)]
+        need_x = [ctx.needs_input_grad[3 + i] for i in range(n)]
+        gxs = [None] * n
+        if any(need_x):
+            w8, Co8, gos8 = w, Co, gos
+            if Co % 8:
+                Co8 = (Co + 7) // 8 * 8
+                gos8 = [_pad_channels(g, Co8) for g in gos]
+                w8 = w.new_zeros((Co8, C, kh, kw)).contiguous(memory_format=_CL)
+                w8[:Co] = w
+            levels = (_lib.ConvLevel * n)()
+            for i, x in enumerate(xs):
+                gxs[i] = torch.empty_like(x, memory_format=_CL)
+                L = levels[i]
+                L.x, L.out, L.B, L.H, L.W = _p(gos8[i]), _p(gxs[i]), x.shape[0], x.shape[2], x.shape[3]
+            ws = torch.empty(2 * w8.numel(), device=w.device, dtype=torch.float32)
+            _lib.check(lib.lsn_conv2d_backward_data_multi(n, levels, _p(w8), _p(ws), C, Co8, kh, kw, 1, pad, dil, _stream()))
+            gxs = [g if need else None for g, need in zip(gxs, need_x)]
+        gw = gb = None
+        if ctx.needs_input_grad[0] or (ctx.has_bias and ctx.needs_input_grad[1]):
+            levels = (_lib.ConvLevel * n)()
+            for i, x in enumerate(xs):
+                L = levels[i]
+                L.x, L.grad_out, L.B, L.H, L.W = _p(x), _p(gos[i]), x.shape[0], x.shape[2], x.shape[3]
+            gw = torch.empty_like(w)
+            gb = torch.empty(Co, device=w.device, dtype=torch.float32) if (ctx.has_bias and ctx.needs_input_grad[1]) else None
+            _lib.check(lib.lsn_conv2d_backward_weight_multi(n, levels, _p(gw), _p(gb), C, Co, kh, kw, 1, pad, dil, _stream()))
+            if not ctx.needs_input_grad[0]:
+                gw = None
+        return (gw, gb, None, *gxs)
+
+
+def conv2d_multi(xs, weight, bias=None, padding=0, dilation=1, relu=False):
+    """[conv2d(x, weight, bias, 1, padding, dilation) for x in xs] in one launch per pass (stride 1, up to 8 maps)."""
+    return list(_ConvMultiFn.apply(weight, bias, (int(padding), int(dilation), bool(relu)), *xs))
+
+
 def hip_conv_ok(x, weight, stride, padding, dilation, groups, padding_mode='zeros'):
     """The own kernels take every dense (groups = 1) fp32 channels-last convolution on the device in the split math
     modes; exact-fp32 mode keeps the vendor library (there is no fp32-MFMA dense conv kernel)."""
@@ -145,6 +221,16 @@ class Conv2d(nn.Conv2d):
         if weight is not None:
             return self._run(x, weight)
         return self._run(x, self.weight)
+
+    def forward_multi(self, xs, relu=False):
+        """The same convolution over several maps (FPN levels) in ONE launch per pass."""
+        xs = list(xs)
+        if (1 < len(xs) <= 8 and self.stride[0] == 1 and xs[0].shape[1] % 4 == 0
+                and all(hip_conv_ok(x, self.weight, self.stride, self.padding, self.dilation, self.groups,
+                                    self.padding_mode) for x in xs)):
+            return conv2d_multi(xs, self.weight, self.bias, self.padding[0], self.dilation[0], relu)
+        outs = [self._run(x, self.weight) for x in xs]
+        return [F.relu(o) for o in outs] if relu else outs
 
     def _run(self, x, w):
         if hip_conv_ok(x, w, self.stride, self.padding, self.dilation, self.groups, self.padding_mode):

@@ -294,7 +294,7 @@ class ModulatedDeformConvPack(ModulatedDeformConv):
     def forward_multi(self, xs):
         # conv_offset's output goes to the op as ONE tensor (offsets | mask logits): no chunk / cat /
         # sigmoid kernels and a single dense gradient for conv_offset's backward
-        return dcn_multi(list(xs), [self.conv_offset(x) for x in xs], None, self.weight, self.bias,
+        return dcn_multi(list(xs), self.conv_offset.forward_multi(list(xs)), None, self.weight, self.bias,
                          self.stride, self.padding, self.dilation, self.groups, self.deformable_groups,
                          fused_om=True)
 

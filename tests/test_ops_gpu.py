@@ -458,6 +458,38 @@ def test_conv2d_matches_torch(B, C, Co, k, s, p, d, H, W, bias, split_mode):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('C,Co,k,bias,relu', [(256, 27, 3, True, False), (256, 256, 3, True, False), (768, 256, 1, True, True),
+                                              (64, 20, 1, False, False)])
+def test_conv2d_multi_level_equals_single(C, Co, k, bias, relu, split_mode):
+    """The FPN levels of a shared convolution in ONE launch each way == level-by-level calls (forward, input
+    gradients, summed weight / bias gradient), and == an fp64 evaluation."""
+    from lsnet_amd.ops.conv import Conv2d
+    torch.manual_seed(6)
+    dev = _dev()
+    tol = 3e-6 if split_mode == 'bf16x6' else 5e-5
+    m = Conv2d(C, Co, k, padding=k // 2, bias=bias).to(dev).to(memory_format=torch.channels_last)
+    xs = [torch.randn(2, C, h, w, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_()
+          for h, w in [(50, 84), (25, 42), (13, 21), (7, 11), (4, 6)]]
+    outs = m.forward_multi(xs, relu=relu)
+    gos = [torch.randn_like(o) for o in outs]
+    params = list(m.parameters())
+    g_multi = torch.autograd.grad(outs, xs + params, gos)
+    singles = [F.relu(m(x)) if relu else m(x) for x in xs]
+    g_single = torch.autograd.grad(singles, xs + params, gos)
+    for a_, b_ in zip(outs, singles):
+        assert _err(a_, b_.detach().cpu()) < 1e-6
+    for a_, b_ in zip(g_multi, g_single):
+        assert _err(a_, b_.detach().cpu()) < tol
+    xr = [x.detach().double().cpu().requires_grad_() for x in xs]
+    pr = [p_.detach().double().cpu().requires_grad_() for p_ in params]
+    yr = [F.conv2d(x, pr[0], pr[1] if bias else None, 1, k // 2) for x in xr]
+    yr = [F.relu(y) for y in yr] if relu else yr
+    gr = torch.autograd.grad(yr, xr + pr, [g.double().cpu() for g in gos])
+    for a_, b_ in zip(list(outs) + list(g_multi), yr + list(gr)):
+        assert _err(a_.double(), b_) < tol
+
+
+@pytest.mark.gpu
 def test_stem_row_merged_forward(split_mode):
     """The frozen 7x7 stride-2 stem on the 3-channel image: row-merged form (lsn_conv2d_forward_pitched)."""
     from lsnet_amd.ops.conv import Conv2d

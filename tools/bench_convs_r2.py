@@ -1,0 +1,69 @@
+"""Own conv kernels (forward / data gradient / weight gradient, current math mode) vs MIOpen on the conv shapes of the
+R-50 benchmark step (B = 2, 800x1344), per shape: where the time of the vendor-free step goes."""
+import sys, os, ctypes
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.nn.functional as F
+from lsnet_amd import _lib
+from lsnet_amd.ops.conv import conv2d
+from tools.bench_convs import SH, B
+
+dev = torch.device('cuda:0')
+mode = os.environ.get('LSNET_MATH', 'bf16x6')
+_lib.set_math_mode(mode)
+EXTRA = [('head 1x1 256->80 P3 (cls out)', 256, 80, 1, 1, 100, 168, 1), ('head 1x1 256->20 P3', 256, 20, 1, 1, 100, 168, 2),
+         ('head 3x3 256->27 P4 (offset conv)', 256, 27, 3, 1, 50, 84, 6), ('fpn P6 3x3 s2 2048->256', 2048, 256, 3, 2, 25, 42, 1),
+         ('stem 7x7 s2 3->64', 3, 64, 7, 2, 800, 1344, 1)]
+
+
+def ev_time(fn, n=10):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / n
+
+
+lib = _lib.load()
+cp = lambda t: ctypes.c_void_p(t.data_ptr())
+st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+print(f'mode {mode}; ms per call (own | MIOpen)')
+print(f'{"shape":38s} {"fwd":>15s} {"bwd-data":>15s} {"wgrad":>15s}   GFLOP  xcount')
+tot = [0.0] * 6
+for name, ci, co, k, s, h, w, cnt in SH + EXTRA:
+    pad = k // 2
+    x = torch.randn(B, ci, h, w, device=dev).contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn(co, ci, k, k, device=dev) * 0.05).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        ref = F.conv2d(x, wt, None, s, pad)
+        t_f = ev_time(lambda: conv2d(x, wt, None, s, pad))
+        t_fm = ev_time(lambda: F.conv2d(x, wt, None, s, pad))
+    fl = 2.0 * ref.numel() * ci * k * k / 1e9
+    go = torch.randn_like(ref)
+    line = f'{name:38s} {t_f:7.3f}|{t_fm:7.3f}'
+    if ci >= 8:
+        co8 = (co + 7) // 8 * 8
+        go8 = go if co8 == co else torch.cat([go, go.new_zeros(B, co8 - co, *go.shape[2:])], 1).contiguous(memory_format=torch.channels_last)
+        w8 = wt if co8 == co else torch.cat([wt, wt.new_zeros(co8 - co, ci, k, k)], 0).contiguous(memory_format=torch.channels_last)
+        ws = torch.empty(2 * w8.numel(), device=dev)
+        gx = torch.empty_like(x)
+        gw = torch.empty_like(wt)
+        t_d = ev_time(lambda: lib.lsn_conv2d_backward_data(cp(go8), cp(w8), cp(gx), cp(ws), B, h, w, ci, co8, k, k, s, pad, 1, st))
+        t_w = ev_time(lambda: lib.lsn_conv2d_backward_weight(cp(x), cp(go), cp(gw), None, B, h, w, ci, co, k, k, s, pad, 1, st))
+        t_dm = ev_time(lambda: torch.ops.aten.convolution_backward(go, x, wt, None, [s, s], [pad, pad], [1, 1], False, [0, 0], 1, [True, False, False]))
+        t_wm = ev_time(lambda: torch.ops.aten.convolution_backward(go, x, wt, None, [s, s], [pad, pad], [1, 1], False, [0, 0], 1, [False, True, False]))
+        line += f' {t_d:7.3f}|{t_dm:7.3f} {t_w:7.3f}|{t_wm:7.3f}'
+        for i, v in enumerate((t_f, t_fm, t_d, t_dm, t_w, t_wm)):
+            tot[i] += v * cnt
+    else:
+        tot[0] += t_f * cnt
+        tot[1] += t_fm * cnt
+        line += ' ' * 32
+    print(line + f' {fl:7.1f}  x{cnt}')
+print(f'network sums (ms): fwd own {tot[0]:.2f} | MIOpen {tot[1]:.2f};  bwd-data own {tot[2]:.2f} | {tot[3]:.2f};  '
+      f'wgrad own {tot[4]:.2f} | {tot[5]:.2f}')
