@@ -49,6 +49,22 @@ def pack(prefix, t, out, stride=13):
         out[f'{prefix}/{k}'] = v
 
 
+STATS = []   # (prefix, worst relative deviation, share of the sample beyond 1e-3, sample size) of every check() call
+
+
+def stats_report(kind='grad'):
+    """One line over the recorded checks whose prefix starts with `kind` (and clears them): what the tolerances of the
+    cross-platform gradient checks are set from."""
+    rows = [r for r in STATS if r[0].startswith(kind) or r[0].startswith('g')]
+    STATS.clear()
+    if not rows:
+        return 'no checks recorded'
+    worst = max(rows, key=lambda r: r[1])
+    share = max(rows, key=lambda r: r[2])
+    return (f'{len(rows)} gradient checks: worst deviation {worst[1]:.2e} of the range ({worst[0]}); largest share beyond '
+            f'1e-3: {100 * share[2]:.2f}% of {share[3]} samples ({share[0]})')
+
+
 def check(prefix, t, ref, rtol=1e-3, stride=13, max_outlier_frac=0.0):
     """Assert `t` matches the fingerprint stored under `prefix` in the npz `ref`.
 
@@ -65,6 +81,7 @@ def check(prefix, t, ref, rtol=1e-3, stride=13, max_outlier_frac=0.0):
     scale = max(float(np.abs(want).max()), 1e-12)
     rel = np.abs(s['sample'] - want) / scale
     frac_bad = float((rel > rtol).mean())
+    STATS.append((prefix, float(rel.max()), float((rel > 1e-3).mean()), len(want)))
     if max_outlier_frac > 0:   # a budget of k % of a 5-element sample (a bias gradient) must still admit one flip
         max_outlier_frac = max(max_outlier_frac, 1.0 / len(want))
     assert frac_bad <= max_outlier_frac, (f'{prefix}: {100 * frac_bad:.2f}% of the sampled elements are off by more '

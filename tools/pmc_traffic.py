@@ -1,0 +1,67 @@
+"""rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/step_shapes.py -> HBM bytes per launch of each deformable-conv
+kernel family of the benchmark step, written as JSON for bench.py (profiles/r2_hbm_traffic.json).
+
+step_shapes.py replays (tower launch, pyramid launch) pairs, so the dispatches of every kernel alternate tower, pyramid,
+tower, ...; a step has 6 tower and 2 pyramid launches of each family: mean launch = (6 tower + 2 pyramid) / 8.
+Units and corrections (MI355X_MICROARCH.md, HBM section): rocprofv3 reports both counters in KiB; on gfx950 FETCH_SIZE
+tallies the 128-byte requests of wide coalesced reads at 64 bytes, so it is DOUBLED; WRITE_SIZE is taken as reported."""
+import csv, glob, json, sys
+from collections import defaultdict
+
+fetch_dir, write_dir, out_json = sys.argv[1:4]
+math = sys.argv[4] if len(sys.argv) > 4 else 'bf16x6'
+FAMILY = [('dcn_fwd_', 'dcn_fwd'), ('dcn_prepare_w_kernel', 'dcn_fwd'), ('dcn_wgrad_', 'dcn_wgrad'),
+          ('dcn_bwd_data', 'dcn_bwd_data'), ('dcn_gather', 'dcn_bwd_data'), ('dcn_bin', 'dcn_bwd_data'),
+          ('dcn_fill', 'dcn_bwd_data'), ('dcn_sort_lists', 'dcn_bwd_data'), ('dcn_prepare_wt', 'dcn_bwd_data'),
+          ('rocprim', 'dcn_bwd_data')]
+
+
+def family(name):
+    for frag, fam in FAMILY:
+        if frag in name:
+            return fam
+    return None
+
+
+def read(d, counter):
+    per = defaultdict(list)
+    for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r['Counter_Name'] == counter:
+                per[r['Kernel_Name']].append((int(r['Dispatch_Id']), float(r['Counter_Value'])))
+    return {k: [v for _, v in sorted(rows)] for k, rows in per.items()}
+
+
+fetch, write = read(fetch_dir, 'FETCH_SIZE'), read(write_dir, 'WRITE_SIZE')
+if not fetch or not write:
+    print('missing counter data', len(fetch), len(write))
+    sys.exit(1)
+KIB = 1024 / 1e9
+fam = defaultdict(lambda: {'tower': [0.0, 0.0], 'pyramid': [0.0, 0.0]})
+print(f'{"kernel":64s} {"n":>3s} | tower: FETCHx2 + WRITE (MB) | pyramid: FETCHx2 + WRITE (MB)')
+for name in sorted(set(fetch) | set(write)):
+    f, w = fetch.get(name, []), write.get(name, [])
+    n = max(len(f), len(w))
+    half = lambda v, odd: (sum(v[odd::2]) / max(len(v[odd::2]), 1)) if v else 0.0
+    ft, fp, wt, wp = 2 * half(f, 0), 2 * half(f, 1), half(w, 0), half(w, 1)
+    print(f'{name[:64]:64s} {n:3d} | {ft * KIB * 1e3:9.1f} + {wt * KIB * 1e3:9.1f} | {fp * KIB * 1e3:9.1f} + {wp * KIB * 1e3:9.1f}')
+    fa = family(name)
+    if fa:
+        fam[fa]['tower'][0] += ft * KIB
+        fam[fa]['tower'][1] += wt * KIB
+        fam[fa]['pyramid'][0] += fp * KIB
+        fam[fa]['pyramid'][1] += wp * KIB
+res = {'math': math, 'source': 'tools/pmc_step_shapes.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over '
+                               'tools/step_shapes.py; FETCH_SIZE x 2 (gfx950), KiB -> bytes', 'kernels': {}}
+for fa, d in fam.items():
+    t, p = sum(d['tower']), sum(d['pyramid'])
+    mean = (6 * t + 2 * p) / 8
+    res['kernels'][fa] = {
+        'gbytes_per_mean_launch': round(mean, 4), 'tower_launch_gb': round(t, 4), 'pyramid_launch_gb': round(p, 4),
+        'tower_fetch_write_gb': [round(v, 4) for v in d['tower']], 'pyramid_fetch_write_gb': [round(v, 4) for v in d['pyramid']],
+        'note': f'rocprofv3 FETCH_SIZE x2 + WRITE_SIZE over all kernels of the family; tower launch (5 levels, 52.8 GFLOP) '
+                f'{t:.3f} GB, pyramid launch (15 pairs, 158.5 GFLOP) {p:.3f} GB, step mean (6 tower + 2 pyramid) / 8; '
+                f'profiles/r2_pmc_hbm.txt'}
+    print(f'{fa}: tower {t:.3f} GB (fetch {d["tower"][0]:.3f} + write {d["tower"][1]:.3f}), pyramid {p:.3f} GB '
+          f'(fetch {d["pyramid"][0]:.3f} + write {d["pyramid"][1]:.3f}); mean launch of the step {mean:.3f} GB')
+json.dump(res, open(out_json, 'w'), indent=1)
