@@ -436,9 +436,9 @@ static void gather_plan(DcnArgs &a, GatherPlan &pl)
             gi = ga.ng++;
             GatherGrp &G = ga.g[gi];
             G.gx = L.gx, G.B = L.B, G.H = L.H, G.W = L.W;
-            G.abase = (int)anchors, G.q0 = (int)Q;
+            G.abase = (int)anchors, G.blk0 = (int)Q;
             anchors += (int64_t)L.B * (L.H + 1) * (L.W + 1);
-            Q += (int64_t)L.B * L.H * L.W;
+            Q += (int64_t)L.B * cdiv(L.H, GT) * cdiv(L.W, GT);
         } else if (ga.g[gi].B != L.B || ga.g[gi].H != L.H || ga.g[gi].W != L.W) {
             return;   // one buffer, two shapes: not a valid call for this path
         }
@@ -449,7 +449,7 @@ static void gather_plan(DcnArgs &a, GatherPlan &pl)
     if (a.C % 4 != 0 || (a.C / a.dg) % 4 != 0) return;
     pl.nsamples = (int)(prow * KD);
     pl.nanchors = (int)anchors;
-    ga.Q = (int)Q;
+    ga.NB = (int)Q;
     ga.C = a.C, ga.K = K, ga.KD = KD, ga.dg = a.dg;
     size_t tmp = 0;
     if (rocprim::exclusive_scan((void *)nullptr, tmp, (int *)nullptr, (int *)nullptr, 0, (size_t)pl.nanchors + 1,
@@ -499,7 +499,7 @@ static int launch_bwd_colbuf(DcnArgs &a, GatherPlan &pl, unsigned char *ws, hipS
     if (int rc = set_lds(dcn_bwd_data_xn_kernel<NP, true>, lds)) return rc;
     hipLaunchKernelGGL((dcn_bwd_data_xn_kernel<NP, true>), dim3(a.ntiles), dim3(256), lds, st, a);
     pl.ga.gcol = a.gcol, pl.ga.start = start, pl.ga.ent = ent;
-    hipLaunchKernelGGL(dcn_gather_kernel, dim3(cdiv(pl.ga.Q, 4)), dim3(256), 0, st, pl.ga);
+    hipLaunchKernelGGL(dcn_gather_kernel, dim3(cdiv(pl.ga.NB, 4)), dim3(256), 0, st, pl.ga);
     LSN_HIP(hipGetLastError());
     return 0;
 }

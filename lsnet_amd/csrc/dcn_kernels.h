@@ -1340,6 +1340,94 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_xn_kernel(const DcnArgs a
     float sy[4] = {0.f, 0.f, 0.f, 0.f}, sx[4] = {0.f, 0.f, 0.f, 0.f}, sm[4] = {0.f, 0.f, 0.f, 0.f};
     // operand reads: row j16 (channel cl = j16) and row 16 + j16, source slot 4 s + kq -> LDS slot (4 s + kq) ^ j16
     const unsigned char *b0 = Bp + j16 * ROW, *b1 = Bp + (16 + j16) * ROW;
+    const int trow = (wave * 16 + kq * 4) * KD;   // tap-table row of this lane's first pixel
+
+    // The corner values of the input that grad_offset / grad_mask need (4 pixels x 4 corners of one channel) are
+    // loaded a phase ahead of their use: half-slab 0 before the MFMA block, half-slab 1 before half-slab 0 is
+    // consumed -- a dependent L2 round trip per half-slab was 2/3 of the epilogue (tools/phase_clocks.py bwd1).
+    auto issue_xv = [&](const Chunk &ch, int tn, float (&xv)[4][4]) {
+        const int cl = tn * 16 + j16;
+        const int c = ch.c0 + (cl < ch.nval ? cl : 0);
+        const int kd = ch.dgi * K + ch.k;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int4 idx = *reinterpret_cast<const int4 *>(&tab[trow + r * KD + kd]);
+            xv[r][0] = L.x[idx.x + c];
+            xv[r][1] = L.x[idx.y + c];
+            xv[r][2] = L.x[idx.z + c];
+            xv[r][3] = L.x[idx.w + c];
+        }
+    };
+    // consume gcol[16 px][16 ch] of half-slab tn: D row = 4*kq + r (x-adjacent pixels), col = tn*16 + j16
+    auto consume = [&](const Chunk &ch, int tn, const f32x4 &acc, const float (&xv)[4][4]) {
+        const int kd = ch.dgi * K + ch.k;
+        const int cl = tn * 16 + j16;
+        const bool cval = cl < ch.nval;
+        const int c = ch.c0 + (cval ? cl : 0);
+        Tap tp[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tp[r] = tab[trow + r * KD + kd];
+        float gm[4], w00[4], w01[4], w10[4], w11[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float gval = cval ? acc[r] : 0.f;
+            corner_weights(tp[r], w00[r], w01[r], w10[r], w11[r]);
+            gm[r] = gval * tp[r].m;
+            if (want_off) {
+                const float hy = 1.f - tp[r].ly, hx = 1.f - tp[r].lx;
+                const float v00 = (tp[r].flags & 1) ? xv[r][0] : 0.f;
+                const float v01 = (tp[r].flags & 2) ? xv[r][1] : 0.f;
+                const float v10 = (tp[r].flags & 4) ? xv[r][2] : 0.f;
+                const float v11 = (tp[r].flags & 8) ? xv[r][3] : 0.f;
+                const float dy = hx * (v10 - v00) + tp[r].lx * (v11 - v01);
+                const float dx = hy * (v01 - v00) + tp[r].ly * (v11 - v10);
+                const float bil = hy * hx * v00 + hy * tp[r].lx * v01 + tp[r].ly * hx * v10 + tp[r].ly * tp[r].lx * v11;
+                sy[r] += gm[r] * dy;
+                sx[r] += gm[r] * dx;
+                sm[r] += gval * bil;
+            }
+        }
+        if (COLBUF) {
+            if (want_gx && cval) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (tp[r].flags != 0) {   // samples outside the map are in no list
+                        const size_t row = (size_t)(L.prow0 + tile_p + wave * 16 + kq * 4 + r) * K + ch.k;
+                        a.gcol[row * C + c] = gm[r];
+                    }
+            }
+        } else if (want_gx && cval) {
+            // merged scatter, one image row of corners at a time: walk the 4 pixels left to right with a pending
+            // (address, value); a corner equal to the pending address is summed into it, anything else flushes.
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                int pa = -1;
+                float pv = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int aL = half ? tp[r].i10 : tp[r].i00, aR = half ? tp[r].i11 : tp[r].i01;
+                    const float vL = (half ? w10[r] : w00[r]) * gm[r], vR = (half ? w11[r] : w01[r]) * gm[r];
+                    const bool live = tp[r].flags != 0;   // wholly invalid samples carry index 0: never touch it
+                    if (live && aL == pa) {
+                        pv += vL;
+                    } else {
+                        if (pa >= 0 && pv != 0.f) atomic_add_f32(L.gx + pa + c, pv);
+                        pa = live ? aL : -1;
+                        pv = vL;
+                    }
+                    if (live && aR == pa) {
+                        pv += vR;
+                    } else {
+                        if (pa >= 0 && pv != 0.f) atomic_add_f32(L.gx + pa + c, pv);
+                        pa = live ? aR : -1;
+                        pv = vR;
+                    }
+                }
+                if (pa >= 0 && pv != 0.f) atomic_add_f32(L.gx + pa + c, pv);
+            }
+        }
+    };
+
     for (int t = 0; t < T; ++t) {
         const Chunk ch = decode_chunk<BK>(a, 0, t, segs, ncc);
         const Chunk chn = decode_chunk<BK>(a, 0, min(t + 1, T - 1), segs, ncc);
@@ -1347,7 +1435,10 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_xn_kernel(const DcnArgs a
         LSN_STAMP(2);
         __syncthreads();   // every wave's slab loads have landed (the barrier's fence waits for this wave's vmcnt)
         LSN_STAMP(4);
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, lo0 = {0.f, 0.f, 0.f, 0.f}, lo1 = {0.f, 0.f, 0.f, 0.f};
+        float xv0[4][4], xv1[4][4];
+        if (want_off) issue_xv(ch, 0, xv0);
+        // K = 256 here: one accumulator per tile (the two-level accumulation of the forward kernels pays from K ~ 1000)
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const int so = (((s << 2) | kq) ^ j16) << 4;
@@ -1357,107 +1448,26 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_xn_kernel(const DcnArgs a
                 w0[q] = *reinterpret_cast<const bf16x8 *>(b0 + q * PLANE + so);
                 w1[q] = *reinterpret_cast<const bf16x8 *>(b1 + q * PLANE + so);
             }
-            acc0 = mfma16_bf16(af[s][0], w0[0], acc0);
-            acc1 = mfma16_bf16(af[s][0], w1[0], acc1);
 #pragma unroll
-            for (int prod = 1; prod < NP; ++prod) {
-                lo0 = mfma16_bf16(af[s][SC::pa(prod)], w0[SC::pb(prod)], lo0);
-                lo1 = mfma16_bf16(af[s][SC::pa(prod)], w1[SC::pb(prod)], lo1);
+            for (int prod = NP - 1; prod >= 0; --prod) {   // small terms first
+                acc0 = mfma16_bf16(af[s][SC::pa(prod)], w0[SC::pb(prod)], acc0);
+                acc1 = mfma16_bf16(af[s][SC::pa(prod)], w1[SC::pb(prod)], acc1);
             }
         }
-        float g0[4], g1[4];   // scalar adds: a vector-typed add would be lowered to v_pk_add_f32 (build.py note)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) g0[r] = acc0[r] + lo0[r], g1[r] = acc1[r] + lo1[r];
         LSN_STAMP(5);
         __syncthreads();   // slab consumed by every wave: the next one may land
         if (t + 1 < T) issue_w(chn);
-
-        // ---- consume gcol[16 px][32 ch] of this wave: D row = 4*kq + r (x-adjacent pixels), col = tn*16 + j16 ----
-        const int kd = ch.dgi * K + ch.k;
-#pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-            const int cl = tn * 16 + j16;
-            const bool cval = cl < ch.nval;
-            const int c = ch.c0 + (cval ? cl : 0);
-            Tap tp[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) tp[r] = tab[(wave * 16 + kq * 4 + r) * KD + kd];
-            float xv[4][4];
-            if (want_off) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    xv[r][0] = L.x[tp[r].i00 + c];
-                    xv[r][1] = L.x[tp[r].i01 + c];
-                    xv[r][2] = L.x[tp[r].i10 + c];
-                    xv[r][3] = L.x[tp[r].i11 + c];
-                }
-            }
-            float gm[4], w00[4], w01[4], w10[4], w11[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float gval = cval ? (tn == 0 ? g0[r] : g1[r]) : 0.f;
-                corner_weights(tp[r], w00[r], w01[r], w10[r], w11[r]);
-                gm[r] = gval * tp[r].m;
-                if (want_off) {
-                    const float hy = 1.f - tp[r].ly, hx = 1.f - tp[r].lx;
-                    const float v00 = (tp[r].flags & 1) ? xv[r][0] : 0.f;
-                    const float v01 = (tp[r].flags & 2) ? xv[r][1] : 0.f;
-                    const float v10 = (tp[r].flags & 4) ? xv[r][2] : 0.f;
-                    const float v11 = (tp[r].flags & 8) ? xv[r][3] : 0.f;
-                    const float dy = hx * (v10 - v00) + tp[r].lx * (v11 - v01);
-                    const float dx = hy * (v01 - v00) + tp[r].ly * (v11 - v10);
-                    const float bil = hy * hx * v00 + hy * tp[r].lx * v01 + tp[r].ly * hx * v10 + tp[r].ly * tp[r].lx * v11;
-                    sy[r] += gm[r] * dy;
-                    sx[r] += gm[r] * dx;
-                    sm[r] += gval * bil;
-                }
-            }
-            if (COLBUF) {
-                if (want_gx && cval) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (tp[r].flags != 0) {   // samples outside the map are in no list
-                            const size_t row = (size_t)(L.prow0 + tile_p + wave * 16 + kq * 4 + r) * K + ch.k;
-                            a.gcol[row * C + c] = gm[r];
-                        }
-                }
-            } else if (want_gx && cval) {
-                // merged scatter, one image row of corners at a time: walk the 4 pixels left to right with a pending
-                // (address, value); a corner equal to the pending address is summed into it, anything else flushes.
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    int pa = -1;
-                    float pv = 0.f;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int aL = half ? tp[r].i10 : tp[r].i00, aR = half ? tp[r].i11 : tp[r].i01;
-                        const float vL = (half ? w10[r] : w00[r]) * gm[r], vR = (half ? w11[r] : w01[r]) * gm[r];
-                        const bool live = tp[r].flags != 0;   // wholly invalid samples carry index 0: never touch it
-                        if (live && aL == pa) {
-                            pv += vL;
-                        } else {
-                            if (pa >= 0 && pv != 0.f) atomic_add_f32(L.gx + pa + c, pv);
-                            pa = live ? aL : -1;
-                            pv = vL;
-                        }
-                        if (live && aR == pa) {
-                            pv += vR;
-                        } else {
-                            if (pa >= 0 && pv != 0.f) atomic_add_f32(L.gx + pa + c, pv);
-                            pa = live ? aR : -1;
-                            pv = vR;
-                        }
-                    }
-                    if (pa >= 0 && pv != 0.f) atomic_add_f32(L.gx + pa + c, pv);
-                }
-            }
-        }
+        if (want_off) issue_xv(ch, 1, xv1);
+        LSN_STAMP(3);
+        consume(ch, 0, acc0, xv0);
+        consume(ch, 1, acc1, xv1);
         if (want_off && (tap_done || ((a.dbg_block >> 21) & 1))) {   // bit 21: reduce after every chunk (diagnostic)
+            const int kd = ch.dgi * K + ch.k;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float vy = row16_sum(sy[r]), vx = row16_sum(sx[r]), vm = row16_sum(sm[r]);
                 if (j16 == 0) {
-                    float *ga = gacc + ((wave * 16 + kq * 4 + r) * KD + kd) * 3;
+                    float *ga = gacc + (trow + r * KD + kd) * 3;
                     ga[0] += vy;
                     ga[1] += vx;
                     ga[2] += vm;
@@ -1519,11 +1529,11 @@ struct GatherGrp {
     float *gx;
     int B, H, W;
     int abase;   // first anchor id: anchors (B, H+1, W+1), (y0+1, x0+1) row-major
-    int q0;      // first input pixel of this group in the launch-wide numbering
+    int blk0;    // first 4x4 pixel block of this group in the launch-wide numbering
 };
 struct GatherArgs {
     GatherGrp g[MAXLV];
-    int ng, Q;          // groups, total input pixels
+    int ng, NB;         // groups, total 4x4 pixel blocks
     int C, K, KD, dg;
     const float *gcol;
     const int *start;   // [anchors + 1]
@@ -1623,55 +1633,91 @@ __global__ __launch_bounds__(256) void dcn_sort_lists_kernel(int nanchors, const
     }
 }
 
-// one wave per input pixel (4 pixels per workgroup pass); lane = 4 consecutive channels
+// One wave per 4x4 block of input pixels; lane = 4 consecutive channels (256 channels per pass).  The 5x5 anchors around
+// the block are walked once each: an entry's column-gradient row (C contiguous floats) is loaded ONCE and added, with
+// its four bilinear corner weights, to the pixels of the block it touches -- 25 lists for 16 pixels instead of the 64 a
+// pixel-by-pixel gather reads (measured before: the gather fetched 3.7 x the column-gradient buffer from the fabric).
+// Fixed order: anchors row-major, entries by sample id.
+constexpr int GT = 4;   // block edge
+constexpr int GU = 4;   // column-gradient rows a wave keeps in flight
 __global__ __launch_bounds__(256) void dcn_gather_kernel(const GatherArgs ga)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int C = ga.C, K = ga.K, KD = ga.KD;
     const int cpdg = C / ga.dg;
-    const int nq = gridDim.x * 4;
-    for (int qi = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave; qi < ga.Q; qi += nq) {
-        int gi = 0;
-        while (gi + 1 < ga.ng && qi >= ga.g[gi + 1].q0) ++gi;
-        const GatherGrp &G = ga.g[gi];
-        const int q = qi - G.q0;
-        const int HW = G.H * G.W;
-        const int b = q / HW, rem = q - b * HW;
-        const int y = rem / G.W, x = rem - y * G.W;
-        for (int cb = 0; cb < C; cb += 256) {
-            const int c = cb + lane * 4;
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int bi = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
+    if (bi >= ga.NB) return;
+    int gi = 0;
+    while (gi + 1 < ga.ng && bi >= ga.g[gi + 1].blk0) ++gi;
+    const GatherGrp &G = ga.g[gi];
+    const int nbx = (G.W + GT - 1) / GT, nby = (G.H + GT - 1) / GT;
+    const int lb_ = bi - G.blk0;
+    const int b = lb_ / (nbx * nby), rem = lb_ - b * nbx * nby;
+    const int y0 = (rem / nbx) * GT, x0 = (rem % nbx) * GT;
+    for (int cb = 0; cb < C; cb += 256) {
+        const int c = cb + lane * 4;
+        float4 acc[GT][GT];
 #pragma unroll
-            for (int corner = 0; corner < 4; ++corner) {
-                const int dy = corner >> 1, dx = corner & 1;
-                const int an = G.abase + (b * (G.H + 1) + y - dy + 1) * (G.W + 1) + x - dx + 1;
+        for (int i = 0; i < GT; ++i)
+#pragma unroll
+            for (int j = 0; j < GT; ++j) acc[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int ai = 0; ai <= GT; ++ai)
+#pragma unroll
+            for (int aj = 0; aj <= GT; ++aj) {
+                const int ay = y0 - 1 + ai, ax = x0 - 1 + aj;   // anchor = floor of the sample position, >= -1
+                if (ay > G.H - 1 || ax > G.W - 1) continue;     // (wave-uniform)
+                const int an = G.abase + (b * (G.H + 1) + ay + 1) * (G.W + 1) + ax + 1;
                 const int lb = __builtin_amdgcn_readfirstlane(ga.start[an]);
                 const int le = __builtin_amdgcn_readfirstlane(ga.start[an + 1]);
                 for (int base = lb; base < le; base += 64) {
                     const int n = min(64, le - base);
                     GEntry e = {};
                     if (lane < n) e = ga.ent[base + lane];
-                    for (int j = 0; j < n; ++j) {
-                        const int s = __builtin_amdgcn_readlane(e.s, j);
-                        const float ly = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e.ly), j));
-                        const float lx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e.lx), j));
-                        const float wy = dy ? ly : 1.f - ly, wx = dx ? lx : 1.f - lx;
-                        const float w = wy * wx;
-                        int row = s, c_lo = 0, c_hi = C;
-                        if (ga.dg > 1) {
-                            const int prow = s / KD, kd = s - prow * KD;
-                            const int dgi = kd / K;
-                            row = prow * K + (kd - dgi * K);
-                            c_lo = dgi * cpdg, c_hi = c_lo + cpdg;
+                    for (int j0 = 0; j0 < n; j0 += GU) {   // GU rows in flight per wave
+                        float4 v[GU];
+                        float ly[GU], lx[GU];
+#pragma unroll
+                        for (int u = 0; u < GU; ++u) {
+                            const int j = min(j0 + u, n - 1);
+                            const int s = __builtin_amdgcn_readlane(e.s, j);
+                            ly[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e.ly), j));
+                            lx[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e.lx), j));
+                            int row = s, c_lo = 0, c_hi = C;
+                            if (ga.dg > 1) {
+                                const int prow = s / KD, kd = s - prow * KD;
+                                const int dgi = kd / K;
+                                row = prow * K + (kd - dgi * K);
+                                c_lo = dgi * cpdg, c_hi = c_lo + cpdg;
+                            }
+                            const bool on = (j0 + u < n) && c < c_hi && c >= c_lo;
+                            v[u] = *reinterpret_cast<const float4 *>(ga.gcol + (size_t)row * C + (c < C ? c : 0));
+                            if (!on) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                         }
-                        if (c < c_hi && c >= c_lo) {
-                            const float4 v = *reinterpret_cast<const float4 *>(ga.gcol + (size_t)row * C + c);
-                            acc.x += w * v.x, acc.y += w * v.y, acc.z += w * v.z, acc.w += w * v.w;
+#pragma unroll
+                        for (int u = 0; u < GU; ++u) {
+                            const float hy = 1.f - ly[u], hx = 1.f - lx[u];
+#pragma unroll
+                            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                                for (int dx = 0; dx < 2; ++dx) {
+                                    const int pi = ai - 1 + dy, pj = aj - 1 + dx;   // compile-time after unrolling
+                                    if (pi < 0 || pi >= GT || pj < 0 || pj >= GT) continue;
+                                    const float w = (dy ? ly[u] : hy) * (dx ? lx[u] : hx);
+                                    acc[pi][pj].x += w * v[u].x, acc[pi][pj].y += w * v[u].y;
+                                    acc[pi][pj].z += w * v[u].z, acc[pi][pj].w += w * v[u].w;
+                                }
                         }
                     }
                 }
             }
-            if (c < C) *reinterpret_cast<float4 *>(G.gx + (size_t)q * C + c) = acc;
+        if (c < C) {
+#pragma unroll
+            for (int i = 0; i < GT; ++i)
+#pragma unroll
+                for (int j = 0; j < GT; ++j)
+                    if (y0 + i < G.H && x0 + j < G.W)
+                        *reinterpret_cast<float4 *>(G.gx + ((size_t)(b * G.H + y0 + i) * G.W + x0 + j) * C + c) = acc[i][j];
         }
     }
 }
