@@ -236,6 +236,10 @@ static int fill_levels(DcnArgs &a, const lsn_dcn_shape &s, int n, const lsn_dcn_
     const int Cg = s.C / s.groups, cpdg = s.C / s.deformable_groups;
     a.SL = Cg < cpdg ? Cg : cpdg;
     a.msig = s.mask_is_logit ? 1 : 0;
+    a.gcol = nullptr;
+    a.gtap = nullptr;
+    a.gtap_rows = 0;
+    a.wg_vec = 0;
     a.dbg = g_dbg_buf;
     a.dbg_block = g_dbg_block;
     a.w = a.bias = nullptr;
@@ -347,6 +351,10 @@ static bool bwd_x3_ok(const DcnArgs &a)
     if (a.Co > 256 || a.Co % 8 != 0 || a.C % 4 != 0) return false;
     if ((int64_t)a.kh * a.kw * a.C * a.Co * 6 >= ((int64_t)1 << 31)) return false;
     if (bwd_xn_lds_bytes(math_np(), a.kh * a.kw * a.dg) > 80 * 1024) return false;
+    for (int i = 0; i < a.nlv; ++i) {   // 32-bit buffer offsets into the input and the level's column-gradient rows
+        if ((int64_t)a.lv[i].B * a.lv[i].H * a.lv[i].W * a.C * 4 >= ((int64_t)1 << 31)) return false;
+        if ((int64_t)a.lv[i].P * a.kh * a.kw * a.C * 4 >= ((int64_t)1 << 31)) return false;
+    }
     return true;
 }
 
@@ -407,7 +415,7 @@ struct GatherPlan {
     bool ok = false;
     int nsamples = 0, nanchors = 0;
     size_t scan_tmp = 0;
-    size_t o_gcol = 0, o_cnt = 0, o_start = 0, o_anchor = 0, o_rank = 0, o_frac = 0, o_ent = 0, o_tmp = 0, bytes = 0;
+    size_t o_gcol = 0, o_cnt = 0, o_start = 0, o_anchor = 0, o_rank = 0, o_frac = 0, o_ent = 0, o_tmp = 0, o_gtap = 0, bytes = 0;
     GatherArgs ga;
 };
 
@@ -465,6 +473,7 @@ static void gather_plan(DcnArgs &a, GatherPlan &pl)
     pl.o_frac = o, o = align256(o + (size_t)pl.nsamples * sizeof(float2));
     pl.o_ent = o, o = align256(o + (size_t)pl.nsamples * sizeof(GEntry));
     pl.o_tmp = o, o = align256(o + tmp + 256);
+    pl.o_gtap = o, o = align256(o + ((size_t)pl.nsamples + 1) * sizeof(Tap));   // + the all-zero entry
     pl.bytes = o;
     pl.ok = true;
 }
@@ -484,9 +493,12 @@ static int launch_bwd_colbuf(DcnArgs &a, GatherPlan &pl, unsigned char *ws, hipS
     int *sanchor = reinterpret_cast<int *>(ws + pl.o_anchor), *srank = reinterpret_cast<int *>(ws + pl.o_rank);
     float2 *sfrac = reinterpret_cast<float2 *>(ws + pl.o_frac);
     GEntry *ent = reinterpret_cast<GEntry *>(ws + pl.o_ent);
+    Tap *gtap = reinterpret_cast<Tap *>(ws + pl.o_gtap);   // also read by the GEMM below and by the weight-gradient pass
+    a.gtap_rows = pl.nsamples / (a.kh * a.kw * a.dg);
     LSN_HIP(hipMemsetAsync(cnt, 0, ((size_t)pl.nanchors + 1) * sizeof(int), st));
     hipLaunchKernelGGL(dcn_bin_kernel, dim3(cdiv(pl.nsamples, 256)), dim3(256), 0, st, a, pl.nsamples, cnt, sanchor,
-                       srank, sfrac);
+                       srank, sfrac, gtap);
+    a.gtap = gtap;
     size_t tmp = pl.scan_tmp;
     LSN_HIP(rocprim::exclusive_scan(ws + pl.o_tmp, tmp, cnt, start, 0, (size_t)pl.nanchors + 1, rocprim::plus<int>(), st));
     hipLaunchKernelGGL(dcn_fill_kernel, dim3(cdiv(pl.nsamples, 256)), dim3(256), 0, st, pl.nsamples, start, sanchor,
@@ -516,7 +528,7 @@ static int launch_bwd_data(DcnArgs &a, void *gather_ws, size_t gather_ws_bytes, 
             return np == 6 ? launch_bwd_colbuf<6>(a, pl, reinterpret_cast<unsigned char *>(gather_ws), st)
                            : launch_bwd_colbuf<3>(a, pl, reinterpret_cast<unsigned char *>(gather_ws), st);
     }
-    a.gcol = nullptr;
+    a.gcol = nullptr, a.gtap = nullptr;
     for (int i = 0; i < a.nlv; ++i)   // the scatter kernels accumulate: start from zero (once per buffer is enough)
         if (a.lv[i].gx)
             LSN_HIP(hipMemsetAsync(a.lv[i].gx, 0, sizeof(float) * (size_t)a.lv[i].B * a.lv[i].H * a.lv[i].W * a.C, st));
@@ -535,8 +547,23 @@ static int launch_bwd_data(DcnArgs &a, void *gather_ws, size_t gather_ws_bytes, 
     return (a.Co / a.groups > 64) ? launch_bwd_data_t<256>(a, st) : launch_bwd_data_t<64>(a, st);
 }
 
-static int launch_wgrad(const DcnArgs &a, int nsteps, hipStream_t st)
+// 8-byte buffer loads in the split weight-gradient kernel: even channel counts, 8-byte aligned tensors, byte offsets < 2^31
+static int wgrad_vec_bits(const DcnArgs &a)
 {
+    bool vx = a.C % 2 == 0, vg = a.Co % 2 == 0;
+    for (int i = 0; i < a.nlv; ++i) {
+        const Lvl &L = a.lv[i];
+        vx = vx && (reinterpret_cast<uintptr_t>(L.x) & 7) == 0 && (long long)L.B * L.H * L.W * a.C < (1ll << 29);
+        vg = vg && (reinterpret_cast<uintptr_t>(L.gout) & 7) == 0 && (long long)(L.P + WG_BP) * a.Co < (1ll << 29);
+    }
+    return (vx ? 1 : 0) | (vg ? 2 : 0);
+}
+
+static int launch_wgrad(const DcnArgs &a_in, int nsteps, hipStream_t st)
+{
+    DcnArgs a = a_in;
+    a.wg_vec = wgrad_vec_bits(a);
+    if ((reinterpret_cast<uintptr_t>(a.gtap) & 15) != 0) a.gtap = nullptr;
     const int K = a.kh * a.kw, Cg = a.C / a.groups, Cog = a.Co / a.groups;
     const int segs = Cg / a.SL, ncc = cdiv(a.SL, WG_BN);
     const int ncol = a.groups * K * segs * ncc, nz = cdiv(Cog, WG_BM);
@@ -805,6 +832,7 @@ static int conv_wgrad_xn(int n, const lsn_conv_level *lv, float *gw, float *gb, 
     a.C = C, a.Co = Co, a.kh = kh, a.kw = kw, a.stride = stride, a.pad = pad, a.dil = dil, a.groups = 1, a.dg = 1;
     a.SL = C;
     a.gw = gw, a.gb = gb;
+    a.wg_vec = wgrad_vec_bits(a);
     const int K = kh * kw;
     LSN_HIP(hipMemsetAsync(gw, 0, sizeof(float) * (size_t)Co * K * C, st));
     if (gb) LSN_HIP(hipMemsetAsync(gb, 0, sizeof(float) * (size_t)Co, st));

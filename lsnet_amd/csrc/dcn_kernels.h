@@ -17,6 +17,7 @@
 // so tiles are kept small enough to balance 700..1400 tiles over 256 CUs and the gather/stage
 // work of chunk t+1 is issued before the MFMA phase of chunk t.
 #pragma once
+#include <type_traits>
 #include "common.h"
 
 namespace lsn {
@@ -46,6 +47,10 @@ struct DcnArgs {
     int msig; // mask tensor holds logits: apply sigmoid on read, chain it into grad_mask
     const unsigned short *wtp;   // pre-split bf16 weight planes (forward: [Co][K][Cg]; backward-data: [K][C][Co])
     float *gcol;   // backward-data: mask-weighted column gradients [(prow0 + pix) * K + k][C] for the gather pass
+    const struct Tap *gtap;   // backward: sampling table of every (pixel, tap) of the launch, k-major:
+    int wg_vec;               // weight gradient: tensors admit 8-byte buffer loads (bit 0: input, bit 1: grad_output)
+    int gtap_rows;            // [kd * gtap_rows + prow0 + pix], gtap_rows = pixel rows of all levels (written once by
+                              // dcn_bin_kernel; the backward kernels copy instead of recomputing)
     long long *dbg;  // optional phase timestamps of block `dbg_block`, wave 0 (lsn_debug_phase_clocks)
     int dbg_block;
 };
@@ -76,31 +81,44 @@ __device__ __forceinline__ const Lvl &find_level(const DcnArgs &a, int tile)
 // Sample position exactly as the oracle / reference compute it:
 //   py = float(ho*stride - pad + i*dil) * scale_h + dy     (kernel.cu:227-228, 281-282, 892-893)
 // yx (optional): clamped corner rows / columns {cy0, cx0, cy1, cx1} of a sample with flags != 0
-__device__ __forceinline__ Tap make_tap_ex(const DcnArgs &a, const Lvl &L, int pix, int k, int dgi, int4 *yx)
+// The memory reads of a tap (offset pair, modulation scalar) and the arithmetic on them are separate steps so that a
+// kernel can issue the loads a phase ahead of the table entry it builds from them.
+struct TapRaw {
+    float oy, ox, m;
+};
+__device__ __forceinline__ TapRaw tap_raw(const DcnArgs &a, const Lvl &L, int pix, int k, int dgi)
+{
+    TapRaw r = {0.f, 0.f, 1.f};   // L.off == NULL: a dense convolution (the regular grid)
+    if (pix >= L.P) return r;
+    const int K = a.kh * a.kw;
+    const int HWo = L.Ho * L.Wo;
+    const int b = pix / HWo;
+    const int rem = pix - b * HWo;
+    const int ho = rem / L.Wo, wo = rem - ho * L.Wo;
+    if (L.off) {
+        const float *op = L.off + (size_t)b * L.osb + (size_t)ho * L.osh + (size_t)wo * L.osw;
+        r.oy = op[(size_t)(dgi * 2 * K + 2 * k) * L.osc];
+        r.ox = op[(size_t)(dgi * 2 * K + 2 * k + 1) * L.osc];
+    }
+    if (L.msk) r.m = L.msk[(size_t)b * L.msb + (size_t)(dgi * K + k) * L.msc + (size_t)ho * L.msh + (size_t)wo * L.msw];
+    return r;
+}
+__device__ __forceinline__ Tap tap_finish(const DcnArgs &a, const Lvl &L, int pix, int k, const TapRaw &raw, int4 *yx)
 {
     Tap t;
     t.i00 = t.i01 = t.i10 = t.i11 = 0;
     t.ly = t.lx = t.m = 0.f;
     t.flags = 0;
     if (pix >= L.P) return t;
-    const int K = a.kh * a.kw;
     const int HWo = L.Ho * L.Wo;
     const int b = pix / HWo;
     const int rem = pix - b * HWo;
     const int ho = rem / L.Wo, wo = rem - ho * L.Wo;
     const int i = k / a.kw, j = k - i * a.kw;
-    float oy = 0.f, ox = 0.f;   // L.off == NULL: a dense convolution (the regular grid)
-    if (L.off) {
-        const float *op = L.off + (size_t)b * L.osb + (size_t)ho * L.osh + (size_t)wo * L.osw;
-        oy = op[(size_t)(dgi * 2 * K + 2 * k) * L.osc];
-        ox = op[(size_t)(dgi * 2 * K + 2 * k + 1) * L.osc];
-    }
-    float m = L.msk ? L.msk[(size_t)b * L.msb + (size_t)(dgi * K + k) * L.msc + (size_t)ho * L.msh +
-                            (size_t)wo * L.msw]
-                    : 1.f;
+    float m = raw.m;
     if (a.msig && L.msk) m = 1.f / (1.f + expf(-m));
-    const float py = __fadd_rn(__fmul_rn((float)(ho * a.stride - a.pad + i * a.dil), L.sh), oy);
-    const float px = __fadd_rn(__fmul_rn((float)(wo * a.stride - a.pad + j * a.dil), L.sw), ox);
+    const float py = __fadd_rn(__fmul_rn((float)(ho * a.stride - a.pad + i * a.dil), L.sh), raw.oy);
+    const float px = __fadd_rn(__fmul_rn((float)(wo * a.stride - a.pad + j * a.dil), L.sw), raw.ox);
     if (py > -1.f && px > -1.f && py < (float)L.H && px < (float)L.W) {
         const float fy = floorf(py), fx = floorf(px);
         const int y0 = (int)fy, x0 = (int)fx, y1 = y0 + 1, x1 = x0 + 1;
@@ -119,6 +137,10 @@ __device__ __forceinline__ Tap make_tap_ex(const DcnArgs &a, const Lvl &L, int p
         if (yx) *yx = make_int4(cy0, cx0, cy1, cx1);
     }
     return t;
+}
+__device__ __forceinline__ Tap make_tap_ex(const DcnArgs &a, const Lvl &L, int pix, int k, int dgi, int4 *yx)
+{
+    return tap_finish(a, L, pix, k, tap_raw(a, L, pix, k, dgi), yx);
 }
 
 __device__ __forceinline__ Tap make_tap(const DcnArgs &a, const Lvl &L, int pix, int k, int dgi)
@@ -1274,10 +1296,21 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_xn_kernel(const DcnArgs a
     const Lvl &L = find_level(a, tile);
     const int tile_p = (tile - L.tile0) * BWD_BM;
 
-    for (int e = tid; e < BWD_BM * KD; e += 256) {
-        const int pl = e / KD, r = e - pl * KD;
-        const int dgi = r / K, k = r - dgi * K;
-        tab[e] = make_tap(a, L, tile_p + pl, k, dgi);
+    if (COLBUF && a.gtap != nullptr) {   // the launch-wide table of dcn_bin_kernel (k-major): per tap, 64 entries in a row
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.gtap + (size_t)(L.prow0 + tile_p));   // 16-byte halves
+        const int nvalid = min(BWD_BM, L.P - tile_p);   // tile rows past the level end stay zero = no sample
+        for (int e = tid; e < BWD_BM * KD * 2; e += 256) {
+            const int ent = e >> 1, kd = ent / BWD_BM, pl = ent - kd * BWD_BM;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (pl < nvalid) v = src[((size_t)kd * a.gtap_rows + pl) * 2 + (e & 1)];
+            reinterpret_cast<uint4 *>(tab)[(pl * KD + kd) * 2 + (e & 1)] = v;
+        }
+    } else {
+        for (int e = tid; e < BWD_BM * KD; e += 256) {
+            const int pl = e / KD, r = e - pl * KD;
+            const int dgi = r / K, k = r - dgi * K;
+            tab[e] = make_tap(a, L, tile_p + pl, k, dgi);
+        }
     }
     for (int e = tid; e < BWD_BM * KD * 3; e += 256) gacc[e] = 0.f;
 
@@ -1336,67 +1369,76 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_xn_kernel(const DcnArgs a
 
     __syncthreads();
     int dbg_n = 0;
-    issue_w(decode_chunk<BK>(a, 0, 0, segs, ncc));
-    float sy[4] = {0.f, 0.f, 0.f, 0.f}, sx[4] = {0.f, 0.f, 0.f, 0.f}, sm[4] = {0.f, 0.f, 0.f, 0.f};
+    ChunkIter<BK> it(a, 0, segs, ncc, T);
+    Chunk ch = it.get();
+    issue_w(ch);
     // operand reads: row j16 (channel cl = j16) and row 16 + j16, source slot 4 s + kq -> LDS slot (4 s + kq) ^ j16
     const unsigned char *b0 = Bp + j16 * ROW, *b1 = Bp + (16 + j16) * ROW;
     const int trow = (wave * 16 + kq * 4) * KD;   // tap-table row of this lane's first pixel
+    const __amdgpu_buffer_rsrc_t xrs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(L.x), 0, L.B * L.H * L.W * C * 4, 0x00020000);
+    // column gradients of this level: rows (pix * K + k) of C floats; rows of pixels past the level end fall outside
+    // num_records and are dropped by the hardware
+    const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(
+        COLBUF && a.gcol ? a.gcol + (size_t)L.prow0 * K * C : const_cast<float *>(L.x), 0,
+        COLBUF && want_gx ? L.P * K * C * 4 : 0, 0x00020000);
+    const int grow0 = (tile_p + wave * 16 + kq * 4) * K * C * 4;   // byte offset of this lane's first pixel, tap 0
 
-    // The corner values of the input that grad_offset / grad_mask need (4 pixels x 4 corners of one channel) are
-    // loaded a phase ahead of their use: half-slab 0 before the MFMA block, half-slab 1 before half-slab 0 is
-    // consumed -- a dependent L2 round trip per half-slab was 2/3 of the epilogue (tools/phase_clocks.py bwd1).
-    auto issue_xv = [&](const Chunk &ch, int tn, float (&xv)[4][4]) {
+    // grad_offset / grad_mask of a sample are bilinear forms of the four dot products
+    //     H_corner = sum over channels of gcol[c] * x[corner, c]
+    // so only these are accumulated per channel (4 fmas; carried over the slabs of a tap in registers); the corner
+    // validity, the fractions and the modulation scalar are applied once per (pixel, tap) after the 16 channel lanes
+    // have been summed.  Invalid corners are loaded from their clamped (valid) addresses and get weight 0 there.
+    // The corner values are loaded a phase ahead of their use: half-slab 0 before the MFMA block, half-slab 1 before
+    // half-slab 0 is consumed (a dependent L2 round trip per half-slab was most of the epilogue).
+    float H[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) H[r][0] = H[r][1] = H[r][2] = H[r][3] = 0.f;
+    auto issue_xv = [&](const Chunk &c_, int tn, float (&xv)[4][4]) {
         const int cl = tn * 16 + j16;
-        const int c = ch.c0 + (cl < ch.nval ? cl : 0);
-        const int kd = ch.dgi * K + ch.k;
+        const int cb = (c_.c0 + (cl < c_.nval ? cl : 0)) * 4;
+        const int kd = c_.dgi * K + c_.k;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int4 idx = *reinterpret_cast<const int4 *>(&tab[trow + r * KD + kd]);
-            xv[r][0] = L.x[idx.x + c];
-            xv[r][1] = L.x[idx.y + c];
-            xv[r][2] = L.x[idx.z + c];
-            xv[r][3] = L.x[idx.w + c];
+            xv[r][0] = buf_load_f32(xrs, idx.x * 4 + cb, 0);
+            xv[r][1] = buf_load_f32(xrs, idx.y * 4 + cb, 0);
+            xv[r][2] = buf_load_f32(xrs, idx.z * 4 + cb, 0);
+            xv[r][3] = buf_load_f32(xrs, idx.w * 4 + cb, 0);
         }
     };
     // consume gcol[16 px][16 ch] of half-slab tn: D row = 4*kq + r (x-adjacent pixels), col = tn*16 + j16
-    auto consume = [&](const Chunk &ch, int tn, const f32x4 &acc, const float (&xv)[4][4]) {
-        const int kd = ch.dgi * K + ch.k;
+    auto consume = [&](const Chunk &c_, int tn, const f32x4 &acc, const float (&xv)[4][4]) {
+        const int kd = c_.dgi * K + c_.k;
         const int cl = tn * 16 + j16;
-        const bool cval = cl < ch.nval;
-        const int c = ch.c0 + (cval ? cl : 0);
-        Tap tp[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) tp[r] = tab[trow + r * KD + kd];
-        float gm[4], w00[4], w01[4], w10[4], w11[4];
+        const bool cval = cl < c_.nval;
+        const int c = c_.c0 + (cval ? cl : 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float gval = cval ? acc[r] : 0.f;
-            corner_weights(tp[r], w00[r], w01[r], w10[r], w11[r]);
-            gm[r] = gval * tp[r].m;
             if (want_off) {
-                const float hy = 1.f - tp[r].ly, hx = 1.f - tp[r].lx;
-                const float v00 = (tp[r].flags & 1) ? xv[r][0] : 0.f;
-                const float v01 = (tp[r].flags & 2) ? xv[r][1] : 0.f;
-                const float v10 = (tp[r].flags & 4) ? xv[r][2] : 0.f;
-                const float v11 = (tp[r].flags & 8) ? xv[r][3] : 0.f;
-                const float dy = hx * (v10 - v00) + tp[r].lx * (v11 - v01);
-                const float dx = hy * (v01 - v00) + tp[r].ly * (v11 - v10);
-                const float bil = hy * hx * v00 + hy * tp[r].lx * v01 + tp[r].ly * hx * v10 + tp[r].ly * tp[r].lx * v11;
-                sy[r] += gm[r] * dy;
-                sx[r] += gm[r] * dx;
-                sm[r] += gval * bil;
+                H[r][0] += gval * xv[r][0];
+                H[r][1] += gval * xv[r][1];
+                H[r][2] += gval * xv[r][2];
+                H[r][3] += gval * xv[r][3];
+            }
+            if (COLBUF) {
+                if (want_gx && cval) {
+                    const float m = tab[trow + r * KD + kd].m;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gval * m), grs,
+                                                          grow0 + (r * K + c_.k) * C * 4 + c * 4, 0, 0);
+                }
             }
         }
-        if (COLBUF) {
-            if (want_gx && cval) {
+        if (!COLBUF && want_gx && cval) {
+            Tap tp[4];
+            float gm[4], w00[4], w01[4], w10[4], w11[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (tp[r].flags != 0) {   // samples outside the map are in no list
-                        const size_t row = (size_t)(L.prow0 + tile_p + wave * 16 + kq * 4 + r) * K + ch.k;
-                        a.gcol[row * C + c] = gm[r];
-                    }
+            for (int r = 0; r < 4; ++r) {
+                tp[r] = tab[trow + r * KD + kd];
+                corner_weights(tp[r], w00[r], w01[r], w10[r], w11[r]);
+                gm[r] = acc[r] * tp[r].m;
             }
-        } else if (want_gx && cval) {
             // merged scatter, one image row of corners at a time: walk the 4 pixels left to right with a pending
             // (address, value); a corner equal to the pending address is summed into it, anything else flushes.
 #pragma unroll
@@ -1429,8 +1471,8 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_xn_kernel(const DcnArgs a
     };
 
     for (int t = 0; t < T; ++t) {
-        const Chunk ch = decode_chunk<BK>(a, 0, t, segs, ncc);
-        const Chunk chn = decode_chunk<BK>(a, 0, min(t + 1, T - 1), segs, ncc);
+        it.next();
+        const Chunk chn = it.get();   // chunk t + 1 (saturates at the last one)
         const bool tap_done = (t + 1 == T) || chn.k != ch.k || chn.dgi != ch.dgi;
         LSN_STAMP(2);
         __syncthreads();   // every wave's slab loads have landed (the barrier's fence waits for this wave's vmcnt)
@@ -1461,20 +1503,30 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_xn_kernel(const DcnArgs a
         LSN_STAMP(3);
         consume(ch, 0, acc0, xv0);
         consume(ch, 1, acc1, xv1);
-        if (want_off && (tap_done || ((a.dbg_block >> 21) & 1))) {   // bit 21: reduce after every chunk (diagnostic)
+        if (want_off && tap_done) {
             const int kd = ch.dgi * K + ch.k;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float vy = row16_sum(sy[r]), vx = row16_sum(sx[r]), vm = row16_sum(sm[r]);
+                const float h00 = row16_sum(H[r][0]), h01 = row16_sum(H[r][1]), h10 = row16_sum(H[r][2]),
+                            h11 = row16_sum(H[r][3]);
+                H[r][0] = H[r][1] = H[r][2] = H[r][3] = 0.f;
                 if (j16 == 0) {
+                    const Tap tp = tab[trow + r * KD + kd];
+                    const float hy = 1.f - tp.ly, hx = 1.f - tp.lx;
+                    const float v00 = (tp.flags & 1) ? h00 : 0.f, v01 = (tp.flags & 2) ? h01 : 0.f;
+                    const float v10 = (tp.flags & 4) ? h10 : 0.f, v11 = (tp.flags & 8) ? h11 : 0.f;
+                    // coordinate weights, kernel.cu:145-188 / 800-845, applied to the channel sums
+                    const float dy = hx * (v10 - v00) + tp.lx * (v11 - v01);
+                    const float dx = hy * (v01 - v00) + tp.ly * (v11 - v10);
+                    const float bil = hy * hx * v00 + hy * tp.lx * v01 + tp.ly * hx * v10 + tp.ly * tp.lx * v11;
                     float *ga = gacc + (trow + r * KD + kd) * 3;
-                    ga[0] += vy;
-                    ga[1] += vx;
-                    ga[2] += vm;
+                    ga[0] += tp.m * dy;
+                    ga[1] += tp.m * dx;
+                    ga[2] += bil;
                 }
-                sy[r] = sx[r] = sm[r] = 0.f;
             }
         }
+        ch = chn;
         LSN_STAMP(6);
     }
     __syncthreads();
@@ -1549,7 +1601,7 @@ __device__ __forceinline__ const Lvl &find_level_by_row(const DcnArgs &a, int pr
 
 // one thread per sample: anchor, rank inside the anchor's list, fractions
 __global__ void dcn_bin_kernel(const DcnArgs a, int nsamples, int *__restrict__ cnt, int *__restrict__ sanchor,
-                               int *__restrict__ srank, float2 *__restrict__ sfrac)
+                               int *__restrict__ srank, float2 *__restrict__ sfrac, Tap *__restrict__ gtap)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nsamples) return;
@@ -1559,17 +1611,20 @@ __global__ void dcn_bin_kernel(const DcnArgs a, int nsamples, int *__restrict__ 
     const Lvl &L = find_level_by_row(a, prow);
     int anchor = -1, rank = 0;
     float2 fr = make_float2(0.f, 0.f);
-    if (L.gx != nullptr) {
-        int4 yx = make_int4(0, 0, 0, 0);
-        const Tap t = make_tap_ex(a, L, prow - L.prow0, k, dgi, &yx);
-        if (t.flags) {
-            const int y0 = (t.flags & 3) ? yx.x : -1, x0 = (t.flags & 5) ? yx.y : -1;   // unclamped floor(py), floor(px)
-            const int HWo = L.Ho * L.Wo;
-            const int b = (prow - L.prow0) / HWo;
-            anchor = L.abase + (b * (L.H + 1) + y0 + 1) * (L.W + 1) + x0 + 1;
-            rank = atomicAdd(&cnt[anchor], 1);
-            fr = make_float2(t.ly, t.lx);
-        }
+    int4 yx = make_int4(0, 0, 0, 0);
+    const Tap t = make_tap_ex(a, L, prow - L.prow0, k, dgi, &yx);
+    gtap[(size_t)kd * a.gtap_rows + prow] = t;   // k-major: a 32-pixel step of one tap is 1 KB contiguous
+    if (s == 0) {
+        Tap z = {};
+        gtap[(size_t)KD * a.gtap_rows] = z;   // the "no sample" entry behind the table
+    }
+    if (L.gx != nullptr && t.flags) {
+        const int y0 = (t.flags & 3) ? yx.x : -1, x0 = (t.flags & 5) ? yx.y : -1;   // unclamped floor(py), floor(px)
+        const int HWo = L.Ho * L.Wo;
+        const int b = (prow - L.prow0) / HWo;
+        anchor = L.abase + (b * (L.H + 1) + y0 + 1) * (L.W + 1) + x0 + 1;
+        rank = atomicAdd(&cnt[anchor], 1);
+        fr = make_float2(t.ly, t.lx);
     }
     sanchor[s] = anchor;
     srank[s] = rank;
@@ -2562,7 +2617,7 @@ __global__ __launch_bounds__(256, 2) void dcn_wgrad_kernel(const DcnArgs a, int 
 template <int NP, int BMW = WG_BM>
 __host__ __device__ inline size_t wgrad_xn_lds_bytes()
 {
-    return (size_t)SplitCfg<NP>::NPL * (BMW + WG_BN) * 80 + 2 * WG_BP * sizeof(Tap);
+    return (size_t)SplitCfg<NP>::NPL * (BMW + WG_BN) * 80 + 3 * WG_BP * sizeof(Tap);
 }
 
 // BMW: output channels per block.  256 (four waves x 64 co x 64 columns) for the wide layers; 64 (four waves x 32 x 32)
@@ -2576,7 +2631,7 @@ __global__ __launch_bounds__(256, 2) void dcn_wgrad_xn_kernel(const DcnArgs a, i
     using SC = SplitCfg<NP>;
     constexpr int NPL = SC::NPL;
     constexpr int RS = 80, PLANE_A = BMW * RS, PLANE_B = WG_BN * RS;
-    extern __shared__ __align__(16) unsigned char smem[];   // [A planes][B planes][tab 2 x 32]
+    extern __shared__ __align__(16) unsigned char smem[];   // [A planes][B planes][tab 3 x 32]
     Tap *tab = reinterpret_cast<Tap *>(smem + NPL * PLANE_A + NPL * PLANE_B);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -2599,16 +2654,30 @@ __global__ __launch_bounds__(256, 2) void dcn_wgrad_xn_kernel(const DcnArgs a, i
     const int st_begin = (int)((long long)nsteps * bsplit / nsplit);
     const int st_end = (int)((long long)nsteps * (bsplit + 1) / nsplit);
 
-    const int kk = tid & 63, pg = tid >> 6;   // gathered columns: channel lane, 8-pixel group
-    const bool cval = kk < ch.nval;
-    const int c = g * Cg + ch.c0 + (cval ? kk : 0);
-    const bool gval = tid < nco;               // gout: this thread's output channel
+    // gathered columns: a thread owns two adjacent channels (one 8-byte load per corner) of a 4-pixel group
+    const int kp = tid & 31, pg = tid >> 5;
+    const bool cval0 = 2 * kp < ch.nval, cval1 = 2 * kp + 1 < ch.nval;
+    const int cbase = g * Cg + ch.c0;
+    // gout: a thread owns two adjacent output channels (one 8-byte load per pixel) and one half of the step's pixels
+    constexpr int CP = BMW / 2;
+    const int gcp = tid % CP, gph = tid / CP;   // co pair, pixel half; threads >= 2 CP (BMW = 64: waves 1..3) idle here
+    const bool gact = tid < 2 * CP;
+    const bool gval0 = gact && 2 * gcp < nco, gval1 = gact && 2 * gcp + 1 < nco;
     const bool do_bias = (a.gb != nullptr) && ch.k == 0 && ch.c0 == 0;
+    const int kd = ch.dgi * K + ch.k;
+
+    // 8-byte buffer loads need even channel counts and bases, 8-byte aligned tensors and byte offsets below 2^31
+    // (tensor alignment and sizes: checked by the host, a.wg_vec bit 0 = input, bit 1 = grad_output)
+    bool vx = (a.wg_vec & 1) && (cbase & 1) == 0, vg = (a.wg_vec & 2) && (co_base & 1) == 0;
+    if ((a.dbg_block >> 25) & 1) vx = vg = false;   // diagnostic: scalar loads
+    // the backward-data pass of the same call left the sampling table of every (pixel, tap) in a.gtap (k-major)
+    const bool use_gtap = !PLAIN && vx && vg && a.gtap != nullptr && !((a.dbg_block >> 24) & 1);
 
     constexpr int NX = PLAIN ? 1 : 4;
-    float xv[8][NX];
-    float gv[WG_BP];
-    float bias_acc = 0.f;
+    float xv0[4][NX], xv1[4][NX];
+    float gv0[WG_BP / 2], gv1[WG_BP / 2];
+    float bias_acc0 = 0.f, bias_acc1 = 0.f;
+    int npx_s = 0;   // scalar gout path: valid pixels of this thread's half in the step whose values sit in gv0 / gv1
 
     f32x16 acc[TI][TI];
 #pragma unroll
@@ -2618,113 +2687,237 @@ __global__ __launch_bounds__(256, 2) void dcn_wgrad_xn_kernel(const DcnArgs a, i
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    auto build_tab = [&](int st, int buf) {
-        if (tid < WG_BP) {
-            const Lvl &L = find_level(a, st);
-            tab[buf * WG_BP + tid] = make_tap(a, L, (st - L.tile0) * WG_BP + tid, ch.k, ch.dgi);
-        }
+    // computed table entry of pixel `tid` of step st (no launch-wide table)
+    auto tap_of = [&](int st) __attribute__((always_inline)) -> Tap {
+        const Lvl &L = find_level(a, st);
+        return make_tap(a, L, (st - L.tile0) * WG_BP + tid, ch.k, ch.dgi);
     };
-    auto load_step = [&](int st, int buf) {
+    // launch-wide table: the step's 32 entries are 1 KB contiguous; lane l of wave 0 moves 16-byte half (l & 1) of
+    // entry (l >> 1).  Pixels past the level's end take the all-zero entry behind the table ("no sample") -- by
+    // address, not by a select on the loaded value, which would make the wave wait for the load where it is issued.
+    auto gtap_load = [&](int st) __attribute__((always_inline)) -> uint4 {
+        const Lvl &L = find_level(a, st);
+        const int pix = (st - L.tile0) * WG_BP + (lane >> 1);
+        const size_t ent = pix < L.P ? (size_t)kd * a.gtap_rows + L.prow0 + pix : (size_t)K * a.dg * a.gtap_rows;
+        return reinterpret_cast<const uint4 *>(a.gtap)[ent * 2 + (lane & 1)];
+    };
+    auto gtap_put = [&](int slot, uint4 v) __attribute__((always_inline)) { reinterpret_cast<uint4 *>(tab + slot * WG_BP)[lane] = v; };
+
+    // issue the global loads of step st (table slot buf); VX / VG: 8-byte buffer loads, out-of-range rows read as 0
+    auto load_step = [&](int st, int buf, auto vx_, auto vg_) __attribute__((always_inline)) {
+        constexpr bool VX = decltype(vx_)::value, VG = decltype(vg_)::value;
         const Lvl &L = find_level(a, st);
         const int p0 = (st - L.tile0) * WG_BP;
+        if constexpr (VX) {
+            const __amdgpu_buffer_rsrc_t xrs =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(L.x), 0, L.B * L.H * L.W * a.C * 4, 0x00020000);
+            const int c4 = (cbase + 2 * kp) * 4;   // (columns past nval hold other channels' values: never written back)
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const Tap *tp = &tab[buf * WG_BP + pg * 8 + q];
-            if (PLAIN) {
-                xv[q][0] = L.x[tp->i00 + c];
-            } else {
-                const int4 idx = *reinterpret_cast<const int4 *>(tp);
-                xv[q][0] = L.x[idx.x + c];
-                xv[q][1] = L.x[idx.y + c];
-                xv[q][2] = L.x[idx.z + c];
-                xv[q][3] = L.x[idx.w + c];
+            for (int q = 0; q < 4; ++q) {
+                const Tap *tp = &tab[buf * WG_BP + pg * 4 + q];
+                int idx[4];
+                if (PLAIN) {
+                    idx[0] = tp->i00;
+                } else {
+                    const int4 i4 = *reinterpret_cast<const int4 *>(tp);
+                    idx[0] = i4.x, idx[1] = i4.y, idx[2] = i4.z, idx[3] = i4.w;
+                }
+#pragma unroll
+                for (int e = 0; e < NX; ++e) {
+                    const float2 v = buf_load_f32x2(xrs, idx[e] * 4 + c4, 0);
+                    xv0[q][e] = v.x, xv1[q][e] = v.y;
+                }
+            }
+        } else {
+            const int c = cbase + (cval0 ? 2 * kp : 0), c1 = cval1 ? 1 : 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const Tap *tp = &tab[buf * WG_BP + pg * 4 + q];
+                int idx[4];
+                if (PLAIN) {
+                    idx[0] = tp->i00;
+                } else {
+                    const int4 i4 = *reinterpret_cast<const int4 *>(tp);
+                    idx[0] = i4.x, idx[1] = i4.y, idx[2] = i4.z, idx[3] = i4.w;
+                }
+#pragma unroll
+                for (int e = 0; e < NX; ++e) {
+                    const float *xp = L.x + idx[e] + c;
+                    xv0[q][e] = xp[0], xv1[q][e] = xp[c1];
+                }
             }
         }
-        if (BMW == 256 || tid < BMW) {   // (wave-uniform: BMW = 64 is the first wave)
-            const float *gp = L.gout + (size_t)p0 * a.Co + co_base + (gval ? tid : 0);
-            const int npx = L.P - p0;   // valid pixels of this step (>= 1)
+        if (gact) {   // (wave-uniform: BMW = 64 is the first wave)
+            const int pbase = gph * (WG_BP / 2);
+            if constexpr (VG) {
+                const __amdgpu_buffer_rsrc_t grs =
+                    __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(L.gout), 0, L.P * a.Co * 4, 0x00020000);
+                const int v0 = ((p0 + pbase) * a.Co + co_base + 2 * gcp) * 4, rowb = a.Co * 4;
 #pragma unroll
-            for (int px = 0; px < WG_BP; ++px) gv[px] = gp[(size_t)(px < npx ? px : 0) * a.Co];
+                for (int px = 0; px < WG_BP / 2; ++px) {
+                    const float2 v = buf_load_f32x2(grs, v0 + px * rowb, 0);
+                    gv0[px] = v.x, gv1[px] = v.y;
+                }
+            } else {
+                const int npx = L.P - p0 - pbase;   // valid pixels of this half (may be <= 0); masked when staged
+                npx_s = npx;
+                const float *gp = L.gout + (size_t)p0 * a.Co + co_base + (gval0 ? 2 * gcp : 0);
+                const int g1 = gval1 ? 1 : 0;
 #pragma unroll
-            for (int px = 0; px < WG_BP; ++px) gv[px] = (gval && px < npx) ? gv[px] : 0.f;
+                for (int px = 0; px < WG_BP / 2; ++px) {
+                    const float *q = gp + (size_t)(px < npx ? pbase + px : 0) * a.Co;
+                    gv0[px] = q[0], gv1[px] = q[g1];
+                }
+            }
         }
     };
-    auto store_step = [&](int buf) {
-        // gathered columns: 8 pixels of channel kk -> one 16-byte piece of row kk in each plane
-        unsigned cp[4][NPL];
+    // split the values loaded by load_step into bf16 planes and write the two LDS operand images
+    auto store_step = [&](int buf, auto vx_, auto vg_) __attribute__((always_inline)) {
+        constexpr bool VX = decltype(vx_)::value, VG = decltype(vg_)::value;
+        // gathered columns: 4 pixels of channels 2 kp, 2 kp + 1 -> one 8-byte piece of rows 2 kp (+1) in each plane
+        float v0[4], v1[4];
 #pragma unroll
-        for (int q2 = 0; q2 < 4; ++q2) {
-            float v[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int q = q2 * 2 + h;
-                const Tap tp = tab[buf * WG_BP + pg * 8 + q];
-                if (PLAIN) {
-                    v[h] = (tp.flags & 1) ? xv[q][0] : 0.f;
-                } else {
-                    float b00, b01, b10, b11;
-                    corner_weights(tp, b00, b01, b10, b11);
-                    v[h] = (b00 * xv[q][0] + b01 * xv[q][1] + b10 * xv[q][2] + b11 * xv[q][3]) * tp.m;
-                }
-                v[h] = cval ? v[h] : 0.f;
+        for (int q = 0; q < 4; ++q) {
+            const Tap tp = tab[buf * WG_BP + pg * 4 + q];
+            if (PLAIN) {
+                v0[q] = (tp.flags & 1) ? xv0[q][0] : 0.f;
+                v1[q] = (tp.flags & 1) ? xv1[q][0] : 0.f;
+            } else {
+                float b00, b01, b10, b11;
+                corner_weights(tp, b00, b01, b10, b11);
+                v0[q] = (b00 * xv0[q][0] + b01 * xv0[q][1] + b10 * xv0[q][2] + b11 * xv0[q][3]) * tp.m;
+                v1[q] = (b00 * xv1[q][0] + b01 * xv1[q][1] + b10 * xv1[q][2] + b11 * xv1[q][3]) * tp.m;
             }
-            split_planes<NPL>(v[0], v[1], cp[q2]);
+            if (!VX) {
+                v0[q] = cval0 ? v0[q] : 0.f;
+                v1[q] = cval1 ? v1[q] : 0.f;
+            }
         }
-        unsigned char *bp = smem + NPL * PLANE_A + kk * RS + pg * 16;
 #pragma unroll
-        for (int q = 0; q < NPL; ++q)
-            *reinterpret_cast<uint4 *>(bp + q * PLANE_B) = make_uint4(cp[0][q], cp[1][q], cp[2][q], cp[3][q]);
-        // gout: 32 pixels of output channel tid -> row tid (64 bytes) in each plane
-        if (tid < BMW)
+        for (int e2 = 0; e2 < 2; ++e2) {
+            unsigned cp[2][NPL];
+            split_planes<NPL>(e2 ? v1[0] : v0[0], e2 ? v1[1] : v0[1], cp[0]);
+            split_planes<NPL>(e2 ? v1[2] : v0[2], e2 ? v1[3] : v0[3], cp[1]);
+            unsigned char *bp = smem + NPL * PLANE_A + (2 * kp + e2) * RS + pg * 8;
 #pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-            unsigned gp4[4][NPL];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) split_planes<NPL>(gv[q4 * 8 + 2 * e], gv[q4 * 8 + 2 * e + 1], gp4[e]);
-            unsigned char *ap = smem + tid * RS + q4 * 16;
-#pragma unroll
-            for (int q = 0; q < NPL; ++q)
-                *reinterpret_cast<uint4 *>(ap + q * PLANE_A) = make_uint4(gp4[0][q], gp4[1][q], gp4[2][q], gp4[3][q]);
+            for (int q = 0; q < NPL; ++q) *reinterpret_cast<uint2 *>(bp + q * PLANE_B) = make_uint2(cp[0][q], cp[1][q]);
         }
-        if (do_bias) {
+        // gout: 16 pixels of output channels 2 gcp, 2 gcp + 1 -> two 16-byte pieces of rows 2 gcp (+1) in each plane.
+        // (VG: pixels past the level's end were read as 0; rows past nco hold other values but are never written back)
+        if (gact) {
+            if (!VG) {
 #pragma unroll
-            for (int px = 0; px < WG_BP; ++px) bias_acc += gv[px];
+                for (int px = 0; px < WG_BP / 2; ++px) {
+                    gv0[px] = (gval0 && px < npx_s) ? gv0[px] : 0.f;
+                    gv1[px] = (gval1 && px < npx_s) ? gv1[px] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int e2 = 0; e2 < 2; ++e2)
+#pragma unroll
+                for (int piece = 0; piece < 2; ++piece) {
+                    unsigned gp4[4][NPL];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float w0 = e2 ? gv1[piece * 8 + 2 * e] : gv0[piece * 8 + 2 * e];
+                        const float w1 = e2 ? gv1[piece * 8 + 2 * e + 1] : gv0[piece * 8 + 2 * e + 1];
+                        split_planes<NPL>(w0, w1, gp4[e]);
+                    }
+                    unsigned char *ap = smem + (2 * gcp + e2) * RS + gph * 32 + piece * 16;
+#pragma unroll
+                    for (int q = 0; q < NPL; ++q)
+                        *reinterpret_cast<uint4 *>(ap + q * PLANE_A) = make_uint4(gp4[0][q], gp4[1][q], gp4[2][q], gp4[3][q]);
+                }
+            if (do_bias) {
+#pragma unroll
+                for (int px = 0; px < WG_BP / 2; ++px) bias_acc0 += gv0[px], bias_acc1 += gv1[px];
+            }
         }
     };
 
+    int dbg_n = 0;
+    // Tap-table slots rotate over three steps: slot (i % 3) holds step st_begin + i.  Iteration st stages step st,
+    // issues the loads of step st + 1 (indices from slot st + 1) and, after its MFMA block, fills slot st + 2:
+    //   GT  (launch-wide table): wave 0 writes the 1 KB it loaded one iteration earlier and issues the load for
+    //       step st + 3 -- a full iteration of slack for an HBM miss, four registers;
+    //   !GT (computed): the entry's offset / mask loads are issued before the MFMA block and finished after it.
+    // (GT: the table load is issued by every wave, unconditionally and always as the YOUNGEST load in flight, also in
+    // the prologue: only then can the compiler count on it and let the staging code wait with vmcnt(1) instead of 0.)
+#define LSN_WG_RUN(VXT, VGT, GTB)                                                                                     \
+    do {                                                                                                              \
+        uint4 tq = make_uint4(0u, 0u, 0u, 0u);                                                                        \
+        if constexpr (GTB) {                                                                                          \
+            if (wave == 0) {                                                                                          \
+                gtap_put(0, gtap_load(st_begin));                                                                     \
+                if (st_begin + 1 < st_end) gtap_put(1, gtap_load(st_begin + 1));                                      \
+            }                                                                                                         \
+        } else {                                                                                                      \
+            if (tid < WG_BP) {                                                                                        \
+                tab[tid] = tap_of(st_begin);                                                                          \
+                if (st_begin + 1 < st_end) tab[WG_BP + tid] = tap_of(st_begin + 1);                                   \
+            }                                                                                                         \
+        }                                                                                                             \
+        __syncthreads();                                                                                              \
+        load_step(st_begin, 0, VXT{}, VGT{});                                                                         \
+        if constexpr (GTB) tq = gtap_load(min(st_begin + 2, st_end - 1));                                             \
+        for (int st = st_begin; st < st_end; ++st) {                                                                  \
+            const int slot = (st - st_begin) % 3, slot1 = (slot + 1) % 3, slot2 = (slot + 2) % 3;                     \
+            LSN_STAMP(2);                                                                                             \
+            store_step(slot, VXT{}, VGT{});                                                                           \
+            LSN_STAMP(3);                                                                                             \
+            __syncthreads();                                                                                          \
+            LSN_STAMP(4);                                                                                             \
+            const bool build2 = !(GTB) && st + 2 < st_end && tid < WG_BP;                                             \
+            Tap t2 = {};                                                                                              \
+            if (build2) t2 = tap_of(st + 2);                                                                          \
+            if (st + 1 < st_end) load_step(st + 1, slot1, VXT{}, VGT{});                                              \
+            LSN_STAMP(5);                                                                                             \
+            const unsigned char *ap = smem + (row0 + (lane & 31)) * RS + (lane >> 5) * 16;                            \
+            const unsigned char *bp = smem + NPL * PLANE_A + (col0 + (lane & 31)) * RS + (lane >> 5) * 16;            \
+_Pragma("unroll")                                                                                                     \
+            for (int ks = 0; ks < 2; ++ks) {                                                                          \
+                bf16x8 Af[TI][NPL], Bf[TI][NPL];                                                                      \
+_Pragma("unroll")                                                                                                     \
+                for (int i = 0; i < TI; ++i)                                                                          \
+_Pragma("unroll")                                                                                                     \
+                    for (int q = 0; q < NPL; ++q) {                                                                   \
+                        Af[i][q] = *reinterpret_cast<const bf16x8 *>(ap + q * PLANE_A + i * 32 * RS + ks * 32);       \
+                        Bf[i][q] = *reinterpret_cast<const bf16x8 *>(bp + q * PLANE_B + i * 32 * RS + ks * 32);       \
+                    }                                                                                                 \
+_Pragma("unroll")                                                                                                     \
+                for (int prod = 0; prod < NP; ++prod)                                                                 \
+_Pragma("unroll")                                                                                                     \
+                    for (int i = 0; i < TI; ++i)                                                                      \
+_Pragma("unroll")                                                                                                     \
+                        for (int j = 0; j < TI; ++j)                                                                  \
+                            acc[i][j] = mfma_bf16(Af[i][SC::pa(prod)], Bf[j][SC::pb(prod)], acc[i][j]);               \
+            }                                                                                                         \
+            LSN_STAMP(6);                                                                                             \
+            if constexpr (GTB) {                                                                                      \
+                if (wave == 0 && st + 2 < st_end) gtap_put(slot2, tq);                                                \
+                tq = gtap_load(min(st + 3, st_end - 1));                                                              \
+            } else {                                                                                                  \
+                if (build2) tab[slot2 * WG_BP + tid] = t2;                                                            \
+            }                                                                                                         \
+            __syncthreads();                                                                                          \
+            LSN_STAMP(7);                                                                                             \
+        }                                                                                                             \
+    } while (0)
     if (st_begin < st_end) {
-        build_tab(st_begin, 0);
-        __syncthreads();
-        load_step(st_begin, 0);
-        for (int st = st_begin; st < st_end; ++st) {
-            const int buf = (st - st_begin) & 1;
-            store_step(buf);
-            if (st + 1 < st_end) build_tab(st + 1, buf ^ 1);
-            __syncthreads();
-            if (st + 1 < st_end) load_step(st + 1, buf ^ 1);
-            const unsigned char *ap = smem + (row0 + (lane & 31)) * RS + (lane >> 5) * 16;
-            const unsigned char *bp = smem + NPL * PLANE_A + (col0 + (lane & 31)) * RS + (lane >> 5) * 16;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 Af[TI][NPL], Bf[TI][NPL];
-#pragma unroll
-                for (int i = 0; i < TI; ++i)
-#pragma unroll
-                    for (int q = 0; q < NPL; ++q) {
-                        Af[i][q] = *reinterpret_cast<const bf16x8 *>(ap + q * PLANE_A + i * 32 * RS + ks * 32);
-                        Bf[i][q] = *reinterpret_cast<const bf16x8 *>(bp + q * PLANE_B + i * 32 * RS + ks * 32);
-                    }
-#pragma unroll
-                for (int prod = 0; prod < NP; ++prod)
-#pragma unroll
-                    for (int i = 0; i < TI; ++i)
-#pragma unroll
-                        for (int j = 0; j < TI; ++j)
-                            acc[i][j] = mfma_bf16(Af[i][SC::pa(prod)], Bf[j][SC::pb(prod)], acc[i][j]);
-            }
-            __syncthreads();
+        using T = std::true_type;
+        using F = std::false_type;
+        if (use_gtap) {
+            if constexpr (!PLAIN) LSN_WG_RUN(T, T, true);
+        } else if (vx && vg) {
+            LSN_WG_RUN(T, T, false);
+        } else {
+            // (Two scalar variants -- input only, both -- pushed the uses of `a` past what the compiler will trace
+            // when it turns the by-value argument copy into kernarg loads: the whole struct landed in scratch.
+            // Check ScratchSize with -Rpass-analysis=kernel-resource-usage after touching this kernel.)
+            LSN_WG_RUN(F, F, false);
         }
     }
+#undef LSN_WG_RUN
 
 #pragma unroll
     for (int i = 0; i < TI; ++i)
@@ -2739,7 +2932,8 @@ __global__ __launch_bounds__(256, 2) void dcn_wgrad_xn_kernel(const DcnArgs a, i
                     atomic_add_f32(a.gw + (size_t)(co_base + row) * Kdim + ch.k * Cg + ch.c0 + col, acc[i][j][r]);
             }
         }
-    if (do_bias && gval) atomic_add_f32(a.gb + co_base + tid, bias_acc);
+    if (do_bias && gval0) atomic_add_f32(a.gb + co_base + 2 * gcp, bias_acc0);
+    if (do_bias && gval1) atomic_add_f32(a.gb + co_base + 2 * gcp + 1, bias_acc1);
 }
 
 }  // namespace lsn

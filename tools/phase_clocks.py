@@ -51,7 +51,29 @@ def run(fn, block, label, flags=0):
 
 
 import sys
-if len(sys.argv) > 1 and sys.argv[1] == 'bwd1':
+if len(sys.argv) > 1 and sys.argv[1] == 'wg':
+    # weight-gradient kernel alone: 2 step top, 3 staged (VALU + LDS), 1 next tap table built, 4 barrier, 5 next loads issued, 6 MFMAs, 7 barrier
+    need_w = dict(input=[False] * 5, offset=[False] * 5, mask=[False] * 5, weight=True, bias=True)
+    for blk in (0, 17):
+        run(lambda: be.dcn_backward(xs, offs, msks, w, gos, cfg, need_w), blk, 'weight gradient (split kernel)')
+elif len(sys.argv) > 1 and sys.argv[1] == 'wgab':
+    # weight gradient inside a full backward call (the backward-data pass leaves its sampling table for it):
+    # bit 24 = ignore that table, bit 25 = scalar loads
+    need_all = dict(input=[True] * 5, offset=[True] * 5, mask=[True] * 5, weight=True, bias=True)
+    for name, fl in (('table + 8-byte loads', 0), ('computed taps', 1 << 24), ('scalar loads', 1 << 25)):
+        lib.lsn_debug_phase_clocks(None, fl)
+        for _ in range(3):
+            be.dcn_backward(xs, offs, msks, w, gos, cfg, need_all)
+        _lib.prof_enable(True)
+        for _ in range(10):
+            be.dcn_backward(xs, offs, msks, w, gos, cfg, need_all)
+        torch.cuda.synchronize()
+        pr = _lib.prof_read()
+        _lib.prof_enable(False)
+        lib.lsn_debug_phase_clocks(None, 0)
+        print(f'== {name}: ' + ', '.join(f"{k} {v['total_ms'] / max(v['launches'], 1):.3f} ms" for k, v in pr.items()))
+        run(lambda: be.dcn_backward(xs, offs, msks, w, gos, cfg, need_all), 17, 'weight gradient, ' + name, fl)
+elif len(sys.argv) > 1 and sys.argv[1] == 'bwd1':
     # split kernels: 2 loop top, 4 slab landed (barrier), 5 MFMAs done, 3 barrier + next slab issued, 6 epilogue done
     for blk in (0, 300, 600):
         run(lambda: be.dcn_backward(xs, offs, msks, w, gos, cfg, need), blk, 'backward-data (split kernel)')

@@ -1,0 +1,18 @@
+#!/bin/bash
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+mkdir -p gpurun_out
+export PYTHONUNBUFFERED=1
+timeout 900 python -m pytest tests/test_ops_gpu.py -q --tb=short -p no:cacheprovider -k "bench_shape or deterministic or split6 or test_dcn_forward_backward or multi_level_launch or named_entry or fused_offset" > gpurun_out/c8_pytest.log 2>&1
+echo "pytest rc $?"; grep -E "passed|failed|^FAILED|^ERROR|Error" gpurun_out/c8_pytest.log | tail -12
+for cfg in "bf16x6 1" "bf16x3 1"; do
+    set -- $cfg
+    echo "== LSNET_MATH=$1"
+    LSNET_MATH=$1 timeout 300 python tools/bench_ops.py --what dcn_all5 --iters 10 2>&1 | grep -v "^{\|amdgpu" | tee -a gpurun_out/c8_bench_ops.log
+done
+timeout 300 python tools/phase_clocks.py bwd1 2>&1 | grep -v amdgpu | head -9
+timeout 300 python bench.py --no-cpu-baseline --no-extra --steps 10 --warmup 3 > gpurun_out/r2e_bench.log 2>&1
+python - <<'PY'
+import json
+l=[x for x in open('gpurun_out/r2e_bench.log') if x.startswith('{')]
+d=json.loads(l[-1]); print(d['value'], d['ms_per_step'], {k:(round(v['avg_ms'],3), round(v['tflops'],1)) for k,v in d.get('kernels',{}).items()})
+PY
