@@ -62,13 +62,16 @@ def test_multiclass_nms_lsvr():
 @pytest.mark.parametrize('math', ['bf16x6', 'bf16x3', 'fp32'])
 def test_training_curve_follows_reference_runner(math):
     """12 SGD iterations on the device against the curve of the reference's detector + mmcv runner on CPU
-    (SURVEY.md 8d).  Measured on the MI355X (profiles/r1y_train_curve_gpu.log): <= 1.5e-4 relative over the first six
-    iterations, <= 1e-2 afterwards, in both arithmetic modes."""
+    (SURVEY.md 8d).  Measured on the MI355X, per iteration (profiles/r2_gpu_tests.log): iterations 1-6 (warm-up, lr still
+    small) <= 1.6e-4 (bf16x6), 2.5e-4 (bf16x3), 9.5e-5 (exact fp32 MFMA) relative; iterations 7-12 up to 2.9e-2 / 6.3e-3 /
+    3.3e-2 in that run and 9e-2 in an earlier one -- the trajectory amplifies rounding-level differences once the
+    learning rate is up, the exact-fp32 kernels no less than the split ones, and fp32 atomics in the weight gradients make
+    the late values vary from run to run.  Tolerances = 3 x the worst measured: 7.5e-4 early, 0.27 late."""
     from lsnet_amd import _lib
     before = _lib.get_math_mode()
     _lib.set_math_mode(math)
     try:
-        worst = gc.train_curve_case(_dev(), early_tol=5e-3, late_tol=0.25, rtol_weight=5e-2, channels_last=True)
+        worst = gc.train_curve_case(_dev(), early_tol=7.5e-4, late_tol=0.27, rtol_weight=5e-2, channels_last=True)
     finally:
         _lib.set_math_mode(before)
     print(math, f'worst relative loss deviation {worst:.2e}')

@@ -106,7 +106,7 @@ def test_focal_and_nms_wrappers(cpu_oracle_backend):
 def test_conv_bn_gn_modules_are_aten_on_cpu():
     import torch.nn.functional as F
     from lsnet_amd.ops.batch_norm import bn_act
-    from lsnet_amd.ops.conv import Conv2d, _own_is_faster, hip_conv_ok
+    from lsnet_amd.ops.conv import Conv2d, hip_conv_ok
     from lsnet_amd.ops.group_norm import GroupNorm
     torch.manual_seed(0)
     x = torch.randn(2, 32, 9, 11)
@@ -121,10 +121,6 @@ def test_conv_bn_gn_modules_are_aten_on_cpu():
     bn = torch.nn.BatchNorm2d(32).eval()
     r = torch.randn_like(x)
     assert torch.allclose(bn_act(bn, x, relu=True, residual=r), F.relu(bn(x) + r))
-    # the shape rule: big deep layers go to the split-bf16 kernel, small / shallow ones stay on the vendor library
-    assert _own_is_faster(2 * 100 * 168, 256, 256, 9) and _own_is_faster(2 * 50 * 84, 1024, 256, 1)
-    assert not _own_is_faster(2 * 200 * 336, 64, 64, 9) and not _own_is_faster(2 * 25 * 42, 512, 512, 9)
-    assert not _own_is_faster(2 * 100 * 168, 256, 27, 9)
 
 
 def test_resnet_block_equals_reference_sequence():

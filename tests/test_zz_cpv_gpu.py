@@ -12,5 +12,10 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize('channels_last', [False, True], ids=['nchw', 'nhwc'])
 def test_cpv_head_forward_loss_backward_decode(channels_last):
     assert torch.cuda.is_available()
-    worst = gc.cpv_head_case(torch.device('cuda:0'), channels_last)
-    print('cpv', 'channels_last' if channels_last else 'contiguous', f'worst sample err {worst:.2e}')
+    from tests import golden_util as gu
+    gu.STATS.clear()
+    try:
+        worst = gc.cpv_head_case(torch.device('cuda:0'), channels_last)
+        print('cpv', 'channels_last' if channels_last else 'contiguous', f'worst sample err {worst:.2e}')
+    finally:
+        print('cpv', 'channels_last' if channels_last else 'contiguous', gu.stats_report())
