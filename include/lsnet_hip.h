@@ -270,6 +270,25 @@ int lsn_conv2d_backward_data(const float *grad_out, const float *w, float *grad_
 int lsn_conv2d_backward_weight(const float *x, const float *grad_out, float *grad_w, float *grad_bias, int B, int H,
                                int W, int C, int Co, int kh, int kw, int stride, int pad, int dil, lsn_stream_t stream);
 
+/* ---- Grouped convolution (ResNeXt bottlenecks) -------------------------------------------------
+ * Reference: torch.nn.Conv2d(groups = G) as built by mmdet/models/backbones/resnext.py:11-83 (Bottleneck.conv2:
+ * 3x3, G = 64, width / G = 4 .. 32 channels per group), i.e. ATen's grouped convolution and its backward
+ * (aten::convolution_backward).  NHWC activations, OHWI weights w[co][i][j][ci] with ci in [0, C / G).
+ * Exact fp32 arithmetic (fmaf chains on the vector ALU; the products are far too thin for the matrix pipe and the
+ * layer is bound by HBM), in every math mode.  Supported: C / G == Co / G in {4, 8, 16, 32}, kh * kw <= 9, any
+ * stride / padding / dilation; anything else returns LSN_ERR_UNSUPPORTED (the caller keeps ATen).
+ * forward: out (B,Ho,Wo,Co) = conv(x (B,H,W,C)) + bias, optional ReLU.  backward_data: grad_in (B,H,W,C), OVERWRITTEN.
+ * backward_weight: grad_w (Co,kh,kw,C/G) and optionally grad_bias (Co), both OVERWRITTEN. */
+int lsn_grouped_conv2d_forward(const float *x, const float *w, const float *bias, float *out, int B, int H, int W, int C,
+                               int Co, int kh, int kw, int stride, int pad, int dil, int groups, int relu,
+                               lsn_stream_t stream);
+int lsn_grouped_conv2d_backward_data(const float *grad_out, const float *w, float *grad_in, int B, int H, int W, int C,
+                                     int Co, int kh, int kw, int stride, int pad, int dil, int groups,
+                                     lsn_stream_t stream);
+int lsn_grouped_conv2d_backward_weight(const float *x, const float *grad_out, float *grad_w, float *grad_bias, int B,
+                                       int H, int W, int C, int Co, int kh, int kw, int stride, int pad, int dil,
+                                       int groups, lsn_stream_t stream);
+
 /* ---- GroupNorm (+ReLU) on channels-last tensors ----------------------------------------------
  * The reference uses torch.nn.GroupNorm followed by nn.ReLU (ATen kernels; call sites
  * lsnet_head.py:1830-1849,136-141 and ConvModule in fpn.py:65-156).  These entry points are the fused

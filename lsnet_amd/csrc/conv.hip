@@ -414,6 +414,10 @@ static void conv_prepare(const float *w, unsigned short *out, int Co, int K, int
 static int conv_forward(ConvArgs &a, hipStream_t st)
 {
     // the block is four 64x64 wave tiles: 1x4 for wide layers, 2x2 for 128 output channels, 4x1 for 64
+    static const int force = [] { const char *e = getenv("LSNET_CONV_TILE"); return e ? atoi(e) : 0; }();   // tile sweeps
+    if (force == 1) return launch_conv<64, 256>(a, st);
+    if (force == 2) return launch_conv<128, 128>(a, st);
+    if (force == 3) return launch_conv<256, 64>(a, st);
     if (a.Co <= 64) return launch_conv<256, 64>(a, st);
     if (a.Co <= 128) return launch_conv<128, 128>(a, st);
     return launch_conv<64, 256>(a, st);

@@ -547,6 +547,19 @@ static int launch_bwd_data(DcnArgs &a, void *gather_ws, size_t gather_ws_bytes, 
     return (a.Co / a.groups > 64) ? launch_bwd_data_t<256>(a, st) : launch_bwd_data_t<64>(a, st);
 }
 
+// Pixel splits of a weight-gradient launch: the grid (columns x splits x co blocks) fills ONE round of the blocks the chip
+// holds at once (256 CUs x per_cu), rounded DOWN.  Measured on the benchmark step (profiles/r2_wgrad_rounds.txt): the
+// old cdiv(1024, 36) = 29 splits made 1044 blocks = two full rounds plus a third with 20 blocks (0.88 ms per DCN
+// launch); 28 splits 0.68 ms; one round instead of two is the same for the DCN launches and 1.1 ms / step faster over
+// the dense layers (half the fp32 atomics of the epilogues).
+static int wgrad_splits(int cols, int per_cu)
+{
+    const int slots = 256 * per_cu;
+    static const int rounds = [] { const char *e = getenv("LSNET_WGRAD_ROUNDS"); return e ? atoi(e) : 1; }();
+    int s = slots * (rounds > 0 ? rounds : 1) / cols;
+    return s < 1 ? 1 : s;
+}
+
 // 8-byte buffer loads in the split weight-gradient kernel: even channel counts, 8-byte aligned tensors, byte offsets < 2^31
 static int wgrad_vec_bits(const DcnArgs &a)
 {
@@ -567,7 +580,7 @@ static int launch_wgrad(const DcnArgs &a_in, int nsteps, hipStream_t st)
     const int K = a.kh * a.kw, Cg = a.C / a.groups, Cog = a.Co / a.groups;
     const int segs = Cg / a.SL, ncc = cdiv(a.SL, WG_BN);
     const int ncol = a.groups * K * segs * ncc, nz = cdiv(Cog, WG_BM);
-    int splits = cdiv(1024, ncol * nz);
+    int splits = wgrad_splits(ncol * nz, 2);   // 2 resident blocks per CU (246 VGPRs, 78 KB LDS)
     if (splits > nsteps) splits = nsteps;
     if (splits < 1) splits = 1;
     if (splits > 65535) splits = 65535;
@@ -797,7 +810,7 @@ template <int NP, int BMW>
 static int conv_wgrad_launch(const DcnArgs &a, int nsteps, int C, int Co, int K, hipStream_t st)
 {
     const int ncc = cdiv(C, WG_BN), ncol = K * ncc, nz = cdiv(Co, BMW);
-    int splits = cdiv(BMW == 256 ? 1024 : 2048, ncol * nz);
+    int splits = wgrad_splits(ncol * nz, BMW == 256 ? 2 : 3);   // resident blocks per CU: registers (246 / 142 VGPRs)
     if (splits > nsteps) splits = nsteps;
     if (splits < 1) splits = 1;
     if (splits > 65535) splits = 65535;

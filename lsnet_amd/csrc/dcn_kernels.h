@@ -2779,7 +2779,7 @@ __global__ __launch_bounds__(256, 2) void dcn_wgrad_xn_kernel(const DcnArgs a, i
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const Tap tp = tab[buf * WG_BP + pg * 4 + q];
-            if (PLAIN) {
+            if constexpr (PLAIN) {
                 v0[q] = (tp.flags & 1) ? xv0[q][0] : 0.f;
                 v1[q] = (tp.flags & 1) ? xv1[q][0] : 0.f;
             } else {

@@ -4,8 +4,9 @@ mmcv/cnn/bricks/conv.py:11-43 `build_conv_layer`).
 `Conv2d` subclasses nn.Conv2d (same parameters and state-dict keys).  Every dense (groups = 1) convolution of a CUDA
 channels-last fp32 tensor -- forward, data gradient (any stride), weight and bias gradient -- runs the split-bf16
 implicit-GEMM kernels of csrc/conv.hip in the library's math modes 'bf16x6' (fp32-equivalent, the default) and
-'bf16x3'; exact-fp32 mode, grouped convolutions and CPU tensors go to ATen's convolution (MIOpen), which is a
-different vendor operator, not a fallback of the HIP path."""
+'bf16x3'.  Grouped convolutions with 4 .. 32 channels per group (ResNeXt 64x4d bottlenecks) run the exact-fp32
+kernels of csrc/gconv.hip in every math mode.  Exact-fp32 dense convolutions, other group shapes and CPU tensors go to
+ATen's convolution (MIOpen), which is a different vendor operator, not a fallback of the HIP path."""
 import ctypes
 
 import torch
@@ -85,6 +86,62 @@ class _ConvFn(torch.autograd.Function):
             if not ctx.needs_input_grad[1]:
                 gw = None
         return gx, gw, gb, None, None, None, None
+
+
+class _GroupConvFn(torch.autograd.Function):
+    """Grouped convolution (ResNeXt): forward, data gradient, weight / bias gradient through csrc/gconv.hip."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, pad, dil, groups):
+        lib = _lib.load()
+        B, C, H, W = x.shape
+        Co, _, kh, kw = w.shape
+        Ho = (H + 2 * pad - (dil * (kh - 1) + 1)) // stride + 1
+        Wo = (W + 2 * pad - (dil * (kw - 1) + 1)) // stride + 1
+        w = w.contiguous(memory_format=_CL)
+        out = torch.empty((B, Co, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=_CL)
+        _lib.check(lib.lsn_grouped_conv2d_forward(_p(x), _p(w), _p(bias), _p(out), B, H, W, C, Co, kh, kw, stride, pad, dil,
+                                                  groups, 0, _stream()))
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (stride, pad, dil, groups, bias is not None)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, go):
+        x, w = ctx.saved_tensors
+        stride, pad, dil, groups, has_bias = ctx.cfg
+        lib = _lib.load()
+        go = go.contiguous(memory_format=_CL)
+        B, C, H, W = x.shape
+        Co, _, kh, kw = w.shape
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x, memory_format=_CL)
+            _lib.check(lib.lsn_grouped_conv2d_backward_data(_p(go), _p(w), _p(gx), B, H, W, C, Co, kh, kw, stride, pad, dil,
+                                                            groups, _stream()))
+        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+            gw = torch.empty_like(w)
+            gb = torch.empty(Co, device=x.device, dtype=torch.float32) if has_bias and ctx.needs_input_grad[2] else None
+            _lib.check(lib.lsn_grouped_conv2d_backward_weight(_p(x), _p(go), _p(gw), _p(gb), B, H, W, C, Co, kh, kw, stride,
+                                                              pad, dil, groups, _stream()))
+            if not ctx.needs_input_grad[1]:
+                gw = None
+        return gx, gw, gb, None, None, None, None
+
+
+def hip_group_conv_ok(x, weight, stride, padding, dilation, groups, padding_mode='zeros'):
+    """Shapes the grouped kernels take (include/lsnet_hip.h): in = out = 4, 8, 16 or 32 channels per group, <= 9 taps."""
+    if not (x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and x.is_contiguous(memory_format=_CL)):
+        return False
+    if groups <= 1 or padding_mode != 'zeros' or isinstance(padding, str):
+        return False
+    if stride[0] != stride[1] or padding[0] != padding[1] or dilation[0] != dilation[1]:
+        return False
+    Co, cg, kh, kw = weight.shape
+    if x.shape[1] != cg * groups or Co != cg * groups or cg not in (4, 8, 16, 32) or kh * kw > 9:
+        return False
+    return x.numel() < 2 ** 31 and Co * x.shape[0] * x.shape[2] * x.shape[3] < 2 ** 31
 
 
 class _ConvMultiFn(torch.autograd.Function):
@@ -235,4 +292,6 @@ class Conv2d(nn.Conv2d):
     def _run(self, x, w):
         if hip_conv_ok(x, w, self.stride, self.padding, self.dilation, self.groups, self.padding_mode):
             return conv2d(x, w, self.bias, self.stride[0], self.padding[0], self.dilation[0], False)
+        if hip_group_conv_ok(x, w, self.stride, self.padding, self.dilation, self.groups, self.padding_mode):
+            return _GroupConvFn.apply(x, w, self.bias, self.stride[0], self.padding[0], self.dilation[0], self.groups)
         return F.conv2d(x, w, self.bias, self.stride, self.padding, self.dilation, self.groups)

@@ -457,6 +457,70 @@ def test_conv2d_matches_torch(B, C, Co, k, s, p, d, H, W, bias, split_mode):
         assert _err(g.double(), r) < tol, (n, _err(g.double(), r))
 
 
+GROUP_CONV_CASES = [
+    # B, C (= Co), groups, k, stride, pad, dil, H, W, bias
+    (2, 256, 64, 3, 1, 1, 1, 50, 84, False),     # ResNeXt-101 64x4d layer1 conv2 (4 channels per group)
+    (2, 512, 64, 3, 2, 1, 1, 27, 41, False),     # layer2.0 conv2: stride 2, odd map (8 per group)
+    (1, 1024, 64, 3, 1, 1, 1, 13, 21, False),    # layer3 width (16 per group)
+    (1, 2048, 64, 3, 2, 1, 1, 14, 11, True),     # layer4.0 width, stride 2 (32 per group)
+    (2, 128, 32, 3, 1, 2, 2, 17, 19, True),      # dilation 2
+    (1, 96, 24, 1, 1, 0, 1, 9, 70, True),        # 1x1 grouped, 24 groups: a partial 32-channel slab at the end
+    (1, 40, 10, 3, 3, 1, 1, 20, 23, False),      # stride 3, 10 groups of 4
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,C,G,k,s,p,d,H,W,bias', GROUP_CONV_CASES)
+def test_grouped_conv2d_matches_torch(B, C, G, k, s, p, d, H, W, bias):
+    """Grouped convolution (ResNeXt bottleneck conv2; reference: nn.Conv2d(groups=64) of resnext.py:11-83) through the
+    exact-fp32 kernels of csrc/gconv.hip -- forward, data gradient, weight and bias gradient, in EVERY math mode --
+    against an fp64 evaluation of F.conv2d: fp32 rounding only (1e-6 of the range)."""
+    from lsnet_amd.ops.conv import Conv2d, hip_group_conv_ok
+    torch.manual_seed(8)
+    dev = _dev()
+    m = Conv2d(C, C, k, stride=s, padding=p, dilation=d, groups=G, bias=bias).to(dev).to(memory_format=torch.channels_last)
+    x = torch.randn(B, C, H, W, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_()
+    assert hip_group_conv_ok(x, m.weight, m.stride, m.padding, m.dilation, m.groups)
+    from lsnet_amd import _lib
+    before = _lib.get_math_mode()
+    try:
+        for mode in ('bf16x6', 'fp32'):
+            _lib.set_math_mode(mode)
+            y = m(x)
+            go = torch.randn_like(y)
+            params = list(m.parameters())
+            grads = torch.autograd.grad(y, [x] + params, go)
+            xr = x.detach().double().cpu().requires_grad_()
+            pr = [q.detach().double().cpu().contiguous().requires_grad_() for q in params]
+            yr = F.conv2d(xr, pr[0], pr[1] if bias else None, s, p, d, G)
+            gr = torch.autograd.grad(yr, [xr] + pr, go.double().cpu())
+            assert y.is_contiguous(memory_format=torch.channels_last) and y.shape == yr.shape
+            assert _err(y.double(), yr) < 1e-6
+            for g, r, n in zip(grads, gr, ('gx', 'gw', 'gb')):
+                assert g.shape == r.shape
+                assert _err(g.double(), r) < 2e-6, (mode, n, _err(g.double(), r))
+    finally:
+        _lib.set_math_mode(before)
+
+
+@pytest.mark.gpu
+def test_grouped_conv2d_unsupported_shape_uses_aten():
+    """5 channels per group is outside the kernels' list: the module keeps ATen's operator, the C entry says so."""
+    import ctypes
+    from lsnet_amd import _lib
+    from lsnet_amd.ops.conv import Conv2d, hip_group_conv_ok
+    dev = _dev()
+    m = Conv2d(20, 20, 3, padding=1, groups=4).to(dev).to(memory_format=torch.channels_last)
+    x = torch.randn(1, 20, 9, 11, device=dev).contiguous(memory_format=torch.channels_last)
+    assert not hip_group_conv_ok(x, m.weight, m.stride, m.padding, m.dilation, m.groups)
+    assert torch.allclose(m(x), F.conv2d(x, m.weight, m.bias, 1, 1, 1, 4), atol=1e-5)
+    lib = _lib.load()
+    out = torch.empty_like(x)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    rc = lib.lsn_grouped_conv2d_forward(p(x), p(m.weight), None, p(out), 1, 9, 11, 20, 20, 3, 3, 1, 1, 1, 4, 0, None)
+    assert rc == -2 and b'channels per group' in lib.lsn_last_error()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('C,Co,k,bias,relu', [(256, 27, 3, True, False), (256, 256, 3, True, False), (768, 256, 1, True, True),
                                               (64, 20, 1, False, False)])

@@ -10,6 +10,7 @@ from tools.bench_convs import SH, B
 
 dev = torch.device('cuda:0')
 mode = os.environ.get('LSNET_MATH', 'bf16x6')
+OWN_ONLY = '--own-only' in sys.argv   # skip the MIOpen columns (tile sweeps: LSNET_CONV_TILE=1|2|3)
 _lib.set_math_mode(mode)
 EXTRA = [('head 1x1 256->80 P3 (cls out)', 256, 80, 1, 1, 100, 168, 1), ('head 1x1 256->20 P3', 256, 20, 1, 1, 100, 168, 2),
          ('head 3x3 256->27 P4 (offset conv)', 256, 27, 3, 1, 50, 84, 6), ('fpn P6 3x3 s2 2048->256', 2048, 256, 3, 2, 25, 42, 1),
@@ -42,7 +43,7 @@ for name, ci, co, k, s, h, w, cnt in SH + EXTRA:
     with torch.no_grad():
         ref = F.conv2d(x, wt, None, s, pad)
         t_f = ev_time(lambda: conv2d(x, wt, None, s, pad))
-        t_fm = ev_time(lambda: F.conv2d(x, wt, None, s, pad))
+        t_fm = 0.0 if OWN_ONLY else ev_time(lambda: F.conv2d(x, wt, None, s, pad))
     fl = 2.0 * ref.numel() * ci * k * k / 1e9
     go = torch.randn_like(ref)
     line = f'{name:38s} {t_f:7.3f}|{t_fm:7.3f}'
@@ -55,8 +56,8 @@ for name, ci, co, k, s, h, w, cnt in SH + EXTRA:
         gw = torch.empty_like(wt)
         t_d = ev_time(lambda: lib.lsn_conv2d_backward_data(cp(go8), cp(w8), cp(gx), cp(ws), B, h, w, ci, co8, k, k, s, pad, 1, st))
         t_w = ev_time(lambda: lib.lsn_conv2d_backward_weight(cp(x), cp(go), cp(gw), None, B, h, w, ci, co, k, k, s, pad, 1, st))
-        t_dm = ev_time(lambda: torch.ops.aten.convolution_backward(go, x, wt, None, [s, s], [pad, pad], [1, 1], False, [0, 0], 1, [True, False, False]))
-        t_wm = ev_time(lambda: torch.ops.aten.convolution_backward(go, x, wt, None, [s, s], [pad, pad], [1, 1], False, [0, 0], 1, [False, True, False]))
+        t_dm = 0.0 if OWN_ONLY else ev_time(lambda: torch.ops.aten.convolution_backward(go, x, wt, None, [s, s], [pad, pad], [1, 1], False, [0, 0], 1, [True, False, False]))
+        t_wm = 0.0 if OWN_ONLY else ev_time(lambda: torch.ops.aten.convolution_backward(go, x, wt, None, [s, s], [pad, pad], [1, 1], False, [0, 0], 1, [False, True, False]))
         line += f' {t_d:7.3f}|{t_dm:7.3f} {t_w:7.3f}|{t_wm:7.3f}'
         for i, v in enumerate((t_f, t_fm, t_d, t_dm, t_w, t_wm)):
             tot[i] += v * cnt
