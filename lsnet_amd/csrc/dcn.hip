@@ -511,7 +511,13 @@ static int launch_bwd_colbuf(DcnArgs &a, GatherPlan &pl, unsigned char *ws, hipS
     if (int rc = set_lds(dcn_bwd_data_xn_kernel<NP, true>, lds)) return rc;
     hipLaunchKernelGGL((dcn_bwd_data_xn_kernel<NP, true>), dim3(a.ntiles), dim3(256), lds, st, a);
     pl.ga.gcol = a.gcol, pl.ga.start = start, pl.ga.ent = ent;
-    hipLaunchKernelGGL(dcn_gather_kernel, dim3(cdiv(pl.ga.NB, 4)), dim3(256), 0, st, pl.ga);
+    // long lists (the pyramid launch: three target levels scatter into every source level): four waves per pixel block
+    static const int force_nw = [] { const char *e = getenv("LSNET_GATHER_NW"); return e ? atoi(e) : 0; }();
+    const bool split = force_nw ? force_nw == 4 : (int64_t)pl.nsamples > (int64_t)300 * pl.ga.NB;
+    if (split)
+        hipLaunchKernelGGL(dcn_gather_kernel<4>, dim3(pl.ga.NB), dim3(256), 0, st, pl.ga);
+    else
+        hipLaunchKernelGGL(dcn_gather_kernel<1>, dim3(cdiv(pl.ga.NB, 4)), dim3(256), 0, st, pl.ga);
     LSN_HIP(hipGetLastError());
     return 0;
 }

@@ -1695,12 +1695,21 @@ __global__ __launch_bounds__(256) void dcn_sort_lists_kernel(int nanchors, const
 // Fixed order: anchors row-major, entries by sample id.
 constexpr int GT = 4;   // block edge
 constexpr int GU = 4;   // column-gradient rows a wave keeps in flight
+// NW = 1: one wave per 4x4 pixel block (four blocks per workgroup) -- short lists, e.g. the tower launch with ~140 entries
+//   per block (measured: 152 us against 186 us for NW = 4).
+// NW = 4: one workgroup per pixel block.  Its four waves share the block's entries -- wave w takes every 4th group of GU
+//   entries, counted along the 25 lists -- and meet in LDS: the longest chain of dependent loads of a block is a quarter
+//   of what one wave walks (the pyramid launch gives source levels P4 .. P7 500-700 entries per block; measured 822 us
+//   against 1295 us for NW = 1).  The partial sums are combined in the fixed order (w0 + w2) + (w1 + w3): deterministic.
+template <int NW>
 __global__ __launch_bounds__(256) void dcn_gather_kernel(const GatherArgs ga)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ float4 red[NW == 4 ? 2 : 1][NW == 4 ? GT * GT : 1][NW == 4 ? 64 : 1];   // NW = 4: 32 KB
+    const int lane = threadIdx.x & 63, wave_id = threadIdx.x >> 6;
+    const int wave = NW == 4 ? wave_id : 0;   // position among the waves that share a pixel block
     const int C = ga.C, K = ga.K, KD = ga.KD;
     const int cpdg = C / ga.dg;
-    const int bi = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
+    const int bi = NW == 4 ? xcd_remap(blockIdx.x, gridDim.x) : xcd_remap(blockIdx.x, gridDim.x) * 4 + wave_id;
     if (bi >= ga.NB) return;
     int gi = 0;
     while (gi + 1 < ga.ng && bi >= ga.g[gi + 1].blk0) ++gi;
@@ -1716,6 +1725,7 @@ __global__ __launch_bounds__(256) void dcn_gather_kernel(const GatherArgs ga)
         for (int i = 0; i < GT; ++i)
 #pragma unroll
             for (int j = 0; j < GT; ++j) acc[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        int grp = 0;   // running group counter of the block (wave-uniform)
 #pragma unroll
         for (int ai = 0; ai <= GT; ++ai)
 #pragma unroll
@@ -1727,9 +1737,14 @@ __global__ __launch_bounds__(256) void dcn_gather_kernel(const GatherArgs ga)
                 const int le = __builtin_amdgcn_readfirstlane(ga.start[an + 1]);
                 for (int base = lb; base < le; base += 64) {
                     const int n = min(64, le - base);
+                    const int ngrp = (n + GU - 1) / GU;
+                    // groups of this batch that are this wave's: first one at offset (wave - grp) mod NW
+                    const int first = (wave - grp) & (NW - 1);
+                    grp += ngrp;
+                    if (first >= ngrp) continue;
                     GEntry e = {};
                     if (lane < n) e = ga.ent[base + lane];
-                    for (int j0 = 0; j0 < n; j0 += GU) {   // GU rows in flight per wave
+                    for (int j0 = first * GU; j0 < n; j0 += NW * GU) {   // GU rows in flight per wave
                         float4 v[GU];
                         float ly[GU], lx[GU];
 #pragma unroll
@@ -1766,7 +1781,31 @@ __global__ __launch_bounds__(256) void dcn_gather_kernel(const GatherArgs ga)
                     }
                 }
             }
-        if (c < C) {
+        auto put = [&](int slot) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < GT; ++i)
+#pragma unroll
+                for (int j = 0; j < GT; ++j) red[slot][i * GT + j][lane] = acc[i][j];
+        };
+        auto add = [&](int slot) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < GT; ++i)
+#pragma unroll
+                for (int j = 0; j < GT; ++j) {
+                    const float4 r = red[slot][i * GT + j][lane];
+                    acc[i][j].x += r.x, acc[i][j].y += r.y, acc[i][j].z += r.z, acc[i][j].w += r.w;
+                }
+        };
+        if constexpr (NW == 4) {
+            if (wave >= 2) put(wave - 2);
+            __syncthreads();
+            if (wave < 2) add(wave);          // w0 += w2, w1 += w3
+            __syncthreads();
+            if (wave == 1) put(0);
+            __syncthreads();
+            if (wave == 0) add(0);
+        }
+        if (wave == 0 && c < C) {
 #pragma unroll
             for (int i = 0; i < GT; ++i)
 #pragma unroll
@@ -1774,6 +1813,7 @@ __global__ __launch_bounds__(256) void dcn_gather_kernel(const GatherArgs ga)
                     if (y0 + i < G.H && x0 + j < G.W)
                         *reinterpret_cast<float4 *>(G.gx + ((size_t)(b * G.H + y0 + i) * G.W + x0 + j) * C + c) = acc[i][j];
         }
+        if constexpr (NW == 4) __syncthreads();   // red is reused by the next channel block
     }
 }
 
