@@ -399,6 +399,22 @@ int lsn_cross_iou_bbox_stage_backward(const float *pred_raw, const float *gt_pts
                                       const float *weight, const float *grad_rows, int64_t n, float base_scale, float alpha,
                                       float eps, float *grad_raw, lsn_stream_t stream);
 
+/* The polygon (instance segmentation: nv contour vectors + centre) and keypoint (pose: nv keypoints + centre) variants
+ * of the same loss -- mmdet/models/losses/cross_iou_loss.py:68-77 and :80-94, call sites lsnet_head.py:1103-1270 --
+ * for n points in one launch each way.  Rows have ncomp = 4 (nv + 1) components (148 for 36 contour vectors, 72 for 17
+ * keypoints).  kind 1 = polygon: overlap = mean over `sub` interleaved landmark subsets (cross_iou_loss.py: stride = 9)
+ * of sum(min) / sum(max), plus the distance / aspect terms on the bounding box of the nv vectors; needs anchor (n, 2)
+ * and bbox_gt (n, 4).  kind 2 = keypoint: mean over the (neg, pos) pairs of sum(min) / sum(max clamped at eps), a
+ * keypoint's two pairs counted when vs (n, nv) > 0, the centre pairs always; anchor / bbox_gt unused (may be NULL).
+ * weight (n) may be NULL.  forward: loss_rows (n) = weight x row loss.  backward: grad_pred (n, ncomp), OVERWRITTEN,
+ * = grad_rows x weight x d row / d pred (ties of max / min split 0.5 / 0.5 as ATen does). */
+int lsn_cross_iou_rows_forward(int kind, const float *pred, const float *target, const uint8_t *active, const float *anchor,
+                               const float *bbox_gt, const float *vs, const float *weight, int64_t n, int ncomp, int sub,
+                               float alpha, float eps, float *loss_rows, lsn_stream_t stream);
+int lsn_cross_iou_rows_backward(int kind, const float *pred, const float *target, const uint8_t *active, const float *anchor,
+                                const float *bbox_gt, const float *vs, const float *weight, const float *grad_rows, int64_t n,
+                                int ncomp, int sub, float alpha, float eps, float *grad_pred, lsn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

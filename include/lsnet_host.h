@@ -86,6 +86,12 @@ void lsn_image_normalize_f32(const float *src, size_t pixels, int c, const float
  * lsn_nms_match: `order` = box indices by descending score; flat (n) receives the groups back to back (keeper first),
  *               group_start (n + 1) their boundaries; returns the number of groups. */
 size_t lsn_soft_nms(const float *dets, size_t n, float iou_thr, int method, float sigma, float min_score, float *out);
+/* Hard NMS of host tensors: `nms_cpu` of the reference's dispatcher (nms_ext.cpp:11-27 -> cpu/nms_cpu.cpp:7-71), for
+ * float32 and float64 boxes as AT_DISPATCH_FLOATING_TYPES does.  `order` = box indices by descending score (the caller
+ * sorts, as the reference does with torch.sort); keep (n) receives the kept indices in visiting order; returns their
+ * number.  A box goes when its IoU with a kept box EXCEEDS iou_thr. */
+size_t lsn_nms_host_f32(const float *dets, const int64_t *order, size_t n, float iou_thr, int64_t *keep);
+size_t lsn_nms_host_f64(const double *dets, const int64_t *order, size_t n, float iou_thr, int64_t *keep);
 size_t lsn_nms_match(const float *dets, const int64_t *order, size_t n, float iou_thr, int64_t *flat, int64_t *group_start);
 
 #ifdef __cplusplus

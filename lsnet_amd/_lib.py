@@ -69,6 +69,7 @@ EXPORTS = [
     'lsn_bn_eval_act_forward', 'lsn_bn_eval_act_backward', 'lsn_bn_eval_act_workspace_bytes',
     'lsn_image_prep_u8', 'lsn_cross_iou_bbox_forward', 'lsn_cross_iou_bbox_backward',
     'lsn_cross_iou_bbox_stage_forward', 'lsn_cross_iou_bbox_stage_backward',
+    'lsn_cross_iou_rows_forward', 'lsn_cross_iou_rows_backward',
 ]
 
 _lib = None

@@ -1,6 +1,7 @@
-// liblsnet_host.so -- the two host-only members of the reference's `nms_ext` module (mmdet/ops/nms/src/nms_ext.cpp:29-43
-// -> src/cpu/nms_cpu.cpp:63-258): soft NMS and NMS matching.  (The hard NMS of the hot path is the device kernel
-// lsn_nms in liblsnet_hip.so.)  float32 boxes [x1, y1, x2, y2, score], the reference's arithmetic and visiting order:
+// liblsnet_host.so -- the host members of the reference's `nms_ext` module (mmdet/ops/nms/src/nms_ext.cpp:11-43 ->
+// src/cpu/nms_cpu.cpp): hard NMS of CPU tensors (:7-71), soft NMS and NMS matching (:73-258).  (The hard NMS of the hot
+// path is the device kernel lsn_nms in liblsnet_hip.so; the host one serves CPU tensors, as `nms_cpu` does in the
+// reference's dispatcher.)  float32 boxes [x1, y1, x2, y2, score], the reference's arithmetic and visiting order:
 // results are index-for-index the reference's.
 #include "../../../include/lsnet_host.h"
 
@@ -22,9 +23,46 @@ inline float overlap(const Det &a, const Det &b)
     return inter / (a.area + b.area - inter);
 }
 
+// nms_cpu_kernel<scalar_t> (nms_cpu.cpp:7-62): boxes visited in `order` (the caller's descending-score sort, so that ties
+// are torch's), a box is dropped when its IoU with an earlier kept box EXCEEDS the threshold; areas without the legacy +1
+template <typename T>
+size_t nms_hard(const T *dets, const int64_t *order, size_t n, float thr, int64_t *keep)
+{
+    std::vector<T> area(n);
+    for (size_t i = 0; i < n; ++i) area[i] = (dets[5 * i + 2] - dets[5 * i]) * (dets[5 * i + 3] - dets[5 * i + 1]);
+    std::vector<unsigned char> gone(n, 0);
+    size_t kept = 0;
+    for (size_t a = 0; a < n; ++a) {
+        const int64_t i = order[a];
+        if (gone[i]) continue;
+        keep[kept++] = i;
+        const T *bi = dets + 5 * i;
+        for (size_t b = a + 1; b < n; ++b) {
+            const int64_t j = order[b];
+            if (gone[j]) continue;
+            const T *bj = dets + 5 * j;
+            const T w = std::max(static_cast<T>(0), std::min(bi[2], bj[2]) - std::max(bi[0], bj[0]));
+            const T h = std::max(static_cast<T>(0), std::min(bi[3], bj[3]) - std::max(bi[1], bj[1]));
+            const T inter = w * h;
+            if (inter / (area[i] + area[j] - inter) > thr) gone[j] = 1;
+        }
+    }
+    return kept;
+}
+
 }  // namespace
 
 extern "C" {
+
+size_t lsn_nms_host_f32(const float *dets, const int64_t *order, size_t n, float iou_thr, int64_t *keep)
+{
+    return nms_hard<float>(dets, order, n, iou_thr, keep);
+}
+
+size_t lsn_nms_host_f64(const double *dets, const int64_t *order, size_t n, float iou_thr, int64_t *keep)
+{
+    return nms_hard<double>(dets, order, n, iou_thr, keep);
+}
 
 // Soft NMS (Bodla et al.): repeatedly move the best remaining box to the front, decay the scores of the rest by their
 // overlap with it (method 1: x (1 - iou) above the threshold; 2: x exp(-iou^2 / sigma); else hard), and drop boxes

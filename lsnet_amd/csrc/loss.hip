@@ -83,6 +83,66 @@ __global__ void cross_iou_bbox_stage_kernel(CiouStageArgs a)
     }
 }
 
+// polygon / keypoint rows (cross_iou_row.h): one thread per point, the row read in place (M = 4 (nv + 1) floats)
+struct CiouGenArgs {
+    const float *pred, *target, *anchor, *gt, *vs, *weight, *grad_rows;
+    const unsigned char *active;
+    float *loss, *grad_pred;
+    long long n;
+    int kind, nv, sub;   // kind 1: polygon, 2: keypoint
+    float alpha, eps;
+};
+
+template <bool BWD>
+__global__ void cross_iou_rows_kernel(CiouGenArgs a)
+{
+    const int M = 4 * (a.nv + 1);
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < a.n; i += (long long)gridDim.x * blockDim.x) {
+        const float *p = a.pred + M * i, *t = a.target + M * i;
+        const unsigned char *act = a.active + M * i;
+        float *g = BWD ? a.grad_pred + M * i : nullptr;
+        const float w = a.weight ? a.weight[i] : 1.f;
+        float loss;
+        if (a.kind == 1)
+            loss = cross_iou_polygon_row(p, t, act, a.anchor + 2 * i, a.gt + 4 * i, a.nv, a.sub, a.alpha, a.eps, g);
+        else
+            loss = cross_iou_keypoint_row(p, t, act, a.vs + (long long)a.nv * i, a.nv, a.alpha, a.eps, g);
+        if (!BWD) {
+            a.loss[i] = loss * w;
+        } else {
+            const float sc = a.grad_rows[i] * w;
+            for (int c = 0; c < M; ++c) g[c] *= sc;
+        }
+    }
+}
+
+static int launch_rows(const CiouGenArgs &a, bool bwd, hipStream_t st)
+{
+    if (a.n == 0) return 0;
+    const int blocks = (int)((a.n + 63) / 64 < 8192 ? (a.n + 63) / 64 : 8192);
+    if (bwd) hipLaunchKernelGGL(cross_iou_rows_kernel<true>, dim3(blocks), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL(cross_iou_rows_kernel<false>, dim3(blocks), dim3(64), 0, st, a);
+    LSN_HIP(hipGetLastError());
+    return 0;
+}
+
+static int check_rows(const char *who, int kind, int64_t n, int ncomp, int sub, const void *pred, const void *target,
+                      const void *active, const void *anchor, const void *gt, const void *vs)
+{
+    LSN_CHECK(n >= 0, "%s: invalid number of rows %lld", who, (long long)n);
+    LSN_CHECK(kind == 1 || kind == 2, "%s: kind must be 1 (polygon) or 2 (keypoint), got %d", who, kind);
+    LSN_CHECK(ncomp >= 8 && ncomp % 4 == 0, "%s: rows have 4 (nv + 1) components, got %d", who, ncomp);
+    if (n == 0) return 0;
+    LSN_CHECK(pred && target && active, "%s: null pointer", who);
+    if (kind == 1) {
+        LSN_CHECK(anchor && gt, "%s: the polygon loss needs anchor points and ground-truth boxes", who);
+        LSN_CHECK(sub >= 1 && sub <= LSN_CIOU_MAXSUB && sub <= ncomp / 4, "%s: subset stride %d out of range", who, sub);
+    } else {
+        LSN_CHECK(vs != nullptr, "%s: the keypoint loss needs the visibility values", who);
+    }
+    return 0;
+}
+
 static int launch(const CiouArgs &a, bool bwd, hipStream_t st)
 {
     if (a.n == 0) return 0;
@@ -154,6 +214,30 @@ int lsn_cross_iou_bbox_stage_backward(const float *pred_raw, const float *gt_pts
     hipLaunchKernelGGL(cross_iou_bbox_stage_kernel<true>, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     LSN_HIP(hipGetLastError());
     return 0;
+}
+
+int lsn_cross_iou_rows_forward(int kind, const float *pred, const float *target, const uint8_t *active, const float *anchor,
+                               const float *bbox_gt, const float *vs, const float *weight, int64_t n, int ncomp, int sub,
+                               float alpha, float eps, float *loss_rows, lsn_stream_t stream)
+{
+    using namespace lsn;
+    if (int rc = check_rows("lsn_cross_iou_rows_forward", kind, n, ncomp, sub, pred, target, active, anchor, bbox_gt, vs)) return rc;
+    LSN_CHECK(n == 0 || loss_rows, "lsn_cross_iou_rows_forward: null output");
+    CiouGenArgs a = {pred, target, anchor, bbox_gt, vs, weight, nullptr, active, loss_rows, nullptr, (long long)n, kind,
+                     ncomp / 4 - 1, sub, alpha, eps};
+    return launch_rows(a, false, static_cast<hipStream_t>(stream));
+}
+
+int lsn_cross_iou_rows_backward(int kind, const float *pred, const float *target, const uint8_t *active, const float *anchor,
+                                const float *bbox_gt, const float *vs, const float *weight, const float *grad_rows, int64_t n,
+                                int ncomp, int sub, float alpha, float eps, float *grad_pred, lsn_stream_t stream)
+{
+    using namespace lsn;
+    if (int rc = check_rows("lsn_cross_iou_rows_backward", kind, n, ncomp, sub, pred, target, active, anchor, bbox_gt, vs)) return rc;
+    LSN_CHECK(n == 0 || (grad_rows && grad_pred), "lsn_cross_iou_rows_backward: null pointer");
+    CiouGenArgs a = {pred, target, anchor, bbox_gt, vs, weight, grad_rows, active, nullptr, grad_pred, (long long)n, kind,
+                     ncomp / 4 - 1, sub, alpha, eps};
+    return launch_rows(a, true, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -17,7 +17,7 @@ _u32p, _f64p, _szp, _u8p = C.POINTER(C.c_uint32), C.POINTER(C.c_double), C.POINT
 EXPORTS = ('lsn_rle_from_polygon', 'lsn_rle_from_bbox', 'lsn_rle_merge', 'lsn_rle_area', 'lsn_rle_to_bbox',
            'lsn_rle_iou', 'lsn_bbox_iou', 'lsn_rle_encode', 'lsn_rle_decode', 'lsn_rle_to_string', 'lsn_rle_from_string',
            'lsn_coco_match', 'lsn_image_resize_bilinear_u8', 'lsn_image_resize_bilinear_f32', 'lsn_image_normalize_u8',
-           'lsn_image_normalize_f32', 'lsn_soft_nms', 'lsn_nms_match')
+           'lsn_image_normalize_f32', 'lsn_soft_nms', 'lsn_nms_match', 'lsn_nms_host_f32', 'lsn_nms_host_f64')
 
 
 def lib():
@@ -64,6 +64,10 @@ def lib():
         L.lsn_soft_nms.argtypes = [f32p, C.c_size_t, C.c_float, C.c_int, C.c_float, C.c_float, f32p]
         L.lsn_nms_match.restype = C.c_size_t
         L.lsn_nms_match.argtypes = [f32p, C.POINTER(C.c_int64), C.c_size_t, C.c_float, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.lsn_nms_host_f32.restype = C.c_size_t
+        L.lsn_nms_host_f32.argtypes = [f32p, C.POINTER(C.c_int64), C.c_size_t, C.c_float, C.POINTER(C.c_int64)]
+        L.lsn_nms_host_f64.restype = C.c_size_t
+        L.lsn_nms_host_f64.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_size_t, C.c_float, C.POINTER(C.c_int64)]
         _lib = L
     return _lib
 

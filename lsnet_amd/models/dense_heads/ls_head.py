@@ -506,7 +506,8 @@ class LSHead(nn.Module):
                 loss_fn = getattr(self, f'loss_{b}_{stage}')
                 if (b == 'bbox' and width == 20 and fused_ciou.enabled() and pred.is_cuda and pred.dtype == torch.float32
                         and getattr(loss_fn, 'loss_type', None) == 'bbox'):
-                    # opt-in (LSNET_FUSED_CIOU=1): scaling, normalisation, target construction and the loss in one launch
+                    # (default; LSNET_FUSED_CIOU=0 switches it off) scaling, normalisation, target construction and the loss
+                    # in one launch; the segm / pose stages below reach the fused polygon / keypoint rows through loss_fn
                     rows = loss_fn.loss_weight * fused_ciou.cross_iou_bbox_stage_rows(
                         pred.reshape(-1, width), gt_pts, anchor, bbox_gt, bw[:, 0], self.point_base_scale, loss_fn.alpha,
                         loss_fn.eps)

@@ -1,6 +1,7 @@
-"""Fused cross-IOU loss of the bbox task (csrc/loss.hip, lsn_cross_iou_bbox_forward / _backward): the per-point loss and
-its gradient in one launch each, instead of the ~60 elementwise launches of the torch formulation
-(models/losses/cross_iou_loss.py).  On by default for device tensors (verified on the MI355X against the torch
+"""Fused cross-IOU loss (csrc/loss.hip): the per-point loss and its gradient in one launch each, instead of the ~60
+elementwise launches of the torch formulation (models/losses/cross_iou_loss.py) -- the bbox task
+(lsn_cross_iou_bbox_forward / _backward and the whole-stage variant), the polygon (instance segmentation) and the
+keypoint (pose) tasks (lsn_cross_iou_rows_forward / _backward).  On by default for device tensors (verified on the MI355X against the torch
 formulation and the reference fixture: tests/test_zz_fused_ciou_gpu.py); `LSNET_FUSED_CIOU=0` keeps the torch formulation."""
 import ctypes
 import os
@@ -54,6 +55,54 @@ class _CrossIouBbox(torch.autograd.Function):
 def usable(pred, target, loss_type):
     return (loss_type == 'bbox' and pred.is_cuda and pred.dtype == torch.float32 and pred.dim() == 2
             and pred.shape[1] == 20 and not target.requires_grad)
+
+
+_KIND = {'polygon': 1, 'keypoint': 2}
+
+
+def rows_usable(pred, target, loss_type, stride=9):
+    """The polygon / keypoint kernels: rows of 4 (nv + 1) fp32 components on the device."""
+    return (loss_type in _KIND and pred.is_cuda and pred.dtype == torch.float32 and pred.dim() == 2
+            and pred.shape[1] >= 8 and pred.shape[1] % 4 == 0 and not target.requires_grad
+            and (loss_type == 'keypoint' or 1 <= stride <= min(16, pred.shape[1] // 4)))
+
+
+class _CrossIouRows(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, pred, target, active, anchor, bbox_gt, vs, weight, kind, sub, alpha, eps):
+        c = lambda t: None if t is None else t.contiguous()
+        pred, target, anchor, bbox_gt, weight = c(pred), c(target), c(anchor), c(bbox_gt), c(weight)
+        vs = None if vs is None else vs.to(torch.float32).contiguous()
+        active = active.to(torch.uint8).contiguous()
+        n, m = pred.shape
+        loss = torch.empty(n, dtype=torch.float32, device=pred.device)
+        _lib.check(_lib.load().lsn_cross_iou_rows_forward(kind, _p(pred), _p(target), _p(active), _p(anchor), _p(bbox_gt), _p(vs),
+                                                          _p(weight), ctypes.c_int64(n), m, sub, ctypes.c_float(alpha),
+                                                          ctypes.c_float(eps), _p(loss), _stream()))
+        ctx.save_for_backward(pred, target, active, anchor, bbox_gt, vs, weight)   # (None entries are allowed)
+        ctx.cfg = (kind, sub, alpha, eps)
+        return loss
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_rows):
+        kind, sub, alpha, eps = ctx.cfg
+        pred, target, active, anchor, bbox_gt, vs, weight = ctx.saved_tensors
+        n, m = pred.shape
+        grad = torch.empty_like(pred)
+        _lib.check(_lib.load().lsn_cross_iou_rows_backward(kind, _p(pred), _p(target), _p(active), _p(anchor), _p(bbox_gt), _p(vs),
+                                                           _p(weight), _p(grad_rows.contiguous()), ctypes.c_int64(n), m, sub,
+                                                           ctypes.c_float(alpha), ctypes.c_float(eps), _p(grad), _stream()))
+        return (grad,) + (None,) * 10
+
+
+def cross_iou_rows(pred, target, active, loss_type, anchor=None, bbox_gt=None, vs=None, weight=None, alpha=0.2, eps=1e-6,
+                   stride=9):
+    """(n,) weighted loss rows (reduction 'none') of the polygon / keypoint cross-IOU loss; gradient flows to `pred` only
+    (the other inputs are targets; they are kept alive for the backward launch)."""
+    return _CrossIouRows.apply(pred, target, active, anchor, bbox_gt, vs, weight, _KIND[loss_type], int(stride), float(alpha),
+                               float(eps))
 
 
 def cross_iou_bbox_rows(pred, target, active, anchor, bbox_gt, weight=None, alpha=0.2, eps=1e-6):

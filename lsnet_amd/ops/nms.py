@@ -1,7 +1,9 @@
 """NMS ops -- mirror of mmdet/ops/nms/nms_wrapper.py:7-59 (`nms`) and :119-157 (`batched_nms`).
 
 The device path never leaves the GPU: IoU bitmask kernel + on-device sweep (lsn_nms).  The keep
-indices are bit-identical to the reference's CPU/GPU kernels (same IoU arithmetic, same order)."""
+indices are bit-identical to the reference's CPU/GPU kernels (same IoU arithmetic, same order).
+CPU tensors and ndarrays without a device id take the host library's `nms_cpu` counterpart (lsn_nms_host_f32 / _f64,
+the reference's own dispatch: nms_wrapper.py:33-37 -> nms_ext.nms -> nms_cpu for non-CUDA tensors), float32 or float64."""
 import numpy as np
 import torch
 
@@ -20,11 +22,31 @@ def nms(dets, iou_thr, device_id=None):
         raise TypeError(f'dets must be either a Tensor or numpy array, but got {type(dets)}')
     if dets_th.shape[0] == 0:
         inds = dets_th.new_zeros(0, dtype=torch.long)
+    elif not dets_th.is_cuda:
+        inds = _nms_host(dets_th, float(iou_thr))
     else:
         inds = get_backend(dets_th).nms(dets_th.float(), float(iou_thr))
     if is_numpy:
         inds = inds.cpu().numpy()
     return dets[inds, :], inds
+
+
+def _nms_host(dets, iou_thr):
+    """nms_cpu (cpu/nms_cpu.cpp:7-71): float32 / float64 boxes on the host, order = torch.sort of the scores."""
+    import ctypes as C
+    if dets.dtype not in (torch.float32, torch.float64):
+        dets = dets.float()
+    a = dets.detach().contiguous().numpy().reshape(-1, 5)
+    order = torch.sort(dets[:, 4], 0, descending=True)[1].numpy()
+    keep = np.zeros(len(a), dtype=np.int64)
+    i64 = C.POINTER(C.c_int64)
+    if a.dtype == np.float64:
+        k = _host().lsn_nms_host_f64(a.ctypes.data_as(C.POINTER(C.c_double)), order.ctypes.data_as(i64), len(a), iou_thr,
+                                     keep.ctypes.data_as(i64))
+    else:
+        k = _host().lsn_nms_host_f32(a.ctypes.data_as(C.POINTER(C.c_float)), order.ctypes.data_as(i64), len(a), iou_thr,
+                                     keep.ctypes.data_as(i64))
+    return torch.from_numpy(keep[:k].copy())
 
 
 def batched_nms(bboxes, scores, inds, nms_cfg, class_agnostic=False):

@@ -32,6 +32,14 @@ extern "C" void stage_rows(const float *p, const float *g, const float *anchor3,
         for (int c = 0; c < 20; ++c) grad[20 * i + c] = r.grad[c];
     }
 }
+extern "C" void gen_rows(int kind, const float *p, const float *t, const unsigned char *a, const float *anchor, const float *gt,
+                         const float *vs, int n, int nv, int sub, float alpha, float eps, float *loss, float *grad) {
+    const int M = 4 * (nv + 1);
+    for (int i = 0; i < n; ++i)
+        loss[i] = kind == 1 ? cross_iou_polygon_row(p + M * i, t + M * i, a + M * i, anchor + 2 * i, gt + 4 * i, nv, sub, alpha, eps,
+                                                    grad + M * i)
+                            : cross_iou_keypoint_row(p + M * i, t + M * i, a + M * i, vs + nv * i, nv, alpha, eps, grad + M * i);
+}
 '''
 
 
@@ -126,3 +134,53 @@ def test_stage_row_matches_head_formulation(rowlib, seed):
     got, ref = grad * (up.numpy() * w)[:, None], p.grad.numpy()
     scale = np.abs(ref).max(1, keepdims=True) + 1e-6
     assert (np.abs(got - ref) / scale).max() < 5e-4, float((np.abs(got - ref) / scale).max())
+
+
+def _gen_case(seed, nv, n=300, zero_pair=False):
+    """Rows of 4 (nv + 1) components as the segm / pose heads build them: per (neg, pos) pair one active half."""
+    g = torch.Generator().manual_seed(seed)
+    m = 4 * (nv + 1)
+    pred = torch.rand(n, m, generator=g) * 3 + 0.01
+    mag = torch.rand(n, m // 2, generator=g) * 3 + 0.01
+    pos = torch.rand(n, m // 2, generator=g) > 0.5
+    target = torch.zeros(n, m)
+    target[:, 0::2] = torch.where(pos, torch.zeros_like(mag), mag)
+    target[:, 1::2] = torch.where(pos, mag, torch.zeros_like(mag))
+    active = torch.zeros(n, m, dtype=torch.bool)
+    active[:, 0::2], active[:, 1::2] = ~pos, pos
+    anchor = torch.rand(n, 2, generator=g) * 10
+    c = anchor + torch.randn(n, 2, generator=g)
+    wh = torch.rand(n, 2, generator=g) * 4 + 0.2
+    gt = torch.cat([c - wh, c + wh], 1)
+    vs = (torch.rand(n, nv, generator=g) > 0.3).float() * 2            # COCO visibility 0 / 2
+    target[::17] = 0                                                   # rows without an object
+    pred[5, 3] = target[5, 3] = 1.25                                   # an exact tie of max / min
+    if zero_pair:                                                      # a landmark below the eps clamp of the keypoint variant
+        pred[7, 8:12] = 0.0                                            # (the polygon variant would divide 0 by 0 there, as the
+        target[7, 8:12] = 0.0                                          # reference does)
+    return pred, target, active, anchor, gt, vs
+
+
+@pytest.mark.parametrize('kind,nv', [('polygon', 36), ('polygon', 9), ('keypoint', 17), ('keypoint', 4)])
+@pytest.mark.parametrize('seed', [0, 1])
+def test_polygon_and_keypoint_rows_match_torch_and_autograd(rowlib, kind, nv, seed):
+    pred, target, active, anchor, gt, vs = _gen_case(seed + 10 * nv, nv, zero_pair=kind == 'keypoint')
+    p = pred.clone().requires_grad_()
+    want = cross_iou_loss(p, target, None, reduction='none', loss_type=kind, anchor_pts=anchor, bbox_gt=gt, pos_inds=active,
+                          vs=vs, stride=9)
+    up = torch.rand(len(pred), generator=torch.Generator().manual_seed(9))
+    (want * up).sum().backward()
+    n, m = pred.shape
+    loss, grad = np.zeros(n, np.float32), np.zeros((n, m), np.float32)
+    f32, u8 = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_ubyte)
+    arrs = [np.ascontiguousarray(x.numpy(), dtype=np.float32) for x in (pred, target, anchor, gt, vs)]
+    act = np.ascontiguousarray(active.numpy().astype(np.uint8))
+    rowlib.gen_rows(1 if kind == 'polygon' else 2, arrs[0].ctypes.data_as(f32), arrs[1].ctypes.data_as(f32),
+                    act.ctypes.data_as(u8), arrs[2].ctypes.data_as(f32), arrs[3].ctypes.data_as(f32),
+                    arrs[4].ctypes.data_as(f32), n, nv, 9, ctypes.c_float(0.2), ctypes.c_float(1e-6),
+                    loss.ctypes.data_as(f32), grad.ctypes.data_as(f32))
+    np.testing.assert_allclose(loss, want.detach().numpy(), rtol=3e-5, atol=3e-6)
+    got = grad * up.numpy()[:, None]
+    ref = p.grad.numpy()
+    scale = np.abs(ref).max(1, keepdims=True) + 1e-6
+    assert (np.abs(got - ref) / scale).max() < 3e-4, float((np.abs(got - ref) / scale).max())

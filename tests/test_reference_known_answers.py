@@ -121,6 +121,19 @@ def test_soft_nms_and_nms_match_known_answers_and_reference_library():
     with pytest.raises(ValueError):
         soft_nms(dets, 0.6, method='cubic')
     assert nms_match(np.zeros((0, 5), np.float32), 0.5) == []
+    from lsnet_amd.ops import nms
+    # tests/test_ops/test_nms.py:14-50 (test_nms_device_and_dtypes_cpu): the reference's vector, float32 and float64,
+    # ndarray and tensor
+    base = np.array([[49.1, 32.4, 51.0, 35.9, 0.1], [49.3, 32.9, 51.0, 35.3, 0.05], [35.3, 11.5, 39.9, 14.5, 0.9],
+                     [35.2, 11.7, 39.7, 15.7, 0.3]])
+    expected = np.array([[35.3, 11.5, 39.9, 14.5, 0.9], [49.1, 32.4, 51.0, 35.9, 0.1]])
+    for dt in (np.float32, np.float64):
+        kept, keep_inds = nms(base.astype(dt), 0.6)
+        assert kept.dtype == dt and np.array_equal(kept, expected.astype(dt)) and keep_inds.tolist() == [2, 0]
+        t_kept, t_inds = nms(torch.from_numpy(base.astype(dt)), 0.6)
+        assert t_kept.dtype == torch.from_numpy(base.astype(dt)).dtype and torch.equal(t_kept, torch.from_numpy(expected.astype(dt)))
+    e_dets, e_inds = nms(np.zeros((0, 5), np.float32), 0.5)
+    assert len(e_dets) == 0 and len(e_inds) == 0
     boxes = np.array([[49.1, 32.4, 51.0, 35.9, 0.9], [49.3, 32.9, 51.0, 35.3, 0.9], [35.3, 11.5, 39.9, 14.5, 0.4],
                       [35.2, 11.7, 39.7, 15.7, 0.3]], dtype=np.float32)       # test_nms.py's boxes
     groups = nms_match(boxes, 0.1)
@@ -147,3 +160,12 @@ def test_soft_nms_and_nms_match_known_answers_and_reference_library():
         want = ref.nms_match(torch.from_numpy(scores_unique), 0.3)
         got = nms_match(scores_unique, 0.3)
         assert [list(map(int, g)) for g in got] == [list(g) for g in want], n
+        # hard NMS of host tensors (nms_cpu, the CPU branch of nms_wrapper.py:33-37), float32 and float64
+        from lsnet_amd.ops import nms
+        for arr in (scores_unique, scores_unique.astype(np.float64)):
+            want_keep = ref.nms(torch.from_numpy(arr), 0.4).numpy()
+            got_dets, got_keep = nms(arr, 0.4)
+            assert got_keep.dtype == np.int64 and np.array_equal(got_keep, want_keep), (n, arr.dtype)
+            assert got_dets.dtype == arr.dtype and np.array_equal(got_dets, arr[want_keep])
+            t_dets, t_keep = nms(torch.from_numpy(arr), 0.4)
+            assert t_dets.dtype == torch.from_numpy(arr).dtype and t_keep.tolist() == want_keep.tolist()
