@@ -485,6 +485,25 @@ static bool bwd_colbuf_env()
     return v != 0;   // LSNET_BWD_GATHER=0: keep the atomic scatter kernels (A/B runs)
 }
 
+// Tap groups of the split backward-data GEMM (grid.y): the launch runs in ceil(tiles x groups / 512) rounds of the 512
+// resident blocks (2 per CU) with blocks 1 / groups as long, plus a per-block prologue (gout tile -> registers, sampling
+// table) of ~5 % of a whole tile (measured: 3 groups beat 9 on the tower launch): pick the divisor of K with the smallest
+// rounds / groups x (1 + 0.05 groups).
+static int bwd_tap_groups(const DcnArgs &a)
+{
+    static const int force = [] { const char *e = getenv("LSNET_BWD_TAP_GROUPS"); return e ? atoi(e) : 0; }();
+    const int K = a.kh * a.kw;
+    if (force > 0) return force <= K ? force : K;
+    int best = 1;
+    double best_cost = 1e30;
+    for (int g = 1; g <= K; ++g) {
+        if (K % g) continue;
+        const double cost = (double)cdiv(a.ntiles * g, 512) / g * (1.0 + 0.05 * g);
+        if (cost < best_cost - 1e-9) best_cost = cost, best = g;
+    }
+    return best;
+}
+
 template <int NP>
 static int launch_bwd_colbuf(DcnArgs &a, GatherPlan &pl, unsigned char *ws, hipStream_t st)
 {
@@ -509,7 +528,7 @@ static int launch_bwd_colbuf(DcnArgs &a, GatherPlan &pl, unsigned char *ws, hipS
     size_t lds = bwd_xn_lds_bytes(NP, a.kh * a.kw * a.dg);
     if ((g_dbg_block >> 22) & 1) lds = 100 * 1024;   // diagnostic: one workgroup per CU
     if (int rc = set_lds(dcn_bwd_data_xn_kernel<NP, true>, lds)) return rc;
-    hipLaunchKernelGGL((dcn_bwd_data_xn_kernel<NP, true>), dim3(a.ntiles), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((dcn_bwd_data_xn_kernel<NP, true>), dim3(a.ntiles, bwd_tap_groups(a)), dim3(256), lds, st, a);
     pl.ga.gcol = a.gcol, pl.ga.start = start, pl.ga.ent = ent;
     // long lists (the pyramid launch: three target levels scatter into every source level): four waves per pixel block
     static const int force_nw = [] { const char *e = getenv("LSNET_GATHER_NW"); return e ? atoi(e) : 0; }();
@@ -542,7 +561,7 @@ static int launch_bwd_data(DcnArgs &a, void *gather_ws, size_t gather_ws_bytes, 
         const size_t lds = bwd_xn_lds_bytes(np, a.kh * a.kw * a.dg);
         auto gox = [&](auto kern) -> int {
             if (int rc = set_lds(kern, lds)) return rc;
-            hipLaunchKernelGGL(kern, dim3(a.ntiles), dim3(256), lds, st, a);
+            hipLaunchKernelGGL(kern, dim3(a.ntiles, bwd_tap_groups(a)), dim3(256), lds, st, a);
             LSN_HIP(hipGetLastError());
             return 0;
         };

@@ -1315,7 +1315,12 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_xn_kernel(const DcnArgs a
     for (int e = tid; e < BWD_BM * KD * 3; e += 256) gacc[e] = 0.f;
 
     const int segs = C / a.SL, ncc = (a.SL + BK - 1) / BK;
-    const int T = K * segs * ncc;
+    // blockIdx.y of gridDim.y: this block's share of the TAPS (all chunks of taps [k_lo, k_hi)).  Every chunk writes its
+    // own slice of the column gradients and a tap's offset / mask gradients are complete inside one block, so the split
+    // needs no atomics; it exists to make the blocks short enough to fill the tail of the launch (699 tiles on 512
+    // resident blocks ran as two rounds, the second 37 % full).
+    const int k_lo = K * (int)blockIdx.y / (int)gridDim.y, k_hi = K * ((int)blockIdx.y + 1) / (int)gridDim.y;
+    const int T = (k_hi - k_lo) * segs * ncc;
     const bool want_off = (L.goff != nullptr) || (L.gmsk != nullptr);
     const bool want_gx = COLBUF ? (a.gcol != nullptr && L.gx != nullptr) : (L.gx != nullptr);
 
@@ -1370,6 +1375,7 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_xn_kernel(const DcnArgs a
     __syncthreads();
     int dbg_n = 0;
     ChunkIter<BK> it(a, 0, segs, ncc, T);
+    it.k = k_lo;   // (t counts from 0 inside the block's range)
     Chunk ch = it.get();
     issue_w(ch);
     // operand reads: row j16 (channel cl = j16) and row 16 + j16, source slot 4 s + kq -> LDS slot (4 s + kq) ^ j16
@@ -1535,7 +1541,7 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_xn_kernel(const DcnArgs a
         const int pl = e / KD, r = e - pl * KD;
         const int dgi = r / K, k = r - dgi * K;
         const int pix = tile_p + pl;
-        if (pix >= L.P) continue;
+        if (pix >= L.P || k < k_lo || k >= k_hi) continue;
         const int HWo = L.Ho * L.Wo;
         const int b = pix / HWo, rem = pix - b * HWo;
         const int ho = rem / L.Wo, wo = rem - ho * L.Wo;

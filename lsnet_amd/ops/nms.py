@@ -37,7 +37,9 @@ def _nms_host(dets, iou_thr):
     if dets.dtype not in (torch.float32, torch.float64):
         dets = dets.float()
     a = dets.detach().contiguous().numpy().reshape(-1, 5)
-    order = torch.sort(dets[:, 4], 0, descending=True)[1].numpy()
+    # stable: equal scores keep their index order, as the device kernel and the oracle do (the reference's unstable
+    # torch.sort leaves the order of exact ties unspecified)
+    order = torch.sort(dets[:, 4], dim=0, descending=True, stable=True)[1].numpy()
     keep = np.zeros(len(a), dtype=np.int64)
     i64 = C.POINTER(C.c_int64)
     if a.dtype == np.float64:

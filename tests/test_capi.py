@@ -51,7 +51,7 @@ def test_argument_checks_need_no_gpu(built_lib):
 
 
 def test_product_ops_refuse_cpu_tensors():
-    """No CPU fallback in the product: like the reference (deform_conv.py:46-47) CPU tensors raise."""
+    """No CPU fallback in the product: like the reference (deform_conv.py:46-47) CPU tensors raise in the device-only ops."""
     import torch
     from lsnet_amd import ops
     x = torch.zeros(1, 4, 5, 5)
@@ -59,5 +59,7 @@ def test_product_ops_refuse_cpu_tensors():
         ops.deform_conv(x, torch.zeros(1, 18, 5, 5), torch.zeros(4, 4, 3, 3), padding=1)
     with pytest.raises(NotImplementedError):
         ops.sigmoid_focal_loss(torch.zeros(4, 3), torch.zeros(4, dtype=torch.long))
-    with pytest.raises(NotImplementedError):
-        ops.nms(torch.zeros(3, 5), 0.5)
+    # NMS is the one op the reference itself serves on the host (nms_wrapper.py:33-37 -> nms_cpu): CPU tensors take the
+    # host library's counterpart, they never reach (or replace) the device kernel
+    dets, keep = ops.nms(torch.tensor([[0., 0., 2., 2., .9], [0., 0., 2., 2., .8], [5., 5., 6., 6., .7]]), 0.5)
+    assert keep.tolist() == [0, 2] and dets.shape == (2, 5)
