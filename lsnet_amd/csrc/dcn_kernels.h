@@ -1292,7 +1292,11 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_xn_kernel(const DcnArgs a
     const int j16 = lane & 15, kq = lane >> 4;
     const int C = a.C, Co = a.Co;   // groups == 1
 
-    const int tile = xcd_remap(blockIdx.x, a.ntiles);
+    // (tile, tap group) from the XCD-ordered linear workgroup id: the tap groups of a tile and the neighbouring tiles
+    // stay behind one L2 (they read the same grad_output rows and the same input rows)
+    const int TG = (int)gridDim.y;
+    const int work = xcd_remap((int)(blockIdx.y * gridDim.x + blockIdx.x), a.ntiles * TG);
+    const int tile = work / TG, tgi = work - tile * TG;
     const Lvl &L = find_level(a, tile);
     const int tile_p = (tile - L.tile0) * BWD_BM;
 
@@ -1315,11 +1319,11 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_xn_kernel(const DcnArgs a
     for (int e = tid; e < BWD_BM * KD * 3; e += 256) gacc[e] = 0.f;
 
     const int segs = C / a.SL, ncc = (a.SL + BK - 1) / BK;
-    // blockIdx.y of gridDim.y: this block's share of the TAPS (all chunks of taps [k_lo, k_hi)).  Every chunk writes its
+    // tap group tgi of TG (= gridDim.y): this block's share of the TAPS (all chunks of taps [k_lo, k_hi)).  Every chunk writes its
     // own slice of the column gradients and a tap's offset / mask gradients are complete inside one block, so the split
     // needs no atomics; it exists to make the blocks short enough to fill the tail of the launch (699 tiles on 512
     // resident blocks ran as two rounds, the second 37 % full).
-    const int k_lo = K * (int)blockIdx.y / (int)gridDim.y, k_hi = K * ((int)blockIdx.y + 1) / (int)gridDim.y;
+    const int k_lo = K * tgi / TG, k_hi = K * (tgi + 1) / TG;
     const int T = (k_hi - k_lo) * segs * ncc;
     const bool want_off = (L.goff != nullptr) || (L.gmsk != nullptr);
     const bool want_gx = COLBUF ? (a.gcol != nullptr && L.gx != nullptr) : (L.gx != nullptr);

@@ -24,26 +24,45 @@ def family(name):
 
 
 def read(d, counter):
-    per = defaultdict(list)
+    """[(dispatch id, kernel name, value)] of one pass, in dispatch order"""
+    rows = []
     for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
         for r in csv.DictReader(open(f)):
             if r['Counter_Name'] == counter:
-                per[r['Kernel_Name']].append((int(r['Dispatch_Id']), float(r['Counter_Value'])))
-    return {k: [v for _, v in sorted(rows)] for k, rows in per.items()}
+                rows.append((int(r['Dispatch_Id']), r['Kernel_Name'], float(r['Counter_Value'])))
+    return sorted(rows)
 
 
-fetch, write = read(fetch_dir, 'FETCH_SIZE'), read(write_dir, 'WRITE_SIZE')
+def by_launch(rows):
+    """{kernel: {'tower': [values], 'pyramid': [values]}}.  step_shapes.py replays (tower, pyramid) pairs and every
+    deformable-conv call starts with dcn_prepare_w_kernel (forward): the n-th such dispatch opens launch group n; even
+    groups are tower launches, odd ones pyramid launches.  (Kernel names no longer appear in both kinds of launch --
+    the gather has a short-list and a long-list variant -- so alternation by name is not enough.)"""
+    out = defaultdict(lambda: {'tower': [], 'pyramid': []})
+    group = -1
+    for _, name, v in rows:
+        if 'dcn_prepare_w_kernel' in name:
+            group += 1
+        if group >= 0:
+            out[name]['tower' if group % 2 == 0 else 'pyramid'].append(v)
+    return out
+
+
+fetch, write = by_launch(read(fetch_dir, 'FETCH_SIZE')), by_launch(read(write_dir, 'WRITE_SIZE'))
 if not fetch or not write:
     print('missing counter data', len(fetch), len(write))
     sys.exit(1)
 KIB = 1024 / 1e9
 fam = defaultdict(lambda: {'tower': [0.0, 0.0], 'pyramid': [0.0, 0.0]})
-print(f'{"kernel":64s} {"n":>3s} | tower: FETCHx2 + WRITE (MB) | pyramid: FETCHx2 + WRITE (MB)')
+print(f'{"kernel":64s} {"n":>3s} | tower: FETCHx2 + WRITE (MB) | pyramid: FETCHx2 + WRITE (MB)   (per launch of that kind)')
+# per launch of a kind = sum over the kernel's dispatches of that kind / number of launches of that kind
+prep = next(n for n in fetch if 'dcn_prepare_w_kernel' in n)
+n_launch = {k: max(len(fetch[prep][k]), 1) for k in ('tower', 'pyramid')}
 for name in sorted(set(fetch) | set(write)):
-    f, w = fetch.get(name, []), write.get(name, [])
-    n = max(len(f), len(w))
-    half = lambda v, odd: (sum(v[odd::2]) / max(len(v[odd::2]), 1)) if v else 0.0
-    ft, fp, wt, wp = 2 * half(f, 0), 2 * half(f, 1), half(w, 0), half(w, 1)
+    f, w = fetch.get(name, {'tower': [], 'pyramid': []}), write.get(name, {'tower': [], 'pyramid': []})
+    per = lambda v, k: sum(v[k]) / n_launch[k]
+    ft, fp, wt, wp = 2 * per(f, 'tower'), 2 * per(f, 'pyramid'), per(w, 'tower'), per(w, 'pyramid')
+    n = len(f['tower']) + len(f['pyramid'])
     print(f'{name[:64]:64s} {n:3d} | {ft * KIB * 1e3:9.1f} + {wt * KIB * 1e3:9.1f} | {fp * KIB * 1e3:9.1f} + {wp * KIB * 1e3:9.1f}')
     fa = family(name)
     if fa:

@@ -13,3 +13,5 @@ echo "bench rc $? in $(( $(date +%s) - s )) s"
 grep '^{' gpurun_out/r2_bench.log | cut -c1-1200
 bash tools/profile_bench.sh r2h 3 > gpurun_out/r2h_prof.log 2>&1
 head -24 gpurun_out/r2h_kernel_stats.txt | cut -c1-150
+bash tools/pmc_sq_step_shapes.sh r2 > gpurun_out/r2_pmc_sq_run.txt 2>&1
+grep -c . gpurun_out/r2_pmc_sq.txt
