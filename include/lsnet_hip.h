@@ -324,7 +324,8 @@ int lsn_group_norm_backward(int n_levels, const lsn_gn_level *levels, int C, int
  *   backward: dz = grad_y * [y > 0] (when relu);  grad_x = dz * gamma_c / sqrt(var_c + eps);  grad_residual = dz;
  *             grad_gamma_c = sum dz * (x - mean_c) / sqrt(var_c + eps);  grad_beta_c = sum dz
  * residual / grad_x / grad_residual / grad_gamma+grad_beta may be NULL (not needed).  grad_gamma / grad_beta are
- * OVERWRITTEN.  Supported: C % 4 == 0, 256 % (C/4) == 0 (C = 4 ... 1024); else LSN_ERR_UNSUPPORTED. */
+ * OVERWRITTEN.  Supported: C % 4 == 0 and 256 % (C/4) == 0 (C = 4 ... 1024), or C a multiple of 1024 (the 2048-channel
+ * maps of a ResNet's last stage); else LSN_ERR_UNSUPPORTED. */
 int lsn_bn_eval_act_forward(const float *x, const float *residual, float *y, const float *running_mean,
                             const float *running_var, const float *gamma, const float *beta, float eps, int relu,
                             int N, int C, lsn_stream_t stream);

@@ -311,7 +311,9 @@ constexpr int BN_PIX = 64;    // pixels per block (many small blocks: these kern
 
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const BnArgs a)
 {
-    const int qn = a.C >> 2, q = threadIdx.x % qn, row = threadIdx.x / qn, rows = 256 / qn;
+    // blockIdx.y: 1024-channel slice (C > 1024: the 2048-channel maps of a ResNet's last stage)
+    const int qb = blockIdx.y * 256, qn = min(256, (a.C >> 2) - qb);
+    const int q = qb + threadIdx.x % qn, row = threadIdx.x / qn, rows = 256 / qn;
     const float4 mu = *reinterpret_cast<const float4 *>(a.mean + q * 4);
     const float4 va = *reinterpret_cast<const float4 *>(a.var + q * 4);
     const float4 ga = *reinterpret_cast<const float4 *>(a.gamma + q * 4);
@@ -336,7 +338,9 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const BnArgs a)
 
 __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const BnArgs a)
 {
-    const int qn = a.C >> 2, q = threadIdx.x % qn, row = threadIdx.x / qn, rows = 256 / qn;
+    // blockIdx.y: 1024-channel slice (C > 1024: the 2048-channel maps of a ResNet's last stage)
+    const int qb = blockIdx.y * 256, qn = min(256, (a.C >> 2) - qb);
+    const int q = qb + threadIdx.x % qn, row = threadIdx.x / qn, rows = 256 / qn;
     const float4 mu = *reinterpret_cast<const float4 *>(a.mean + q * 4);
     const float4 va = *reinterpret_cast<const float4 *>(a.var + q * 4);
     const float4 ga = *reinterpret_cast<const float4 *>(a.gamma + q * 4);
@@ -378,7 +382,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const BnArgs a)
             for (int j = 0; j < 8; ++j) t[j] += red[(r * qn + threadIdx.x) * 8 + j];
         // per-block partials, summed by bn_param_reduce_kernel: thousands of blocks adding atomically to the same
         // 2 C addresses cost more than the streaming pass itself (C = 64: 230 us against 50 us of traffic)
-        float *dst = a.part + (size_t)blockIdx.x * 2 * a.C + threadIdx.x * 4;
+        float *dst = a.part + (size_t)blockIdx.x * 2 * a.C + (qb + threadIdx.x) * 4;
         *reinterpret_cast<float4 *>(dst) = make_float4(t[0] * r0, t[1] * r1, t[2] * r2, t[3] * r3);
         *reinterpret_cast<float4 *>(dst + a.C) = make_float4(t[4], t[5], t[6], t[7]);
     }
@@ -406,8 +410,8 @@ static int bn_check(int N, int C)
 {
     LSN_CHECK(N > 0 && C > 0, "batch norm: empty tensor");
     const int qn = C / 4;
-    if (C % 4 != 0 || qn > 256 || 256 % qn != 0)
-        return fail(LSN_ERR_UNSUPPORTED, "batch norm kernel needs C in {4..1024} with 256 %% (C/4) == 0, got %d", C);
+    if (C % 4 != 0 || (qn <= 256 ? 256 % qn != 0 : qn % 256 != 0))
+        return fail(LSN_ERR_UNSUPPORTED, "batch norm kernel needs C in {4..1024} with 256 %% (C/4) == 0, or a multiple of 1024, got %d", C);
     return 0;
 }
 
@@ -486,7 +490,7 @@ int lsn_bn_eval_act_forward(const float *x, const float *residual, float *y, con
     BnArgs a = {};
     a.x = x, a.res = residual, a.y = y, a.mean = running_mean, a.var = running_var, a.gamma = gamma, a.beta = beta;
     a.eps = eps, a.N = N, a.C = C, a.relu = relu;
-    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3((N + BN_PIX - 1) / BN_PIX), dim3(256), 0,
+    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3((N + BN_PIX - 1) / BN_PIX, (C / 4 + 255) / 256), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), a);
     LSN_HIP(hipGetLastError());
     return 0;
@@ -520,7 +524,7 @@ int lsn_bn_eval_act_backward(const float *grad_y, const float *y, const float *x
         LSN_HIP(hipMemsetAsync(grad_gamma, 0, sizeof(float) * C, st));
         LSN_HIP(hipMemsetAsync(grad_beta, 0, sizeof(float) * C, st));
     }
-    hipLaunchKernelGGL(bn_act_bwd_kernel, dim3(blocks), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(bn_act_bwd_kernel, dim3(blocks, (C / 4 + 255) / 256), dim3(256), 0, st, a);
     if (grad_gamma) {
         const int splits = blocks >= 512 ? 16 : (blocks >= 64 ? 4 : 1);
         hipLaunchKernelGGL(bn_param_reduce_kernel, dim3((2 * C + 255) / 256, splits), dim3(256), 0, st, a, blocks);

@@ -68,7 +68,7 @@ def _hip_ok(bn, x, residual):
                                      and residual.is_contiguous(memory_format=_CL)):
         return False
     C = x.shape[1]
-    return C % 4 == 0 and C // 4 <= 256 and 256 % (C // 4) == 0
+    return C % 4 == 0 and (256 % (C // 4) == 0 if C <= 1024 else C % 1024 == 0)
 
 
 def bn_act(bn, x, relu=False, residual=None):

@@ -593,7 +593,8 @@ def test_conv2d_module_dispatch():
 # ---------------------------------------------------------------------------------- frozen BN + add + ReLU
 @pytest.mark.gpu
 @pytest.mark.parametrize('C,shape,relu,res', [(64, (2, 40, 52), True, False), (256, (2, 25, 42), True, True),
-                                               (1024, (1, 13, 21), False, False), (512, (2, 9, 7), True, True)])
+                                               (1024, (1, 13, 21), False, False), (512, (2, 9, 7), True, True),
+                                               (2048, (2, 7, 11), True, True), (2048, (1, 5, 9), False, False)])
 def test_bn_eval_act_matches_torch(C, shape, relu, res):
     from lsnet_amd.ops.batch_norm import bn_act
     torch.manual_seed(4)
