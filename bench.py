@@ -270,11 +270,16 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
     assert torch.cuda.is_available(), 'bench.py measures the HIP path: a GPU is required'
+    # one process per GPU.  (LSNET_BENCH_BACKEND=gloo with more ranks than GPUs is the self-test of the N > 1 code path
+    # on a single-GPU box: ranks then share a device and the gradients travel through the host.)
+    backend = os.environ.get('LSNET_BENCH_BACKEND', 'nccl')
+    if backend != 'nccl':
+        local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl')
+        dist.init_process_group(backend)
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
 
     from lsnet_amd.data import synthetic_batch
