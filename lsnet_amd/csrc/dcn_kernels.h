@@ -1704,7 +1704,10 @@ __global__ __launch_bounds__(256) void dcn_sort_lists_kernel(int nanchors, const
 // pixel-by-pixel gather reads (measured before: the gather fetched 3.7 x the column-gradient buffer from the fabric).
 // Fixed order: anchors row-major, entries by sample id.
 constexpr int GT = 4;   // block edge
-constexpr int GU = 4;   // column-gradient rows a wave keeps in flight
+#ifndef LSN_GU4
+#define LSN_GU4 4   // (8 measured: the 25-list walk no longer unrolls, backward-data family 1.07 -> 2.07 ms)
+#endif
+constexpr int GU1 = 4, GU4 = LSN_GU4;   // column-gradient rows a wave keeps in flight (NW = 1, NW = 4)
 // NW = 1: one wave per 4x4 pixel block (four blocks per workgroup) -- short lists, e.g. the tower launch with ~140 entries
 //   per block (measured: 152 us against 186 us for NW = 4).
 // NW = 4: one workgroup per pixel block.  Its four waves share the block's entries -- wave w takes every 4th group of GU
@@ -1714,6 +1717,7 @@ constexpr int GU = 4;   // column-gradient rows a wave keeps in flight
 template <int NW>
 __global__ __launch_bounds__(256) void dcn_gather_kernel(const GatherArgs ga)
 {
+    constexpr int GU = NW == 4 ? GU4 : GU1;
     __shared__ float4 red[NW == 4 ? 2 : 1][NW == 4 ? GT * GT : 1][NW == 4 ? 64 : 1];   // NW = 4: 32 KB
     const int lane = threadIdx.x & 63, wave_id = threadIdx.x >> 6;
     const int wave = NW == 4 ? wave_id : 0;   // position among the waves that share a pixel block
