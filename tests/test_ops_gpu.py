@@ -116,7 +116,9 @@ def _to(t, dev, cl):
 
 KERNEL_CHOICES = {
     # name: (math mode, debug word).  Bit 23: atomic scatter instead of the anchor-list gather; bits 25 / 24: force the
-    # first / the windowed backward-data kernel (lsn_debug_phase_clocks)
+    # first / the windowed backward-data kernel (lsn_debug_phase_clocks).  The split weight-gradient kernel reads the
+    # same two bits as "scalar loads" / "compute the sampling table instead of copying the launch-wide one", so those two
+    # choices also cover its fallback paths.
     'default': ('bf16x6', 0),                       # fp32-equivalent products, atomic-free grad_input
     'x6_atomic': ('bf16x6', 1 << 23),
     'x3_gather': ('bf16x3', 0),
