@@ -1,20 +1,21 @@
-// Dense 2-D convolution (groups = 1) on channels-last fp32 tensors as an implicit GEMM on the bf16 matrix pipe
-// with split operands (common.h: a*b = a_hi*b_hi + a_hi*b_lo + a_lo*b_hi, fp32 accumulation).
+// Dense 2-D convolution (groups = 1) on channels-last fp32 tensors as an implicit GEMM on the bf16 matrix pipe with
+// split operands (common.h: NP = 6 products of exact 3-way bf16 splits = fp32-equivalent, the default; NP = 3 products
+// of 2-way splits), fp32 accumulation.
 //
 // The reference runs torch.nn.Conv2d = cuDNN for every dense conv of the path (backbone resnet.py:624-631,
 // 261-301; neck fpn.py:171-217; head lsnet_head.py:160-257).  On MI355X fp32 MFMA runs at the fp32 vector rate
-// (157 TF, 1/16 of the bf16 rate), so an exact-fp32 GEMM tops out near 100 TF in practice (MIOpen's igemm kernels
-// measure 38-117 TF on these shapes, tools/bench_convs.py).  This kernel keeps fp32 tensors in memory, splits
-// both operands into bf16 hi/lo pairs while staging them into LDS and issues three bf16 MFMAs per product term:
-// 2^-16 relative error per product (parity bar of the path: 1e-3), 24 MFMAs of 32 cycles per 64x64x32 wave tile.
+// (157 TF, 1/16 of the bf16 rate), so an exact-fp32 GEMM tops out near 100 TF in practice (the vendor igemm kernels
+// measure 38-117 TF on these shapes, tools/bench_convs.py).  This kernel keeps fp32 tensors in memory and splits both
+// operands into bf16 planes while staging them into LDS (weights once per call: conv_prepare_kernel).
 //
-//   forward      : out[p][co] = sum_{tap, ci} x[p @ tap][ci] * w[co][tap][ci] (+ bias)
-//   backward-data: the same kernel on grad_output with the weights transposed and flipped (stride 1)
-//   backward-weight: conv_wgrad_x3_kernel, reduction over pixels with px-contiguous LDS images
+//   forward      : out[p][co] = sum_{tap, ci} x[p @ tap][ci] * w[co][tap][ci] (+ bias, ReLU); up to 8 maps per launch
+//   backward-data: the same kernel on grad_output with the weights transposed and flipped; a stride-s convolution is
+//                  s x s stride-1 convolutions over tap subsets (TapSub), each writing its residue class of input pixels
+//   backward-weight: dcn_wgrad_xn_kernel<PLAIN = true> (dcn_kernels.h), reduction over pixels with px-contiguous LDS images
 //
 // Tiling: block = BM output pixels x BN output channels, BM + BN = 320, four waves each owning a 64x64 tile
 // (1x4, 2x2 or 4x1 waves); chunk = one tap x 32 input channels; software pipeline over chunks exactly as
-// dcn_fwd_x3_kernel: MFMAs of chunk t, LDS commit of chunk t+1, global-load issue of chunk t+2, one staging
+// dcn_fwd_xn_kernel: MFMAs of chunk t, LDS commit of chunk t+1, global-load issue of chunk t+2, one staging
 // slice in every MFMA gap.  LDS rows are 32 bf16 + 16 B pad (80 B) so the 16-byte operand reads are conflict free.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -50,7 +51,16 @@ struct ConvArgs {
     // (OH, OW) map.  ostep = 0: the dense case (OH = Ho, OW = Wo).  Used by the strided backward-data pass, which
     // computes each residue class of input pixels as its own stride-1 convolution over a subset of the taps.
     int ostep, oy0, ox0, OH, OW;
+    long long *dbg;   // optional phase timestamps of block dbg_block, thread 0 (lsn_debug_phase_clocks)
+    int dbg_block;
 };
+
+#define CV_STAMP(slot)                                                                                            \
+    do {                                                                                                          \
+        if (a.dbg != nullptr && blockIdx.x == (unsigned)(a.dbg_block & 0xfffff) && blockIdx.y == 0 &&             \
+            blockIdx.z == 0 && threadIdx.x == 0 && dbg_n < 512)                                                    \
+            a.dbg[dbg_n++] = ((long long)(slot) << 56) | (clock64() & 0x00ffffffffffffffll);                       \
+    } while (0)
 
 constexpr int CV_RS = 80;   // LDS row stride in bytes
 
@@ -81,6 +91,7 @@ __global__ __launch_bounds__(256, 1) void conv_fwd_xn_kernel(const ConvArgs a)
     constexpr int NPA = BM / 16, NPB = PREP ? NPL * (BN / 64) : BN / 32, NS = NPA + NPB;   // staging slices per chunk
     constexpr int PLANE_A = BM * RS, PLANE_B = BN * RS, BUF = NPL * (PLANE_A + PLANE_B);
     constexpr int NGAP = 2 * NP * 4;
+    constexpr int NSLOT = 4 * NPA + 2 * NPB;   // micro-slots of a chunk's staging: 4 per pixel slice, 2 per weight slice
     extern __shared__ __align__(16) unsigned char smem[];   // 2 x [A planes][B planes]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -125,6 +136,22 @@ __global__ __launch_bounds__(256, 1) void conv_fwd_xn_kernel(const ConvArgs a)
         iy0[ps] = ok ? ho * a.stride - a.pad_h : -0x40000000;   // an invalid pixel is out of range for every tap
         ix0[ps] = wo * a.stride - a.pad_w;
         ibase[ps] = b * L.H * L.W;
+    }
+    // For the pipelined loop: byte offset of the pass's pixel at tap (0, 0), channel pair kk2, and one validity bit per
+    // tap (kh * kw <= 64: checked by the host).  A chunk then costs one add and one bit test per slice instead of the
+    // coordinate arithmetic above.
+    int pbase[NPA];
+    unsigned long long vmask[NPA];
+#pragma unroll
+    for (int ps = 0; ps < NPA; ++ps) {
+        pbase[ps] = ((ibase[ps] + iy0[ps] * L.W + ix0[ps]) * a.xpitch + 2 * kk2) * 4;
+        unsigned long long m = 0;
+        for (int i = 0; i < a.kh; ++i)
+            for (int j = 0; j < a.kw; ++j) {
+                const int y = iy0[ps] + i * a.dil, x = ix0[ps] + j * a.dil;
+                if ((unsigned)y < (unsigned)L.H && (unsigned)x < (unsigned)L.W) m |= 1ull << (i * a.kw + j);
+            }
+        vmask[ps] = m;
     }
     int wvoff[NPB];
 #pragma unroll
@@ -188,6 +215,44 @@ __global__ __launch_bounds__(256, 1) void conv_fwd_xn_kernel(const ConvArgs a)
         for (int q = 0; q < NPL; ++q) *reinterpret_cast<uint2 *>(p + q * PLANE_B) = make_uint2(p0[q], p1[q]);
     };
 
+    // ---- the same staging cut into micro-slots of <= ~6 instructions for the MFMA gaps of the pipelined loop ----------
+    // A wave owns its SIMD alone (one workgroup per CU), so whatever does not fit into the 32-cycle shadow of an MFMA
+    // stalls the matrix pipe: tools/phase_clocks.py conv measured 1.64 k cycles for the 48 MFMAs of a chunk alone and
+    // 2.8 k with one whole (commit + issue) slice per gap.  Pixel slice ps = 4 slots: split step A (hi plane + residual),
+    // split step B (mid / lo planes), the LDS writes, address + load of chunk t+2; weight slice = 2 slots.
+    unsigned sp_h = 0, sp_m = 0, sp_l = 0;
+    float sp_r0 = 0.f, sp_r1 = 0.f;
+    int tap2 = 0, toff2 = 0, clim2 = 0;   // chunk t+2: tap index, byte offset of (tap, channel slab), valid channels
+    auto chunk_scalars = [&](const Ck &c) {
+        tap2 = c.i * a.kw + c.j;
+        toff2 = ((c.i * a.dil * L.W + c.j * a.dil) * a.xpitch + c.cc * BK) * 4;
+        clim2 = a.C - c.cc * BK;
+    };
+    auto micro_x = [&](int ps, int part, unsigned char *buf) {
+        if (part == 0) {
+            const bf16x2 h = {(__bf16)xv[ps].x, (__bf16)xv[ps].y};
+            sp_h = __builtin_bit_cast(unsigned, h);
+            sp_r0 = xv[ps].x - __uint_as_float(sp_h << 16);
+            sp_r1 = xv[ps].y - __uint_as_float(sp_h & 0xffff0000u);
+        } else if (part == 1) {
+            const bf16x2 m = {(__bf16)sp_r0, (__bf16)sp_r1};
+            sp_m = __builtin_bit_cast(unsigned, m);
+            if constexpr (NPL == 3) {
+                const float s0 = sp_r0 - __uint_as_float(sp_m << 16), s1 = sp_r1 - __uint_as_float(sp_m & 0xffff0000u);
+                const bf16x2 l = {(__bf16)s0, (__bf16)s1};
+                sp_l = __builtin_bit_cast(unsigned, l);
+            }
+        } else if (part == 2) {
+            unsigned char *p = buf + (ps * 16 + prow) * RS + kk2 * 4;
+            *reinterpret_cast<unsigned *>(p) = sp_h;
+            *reinterpret_cast<unsigned *>(p + PLANE_A) = sp_m;
+            if constexpr (NPL == 3) *reinterpret_cast<unsigned *>(p + 2 * PLANE_A) = sp_l;
+        } else {
+            const bool ok = ((vmask[ps] >> tap2) & 1ull) != 0 && 2 * kk2 < clim2;
+            xv[ps] = cv_load2(xrs, ok ? pbase[ps] + toff2 : OOB, 0);
+        }
+    };
+
     // leading product h*h in acc, the small products in accl (added once at the end): the fp32 rounding of the large
     // running sum is then paid once per 16 k-values, not once per product term
     f32x16 acc[2][2], accl[2][2];
@@ -226,13 +291,16 @@ __global__ __launch_bounds__(256, 1) void conv_fwd_xn_kernel(const ConvArgs a)
     }
     __syncthreads();
 
+    int dbg_n = 0;
     for (int t = 0; t < T; ++t) {
+        CV_STAMP(2);
         const int cur = t & 1;
         const unsigned char *bc = smem + cur * BUF;
         unsigned char *bn = smem + (cur ^ 1) * BUF;
         // registers hold chunk t+1 (to commit); c2 = chunk t+2 (to issue); both saturate at the last chunk
         const unsigned char *ap = bc + (wm * 64 + (lane & 31)) * RS + (lane >> 5) * 16;
         const unsigned char *bp = bc + NPL * PLANE_A + (wn * 64 + (lane & 31)) * RS + (lane >> 5) * 16;
+        chunk_scalars(c2);
         bf16x8 Af[2][2][NPL], Bf[2][2][NPL];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -243,6 +311,10 @@ __global__ __launch_bounds__(256, 1) void conv_fwd_xn_kernel(const ConvArgs a)
                     Af[ks][i][q] = *reinterpret_cast<const bf16x8 *>(ap + q * PLANE_A + i * 32 * RS + ks * 32);
                     Bf[ks][i][q] = *reinterpret_cast<const bf16x8 *>(bp + q * PLANE_B + i * 32 * RS + ks * 32);
                 }
+        if (a.dbg != nullptr) {
+            __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): diagnostic only (operand reads landed)
+            CV_STAMP(5);
+        }
         // NGAP MFMAs, NS staging slice pairs (commit, issue) spread over the gaps
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -257,21 +329,24 @@ __global__ __launch_bounds__(256, 1) void conv_fwd_xn_kernel(const ConvArgs a)
                     else
                         accl[i][j] = mfma_bf16(Af[ks][i][SC::pa(prod)], Bf[ks][j][SC::pb(prod)], accl[i][j]);
                     __builtin_amdgcn_sched_barrier(0);
-                    // slices s in [gap*NS/NGAP, (gap+1)*NS/NGAP): x slices first, then weight slices
+                    // micro-slots [gap * NSLOT / NGAP, (gap + 1) * NSLOT / NGAP) of the staging (see micro_x)
+#ifndef CV_ABLATE_STAGING   // (diagnostic builds: the MFMA block alone, tools/phase_clocks.py conv)
 #pragma unroll
-                    for (int s = gap * NS / NGAP; s < (gap + 1) * NS / NGAP; ++s) {
-                        if (s < NPA) {
-                            commit_x(s, bn);
-                            issue_x(c2, s);
+                    for (int s = gap * NSLOT / NGAP; s < (gap + 1) * NSLOT / NGAP; ++s) {
+                        if (s < 4 * NPA) {
+                            micro_x(s >> 2, s & 3, bn);
                         } else {
-                            commit_w(s - NPA, bn);
-                            issue_w(c2, s - NPA);
+                            const int sw = s - 4 * NPA;
+                            if ((sw & 1) == 0) commit_w(sw >> 1, bn); else issue_w(c2, sw >> 1);
                         }
                     }
+#endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
         if (t + 3 < T) next(c2);
+        CV_STAMP(6);
         __syncthreads();
+        CV_STAMP(7);
     }
 
 #pragma unroll
@@ -352,6 +427,7 @@ __global__ void conv_prepare_kernel(const float *w, unsigned short *out, int Co,
     }
 }
 
+void dbg_state(long long **buf, int *block);   // dcn.hip: lsn_debug_phase_clocks
 int split_np();   // dcn.hip: bf16 products per fp32 product of the current math mode (0: exact fp32)
 static int conv_np() { return split_np() == 3 ? 3 : 6; }   // these kernels have no fp32-MFMA variant: exact mode gets x6
 
@@ -377,6 +453,7 @@ static int launch_conv_np(ConvArgs &a, hipStream_t st)
         if (ks < 1) ks = 1;
     }
     a.ksplit = ks;
+    dbg_state(&a.dbg, &a.dbg_block);
     if (ks > 1)
         for (int i = 0; i < a.nlv; ++i)
             LSN_HIP(hipMemsetAsync(a.lv[i].out, 0, sizeof(float) * (size_t)a.lv[i].P * a.Co, st));
@@ -431,6 +508,7 @@ static int conv_check(int B, int H, int W, int C, int Co, int kh, int kw, int st
     LSN_CHECK(B > 0 && H > 0 && W > 0 && C > 0 && Co > 0 && kh > 0 && kw > 0, "conv2d: empty tensor");
     LSN_CHECK(stride > 0 && dil > 0 && pad >= 0, "conv2d: bad stride / dilation / padding");
     if (C % 4 != 0) return fail(LSN_ERR_UNSUPPORTED, "conv2d kernel needs C %% 4 == 0, got %d", C);
+    if (kh * kw > 64) return fail(LSN_ERR_UNSUPPORTED, "conv2d kernel takes at most 64 taps, got %d x %d", kh, kw);
     *Ho = conv_out_size(H, kh, stride, pad, dil);
     *Wo = conv_out_size(W, kw, stride, pad, dil);
     LSN_CHECK(*Ho > 0 && *Wo > 0, "conv2d: output size is too small");

@@ -45,6 +45,7 @@ static int math_mode()
 // bf16 products per fp32 product of the current mode (0: exact fp32 MFMA)
 static int math_np() { return math_mode() == LSN_MATH_BF16X6 ? 6 : (math_mode() == LSN_MATH_BF16X3 ? 3 : 0); }
 int split_np() { return math_np(); }
+void dbg_state(long long **buf, int *block) { *buf = g_dbg_buf, *block = g_dbg_block; }
 
 // ---- per-kernel launch timing (lsn_prof_*): HIP events recorded on the launch stream around each
 // deformable-conv kernel, so bench.py can quote a kernel's own average duration live.

@@ -229,7 +229,7 @@ def hip_conv_ok(x, weight, stride, padding, dilation, groups, padding_mode='zero
         return False
     if stride[0] != stride[1] or padding[0] != padding[1] or dilation[0] != dilation[1]:
         return False
-    if x.numel() * 4 >= 2 ** 31 or weight.numel() * 8 >= 2 ** 31:
+    if x.numel() * 4 >= 2 ** 31 or weight.numel() * 8 >= 2 ** 31 or weight.shape[2] * weight.shape[3] > 64:
         return False
     return _lib.split_math()
 

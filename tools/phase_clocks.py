@@ -56,6 +56,15 @@ if len(sys.argv) > 1 and sys.argv[1] == 'wg':
     need_w = dict(input=[False] * 5, offset=[False] * 5, mask=[False] * 5, weight=True, bias=True)
     for blk in (0, 17):
         run(lambda: be.dcn_backward(xs, offs, msks, w, gos, cfg, need_w), blk, 'weight gradient (split kernel)')
+elif len(sys.argv) > 1 and sys.argv[1] == 'conv':
+    # dense conv kernel: 2 loop top, 5 operand reads of the chunk landed, 6 MFMAs + staging slices done, 7 barrier
+    from lsnet_amd.ops.conv import conv2d
+    for name, ci, co, k, hw in (('head 3x3 256->256 P3', 256, 256, 3, (100, 168)), ('l1 1x1 64->256', 64, 256, 1, (200, 336)),
+                                ('l3 3x3 256->256', 256, 256, 3, (50, 84)), ('l2 3x3 128->128', 128, 128, 3, (100, 168))):
+        xc = torch.randn(2, ci, *hw, device=dev).contiguous(memory_format=cl)
+        wc = (torch.randn(co, ci, k, k, device=dev) * 0.05).contiguous(memory_format=cl)
+        with torch.no_grad():
+            run(lambda: conv2d(xc, wc, None, 1, k // 2), 17, 'conv forward ' + name)
 elif len(sys.argv) > 1 and sys.argv[1] == 'wgab':
     # weight gradient inside a full backward call (the backward-data pass leaves its sampling table for it):
     # bit 24 = ignore that table, bit 25 = scalar loads
