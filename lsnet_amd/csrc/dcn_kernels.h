@@ -742,8 +742,9 @@ __global__ __launch_bounds__(256, 1) void dcn_fwd_xn_kernel(const DcnArgs a)
     constexpr int NPA = BM / 16;                       // 4 gather passes (2 channels per thread)
     constexpr int NPB = PREP ? NPL * (BN / 64) : BN / 32;   // weight slices of 256 threads x 16 B
     constexpr int PLANE_A = BM * RS, PLANE_B = BN * RS, BUF = NPL * (PLANE_A + PLANE_B);
-    constexpr int NGAP = 2 * NP * 4, NSLOT = 2 * (NPA + NPB);
-    static_assert(NSLOT <= NGAP, "one staging slot per MFMA gap at most");
+    // micro-slots of a chunk's staging: 5 per pixel slice (blend, split A, split B, LDS writes, loads of chunk t+2),
+    // 2 per weight slice; spread over the NGAP gaps between the MFMAs (see staging_slot)
+    constexpr int NGAP = 2 * NP * 4, NSLOT = 5 * NPA + 2 * NPB;
     extern __shared__ __align__(16) unsigned char smem[];
     Tap *tab = reinterpret_cast<Tap *>(smem + 2 * BUF);   // [BM][K*dg]
 
@@ -855,17 +856,48 @@ __global__ __launch_bounds__(256, 1) void dcn_fwd_xn_kernel(const DcnArgs a)
 #pragma unroll
         for (int q = 0; q < NPL; ++q) *reinterpret_cast<uint2 *>(p + q * PLANE_B) = make_uint2(p0[q], p1[q]);
     };
-    // staging slot s of a chunk: x slices first (commit, then the issue that reuses the registers just consumed),
-    // then the weight slices
+    // Staging slot s of a chunk.  The wave owns its SIMD alone, so what does not fit into the 32-cycle shadow of an
+    // MFMA stalls the matrix pipe (dense-conv kernel, tools/phase_clocks.py conv: 48 MFMAs alone 1.64 k cycles, 2.8 k
+    // with whole slices in the gaps, 1.9 k with micro-slots).  A pixel slice is therefore cut into five slots of a few
+    // instructions -- bilinear blend, split step A (hi plane + residual), split step B (mid / lo planes), the LDS
+    // writes, the four corner loads of chunk t+2 into the registers just consumed -- then the weight slices
+    // (commit, issue).
+    float sp_v0 = 0.f, sp_v1 = 0.f, sp_r0 = 0.f, sp_r1 = 0.f;
+    unsigned sp_h = 0, sp_m = 0, sp_l = 0;
     auto staging_slot = [&](int s, const Chunk &c1, const Chunk &c2, unsigned char *bn) {
-        if (s < 2 * NPA) {
-            if ((s & 1) == 0)
-                commit_x(c1, s >> 1, bn);
-            else
-                issue_x(c2, s >> 1);
+        if (s < 5 * NPA) {
+            const int ps = s / 5, part = s - 5 * ps;
+            if (part == 0) {
+                const float v0 = wgtC[ps][0] * xv[ps][0].x + wgtC[ps][1] * xv[ps][1].x + wgtC[ps][2] * xv[ps][2].x +
+                                 wgtC[ps][3] * xv[ps][3].x;
+                const float v1 = wgtC[ps][0] * xv[ps][0].y + wgtC[ps][1] * xv[ps][1].y + wgtC[ps][2] * xv[ps][2].y +
+                                 wgtC[ps][3] * xv[ps][3].y;
+                sp_v0 = (2 * kk2 < c1.nval) ? v0 : 0.f;
+                sp_v1 = (2 * kk2 + 1 < c1.nval) ? v1 : 0.f;
+            } else if (part == 1) {
+                const bf16x2 h = {(__bf16)sp_v0, (__bf16)sp_v1};
+                sp_h = __builtin_bit_cast(unsigned, h);
+                sp_r0 = sp_v0 - __uint_as_float(sp_h << 16);
+                sp_r1 = sp_v1 - __uint_as_float(sp_h & 0xffff0000u);
+            } else if (part == 2) {
+                const bf16x2 m = {(__bf16)sp_r0, (__bf16)sp_r1};
+                sp_m = __builtin_bit_cast(unsigned, m);
+                if constexpr (NPL == 3) {
+                    const float s0 = sp_r0 - __uint_as_float(sp_m << 16), s1 = sp_r1 - __uint_as_float(sp_m & 0xffff0000u);
+                    const bf16x2 l = {(__bf16)s0, (__bf16)s1};
+                    sp_l = __builtin_bit_cast(unsigned, l);
+                }
+            } else if (part == 3) {
+                unsigned char *p = bn + ps * 16 * RS + xcommit;
+                *reinterpret_cast<unsigned *>(p) = sp_h;
+                *reinterpret_cast<unsigned *>(p + PLANE_A) = sp_m;
+                if constexpr (NPL == 3) *reinterpret_cast<unsigned *>(p + 2 * PLANE_A) = sp_l;
+            } else {
+                issue_x(c2, ps);
+            }
         } else {
-            const int ps = (s - 2 * NPA) >> 1;
-            if ((s & 1) == 0)
+            const int sw = s - 5 * NPA, ps = sw >> 1;
+            if ((sw & 1) == 0)
                 commit_w(c1, ps, bn);
             else
                 issue_w(c2, ps);
