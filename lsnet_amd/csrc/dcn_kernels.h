@@ -1245,16 +1245,18 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_kernel(const DcnArgs a)
 }
 
 // =============================================================================================
-// Backward-data on the bf16 matrix pipe (dcn_bwd_data_x3_kernel), groups = 1.
+// Backward-data on the bf16 matrix pipe (dcn_bwd_data_xn_kernel<NP, COLBUF>), groups = 1.
 //
-// dcn_bwd_data_kernel with (1) the column-gradient GEMM as split-bf16 products on v_mfma_f32_16x16x32_bf16 -- the
-// gout rows are split once per tile into bf16 hi/lo registers, the weight slab of a chunk comes from planes that
-// dcn_prepare_wt_kernel has split AND transposed to [tap][ci][co] (co contiguous = the MFMA k index), so its staging
-// is a plain 16-byte copy -- and (2) a scatter that merges before it adds: the 4 pixels a lane owns are x-adjacent,
-// so for smooth offset fields the right corner of one is the left corner of the next; equal addresses are summed in
-// registers and zero contributions (integer offsets) are dropped.  The comparison is uniform over the 16 channel
-// lanes of a pixel group, so every skipped add removes a whole 64-byte atomic transaction.
-// =============================================================================================
+// The column-gradient GEMM of dcn_bwd_data_kernel as split-bf16 products on v_mfma_f32_16x16x32_bf16: the gout rows are
+// split once per tile into bf16 plane registers, the weight slab of a chunk comes from planes that
+// dcn_prepare_wt_kernel has split AND transposed to [tap][ci][co] (co contiguous = the MFMA k index) and is DMA'd
+// into LDS (buffer_load ... lds; rows unpadded, 16-byte slots XOR-swizzled on the source side).
+// COLBUF = true (default, see "grad_input without atomics" below): the mask-weighted column gradient is stored once
+// per element into a.gcol and grad_input is produced by dcn_gather_kernel; the epilogue keeps only the four corner
+// sums H = sum_c colgrad[c] x[corner, c] for the offset / mask gradients.
+// COLBUF = false: the merged atomic scatter of round 1 -- the 4 pixels a lane owns are x-adjacent, equal corner
+// addresses are summed in registers before one fp32 atomic per run (exact-mode / A/B runs: LSNET_BWD_GATHER=0).
+// grid.y = tap groups: see the kernel.
 constexpr int BX3_RS = 528;   // bytes per LDS row of the transposed weight slab: 256 co x 2 B + 16 B pad
 
 
@@ -2692,12 +2694,13 @@ __global__ __launch_bounds__(256, 2) void dcn_wgrad_kernel(const DcnArgs a, int 
 // =============================================================================================
 // Backward-weight on the bf16 matrix pipe with split operands (dcn_wgrad_xn_kernel).
 //
-// Same decomposition as dcn_wgrad_kernel (grid = column blocks x pixel splits x 256-co blocks, 32-pixel steps,
-// fp32 atomics into gw at the end).  The reduction index of this GEMM is the PIXEL, so both LDS images are built
-// pixel-contiguous -- As[co][32 px], Bs[kcol][32 px], bf16 hi and lo planes, 80-byte rows -- to give every lane
-// the 8 consecutive k-values v_mfma_f32_32x32x16_bf16 wants: a thread owns one output channel (gout column) resp.
-// one (channel, 8-pixel group) of the gathered columns, splits its values in registers and writes whole 16-byte
-// row pieces.  24 MFMAs of 32 cycles per step and wave instead of 64 of 64.
+// Same decomposition as dcn_wgrad_kernel (grid = column blocks x pixel splits x co blocks, 32-pixel steps, fp32 atomics
+// into gw at the end).  The reduction index of this GEMM is the PIXEL, so both LDS images are built pixel-contiguous
+// -- As[co][32 px], Bs[kcol][32 px], NPL bf16 planes each (2 or 3), 80-byte rows -- to give every lane the 8
+// consecutive k-values v_mfma_f32_32x32x16_bf16 wants.  A thread owns two adjacent output channels x 16 pixels of
+// grad_output and two adjacent channels x 4 pixels of the gathered columns (8-byte buffer loads, out-of-range rows read
+// as zero), splits its values in registers and writes 16- resp. 8-byte row pieces.  48 (24) bf16 MFMAs per step and wave.
+// The step's sampling table comes from the launch-wide table of the backward-data pass when there is one (a.gtap).
 // PLAIN: a dense convolution (no offsets, no mask): one load per sample instead of four corners.
 // =============================================================================================
 template <int NP, int BMW = WG_BM>
