@@ -123,6 +123,31 @@ def test_conv_bn_gn_modules_are_aten_on_cpu():
     assert torch.allclose(bn_act(bn, x, relu=True, residual=r), F.relu(bn(x) + r))
 
 
+def test_device_only_dispatch_predicates_are_false_on_cpu():
+    """Grouped convolution, the fused cross-IOU rows and the frozen-BN kernel are device paths: on CPU tensors the modules
+    keep ATen / the torch formulation (the reference's own operators), and the shape rules of the kernels are what the
+    header documents."""
+    import torch.nn.functional as F
+    from lsnet_amd.models.losses import CrossIOULoss
+    from lsnet_amd.ops import cross_iou as fused
+    from lsnet_amd.ops.batch_norm import _hip_ok
+    from lsnet_amd.ops.conv import Conv2d, hip_group_conv_ok
+    torch.manual_seed(3)
+    x = torch.randn(1, 256, 9, 11).contiguous(memory_format=torch.channels_last)
+    conv = Conv2d(256, 256, 3, padding=1, groups=64, bias=False)
+    assert not hip_group_conv_ok(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups)
+    assert torch.equal(conv(x), F.conv2d(x, conv.weight, None, 1, 1, 1, 64))
+    pred, target = torch.rand(6, 148) + 0.1, torch.rand(6, 148)
+    assert not fused.rows_usable(pred, target, 'polygon') and not fused.usable(pred[:, :20], target[:, :20], 'bbox')
+    active = torch.zeros(6, 148, dtype=torch.bool)
+    active[:, 0::2] = True
+    loss = CrossIOULoss(loss_type='polygon')(pred, target, anchor_pts=torch.rand(6, 2), bbox_gt=torch.rand(6, 4) + 1,
+                                             pos_inds=active)
+    assert torch.isfinite(loss)
+    bn = torch.nn.BatchNorm2d(2048).eval()
+    assert not _hip_ok(bn, torch.randn(1, 2048, 3, 3).contiguous(memory_format=torch.channels_last), None)   # CPU tensor
+
+
 def test_resnet_block_equals_reference_sequence():
     """Bottleneck with the fused bn_act calls == conv/bn/relu/add written out (CPU: ATen both ways)."""
     import torch.nn.functional as F
