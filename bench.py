@@ -166,7 +166,7 @@ def cpu_baseline_worker(args):
     t0 = time.time()
     step(data)                                   # warm-up (allocations, thread pools), not timed
     warm = time.time() - t0
-    nstep = 3 if warm < 20 else 1                # keep the whole bench run inside a few minutes
+    nstep = 3 if warm < 45 else 1                # (~25 s per step on the GPU box's host: 3 timed steps, ~110 s in all)
     t0 = time.time()
     for _ in range(nstep):
         out = step(data)
