@@ -2924,6 +2924,47 @@ __global__ __launch_bounds__(256, 2) void dcn_wgrad_xn_kernel(const DcnArgs a, i
         }
     };
 
+#ifdef LSN_WG_INTERLEAVE
+    // Experiment (not the default build): the 8-byte loads of step st + 1 issued one by one in the gaps between the MFMAs
+    // of step st instead of as a block before them (the block costs ~2.5 k cycles of pure issue time per step).
+    constexpr int IL_NL = 4 * NX + WG_BP / 2, IL_NG = 2 * NP * TI * TI;
+    int il_xoff[4][NX];
+    int il_g0 = 0, il_rowb = 0, il_xbytes = 0, il_gbytes = 0;
+    const float *il_xp = nullptr, *il_gp = nullptr;
+    auto il_prepare = [&](int st, int buf) __attribute__((always_inline)) {
+        const Lvl &L = find_level(a, st);
+        const int p0 = (st - L.tile0) * WG_BP;
+        il_xp = L.x, il_gp = L.gout;
+        il_xbytes = L.B * L.H * L.W * a.C * 4, il_gbytes = L.P * a.Co * 4;
+        const int c4 = (cbase + 2 * kp) * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const Tap *tp = &tab[buf * WG_BP + pg * 4 + q];
+            if (PLAIN) {
+                il_xoff[q][0] = tp->i00 * 4 + c4;
+            } else {
+                const int4 i4 = *reinterpret_cast<const int4 *>(tp);
+                il_xoff[q][0] = i4.x * 4 + c4, il_xoff[q][NX > 1 ? 1 : 0] = i4.y * 4 + c4;
+                il_xoff[q][NX > 2 ? 2 : 0] = i4.z * 4 + c4, il_xoff[q][NX > 3 ? 3 : 0] = i4.w * 4 + c4;
+            }
+        }
+        il_g0 = ((p0 + gph * (WG_BP / 2)) * a.Co + co_base + 2 * gcp) * 4;
+        il_rowb = a.Co * 4;
+    };
+    auto il_issue = [&](int m) __attribute__((always_inline)) {
+        if (m < 4 * NX) {
+            const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(il_xp), 0, il_xbytes, 0x00020000);
+            const int q = m / NX, e = m - q * NX;
+            const float2 v = buf_load_f32x2(xrs, il_xoff[q][e], 0);
+            xv0[q][e] = v.x, xv1[q][e] = v.y;
+        } else if (gact) {
+            const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(il_gp), 0, il_gbytes, 0x00020000);
+            const int px = m - 4 * NX;
+            const float2 v = buf_load_f32x2(grs, il_g0 + px * il_rowb, 0);
+            gv0[px] = v.x, gv1[px] = v.y;
+        }
+    };
+#endif
     int dbg_n = 0;
     // Tap-table slots rotate over three steps: slot (i % 3) holds step st_begin + i.  Iteration st stages step st,
     // issues the loads of step st + 1 (indices from slot st + 1) and, after its MFMA block, fills slot st + 2:
@@ -2932,6 +2973,30 @@ __global__ __launch_bounds__(256, 2) void dcn_wgrad_xn_kernel(const DcnArgs a, i
     //   !GT (computed): the entry's offset / mask loads are issued before the MFMA block and finished after it.
     // (GT: the table load is issued by every wave, unconditionally and always as the YOUNGEST load in flight, also in
     // the prologue: only then can the compiler count on it and let the staging code wait with vmcnt(1) instead of 0.)
+#ifdef LSN_WG_INTERLEAVE
+#define LSN_WG_LOADS(st, slot1, VXT, VGT)                                                                             \
+    do {                                                                                                              \
+        if constexpr (VXT::value && VGT::value) il_prepare(min(st + 1, st_end - 1), (st + 1 < st_end) ? slot1 : slot); \
+        else if (st + 1 < st_end) load_step(st + 1, slot1, VXT{}, VGT{});                                             \
+    } while (0)
+#define LSN_WG_GAP(gap, VXT, VGT)                                                                                     \
+    do {                                                                                                              \
+        if constexpr (VXT::value && VGT::value) {                                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                                        \
+_Pragma("unroll")                                                                                                     \
+            for (int m_ = (gap) * IL_NL / IL_NG; m_ < ((gap) + 1) * IL_NL / IL_NG; ++m_) il_issue(m_);                 \
+            __builtin_amdgcn_sched_barrier(0);                                                                        \
+        }                                                                                                             \
+    } while (0)
+#else
+#define LSN_WG_LOADS(st, slot1, VXT, VGT)                                                                             \
+    do {                                                                                                              \
+        if (st + 1 < st_end) load_step(st + 1, slot1, VXT{}, VGT{});                                                  \
+    } while (0)
+#define LSN_WG_GAP(gap, VXT, VGT)                                                                                     \
+    do {                                                                                                              \
+    } while (0)
+#endif
 #define LSN_WG_RUN(VXT, VGT, GTB)                                                                                     \
     do {                                                                                                              \
         uint4 tq = make_uint4(0u, 0u, 0u, 0u);                                                                        \
@@ -2959,7 +3024,7 @@ __global__ __launch_bounds__(256, 2) void dcn_wgrad_xn_kernel(const DcnArgs a, i
             const bool build2 = !(GTB) && st + 2 < st_end && tid < WG_BP;                                             \
             Tap t2 = {};                                                                                              \
             if (build2) t2 = tap_of(st + 2);                                                                          \
-            if (st + 1 < st_end) load_step(st + 1, slot1, VXT{}, VGT{});                                              \
+            LSN_WG_LOADS(st, slot1, VXT, VGT);                                                                        \
             LSN_STAMP(5);                                                                                             \
             const unsigned char *ap = smem + (row0 + (lane & 31)) * RS + (lane >> 5) * 16;                            \
             const unsigned char *bp = smem + NPL * PLANE_A + (col0 + (lane & 31)) * RS + (lane >> 5) * 16;            \
@@ -2979,7 +3044,10 @@ _Pragma("unroll")                                                               
                     for (int i = 0; i < TI; ++i)                                                                      \
 _Pragma("unroll")                                                                                                     \
                         for (int j = 0; j < TI; ++j)                                                                  \
+                        {                                                                                             \
                             acc[i][j] = mfma_bf16(Af[i][SC::pa(prod)], Bf[j][SC::pb(prod)], acc[i][j]);               \
+                            LSN_WG_GAP(((ks * NP + prod) * TI + i) * TI + j, VXT, VGT);                               \
+                        }                                                                                             \
             }                                                                                                         \
             LSN_STAMP(6);                                                                                             \
             if constexpr (GTB) {                                                                                      \
@@ -3007,6 +3075,8 @@ _Pragma("unroll")                                                               
         }
     }
 #undef LSN_WG_RUN
+#undef LSN_WG_LOADS
+#undef LSN_WG_GAP
 
 #pragma unroll
     for (int i = 0; i < TI; ++i)
