@@ -233,17 +233,22 @@ int lsn_nms(const float *dets, const int64_t *order, int n, float iou_thr, int64
  * F.conv2d.  Arithmetic: split-bf16 products with fp32 accumulation -- LSN_MATH_BF16X6 (fp32-equivalent) unless the
  * mode is LSN_MATH_BF16X3; there is no fp32-MFMA variant of these kernels (in LSN_MATH_FP32 the Python mirror keeps
  * the vendor library).  `relu` fuses max(., 0).  Supported: C % 4 == 0; tensors < 2 GiB.
- * `workspace` / `wt_workspace`: Co*kh*kw*C*8 bytes of scratch for the pre-split (backward: also flipped and
- * transposed) weight planes, rebuilt by every call; forward accepts NULL (the weights are then split inside every
- * block, slower).
+ *
+ * The kernels read the weight as a PREPARED IMAGE: bf16 planes in MFMA fragment order, which a wave fetches straight
+ * into registers (csrc/conv_kernels.h).  kind 0 = forward image, kind 1 = backward-data image (transposed, taps flipped,
+ * one sub-image per residue class of a strided convolution).  A caller that keeps the image rebuilds it only when the
+ * weight changes (once per optimizer step; the Python mirror keys it on the parameter's version counter):
+ *   lsn_conv2d_prepared_bytes    size of the image in bytes (< 0: unsupported stride / dilation combination)
+ *   lsn_conv2d_prepare_weights   w -> image (depends on the math mode current at the call)
+ *   lsn_conv2d_forward_prepared / lsn_conv2d_backward_data_prepared   the passes proper; `xpitch` = C except for the
+ *                                row-merged form below
+ * The one-shot entry points below build the image inside the call, into `workspace` / `wt_workspace` (at least
+ * lsn_conv2d_prepared_bytes bytes) or, when that is NULL, into a stream-ordered temporary.
  * backward_data: any stride -- every residue class (y mod stride, x mod stride) of input pixels is computed as its own
- * stride-1 convolution of grad_out over the taps that reach it; needs Co % 8 == 0 (pad grad_out and w with zero filters).
+ * stride-1 convolution of grad_out over the taps that reach it; needs Co % 4 == 0 (pad grad_out and w with zero filters).
  * forward_pitched: the row-merged form for shallow inputs (the 7x7 stem on 3(+1) channels): `xpitch` floats separate
  * adjacent pixels while a tap spans C = n * xpitch consecutive floats (n pixels of the same row), kw = 1, pad = 0;
  * w is (Co, kh, 1, C) = the memory image of a (Co, kh, n, xpitch) weight.  The caller pads the image spatially. */
-int lsn_conv2d_forward(const float *x, const float *w, const float *bias, float *out, void *workspace, int B, int H,
-                       int W, int C, int Co, int kh, int kw, int stride, int pad, int dil, int relu,
-                       lsn_stream_t stream);
 /* Batched forms: up to 8 input maps of different sizes that share one weight (the FPN levels under LSHead's shared
  * convolutions, lsnet_head.py:502-513) in ONE launch each way.  forward: x -> out.  backward_data: x = grad_out
  * (B,Ho,Wo,Co), out = grad_in (B,H,W,C), and B/H/W are the forward INPUT sizes; stride 1 when n_levels > 1.
@@ -254,6 +259,17 @@ typedef struct lsn_conv_level {
     const float *grad_out;   /* backward_weight only */
     int B, H, W;
 } lsn_conv_level;
+int64_t lsn_conv2d_prepared_bytes(int kind, int C, int Co, int kh, int kw, int stride, int pad, int dil);
+int lsn_conv2d_prepare_weights(int kind, const float *w, void *prepared, int C, int Co, int kh, int kw, int stride,
+                               int pad, int dil, lsn_stream_t stream);
+int lsn_conv2d_forward_prepared(int n_levels, const lsn_conv_level *levels, const void *prepared, const float *bias,
+                                int C, int xpitch, int Co, int kh, int kw, int stride, int pad, int dil, int relu,
+                                lsn_stream_t stream);
+int lsn_conv2d_backward_data_prepared(int n_levels, const lsn_conv_level *levels, const void *prepared, int C,
+                                      int Co, int kh, int kw, int stride, int pad, int dil, lsn_stream_t stream);
+int lsn_conv2d_forward(const float *x, const float *w, const float *bias, float *out, void *workspace, int B, int H,
+                       int W, int C, int Co, int kh, int kw, int stride, int pad, int dil, int relu,
+                       lsn_stream_t stream);
 int lsn_conv2d_forward_multi(int n_levels, const lsn_conv_level *levels, const float *w, const float *bias, void *workspace,
                              int C, int Co, int kh, int kw, int stride, int pad, int dil, int relu, lsn_stream_t stream);
 int lsn_conv2d_backward_data_multi(int n_levels, const lsn_conv_level *levels, const float *w, float *wt_workspace, int C,
@@ -341,12 +357,12 @@ int lsn_bn_eval_act_backward(const float *grad_y, const float *y, const float *x
  * phase boundaries: a per-chunk cycle anatomy for tuning.  Not thread-safe; profiling only. */
 int lsn_debug_phase_clocks(long long *device_buf_512, int block);
 
-/* Per-kernel launch timing.  lsn_prof_enable(1) clears the log and makes every deformable-conv kernel
- * launch record a HIP event pair on its launch stream; lsn_prof_read() waits for the recorded events
- * and returns one entry per kernel family (dcn_fwd, dcn_bwd_data, dcn_wgrad) with the launch count,
- * the summed kernel time and the summed ALGORITHMIC flops / bytes of those launches (flops: 2 x output
- * pixels x Co x C/groups x kh x kw per launch; bytes: each operand read or written once).
- * Returns the number of entries written (3) or a negative lsn error.  Not thread-safe. */
+/* Per-kernel-family launch timing.  lsn_prof_enable(1) clears the log and makes every launch of the instrumented
+ * families record a HIP event pair on its launch stream; lsn_prof_read() waits for the recorded events and returns one
+ * entry per family -- dcn_fwd, dcn_bwd_data, dcn_wgrad, conv_fwd, conv_bwd_data, conv_wgrad, norm, gconv -- with the
+ * launch count, the summed kernel time and the summed ALGORITHMIC flops / bytes of those launches (contractions: 2 x
+ * output pixels x Co x C/groups x kh x kw flops; bytes: each operand read or written once).
+ * Returns the number of entries written (8) or a negative lsn error.  Not thread-safe. */
 typedef struct lsn_prof_entry {
     char name[48];
     long long launches;

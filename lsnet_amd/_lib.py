@@ -64,6 +64,8 @@ EXPORTS = [
     'lsn_prof_enable', 'lsn_prof_read',
     'lsn_group_norm_workspace_bytes', 'lsn_group_norm_forward', 'lsn_group_norm_backward',
     'lsn_set_math_mode', 'lsn_get_math_mode', 'lsn_conv2d_forward', 'lsn_conv2d_forward_pitched', 'lsn_conv2d_backward_data',
+    'lsn_conv2d_prepared_bytes', 'lsn_conv2d_prepare_weights', 'lsn_conv2d_forward_prepared',
+    'lsn_conv2d_backward_data_prepared',
     'lsn_conv2d_forward_multi', 'lsn_conv2d_backward_data_multi', 'lsn_conv2d_backward_weight_multi', 'lsn_conv2d_backward_weight',
     'lsn_grouped_conv2d_forward', 'lsn_grouped_conv2d_backward_data', 'lsn_grouped_conv2d_backward_weight',
     'lsn_bn_eval_act_forward', 'lsn_bn_eval_act_backward', 'lsn_bn_eval_act_workspace_bytes',
@@ -90,6 +92,7 @@ def load():
     lib.lsn_group_norm_workspace_bytes.restype = ctypes.c_int64
     lib.lsn_bn_eval_act_workspace_bytes.restype = ctypes.c_int64
     lib.lsn_dcn_backward_workspace_bytes.restype = ctypes.c_int64
+    lib.lsn_conv2d_prepared_bytes.restype = ctypes.c_int64
     for name in EXPORTS:
         getattr(lib, name)  # AttributeError here means header and library disagree
     _lib = lib
@@ -111,8 +114,8 @@ def prof_enable(on):
 
 def prof_read():
     """{family: dict(launches, total_ms, flops, bytes)} of the launches logged since prof_enable(True)."""
-    arr = (ProfEntry * 8)()
-    n = load().lsn_prof_read(arr, 8)
+    arr = (ProfEntry * 16)()
+    n = load().lsn_prof_read(arr, 16)
     if n < 0:
         check(n)
     return {arr[i].name.decode(): dict(launches=int(arr[i].launches), total_ms=arr[i].total_ms,

@@ -1,0 +1,404 @@
+// Dense-convolution kernels of liblsnet_hip.so (included by conv.hip): implicit GEMM on the bf16 matrix pipe with split
+// fp32 operands (common.h), designed for TWO workgroups per CU.
+//
+//   out[p][co] = sum_{tap, ci} x[p @ tap][ci] * w[co][tap][ci]            (channels-last fp32 tensors)
+//
+// * The WEIGHTS never pass through LDS.  conv_wfrag_kernel writes them once per optimizer step in MFMA FRAGMENT ORDER
+//   ([chunk][32-co tile][k-step][plane][lane][8 bf16]: the 1 KiB a wave needs for one operand of one MFMA is one
+//   contiguous, fully coalesced buffer_load_dwordx4), so a wave fetches its own weight fragments from L2 straight into
+//   registers, half a chunk ahead of their use.  No staging instructions, no LDS space, no barrier for that operand.
+// * The PIXELS (fp32 in HBM) are loaded as float4 per lane (8 lanes = one pixel's 32-channel slab = 128 B), split
+//   exactly into bf16 planes in registers and written to a double-buffered LDS image of 64-byte rows whose 16-byte slots
+//   are XOR-swizzled by (row >> 2) & 3: the ds_write_b64 stores and the ds_read_b128 fragment reads are both
+//   conflict-free without padding.  24 KB per stage for 128 pixels => 48 KB per workgroup.
+// * Operand roles are SWAPPED in the MFMA (rows of D = output channels, columns = pixels): a lane then owns ONE pixel of
+//   a 32x32 tile and four consecutive output channels per register quad, so the epilogue is one 16-byte store per quad
+//   (bias and ReLU applied on the way) instead of sixteen 4-byte stores, and the pixel's output address is computed once.
+// * <= 256 VGPRs and 48 KB of LDS: two workgroups share a CU, i.e. two waves per SIMD that are NOT barrier-coupled --
+//   one's split / staging VALU work and barrier waits sit in the shadow of the other's MFMAs, tiles are handed out at
+//   512 slots per round instead of 256, and twice the bytes are in flight on the layers that are bound by HBM latency.
+//
+// Template: wave tile = (TM x 32 pixels) x (TN x 32 output channels), workgroup = WM x WN waves (= 4).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "common.h"
+
+namespace lsn {
+
+constexpr int CV_MAXLV = 8;
+
+// One input map of a batched launch: the FPN levels that share a convolution's weights (LSHead) go into ONE launch.
+struct ConvLvl {
+    const float *x;
+    float *out;
+    int B, H, W, Ho, Wo;
+    int P;       // B * Ho * Wo
+    int tile0;   // first pixel tile of this level
+};
+
+struct ConvArgs {
+    ConvLvl lv[CV_MAXLV];
+    int nlv, ntiles;
+    const float *bias;
+    int C, Co, kh, kw, stride, pad_h, pad_w, dil;
+    int xpitch;   // floats between horizontally adjacent input pixels (= C, except for the row-merged stem form)
+    int relu;
+    int ksplit;   // > 1 (one level, dense output): the chunk range is divided over blockIdx.z and split z stores its
+                  // partial tile at part + z * P * Co; conv_splitk_reduce_kernel adds them up (+ bias, ReLU).  Few
+                  // pixels under a deep reduction (layer 4, FPN P5 .. P7) would otherwise leave most CUs idle; fp32
+                  // atomics into the output were measured 5 - 10 x slower than the whole convolution.
+    float *part;
+    const unsigned short *wf;   // weights in fragment order (conv_wfrag_kernel)
+    int wf_bytes;
+    // output placement: pixel (b, ho, wo) of the (Ho, Wo) grid is stored at (b, oy0 + ho * ostep, ox0 + wo * ostep) of an
+    // (OH, OW) map.  ostep = 0: the dense case.  Used by the strided backward-data pass (one residue class per launch).
+    int ostep, oy0, ox0, OH, OW;
+};
+
+// Tap subset of a transposed convolution: taps i = i0 + m * istep (m < ni), j likewise.
+struct TapSub {
+    int i0, istep, ni, j0, jstep, nj, kw;
+};
+
+__host__ __device__ inline int cv_ncc(int C) { return (C + 31) / 32; }
+// 32-channel output tiles of the weight image, padded with zero tiles to the width of the workgroup tile that serves
+// this Co (conv.hip conv_forward: 32, 64 or 128 columns): the scalar part of a buffer address is not range-checked, so
+// every tile a wave may ask for has to exist.
+__host__ __device__ inline int cv_nt(int Co) { return Co <= 32 ? 1 : Co <= 64 ? 2 : (Co + 127) / 128 * 4; }
+// bytes of the fragment-order image of a (Co, Kd, C) weight
+__host__ __device__ inline size_t cv_wfrag_bytes(int Co, int Kd, int C, int npl)
+{
+    return (size_t)Kd * cv_ncc(C) * cv_nt(Co) * 2 * npl * 1024;
+}
+
+// w -> fragment order.  GEMM view of the convolution the main kernel runs: output column n (< Co), reduction index
+// (tap, c) with c < C.  flipT = 0: Wt[n][tap][c] = w[(n * K + tap) * C + c].  flipT = 1 (backward-data): the source is the
+// forward weight (Cs = C of this GEMM = forward Co... see conv.hip), Wt[n][tap'][c] = w[(c * K + tap(tap')) * Co + n] with
+// the tap subset reversed.  Element (t, nt, ks, q, lane, e): n = nt * 32 + (lane & 31), k = ks * 16 + 8 * (lane >> 5) + e,
+// value = plane q of Wt[n][tap(t)][cc(t) * 32 + k] (0 beyond Co / C).
+template <int NPL>
+__global__ void conv_wfrag_kernel(const float *__restrict__ w, unsigned short *__restrict__ out, int Co, int K, int C,
+                                  int flipT, TapSub ts)
+{
+    const int Kd = flipT ? ts.ni * ts.nj : K;
+    const int ncc = cv_ncc(C), NT = cv_nt(Co);
+    const long long total = (long long)Kd * ncc * NT * 2 * 64;   // one thread per (t, nt, ks, lane)
+    for (long long id = blockIdx.x * (long long)blockDim.x + threadIdx.x; id < total; id += (long long)gridDim.x * blockDim.x) {
+        const int lane = (int)(id & 63);
+        long long r = id >> 6;
+        const int ks = (int)(r & 1);
+        r >>= 1;
+        const int nt = (int)(r % NT);
+        const int t = (int)(r / NT);
+        const int tap = t / ncc, cc = t - tap * ncc;
+        const int n = nt * 32 + (lane & 31);
+        const int c0 = cc * 32 + ks * 16 + 8 * (lane >> 5);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = c0 + e;
+            float val = 0.f;
+            if (n < Co && c < C) {
+                if (!flipT) {
+                    val = w[((size_t)n * K + tap) * C + c];
+                } else {
+                    // transposed convolution: this GEMM's (n, c) = forward (ci, co); source layout (Co_f = C, K, C_f = Co)
+                    const int m = tap / ts.nj, nn = tap - m * ts.nj;
+                    const int i = ts.i0 + (ts.ni - 1 - m) * ts.istep, j = ts.j0 + (ts.nj - 1 - nn) * ts.jstep;
+                    val = w[((size_t)c * K + i * ts.kw + j) * Co + n];
+                }
+            }
+            v[e] = val;
+        }
+        unsigned pl[4][NPL];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split_planes<NPL>(v[2 * e], v[2 * e + 1], pl[e]);
+        unsigned short *dst = out + ((((size_t)t * NT + nt) * 2 + ks) * NPL) * 512 + (size_t)lane * 8;
+#pragma unroll
+        for (int q = 0; q < NPL; ++q)
+            *reinterpret_cast<uint4 *>(dst + (size_t)q * 512) = make_uint4(pl[0][q], pl[1][q], pl[2][q], pl[3][q]);
+    }
+}
+
+__device__ __forceinline__ float4 cv_load4(__amdgpu_buffer_rsrc_t rs, int voff, int soff)
+{
+    auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+    float4 f;
+    __builtin_memcpy(&f, &v, 16);
+    return f;
+}
+__device__ __forceinline__ bf16x8 cv_load_frag(__amdgpu_buffer_rsrc_t rs, int voff, int soff)
+{
+    auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+    bf16x8 f;
+    __builtin_memcpy(&f, &v, 16);
+    return f;
+}
+
+template <int TM, int TN, int WM, int WN, int NP>
+__global__ __launch_bounds__(256, 2) void conv_mm_kernel(const ConvArgs a)
+{
+    using SC = SplitCfg<NP>;
+    constexpr int NPL = SC::NPL;
+    static_assert(WM * WN == 4, "four waves");
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BK = 32;
+    constexpr int NLD = BM / 32;         // float4 loads per thread and chunk (8 lanes per pixel, 32 pixels per pass)
+    constexpr int PLANE = BM * 64;       // bytes of one bf16 plane of a stage: BM rows of 32 bf16
+    constexpr int BUF = NPL * PLANE;
+    constexpr int OOB = 0x7ffffff0;      // beyond num_records: the buffer load returns 0
+    extern __shared__ __align__(16) unsigned char smem[];   // 2 x BUF
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int K = a.kh * a.kw;
+    // XCD-ordered (pixel tile, column block) with the column blocks of a pixel tile adjacent (same input rows)
+    const int work = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int ptile = work / (int)gridDim.y;
+    int li = 0;
+    while (li + 1 < a.nlv && ptile >= a.lv[li + 1].tile0) ++li;
+    const ConvLvl &L = a.lv[li];
+    const int tile_p = (ptile - L.tile0) * BM;
+    const int co_blk = (work - ptile * (int)gridDim.y) * BN;
+    const int ncc = cv_ncc(a.C), NT = cv_nt(a.Co);
+    const int Tall = K * ncc;
+    const int t_begin = (int)((long long)Tall * blockIdx.z / gridDim.z);
+    const int T = (int)((long long)Tall * (blockIdx.z + 1) / gridDim.z) - t_begin;
+
+    const __amdgpu_buffer_rsrc_t xrs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(L.x), 0, L.B * L.H * L.W * a.xpitch * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(a.wf), 0, a.wf_bytes, 0x00020000);
+
+    // ---- pixel operand: thread = (float4 slot c4 of the 32-channel slab, pixel row prow of a 32-row pass) ----
+    const int c4 = tid & 7, prow = tid >> 3;
+    int pbase[NLD];                 // byte offset of the pass's pixel at tap (0, 0), channel 4 c4 (may be negative)
+    unsigned long long vmask[NLD];  // one validity bit per tap (kh * kw <= 64: checked by the host)
+#pragma unroll
+    for (int ps = 0; ps < NLD; ++ps) {
+        const int p = tile_p + ps * 32 + prow;
+        const bool ok = p < L.P;
+        const int HWo = L.Ho * L.Wo;
+        const int b = ok ? p / HWo : 0, rem = ok ? p - b * HWo : 0;
+        const int ho = rem / L.Wo, wo = rem - ho * L.Wo;
+        const int iy0 = ho * a.stride - a.pad_h, ix0 = wo * a.stride - a.pad_w;
+        pbase[ps] = ((b * L.H * L.W + iy0 * L.W + ix0) * a.xpitch + 4 * c4) * 4;
+        unsigned long long m = 0;
+        if (ok)
+            for (int i = 0; i < a.kh; ++i)
+                for (int j = 0; j < a.kw; ++j) {
+                    const int y = iy0 + i * a.dil, x = ix0 + j * a.dil;
+                    if ((unsigned)y < (unsigned)L.H && (unsigned)x < (unsigned)L.W) m |= 1ull << (i * a.kw + j);
+                }
+        vmask[ps] = m;
+    }
+    // LDS byte offset of this thread's 8 bytes in row (ps * 32 + prow): 16-byte slot (c4 >> 1) ^ ((row >> 2) & 3)
+    const int st_off = prow * 64 + ((((c4 >> 1) ^ ((prow >> 2) & 3)) << 4) | ((c4 & 1) << 3));
+
+    struct Ck {
+        int i, j, cc;
+    };
+    auto next = [&](Ck &c) {
+        if (++c.cc == ncc) {
+            c.cc = 0;
+            if (++c.j == a.kw) {
+                c.j = 0;
+                ++c.i;
+            }
+        }
+    };
+    float4 xv[NLD];
+    auto issue_x = [&](const Ck &c, bool live) {   // !live: past the last chunk, no memory access
+        const int tap = c.i * a.kw + c.j;
+        const int toff = ((c.i * a.dil * L.W + c.j * a.dil) * a.xpitch + c.cc * BK) * 4;
+        const bool cok = live && c.cc * BK + 4 * c4 < a.C;
+#pragma unroll
+        for (int ps = 0; ps < NLD; ++ps) {
+            const bool ok = ((vmask[ps] >> tap) & 1ull) != 0 && cok;
+            xv[ps] = cv_load4(xrs, ok ? pbase[ps] + toff : OOB, 0);
+        }
+    };
+    auto commit_x = [&](unsigned char *buf) {
+#pragma unroll
+        for (int ps = 0; ps < NLD; ++ps) {
+            unsigned p0[NPL], p1[NPL];
+            split_planes<NPL>(xv[ps].x, xv[ps].y, p0);
+            split_planes<NPL>(xv[ps].z, xv[ps].w, p1);
+            unsigned char *p = buf + ps * 32 * 64 + st_off;
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) *reinterpret_cast<uint2 *>(p + q * PLANE) = make_uint2(p0[q], p1[q]);
+        }
+    };
+
+    // ---- weight operand: fragments straight from L2.  Byte offset of (chunk t, tile nt, k-step ks, plane q):
+    // ((((t * NT + nt) * 2 + ks) * NPL + q) * 1024 + lane * 16 ----
+    // The wave's part (lane, wn) goes into the VGPR offset, the chunk's into a scalar one: no waterfall loop around a
+    // wave-uniform-but-not-provably-so soffset.
+    const int wvoff = lane * 16 + wn * TN * (2 * NPL * 1024);
+    const int wsbase = (t_begin * NT + co_blk / 32) * (2 * NPL * 1024), wsstep = NT * (2 * NPL * 1024);
+    bf16x8 Wf[2][TN][NPL];
+    auto issue_w = [&](int t, int ks) {   // t saturates at the last chunk (a repeated L2 hit, never used)
+        const int soff = wsbase + (t < T ? t : T - 1) * wsstep;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < NPL; ++q)
+                Wf[ks][j][q] = cv_load_frag(wrs, wvoff + ((j * 2 + ks) * NPL + q) * 1024, soff);
+    };
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+
+    // ---- prologue: chunk 0 -> LDS buffer 0, raw pixels of chunk 1 and the weight fragments of chunk 0 in flight ----
+    Ck c1;
+    {
+        const int k0 = t_begin / ncc;
+        c1.cc = t_begin - k0 * ncc;
+        c1.i = k0 / a.kw;
+        c1.j = k0 - c1.i * a.kw;
+    }
+    // (issue order = consumption order of the steady state: pixels of t + 1, then the two weight k-steps of t, so that
+    // the counted vmcnt waits of the loop leave the younger loads in flight)
+    issue_x(c1, true);
+    commit_x(smem);
+    if (T > 1) next(c1);
+    issue_x(c1, T > 1);
+    issue_w(0, 0);
+    issue_w(0, 1);
+    __syncthreads();
+
+    // fragment read address: row = wm * TM * 32 + i * 32 + (lane & 31), slot = (ks * 2 + (lane >> 5)) ^ ((row >> 2) & 3)
+    const int frow = wm * TM * 32 + (lane & 31);
+    const int fsw = (frow >> 2) & 3;   // (row >> 2) & 3 is the same for every i (rows differ by 32)
+
+    bf16x8 Xf[2][TM][NPL];
+    auto read_x = [&](const unsigned char *buf, int ks) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int q = 0; q < NPL; ++q)
+                Xf[ks][i][q] = *reinterpret_cast<const bf16x8 *>(buf + q * PLANE + (frow + i * 32) * 64 +
+                                                                 (((ks * 2 + (lane >> 5)) ^ fsw) << 4));
+    };
+    auto mfma_block = [&](int ks) {
+#pragma unroll
+        for (int prod = 0; prod < NP; ++prod)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    acc[j][i] = mfma_bf16(Wf[ks][j][SC::pb(prod)], Xf[ks][i][SC::pa(prod)], acc[j][i]);
+    };
+
+    // One iteration = one chunk.  The fences pin the order of its phases; inside a phase hipcc schedules freely.  Left
+    // alone it sinks all sixteen loads to the end of the iteration (the next one then opens with a full memory-latency
+    // wait) and reads every fragment right before its first MFMA.
+    //   A  fragment reads of k-step 0 (their LDS latency hides behind B)
+    //   B  split the raw pixels of chunk t + 1 -> the other LDS buffer; issue the pixel loads of chunk t + 2
+    //   C  fragment reads of k-step 1, MFMAs of k-step 0, then the weight loads of (t + 1, 0) into the dead registers
+    //   D  MFMAs of k-step 1, weight loads of (t + 1, 1); barrier
+    // Loads are issued in the order they are consumed, so every counted vmcnt wait leaves the younger ones in flight:
+    // each load has at least half an iteration (24 MFMAs of this wave plus the partner workgroup's share of the SIMD).
+    for (int t = 0; t < T; ++t) {
+        const unsigned char *bc = smem + (t & 1) * BUF;
+        unsigned char *bn = smem + ((t & 1) ^ 1) * BUF;
+        read_x(bc, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < T) commit_x(bn);   // registers hold the raw pixels of chunk t + 1
+        if (t + 2 < T) next(c1);
+        issue_x(c1, t + 2 < T);
+        __builtin_amdgcn_sched_barrier(0);
+        read_x(bc, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_block(0);
+        issue_w(t + 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_block(1);
+        issue_w(t + 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane = pixel (lane & 31) of tile i, output channels 8 g + 4 (lane >> 5) + (0..3) of tile j ----
+    const bool partial = a.ksplit > 1;
+    const bool vec_ok = (a.Co & 3) == 0;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int pix = tile_p + wm * TM * 32 + i * 32 + (lane & 31);
+        if (pix >= L.P) continue;
+        size_t opix = pix;
+        if (a.ostep) {
+            const int HWo = L.Ho * L.Wo;
+            const int b = pix / HWo, rem = pix - b * HWo;
+            const int ho = rem / L.Wo, wo = rem - ho * L.Wo;
+            opix = ((size_t)b * a.OH + a.oy0 + ho * a.ostep) * a.OW + a.ox0 + wo * a.ostep;
+        }
+        float *orow = partial ? a.part + ((size_t)blockIdx.z * L.P + pix) * a.Co : L.out + opix * a.Co;
+        const bool fin = !partial;   // bias and ReLU belong to the finished sum
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = co_blk + (wn * TN + j) * 32 + 8 * g + 4 * (lane >> 5);
+                if (co >= a.Co) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[j][i][4 * g + e];
+                if (vec_ok) {
+                    if (fin && a.bias) {
+                        const float4 bv = *reinterpret_cast<const float4 *>(a.bias + co);
+                        v[0] += bv.x, v[1] += bv.y, v[2] += bv.z, v[3] += bv.w;
+                    }
+                    if (fin && a.relu)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    *reinterpret_cast<float4 *>(orow + co) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (co + e >= a.Co) break;
+                        float u = v[e] + ((fin && a.bias) ? a.bias[co + e] : 0.f);
+                        if (fin && a.relu) u = fmaxf(u, 0.f);
+                        orow[co + e] = u;
+                    }
+                }
+            }
+    }
+}
+
+// out[e] = sum_z part[z * n + e] + bias[e % Co] (ReLU): the second pass of a split reduction; n = P * Co
+__global__ void conv_splitk_reduce_kernel(const float *__restrict__ part, float *__restrict__ out,
+                                          const float *__restrict__ bias, int n, int Co, int ks, int relu)
+{
+    const bool v4 = (n & 3) == 0 && (Co & 3) == 0;
+    if (v4) {
+        for (int e = (blockIdx.x * blockDim.x + threadIdx.x) * 4; e < n; e += gridDim.x * blockDim.x * 4) {
+            float4 s = *reinterpret_cast<const float4 *>(part + e);
+            for (int z = 1; z < ks; ++z) {
+                const float4 p = *reinterpret_cast<const float4 *>(part + (size_t)z * n + e);
+                s.x += p.x, s.y += p.y, s.z += p.z, s.w += p.w;
+            }
+            if (bias) {
+                const float4 b = *reinterpret_cast<const float4 *>(bias + e % Co);
+                s.x += b.x, s.y += b.y, s.z += b.z, s.w += b.w;
+            }
+            if (relu) s.x = fmaxf(s.x, 0.f), s.y = fmaxf(s.y, 0.f), s.z = fmaxf(s.z, 0.f), s.w = fmaxf(s.w, 0.f);
+            *reinterpret_cast<float4 *>(out + e) = s;
+        }
+    } else {
+        for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+            float s = part[e];
+            for (int z = 1; z < ks; ++z) s += part[(size_t)z * n + e];
+            if (bias) s += bias[e % Co];
+            out[e] = relu ? fmaxf(s, 0.f) : s;
+        }
+    }
+}
+
+}  // namespace lsn

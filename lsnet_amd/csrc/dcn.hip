@@ -12,6 +12,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include "dcn_kernels.h"
+#include "prof.h"
 
 namespace lsn {
 
@@ -47,17 +48,13 @@ static int math_np() { return math_mode() == LSN_MATH_BF16X6 ? 6 : (math_mode() 
 int split_np() { return math_np(); }
 void dbg_state(long long **buf, int *block) { *buf = g_dbg_buf, *block = g_dbg_block; }
 
-// ---- per-kernel launch timing (lsn_prof_*): HIP events recorded on the launch stream around each
-// deformable-conv kernel, so bench.py can quote a kernel's own average duration live.
-enum { PROF_FWD = 0, PROF_BWD_DATA = 1, PROF_WGRAD = 2, PROF_N = 3 };
-static const char *const kProfNames[PROF_N] = {"dcn_fwd", "dcn_bwd_data", "dcn_wgrad"};
-struct ProfRec {
-    hipEvent_t e0, e1;
-    int fam;
-    double flops, bytes;
-};
+// ---- per-kernel launch timing (prof.h) ----
+static const char *const kProfNames[PROF_N] = {"dcn_fwd", "dcn_bwd_data", "dcn_wgrad", "conv_fwd", "conv_bwd_data",
+                                               "conv_wgrad", "norm", "gconv"};
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
+bool prof_on() { return g_prof_on; }
+void prof_push(const ProfRec &r) { g_prof.push_back(r); }
 
 static double dcn_flops(const DcnArgs &a)
 {
@@ -85,28 +82,8 @@ static double dcn_bytes(const DcnArgs &a, int fam)
     }
 }
 
-struct ProfScope {
-    ProfRec r;
-    hipStream_t st;
-    bool on;
-    ProfScope(int fam, const DcnArgs &a, hipStream_t s) : st(s), on(g_prof_on)
-    {
-        if (!on) return;
-        r.fam = fam;
-        r.flops = dcn_flops(a);
-        r.bytes = dcn_bytes(a, fam);
-        if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) {
-            on = false;
-            return;
-        }
-        (void)hipEventRecord(r.e0, st);
-    }
-    ~ProfScope()
-    {
-        if (!on) return;
-        (void)hipEventRecord(r.e1, st);
-        g_prof.push_back(r);
-    }
+struct ProfScope : ProfSpan {
+    ProfScope(int fam, const DcnArgs &a, hipStream_t s) : ProfSpan(fam, dcn_flops(a), dcn_bytes(a, fam), s) {}
 };
 
 // in[b][r][s] -> out[b][s][r]   (NCHW <-> NHWC with r = C, s = H*W; weight OIHW <-> OHWI with
@@ -875,6 +852,9 @@ static int conv_wgrad_xn(int n, const lsn_conv_level *lv, float *gw, float *gb, 
     const int K = kh * kw;
     LSN_HIP(hipMemsetAsync(gw, 0, sizeof(float) * (size_t)Co * K * C, st));
     if (gb) LSN_HIP(hipMemsetAsync(gb, 0, sizeof(float) * (size_t)Co, st));
+    double px = 0, in_el = 0;
+    for (int i = 0; i < n; ++i) px += (double)a.lv[i].P, in_el += (double)a.lv[i].B * a.lv[i].H * a.lv[i].W * C;
+    ProfSpan prof(PROF_CONV_WGRAD, 2.0 * px * Co * C * K, 4.0 * (in_el + px * Co + (double)Co * K * C), st);
     const bool x3 = math_np() == 3;   // exact-mode callers get the fp32-equivalent split: there is no fp32-MFMA dense wgrad
     if (Co <= 64) return x3 ? conv_wgrad_launch<3, 64>(a, steps, C, Co, K, st) : conv_wgrad_launch<6, 64>(a, steps, C, Co, K, st);
     return x3 ? conv_wgrad_launch<3, 256>(a, steps, C, Co, K, st) : conv_wgrad_launch<6, 256>(a, steps, C, Co, K, st);

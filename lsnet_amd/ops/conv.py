@@ -3,11 +3,14 @@ mmcv/cnn/bricks/conv.py:11-43 `build_conv_layer`).
 
 `Conv2d` subclasses nn.Conv2d (same parameters and state-dict keys).  Every dense (groups = 1) convolution of a CUDA
 channels-last fp32 tensor -- forward, data gradient (any stride), weight and bias gradient -- runs the split-bf16
-implicit-GEMM kernels of csrc/conv.hip in the library's math modes 'bf16x6' (fp32-equivalent, the default) and
-'bf16x3'.  Grouped convolutions with 4 .. 32 channels per group (ResNeXt 64x4d bottlenecks) run the exact-fp32
-kernels of csrc/gconv.hip in every math mode.  Exact-fp32 dense convolutions, other group shapes and CPU tensors go to
-ATen's convolution (MIOpen), which is a different vendor operator, not a fallback of the HIP path."""
+implicit-GEMM kernels of csrc/conv_kernels.h in the library's math modes 'bf16x6' (fp32-equivalent, the default) and
+'bf16x3'.  The kernels read weights as prepared images (MFMA fragment order); `weight_image` keeps one per (weight
+tensor, pass) and rebuilds it when the tensor's version counter moves, i.e. once per optimizer step.  Grouped
+convolutions with 4 .. 32 channels per group (ResNeXt 64x4d bottlenecks) run the exact-fp32 kernels of csrc/gconv.hip
+in every math mode.  Exact-fp32 dense convolutions, other group shapes and CPU tensors go to ATen's convolution
+(MIOpen), which is a different vendor operator, not a fallback of the HIP path."""
 import ctypes
+import weakref
 
 import torch
 import torch.nn as nn
@@ -33,6 +36,33 @@ def _pad_channels(t, c_to):
     return out
 
 
+_images = {}    # (id(weight), kind, stride, pad, dil, math mode) -> (weakref, version, data_ptr, image)
+
+
+def weight_image(w, kind, stride=1, pad=0, dil=1):
+    """The prepared image (lsn_conv2d_prepare_weights) of a channels-last (Co, C, kh, kw) weight for the forward
+    (kind 0) or backward-data (kind 1) pass.  Cached per tensor OBJECT and version: a parameter's image is rebuilt
+    once per optimizer step; a temporary (padded view, test tensor) gets a fresh one and drops it when it dies."""
+    lib = _lib.load()
+    Co, C, kh, kw = w.shape
+    key = (id(w), kind, stride, pad, dil, lib.lsn_get_math_mode())
+    ent = _images.get(key)
+    if ent is not None and ent[0]() is w and ent[1] == w._version and ent[2] == w.data_ptr():
+        return ent[3]
+    nbytes = lib.lsn_conv2d_prepared_bytes(kind, C, Co, kh, kw, stride, pad, dil)
+    if nbytes < 0:
+        _lib.check(-2)
+    img = ent[3] if (ent is not None and ent[0]() is w and ent[3].numel() == nbytes) else \
+        torch.empty(nbytes, device=w.device, dtype=torch.uint8)
+    _lib.check(lib.lsn_conv2d_prepare_weights(kind, _p(w), _p(img), C, Co, kh, kw, stride, pad, dil, _stream()))
+    _images[key] = (weakref.ref(w, lambda _, k=key: _images.pop(k, None)), w._version, w.data_ptr(), img)
+    return img
+
+
+def _levels(n):
+    return (_lib.ConvLevel * n)()
+
+
 class _ConvFn(torch.autograd.Function):
     """Forward, data gradient (any stride: residue classes of the transposed convolution), weight and bias gradient:
     all through liblsnet_hip.so.  Needs C % 4 == 0 (`conv2d` pads the 3-channel stem input)."""
@@ -46,9 +76,10 @@ class _ConvFn(torch.autograd.Function):
         Wo = (W + 2 * pad - (dil * (kw - 1) + 1)) // stride + 1
         w = w.contiguous(memory_format=_CL)
         out = torch.empty((B, Co, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=_CL)
-        ws = torch.empty(2 * w.numel(), device=x.device, dtype=torch.float32)
-        _lib.check(lib.lsn_conv2d_forward(_p(x), _p(w), _p(bias), _p(out), _p(ws), B, H, W, C, Co, kh, kw, stride, pad,
-                                          dil, 1 if relu else 0, _stream()))
+        lv = _levels(1)
+        lv[0].x, lv[0].out, lv[0].B, lv[0].H, lv[0].W = _p(x), _p(out), B, H, W
+        _lib.check(lib.lsn_conv2d_forward_prepared(1, lv, _p(weight_image(w, 0)), _p(bias), C, C, Co, kh, kw, stride, pad,
+                                                   dil, 1 if relu else 0, _stream()))
         ctx.save_for_backward(x, w, out if relu else None)
         ctx.cfg = (stride, pad, dil, relu, bias is not None)
         return out
@@ -67,15 +98,16 @@ class _ConvFn(torch.autograd.Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             go8, w8, Co8 = go, w, Co
-            if Co % 8:    # the transposed convolution reads grad_output in 8-channel pieces: zero filters are free
-                Co8 = (Co + 7) // 8 * 8
+            if Co % 4:    # the transposed convolution reads grad_output in 4-channel pieces: zero filters are free
+                Co8 = (Co + 3) // 4 * 4
                 go8 = _pad_channels(go, Co8)
                 w8 = w.new_zeros((Co8, C, kh, kw)).contiguous(memory_format=_CL)
                 w8[:Co] = w
             gx = torch.empty_like(x, memory_format=_CL)
-            ws = torch.empty(2 * w8.numel(), device=x.device, dtype=torch.float32)
-            _lib.check(lib.lsn_conv2d_backward_data(_p(go8), _p(w8), _p(gx), _p(ws), B, H, W, C, Co8, kh, kw, stride, pad,
-                                                    dil, _stream()))
+            lv = _levels(1)
+            lv[0].x, lv[0].out, lv[0].B, lv[0].H, lv[0].W = _p(go8), _p(gx), B, H, W
+            _lib.check(lib.lsn_conv2d_backward_data_prepared(1, lv, _p(weight_image(w8, 1, stride, pad, dil)), C, Co8, kh,
+                                                             kw, stride, pad, dil, _stream()))
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
             # weight gradient and the bias gradient in one pass over grad_output
             gw = torch.empty_like(w)
@@ -164,9 +196,8 @@ class _ConvMultiFn(torch.autograd.Function):
             outs.append(out)
             L = levels[i]
             L.x, L.out, L.B, L.H, L.W = _p(x), _p(out), B, H, W
-        ws = torch.empty(2 * w.numel(), device=w.device, dtype=torch.float32)
-        _lib.check(lib.lsn_conv2d_forward_multi(n, levels, _p(w), _p(bias), _p(ws), C, Co, kh, kw, 1, pad, dil,
-                                                1 if relu else 0, _stream()))
+        _lib.check(lib.lsn_conv2d_forward_prepared(n, levels, _p(weight_image(w, 0)), _p(bias), C, C, Co, kh, kw, 1, pad,
+                                                   dil, 1 if relu else 0, _stream()))
         ctx.save_for_backward(w, *xs, *(outs if relu else []))
         ctx.cfg, ctx.n, ctx.has_bias = cfg, n, bias is not None
         return tuple(outs)
@@ -188,8 +219,8 @@ class _ConvMultiFn(torch.autograd.Function):
         gxs = [None] * n
         if any(need_x):
             w8, Co8, gos8 = w, Co, gos
-            if Co % 8:
-                Co8 = (Co + 7) // 8 * 8
+            if Co % 4:
+                Co8 = (Co + 3) // 4 * 4
                 gos8 = [_pad_channels(g, Co8) for g in gos]
                 w8 = w.new_zeros((Co8, C, kh, kw)).contiguous(memory_format=_CL)
                 w8[:Co] = w
@@ -198,8 +229,8 @@ class _ConvMultiFn(torch.autograd.Function):
                 gxs[i] = torch.empty_like(x, memory_format=_CL)
                 L = levels[i]
                 L.x, L.out, L.B, L.H, L.W = _p(gos8[i]), _p(gxs[i]), x.shape[0], x.shape[2], x.shape[3]
-            ws = torch.empty(2 * w8.numel(), device=w.device, dtype=torch.float32)
-            _lib.check(lib.lsn_conv2d_backward_data_multi(n, levels, _p(w8), _p(ws), C, Co8, kh, kw, 1, pad, dil, _stream()))
+            _lib.check(lib.lsn_conv2d_backward_data_prepared(n, levels, _p(weight_image(w8, 1, 1, pad, dil)), C, Co8, kh, kw,
+                                                             1, pad, dil, _stream()))
             gxs = [g if need else None for g, need in zip(gxs, need_x)]
         gw = gb = None
         if ctx.needs_input_grad[0] or (ctx.has_bias and ctx.needs_input_grad[1]):
@@ -249,8 +280,7 @@ def _stem_forward(x, weight, bias, stride, pad, relu):
     w4[:, :C] = weight
     Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
     out = torch.empty((B, Co, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=_CL)
-    ws = torch.empty(2 * w4.numel(), device=x.device, dtype=torch.float32)
-    _lib.check(lib.lsn_conv2d_forward_pitched(_p(xp), _p(w4), _p(bias), _p(out), _p(ws), B, H + 2 * pad, W + 2 * pad,
+    _lib.check(lib.lsn_conv2d_forward_pitched(_p(xp), _p(w4), _p(bias), _p(out), None, B, H + 2 * pad, W + 2 * pad,
                                               kw * C4, C4, Co, kh, 1, stride, 0, 1, 1 if relu else 0, _stream()))
     return out
 

@@ -542,8 +542,8 @@ def test_conv2d_multi_level_equals_single(C, Co, k, bias, relu, split_mode):
     g_multi = torch.autograd.grad(outs, xs + params, gos)
     singles = [F.relu(m(x)) if relu else m(x) for x in xs]
     g_single = torch.autograd.grad(singles, xs + params, gos)
-    for a_, b_ in zip(outs, singles):
-        assert _err(a_, b_.detach().cpu()) < 1e-6
+    for a_, b_ in zip(outs, singles):   # (a small level on its own may take a split reduction: another fp32 summation order)
+        assert _err(a_, b_.detach().cpu()) < tol
     for a_, b_ in zip(g_multi, g_single):
         assert _err(a_, b_.detach().cpu()) < tol
     xr = [x.detach().double().cpu().requires_grad_() for x in xs]

@@ -33,28 +33,44 @@ def ev_time(fn, n=10):
 lib = _lib.load()
 cp = lambda t: ctypes.c_void_p(t.data_ptr())
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-print(f'mode {mode}; ms per call (own | MIOpen)')
-print(f'{"shape":38s} {"fwd":>15s} {"bwd-data":>15s} {"wgrad":>15s}   GFLOP  xcount')
+from lsnet_amd.ops.conv import weight_image, _levels
+print(f'mode {mode}; ms per call (own | MIOpen); err = max |own - fp64 reference| / max |reference|')
+print(f'{"shape":38s} {"fwd":>15s} {"bwd-data":>15s} {"wgrad":>15s}   GFLOP  xcount   TF(fwd) TB/s(fwd)  err fwd / bwd')
 tot = [0.0] * 6
+ONLY = os.environ.get('CONV_ONLY')   # substring filter on the shape name
 for name, ci, co, k, s, h, w, cnt in SH + EXTRA:
+    if ONLY and ONLY not in name:
+        continue
     pad = k // 2
     x = torch.randn(B, ci, h, w, device=dev).contiguous(memory_format=torch.channels_last)
     wt = (torch.randn(co, ci, k, k, device=dev) * 0.05).contiguous(memory_format=torch.channels_last)
     with torch.no_grad():
         ref = F.conv2d(x, wt, None, s, pad)
+        own = conv2d(x, wt, None, s, pad)
+        r64 = F.conv2d(x[:1, :, :min(h, 64)].double(), wt.double(), None, s, pad)
+        nr = r64.shape[2] - (4 if h > 64 else 0)   # (the cropped input has a padded bottom edge the full one lacks)
+        err_f = float((own[:1, :, :nr].double() - r64[:, :, :nr]).abs().max() / r64.abs().max())
         t_f = ev_time(lambda: conv2d(x, wt, None, s, pad))
         t_fm = 0.0 if OWN_ONLY else ev_time(lambda: F.conv2d(x, wt, None, s, pad))
     fl = 2.0 * ref.numel() * ci * k * k / 1e9
+    by = 4.0 * (x.numel() + ref.numel() + wt.numel()) / 1e9
     go = torch.randn_like(ref)
     line = f'{name:38s} {t_f:7.3f}|{t_fm:7.3f}'
+    err_d = 0.0
     if ci >= 8:
-        co8 = (co + 7) // 8 * 8
+        co8 = (co + 3) // 4 * 4
         go8 = go if co8 == co else torch.cat([go, go.new_zeros(B, co8 - co, *go.shape[2:])], 1).contiguous(memory_format=torch.channels_last)
         w8 = wt if co8 == co else torch.cat([wt, wt.new_zeros(co8 - co, ci, k, k)], 0).contiguous(memory_format=torch.channels_last)
-        ws = torch.empty(2 * w8.numel(), device=dev)
         gx = torch.empty_like(x)
         gw = torch.empty_like(wt)
-        t_d = ev_time(lambda: lib.lsn_conv2d_backward_data(cp(go8), cp(w8), cp(gx), cp(ws), B, h, w, ci, co8, k, k, s, pad, 1, st))
+        lv = _levels(1)
+        lv[0].x, lv[0].out, lv[0].B, lv[0].H, lv[0].W = cp(go8), cp(gx), B, h, w
+        img = weight_image(w8, 1, s, pad, 1)
+        f_d = lambda: lib.lsn_conv2d_backward_data_prepared(1, lv, cp(img), ci, co8, k, k, s, pad, 1, st)
+        assert f_d() == 0, lib.lsn_last_error()
+        gref = torch.ops.aten.convolution_backward(go, x, wt, None, [s, s], [pad, pad], [1, 1], False, [0, 0], 1, [True, False, False])[0]
+        err_d = float((gx - gref).abs().max() / gref.abs().max())
+        t_d = ev_time(f_d)
         t_w = ev_time(lambda: lib.lsn_conv2d_backward_weight(cp(x), cp(go), cp(gw), None, B, h, w, ci, co, k, k, s, pad, 1, st))
         t_dm = 0.0 if OWN_ONLY else ev_time(lambda: torch.ops.aten.convolution_backward(go, x, wt, None, [s, s], [pad, pad], [1, 1], False, [0, 0], 1, [True, False, False]))
         t_wm = 0.0 if OWN_ONLY else ev_time(lambda: torch.ops.aten.convolution_backward(go, x, wt, None, [s, s], [pad, pad], [1, 1], False, [0, 0], 1, [False, True, False]))
@@ -65,6 +81,6 @@ for name, ci, co, k, s, h, w, cnt in SH + EXTRA:
         tot[0] += t_f * cnt
         tot[1] += t_fm * cnt
         line += ' ' * 32
-    print(line + f' {fl:7.1f}  x{cnt}')
+    print(line + f' {fl:7.1f}  x{cnt}   {fl / t_f:7.1f} {by / t_f:7.2f}   {err_f:.1e} {err_d:.1e}', flush=True)
 print(f'network sums (ms): fwd own {tot[0]:.2f} | MIOpen {tot[1]:.2f};  bwd-data own {tot[2]:.2f} | {tot[3]:.2f};  '
       f'wgrad own {tot[4]:.2f} | {tot[5]:.2f}')
