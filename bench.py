@@ -295,8 +295,7 @@ def main():
     if not args.nchw:
         model = model.to(memory_format=torch.channels_last)
     model.train()
-    if world > 1:
-        model = DataParallelModel(model)
+    model = DataParallelModel(model)   # N = 1: the gradient arena alone (no communication), as train_detector builds it
     step, runner = build_step(model, cfg)
     data = synthetic_batch(args.task, args.batch, args.height, args.width, seed=1234 + rank, device=dev,
                            channels_last=not args.nchw)

@@ -79,6 +79,8 @@ typedef struct {
                         * backward-data kernel runs.  Contents undefined afterwards. */
     void *gather_workspace;          /* optional device scratch for lsn_dcn_backward's atomic-free grad_input path */
     int64_t gather_workspace_bytes;  /* (>= lsn_dcn_backward_workspace_bytes()); NULL / too small: fp32 atomics.   */
+    int accumulate_param_grads;      /* lsn_dcn_backward: 1 = ADD grad_weight / grad_bias to the buffers' contents (see
+                                      * lsn_conv2d_backward_weight), 0 = overwrite */
 } lsn_dcn_shape;
 
 /* One (source map, offset field, output) triple of a batched launch.  All levels of a launch
@@ -239,7 +241,7 @@ int lsn_nms(const float *dets, const int64_t *order, int n, float iou_thr, int64
  * one sub-image per residue class of a strided convolution).  A caller that keeps the image rebuilds it only when the
  * weight changes (once per optimizer step; the Python mirror keys it on the parameter's version counter):
  *   lsn_conv2d_prepared_bytes    size of the image in bytes (< 0: unsupported stride / dilation combination)
- *   lsn_conv2d_prepare_weights   w -> image (depends on the math mode current at the call)
+ *   lsn_conv2d_prepare_weights   w -> image (depends on the math mode current at the call); _multi: many at once
  *   lsn_conv2d_forward_prepared / lsn_conv2d_backward_data_prepared   the passes proper; `xpitch` = C except for the
  *                                row-merged form below
  * The one-shot entry points below build the image inside the call, into `workspace` / `wt_workspace` (at least
@@ -262,6 +264,14 @@ typedef struct lsn_conv_level {
 int64_t lsn_conv2d_prepared_bytes(int kind, int C, int Co, int kh, int kw, int stride, int pad, int dil);
 int lsn_conv2d_prepare_weights(int kind, const float *w, void *prepared, int C, int Co, int kh, int kw, int stride,
                                int pad, int dil, lsn_stream_t stream);
+/* The images of many weights in ONE launch (every trainable convolution after an optimizer step). */
+typedef struct lsn_conv_wprep {
+    int kind;            /* 0 forward, 1 backward-data */
+    const float *w;
+    void *prepared;
+    int C, Co, kh, kw, stride, pad, dil;
+} lsn_conv_wprep;
+int lsn_conv2d_prepare_weights_multi(int n_items, const lsn_conv_wprep *items, lsn_stream_t stream);
 int lsn_conv2d_forward_prepared(int n_levels, const lsn_conv_level *levels, const void *prepared, const float *bias,
                                 int C, int xpitch, int Co, int kh, int kw, int stride, int pad, int dil, int relu,
                                 lsn_stream_t stream);
@@ -275,16 +285,21 @@ int lsn_conv2d_forward_multi(int n_levels, const lsn_conv_level *levels, const f
 int lsn_conv2d_backward_data_multi(int n_levels, const lsn_conv_level *levels, const float *w, float *wt_workspace, int C,
                                    int Co, int kh, int kw, int stride, int pad, int dil, lsn_stream_t stream);
 int lsn_conv2d_backward_weight_multi(int n_levels, const lsn_conv_level *levels, float *grad_w, float *grad_bias, int C,
-                                     int Co, int kh, int kw, int stride, int pad, int dil, lsn_stream_t stream);
+                                     int Co, int kh, int kw, int stride, int pad, int dil, int accumulate,
+                                     lsn_stream_t stream);
 int lsn_conv2d_forward_pitched(const float *x, const float *w, const float *bias, float *out, void *workspace, int B,
                                int H, int W, int C, int xpitch, int Co, int kh, int kw, int stride, int pad, int dil,
                                int relu, lsn_stream_t stream);
 int lsn_conv2d_backward_data(const float *grad_out, const float *w, float *grad_in, float *wt_workspace, int B,
                              int H, int W, int C, int Co, int kh, int kw, int stride, int pad, int dil,
                              lsn_stream_t stream);
-/* grad_w (Co,kh,kw,C) and optionally grad_bias (Co), both OVERWRITTEN; any stride / padding / dilation. */
+/* grad_w (Co,kh,kw,C) and optionally grad_bias (Co); any stride / padding / dilation.
+ * `accumulate` (all parameter-gradient entry points of this header): 0 = the outputs are OVERWRITTEN; 1 = the results are
+ * ADDED to what the buffers hold -- the caller keeps every parameter gradient of a step in one arena it zeroes once
+ * (the all-reduce buckets of data-parallel training: no per-tensor memset, no gradient -> bucket copy or add). */
 int lsn_conv2d_backward_weight(const float *x, const float *grad_out, float *grad_w, float *grad_bias, int B, int H,
-                               int W, int C, int Co, int kh, int kw, int stride, int pad, int dil, lsn_stream_t stream);
+                               int W, int C, int Co, int kh, int kw, int stride, int pad, int dil, int accumulate,
+                               lsn_stream_t stream);
 
 /* ---- Grouped convolution (ResNeXt bottlenecks) -------------------------------------------------
  * Reference: torch.nn.Conv2d(groups = G) as built by mmdet/models/backbones/resnext.py:11-83 (Bottleneck.conv2:
@@ -294,7 +309,7 @@ int lsn_conv2d_backward_weight(const float *x, const float *grad_out, float *gra
  * layer is bound by HBM), in every math mode.  Supported: C / G == Co / G in {4, 8, 16, 32}, kh * kw <= 9, any
  * stride / padding / dilation; anything else returns LSN_ERR_UNSUPPORTED (the caller keeps ATen).
  * forward: out (B,Ho,Wo,Co) = conv(x (B,H,W,C)) + bias, optional ReLU.  backward_data: grad_in (B,H,W,C), OVERWRITTEN.
- * backward_weight: grad_w (Co,kh,kw,C/G) and optionally grad_bias (Co), both OVERWRITTEN. */
+ * backward_weight: grad_w (Co,kh,kw,C/G) and optionally grad_bias (Co), OVERWRITTEN or (accumulate = 1) added to. */
 int lsn_grouped_conv2d_forward(const float *x, const float *w, const float *bias, float *out, int B, int H, int W, int C,
                                int Co, int kh, int kw, int stride, int pad, int dil, int groups, int relu,
                                lsn_stream_t stream);
@@ -303,7 +318,7 @@ int lsn_grouped_conv2d_backward_data(const float *grad_out, const float *w, floa
                                      lsn_stream_t stream);
 int lsn_grouped_conv2d_backward_weight(const float *x, const float *grad_out, float *grad_w, float *grad_bias, int B,
                                        int H, int W, int C, int Co, int kh, int kw, int stride, int pad, int dil,
-                                       int groups, lsn_stream_t stream);
+                                       int groups, int accumulate, lsn_stream_t stream);
 
 /* ---- GroupNorm (+ReLU) on channels-last tensors ----------------------------------------------
  * The reference uses torch.nn.GroupNorm followed by nn.ReLU (ATen kernels; call sites
@@ -330,7 +345,7 @@ int lsn_group_norm_forward(int n_levels, const lsn_gn_level *levels, int C, int 
                            lsn_stream_t stream);
 int lsn_group_norm_backward(int n_levels, const lsn_gn_level *levels, int C, int G, const float *gamma,
                             const float *beta, int relu, const float *mean_rstd, float *grad_gamma,
-                            float *grad_beta, void *workspace, lsn_stream_t stream);
+                            float *grad_beta, void *workspace, int accumulate, lsn_stream_t stream);
 
 /* ---- BatchNorm with frozen statistics (+ residual add, + ReLU), channels-last ------------------
  * The LSNet backbones keep every BatchNorm in eval mode while training (norm_eval=True, resnet.py:636-645) but
@@ -340,7 +355,7 @@ int lsn_group_norm_backward(int n_levels, const lsn_gn_level *levels, int C, int
  *   backward: dz = grad_y * [y > 0] (when relu);  grad_x = dz * gamma_c / sqrt(var_c + eps);  grad_residual = dz;
  *             grad_gamma_c = sum dz * (x - mean_c) / sqrt(var_c + eps);  grad_beta_c = sum dz
  * residual / grad_x / grad_residual / grad_gamma+grad_beta may be NULL (not needed).  grad_gamma / grad_beta are
- * OVERWRITTEN.  Supported: C % 4 == 0 and 256 % (C/4) == 0 (C = 4 ... 1024), or C a multiple of 1024 (the 2048-channel
+ * OVERWRITTEN, or added to when accumulate = 1 (see lsn_conv2d_backward_weight).  Supported: C % 4 == 0 and 256 % (C/4) == 0 (C = 4 ... 1024), or C a multiple of 1024 (the 2048-channel
  * maps of a ResNet's last stage); else LSN_ERR_UNSUPPORTED. */
 int lsn_bn_eval_act_forward(const float *x, const float *residual, float *y, const float *running_mean,
                             const float *running_var, const float *gamma, const float *beta, float eps, int relu,
@@ -349,7 +364,7 @@ int64_t lsn_bn_eval_act_workspace_bytes(int N, int C);   /* scratch for backward
 int lsn_bn_eval_act_backward(const float *grad_y, const float *y, const float *x, const float *running_mean,
                              const float *running_var, const float *gamma, float eps, int relu, float *grad_x,
                              float *grad_residual, float *grad_gamma, float *grad_beta, void *workspace, int N,
-                             int C, lsn_stream_t stream);
+                             int C, int accumulate, lsn_stream_t stream);
 
 /* ---- diagnostics ---------------------------------------------------------------------------- */
 /* When set to a device buffer of 512 int64 (NULL disables), thread 0 of workgroup `block` of the

@@ -24,7 +24,7 @@ class DcnShape(ctypes.Structure):
                 ('dil', ctypes.c_int), ('groups', ctypes.c_int), ('deformable_groups', ctypes.c_int),
                 ('scale_h', ctypes.c_float), ('scale_w', ctypes.c_float), ('mask_is_logit', ctypes.c_int),
                 ('workspace', ctypes.c_void_p), ('gather_workspace', ctypes.c_void_p),
-                ('gather_workspace_bytes', ctypes.c_int64)]
+                ('gather_workspace_bytes', ctypes.c_int64), ('accumulate_param_grads', ctypes.c_int)]
 
 
 class DcnLevel(ctypes.Structure):
@@ -39,6 +39,12 @@ class DcnLevel(ctypes.Structure):
 class ConvLevel(ctypes.Structure):
     _fields_ = [('x', ctypes.c_void_p), ('out', ctypes.c_void_p), ('grad_out', ctypes.c_void_p),
                 ('B', ctypes.c_int), ('H', ctypes.c_int), ('W', ctypes.c_int)]
+
+
+class ConvWprep(ctypes.Structure):
+    _fields_ = [('kind', ctypes.c_int), ('w', ctypes.c_void_p), ('prepared', ctypes.c_void_p), ('C', ctypes.c_int),
+                ('Co', ctypes.c_int), ('kh', ctypes.c_int), ('kw', ctypes.c_int), ('stride', ctypes.c_int),
+                ('pad', ctypes.c_int), ('dil', ctypes.c_int)]
 
 
 class GnLevel(ctypes.Structure):
@@ -64,7 +70,8 @@ EXPORTS = [
     'lsn_prof_enable', 'lsn_prof_read',
     'lsn_group_norm_workspace_bytes', 'lsn_group_norm_forward', 'lsn_group_norm_backward',
     'lsn_set_math_mode', 'lsn_get_math_mode', 'lsn_conv2d_forward', 'lsn_conv2d_forward_pitched', 'lsn_conv2d_backward_data',
-    'lsn_conv2d_prepared_bytes', 'lsn_conv2d_prepare_weights', 'lsn_conv2d_forward_prepared',
+    'lsn_conv2d_prepared_bytes', 'lsn_conv2d_prepare_weights', 'lsn_conv2d_prepare_weights_multi',
+    'lsn_conv2d_forward_prepared',
     'lsn_conv2d_backward_data_prepared',
     'lsn_conv2d_forward_multi', 'lsn_conv2d_backward_data_multi', 'lsn_conv2d_backward_weight_multi', 'lsn_conv2d_backward_weight',
     'lsn_grouped_conv2d_forward', 'lsn_grouped_conv2d_backward_data', 'lsn_grouped_conv2d_backward_weight',

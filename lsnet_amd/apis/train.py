@@ -13,7 +13,10 @@ def train_detector(model, data_loaders, cfg, distributed=False, validate=False, 
         model = model.cuda()
         if channels_last:
             model = model.to(memory_format=torch.channels_last)
-    model = DataParallelModel(model) if distributed else model
+    # One process per GPU; the wrapper also is the gradient arena of a single process (bucket views as `p.grad` and as the
+    # kernels' gradient sinks, parallel/reducer.py), so it is used on the device whether or not there are peers.
+    if distributed or next(model.parameters()).is_cuda:
+        model = DataParallelModel(model)
     optimizer = build_optimizer(model, cfg.optimizer)
     runner = EpochBasedRunner(model, optimizer=optimizer, work_dir=cfg.get('work_dir'), logger=logger, meta=meta)
     runner.register_training_hooks(cfg.lr_config, cfg.optimizer_config, cfg.get('checkpoint_config'),

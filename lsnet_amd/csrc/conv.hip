@@ -16,6 +16,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
+
+#include <vector>
 
 #include "../../include/lsnet_hip.h"
 #include "common.h"
@@ -48,7 +51,7 @@ static int part_buffer(size_t floats, float **p)
     return 0;
 }
 
-template <int TM, int TN, int WM, int WN, int NP>
+template <int TM, int TN, int WM, int WN, int NP, bool UNAL>
 static int launch_conv_cfg(ConvArgs &a, int ks, hipStream_t st)
 {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -64,7 +67,7 @@ static int launch_conv_cfg(ConvArgs &a, int ks, hipStream_t st)
     if (ks > 1)
         if (int rc = part_buffer(n * ks, &a.part)) return rc;
     dim3 grid(tiles, (a.Co + BN - 1) / BN, ks);
-    auto k = conv_mm_kernel<TM, TN, WM, WN, NP>;
+    auto k = conv_mm_kernel<TM, TN, WM, WN, NP, UNAL>;
     static bool attr_set = false;   // per instantiation
     if (!attr_set) {
         LSN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -83,7 +86,15 @@ static int launch_conv_cfg(ConvArgs &a, int ks, hipStream_t st)
 template <int TM, int TN, int WM, int WN>
 static int launch_conv(ConvArgs &a, int ks, hipStream_t st)
 {
-    return conv_np() == 3 ? launch_conv_cfg<TM, TN, WM, WN, 3>(a, ks, st) : launch_conv_cfg<TM, TN, WM, WN, 6>(a, ks, st);
+    if constexpr (TN == 2 && WN == 2) {   // the unaligned-slab variant exists for the two wide tiles
+        if (a.C % 4 != 0 || a.xpitch % 4 != 0)
+            return conv_np() == 3 ? launch_conv_cfg<TM, TN, WM, WN, 3, true>(a, ks, st)
+                                  : launch_conv_cfg<TM, TN, WM, WN, 6, true>(a, ks, st);
+    }
+    if (a.C % 4 != 0 || a.xpitch % 4 != 0)
+        return fail(LSN_ERR_UNSUPPORTED, "conv2d: C %% 4 != 0 needs more than 64 output channels");
+    return conv_np() == 3 ? launch_conv_cfg<TM, TN, WM, WN, 3, false>(a, ks, st)
+                          : launch_conv_cfg<TM, TN, WM, WN, 6, false>(a, ks, st);
 }
 
 // Tile choice.  Two workgroups share a CU, so the chip holds 512 of them at once.  128 x 128 tiles (half the weight
@@ -160,7 +171,6 @@ static int conv_check(int B, int H, int W, int C, int Co, int kh, int kw, int st
 {
     LSN_CHECK(B > 0 && H > 0 && W > 0 && C > 0 && Co > 0 && kh > 0 && kw > 0, "conv2d: empty tensor");
     LSN_CHECK(stride > 0 && dil > 0 && pad >= 0, "conv2d: bad stride / dilation / padding");
-    if (C % 4 != 0) return fail(LSN_ERR_UNSUPPORTED, "conv2d kernel needs C %% 4 == 0, got %d", C);
     if (kh * kw > 64) return fail(LSN_ERR_UNSUPPORTED, "conv2d kernel takes at most 64 taps, got %d x %d", kh, kw);
     *Ho = conv_out_size(H, kh, stride, pad, dil);
     *Wo = conv_out_size(W, kw, stride, pad, dil);
@@ -191,7 +201,9 @@ static int conv_forward_impl(int n, const lsn_conv_level *lv, const void *prepar
                              int Co, int kh, int kw, int stride, int pad, int dil, int relu, hipStream_t st)
 {
     LSN_CHECK(n >= 1 && n <= CV_MAXLV && lv && prepared, "conv2d: bad level list");
-    LSN_CHECK(xpitch > 0 && xpitch % 4 == 0, "conv2d: the pixel pitch must be a multiple of 4 floats, got %d", xpitch);
+    LSN_CHECK(xpitch > 0, "conv2d: bad pixel pitch %d", xpitch);
+    if ((C % 4 != 0 || xpitch % 4 != 0) && Co <= 64)
+        return fail(LSN_ERR_UNSUPPORTED, "conv2d: C %% 4 != 0 needs more than 64 output channels");
     ConvArgs a = {};
     a.nlv = n;
     for (int i = 0; i < n; ++i) {
@@ -286,7 +298,7 @@ static int conv_backward_data_impl(int n, const lsn_conv_level *lv, const void *
                                    int stride, int pad, int dil, hipStream_t st)
 {
     LSN_CHECK(n >= 1 && n <= CV_MAXLV && lv && prepared, "conv2d backward: bad arguments");
-    if (Co % 4 != 0) return fail(LSN_ERR_UNSUPPORTED, "conv2d backward-data kernel needs Co %% 4 == 0");
+    if (Co % 4 != 0 && C <= 64) return fail(LSN_ERR_UNSUPPORTED, "conv2d backward-data: Co %% 4 != 0 needs C > 64");
     const int s = stride;
     int Ho[CV_MAXLV], Wo[CV_MAXLV];
     for (int i = 0; i < n; ++i) {
@@ -351,9 +363,74 @@ static int prepare_weights(int kind, const float *w, void *prepared, int C, int 
     return 0;
 }
 
+// ---- every stale image of a step in one launch ----
+static WfragJob *g_jobs_dev = nullptr;
+static size_t g_jobs_cap = 0;
+static std::vector<WfragJob> g_jobs_host;   // what the device table holds
+
+static int prepare_weights_multi(int n, const lsn_conv_wprep *it, hipStream_t st)
+{
+    LSN_CHECK(n >= 0 && (n == 0 || it), "conv2d prepare: bad item list");
+    std::vector<WfragJob> jobs;
+    long long total = 0;
+    for (int i = 0; i < n; ++i) {
+        const lsn_conv_wprep &p = it[i];
+        LSN_CHECK(p.w && p.prepared && p.C > 0 && p.Co > 0 && p.kh > 0 && p.kw > 0 && p.kh * p.kw <= 64,
+                  "conv2d prepare: bad item %d", i);
+        if (prepared_bytes(p.kind, p.C, p.Co, p.kh, p.kw, p.stride, p.pad, p.dil) >= ((int64_t)1 << 31))
+            return fail(LSN_ERR_UNSUPPORTED, "conv2d: weight too large for 32-bit buffer offsets");
+        if (p.kind == 0) {
+            WfragJob j = {};
+            j.w = p.w, j.out = reinterpret_cast<unsigned short *>(p.prepared);
+            j.Co = p.Co, j.K = p.kh * p.kw, j.C = p.C, j.flipT = 0, j.start = total;
+            total += (long long)j.K * cv_ncc(j.C) * cv_nt(j.Co) * 2 * 64;
+            jobs.push_back(j);
+        } else {
+            BwdPlan pl;
+            if (int rc = bwd_plan(p.C, p.Co, p.kh, p.kw, p.stride, p.pad, p.dil, &pl)) return rc;
+            for (int c = 0; c < pl.ncls; ++c) {
+                WfragJob j = {};
+                j.w = p.w, j.out = reinterpret_cast<unsigned short *>(reinterpret_cast<unsigned char *>(p.prepared) + pl.cls[c].wf_off);
+                j.Co = p.C, j.K = p.kh * p.kw, j.C = p.Co, j.flipT = 1, j.ts = pl.cls[c].ts, j.start = total;
+                total += (long long)j.ts.ni * j.ts.nj * cv_ncc(j.C) * cv_nt(j.Co) * 2 * 64;
+                jobs.push_back(j);
+            }
+        }
+    }
+    if (jobs.empty()) return 0;
+    const size_t bytes = jobs.size() * sizeof(WfragJob);
+    const bool same = jobs.size() == g_jobs_host.size() && memcmp(jobs.data(), g_jobs_host.data(), bytes) == 0;
+    if (!same) {   // the table changes only when the set of weights does (first steps): upload then, reuse afterwards
+        if (jobs.size() > g_jobs_cap) {
+            if (g_jobs_dev) {
+                LSN_HIP(hipDeviceSynchronize());
+                LSN_HIP(hipFree(g_jobs_dev));
+                g_jobs_dev = nullptr, g_jobs_cap = 0;
+            }
+            LSN_HIP(hipMalloc(reinterpret_cast<void **>(&g_jobs_dev), (jobs.size() + 64) * sizeof(WfragJob)));
+            g_jobs_cap = jobs.size() + 64;
+        }
+        LSN_HIP(hipStreamSynchronize(st));   // (an earlier launch may still read the old table)
+        LSN_HIP(hipMemcpy(g_jobs_dev, jobs.data(), bytes, hipMemcpyHostToDevice));
+        g_jobs_host = jobs;
+    }
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    if (conv_npl() == 2)
+        hipLaunchKernelGGL(conv_wfrag_multi_kernel<2>, dim3(blocks), dim3(256), 0, st, g_jobs_dev, (int)jobs.size(), total);
+    else
+        hipLaunchKernelGGL(conv_wfrag_multi_kernel<3>, dim3(blocks), dim3(256), 0, st, g_jobs_dev, (int)jobs.size(), total);
+    LSN_HIP(hipGetLastError());
+    return 0;
+}
+
 }  // namespace lsn
 
 extern "C" {
+
+int lsn_conv2d_prepare_weights_multi(int n_items, const lsn_conv_wprep *items, lsn_stream_t stream)
+{
+    return lsn::prepare_weights_multi(n_items, items, reinterpret_cast<hipStream_t>(stream));
+}
 
 int64_t lsn_conv2d_prepared_bytes(int kind, int C, int Co, int kh, int kw, int stride, int pad, int dil)
 {

@@ -79,46 +79,76 @@ __host__ __device__ inline size_t cv_wfrag_bytes(int Co, int Kd, int C, int npl)
 // the tap subset reversed.  Element (t, nt, ks, q, lane, e): n = nt * 32 + (lane & 31), k = ks * 16 + 8 * (lane >> 5) + e,
 // value = plane q of Wt[n][tap(t)][cc(t) * 32 + k] (0 beyond Co / C).
 template <int NPL>
+__device__ __forceinline__ void wfrag_item(const float *__restrict__ w, unsigned short *__restrict__ out, int Co, int K,
+                                           int C, int flipT, const TapSub &ts, long long id)
+{
+    const int ncc = cv_ncc(C), NT = cv_nt(Co);
+    const int lane = (int)(id & 63);
+    long long r = id >> 6;
+    const int ks = (int)(r & 1);
+    r >>= 1;
+    const int nt = (int)(r % NT);
+    const int t = (int)(r / NT);
+    const int tap = t / ncc, cc = t - tap * ncc;
+    const int n = nt * 32 + (lane & 31);
+    const int c0 = cc * 32 + ks * 16 + 8 * (lane >> 5);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = c0 + e;
+        float val = 0.f;
+        if (n < Co && c < C) {
+            if (!flipT) {
+                val = w[((size_t)n * K + tap) * C + c];
+            } else {
+                // transposed convolution: this GEMM's (n, c) = forward (ci, co); source layout (Co_f = C, K, C_f = Co)
+                const int m = tap / ts.nj, nn = tap - m * ts.nj;
+                const int i = ts.i0 + (ts.ni - 1 - m) * ts.istep, j = ts.j0 + (ts.nj - 1 - nn) * ts.jstep;
+                val = w[((size_t)c * K + i * ts.kw + j) * Co + n];
+            }
+        }
+        v[e] = val;
+    }
+    unsigned pl[4][NPL];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split_planes<NPL>(v[2 * e], v[2 * e + 1], pl[e]);
+    unsigned short *dst = out + ((((size_t)t * NT + nt) * 2 + ks) * NPL) * 512 + (size_t)lane * 8;
+#pragma unroll
+    for (int q = 0; q < NPL; ++q)
+        *reinterpret_cast<uint4 *>(dst + (size_t)q * 512) = make_uint4(pl[0][q], pl[1][q], pl[2][q], pl[3][q]);
+}
+
+template <int NPL>
 __global__ void conv_wfrag_kernel(const float *__restrict__ w, unsigned short *__restrict__ out, int Co, int K, int C,
                                   int flipT, TapSub ts)
 {
     const int Kd = flipT ? ts.ni * ts.nj : K;
-    const int ncc = cv_ncc(C), NT = cv_nt(Co);
-    const long long total = (long long)Kd * ncc * NT * 2 * 64;   // one thread per (t, nt, ks, lane)
+    const long long total = (long long)Kd * cv_ncc(C) * cv_nt(Co) * 2 * 64;   // one thread per (t, nt, ks, lane)
+    for (long long id = blockIdx.x * (long long)blockDim.x + threadIdx.x; id < total; id += (long long)gridDim.x * blockDim.x)
+        wfrag_item<NPL>(w, out, Co, K, C, flipT, ts, id);
+}
+
+// Many weights in ONE launch (the images of every trainable convolution after an optimizer step): job j owns the
+// thread ids [start_j, start_{j+1}).
+struct WfragJob {
+    const float *w;
+    unsigned short *out;
+    int Co, K, C, flipT;
+    TapSub ts;
+    long long start;
+};
+
+template <int NPL>
+__global__ void conv_wfrag_multi_kernel(const WfragJob *__restrict__ jobs, int njobs, long long total)
+{
     for (long long id = blockIdx.x * (long long)blockDim.x + threadIdx.x; id < total; id += (long long)gridDim.x * blockDim.x) {
-        const int lane = (int)(id & 63);
-        long long r = id >> 6;
-        const int ks = (int)(r & 1);
-        r >>= 1;
-        const int nt = (int)(r % NT);
-        const int t = (int)(r / NT);
-        const int tap = t / ncc, cc = t - tap * ncc;
-        const int n = nt * 32 + (lane & 31);
-        const int c0 = cc * 32 + ks * 16 + 8 * (lane >> 5);
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int c = c0 + e;
-            float val = 0.f;
-            if (n < Co && c < C) {
-                if (!flipT) {
-                    val = w[((size_t)n * K + tap) * C + c];
-                } else {
-                    // transposed convolution: this GEMM's (n, c) = forward (ci, co); source layout (Co_f = C, K, C_f = Co)
-                    const int m = tap / ts.nj, nn = tap - m * ts.nj;
-                    const int i = ts.i0 + (ts.ni - 1 - m) * ts.istep, j = ts.j0 + (ts.nj - 1 - nn) * ts.jstep;
-                    val = w[((size_t)c * K + i * ts.kw + j) * Co + n];
-                }
-            }
-            v[e] = val;
+        int lo = 0, hi = njobs - 1;   // last job with start <= id
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (jobs[mid].start <= id) lo = mid; else hi = mid - 1;
         }
-        unsigned pl[4][NPL];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) split_planes<NPL>(v[2 * e], v[2 * e + 1], pl[e]);
-        unsigned short *dst = out + ((((size_t)t * NT + nt) * 2 + ks) * NPL) * 512 + (size_t)lane * 8;
-#pragma unroll
-        for (int q = 0; q < NPL; ++q)
-            *reinterpret_cast<uint4 *>(dst + (size_t)q * 512) = make_uint4(pl[0][q], pl[1][q], pl[2][q], pl[3][q]);
+        const WfragJob jb = jobs[lo];
+        wfrag_item<NPL>(jb.w, jb.out, jb.Co, jb.K, jb.C, jb.flipT, jb.ts, id - jb.start);
     }
 }
 
@@ -137,7 +167,10 @@ __device__ __forceinline__ bf16x8 cv_load_frag(__amdgpu_buffer_rsrc_t rs, int vo
     return f;
 }
 
-template <int TM, int TN, int WM, int WN, int NP>
+// UNAL: the reduction channel count is not a multiple of 4 (the data gradient of LSHead's 27-channel offset / mask
+// convolutions): a pixel's slab is then neither 16-byte aligned nor a whole number of float4, so the pixel operand is
+// fetched with four 4-byte loads per lane, each with its own channel guard.
+template <int TM, int TN, int WM, int WN, int NP, bool UNAL = false>
 __global__ __launch_bounds__(256, 2) void conv_mm_kernel(const ConvArgs a)
 {
     using SC = SplitCfg<NP>;
@@ -216,7 +249,15 @@ __global__ __launch_bounds__(256, 2) void conv_mm_kernel(const ConvArgs a)
 #pragma unroll
         for (int ps = 0; ps < NLD; ++ps) {
             const bool ok = ((vmask[ps] >> tap) & 1ull) != 0 && cok;
-            xv[ps] = cv_load4(xrs, ok ? pbase[ps] + toff : OOB, 0);
+            if constexpr (!UNAL) {
+                xv[ps] = cv_load4(xrs, ok ? pbase[ps] + toff : OOB, 0);
+            } else {
+                const int c0 = c.cc * BK + 4 * c4, vo = pbase[ps] + toff;
+                xv[ps].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, ok ? vo : OOB, 0, 0));
+                xv[ps].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, ok && c0 + 1 < a.C ? vo + 4 : OOB, 0, 0));
+                xv[ps].z = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, ok && c0 + 2 < a.C ? vo + 8 : OOB, 0, 0));
+                xv[ps].w = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, ok && c0 + 3 < a.C ? vo + 12 : OOB, 0, 0));
+            }
         }
     };
     auto commit_x = [&](unsigned char *buf) {

@@ -575,7 +575,7 @@ static int wgrad_vec_bits(const DcnArgs &a)
     return (vx ? 1 : 0) | (vg ? 2 : 0);
 }
 
-static int launch_wgrad(const DcnArgs &a_in, int nsteps, hipStream_t st)
+static int launch_wgrad(const DcnArgs &a_in, int nsteps, bool accumulate, hipStream_t st)
 {
     DcnArgs a = a_in;
     a.wg_vec = wgrad_vec_bits(a);
@@ -588,8 +588,10 @@ static int launch_wgrad(const DcnArgs &a_in, int nsteps, hipStream_t st)
     if (splits < 1) splits = 1;
     if (splits > 65535) splits = 65535;
     const size_t lds = (size_t)WG_BP * (WG_BM + WG_BN) * 4 + 2 * WG_BP * sizeof(Tap);
-    LSN_HIP(hipMemsetAsync(a.gw, 0, sizeof(float) * (size_t)a.Co * K * Cg, st));
-    if (a.gb) LSN_HIP(hipMemsetAsync(a.gb, 0, sizeof(float) * (size_t)a.Co, st));
+    if (!accumulate) {
+        LSN_HIP(hipMemsetAsync(a.gw, 0, sizeof(float) * (size_t)a.Co * K * Cg, st));
+        if (a.gb) LSN_HIP(hipMemsetAsync(a.gb, 0, sizeof(float) * (size_t)a.Co, st));
+    }
     ProfScope prof(PROF_WGRAD, a, st);
     if (math_np() && !((g_dbg_block >> 30) & 1)) {   // bit 30: force the fp32 MFMA kernel
         if (math_np() == 6) {
@@ -747,7 +749,8 @@ static int dcn_backward_impl(const lsn_dcn_shape &s, int n, const lsn_dcn_level 
             w.lv[i].tile0 = steps;
             steps += cdiv(w.lv[i].P, WG_BP);
         }
-        if (int rc = launch_wgrad(w, steps, st)) return rc;
+        // (the reference-layout path computes into a temporary that is permuted into grad_weight: no accumulation there)
+        if (int rc = launch_wgrad(w, steps, s.accumulate_param_grads != 0 && layout == LSN_NHWC, st)) return rc;
     }
     if (layout == LSN_NCHW) {
         for (int i = 0; i < n; ++i)
@@ -826,7 +829,7 @@ static int conv_wgrad_launch(const DcnArgs &a, int nsteps, int C, int Co, int K,
 }
 
 static int conv_wgrad_xn(int n, const lsn_conv_level *lv, float *gw, float *gb, int C, int Co, int kh, int kw, int stride,
-                         int pad, int dil, hipStream_t st)
+                         int pad, int dil, bool accumulate, hipStream_t st)
 {
     LSN_CHECK(n >= 1 && n <= MAXLV && lv && gw, "conv2d backward-weight: bad arguments");
     DcnArgs a = {};
@@ -850,8 +853,10 @@ static int conv_wgrad_xn(int n, const lsn_conv_level *lv, float *gw, float *gb, 
     a.gw = gw, a.gb = gb;
     a.wg_vec = wgrad_vec_bits(a);
     const int K = kh * kw;
-    LSN_HIP(hipMemsetAsync(gw, 0, sizeof(float) * (size_t)Co * K * C, st));
-    if (gb) LSN_HIP(hipMemsetAsync(gb, 0, sizeof(float) * (size_t)Co, st));
+    if (!accumulate) {
+        LSN_HIP(hipMemsetAsync(gw, 0, sizeof(float) * (size_t)Co * K * C, st));
+        if (gb) LSN_HIP(hipMemsetAsync(gb, 0, sizeof(float) * (size_t)Co, st));
+    }
     double px = 0, in_el = 0;
     for (int i = 0; i < n; ++i) px += (double)a.lv[i].P, in_el += (double)a.lv[i].B * a.lv[i].H * a.lv[i].W * C;
     ProfSpan prof(PROF_CONV_WGRAD, 2.0 * px * Co * C * K, 4.0 * (in_el + px * Co + (double)Co * K * C), st);
@@ -901,19 +906,21 @@ int lsn_set_math_mode(int mode)
 int lsn_get_math_mode(void) { return lsn::math_mode(); }
 
 int lsn_conv2d_backward_weight_multi(int n_levels, const lsn_conv_level *levels, float *grad_w, float *grad_bias, int C,
-                                     int Co, int kh, int kw, int stride, int pad, int dil, lsn_stream_t stream)
+                                     int Co, int kh, int kw, int stride, int pad, int dil, int accumulate,
+                                     lsn_stream_t stream)
 {
     LSN_CHECK(C > 0 && Co > 0 && kh > 0 && kw > 0 && stride > 0 && dil > 0 && pad >= 0, "conv2d backward-weight: bad shape");
-    return conv_wgrad_xn(n_levels, levels, grad_w, grad_bias, C, Co, kh, kw, stride, pad, dil,
+    return conv_wgrad_xn(n_levels, levels, grad_w, grad_bias, C, Co, kh, kw, stride, pad, dil, accumulate != 0,
                          reinterpret_cast<hipStream_t>(stream));
 }
 
 int lsn_conv2d_backward_weight(const float *x, const float *grad_out, float *grad_w, float *grad_bias, int B, int H,
-                               int W, int C, int Co, int kh, int kw, int stride, int pad, int dil, lsn_stream_t stream)
+                               int W, int C, int Co, int kh, int kw, int stride, int pad, int dil, int accumulate,
+                               lsn_stream_t stream)
 {
     lsn_conv_level L = {};
     L.x = x, L.grad_out = grad_out, L.B = B, L.H = H, L.W = W;
-    return lsn_conv2d_backward_weight_multi(1, &L, grad_w, grad_bias, C, Co, kh, kw, stride, pad, dil, stream);
+    return lsn_conv2d_backward_weight_multi(1, &L, grad_w, grad_bias, C, Co, kh, kw, stride, pad, dil, accumulate, stream);
 }
 
 int lsn_prof_enable(int on)

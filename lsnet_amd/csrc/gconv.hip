@@ -214,7 +214,7 @@ int lsn_grouped_conv2d_backward_data(const float *grad_out, const float *w, floa
 
 int lsn_grouped_conv2d_backward_weight(const float *x, const float *grad_out, float *grad_w, float *grad_bias, int B,
                                        int H, int W, int C, int Co, int kh, int kw, int stride, int pad, int dil,
-                                       int groups, lsn_stream_t stream)
+                                       int groups, int accumulate, lsn_stream_t stream)
 {
     LSN_CHECK(x && grad_out && grad_w, "grouped conv2d backward-weight: NULL tensor");
     GcArgs a = {};
@@ -223,8 +223,10 @@ int lsn_grouped_conv2d_backward_weight(const float *x, const float *grad_out, fl
     a.x = x, a.gout = grad_out, a.gw = grad_w, a.gb = grad_bias;
     a.P = B * a.Ho * a.Wo;
     const int cg = C / groups, K = kh * kw;
-    LSN_HIP(hipMemsetAsync(grad_w, 0, sizeof(float) * (size_t)Co * K * cg, st));
-    if (grad_bias) LSN_HIP(hipMemsetAsync(grad_bias, 0, sizeof(float) * (size_t)Co, st));
+    if (!accumulate) {
+        LSN_HIP(hipMemsetAsync(grad_w, 0, sizeof(float) * (size_t)Co * K * cg, st));
+        if (grad_bias) LSN_HIP(hipMemsetAsync(grad_bias, 0, sizeof(float) * (size_t)Co, st));
+    }
     const int ny = cdiv(groups * cg * cg, 256);
     int nsplit = cdiv(4096, ny);   // ~16 blocks per CU in flight: the kernel is load-latency bound
     if (nsplit > cdiv(a.P, 32)) nsplit = cdiv(a.P, 32);

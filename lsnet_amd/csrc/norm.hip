@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const GnArgs a)
 }
 
 // d gamma[c] = sum_images A[img][c], d beta[c] = sum_images Bc[img][c]
-__global__ void gn_param_grad_kernel(const GnArgs a, int images)
+__global__ void gn_param_grad_kernel(const GnArgs a, int images, int accumulate)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= a.C) return;
@@ -254,8 +254,8 @@ __global__ void gn_param_grad_kernel(const GnArgs a, int images)
         sa += a.ab[((size_t)i * a.C + c) * 2];
         sb += a.ab[((size_t)i * a.C + c) * 2 + 1];
     }
-    if (a.dgamma) a.dgamma[c] = sa;
-    if (a.dbeta) a.dbeta[c] = sb;
+    if (a.dgamma) a.dgamma[c] = accumulate ? a.dgamma[c] + sa : sa;
+    if (a.dbeta) a.dbeta[c] = accumulate ? a.dbeta[c] + sb : sb;
 }
 
 static int gn_fill(GnArgs &a, int n, const lsn_gn_level *lv, int C, int G, int *tiles, int *images)
@@ -454,7 +454,7 @@ int lsn_group_norm_forward(int n_levels, const lsn_gn_level *levels, int C, int 
 
 int lsn_group_norm_backward(int n_levels, const lsn_gn_level *levels, int C, int G, const float *gamma,
                             const float *beta, int relu, const float *mean_rstd, float *grad_gamma,
-                            float *grad_beta, void *workspace, lsn_stream_t stream)
+                            float *grad_beta, void *workspace, int accumulate, lsn_stream_t stream)
 {
     using namespace lsn;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -475,7 +475,7 @@ int lsn_group_norm_backward(int n_levels, const lsn_gn_level *levels, int C, int
     hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(tiles), dim3(256), 0, st, a);
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(tiles), dim3(256), 0, st, a);
     if (grad_gamma || grad_beta)
-        hipLaunchKernelGGL(gn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, st, a, images);
+        hipLaunchKernelGGL(gn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, st, a, images, accumulate);
     LSN_HIP(hipGetLastError());
     return 0;
 }
@@ -504,7 +504,7 @@ int64_t lsn_bn_eval_act_workspace_bytes(int N, int C)
 int lsn_bn_eval_act_backward(const float *grad_y, const float *y, const float *x, const float *running_mean,
                              const float *running_var, const float *gamma, float eps, int relu, float *grad_x,
                              float *grad_residual, float *grad_gamma, float *grad_beta, void *workspace, int N,
-                             int C, lsn_stream_t stream)
+                             int C, int accumulate, lsn_stream_t stream)
 {
     using namespace lsn;
     if (int rc = bn_check(N, C)) return rc;
@@ -521,8 +521,10 @@ int lsn_bn_eval_act_backward(const float *grad_y, const float *y, const float *x
     if (grad_gamma) {
         LSN_CHECK(workspace != nullptr, "batch norm backward: grad_gamma needs the workspace");
         a.part = reinterpret_cast<float *>(workspace);
-        LSN_HIP(hipMemsetAsync(grad_gamma, 0, sizeof(float) * C, st));
-        LSN_HIP(hipMemsetAsync(grad_beta, 0, sizeof(float) * C, st));
+        if (!accumulate) {
+            LSN_HIP(hipMemsetAsync(grad_gamma, 0, sizeof(float) * C, st));
+            LSN_HIP(hipMemsetAsync(grad_beta, 0, sizeof(float) * C, st));
+        }
     }
     hipLaunchKernelGGL(bn_act_bwd_kernel, dim3(blocks, (C / 4 + 255) / 256), dim3(256), 0, st, a);
     if (grad_gamma) {

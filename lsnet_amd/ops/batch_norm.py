@@ -11,6 +11,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import _lib
+from . import grad_sink
 
 _CL = torch.channels_last
 
@@ -34,6 +35,7 @@ class _BnActFn(torch.autograd.Function):
                                                        _stream()))
         ctx.save_for_backward(x, y if relu else None, gamma, mean, var)
         ctx.cfg = (eps, relu, residual is not None)
+        ctx.beta_ref = beta    # backward only asks where its gradient goes (ops/grad_sink.py)
         return y
 
     @staticmethod
@@ -47,14 +49,24 @@ class _BnActFn(torch.autograd.Function):
         need_p = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
         dx = torch.empty_like(x, memory_format=_CL) if need_x else None
         dres = torch.empty_like(x, memory_format=_CL) if need_res else None
-        dg = torch.empty_like(gamma) if need_p else None
-        db = torch.empty_like(gamma) if need_p else None
+        sg = grad_sink.sink(gamma) if ctx.needs_input_grad[2] else None
+        sb = grad_sink.sink(ctx.beta_ref) if ctx.needs_input_grad[3] else None
+        acc = 1 if (sg is not None and sb is not None) else 0
+        if acc:
+            dg, db = sg, sb
+        else:
+            dg = torch.empty_like(gamma) if need_p else None
+            db = torch.empty_like(gamma) if need_p else None
         lib = _lib.load()
         ws = torch.empty(lib.lsn_bn_eval_act_workspace_bytes(B * H * W, C), device=x.device, dtype=torch.uint8) \
             if need_p else None
         _lib.check(lib.lsn_bn_eval_act_backward(_p(dy), _p(y), _p(x), _p(mean), _p(var), _p(gamma), ctypes.c_float(eps),
                                                 1 if relu else 0, _p(dx), _p(dres), _p(dg), _p(db), _p(ws), B * H * W, C,
-                                                _stream()))
+                                                acc, _stream()))
+        if acc:
+            grad_sink.done(gamma)
+            grad_sink.done(ctx.beta_ref)
+            dg = db = None
         return dx, dres, dg if ctx.needs_input_grad[2] else None, db if ctx.needs_input_grad[3] else None, \
             None, None, None, None
 

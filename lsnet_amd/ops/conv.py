@@ -17,6 +17,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import _lib
+from . import grad_sink
 
 _CL = torch.channels_last
 
@@ -36,31 +37,78 @@ def _pad_channels(t, c_to):
     return out
 
 
-_images = {}    # (id(weight), kind, stride, pad, dil, math mode) -> (weakref, version, data_ptr, image)
+_images = {}    # (id(weight), kind, stride, pad, dil, math mode) -> [weakref, version, data_ptr, image]
+
+
+def _refresh_stale(mode):
+    """Rebuild EVERY cached image whose weight has moved on (all trainable convolutions after an optimizer step) in one
+    launch (lsn_conv2d_prepare_weights_multi): called when the first stale image of a step is asked for."""
+    items = []
+    for key, ent in _images.items():
+        w = ent[0]()
+        if w is None or key[5] != mode or (ent[1] == w._version and ent[2] == w.data_ptr()):
+            continue
+        items.append((key, ent, w))
+    if not items:
+        return
+    arr = (_lib.ConvWprep * len(items))()
+    for it, (key, ent, w) in zip(arr, items):
+        Co, C, kh, kw = w.shape
+        it.kind, it.w, it.prepared = key[1], w.data_ptr(), ent[3].data_ptr()
+        it.C, it.Co, it.kh, it.kw, it.stride, it.pad, it.dil = C, Co, kh, kw, key[2], key[3], key[4]
+    _lib.check(_lib.load().lsn_conv2d_prepare_weights_multi(len(items), arr, _stream()))
+    for key, ent, w in items:
+        ent[1], ent[2] = w._version, w.data_ptr()
 
 
 def weight_image(w, kind, stride=1, pad=0, dil=1):
     """The prepared image (lsn_conv2d_prepare_weights) of a channels-last (Co, C, kh, kw) weight for the forward
-    (kind 0) or backward-data (kind 1) pass.  Cached per tensor OBJECT and version: a parameter's image is rebuilt
-    once per optimizer step; a temporary (padded view, test tensor) gets a fresh one and drops it when it dies."""
+    (kind 0) or backward-data (kind 1) pass.  Cached per tensor OBJECT and version: the images of all parameters are
+    rebuilt together, once per optimizer step, when the first of them is needed; a temporary (padded view, test tensor)
+    gets a fresh one and drops it when it dies."""
     lib = _lib.load()
-    Co, C, kh, kw = w.shape
-    key = (id(w), kind, stride, pad, dil, lib.lsn_get_math_mode())
+    mode = lib.lsn_get_math_mode()
+    key = (id(w), kind, stride, pad, dil, mode)
     ent = _images.get(key)
-    if ent is not None and ent[0]() is w and ent[1] == w._version and ent[2] == w.data_ptr():
+    if ent is not None and ent[0]() is w:
+        if ent[1] != w._version or ent[2] != w.data_ptr():
+            _refresh_stale(mode)
         return ent[3]
+    Co, C, kh, kw = w.shape
     nbytes = lib.lsn_conv2d_prepared_bytes(kind, C, Co, kh, kw, stride, pad, dil)
     if nbytes < 0:
         _lib.check(-2)
-    img = ent[3] if (ent is not None and ent[0]() is w and ent[3].numel() == nbytes) else \
-        torch.empty(nbytes, device=w.device, dtype=torch.uint8)
+    img = torch.empty(nbytes, device=w.device, dtype=torch.uint8)
     _lib.check(lib.lsn_conv2d_prepare_weights(kind, _p(w), _p(img), C, Co, kh, kw, stride, pad, dil, _stream()))
-    _images[key] = (weakref.ref(w, lambda _, k=key: _images.pop(k, None)), w._version, w.data_ptr(), img)
+    _images[key] = [weakref.ref(w, lambda _, k=key: _images.pop(k, None)), w._version, w.data_ptr(), img]
     return img
 
 
 def _levels(n):
     return (_lib.ConvLevel * n)()
+
+
+def _param_grad_buffers(w, bias, want_w, want_b):
+    """Where a weight / bias gradient kernel writes: the parameters' gradient sinks (ops/grad_sink.py; accumulate = 1)
+    when BOTH wanted gradients have one, fresh tensors otherwise.  Returns (grad_w buffer, grad_b buffer or None, acc)."""
+    sw = grad_sink.sink(w) if want_w else None
+    sb = grad_sink.sink(bias) if (want_b and bias is not None) else None
+    if want_w and sw is not None and (not want_b or sb is not None) and sw.is_contiguous(memory_format=_CL) == \
+            w.is_contiguous(memory_format=_CL) and sw.stride() == w.stride():
+        return sw, sb, 1
+    gw = torch.empty_like(w)
+    gb = torch.empty(w.shape[0], device=w.device, dtype=torch.float32) if want_b else None
+    return gw, gb, 0
+
+
+def _param_grad_results(w, bias, gw, gb, acc, want_w):
+    """What the Function returns to autograd for (weight, bias) after the kernel ran."""
+    if acc:
+        grad_sink.done(w)
+        if gb is not None:
+            grad_sink.done(bias)
+        return None, None
+    return (gw if want_w else None), gb
 
 
 class _ConvFn(torch.autograd.Function):
@@ -82,6 +130,7 @@ class _ConvFn(torch.autograd.Function):
                                                    dil, 1 if relu else 0, _stream()))
         ctx.save_for_backward(x, w, out if relu else None)
         ctx.cfg = (stride, pad, dil, relu, bias is not None)
+        ctx.bias_ref = bias    # (not saved for its value: backward only asks where its gradient goes)
         return out
 
     @staticmethod
@@ -98,7 +147,7 @@ class _ConvFn(torch.autograd.Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             go8, w8, Co8 = go, w, Co
-            if Co % 4:    # the transposed convolution reads grad_output in 4-channel pieces: zero filters are free
+            if Co % 4 and C <= 64:    # (narrow tiles read grad_output in 4-channel pieces: zero filters are free)
                 Co8 = (Co + 3) // 4 * 4
                 go8 = _pad_channels(go, Co8)
                 w8 = w.new_zeros((Co8, C, kh, kw)).contiguous(memory_format=_CL)
@@ -110,13 +159,11 @@ class _ConvFn(torch.autograd.Function):
                                                              kw, stride, pad, dil, _stream()))
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
             # weight gradient and the bias gradient in one pass over grad_output
-            gw = torch.empty_like(w)
             want_b = has_bias and ctx.needs_input_grad[2]
-            gb = torch.empty(Co, device=x.device, dtype=torch.float32) if want_b else None
+            gw, gb, acc = _param_grad_buffers(w, ctx.bias_ref if want_b else None, ctx.needs_input_grad[1], want_b)
             _lib.check(lib.lsn_conv2d_backward_weight(_p(x), _p(go), _p(gw), _p(gb), B, H, W, C, Co, kh, kw, stride, pad,
-                                                      dil, _stream()))
-            if not ctx.needs_input_grad[1]:
-                gw = None
+                                                      dil, acc, _stream()))
+            gw, gb = _param_grad_results(w, ctx.bias_ref if want_b else None, gw, gb, acc, ctx.needs_input_grad[1])
         return gx, gw, gb, None, None, None, None
 
 
@@ -156,7 +203,7 @@ class _GroupConvFn(torch.autograd.Function):
             gw = torch.empty_like(w)
             gb = torch.empty(Co, device=x.device, dtype=torch.float32) if has_bias and ctx.needs_input_grad[2] else None
             _lib.check(lib.lsn_grouped_conv2d_backward_weight(_p(x), _p(go), _p(gw), _p(gb), B, H, W, C, Co, kh, kw, stride,
-                                                              pad, dil, groups, _stream()))
+                                                              pad, dil, groups, 0, _stream()))
             if not ctx.needs_input_grad[1]:
                 gw = None
         return gx, gw, gb, None, None, None, None
@@ -200,6 +247,7 @@ class _ConvMultiFn(torch.autograd.Function):
                                                    dil, 1 if relu else 0, _stream()))
         ctx.save_for_backward(w, *xs, *(outs if relu else []))
         ctx.cfg, ctx.n, ctx.has_bias = cfg, n, bias is not None
+        ctx.bias_ref = bias
         return tuple(outs)
 
     @staticmethod
@@ -219,7 +267,7 @@ class _ConvMultiFn(torch.autograd.Function):
         gxs = [None] * n
         if any(need_x):
             w8, Co8, gos8 = w, Co, gos
-            if Co % 4:
+            if Co % 4 and C <= 64:
                 Co8 = (Co + 3) // 4 * 4
                 gos8 = [_pad_channels(g, Co8) for g in gos]
                 w8 = w.new_zeros((Co8, C, kh, kw)).contiguous(memory_format=_CL)
@@ -238,11 +286,11 @@ class _ConvMultiFn(torch.autograd.Function):
             for i, x in enumerate(xs):
                 L = levels[i]
                 L.x, L.grad_out, L.B, L.H, L.W = _p(x), _p(gos[i]), x.shape[0], x.shape[2], x.shape[3]
-            gw = torch.empty_like(w)
-            gb = torch.empty(Co, device=w.device, dtype=torch.float32) if (ctx.has_bias and ctx.needs_input_grad[1]) else None
-            _lib.check(lib.lsn_conv2d_backward_weight_multi(n, levels, _p(gw), _p(gb), C, Co, kh, kw, 1, pad, dil, _stream()))
-            if not ctx.needs_input_grad[0]:
-                gw = None
+            want_b = ctx.has_bias and ctx.needs_input_grad[1]
+            gw, gb, acc = _param_grad_buffers(w, ctx.bias_ref if want_b else None, ctx.needs_input_grad[0], want_b)
+            _lib.check(lib.lsn_conv2d_backward_weight_multi(n, levels, _p(gw), _p(gb), C, Co, kh, kw, 1, pad, dil, acc,
+                                                            _stream()))
+            gw, gb = _param_grad_results(w, ctx.bias_ref if want_b else None, gw, gb, acc, ctx.needs_input_grad[0])
         return (gw, gb, None, *gxs)
 
 

@@ -20,6 +20,7 @@ from torch.autograd.function import once_differentiable
 from torch.nn.modules.utils import _pair, _single
 
 from ..cnn.registry import CONV_LAYERS
+from . import grad_sink
 from .backend import get_backend
 from .conv import Conv2d
 
@@ -61,6 +62,7 @@ class _DCNFunction(Function):
             out_hw.append(hw)
         ctx.cfg, ctx.n, ctx.backend = cfg, n, backend
         ctx.has_bias = bias is not None
+        ctx.bias_ref = bias    # backward only asks where its gradient goes (ops/grad_sink.py)
         ctx.mask_none = [m is None for m in masks]
         ctx.save_for_backward(weight, *inputs, *offsets, *[m for m in masks if m is not None])
         outs = backend.dcn_forward(list(inputs), list(offsets), list(masks), weight, bias, cfg, out_hw)
@@ -85,15 +87,28 @@ class _DCNFunction(Function):
                 x, off = inputs[i], offsets[i]
                 g = x.new_zeros((x.shape[0], weight.shape[0], off.shape[2], off.shape[3]))
             gos.append(g)
+        # parameter gradients straight into their sinks (the all-reduce buckets) when both have one
+        sw = grad_sink.sink(weight) if need['weight'] else None
+        sb = grad_sink.sink(ctx.bias_ref) if need['bias'] else None
+        sunk = sw is not None and (not need['bias'] or sb is not None) and sw.stride() == weight.stride() \
+            and getattr(ctx.backend, 'supports_grad_sinks', False)
+        if sunk:
+            need['sinks'] = (sw, sb)
         gxs, goffs, gmsks, gw, gb = ctx.backend.dcn_backward(list(inputs), list(offsets), masks, weight, gos,
                                                             cfg, need)
+        if sunk and need.get('sunk'):
+            grad_sink.done(weight)
+            if sb is not None:
+                grad_sink.done(ctx.bias_ref)
+            gw = gb = None
         gxs = [g if need['input'][i] else None for i, g in enumerate(gxs)]
         goffs = [g if need['offset'][i] else None for i, g in enumerate(goffs)]
         gmsks = [g if (need['mask'][i] and not ctx.mask_none[i]) else None for i, g in enumerate(gmsks)]
         if gw is not None and gw.stride() != weight.stride():
             gw = gw.contiguous(memory_format=torch.channels_last if weight.is_contiguous(
                 memory_format=torch.channels_last) and not weight.is_contiguous() else torch.contiguous_format)
-        return (gw if need['weight'] else None, gb if need['bias'] else None, None, None, *gxs, *goffs, *gmsks)
+        return (gw if need['weight'] else None, gb if (need['bias'] and gb is not None) else None, None, None,
+                *gxs, *goffs, *gmsks)
 
 
 def dcn_multi(inputs, offsets, masks, weight, bias=None, stride=1, padding=0, dilation=1, groups=1,

@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import grad_sink
 from .backend import get_backend
 
 _CL = torch.channels_last
@@ -33,7 +34,16 @@ class _GroupNormFn(torch.autograd.Function):
         groups, relu = ctx.cfg
         dys = [torch.zeros_like(x) if d is None else d for d, x in zip(dys, xs)]
         need_p = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
-        dxs, dg, db = get_backend(xs[0]).group_norm_backward(xs, dys, gamma, beta, groups, relu, mean_rstd, need_p)
+        be = get_backend(xs[0])
+        sg = grad_sink.sink(gamma) if ctx.needs_input_grad[0] else None
+        sb = grad_sink.sink(beta) if ctx.needs_input_grad[1] else None
+        sinks = (sg, sb) if (sg is not None and sb is not None and getattr(be, 'supports_grad_sinks', False)) else None
+        if sinks:
+            dxs, _, _ = be.group_norm_backward(xs, dys, gamma, beta, groups, relu, mean_rstd, True, sinks=sinks)
+            grad_sink.done(gamma)
+            grad_sink.done(beta)
+            return (None, None, None, None, None, *dxs)
+        dxs, dg, db = be.group_norm_backward(xs, dys, gamma, beta, groups, relu, mean_rstd, need_p)
         return (dg if ctx.needs_input_grad[0] else None, db if ctx.needs_input_grad[1] else None, None, None, None,
                 *dxs)
 

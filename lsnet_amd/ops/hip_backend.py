@@ -76,19 +76,26 @@ class HipBackend:
                                               1 if relu else 0, _ptr(mean_rstd), _ptr(ws), _stream()))
         return ys, mean_rstd
 
-    def group_norm_backward(self, xs, dys, gamma, beta, groups, relu, mean_rstd, need_params):
-        """Returns (dxs, dgamma, dbeta); dgamma/dbeta are None unless need_params."""
+    supports_grad_sinks = True
+
+    def group_norm_backward(self, xs, dys, gamma, beta, groups, relu, mean_rstd, need_params, sinks=None):
+        """Returns (dxs, dgamma, dbeta); dgamma/dbeta are None unless need_params.  `sinks` = (dgamma, dbeta) buffers
+        to ADD the parameter gradients to (ops/grad_sink.py)."""
         lib = _lib.load()
         n, C = len(xs), xs[0].shape[1]
         dys = [d.contiguous(memory_format=_CL) for d in dys]
         dxs = [torch.empty_like(x, memory_format=_CL) for x in xs]
         levels = self._gn_levels(xs, dys=dys, dxs=dxs)
-        dg = torch.empty_like(gamma) if need_params else None
-        db = torch.empty_like(beta) if need_params else None
+        if sinks:
+            dg, db = sinks
+        else:
+            dg = torch.empty_like(gamma) if need_params else None
+            db = torch.empty_like(beta) if need_params else None
         ws = torch.empty(lib.lsn_group_norm_workspace_bytes(n, levels, C, groups), device=xs[0].device,
                          dtype=torch.uint8)
         _lib.check(lib.lsn_group_norm_backward(n, levels, C, groups, _ptr(gamma), _ptr(beta), 1 if relu else 0,
-                                               _ptr(mean_rstd), _ptr(dg), _ptr(db), _ptr(ws), _stream()))
+                                               _ptr(mean_rstd), _ptr(dg), _ptr(db), _ptr(ws), 1 if sinks else 0,
+                                               _stream()))
         return dxs, dg, db
 
     # ------------------------------------------------------------------ deformable conv family
@@ -200,8 +207,14 @@ class HipBackend:
             if nbytes > 0:   # column-gradient buffer + anchor lists of the atomic-free grad_input path
                 gws = torch.empty(nbytes, device=w.device, dtype=torch.uint8)
                 shape.gather_workspace, shape.gather_workspace_bytes = gws.data_ptr(), nbytes
-        gw = torch.empty_like(w) if (need['weight'] or need['bias']) else None
-        gb = torch.empty(w.shape[0], device=w.device, dtype=torch.float32) if need['bias'] else None
+        sinks = need.get('sinks') if (nhwc and w is weight) else None
+        if sinks is not None:     # accumulate into the caller's gradient arena (ops/grad_sink.py)
+            gw, gb = sinks
+            shape.accumulate_param_grads = 1
+            need['sunk'] = True
+        else:
+            gw = torch.empty_like(w) if (need['weight'] or need['bias']) else None
+            gb = torch.empty(w.shape[0], device=w.device, dtype=torch.float32) if need['bias'] else None
         _lib.check(lib.lsn_dcn_backward(ctypes.byref(shape), n, levels, _ptr(w), _ptr(gw), _ptr(gb),
                                         1 if nhwc else 0, _stream()))
         return gxs, goffs, gmsks, gw, gb

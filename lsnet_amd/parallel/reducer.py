@@ -17,6 +17,8 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
+from ..ops import grad_sink
+
 
 def init_dist(backend='nccl', **kwargs):
     """`init_dist('pytorch')` of the reference (mmcv/runner/dist_utils.py:26-31): env:// rendezvous,
@@ -32,16 +34,21 @@ def init_dist(backend='nccl', **kwargs):
 class BucketedGradReducer:
     """Gradient-VIEW buckets: every `p.grad` is a view (in the parameter's own memory layout) into one of a few flat
     tensors, so backward accumulates straight into the communication buffers -- no gradient -> bucket -> gradient
-    copies, one fill per bucket to zero them, one all-reduce per bucket.
+    copies, one fill per bucket to zero them, one all-reduce per bucket.  The views are also registered as the
+    parameters' gradient SINKS (ops/grad_sink.py): the package's weight-gradient kernels add into them directly, so a
+    step has no per-parameter gradient allocation, memset or `p.grad.add_()` either.  With world size 1 the class is
+    just that gradient arena (no communication).
 
     Buckets are all-reduced strictly in index order (the order backward completes them: head -> neck -> backbone):
-    a bucket is launched from the grad-ready hook only when every earlier bucket has been launched, everything else
-    in `finish()`.  All ranks therefore issue the same collectives in the same order whatever subset of parameters
-    received a gradient.  Parameters without a gradient in a step keep zeros in their slot (with torch DDP they would
-    keep `grad=None`; every trainable LSNet parameter gets a gradient in every step, frozen ones have
-    requires_grad=False and are not bucketed)."""
+    a bucket is launched during backward only when every earlier bucket has been launched, everything else in
+    `finish()`.  All ranks therefore issue the same collectives in the same order whatever subset of parameters
+    received a gradient.  A parameter is "complete" when it has received as many gradient contributions (autograd's
+    AccumulateGrad, or a kernel's direct accumulation into the sink) as in the previous step -- the training graph is
+    static; a contribution that arrives after its bucket went out raises instead of being lost.  Parameters without a
+    gradient in a step keep zeros in their slot (with torch DDP they would keep `grad=None`; every trainable LSNet
+    parameter gets a gradient in every step, frozen ones have requires_grad=False and are not bucketed)."""
 
-    def __init__(self, params, bucket_mb=64.0, process_group=None):
+    def __init__(self, params, bucket_mb=25.0, process_group=None):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.params = [p for p in params if p.requires_grad]
@@ -60,8 +67,10 @@ class BucketedGradReducer:
         for bi, b in enumerate(self.buckets):
             for pi, p in enumerate(b['params']):
                 self._where[p] = (bi, pi)
-        self._handles = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params] \
-            if self.world > 1 else []
+        self._handles = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        self._expected = None      # contributions per parameter and step, learnt from the previous step
+        self._events = {}
+        self._zeroed = False
         self.reset()
 
     def _close(self, plist):
@@ -81,56 +90,84 @@ class BucketedGradReducer:
         for b in self.buckets:
             b['pending'] = len(b['params'])
             b['work'] = None
+        self._events = {}
 
     @staticmethod
     def _is_view(g, v):
         return g is v or (g is not None and g.data_ptr() == v.data_ptr() and g.stride() == v.stride())
 
     def zero_grad(self):
-        """Replaces optimizer.zero_grad(): one fill per bucket, and p.grad (re)pointed at its bucket view."""
+        """Replaces optimizer.zero_grad(): one fill per bucket; p.grad (re)pointed at its bucket view, which is also
+        the parameter's gradient sink."""
         for b in self.buckets:
             b['flat'].zero_()
             for p, v in zip(b['params'], b['views']):
-                if not self._is_view(p.grad, v):
+                if p.grad is not v:
                     p.grad = v
+                if getattr(p, '_lsn_sink', None) is not v:
+                    grad_sink.register(p, v, self._on_sink)
+        self._zeroed = True
 
     def _launch_ready(self):
+        if self.world == 1:
+            return
         while self._next < len(self.buckets) and self.buckets[self._next]['pending'] == 0:
             b = self.buckets[self._next]
             b['work'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self._next += 1
 
+    def _event(self, p):
+        """One gradient contribution to p has been accumulated into its bucket."""
+        bi, _ = self._where[p]
+        if bi < self._next:
+            raise RuntimeError('BucketedGradReducer: a gradient arrived after its bucket was all-reduced -- the number of '
+                               'gradient contributions per parameter changed between steps (or a second backward() ran '
+                               'before finish()); dynamic graphs are not supported')
+        c = self._events.get(p, 0) + 1
+        self._events[p] = c
+        if self._expected is not None and c == self._expected.get(p, -1):
+            b = self.buckets[bi]
+            b['pending'] -= 1
+            if b['pending'] == 0:
+                self._launch_ready()
+
+    def _on_sink(self, p):
+        self._event(p)
+
     def _on_grad(self, p):
         bi, pi = self._where[p]
-        b = self.buckets[bi]
-        v = b['views'][pi]
+        v = self.buckets[bi]['views'][pi]
         if not self._is_view(p.grad, v):   # the gradient was not preset (zero_grad() skipped): move it into the bucket
-            v.copy_(p.grad)
+            if not self._zeroed and self._events.get(p, 0) == 0:
+                v.copy_(p.grad)
+            else:
+                v.add_(p.grad)
             p.grad = v
-        b['pending'] -= 1
-        if b['pending'] < 0:
-            raise RuntimeError('BucketedGradReducer: a second backward() before finish() -- gradient accumulation '
-                               'over several backward passes is not supported')
-        if b['pending'] == 0:
-            self._launch_ready()
+        self._event(p)
 
     def finish(self):
-        """Launch what the hooks could not (in order), wait, average."""
-        if self.world == 1:
-            return
+        """Launch what backward could not (in order), wait, average."""
         while self._next < len(self.buckets):
             b = self.buckets[self._next]
             for p, v in zip(b['params'], b['views']):
                 if p.grad is None:
-                    p.grad = v    # zeros unless zero_grad() was skipped (then: stale values are cleared here)
+                    if not self._zeroed and self._events.get(p, 0) == 0:
+                        v.zero_()     # no zero_grad() before this step: the slot still holds the previous gradient
+                    p.grad = v
                 elif not self._is_view(p.grad, v):
                     v.copy_(p.grad)
                     p.grad = v
             b['pending'] = 0
-            self._launch_ready()
-        for b in self.buckets:
-            b['work'].wait()
-            b['flat'].div_(self.world)
+            if self.world == 1:
+                self._next += 1
+            else:
+                self._launch_ready()
+        if self.world > 1:
+            for b in self.buckets:
+                b['work'].wait()
+                b['flat'].div_(self.world)
+        self._expected = dict(self._events)
+        self._zeroed = False
         self.reset()
 
 
@@ -140,7 +177,7 @@ class DataParallelModel(nn.Module):
     started by hooks during backward and completed by `reduce_gradients()` (called by OptimizerHook
     right after `loss.backward()`)."""
 
-    def __init__(self, module, bucket_mb=64.0, broadcast_params=True):
+    def __init__(self, module, bucket_mb=25.0, broadcast_params=True):
         super().__init__()
         self.module = module
         if dist.is_initialized() and dist.get_world_size() > 1 and broadcast_params:

@@ -14,6 +14,8 @@ The reference has no counterpart (mmcv's runner launches every kernel eagerly, h
 import torch
 import torch.distributed as dist
 
+from ..ops import grad_sink
+
 
 def _walk(obj, fn, path=()):
     """Applies fn(path, tensor) to every tensor in nested dict / list / tuple containers."""
@@ -68,6 +70,7 @@ class GraphedForwardBackward:
             # without a layout conversion; the all-reduce only sees the flat bucket
             dense = p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))
             p.grad = seg.as_strided(p.shape, p.stride()) if dense else seg.view_as(p)
+            grad_sink.register(p, p.grad)    # the weight-gradient kernels add straight into the bucket
             o += p.numel()
         self.buckets.append(flat)
 

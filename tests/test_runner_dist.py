@@ -96,6 +96,67 @@ def test_reducer_is_a_noop_without_process_group():
     assert torch.equal(m.a.weight.grad, g)
 
 
+def test_reducer_clears_stale_slot_of_an_unused_parameter():
+    """A parameter that gets no gradient in a step must hold zeros afterwards even when the caller used
+    `p.grad = None` instead of the reducer's zero_grad() (round-2 advisor finding: the slot kept last step's value)."""
+    from lsnet_amd.parallel.reducer import BucketedGradReducer
+    torch.manual_seed(0)
+    a, b = torch.nn.Linear(3, 3), torch.nn.Linear(3, 3)
+    red = BucketedGradReducer(list(a.parameters()) + list(b.parameters()))
+    x = torch.randn(4, 3)
+    (a(x).sum() + b(x).sum()).backward()
+    red.finish()
+    assert float(b.weight.grad.abs().sum()) > 0
+    for p in list(a.parameters()) + list(b.parameters()):
+        p.grad = None                        # the old protocol: no zero_grad() of the reducer
+    a(x).sum().backward()                    # b is unused in this step
+    red.finish()
+    assert float(b.weight.grad.abs().sum()) == 0 and float(b.bias.grad.abs().sum()) == 0
+    assert torch.allclose(a.weight.grad, x.sum(0).expand(3, 3))
+
+
+def test_gradient_sinks_accumulate_into_the_buckets():
+    """ops/grad_sink.py protocol on the reducer: an operator that adds its parameter gradient straight into the sink
+    and reports `done` is equivalent to returning the gradient to autograd; classic and sunk contributions mix."""
+    from lsnet_amd.ops import grad_sink
+    from lsnet_amd.parallel.reducer import BucketedGradReducer
+
+    class SunkLinear(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w):
+            ctx.save_for_backward(x, w)
+            return x @ w.t()
+
+        @staticmethod
+        def backward(ctx, g):
+            x, w = ctx.saved_tensors
+            gw = g.t() @ x
+            s = grad_sink.sink(w)
+            if s is not None:
+                s.add_(gw)
+                grad_sink.done(w)
+                gw = None
+            return g @ w, gw
+
+    torch.manual_seed(1)
+    w = torch.nn.Parameter(torch.randn(3, 3))
+    x = torch.randn(5, 3)
+    ref = torch.autograd.grad((x @ w.t()).sum() * 2 + (x @ w.t()).pow(2).sum(), w)[0]
+    red = BucketedGradReducer([w])
+    assert grad_sink.sink(w) is None         # nothing registered before zero_grad()
+    for _ in range(3):                       # (the reducer learns the contribution count in the first step)
+        red.zero_grad()
+        assert grad_sink.sink(w) is w.grad
+        # two sunk uses and one classic use of the same parameter
+        (SunkLinear.apply(x, w).sum() + SunkLinear.apply(x, w).sum() + (x @ w.t()).pow(2).sum()).backward()
+        red.finish()
+        assert torch.allclose(w.grad, ref, atol=1e-5)
+    w.grad = None                            # user replaced the gradient: the sink is off, the classic path works
+    assert grad_sink.sink(w) is None
+    SunkLinear.apply(x, w).sum().backward()
+    assert torch.allclose(w.grad, torch.ones(3, 5) @ x, atol=1e-6)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
