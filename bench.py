@@ -13,11 +13,15 @@ hooks a real run uses (lsnet_amd/runner).  Inputs are resident in HBM before the
 
 Prints ONE JSON line (rank 0):  value = total images / s over all N GPUs (weak scaling, 2 img/GPU).
   value        : at the library's default arithmetic 'bf16x6' = fp32-equivalent (include/lsnet_hip.h).
-  roofline     : the hand-written kernel family with the most GPU time in the step (a deformable-convolution family):
-                 algorithmic FLOPs of its launches / their HIP-event time (events recorded by the library around each
-                 family's kernels on the launch stream, over the timed steps), against the MFMA
-                 peak of its arithmetic -- 2516 / 6 TFLOP/s for 'bf16x6', 157.3 for exact fp32 (MI355X_MICROARCH.md);
+  roofline     : the hand-written kernel family with the most GPU time in the step, chosen over ALL instrumented families
+                 (deformable conv forward / backward-data / weight gradient, dense conv forward / data gradient / weight
+                 gradient, normalisation passes) by a survey pass of 3 untimed steps with HIP events around every launch;
+                 the K timed steps then carry events around that ONE family only (a few dozen launches per step, so the
+                 events do not slow the step they measure): algorithmic FLOPs (bytes, for the HBM-bound norm family) of
+                 its launches / their HIP-event time on the launch stream, against the MFMA peak of its arithmetic --
+                 2516 / 6 TFLOP/s for 'bf16x6', 157.3 for exact fp32 -- or 8 TB/s of HBM (MI355X_MICROARCH.md);
                  `traffic`: HBM bytes of this step's own launch shapes from committed rocprofv3 counter passes.
+  kernels      : the survey pass: per family launches, ms per step, TFLOP/s and algorithmic GB/s.
   extra        : the same step in the other arithmetic modes (bf16x3: 3-term split; fp32: exact fp32 MFMA + MIOpen),
                  5 steps each, and BASELINE config 5 (pose-head inference, bs 4).
   cpu_baseline : BASELINE config 1 (2 x 3x800x800) on the host CPU: this repo's host code with the CPU oracle standing
@@ -43,7 +47,9 @@ PRODUCTS = {'bf16x6': 6, 'bf16x3': 3}
 # HBM traffic of the deformable-conv launches of THIS step (tower launch over 5 levels, pyramid launch over 15 pairs),
 # written by tools/pmc_step_shapes.sh from rocprofv3 FETCH_SIZE / WRITE_SIZE passes (separate passes; FETCH doubled as
 # MI355X_MICROARCH.md prescribes for gfx950) and committed with the round's profiles
-TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'r2_hbm_traffic.json')
+TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'r3_hbm_traffic.json')
+HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E, 8 TB/s
+HBM_BOUND = ('norm',)            # families that are streaming passes, priced against HBM bandwidth
 
 
 def parse():
@@ -71,19 +77,31 @@ def parse():
     return ap.parse_args()
 
 
+_COMMON_NOTES = {
+    'conv_fwd': 'lsn::conv_mm_kernel (dense conv forward: implicit GEMM, pixel planes split into a swizzled LDS image, weight '
+                'fragments straight from L2, two workgroups per CU) + conv_splitk_reduce_kernel',
+    'conv_bwd_data': 'lsn::conv_mm_kernel on grad_output with transposed / flipped weight images (one launch per residue '
+                     'class of a strided convolution)',
+    'conv_wgrad': 'lsn::conv_wgrad_kernel + conv_wgrad_reduce_kernel (3x3 / 1x1: input patch + grad_output rows staged once '
+                  'per 16-pixel segment, ds_read_b64_tr_b16 fragments, split-pixel partial tiles); strided 3x3 and other tap '
+                  'counts: dcn_wgrad_xn_kernel<PLAIN>',
+    'norm': 'lsn::bn_act_fwd / bn_act_bwd / bn_param_reduce and gn_stats / gn_apply / gn_bwd_reduce / gn_bwd_apply / '
+            'gn_param_grad kernels (frozen-statistics BatchNorm + add + ReLU, GroupNorm + ReLU; streaming passes)',
+    'gconv': 'lsn::gconv_kernel / gconv_wgrad_kernel (grouped convolution, exact fp32)',
+}
 KERNEL_NOTES = {
-    'split': {
+    'split': dict(_COMMON_NOTES, **{
         'dcn_fwd': 'lsn::dcn_fwd_xn_kernel (fused bilinear gather + split-bf16 MFMA implicit GEMM, forward)',
         'dcn_bwd_data': 'lsn::dcn_bwd_data_xn_kernel + dcn_gather_kernel (gout x W^T as split-bf16 MFMA -> grad offset/mask '
                         'and mask-weighted column gradients; grad input by an atomic-free gather over per-anchor sample '
                         'lists: dcn_bin / scan / fill / sort_lists kernels, all inside the timed bracket)',
         'dcn_wgrad': 'lsn::dcn_wgrad_xn_kernel (gathered columns^T x gout as split-bf16 MFMA: grad weight/bias)',
-    },
-    'fp32': {
+    }),
+    'fp32': dict(_COMMON_NOTES, **{
         'dcn_fwd': 'lsn::dcn_fwd_pipe_kernel (fused bilinear gather + fp32 MFMA implicit GEMM, forward)',
         'dcn_bwd_data': 'lsn::dcn_bwd_data_kernel / _win_kernel (gout x W^T on fp32 MFMA, fused bilinear scatter)',
         'dcn_wgrad': 'lsn::dcn_wgrad_kernel (gathered columns^T x gout on fp32 MFMA: grad weight/bias)',
-    },
+    }),
 }
 MATH_NOTES = {
     'bf16x6': 'fp32 tensors; every conv / deformable-conv product a*b evaluated as 6 bf16 MFMA terms of the EXACT 3-way '
@@ -103,8 +121,8 @@ class KernelTimer:
         from lsnet_amd import _lib
         self.lib = _lib
 
-    def start(self):
-        self.lib.prof_enable(True)
+    def start(self, families=None):
+        self.lib.prof_enable(True, families)
 
     def stop(self):
         torch.cuda.synchronize()
@@ -300,6 +318,7 @@ def main():
     data = synthetic_batch(args.task, args.batch, args.height, args.width, seed=1234 + rank, device=dev,
                            channels_last=not args.nchw)
     timer = None if args.no_kernel_timing else KernelTimer()
+    survey, dominant = {}, None
     use_graph = args.graph
     if use_graph:
         # forward+backward replayed from one hipGraph.  Library autotuning and the capture itself happen here,
@@ -312,6 +331,17 @@ def main():
     for _ in range(args.warmup):
         step(data)
     torch.cuda.synchronize()
+    if timer and not use_graph:
+        # survey: events around every launch of every family for 3 untimed steps -> which family dominates the step
+        timer.start()
+        for _ in range(3):
+            step(data)
+        survey = timer.stop()
+        for v in survey.values():
+            v['ms_per_step'] = v['total_ms'] / 3
+        if survey:
+            dominant = max(survey, key=lambda k: survey[k]['total_ms'])
+    torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -320,8 +350,8 @@ def main():
         mk = torch.ones(32, 32, device=dev)
         get_backend(mk).selftest_mfma(mk, mk, 0)
         torch.cuda.synchronize()
-    if timer and not use_graph:
-        timer.start()      # HIP events around every deformable-conv family launch of the timed steps
+    if timer and not use_graph and dominant:
+        timer.start([dominant])      # HIP events around the launches of the dominant family only
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step(data)
@@ -399,10 +429,15 @@ def main():
         peak = BF16_MFMA_PEAK_TFLOPS / np_ if np_ else FP32_MFMA_PEAK_TFLOPS
         peak_note = (f'dense bf16 MFMA peak / {np_} ({np_} bf16 products per fp32 product)' if np_
                      else 'dense fp32 MFMA peak (v_mfma_f32_*_f32)')
-        if ks:
-            dom = max(ks, key=lambda k: ks[k]['total_ms'])   # the kernel family with the most GPU time
+        if use_graph and ks:
+            survey = ks
+            for v in survey.values():
+                v['ms_per_step'] = v['total_ms'] / max(nk, 1)
+            dominant = max(ks, key=lambda k: ks[k]['total_ms'])
+        if ks and dominant in ks:
+            dom = dominant   # the kernel family with the most GPU time (survey pass), timed here over the K steps
             k = ks[dom]
-            res['kernels'] = ks
+            res['kernels'] = survey
             traffic, traffic_note = None, 'not measured'
             try:
                 with open(TRAFFIC_FILE) as f:
@@ -413,9 +448,14 @@ def main():
                     traffic_note = e['note']
             except (OSError, ValueError, KeyError):
                 pass
-            res['roofline'] = {'kernel': KERNEL_NOTES['split' if np_ else 'fp32'].get(dom, dom), 'bound': 'mfma',
-                               'achieved': k['tflops'], 'peak': peak, 'unit': 'TFLOP/s', 'frac': k['tflops'] / peak,
-                               'peak_note': peak_note, 'traffic': traffic, 'traffic_unit': 'GB per mean launch: ' + traffic_note,
+            hbm = dom in HBM_BOUND
+            res['roofline'] = {'family': dom, 'kernel': KERNEL_NOTES['split' if np_ else 'fp32'].get(dom, dom),
+                               'bound': 'hbm' if hbm else 'mfma',
+                               'achieved': k['alg_gbps'] if hbm else k['tflops'],
+                               'peak': HBM_PEAK_GBPS if hbm else peak, 'unit': 'GB/s' if hbm else 'TFLOP/s',
+                               'frac': k['alg_gbps'] / HBM_PEAK_GBPS if hbm else k['tflops'] / peak,
+                               'peak_note': 'HBM3E 8 TB/s' if hbm else peak_note,
+                               'traffic': traffic, 'traffic_unit': 'GB per mean launch: ' + traffic_note,
                                'launches_timed': k['launches'], 'avg_launch_ms': k['avg_ms'],
                                'gflop_per_launch': k['gflop_per_launch'],
                                'alg_gbytes_per_launch': k['alg_gbytes_per_launch'],

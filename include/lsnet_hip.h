@@ -260,6 +260,9 @@ typedef struct lsn_conv_level {
     float *out;
     const float *grad_out;   /* backward_weight only */
     int B, H, W;
+    const float *residual;   /* forward only, optional: a tensor of the output's shape ADDED before the ReLU -- the
+                              * `relu(bn(conv(x)) + identity)` tail of a ResNet block whose frozen BatchNorm has been
+                              * folded into the weight and bias (resnet.py:261-301) */
 } lsn_conv_level;
 int64_t lsn_conv2d_prepared_bytes(int kind, int C, int Co, int kh, int kw, int stride, int pad, int dil);
 int lsn_conv2d_prepare_weights(int kind, const float *w, void *prepared, int C, int Co, int kh, int kw, int stride,
@@ -377,6 +380,9 @@ int lsn_debug_phase_clocks(long long *device_buf_512, int block);
  * entry per family -- dcn_fwd, dcn_bwd_data, dcn_wgrad, conv_fwd, conv_bwd_data, conv_wgrad, norm, gconv -- with the
  * launch count, the summed kernel time and the summed ALGORITHMIC flops / bytes of those launches (contractions: 2 x
  * output pixels x Co x C/groups x kh x kw flops; bytes: each operand read or written once).
+ * lsn_prof_enable(on): 0 = off, 1 = every family, any other value = a bit mask of families in the order above (bit 0 =
+ * dcn_fwd ...), so that a timed run can carry the events of ONE family only (a few dozen launches per step) after a
+ * warm-up run with all of them found out which one dominates.
  * Returns the number of entries written (8) or a negative lsn error.  Not thread-safe. */
 typedef struct lsn_prof_entry {
     char name[48];

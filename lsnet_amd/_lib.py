@@ -38,7 +38,7 @@ class DcnLevel(ctypes.Structure):
 
 class ConvLevel(ctypes.Structure):
     _fields_ = [('x', ctypes.c_void_p), ('out', ctypes.c_void_p), ('grad_out', ctypes.c_void_p),
-                ('B', ctypes.c_int), ('H', ctypes.c_int), ('W', ctypes.c_int)]
+                ('B', ctypes.c_int), ('H', ctypes.c_int), ('W', ctypes.c_int), ('residual', ctypes.c_void_p)]
 
 
 class ConvWprep(ctypes.Structure):
@@ -114,9 +114,18 @@ def check(rc):
         raise RuntimeError(msg)
 
 
-def prof_enable(on):
-    """Start (and clear) / stop the library's per-kernel event log (lsn_prof_enable)."""
-    check(load().lsn_prof_enable(1 if on else 0))
+PROF_FAMILIES = ('dcn_fwd', 'dcn_bwd_data', 'dcn_wgrad', 'conv_fwd', 'conv_bwd_data', 'conv_wgrad', 'norm', 'gconv')
+
+
+def prof_enable(on, families=None):
+    """Start (and clear) / stop the library's per-kernel event log (lsn_prof_enable); `families`: names of the only
+    families to record (default: all)."""
+    mask = 0
+    if on:
+        mask = 1 if families is None else sum(1 << PROF_FAMILIES.index(f) for f in families)
+        if mask == 1 and families is not None:
+            mask |= 1 << 31    # (the value 1 means "all": keep a single-family mask of bit 0 distinct)
+    check(load().lsn_prof_enable(mask))
 
 
 def prof_read():

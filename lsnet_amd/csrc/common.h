@@ -68,14 +68,22 @@ __device__ __forceinline__ f32x4 mfma16_bf16(bf16x8 a, bf16x8 b, f32x4 c)
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
+// bf16(v0) | bf16(v1) << 16, round to nearest even: ONE v_cvt_pk_bf16_f32.  (Written as asm because hipcc, given the
+// equivalent vector conversion, also converts element 0 on its own and re-packs with v_bfi: 16 instead of 11 VALU
+// operations per 3-way split of a pair, in kernels whose staging instruction stream is what limits them.)
+__device__ __forceinline__ unsigned cvt_pk_bf16(float v0, float v1)
+{
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(v0), "v"(v1));
+    return r;
+}
+
 // (v0, v1) -> packed bf16 pairs hi = bf16(v), lo = bf16(v - hi); element 0 in the low half-word
 __device__ __forceinline__ void split_bf16x2(float v0, float v1, unsigned &hi, unsigned &lo)
 {
-    const bf16x2 h = {(__bf16)v0, (__bf16)v1};
-    hi = __builtin_bit_cast(unsigned, h);
+    hi = cvt_pk_bf16(v0, v1);
     const float h0 = __uint_as_float(hi << 16), h1 = __uint_as_float(hi & 0xffff0000u);
-    const bf16x2 l = {(__bf16)(v0 - h0), (__bf16)(v1 - h1)};
-    lo = __builtin_bit_cast(unsigned, l);
+    lo = cvt_pk_bf16(v0 - h0, v1 - h1);
 }
 
 // ---- fp32-equivalent products on the matrix pipe ("bf16x6") -------------------------------------------
@@ -87,14 +95,11 @@ __device__ __forceinline__ void split_bf16x2(float v0, float v1, unsigned &hi, u
 // algorithmic flops, 2.7x the fp32 MFMA pipe.
 __device__ __forceinline__ void split3_bf16x2(float v0, float v1, unsigned &hi, unsigned &mid, unsigned &lo)
 {
-    const bf16x2 h = {(__bf16)v0, (__bf16)v1};
-    hi = __builtin_bit_cast(unsigned, h);
+    hi = cvt_pk_bf16(v0, v1);
     const float r0 = v0 - __uint_as_float(hi << 16), r1 = v1 - __uint_as_float(hi & 0xffff0000u);
-    const bf16x2 m = {(__bf16)r0, (__bf16)r1};
-    mid = __builtin_bit_cast(unsigned, m);
+    mid = cvt_pk_bf16(r0, r1);
     const float s0 = r0 - __uint_as_float(mid << 16), s1 = r1 - __uint_as_float(mid & 0xffff0000u);
-    const bf16x2 l = {(__bf16)s0, (__bf16)s1};
-    lo = __builtin_bit_cast(unsigned, l);
+    lo = cvt_pk_bf16(s0, s1);
 }
 
 // NP = number of bf16 products per fp32 product (3: "bf16x3", 6: "bf16x6"); planes per operand and the

@@ -23,6 +23,7 @@
 #include "../../include/lsnet_hip.h"
 #include "common.h"
 #include "conv_kernels.h"
+#include "conv_wgrad_kernels.h"
 #include "prof.h"
 
 namespace lsn {
@@ -77,7 +78,7 @@ static int launch_conv_cfg(ConvArgs &a, int ks, hipStream_t st)
     if (ks > 1) {
         const int blocks = (int)((n / 4 + 255) / 256 < 1024 ? (n / 4 + 255) / 256 : 1024);
         hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, st, a.part, a.lv[0].out, a.bias,
-                           (int)n, a.Co, ks, a.relu);
+                           a.lv[0].res, (int)n, a.Co, ks, a.relu);
     }
     LSN_HIP(hipGetLastError());
     return 0;
@@ -218,6 +219,7 @@ static int conv_forward_impl(int n, const lsn_conv_level *lv, const void *prepar
             LSN_CHECK(L.Wo > 0, "conv2d: output size is too small");
         }
         L.x = lv[i].x, L.out = lv[i].out, L.B = lv[i].B, L.H = lv[i].H, L.W = lv[i].W;
+        L.res = lv[i].residual;
         L.P = L.B * L.Ho * L.Wo;
     }
     a.bias = bias;
@@ -361,6 +363,104 @@ static int prepare_weights(int kind, const float *w, void *prepared, int C, int 
     }
     LSN_HIP(hipGetLastError());
     return 0;
+}
+
+// ---- weight / bias gradient (conv_wgrad_kernels.h) ----
+template <int TI, int TJ, int TG, int WI, int WJ, int PMAX, bool UN_OK>
+static int launch_wgrad_cfg(WgArgs &a, float *gw, float *gb, int accumulate, hipStream_t st)
+{
+    const bool un = a.Co % 4 != 0;
+    if (un && !UN_OK) return 1;
+    constexpr int BN = WI * TI * 32, BM = WJ * TJ * 32;
+    const int npl = conv_npl(), K = a.kh * a.kw;
+    const int blocks = cdiv(a.Co, BM) * cdiv(a.C, BN);
+    const size_t nW = (size_t)a.Co * K * a.C;
+    int S = (512 + blocks / 2) / blocks;
+    const size_t cap = ((size_t)192 << 20) / 4 / (nW + a.Co);   // partial tiles: at most 192 MB
+    if ((size_t)S > cap) S = (int)cap;
+    if (S > a.nseg / 6) S = a.nseg / 6;   // a split should run long enough to amortise its prologue and its partial tile
+    static const int force_s = [] { const char *e = getenv("LSNET_WGRAD_SPLITS"); return e ? atoi(e) : 0; }();
+    if (force_s > 0) S = force_s < a.nseg ? force_s : a.nseg;
+    if (S < 1) S = 1;
+    float *part = nullptr;
+    if (int rc = part_buffer((size_t)S * (nW + a.Co) + 16, &part)) return rc;
+    a.part = part;
+    a.part_b = part + (((size_t)S * nW + 3) & ~(size_t)3);
+    a.want_bias = gb != nullptr;
+    constexpr int XP = 1024 / BN, GP = 1024 / BM;   // pixels per staging pass (conv_wgrad_kernel)
+    const size_t lds = (size_t)2 * npl * ((size_t)cdiv(PMAX, XP) * XP * BN * 2 + (size_t)cdiv(16, GP) * GP * BM * 2);
+    if (lds > 160 * 1024) return 1;
+    dim3 grid(blocks, S);
+    auto launch = [&](auto kern) -> int {
+        LSN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
+        return 0;
+    };
+    int rc;
+    if constexpr (UN_OK) {
+        if (un)
+            rc = npl == 2 ? launch(conv_wgrad_kernel<TI, TJ, TG, WI, WJ, 3, true, PMAX>)
+                          : launch(conv_wgrad_kernel<TI, TJ, TG, WI, WJ, 6, true, PMAX>);
+        else
+            rc = npl == 2 ? launch(conv_wgrad_kernel<TI, TJ, TG, WI, WJ, 3, false, PMAX>)
+                          : launch(conv_wgrad_kernel<TI, TJ, TG, WI, WJ, 6, false, PMAX>);
+    } else {
+        rc = npl == 2 ? launch(conv_wgrad_kernel<TI, TJ, TG, WI, WJ, 3, false, PMAX>)
+                      : launch(conv_wgrad_kernel<TI, TJ, TG, WI, WJ, 6, false, PMAX>);
+    }
+    if (rc) return rc;
+    const size_t n4 = nW / 4;
+    int LS = 1;
+    while (LS < 64 && LS * 8 <= S) LS <<= 1;   // >= 4 loads per lane; a wave's lanes share 64 / LS elements
+    const size_t thr = n4 * LS;
+    const int rb = (int)((thr + 255) / 256 < 4096 ? (thr + 255) / 256 : 4096);
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(rb > 0 ? rb : 1), dim3(256), 0, st, a.part, gw, nW, a.part_b, gb, a.Co, S,
+                       accumulate, LS);
+    LSN_HIP(hipGetLastError());
+    return 0;
+}
+
+// Returns 1 when the shape is not served here (more than nine taps, C % 4 != 0, 64-bit offsets): the caller keeps the
+// general kernel of dcn.hip.
+int conv_wgrad_mm(int n, const lsn_conv_level *lv, float *gw, float *gb, int C, int Co, int kh, int kw, int stride, int pad,
+                  int dil, int accumulate, hipStream_t st)
+{
+    static const int off = [] { const char *e = getenv("LSNET_WGRAD_OLD"); return e ? atoi(e) : 0; }();
+    // 3x3 / stride 1 / dilation 1 and 1x1 (any stride) run here.  (A strided 3x3 needs a 3 x 33 patch: one workgroup per
+    // CU and 2-way bank-conflicted tr-reads -- the general kernel of dcn.hip was faster, profiles/r3_wgrad_table.txt.)
+    const bool k33 = kh == 3 && kw == 3 && stride == 1 && dil == 1, k11 = kh == 1 && kw == 1;
+    if (off || n < 1 || n > CV_MAXLV || !(k33 || k11) || C % 4 != 0) return 1;
+    WgArgs a = {};
+    int seg = 0;
+    for (int i = 0; i < n; ++i) {
+        WgLvl &L = a.lv[i];
+        const int B = lv[i].B, H = lv[i].H, W = lv[i].W;
+        if (!lv[i].x || !lv[i].grad_out || B <= 0 || H <= 0 || W <= 0) return 1;
+        const int Ho = conv_out_size(H, kh, stride, pad, dil), Wo = conv_out_size(W, kw, stride, pad, dil);
+        if (Ho <= 0 || Wo <= 0) return 1;
+        if ((int64_t)B * H * W * C * 4 >= ((int64_t)1 << 31) || (int64_t)B * Ho * Wo * Co * 4 >= ((int64_t)1 << 31)) return 1;
+        L.x = lv[i].x, L.go = lv[i].grad_out, L.B = B, L.H = H, L.W = W, L.Ho = Ho, L.Wo = Wo;
+        L.nsx = cdiv(Wo, 16);
+        L.seg0 = seg;
+        seg += B * Ho * L.nsx;
+    }
+    a.nlv = n, a.nseg = seg;
+    a.C = C, a.Co = Co, a.kh = kh, a.kw = kw, a.stride = stride, a.pad = pad, a.dil = dil;
+    a.cstep = kw == 1 ? stride : 1;
+    a.PW = kw == 1 ? 16 : 15 * stride + (kw - 1) * dil + 1;
+    if (kh * a.PW > 99) return 1;
+    double px = 0, in_el = 0;
+    for (int i = 0; i < n; ++i) px += (double)a.lv[i].B * a.lv[i].Ho * a.lv[i].Wo, in_el += (double)a.lv[i].B * a.lv[i].H * a.lv[i].W * C;
+    ProfSpan prof(PROF_CONV_WGRAD, 2.0 * px * Co * C * kh * kw, 4.0 * (in_el + px * Co + (double)Co * kh * kw * C), st);
+    if (kh * kw == 1) {   // one tap: 32 .. 64 channels per wave on either side, by the layer's width
+        if (C <= 64)
+            return Co <= 64 ? launch_wgrad_cfg<1, 1, 1, 2, 2, 16, false>(a, gw, gb, accumulate, st)
+                            : launch_wgrad_cfg<1, 2, 1, 2, 2, 16, false>(a, gw, gb, accumulate, st);
+        return Co <= 64 ? launch_wgrad_cfg<2, 1, 1, 2, 2, 16, false>(a, gw, gb, accumulate, st)
+                        : launch_wgrad_cfg<2, 2, 1, 2, 2, 16, false>(a, gw, gb, accumulate, st);
+    }
+    if (Co <= 32) return launch_wgrad_cfg<1, 1, 9, 4, 1, 54, true>(a, gw, gb, accumulate, st);
+    return launch_wgrad_cfg<1, 1, 9, 2, 2, 54, false>(a, gw, gb, accumulate, st);
 }
 
 // ---- every stale image of a step in one launch ----

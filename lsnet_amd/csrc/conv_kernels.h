@@ -32,6 +32,7 @@ constexpr int CV_MAXLV = 8;
 // One input map of a batched launch: the FPN levels that share a convolution's weights (LSHead) go into ONE launch.
 struct ConvLvl {
     const float *x;
+    const float *res;   // optional residual of the output's shape, added before the ReLU (dense output only)
     float *out;
     int B, H, W, Ho, Wo;
     int P;       // B * Ho * Wo
@@ -396,6 +397,10 @@ __global__ __launch_bounds__(256, 2) void conv_mm_kernel(const ConvArgs a)
                         const float4 bv = *reinterpret_cast<const float4 *>(a.bias + co);
                         v[0] += bv.x, v[1] += bv.y, v[2] += bv.z, v[3] += bv.w;
                     }
+                    if (fin && L.res) {
+                        const float4 rv = *reinterpret_cast<const float4 *>(L.res + opix * a.Co + co);
+                        v[0] += rv.x, v[1] += rv.y, v[2] += rv.z, v[3] += rv.w;
+                    }
                     if (fin && a.relu)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -405,6 +410,7 @@ __global__ __launch_bounds__(256, 2) void conv_mm_kernel(const ConvArgs a)
                     for (int e = 0; e < 4; ++e) {
                         if (co + e >= a.Co) break;
                         float u = v[e] + ((fin && a.bias) ? a.bias[co + e] : 0.f);
+                        if (fin && L.res) u += L.res[opix * a.Co + co + e];
                         if (fin && a.relu) u = fmaxf(u, 0.f);
                         orow[co + e] = u;
                     }
@@ -415,7 +421,8 @@ __global__ __launch_bounds__(256, 2) void conv_mm_kernel(const ConvArgs a)
 
 // out[e] = sum_z part[z * n + e] + bias[e % Co] (ReLU): the second pass of a split reduction; n = P * Co
 __global__ void conv_splitk_reduce_kernel(const float *__restrict__ part, float *__restrict__ out,
-                                          const float *__restrict__ bias, int n, int Co, int ks, int relu)
+                                          const float *__restrict__ bias, const float *__restrict__ res, int n, int Co,
+                                          int ks, int relu)
 {
     const bool v4 = (n & 3) == 0 && (Co & 3) == 0;
     if (v4) {
@@ -429,6 +436,10 @@ __global__ void conv_splitk_reduce_kernel(const float *__restrict__ part, float 
                 const float4 b = *reinterpret_cast<const float4 *>(bias + e % Co);
                 s.x += b.x, s.y += b.y, s.z += b.z, s.w += b.w;
             }
+            if (res) {
+                const float4 r = *reinterpret_cast<const float4 *>(res + e);
+                s.x += r.x, s.y += r.y, s.z += r.z, s.w += r.w;
+            }
             if (relu) s.x = fmaxf(s.x, 0.f), s.y = fmaxf(s.y, 0.f), s.z = fmaxf(s.z, 0.f), s.w = fmaxf(s.w, 0.f);
             *reinterpret_cast<float4 *>(out + e) = s;
         }
@@ -437,6 +448,7 @@ __global__ void conv_splitk_reduce_kernel(const float *__restrict__ part, float 
             float s = part[e];
             for (int z = 1; z < ks; ++z) s += part[(size_t)z * n + e];
             if (bias) s += bias[e % Co];
+            if (res) s += res[e];
             out[e] = relu ? fmaxf(s, 0.f) : s;
         }
     }

@@ -51,9 +51,9 @@ void dbg_state(long long **buf, int *block) { *buf = g_dbg_buf, *block = g_dbg_b
 // ---- per-kernel launch timing (prof.h) ----
 static const char *const kProfNames[PROF_N] = {"dcn_fwd", "dcn_bwd_data", "dcn_wgrad", "conv_fwd", "conv_bwd_data",
                                                "conv_wgrad", "norm", "gconv"};
-static bool g_prof_on = false;
+static unsigned g_prof_mask = 0;   // bit f: family f records events
 static std::vector<ProfRec> g_prof;
-bool prof_on() { return g_prof_on; }
+bool prof_on(int fam) { return (g_prof_mask >> fam) & 1u; }
 void prof_push(const ProfRec &r) { g_prof.push_back(r); }
 
 static double dcn_flops(const DcnArgs &a)
@@ -828,9 +828,16 @@ static int conv_wgrad_launch(const DcnArgs &a, int nsteps, int C, int Co, int K,
     return 0;
 }
 
+int conv_wgrad_mm(int n, const lsn_conv_level *lv, float *gw, float *gb, int C, int Co, int kh, int kw, int stride, int pad,
+                  int dil, int accumulate, hipStream_t st);   // conv.hip
+
 static int conv_wgrad_xn(int n, const lsn_conv_level *lv, float *gw, float *gb, int C, int Co, int kh, int kw, int stride,
                          int pad, int dil, bool accumulate, hipStream_t st)
 {
+    {   // the patch kernel of conv_wgrad_kernels.h serves up to nine taps; anything else stays here
+        const int rc = conv_wgrad_mm(n, lv, gw, gb, C, Co, kh, kw, stride, pad, dil, accumulate ? 1 : 0, st);
+        if (rc != 1) return rc;
+    }
     LSN_CHECK(n >= 1 && n <= MAXLV && lv && gw, "conv2d backward-weight: bad arguments");
     DcnArgs a = {};
     int steps = 0;
@@ -930,7 +937,7 @@ int lsn_prof_enable(int on)
         (void)hipEventDestroy(r.e1);
     }
     lsn::g_prof.clear();
-    lsn::g_prof_on = on != 0;
+    lsn::g_prof_mask = on == 1 ? ~0u : (unsigned)on;
     return 0;
 }
 

@@ -17,6 +17,7 @@
 
 #include "../../include/lsnet_hip.h"
 #include "common.h"
+#include "prof.h"
 
 namespace lsn {
 
@@ -446,6 +447,9 @@ int lsn_group_norm_forward(int n_levels, const lsn_gn_level *levels, int C, int 
     a.sums = reinterpret_cast<double *>(workspace);
     a.mean_rstd = mean_rstd;
     LSN_HIP(hipMemsetAsync(a.sums, 0, sizeof(double) * (size_t)images * G * 2, st));
+    double el = 0;
+    for (int i = 0; i < n_levels; ++i) el += (double)levels[i].B * levels[i].HW * C;
+    ProfSpan prof(PROF_NORM, 8.0 * el, 4.0 * 2 * el, st);   // algorithmic: x read once, y written once
     hipLaunchKernelGGL(gn_stats_kernel, dim3(tiles), dim3(256), 0, st, a);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(tiles), dim3(256), 0, st, a);
     LSN_HIP(hipGetLastError());
@@ -472,6 +476,9 @@ int lsn_group_norm_backward(int n_levels, const lsn_gn_level *levels, int C, int
     a.dgamma = grad_gamma;
     a.dbeta = grad_beta;
     LSN_HIP(hipMemsetAsync(a.ab, 0, sizeof(float) * (size_t)images * C * 2, st));
+    double el = 0;
+    for (int i = 0; i < n_levels; ++i) el += (double)levels[i].B * levels[i].HW * C;
+    ProfSpan prof(PROF_NORM, 16.0 * el, 4.0 * 3 * el, st);   // x, dy read, dx written
     hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(tiles), dim3(256), 0, st, a);
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(tiles), dim3(256), 0, st, a);
     if (grad_gamma || grad_beta)
@@ -490,6 +497,7 @@ int lsn_bn_eval_act_forward(const float *x, const float *residual, float *y, con
     BnArgs a = {};
     a.x = x, a.res = residual, a.y = y, a.mean = running_mean, a.var = running_var, a.gamma = gamma, a.beta = beta;
     a.eps = eps, a.N = N, a.C = C, a.relu = relu;
+    ProfSpan prof(PROF_NORM, 4.0 * N * C, 4.0 * N * C * (residual ? 3 : 2), reinterpret_cast<hipStream_t>(stream));
     hipLaunchKernelGGL(bn_act_fwd_kernel, dim3((N + BN_PIX - 1) / BN_PIX, (C / 4 + 255) / 256), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), a);
     LSN_HIP(hipGetLastError());
@@ -526,6 +534,8 @@ int lsn_bn_eval_act_backward(const float *grad_y, const float *y, const float *x
             LSN_HIP(hipMemsetAsync(grad_beta, 0, sizeof(float) * C, st));
         }
     }
+    ProfSpan prof(PROF_NORM, 6.0 * N * C,
+                  4.0 * N * C * (1 + (relu ? 1 : 0) + (grad_gamma ? 1 : 0) + (grad_x ? 1 : 0) + (grad_residual ? 1 : 0)), st);
     hipLaunchKernelGGL(bn_act_bwd_kernel, dim3(blocks, (C / 4 + 255) / 256), dim3(256), 0, st, a);
     if (grad_gamma) {
         const int splits = blocks >= 512 ? 16 : (blocks >= 64 ? 4 : 1);

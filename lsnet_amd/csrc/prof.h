@@ -26,7 +26,7 @@ struct ProfRec {
     double flops, bytes;
 };
 
-bool prof_on();
+bool prof_on(int fam);
 void prof_push(const ProfRec &r);
 
 // RAII: events around the launches issued while the object lives
@@ -34,7 +34,7 @@ struct ProfSpan {
     ProfRec r;
     hipStream_t st;
     bool on;
-    ProfSpan(int fam, double flops, double bytes, hipStream_t s) : st(s), on(prof_on())
+    ProfSpan(int fam, double flops, double bytes, hipStream_t s) : st(s), on(prof_on(fam))
     {
         if (!on) return;
         r.fam = fam, r.flops = flops, r.bytes = bytes;

@@ -12,7 +12,15 @@ from torch.nn.modules.batchnorm import _BatchNorm
 
 from ...cnn import build_conv_layer, build_norm_layer, constant_init, kaiming_init
 from ...ops.batch_norm import bn_act
+from ...ops.conv import conv_bn_act_frozen
 from ..builder import BACKBONES
+
+
+def _conv_bn(conv, bn, x, relu, residual=None):
+    """act(bn(conv(x)) + residual): one fused launch for a frozen pair (ops/conv.py conv_bn_act_frozen), else the
+    convolution followed by the fused norm + add + ReLU pass."""
+    out = conv_bn_act_frozen(conv, bn, x, relu, residual) if isinstance(bn, _BatchNorm) else None
+    return out if out is not None else bn_act(bn, conv(x), relu=relu, residual=residual)
 
 
 def _shortcut(downsample, x):
@@ -21,8 +29,10 @@ def _shortcut(downsample, x):
         return x
     mods = list(downsample)
     if isinstance(mods[-1], _BatchNorm):
-        for m in mods[:-1]:
+        for m in mods[:-2]:
             x = m(x)
+        if len(mods) >= 2:
+            return _conv_bn(mods[-2], mods[-1], x, relu=False)
         return bn_act(mods[-1], x, relu=False)
     return downsample(x)
 
@@ -48,8 +58,8 @@ class BasicBlock(nn.Module):
     norm2 = property(lambda self: getattr(self, self.norm2_name))
 
     def _body(self, x):
-        out = bn_act(self.norm1, self.conv1(x), relu=True)
-        return bn_act(self.norm2, self.conv2(out), relu=True, residual=_shortcut(self.downsample, x))
+        out = _conv_bn(self.conv1, self.norm1, x, relu=True)
+        return _conv_bn(self.conv2, self.norm2, out, relu=True, residual=_shortcut(self.downsample, x))
 
     def forward(self, x):
         return cp.checkpoint(self._body, x) if (self.with_cp and x.requires_grad) else self._body(x)
@@ -99,10 +109,10 @@ class Bottleneck(nn.Module):
     norm3 = property(lambda self: getattr(self, self.norm3_name))
 
     def _body(self, x):
-        out = bn_act(self.norm1, self.conv1(x), relu=True)
-        out = bn_act(self.norm2, self.conv2(out), relu=True)
+        out = _conv_bn(self.conv1, self.norm1, x, relu=True)
+        out = _conv_bn(self.conv2, self.norm2, out, relu=True)
         # relu(bn3(conv3) + identity): norm, residual add and activation in one pass (resnet.py:261-301)
-        return bn_act(self.norm3, self.conv3(out), relu=True, residual=_shortcut(self.downsample, x))
+        return _conv_bn(self.conv3, self.norm3, out, relu=True, residual=_shortcut(self.downsample, x))
 
     def forward(self, x):
         return cp.checkpoint(self._body, x) if (self.with_cp and x.requires_grad) else self._body(x)
@@ -242,7 +252,7 @@ class ResNet(nn.Module):
                     constant_init(m.norm2, 0)
 
     def forward(self, x):
-        x = self.stem(x) if self.deep_stem else bn_act(self.norm1, self.conv1(x), relu=True)
+        x = self.stem(x) if self.deep_stem else _conv_bn(self.conv1, self.norm1, x, relu=True)
         x = self.maxpool(x)
         outs = []
         for i, name in enumerate(self.res_layers):

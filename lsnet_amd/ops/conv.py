@@ -37,7 +37,23 @@ def _pad_channels(t, c_to):
     return out
 
 
-_images = {}    # (id(weight), kind, stride, pad, dil, math mode) -> [weakref, version, data_ptr, image]
+_images = {}    # (id(weight), kind, stride, pad, dil, math mode) -> [weakref, version, data_ptr, image, optimizer epoch]
+_opt_epoch = [0]
+
+
+def _after_optimizer_step(*_):
+    """Global optimizer post-step hook: every image of a trainable weight is stale now.  (The tensors' version counters
+    are not enough: torch's FUSED optimizers update parameters without bumping them.)"""
+    _opt_epoch[0] += 1
+
+
+from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_post_step  # noqa: E402
+
+_reg_post_step(_after_optimizer_step)
+
+
+def _stale(ent, w):
+    return ent[1] != w._version or ent[2] != w.data_ptr() or (w.requires_grad and ent[4] != _opt_epoch[0])
 
 
 def _refresh_stale(mode):
@@ -46,7 +62,7 @@ def _refresh_stale(mode):
     items = []
     for key, ent in _images.items():
         w = ent[0]()
-        if w is None or key[5] != mode or (ent[1] == w._version and ent[2] == w.data_ptr()):
+        if w is None or key[5] != mode or not _stale(ent, w):
             continue
         items.append((key, ent, w))
     if not items:
@@ -58,20 +74,21 @@ def _refresh_stale(mode):
         it.C, it.Co, it.kh, it.kw, it.stride, it.pad, it.dil = C, Co, kh, kw, key[2], key[3], key[4]
     _lib.check(_lib.load().lsn_conv2d_prepare_weights_multi(len(items), arr, _stream()))
     for key, ent, w in items:
-        ent[1], ent[2] = w._version, w.data_ptr()
+        ent[1], ent[2], ent[4] = w._version, w.data_ptr(), _opt_epoch[0]
 
 
 def weight_image(w, kind, stride=1, pad=0, dil=1):
     """The prepared image (lsn_conv2d_prepare_weights) of a channels-last (Co, C, kh, kw) weight for the forward
-    (kind 0) or backward-data (kind 1) pass.  Cached per tensor OBJECT and version: the images of all parameters are
-    rebuilt together, once per optimizer step, when the first of them is needed; a temporary (padded view, test tensor)
-    gets a fresh one and drops it when it dies."""
+    (kind 0) or backward-data (kind 1) pass.  Cached per tensor OBJECT; stale when the tensor's version counter or
+    storage moved, or -- for a trainable weight -- when any optimizer has stepped since.  The stale images of all
+    parameters are rebuilt together, once per optimizer step, when the first of them is needed; a temporary (padded
+    view, test tensor) gets a fresh one and drops it when it dies."""
     lib = _lib.load()
     mode = lib.lsn_get_math_mode()
     key = (id(w), kind, stride, pad, dil, mode)
     ent = _images.get(key)
     if ent is not None and ent[0]() is w:
-        if ent[1] != w._version or ent[2] != w.data_ptr():
+        if _stale(ent, w):
             _refresh_stale(mode)
         return ent[3]
     Co, C, kh, kw = w.shape
@@ -80,7 +97,7 @@ def weight_image(w, kind, stride=1, pad=0, dil=1):
         _lib.check(-2)
     img = torch.empty(nbytes, device=w.device, dtype=torch.uint8)
     _lib.check(lib.lsn_conv2d_prepare_weights(kind, _p(w), _p(img), C, Co, kh, kw, stride, pad, dil, _stream()))
-    _images[key] = [weakref.ref(w, lambda _, k=key: _images.pop(k, None)), w._version, w.data_ptr(), img]
+    _images[key] = [weakref.ref(w, lambda _, k=key: _images.pop(k, None)), w._version, w.data_ptr(), img, _opt_epoch[0]]
     return img
 
 
@@ -346,6 +363,64 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, relu=False):
         w4[:, :C] = weight
         weight = w4
     return _ConvFn.apply(x, weight, bias, int(stride), int(padding), int(dilation), bool(relu))
+
+
+_folded = {}    # (id(conv.weight), id(bn)) -> [weakrefs, versions, folded weight, shift]
+
+
+def _fold_bn(conv, bn):
+    """(w * scale[co], shift) with scale = gamma / sqrt(var + eps), shift = beta - mean * scale: a frozen BatchNorm behind
+    a frozen convolution is the same convolution with other constants.  Rebuilt only when a tensor's version moves."""
+    key = (id(conv.weight), id(bn))
+    vers = (conv.weight._version, bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
+            conv.weight.data_ptr())
+    ent = _folded.get(key)
+    if ent is not None and ent[0]() is conv.weight and ent[1]() is bn and ent[2] == vers:
+        return ent[3], ent[4]
+    with torch.no_grad():
+        scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+        shift = (bn.bias - bn.running_mean * scale).contiguous()
+        w = (conv.weight * scale.view(-1, 1, 1, 1)).contiguous(memory_format=_CL)
+    _folded[key] = [weakref.ref(conv.weight, lambda _, k=key: _folded.pop(k, None)), weakref.ref(bn), vers, w, shift]
+    return w, shift
+
+
+def conv_bn_act_frozen(conv, bn, x, relu=True, residual=None):
+    """relu(bn(conv(x)) + residual) in ONE launch for a FROZEN conv + eval-mode BatchNorm pair whose input needs no
+    gradient (stem and stage 1 of every LSNet backbone, `frozen_stages=1`: resnet.py:569-585, 636-645): the norm is folded
+    into the weight / bias, residual add and ReLU ride in the convolution's epilogue (include/lsnet_hip.h
+    lsn_conv_level.residual) -- no normalisation pass over the largest activations of the network.  Returns None when the
+    pair does not qualify (the caller then runs conv and bn_act separately)."""
+    if not isinstance(conv, Conv2d) or conv.bias is not None or conv.groups != 1 or bn.training or not bn.affine \
+            or not bn.track_running_stats:
+        return None
+    if conv.weight.requires_grad or bn.weight.requires_grad or bn.bias.requires_grad \
+            or (torch.is_grad_enabled() and x.requires_grad):
+        return None
+    if not hip_conv_ok(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups, conv.padding_mode):
+        return None
+    w, shift = _fold_bn(conv, bn)
+    stride, pad, dil = conv.stride[0], conv.padding[0], conv.dilation[0]
+    B, C, H, W = x.shape
+    Co, _, kh, kw = w.shape
+    if C < 8:    # the image stem: row-merged form, no residual there
+        if residual is not None or kw == 1 or dil != 1:
+            return None
+        return _stem_forward(x, w, shift, stride, pad, relu)
+    if C % 4:
+        return None
+    Ho = (H + 2 * pad - (dil * (kh - 1) + 1)) // stride + 1
+    Wo = (W + 2 * pad - (dil * (kw - 1) + 1)) // stride + 1
+    if residual is not None and not (tuple(residual.shape) == (B, Co, Ho, Wo) and residual.dtype == torch.float32
+                                     and residual.is_contiguous(memory_format=_CL) and Co % 4 == 0):
+        return None
+    lib = _lib.load()
+    out = torch.empty((B, Co, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=_CL)
+    lv = _levels(1)
+    lv[0].x, lv[0].out, lv[0].B, lv[0].H, lv[0].W, lv[0].residual = _p(x), _p(out), B, H, W, _p(residual)
+    _lib.check(lib.lsn_conv2d_forward_prepared(1, lv, _p(weight_image(w, 0)), _p(shift), C, C, Co, kh, kw, stride, pad,
+                                               dil, 1 if relu else 0, _stream()))
+    return out
 
 
 class Conv2d(nn.Conv2d):

@@ -20,7 +20,11 @@ def build_optimizer(model, cfg):
     kind = cfg.pop('type')
     cfg.pop('paramwise_cfg', None)
     target = model.module if hasattr(model, 'module') else model
-    return getattr(torch.optim, kind)(target.parameters(), **cfg)
+    params = list(target.parameters())
+    if kind == 'SGD' and 'fused' not in cfg and 'foreach' not in cfg and params and all(p.is_cuda for p in params):
+        cfg['fused'] = True    # weight decay + momentum + update in ONE multi-tensor launch (same arithmetic as the
+                               # foreach form, which takes four launches over the 160 parameter tensors)
+    return getattr(torch.optim, kind)(params, **cfg)
 
 
 class EpochBasedRunner:

@@ -67,12 +67,15 @@ def test_training_curve_follows_reference_runner(math):
     3.3e-2 in that run and 9e-2 in an earlier one -- the trajectory amplifies rounding-level differences once the
     learning rate is up, the exact-fp32 kernels no less than the split ones, and fp32 atomics in the weight gradients make
     the late values vary from run to run.  Tolerances = 3 x the worst measured: early 7.5e-4 for the fp32-equivalent
-    and exact modes and 5e-3 for the 3-product mode (1.4e-3 at iteration 3 in one run), 0.27 late."""
+    and exact modes and 5e-3 for the 3-product mode (1.4e-3 at iteration 3 in one run).  Round 3 (new dense-conv kernels, frozen stage-1
+    BatchNorm folded into its convolutions, fused SGD; profiles/r3_gpu_tests.log): iterations 1-6 <= 2.0e-4 / 6.9e-4 / 1.3e-4,
+    iterations 7-12 <= 2.8e-2 / 1.2e-2 / 4.7e-2: late tolerance 0.12 (round 2: 0.27).  Teacher-forcing every iteration from
+    the reference's weights would remove the chaos, but the fixture would have to carry 12 x 38 M parameters."""
     from lsnet_amd import _lib
     before = _lib.get_math_mode()
     _lib.set_math_mode(math)
     try:
-        worst = gc.train_curve_case(_dev(), early_tol=5e-3 if math == 'bf16x3' else 7.5e-4, late_tol=0.27, rtol_weight=5e-2, channels_last=True)
+        worst = gc.train_curve_case(_dev(), early_tol=5e-3 if math == 'bf16x3' else 7.5e-4, late_tol=0.12, rtol_weight=5e-2, channels_last=True)
     finally:
         _lib.set_math_mode(before)
     print(math, f'worst relative loss deviation {worst:.2e}')

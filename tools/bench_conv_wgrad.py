@@ -21,7 +21,7 @@ for name, ci, co, k, s, h, w, cnt in SH:
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     gw = torch.empty_like(wt)
     gb = torch.empty(co, device=dev)
-    f_own = lambda: lib.lsn_conv2d_backward_weight(cp(x), cp(go), cp(gw), cp(gb), B, h, w, ci, co, k, k, s, pad, 1, st)
+    f_own = lambda: lib.lsn_conv2d_backward_weight(cp(x), cp(go), cp(gw), cp(gb), B, h, w, ci, co, k, k, s, pad, 1, 0, st)
     f_ref = lambda: torch.ops.aten.convolution_backward(go, x, wt, None, [s, s], [pad, pad], [1, 1], False, [0, 0], 1, [False, True, False])
     assert f_own() == 0, lib.lsn_last_error()
     ref = f_ref()[1]

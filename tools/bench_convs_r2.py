@@ -56,7 +56,7 @@ for name, ci, co, k, s, h, w, cnt in SH + EXTRA:
     by = 4.0 * (x.numel() + ref.numel() + wt.numel()) / 1e9
     go = torch.randn_like(ref)
     line = f'{name:38s} {t_f:7.3f}|{t_fm:7.3f}'
-    err_d = 0.0
+    err_d = err_w = 0.0
     if ci >= 8:
         co8 = (co + 3) // 4 * 4
         go8 = go if co8 == co else torch.cat([go, go.new_zeros(B, co8 - co, *go.shape[2:])], 1).contiguous(memory_format=torch.channels_last)
@@ -71,7 +71,10 @@ for name, ci, co, k, s, h, w, cnt in SH + EXTRA:
         gref = torch.ops.aten.convolution_backward(go, x, wt, None, [s, s], [pad, pad], [1, 1], False, [0, 0], 1, [True, False, False])[0]
         err_d = float((gx - gref).abs().max() / gref.abs().max())
         t_d = ev_time(f_d)
-        t_w = ev_time(lambda: lib.lsn_conv2d_backward_weight(cp(x), cp(go), cp(gw), None, B, h, w, ci, co, k, k, s, pad, 1, st))
+        wref = torch.ops.aten.convolution_backward(go, x, wt, None, [s, s], [pad, pad], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+        assert lib.lsn_conv2d_backward_weight(cp(x), cp(go), cp(gw), None, B, h, w, ci, co, k, k, s, pad, 1, 0, st) == 0, lib.lsn_last_error()
+        err_w = float((gw - wref).abs().max() / wref.abs().max())
+        t_w = ev_time(lambda: lib.lsn_conv2d_backward_weight(cp(x), cp(go), cp(gw), None, B, h, w, ci, co, k, k, s, pad, 1, 0, st))
         t_dm = 0.0 if OWN_ONLY else ev_time(lambda: torch.ops.aten.convolution_backward(go, x, wt, None, [s, s], [pad, pad], [1, 1], False, [0, 0], 1, [True, False, False]))
         t_wm = 0.0 if OWN_ONLY else ev_time(lambda: torch.ops.aten.convolution_backward(go, x, wt, None, [s, s], [pad, pad], [1, 1], False, [0, 0], 1, [False, True, False]))
         line += f' {t_d:7.3f}|{t_dm:7.3f} {t_w:7.3f}|{t_wm:7.3f}'
@@ -81,6 +84,6 @@ for name, ci, co, k, s, h, w, cnt in SH + EXTRA:
         tot[0] += t_f * cnt
         tot[1] += t_fm * cnt
         line += ' ' * 32
-    print(line + f' {fl:7.1f}  x{cnt}   {fl / t_f:7.1f} {by / t_f:7.2f}   {err_f:.1e} {err_d:.1e}', flush=True)
+    print(line + f' {fl:7.1f}  x{cnt}   {fl / t_f:7.1f} {by / t_f:7.2f}   {err_f:.1e} {err_d:.1e} {err_w:.1e}', flush=True)
 print(f'network sums (ms): fwd own {tot[0]:.2f} | MIOpen {tot[1]:.2f};  bwd-data own {tot[2]:.2f} | {tot[3]:.2f};  '
       f'wgrad own {tot[4]:.2f} | {tot[5]:.2f}')

@@ -13,16 +13,19 @@ dev = torch.device('cuda:0')
 torch.manual_seed(0)
 model, cfg = build_lsnet('bbox', 'r50')
 model = model.to(dev).to(memory_format=torch.channels_last).train()
+from lsnet_amd.parallel import DataParallelModel
+model = DataParallelModel(model)
 step, runner = bench.build_step(model, cfg)
 data = synthetic_batch('bbox', 2, 800, 1344, seed=1234, device=dev)
 for _ in range(3):
     step(data)
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True,
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True,
              experimental_config=torch._C._profiler._ExperimentalConfig(verbose=True)) as prof:
     step(data)
     torch.cuda.synchronize()
 agg = defaultdict(lambda: [0, 0.0])
+shapes = defaultdict(lambda: [0, 0.0])
 for e in prof.events():
     dt = getattr(e, 'self_device_time_total', None)
     if dt is None:
@@ -34,6 +37,10 @@ for e in prof.events():
     if frames:
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + '/'
         site = ' <- '.join(f.replace(root, '').replace('lsnet_amd/', '') for f in frames[:2])
+    if 'hooks.py' in site or site.startswith('autograd'):
+        sh = shapes[(e.name, str(getattr(e, 'input_shapes', None))[:90])]
+        sh[0] += 1
+        sh[1] += dt
     a = agg[(e.name, site)]
     a[0] += 1
     a[1] += dt
@@ -42,3 +49,6 @@ tot_n = sum(v[0] for v in agg.values()); tot_t = sum(v[1] for v in agg.values())
 print(f'ATen ops with device time in one step: {tot_n} launches, {tot_t / 1e3:.2f} ms')
 for (name, site), (n, t) in rows[:70]:
     print(f'{n:5d} {t / 1e3:8.3f} ms  {name:28s} {site[:110]}')
+print('--- ops launched from backward() / the autograd engine, by input shapes')
+for (name, shp), (n, t) in sorted(shapes.items(), key=lambda kv: -kv[1][1])[:45]:
+    print(f'{n:5d} {t / 1e3:8.3f} ms  {name:24s} {shp}')
