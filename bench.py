@@ -314,6 +314,17 @@ def main():
         model = model.to(memory_format=torch.channels_last)
     model.train()
     model = DataParallelModel(model)   # N = 1: the gradient arena alone (no communication), as train_detector builds it
+    exposed = []   # N > 1: (start, end) events around the wait for the gradient all-reduces = what backward did not hide
+    if world > 1:
+        finish = model.reduce_gradients
+
+        def timed_finish():
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            finish()
+            e1.record()
+            exposed.append((e0, e1))
+        model.reduce_gradients = timed_finish
     step, runner = build_step(model, cfg)
     data = synthetic_batch(args.task, args.batch, args.height, args.width, seed=1234 + rank, device=dev,
                            channels_last=not args.nchw)
@@ -352,22 +363,30 @@ def main():
         torch.cuda.synchronize()
     if timer and not use_graph and dominant:
         timer.start([dominant])      # HIP events around the launches of the dominant family only
+    del exposed[:]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step(data)
     torch.cuda.synchronize()
+    dt_rank = time.perf_counter() - t0     # this rank's own K steps, before it waits for the others
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    exposed_ms = sum(a.elapsed_time(b) for a, b in exposed) / max(len(exposed), 1) if exposed else 0.0
     ks = timer.stop() if (timer and not use_graph) else {}
     if markers:
         get_backend(mk).selftest_mfma(mk, mk, 0)
         torch.cuda.synchronize()
+    per_rank = None
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        mine = torch.tensor([dt_rank / args.steps * 1e3, exposed_ms], device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [[round(float(v), 3) for v in r] for r in allr]
     losses = out['log_vars'].items_as_float() if hasattr(out['log_vars'], 'items_as_float') else {}
 
     nk = args.steps
@@ -425,6 +444,12 @@ def main():
             except Exception:
                 res['config']['rccl_version'] = 'unknown'
             res['config'].update(comm)
+            res['config']['rccl_ranks'] = dist.get_world_size()    # what the process group reports, not the flag
+            res['config']['per_rank_ms_per_step'] = [r[0] for r in per_rank]
+            # GPU time the compute stream spent waiting for the bucket all-reduces after backward (mean per step, per rank):
+            # the part of `allreduce_ms_per_step_standalone` that backward did NOT hide
+            res['config']['allreduce_exposed_ms_per_step'] = [r[1] for r in per_rank]
+            res['config']['grad_buckets_mb'] = [round(b['flat'].numel() * 4 / 2 ** 20, 1) for b in model.reducer.buckets]
 
         peak = BF16_MFMA_PEAK_TFLOPS / np_ if np_ else FP32_MFMA_PEAK_TFLOPS
         peak_note = (f'dense bf16 MFMA peak / {np_} ({np_} bf16 products per fp32 product)' if np_

@@ -1519,7 +1519,11 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_data_xn_kernel(const DcnArgs a
         const Chunk chn = it.get();   // chunk t + 1 (saturates at the last one)
         const bool tap_done = (t + 1 == T) || chn.k != ch.k || chn.dgi != ch.dgi;
         LSN_STAMP(2);
-        __syncthreads();   // every wave's slab loads have landed (the barrier's fence waits for this wave's vmcnt)
+        // The slab of this chunk arrives by LDS-DMA (buffer_load ... lds): nothing orders a ds_read behind it except the
+        // ISSUING wave's vmcnt followed by a barrier.  hipcc (ROCm 7.2) does put s_waitcnt vmcnt(0) in front of this
+        // barrier while an LDS-DMA is in flight, but that is compiler behaviour, not a guarantee of the source: spell it.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();   // every wave's slab loads have landed
         LSN_STAMP(4);
         float xv0[4][4], xv1[4][4];
         if (want_off) issue_xv(ch, 0, xv0);

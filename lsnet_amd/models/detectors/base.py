@@ -79,7 +79,10 @@ class BaseDetector(nn.Module):
         loss = sum(v for k, v in log_vars.items() if 'loss' in k)
         log_vars['loss'] = loss
         capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and not capturing:
+        # `_log_reduce_elsewhere`: a GraphedForwardBackward owns the ONE reduction of the log scalars of its steps -- warm-up,
+        # capture and replay alike, so that every rank issues the same sequence of collectives whatever its call count
+        elsewhere = getattr(self, '_log_reduce_elsewhere', False)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and not capturing and not elsewhere:
             packed = torch.stack([v.detach().reshape(()) for v in log_vars.values()])
             dist.all_reduce(packed.div_(dist.get_world_size()))   # one collective for all scalars
             for i, k in enumerate(list(log_vars.keys())):

@@ -104,7 +104,9 @@ class CrossIOULoss(nn.Module):
             rows = fused.cross_iou_bbox_rows(pred, target, kwargs['pos_inds'], kwargs['anchor_pts'], kwargs['bbox_gt'],
                                              weight, self.alpha, self.eps)      # already weighted
             return self.loss_weight * weight_reduce_loss(rows, None, reduction, avg_factor)
-        if (fused.enabled() and kwargs.get('pos_inds') is not None and fused.rows_usable(pred, target, self.loss_type, self.stride)
+        if (fused.enabled() and kwargs.get('pos_inds') is not None
+                and fused.rows_usable(pred, target, self.loss_type, self.stride, kwargs.get('pos_inds'), kwargs.get('anchor_pts'),
+                                      kwargs.get('bbox_gt'), kwargs.get('vs'), weight)
                 and (self.loss_type == 'keypoint' or (kwargs.get('anchor_pts') is not None and kwargs.get('bbox_gt') is not None))
                 and (self.loss_type == 'polygon' or kwargs.get('vs') is not None)):
             from .utils import weight_reduce_loss

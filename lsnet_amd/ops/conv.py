@@ -7,8 +7,9 @@ implicit-GEMM kernels of csrc/conv_kernels.h in the library's math modes 'bf16x6
 'bf16x3'.  The kernels read weights as prepared images (MFMA fragment order); `weight_image` keeps one per (weight
 tensor, pass) and rebuilds it when the tensor's version counter moves, i.e. once per optimizer step.  Grouped
 convolutions with 4 .. 32 channels per group (ResNeXt 64x4d bottlenecks) run the exact-fp32 kernels of csrc/gconv.hip
-in every math mode.  Exact-fp32 dense convolutions, other group shapes and CPU tensors go to ATen's convolution
-(MIOpen), which is a different vendor operator, not a fallback of the HIP path."""
+in every math mode.  Contiguous (NCHW) inputs are re-laid channels-last and LSN_MATH_FP32 runs the same fp32-equivalent
+kernels: no vendor convolution is reached from a CUDA fp32 tensor.  Other group shapes, dtypes and CPU tensors go to ATen's
+convolution, which is a different operator, not a fallback of the HIP path."""
 import ctypes
 import weakref
 
@@ -317,9 +318,13 @@ def conv2d_multi(xs, weight, bias=None, padding=0, dilation=1, relu=False):
 
 
 def hip_conv_ok(x, weight, stride, padding, dilation, groups, padding_mode='zeros'):
-    """The own kernels take every dense (groups = 1) fp32 channels-last convolution on the device in the split math
-    modes; exact-fp32 mode keeps the vendor library (there is no fp32-MFMA dense conv kernel)."""
-    if not (x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and x.is_contiguous(memory_format=_CL)):
+    """The own kernels take every dense (groups = 1) fp32 convolution on the device, in every math mode and memory
+    format: a contiguous (NCHW) tensor is re-laid channels-last on the way in (`_as_cl`, a layout copy -- the result stays
+    channels-last, as ATen's own convolution propagates the format), and LSN_MATH_FP32 runs the fp32-EQUIVALENT 6-term
+    kernels here (exactness of that mode concerns the deformable family; there is no fp32-MFMA dense kernel, and no vendor
+    convolution is called either).  What is left for F.conv2d: other dtypes / devices, 'same' / non-zero padding modes,
+    unequal strides, tensors beyond 32-bit byte offsets."""
+    if not (x.is_cuda and x.dim() == 4 and x.dtype == torch.float32):
         return False
     if groups != 1 or padding_mode != 'zeros' or isinstance(padding, str):
         return False
@@ -327,7 +332,17 @@ def hip_conv_ok(x, weight, stride, padding, dilation, groups, padding_mode='zero
         return False
     if x.numel() * 4 >= 2 ** 31 or weight.numel() * 8 >= 2 ** 31 or weight.shape[2] * weight.shape[3] > 64:
         return False
-    return _lib.split_math()
+    # the output (and with it grad_output of the backward passes) must fit 32-bit byte offsets too: csrc/conv.hip conv_check
+    kh, kw = weight.shape[2], weight.shape[3]
+    ho = (x.shape[2] + 2 * padding[0] - (dilation[0] * (kh - 1) + 1)) // stride[0] + 1
+    wo = (x.shape[3] + 2 * padding[1] - (dilation[1] * (kw - 1) + 1)) // stride[1] + 1
+    if ho <= 0 or wo <= 0 or x.shape[0] * ho * wo * weight.shape[0] * 4 >= 2 ** 31:
+        return False
+    return True
+
+
+def _as_cl(x):
+    return x if x.is_contiguous(memory_format=_CL) else x.contiguous(memory_format=_CL)
 
 
 def _stem_forward(x, weight, bias, stride, pad, relu):
@@ -399,6 +414,7 @@ def conv_bn_act_frozen(conv, bn, x, relu=True, residual=None):
         return None
     if not hip_conv_ok(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups, conv.padding_mode):
         return None
+    x = _as_cl(x)
     w, shift = _fold_bn(conv, bn)
     stride, pad, dil = conv.stride[0], conv.padding[0], conv.dilation[0]
     B, C, H, W = x.shape
@@ -411,9 +427,10 @@ def conv_bn_act_frozen(conv, bn, x, relu=True, residual=None):
         return None
     Ho = (H + 2 * pad - (dil * (kh - 1) + 1)) // stride + 1
     Wo = (W + 2 * pad - (dil * (kw - 1) + 1)) // stride + 1
-    if residual is not None and not (tuple(residual.shape) == (B, Co, Ho, Wo) and residual.dtype == torch.float32
-                                     and residual.is_contiguous(memory_format=_CL) and Co % 4 == 0):
-        return None
+    if residual is not None:
+        if not (tuple(residual.shape) == (B, Co, Ho, Wo) and residual.dtype == torch.float32 and Co % 4 == 0):
+            return None
+        residual = _as_cl(residual)
     lib = _lib.load()
     out = torch.empty((B, Co, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=_CL)
     lv = _levels(1)
@@ -438,13 +455,13 @@ class Conv2d(nn.Conv2d):
         if (1 < len(xs) <= 8 and self.stride[0] == 1 and xs[0].shape[1] % 4 == 0
                 and all(hip_conv_ok(x, self.weight, self.stride, self.padding, self.dilation, self.groups,
                                     self.padding_mode) for x in xs)):
-            return conv2d_multi(xs, self.weight, self.bias, self.padding[0], self.dilation[0], relu)
+            return conv2d_multi([_as_cl(x) for x in xs], self.weight, self.bias, self.padding[0], self.dilation[0], relu)
         outs = [self._run(x, self.weight) for x in xs]
         return [F.relu(o) for o in outs] if relu else outs
 
     def _run(self, x, w):
         if hip_conv_ok(x, w, self.stride, self.padding, self.dilation, self.groups, self.padding_mode):
-            return conv2d(x, w, self.bias, self.stride[0], self.padding[0], self.dilation[0], False)
+            return conv2d(_as_cl(x), w, self.bias, self.stride[0], self.padding[0], self.dilation[0], False)
         if hip_group_conv_ok(x, w, self.stride, self.padding, self.dilation, self.groups, self.padding_mode):
             return _GroupConvFn.apply(x, w, self.bias, self.stride[0], self.padding[0], self.dilation[0], self.groups)
         return F.conv2d(x, w, self.bias, self.stride, self.padding, self.dilation, self.groups)

@@ -60,11 +60,21 @@ def usable(pred, target, loss_type):
 _KIND = {'polygon': 1, 'keypoint': 2}
 
 
-def rows_usable(pred, target, loss_type, stride=9):
-    """The polygon / keypoint kernels: rows of 4 (nv + 1) fp32 components on the device."""
-    return (loss_type in _KIND and pred.is_cuda and pred.dtype == torch.float32 and pred.dim() == 2
+def rows_usable(pred, target, loss_type, stride=9, active=None, anchor=None, bbox_gt=None, vs=None, weight=None):
+    """The polygon / keypoint kernels: rows of 4 (nv + 1) fp32 components on the device.  The kernels index the side
+    tensors unchecked (active[M i], anchor[2 i], bbox_gt[4 i], vs[(M / 4 - 1) i], weight[i]): every tensor handed in is
+    verified here -- shape, device -- and a mismatch sends the caller to the torch formulation, which raises the shape
+    error a user expects instead of reading out of bounds."""
+    if not (loss_type in _KIND and pred.is_cuda and pred.dtype == torch.float32 and pred.dim() == 2
             and pred.shape[1] >= 8 and pred.shape[1] % 4 == 0 and not target.requires_grad
-            and (loss_type == 'keypoint' or 1 <= stride <= min(16, pred.shape[1] // 4)))
+            and (loss_type == 'keypoint' or 1 <= stride <= min(16, pred.shape[1] // 4))):
+        return False
+    n, m = pred.shape
+    want = ((target, (n, m)), (active, (n, m)), (anchor, (n, 2)), (bbox_gt, (n, 4)), (vs, (n, m // 4 - 1)), (weight, (n,)))
+    for t, shape in want:
+        if t is not None and (tuple(t.shape) != shape or t.device != pred.device):
+            return False
+    return True
 
 
 class _CrossIouRows(torch.autograd.Function):

@@ -40,6 +40,7 @@ class GraphedForwardBackward:
     def __init__(self, model, bucket_mb=64.0, warmup=3, process_group=None):
         self.model = model
         self.module = model.module if hasattr(model, 'module') else model
+        self.module._log_reduce_elsewhere = True   # __call__ averages the log scalars once per step (base.py _parse_losses)
         self.warmup, self.calls = warmup, 0
         self.graph, self.static_in, self.static_out = None, None, None
         # autograd remembers the stream each parameter's AccumulateGrad node first ran on; the eager warm-up

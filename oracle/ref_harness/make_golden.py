@@ -53,11 +53,12 @@ def _gt_for(task, batch=2):
     return boxes, labels, extremes, masks, kps, metas
 
 
-def golden_head(task):
-    """(8) full LSHead.forward + loss (+ gradients) and get_bboxes, reference code end to end."""
-    head = _ref_head(task)
+def golden_head(task, channels=32):
+    """(8) full LSHead.forward + loss (+ gradients) and get_bboxes, reference code end to end.  channels = 256: the head at
+    the width of configs/lsnet/* (GN32, 256-channel towers), fixture head_<task>_256."""
+    head = _ref_head(task, channels)
     head.train()
-    feats = [f.requires_grad_() for f in gu.head_inputs(11)]
+    feats = [f.requires_grad_() for f in gu.head_inputs(11, channels)]
     outs = head(feats)
     data = {}
     names = ['cls', 'bbox_init', 'bbox_refine', 'segm_init', 'segm_refine', 'pose_init', 'pose_refine']
@@ -89,7 +90,7 @@ def golden_head(task):
         data[f'det/{i}/bboxes'] = b.numpy()
         data[f'det/{i}/vectors'] = v.numpy()
         data[f'det/{i}/labels'] = l.numpy()
-    _save(f'head_{task}', data)
+    _save(f'head_{task}' + ('' if channels == 32 else f'_{channels}'), data)
 
 
 def golden_head_cpv():
@@ -625,6 +626,7 @@ def golden_data_pipeline():
 
 
 ALL = dict(backbones_dcn=golden_backbones_dcn, train_curve=golden_train_curve, coco_eval=golden_coco_eval, head_cpv=golden_head_cpv, data_pipeline=golden_data_pipeline, gt_formats=golden_gt_formats, res2net=golden_res2net, vote=golden_vote, head_bbox=lambda: golden_head('bbox'), head_segm=lambda: golden_head('segm'),
+           head_bbox_256=lambda: golden_head('bbox', 256),
            head_pose_bbox=lambda: golden_head('pose_bbox'), head_pose_kbox=lambda: golden_head('pose_kbox'),
            assign=golden_assign, cross_iou=golden_cross_iou, backbone=golden_backbone, nms=golden_nms)
 

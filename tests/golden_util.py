@@ -145,7 +145,7 @@ def make_keypoints(seed, boxes, nk=17):
 
 def head_cfg(task, channels=32, num_classes=8):
     """A reduced LSHead config (same code paths as configs/lsnet/*, small tensors)."""
-    norm_cfg = dict(type='GN', num_groups=8, requires_grad=True)
+    norm_cfg = dict(type='GN', num_groups=8 if channels < 256 else 32, requires_grad=True)   # (GN32 at the real width)
     nv = {'bbox': 4, 'segm': 36, 'pose_bbox': 17, 'pose_kbox': 17}[task]
     cfg = dict(type='LSHead', task=task, num_vectors=nv, num_classes=num_classes, in_channels=channels,
                feat_channels=channels, point_feat_channels=channels, stacked_convs=3, num_kernel_points=9,

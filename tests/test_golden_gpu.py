@@ -28,6 +28,14 @@ def test_assigners_exact():
     gc.assign_case(_dev())
 
 
+@pytest.mark.parametrize('channels_last', [False, True], ids=['nchw', 'nhwc'])
+def test_head_at_256_channels(channels_last):
+    """The bbox head at the width every LSNet config uses (256 channels, GN32) against the reference's own head run at
+    that width (fixture head_bbox_256.npz, oracle/ref_harness/make_golden.py head_bbox_256): forward, losses, feature
+    and parameter gradients, decode -- and the split kernels against exact fp32 on the same device."""
+    gc.head_case('bbox', _dev(), channels_last, channels=256)
+
+
 def test_cross_iou_loss():
     gc.cross_iou_case(_dev())
 

@@ -49,7 +49,7 @@ def test_pmc_traffic_splits_by_launch_kind(tmp_path):
 
 
 def test_bench_reads_the_committed_traffic_file():
-    """bench.py takes roofline.traffic from profiles/r2_hbm_traffic.json: the committed file has the fields it reads."""
+    """bench.py takes roofline.traffic from profiles/r3_hbm_traffic.json: the committed file has the fields it reads."""
     sys.path.insert(0, ROOT)
     import bench
     with open(bench.TRAFFIC_FILE) as f:

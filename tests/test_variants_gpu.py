@@ -1,6 +1,8 @@
-"""One training step of the other BASELINE configurations on the GPU: R-101-DCN bbox (config 3: DCNv2 in the backbone)
-and X-101-64x4d-DCN segm (config 4: grouped DCNv2 + activation checkpointing) run by default; R-50 pose head and
-Res2Net-101-DCN are opt-in (LSNET_SLOW_TESTS=1).  Loss finite, the head's parameters move, the backbone's deformable
+"""One training step of the other BASELINE configurations on the GPU: R-101-DCN bbox (config 3: DCNv2 in the backbone),
+X-101-64x4d-DCN segm (config 4: grouped DCNv2 + activation checkpointing) and the R-50 pose head, at a reduced image size and
+-- `test_full_size_*` -- at the 800 x 1344 of BASELINE.json (tile tables, 32-bit offset guards and checkpointing memory
+at the real shapes); one inference batch of config 5 (pose head, 4 images) at full size.  Res2Net-101-DCN is opt-in
+(LSNET_SLOW_TESTS=1).  Loss finite, the head's parameters move, the backbone's deformable
 convs receive finite gradients.  (Feature / gradient parity of these backbones against the reference:
 tests/test_golden_gpu.py::test_dcn_backbones_of_configs_3_and_4.)"""
 import os
@@ -18,7 +20,7 @@ SLOW = pytest.mark.skipif(os.environ.get('LSNET_SLOW_TESTS') != '1', reason='opt
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('task,backbone', [('bbox', 'r101-dcn'), ('segm', 'x101-dcn'),
-                                           pytest.param('pose_bbox', 'r50', marks=SLOW),
+                                           ('pose_bbox', 'r50'),
                                            pytest.param('bbox', 'res2-101-dcn', marks=SLOW)])
 def test_one_training_step(task, backbone):
     dev = torch.device('cuda:0')
@@ -39,3 +41,49 @@ def test_one_training_step(task, backbone):
     if 'dcn' in backbone:   # the backbone's deformable convs received gradients
         g = [p.grad for n, p in model.backbone.named_parameters() if 'conv_offset' in n]
         assert g and all(t is not None and torch.isfinite(t).all() for t in g)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('task,backbone', [('bbox', 'r101-dcn'), ('segm', 'x101-dcn')])
+def test_full_size_training_step(task, backbone):
+    """BASELINE configs 3 and 4 at 2 x 3 x 800 x 1344: forward, losses, backward, clip, SGD through the runner's hooks --
+    twice, so that the second step runs on refreshed weight images and learnt gradient-contribution counts."""
+    from lsnet_amd.parallel import DataParallelModel
+    dev = torch.device('cuda:0')
+    torch.manual_seed(0)
+    model, cfg = build_lsnet(task, backbone)
+    model = DataParallelModel(model.to(dev).to(memory_format=torch.channels_last).train())
+    opt = build_optimizer(model, cfg.optimizer)
+    r = EpochBasedRunner(model, optimizer=opt, logger=lambda s: None)
+    r.register_training_hooks(cfg.lr_config, cfg.optimizer_config, None, dict(interval=10 ** 9, hooks=[]))
+    batch = synthetic_batch(task, 2, 800, 1344, seed=9, device=dev)
+    before = {k: v.detach().clone() for k, v in model.module.bbox_head.named_parameters() if v.requires_grad}
+    r.run([[batch, batch]], [('train', 1)], 1)
+    loss = float(r.outputs['log_vars']['loss'])
+    assert loss == loss and 0 < loss < 200, loss
+    moved = sum(int(not torch.equal(before[k], v.detach())) for k, v in model.module.bbox_head.named_parameters()
+                if v.requires_grad)
+    assert moved > 0.8 * len(before), (moved, len(before))
+    g = [p.grad for n, p in model.module.backbone.named_parameters() if 'conv_offset' in n]
+    assert g and all(t is not None and torch.isfinite(t).all() for t in g)
+    assert all(torch.isfinite(p).all() for p in model.parameters())
+
+
+@pytest.mark.gpu
+def test_full_size_pose_inference_batch():
+    """BASELINE config 5: R-50-FPN pose head, 4 images 3 x 800 x 1344, forward + decode + NMS on the device."""
+    dev = torch.device('cuda:0')
+    torch.manual_seed(0)
+    model, _ = build_lsnet('pose_kbox', 'r50')
+    model = model.to(dev).to(memory_format=torch.channels_last).eval()
+    with torch.no_grad():
+        model.bbox_head.pts_cls_out.bias.add_(2.0)    # random-init logits sit below score_thr: let detections through
+        img = torch.randn(4, 3, 800, 1344, device=dev).contiguous(memory_format=torch.channels_last)
+        metas = [dict(pad_shape=(800, 1344, 3), img_shape=(800, 1344, 3), scale_factor=1.0, ori_shape=(800, 1344, 3),
+                      flip=False)] * 4
+        dets = model.simple_test_batch(img, metas)
+    assert len(dets) == 4
+    for boxes, vectors, labels in dets:
+        assert boxes.shape[0] == labels.shape[0] == vectors.shape[0] and boxes.shape[0] > 0
+        assert torch.isfinite(boxes).all() and torch.isfinite(vectors).all()
+        assert boxes.shape[1] == 5 and int(labels.min()) >= 0
