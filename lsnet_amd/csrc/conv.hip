@@ -112,12 +112,17 @@ static int conv_forward(ConvArgs &a, hipStream_t st)
         for (int i = 0; i < a.nlv; ++i) t += (a.lv[i].P + bm - 1) / bm;
         return t * ((a.Co + bn - 1) / bn);
     };
-    int cfg;   // 1: 128 x 128, 2: 64 x 128, 3: 128 x 64, 4: 128 x 32
+    int cfg;   // 1: 128 x 128, 2: 64 x 128, 3: 128 x 64, 4: 128 x 32, 5: 64 x 256
     if (a.Co <= 32) cfg = 4;
     else if (a.Co <= 64) cfg = 3;
     else cfg = blocks(128, 128) >= 700 ? 1 : 2;
+    // 64 x 256 (a pixel slab is fetched and split ONCE for 256 output channels; half the split work per MFMA of the 128-wide
+    // tiles): +6 .. 8 % on the head's 3x3 256 -> 256 launches (profiles/r3_conv_ksplit.txt), taken when it fills a round
+    if (a.Co % 256 == 0 && a.C % 4 == 0 && blocks(64, 256) >= 512) cfg = 5;
     if ((force == 1 || force == 2) && a.Co > 64) cfg = force;   // (the weight image is padded for the natural width only)
-    const int nb = cfg == 1 ? blocks(128, 128) : cfg == 2 ? blocks(64, 128) : cfg == 3 ? blocks(128, 64) : blocks(128, 32);
+    if (force == 5 && a.Co % 256 == 0 && a.C % 4 == 0) cfg = 5;
+    const int nb = cfg == 1 ? blocks(128, 128) : cfg == 2 ? blocks(64, 128) : cfg == 3 ? blocks(128, 64)
+                 : cfg == 5 ? blocks(64, 256) : blocks(128, 32);
     const int Tall = a.kh * a.kw * cv_ncc(a.C);
     int ks = 1;
     if (a.nlv == 1 && !a.ostep && nb <= 320 && Tall >= 16) {
@@ -131,6 +136,7 @@ static int conv_forward(ConvArgs &a, hipStream_t st)
     case 1: return launch_conv<2, 2, 2, 2>(a, ks, st);
     case 2: return launch_conv<1, 2, 2, 2>(a, ks, st);
     case 3: return launch_conv<1, 2, 4, 1>(a, ks, st);
+    case 5: return launch_conv<2, 2, 1, 4>(a, ks, st);
     default: return launch_conv<1, 1, 4, 1>(a, ks, st);
     }
 }

@@ -243,34 +243,43 @@ __global__ __launch_bounds__(256, 2) void conv_mm_kernel(const ConvArgs a)
         }
     };
     float4 xv[NLD];
-    auto issue_x = [&](const Ck &c, bool live) {   // !live: past the last chunk, no memory access
-        const int tap = c.i * a.kw + c.j;
-        const int toff = ((c.i * a.dil * L.W + c.j * a.dil) * a.xpitch + c.cc * BK) * 4;
-        const bool cok = live && c.cc * BK + 4 * c4 < a.C;
-#pragma unroll
-        for (int ps = 0; ps < NLD; ++ps) {
-            const bool ok = ((vmask[ps] >> tap) & 1ull) != 0 && cok;
-            if constexpr (!UNAL) {
-                xv[ps] = cv_load4(xrs, ok ? pbase[ps] + toff : OOB, 0);
-            } else {
-                const int c0 = c.cc * BK + 4 * c4, vo = pbase[ps] + toff;
-                xv[ps].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, ok ? vo : OOB, 0, 0));
-                xv[ps].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, ok && c0 + 1 < a.C ? vo + 4 : OOB, 0, 0));
-                xv[ps].z = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, ok && c0 + 2 < a.C ? vo + 8 : OOB, 0, 0));
-                xv[ps].w = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, ok && c0 + 3 < a.C ? vo + 12 : OOB, 0, 0));
-            }
+    int sx_c0 = 0;
+    int sx_tap = 0, sx_toff = 0;   // chunk under issue (scalars shared by its load slices)
+    bool sx_cok = false;
+    auto open_x = [&](const Ck &c, bool live) {   // !live: past the last chunk, no memory access
+        sx_tap = c.i * a.kw + c.j;
+        sx_toff = ((c.i * a.dil * L.W + c.j * a.dil) * a.xpitch + c.cc * BK) * 4;
+        sx_cok = live && c.cc * BK + 4 * c4 < a.C;
+        sx_c0 = c.cc * BK + 4 * c4;
+    };
+    auto issue_slice = [&](int ps) {
+        const bool ok = ((vmask[ps] >> sx_tap) & 1ull) != 0 && sx_cok;
+        if constexpr (!UNAL) {
+            xv[ps] = cv_load4(xrs, ok ? pbase[ps] + sx_toff : OOB, 0);
+        } else {
+            const int c0 = sx_c0, vo = pbase[ps] + sx_toff;
+            xv[ps].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, ok ? vo : OOB, 0, 0));
+            xv[ps].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, ok && c0 + 1 < a.C ? vo + 4 : OOB, 0, 0));
+            xv[ps].z = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, ok && c0 + 2 < a.C ? vo + 8 : OOB, 0, 0));
+            xv[ps].w = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, ok && c0 + 3 < a.C ? vo + 12 : OOB, 0, 0));
         }
+    };
+    auto commit_slice = [&](int ps, unsigned char *buf) {
+        unsigned p0[NPL], p1[NPL];
+        split_planes<NPL>(xv[ps].x, xv[ps].y, p0);
+        split_planes<NPL>(xv[ps].z, xv[ps].w, p1);
+        unsigned char *p = buf + ps * 32 * 64 + st_off;
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) *reinterpret_cast<uint2 *>(p + q * PLANE) = make_uint2(p0[q], p1[q]);
+    };
+    auto issue_x = [&](const Ck &c, bool live) {
+        open_x(c, live);
+#pragma unroll
+        for (int ps = 0; ps < NLD; ++ps) issue_slice(ps);
     };
     auto commit_x = [&](unsigned char *buf) {
 #pragma unroll
-        for (int ps = 0; ps < NLD; ++ps) {
-            unsigned p0[NPL], p1[NPL];
-            split_planes<NPL>(xv[ps].x, xv[ps].y, p0);
-            split_planes<NPL>(xv[ps].z, xv[ps].w, p1);
-            unsigned char *p = buf + ps * 32 * 64 + st_off;
-#pragma unroll
-            for (int q = 0; q < NPL; ++q) *reinterpret_cast<uint2 *>(p + q * PLANE) = make_uint2(p0[q], p1[q]);
-        }
+        for (int ps = 0; ps < NLD; ++ps) commit_slice(ps, buf);
     };
 
     // ---- weight operand: fragments straight from L2.  Byte offset of (chunk t, tile nt, k-step ks, plane q):
@@ -350,15 +359,42 @@ __global__ __launch_bounds__(256, 2) void conv_mm_kernel(const ConvArgs a)
     for (int t = 0; t < T; ++t) {
         const unsigned char *bc = smem + (t & 1) * BUF;
         unsigned char *bn = smem + ((t & 1) ^ 1) * BUF;
+#ifdef LSNET_CONV_NO_ILV   // diagnostic build: staging in front of the MFMAs instead of between them
         read_x(bc, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (t + 1 < T) commit_x(bn);   // registers hold the raw pixels of chunk t + 1
+        if (t + 1 < T) commit_x(bn);
         if (t + 2 < T) next(c1);
         issue_x(c1, t + 2 < T);
         __builtin_amdgcn_sched_barrier(0);
         read_x(bc, 1);
-        __builtin_amdgcn_sched_barrier(0);
         mfma_block(0);
+        issue_w(t + 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_block(1);
+        issue_w(t + 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        continue;
+#endif
+        read_x(bc, 0);
+        read_x(bc, 1);
+        if (t + 2 < T) next(c1);
+        open_x(c1, t + 2 < T);
+        __builtin_amdgcn_sched_barrier(0);
+        // k-step 0 in NLD parts; behind each part one staging slice: split 32 pixels of chunk t + 1 into the other LDS
+        // buffer, then fetch the same rows of chunk t + 2 into the freed registers -- the split's VALU work runs in the
+        // shadow of this wave's own MFMAs instead of in front of them
+        constexpr int NM = NP * TN * TM;
+#pragma unroll
+        for (int ps = 0; ps < NLD; ++ps) {
+#pragma unroll
+            for (int m = ps * NM / NLD; m < (ps + 1) * NM / NLD; ++m) {
+                const int prod = m / (TN * TM), j = (m / TM) % TN, i = m % TM;
+                acc[j][i] = mfma_bf16(Wf[0][j][SC::pb(prod)], Xf[0][i][SC::pa(prod)], acc[j][i]);
+            }
+            if (t + 1 < T) commit_slice(ps, bn);   // registers hold the raw pixels of chunk t + 1
+            issue_slice(ps);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         issue_w(t + 1, 0);
         __builtin_amdgcn_sched_barrier(0);
         mfma_block(1);

@@ -394,7 +394,11 @@ struct GatherPlan {
     int nsamples = 0, nanchors = 0;
     size_t scan_tmp = 0;
     size_t o_gcol = 0, o_cnt = 0, o_start = 0, o_anchor = 0, o_rank = 0, o_frac = 0, o_ent = 0, o_tmp = 0, o_gtap = 0, bytes = 0;
-    GatherArgs ga;
+    size_t o_S = 0;
+    GatherArgs ga;        // groups gathered per 4x4 pixel block
+    AnchorArgs aa;        // groups with long lists: gathered per anchor (dcn_anchor_sum / combine)
+    int anchor_pixels = 0;
+    int64_t block_samples = 0;   // samples (upper bound) of the block-gathered groups
 };
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -408,6 +412,7 @@ static void gather_plan(DcnArgs &a, GatherPlan &pl)
     GatherArgs &ga = pl.ga;
     ga.ng = 0;
     bool any = false;
+    int64_t gsamp[MAXLV] = {};   // samples (upper bound: every tap valid) that scatter into each group
     for (int i = 0; i < a.nlv; ++i) {
         Lvl &L = a.lv[i];
         L.prow0 = (int)prow;
@@ -429,14 +434,46 @@ static void gather_plan(DcnArgs &a, GatherPlan &pl)
             return;   // one buffer, two shapes: not a valid call for this path
         }
         L.abase = ga.g[gi].abase;
+        gsamp[gi] += (int64_t)L.P * KD;
     }
     if (!any) return;
     if (prow * KD >= ((int64_t)1 << 30) || anchors >= ((int64_t)1 << 30) || Q >= ((int64_t)1 << 30)) return;
     if (a.C % 4 != 0 || (a.C / a.dg) % 4 != 0) return;
     pl.nsamples = (int)(prow * KD);
     pl.nanchors = (int)anchors;
+    // Groups with more than ~400 samples per 4x4 pixel block go to the per-anchor gather (the pyramid op's coarse source
+    // levels); the others keep the block walk.  LSNET_GATHER_ANCHOR=0 keeps every group on the block walk (A/B runs).
+    static const int anchor_thr = [] { const char *e = getenv("LSNET_GATHER_ANCHOR"); return e ? atoi(e) : 400; }();
+    AnchorArgs &aa = pl.aa;
+    aa.ng = 0, aa.NA = 0;
+    pl.anchor_pixels = 0, pl.block_samples = 0;
+    {
+        GatherGrp keep[MAXLV];
+        int nk = 0;
+        int64_t q = 0;
+        for (int j = 0; j < ga.ng; ++j) {
+            const GatherGrp &G = ga.g[j];
+            const int64_t nblk = (int64_t)G.B * cdiv(G.H, GT) * cdiv(G.W, GT);
+            if (anchor_thr > 0 && gsamp[j] > (int64_t)anchor_thr * nblk) {
+                AnchorGrp &A = aa.g[aa.ng++];
+                A.gx = G.gx, A.B = G.B, A.H = G.H, A.W = G.W, A.abase = G.abase, A.a0 = aa.NA;
+                aa.NA += G.B * (G.H + 1) * (G.W + 1);
+                pl.anchor_pixels += G.B * G.H * G.W;
+            } else {
+                keep[nk] = G;
+                keep[nk].blk0 = (int)q;
+                q += nblk;
+                pl.block_samples += gsamp[j];
+                ++nk;
+            }
+        }
+        for (int j = 0; j < nk; ++j) ga.g[j] = keep[j];
+        ga.ng = nk;
+        Q = q;
+    }
     ga.NB = (int)Q;
     ga.C = a.C, ga.K = K, ga.KD = KD, ga.dg = a.dg;
+    aa.C = a.C, aa.K = K, aa.KD = KD, aa.dg = a.dg;
     size_t tmp = 0;
     if (rocprim::exclusive_scan((void *)nullptr, tmp, (int *)nullptr, (int *)nullptr, 0, (size_t)pl.nanchors + 1,
                                 rocprim::plus<int>(), (hipStream_t)0) != hipSuccess)
@@ -452,6 +489,7 @@ static void gather_plan(DcnArgs &a, GatherPlan &pl)
     pl.o_ent = o, o = align256(o + (size_t)pl.nsamples * sizeof(GEntry));
     pl.o_tmp = o, o = align256(o + tmp + 256);
     pl.o_gtap = o, o = align256(o + ((size_t)pl.nsamples + 1) * sizeof(Tap));   // + the all-zero entry
+    pl.o_S = o, o = align256(o + (size_t)pl.aa.NA * 4 * a.C * sizeof(float));
     pl.bytes = o;
     pl.ok = true;
 }
@@ -508,13 +546,21 @@ static int launch_bwd_colbuf(DcnArgs &a, GatherPlan &pl, unsigned char *ws, hipS
     if (int rc = set_lds(dcn_bwd_data_xn_kernel<NP, true>, lds)) return rc;
     hipLaunchKernelGGL((dcn_bwd_data_xn_kernel<NP, true>), dim3(a.ntiles, bwd_tap_groups(a)), dim3(256), lds, st, a);
     pl.ga.gcol = a.gcol, pl.ga.start = start, pl.ga.ent = ent;
-    // long lists (the pyramid launch: three target levels scatter into every source level): four waves per pixel block
-    static const int force_nw = [] { const char *e = getenv("LSNET_GATHER_NW"); return e ? atoi(e) : 0; }();
-    const bool split = force_nw ? force_nw == 4 : (int64_t)pl.nsamples > (int64_t)300 * pl.ga.NB;
-    if (split)
-        hipLaunchKernelGGL(dcn_gather_kernel<4>, dim3(pl.ga.NB), dim3(256), 0, st, pl.ga);
-    else
-        hipLaunchKernelGGL(dcn_gather_kernel<1>, dim3(cdiv(pl.ga.NB, 4)), dim3(256), 0, st, pl.ga);
+    if (pl.aa.ng > 0) {   // long-list groups: per-anchor sums, then four of them per pixel
+        pl.aa.gcol = a.gcol, pl.aa.start = start, pl.aa.ent = ent;
+        pl.aa.S = reinterpret_cast<float *>(ws + pl.o_S);
+        hipLaunchKernelGGL(dcn_anchor_sum_kernel, dim3(pl.aa.NA), dim3(256), 0, st, pl.aa);
+        hipLaunchKernelGGL(dcn_anchor_combine_kernel, dim3(cdiv(pl.anchor_pixels, 4)), dim3(256), 0, st, pl.aa, pl.anchor_pixels);
+    }
+    if (pl.ga.NB > 0) {
+        // medium lists: four waves per pixel block; short ones (the tower launch, ~140 entries per block): one
+        static const int force_nw = [] { const char *e = getenv("LSNET_GATHER_NW"); return e ? atoi(e) : 0; }();
+        const bool split = force_nw ? force_nw == 4 : pl.block_samples > (int64_t)300 * pl.ga.NB;
+        if (split)
+            hipLaunchKernelGGL(dcn_gather_kernel<4>, dim3(pl.ga.NB), dim3(256), 0, st, pl.ga);
+        else
+            hipLaunchKernelGGL(dcn_gather_kernel<1>, dim3(cdiv(pl.ga.NB, 4)), dim3(256), 0, st, pl.ga);
+    }
     LSN_HIP(hipGetLastError());
     return 0;
 }

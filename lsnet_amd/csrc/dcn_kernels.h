@@ -1640,6 +1640,30 @@ struct GatherArgs {
     const GEntry *ent;
 };
 
+// Groups whose lists are LONG (the pyramid op: source level P5 receives the samples of target levels P3 .. P7, 2600 per
+// 4x4 pixel block) are gathered per ANCHOR instead of per pixel block: a map of 25 x 42 pixels has 154 blocks but 2236
+// anchors -- 14 x the workgroups walking lists that are as many times shorter.
+//   dcn_anchor_sum_kernel     one workgroup per anchor: S[anchor][dy][dx][C] = sum over the anchor's entries of the
+//                             bilinear corner weight x the entry's column-gradient row (four waves share the list and
+//                             meet in LDS in a fixed order);
+//   dcn_anchor_combine_kernel grad_input[y][x] = S[y-1][x-1][1][1] + S[y-1][x][1][0] + S[y][x-1][0][1] + S[y][x][0][0]
+//                             (anchor coordinates shifted by one as in the lists): each element written once.
+struct AnchorGrp {
+    float *gx;
+    int B, H, W;
+    int abase;   // first anchor id in the launch-wide numbering (lists)
+    int a0;      // first anchor of this group in the S buffer
+};
+struct AnchorArgs {
+    AnchorGrp g[MAXLV];
+    int ng, NA;         // groups, anchors of all of them
+    int C, K, KD, dg;
+    const float *gcol;
+    const int *start;
+    const GEntry *ent;
+    float *S;           // [NA][4][C]
+};
+
 __device__ __forceinline__ const Lvl &find_level_by_row(const DcnArgs &a, int prow)
 {
     int li = 0;
@@ -1761,7 +1785,10 @@ __global__ __launch_bounds__(256) void dcn_gather_kernel(const GatherArgs ga)
     const int wave = NW == 4 ? wave_id : 0;   // position among the waves that share a pixel block
     const int C = ga.C, K = ga.K, KD = ga.KD;
     const int cpdg = C / ga.dg;
-    const int bi = NW == 4 ? xcd_remap(blockIdx.x, gridDim.x) : xcd_remap(blockIdx.x, gridDim.x) * 4 + wave_id;
+    // NW = 4 walks the blocks LAST GROUP FIRST: in the pyramid launch the coarse source levels (P5 .. P7) have a few dozen
+    // blocks with thousands of entries each -- a chain of dependent row reads hundreds of microseconds long.  Started last
+    // they are the launch's tail; started first the thousands of short fine-level blocks fill in behind them.
+    const int bi = NW == 4 ? ga.NB - 1 - xcd_remap(blockIdx.x, gridDim.x) : xcd_remap(blockIdx.x, gridDim.x) * 4 + wave_id;
     if (bi >= ga.NB) return;
     int gi = 0;
     while (gi + 1 < ga.ng && bi >= ga.g[gi + 1].blk0) ++gi;
@@ -1866,6 +1893,122 @@ __global__ __launch_bounds__(256) void dcn_gather_kernel(const GatherArgs ga)
                         *reinterpret_cast<float4 *>(G.gx + ((size_t)(b * G.H + y0 + i) * G.W + x0 + j) * C + c) = acc[i][j];
         }
         if constexpr (NW == 4) __syncthreads();   // red is reused by the next channel block
+    }
+}
+
+__global__ __launch_bounds__(256) void dcn_anchor_sum_kernel(const AnchorArgs ga)
+{
+    constexpr int GU = 4;
+    __shared__ float4 red[2][4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int C = ga.C, K = ga.K, KD = ga.KD, cpdg = C / ga.dg;
+    const int ai = xcd_remap(blockIdx.x, gridDim.x);
+    int gi = 0;
+    while (gi + 1 < ga.ng && ai >= ga.g[gi + 1].a0) ++gi;
+    const AnchorGrp &G = ga.g[gi];
+    const int an = G.abase + (ai - G.a0);
+    const int lb = ga.start[an], le = ga.start[an + 1];
+    for (int cb = 0; cb < C; cb += 256) {
+        const int c = cb + lane * 4;
+        float4 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int base = lb; base < le; base += 64) {
+            const int n = min(64, le - base);
+            GEntry e = {};
+            if (lane < n) e = ga.ent[base + lane];
+            for (int j0 = wave * GU; j0 < n; j0 += 4 * GU) {   // wave w: groups w, w + 4, ... of GU entries
+                float4 v[GU];
+                float ly[GU], lx[GU];
+#pragma unroll
+                for (int u = 0; u < GU; ++u) {
+                    const int j = min(j0 + u, n - 1);
+                    const int s = __builtin_amdgcn_readlane(e.s, j);
+                    ly[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e.ly), j));
+                    lx[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e.lx), j));
+                    int row = s, c_lo = 0, c_hi = C;
+                    if (ga.dg > 1) {
+                        const int prow = s / KD, kd = s - prow * KD;
+                        const int dgi = kd / K;
+                        row = prow * K + (kd - dgi * K);
+                        c_lo = dgi * cpdg, c_hi = c_lo + cpdg;
+                    }
+                    const bool on = (j0 + u < n) && c < c_hi && c >= c_lo;
+                    v[u] = *reinterpret_cast<const float4 *>(ga.gcol + (size_t)row * C + (c < C ? c : 0));
+                    if (!on) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < GU; ++u) {
+                    const float hy = 1.f - ly[u], hx = 1.f - lx[u];
+#pragma unroll
+                    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                        for (int dx = 0; dx < 2; ++dx) {
+                            const float w = (dy ? ly[u] : hy) * (dx ? lx[u] : hx);
+                            acc[dy][dx].x += w * v[u].x, acc[dy][dx].y += w * v[u].y;
+                            acc[dy][dx].z += w * v[u].z, acc[dy][dx].w += w * v[u].w;
+                        }
+                }
+            }
+        }
+        // (w0 + w2) + (w1 + w3): fixed order
+        auto put = [&](int slot) __attribute__((always_inline)) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) red[slot][q][lane] = acc[q >> 1][q & 1];
+        };
+        auto add = [&](int slot) __attribute__((always_inline)) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 r = red[slot][q][lane];
+                acc[q >> 1][q & 1].x += r.x, acc[q >> 1][q & 1].y += r.y, acc[q >> 1][q & 1].z += r.z, acc[q >> 1][q & 1].w += r.w;
+            }
+        };
+        if (wave >= 2) put(wave - 2);
+        __syncthreads();
+        if (wave < 2) add(wave);
+        __syncthreads();
+        if (wave == 1) put(0);
+        __syncthreads();
+        if (wave == 0) {
+            add(0);
+            if (c < C) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4 *>(ga.S + ((size_t)ai * 4 + q) * C + c) = acc[q >> 1][q & 1];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// one wave per pixel of a long-list group
+__global__ __launch_bounds__(256) void dcn_anchor_combine_kernel(const AnchorArgs ga, int npix)
+{
+    const int lane = threadIdx.x & 63;
+    const int pi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pi >= npix) return;
+    int gi = 0, p0 = 0;
+    while (gi + 1 < ga.ng && pi >= p0 + ga.g[gi].B * ga.g[gi].H * ga.g[gi].W) p0 += ga.g[gi].B * ga.g[gi].H * ga.g[gi].W, ++gi;
+    const AnchorGrp &G = ga.g[gi];
+    const int lp = pi - p0;
+    const int b = lp / (G.H * G.W), rem = lp - b * G.H * G.W;
+    const int y = rem / G.W, x = rem - y * G.W;
+    // anchor (ay, ax) (= floor of a sample position, >= -1) lives at row ay + 1, column ax + 1 of the (H + 1) x (W + 1) grid;
+    // pixel (y, x) is corner (dy, dx) of anchor (y - dy, x - dx)
+    auto S = [&](int ay, int ax, int q) -> const float * {
+        return ga.S + ((size_t)(G.a0 + (b * (G.H + 1) + ay + 1) * (G.W + 1) + ax + 1) * 4 + q) * ga.C;
+    };
+    for (int c = lane * 4; c < ga.C; c += 256) {
+        const float4 s11 = *reinterpret_cast<const float4 *>(S(y - 1, x - 1, 3) + c);
+        const float4 s10 = *reinterpret_cast<const float4 *>(S(y - 1, x, 2) + c);
+        const float4 s01 = *reinterpret_cast<const float4 *>(S(y, x - 1, 1) + c);
+        const float4 s00 = *reinterpret_cast<const float4 *>(S(y, x, 0) + c);
+        float4 r;
+        r.x = ((s11.x + s10.x) + s01.x) + s00.x, r.y = ((s11.y + s10.y) + s01.y) + s00.y;
+        r.z = ((s11.z + s10.z) + s01.z) + s00.z, r.w = ((s11.w + s10.w) + s01.w) + s00.w;
+        *reinterpret_cast<float4 *>(G.gx + ((size_t)(b * G.H + y) * G.W + x) * ga.C + c) = r;
     }
 }
 

@@ -429,6 +429,9 @@ CONV_CASES = [
     (1, 32, 48, 5, 2, 2, 1, 19, 22, False),       # 5x5 stride 2: 3- and 2-tap residue classes
     (1, 16, 24, 3, 2, 2, 2, 21, 26, True),        # stride 2 with dilation 2 (one residue class per axis has all taps)
     (2, 3, 64, 7, 2, 3, 1, 64, 96, False),        # the ResNet stem WITH gradients (generic path on 4 padded channels)
+    (1, 256, 256, 1, 1, 0, 1, 184, 180, True),    # >= 512 tiles of 64 px x 256 channels: the 64x256 configuration
+    (2, 256, 27, 3, 1, 1, 1, 100, 168, True),     # conv_offset at the P3 size: its data gradient reduces over 27 channels
+                                                  # into 256 (unaligned slabs, which the 64x256 configuration lacks)
 ]
 
 
