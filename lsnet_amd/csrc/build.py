@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.path.join(HERE, 'liblsnet_hip.so')
 SOURCES = ['dcn.hip', 'misc.hip', 'norm.hip', 'conv.hip', 'gconv.hip', 'image.hip', 'loss.hip']
-HEADERS = ['common.h', 'dcn_kernels.h', 'conv_kernels.h', 'conv_wgrad_kernels.h', 'prof.h', 'cross_iou_row.h', os.path.join('..', '..', 'include', 'lsnet_hip.h')]
+HEADERS = ['common.h', 'dcn_kernels.h', 'conv_kernels.h', 'conv_wgrad_kernels.h', 'dcn_mm_kernels.h', 'prof.h', 'cross_iou_row.h', os.path.join('..', '..', 'include', 'lsnet_hip.h')]
 # -fno-slp-vectorize: hipcc (ROCm 7.2) packs adjacent scalar fp32 adds / fmas into v_pk_add_f32 / v_pk_fma_f32.  In the
 # backward-data kernels the HIGH dword of such packed accumulators came back wrong for the last 16 lanes of a wave in
 # 0.7 % of the cases, differently on every run, whenever two workgroups shared a CU (tools/dbg_goff.py on the MI355X:

@@ -141,6 +141,27 @@ static int conv_forward(ConvArgs &a, hipStream_t st)
     }
 }
 
+// dcn.hip: out_i[r][0 .. N) = x_i[r][0 .. Cr) . Wt for row blocks i (the backward-data GEMM of the deformable
+// convolutions: a 1x1 convolution of grad_output whose N = K * C output columns are the column gradients); wf = the
+// fragment image of the (N, 1, Cr) GEMM view.  No profiling span of its own: it runs inside the caller's.
+int conv_mm_rows(int n, const float *const *x, float *const *out, const int *rows, int Cr, int N, const unsigned short *wf,
+                 hipStream_t st)
+{
+    LSN_CHECK(n >= 1 && n <= CV_MAXLV && Cr % 4 == 0, "conv_mm_rows: bad arguments");
+    ConvArgs a = {};
+    a.nlv = n;
+    for (int i = 0; i < n; ++i) {
+        ConvLvl &L = a.lv[i];
+        L.x = x[i], L.out = out[i], L.res = nullptr;
+        L.B = 1, L.H = 1, L.W = rows[i], L.Ho = 1, L.Wo = rows[i], L.P = rows[i];
+    }
+    a.wf = wf;
+    a.wf_bytes = (int)cv_wfrag_bytes(N, 1, Cr, conv_npl());
+    a.C = Cr, a.Co = N, a.kh = a.kw = 1, a.stride = 1, a.pad_h = a.pad_w = 0, a.dil = 1;
+    a.xpitch = Cr;
+    return conv_forward(a, st);
+}
+
 static void conv_wfrag(const float *w, unsigned short *out, int Co, int K, int C, int flipT, const TapSub &ts, hipStream_t st)
 {
     const int Kd = flipT ? ts.ni * ts.nj : K;

@@ -27,7 +27,7 @@
 
 namespace lsn {
 
-constexpr int CV_MAXLV = 8;
+constexpr int CV_MAXLV = 16;   // (the pyramid deformable op batches 15 (level, source) pairs)
 
 // One input map of a batched launch: the FPN levels that share a convolution's weights (LSHead) go into ONE launch.
 struct ConvLvl {
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(256, 2) void conv_mm_kernel(const ConvArgs a)
 }
 
 // out[e] = sum_z part[z * n + e] + bias[e % Co] (ReLU): the second pass of a split reduction; n = P * Co
-__global__ void conv_splitk_reduce_kernel(const float *__restrict__ part, float *__restrict__ out,
+static __global__ void conv_splitk_reduce_kernel(const float *__restrict__ part, float *__restrict__ out,
                                           const float *__restrict__ bias, const float *__restrict__ res, int n, int Co,
                                           int ks, int relu)
 {

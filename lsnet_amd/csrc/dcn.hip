@@ -12,6 +12,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include "dcn_kernels.h"
+#include "dcn_mm_kernels.h"
 #include "prof.h"
 
 namespace lsn {
@@ -218,6 +219,8 @@ static int fill_levels(DcnArgs &a, const lsn_dcn_shape &s, int n, const lsn_dcn_
     a.gtap = nullptr;
     a.gtap_rows = 0;
     a.wg_vec = 0;
+    a.mm = 0;
+    a.wtp_bytes = 0;
     a.dbg = g_dbg_buf;
     a.dbg_block = g_dbg_block;
     a.w = a.bias = nullptr;
@@ -231,6 +234,88 @@ static bool vec_ok(const DcnArgs &a)
 {
     const int Cg = a.C / a.groups, Cog = a.Co / a.groups;
     return (Cg % 4 == 0) && (Cog % 4 == 0) && (a.Co % 4 == 0) && (a.SL % 4 == 0);
+}
+
+// ---- the kernels of dcn_mm_kernels.h (dense-convolution skeleton): conditions, weight image, launches ----
+static bool dcn_mm_env()
+{
+    static const int v = [] { const char *e = getenv("LSNET_DCN_MM"); return e ? atoi(e) : 1; }();
+    if ((g_dbg_block >> 28) & 1) return false;   // bit 28 of the debug word: the kernels of dcn_kernels.h only (tests)
+    return v != 0;   // LSNET_DCN_MM=0: likewise (A/B runs)
+}
+
+static bool mm_common_ok(const DcnArgs &a)
+{
+    if (math_np() == 0 || a.groups != 1 || a.dg < 1 || a.C % a.dg != 0 || !dcn_mm_env()) return false;
+    for (int i = 0; i < a.nlv; ++i) {   // 32-bit buffer offsets
+        if ((int64_t)a.lv[i].B * a.lv[i].H * a.lv[i].W * a.C * 4 >= ((int64_t)1 << 31)) return false;
+        if ((int64_t)a.lv[i].P * a.Co * 4 >= ((int64_t)1 << 31)) return false;
+    }
+    return true;
+}
+
+static int mm_npl() { return math_np() == 6 ? 3 : 2; }
+
+static bool mm_fwd_ok(const DcnArgs &a)
+{
+    if (!mm_common_ok(a) || (a.C / a.dg) % 32 != 0 || a.Co % 128 != 0) return false;
+    if (dcn_fwd_mm_lds_bytes(mm_npl(), a.kh * a.kw * a.dg) > 80 * 1024) return false;
+    return cv_wfrag_bytes(a.Co, a.kh * a.kw, a.C, mm_npl()) < ((size_t)1 << 31);
+}
+
+// backward-data GEMM as a 1x1 convolution (conv.hip conv_mm_rows) + corner sums in the gather pass: every level that
+// wants offset / mask gradients must also want grad_input (its samples are then on the anchor lists); the fragment image
+// has to fit the caller's weight workspace (8 bytes per weight element, include/lsnet_hip.h)
+int conv_mm_rows(int n, const float *const *x, float *const *out, const int *rows, int Cr, int N, const unsigned short *wf,
+                 hipStream_t st);
+static bool mm_bwd_ok(const DcnArgs &a)
+{
+    if (!mm_common_ok(a) || a.C % 4 != 0 || a.Co % 4 != 0) return false;
+    for (int i = 0; i < a.nlv; ++i)
+        if ((a.lv[i].goff || a.lv[i].gmsk) && !a.lv[i].gx) return false;
+    const size_t wb = cv_wfrag_bytes(a.kh * a.kw * a.C, 1, a.Co, mm_npl());
+    return wb < ((size_t)1 << 31) && wb <= (size_t)8 * a.Co * a.kh * a.kw * a.C;
+}
+
+// weight image in fragment order into `dst` (forward: (Co, K, C) as it lies; backward: the transposed 1x1 view with
+// N = K * C columns and the reduction over Co)
+static int mm_prepare_weights(DcnArgs &a, bool backward, void *dst, hipStream_t st)
+{
+    const int K = a.kh * a.kw;
+    const int Co = backward ? K * a.C : a.Co, Kd = backward ? 1 : K, C = backward ? a.Co : a.C;
+    TapSub ts = {0, 1, 1, 0, 1, 1, 1};
+    const long long total = (long long)Kd * cv_ncc(C) * cv_nt(Co) * 2 * 64;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    unsigned short *out = reinterpret_cast<unsigned short *>(dst);
+    if (mm_npl() == 3)
+        hipLaunchKernelGGL(conv_wfrag_kernel<3>, dim3(blocks), dim3(256), 0, st, a.w, out, Co, Kd, C, backward ? 1 : 0, ts);
+    else
+        hipLaunchKernelGGL(conv_wfrag_kernel<2>, dim3(blocks), dim3(256), 0, st, a.w, out, Co, Kd, C, backward ? 1 : 0, ts);
+    LSN_HIP(hipGetLastError());
+    a.wtp = out;
+    a.wtp_bytes = (int)cv_wfrag_bytes(Co, Kd, C, mm_npl());
+    a.mm = 1;
+    return 0;
+}
+
+template <int TM, int TN, int WM, int WN, int NP>
+static int launch_fwd_mm_cfg(const DcnArgs &a, hipStream_t st)
+{
+    auto k = dcn_fwd_mm_kernel<TM, TN, WM, WN, NP>;
+    const size_t lds = dcn_fwd_mm_lds_bytes(SplitCfg<NP>::NPL, a.kh * a.kw * a.dg);
+    if (int rc = set_lds(k, lds)) return rc;
+    const int blocks = a.ntiles * (a.Co / (WN * TN * 32));
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(256), lds, st, a, a.wtp, a.wtp_bytes);
+    LSN_HIP(hipGetLastError());
+    return 0;
+}
+
+static int launch_forward_mm(const DcnArgs &a, hipStream_t st)
+{
+    ProfScope prof(PROF_FWD, a, st);
+    const bool wide = a.Co % 256 == 0;
+    if (math_np() == 6) return wide ? launch_fwd_mm_cfg<2, 2, 1, 4, 6>(a, st) : launch_fwd_mm_cfg<1, 2, 2, 2, 6>(a, st);
+    return wide ? launch_fwd_mm_cfg<2, 2, 1, 4, 3>(a, st) : launch_fwd_mm_cfg<1, 2, 2, 2, 3>(a, st);
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -269,6 +354,7 @@ static bool pipe_ok(const DcnArgs &a)
 
 static int launch_forward(const DcnArgs &a, hipStream_t st)
 {
+    if (a.mm) return launch_forward_mm(a, st);
     if (a.Co / a.groups <= 64 || !pipe_ok(a)) {
         ProfScope prof(PROF_FWD, a, st);
         return (a.Co / a.groups <= 64) ? launch_forward_t<64, 64, 2, 2>(a, st) : launch_forward_t<64, 256, 1, 4>(a, st);
@@ -326,9 +412,11 @@ static int launch_bwd_data_t(const DcnArgs &a, hipStream_t st)
 static bool bwd_x3_ok(const DcnArgs &a)
 {
     if (math_np() == 0 || a.wtp == nullptr || a.groups != 1) return false;
-    if (a.Co > 256 || a.Co % 8 != 0 || a.C % 4 != 0) return false;
+    const bool mm = mm_bwd_ok(a);   // (its GEMM has no limit on the reduction length Co)
+    if (!mm && a.Co > 256) return false;
+    if ((!mm && a.Co % 8 != 0) || a.C % 4 != 0) return false;
     if ((int64_t)a.kh * a.kw * a.C * a.Co * 6 >= ((int64_t)1 << 31)) return false;
-    if (bwd_xn_lds_bytes(math_np(), a.kh * a.kw * a.dg) > 80 * 1024) return false;
+    if (!mm && bwd_xn_lds_bytes(math_np(), a.kh * a.kw * a.dg) > 80 * 1024) return false;
     for (int i = 0; i < a.nlv; ++i) {   // 32-bit buffer offsets into the input and the level's column-gradient rows
         if ((int64_t)a.lv[i].B * a.lv[i].H * a.lv[i].W * a.C * 4 >= ((int64_t)1 << 31)) return false;
         if ((int64_t)a.lv[i].P * a.kh * a.kw * a.C * 4 >= ((int64_t)1 << 31)) return false;
@@ -394,10 +482,11 @@ struct GatherPlan {
     int nsamples = 0, nanchors = 0;
     size_t scan_tmp = 0;
     size_t o_gcol = 0, o_cnt = 0, o_start = 0, o_anchor = 0, o_rank = 0, o_frac = 0, o_ent = 0, o_tmp = 0, o_gtap = 0, bytes = 0;
-    size_t o_S = 0;
+    size_t o_S = 0, o_H = 0;
     GatherArgs ga;        // groups gathered per 4x4 pixel block
     AnchorArgs aa;        // groups with long lists: gathered per anchor (dcn_anchor_sum / combine)
     int anchor_pixels = 0;
+    int na_long = 0;             // the first na_long anchors of the S buffer belong to long-list groups (4 waves each)
     int64_t block_samples = 0;   // samples (upper bound) of the block-gathered groups
 };
 
@@ -426,7 +515,7 @@ static void gather_plan(DcnArgs &a, GatherPlan &pl)
         if (gi < 0) {
             gi = ga.ng++;
             GatherGrp &G = ga.g[gi];
-            G.gx = L.gx, G.B = L.B, G.H = L.H, G.W = L.W;
+            G.gx = L.gx, G.x = L.x, G.B = L.B, G.H = L.H, G.W = L.W;
             G.abase = (int)anchors, G.blk0 = (int)Q;
             anchors += (int64_t)L.B * (L.H + 1) * (L.W + 1);
             Q += (int64_t)L.B * cdiv(L.H, GT) * cdiv(L.W, GT);
@@ -448,24 +537,39 @@ static void gather_plan(DcnArgs &a, GatherPlan &pl)
     aa.ng = 0, aa.NA = 0;
     pl.anchor_pixels = 0, pl.block_samples = 0;
     {
+        // anchor path: every group when the unweighted-GEMM pipeline serves the call (its corner sums are cheapest per
+        // anchor), otherwise the groups above the threshold.  Long-list groups first: they get four waves per anchor.
+        const bool all_anchor = mm_bwd_ok(a);
         GatherGrp keep[MAXLV];
+        bool to_anchor[MAXLV], is_long[MAXLV];
         int nk = 0;
         int64_t q = 0;
         for (int j = 0; j < ga.ng; ++j) {
             const GatherGrp &G = ga.g[j];
             const int64_t nblk = (int64_t)G.B * cdiv(G.H, GT) * cdiv(G.W, GT);
-            if (anchor_thr > 0 && gsamp[j] > (int64_t)anchor_thr * nblk) {
+            const int64_t nanch = (int64_t)G.B * (G.H + 1) * (G.W + 1);
+            to_anchor[j] = all_anchor || (anchor_thr > 0 && gsamp[j] > (int64_t)anchor_thr * nblk);
+            is_long[j] = !all_anchor || gsamp[j] > 40 * nanch;
+        }
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int j = 0; j < ga.ng; ++j) {
+                const GatherGrp &G = ga.g[j];
+                if (!to_anchor[j] || is_long[j] != (pass == 0)) continue;
                 AnchorGrp &A = aa.g[aa.ng++];
-                A.gx = G.gx, A.B = G.B, A.H = G.H, A.W = G.W, A.abase = G.abase, A.a0 = aa.NA;
+                A.gx = G.gx, A.x = G.x, A.B = G.B, A.H = G.H, A.W = G.W, A.abase = G.abase, A.a0 = aa.NA;
                 aa.NA += G.B * (G.H + 1) * (G.W + 1);
                 pl.anchor_pixels += G.B * G.H * G.W;
-            } else {
-                keep[nk] = G;
-                keep[nk].blk0 = (int)q;
-                q += nblk;
-                pl.block_samples += gsamp[j];
-                ++nk;
             }
+            if (pass == 0) pl.na_long = aa.NA;
+        }
+        for (int j = 0; j < ga.ng; ++j) {
+            if (to_anchor[j]) continue;
+            const GatherGrp &G = ga.g[j];
+            keep[nk] = G;
+            keep[nk].blk0 = (int)q;
+            q += (int64_t)G.B * cdiv(G.H, GT) * cdiv(G.W, GT);
+            pl.block_samples += gsamp[j];
+            ++nk;
         }
         for (int j = 0; j < nk; ++j) ga.g[j] = keep[j];
         ga.ng = nk;
@@ -490,6 +594,7 @@ static void gather_plan(DcnArgs &a, GatherPlan &pl)
     pl.o_tmp = o, o = align256(o + tmp + 256);
     pl.o_gtap = o, o = align256(o + ((size_t)pl.nsamples + 1) * sizeof(Tap));   // + the all-zero entry
     pl.o_S = o, o = align256(o + (size_t)pl.aa.NA * 4 * a.C * sizeof(float));
+    pl.o_H = o, o = align256(o + (size_t)pl.nsamples * 4 * sizeof(float));   // corner sums (dcn_offgrad_kernel)
     pl.bytes = o;
     pl.ok = true;
 }
@@ -537,19 +642,41 @@ static int launch_bwd_colbuf(DcnArgs &a, GatherPlan &pl, unsigned char *ws, hipS
     size_t tmp = pl.scan_tmp;
     LSN_HIP(rocprim::exclusive_scan(ws + pl.o_tmp, tmp, cnt, start, 0, (size_t)pl.nanchors + 1, rocprim::plus<int>(), st));
     hipLaunchKernelGGL(dcn_fill_kernel, dim3(cdiv(pl.nsamples, 256)), dim3(256), 0, st, pl.nsamples, start, sanchor,
-                       srank, sfrac, ent);
+                       srank, sfrac, ent, gtap, a.kh * a.kw * a.dg, a.gtap_rows);
     int sort_blocks = cdiv(pl.nanchors, 4);
     if (sort_blocks > 4096) sort_blocks = 4096;
     hipLaunchKernelGGL(dcn_sort_lists_kernel, dim3(sort_blocks), dim3(256), 0, st, pl.nanchors, start, ent);
-    size_t lds = bwd_xn_lds_bytes(NP, a.kh * a.kw * a.dg);
-    if ((g_dbg_block >> 22) & 1) lds = 100 * 1024;   // diagnostic: one workgroup per CU
-    if (int rc = set_lds(dcn_bwd_data_xn_kernel<NP, true>, lds)) return rc;
-    hipLaunchKernelGGL((dcn_bwd_data_xn_kernel<NP, true>), dim3(a.ntiles, bwd_tap_groups(a)), dim3(256), lds, st, a);
+    float *Hb = nullptr;
+    if (a.mm) {   // the dense kernel writes the unweighted column gradients; everything else happens in the gather pass
+        const float *xs[MAXLV];
+        float *outs[MAXLV];
+        int rows[MAXLV];
+        bool any_off = false;
+        for (int i = 0; i < a.nlv; ++i) {
+            xs[i] = a.lv[i].gout;
+            outs[i] = a.gcol + (size_t)a.lv[i].prow0 * a.kh * a.kw * a.C;
+            rows[i] = a.lv[i].P;
+            any_off = any_off || a.lv[i].goff || a.lv[i].gmsk;
+        }
+        if (int rc = conv_mm_rows(a.nlv, xs, outs, rows, a.Co, a.kh * a.kw * a.C, a.wtp, st)) return rc;
+        if (any_off) Hb = reinterpret_cast<float *>(ws + pl.o_H);
+    } else {
+        size_t lds = bwd_xn_lds_bytes(NP, a.kh * a.kw * a.dg);
+        if ((g_dbg_block >> 22) & 1) lds = 100 * 1024;   // diagnostic: one workgroup per CU
+        if (int rc = set_lds(dcn_bwd_data_xn_kernel<NP, true>, lds)) return rc;
+        hipLaunchKernelGGL((dcn_bwd_data_xn_kernel<NP, true>), dim3(a.ntiles, bwd_tap_groups(a)), dim3(256), lds, st, a);
+    }
+    pl.ga.raw = pl.aa.raw = a.mm ? 1 : 0;
+    pl.ga.Hb = pl.aa.Hb = Hb;
     pl.ga.gcol = a.gcol, pl.ga.start = start, pl.ga.ent = ent;
     if (pl.aa.ng > 0) {   // long-list groups: per-anchor sums, then four of them per pixel
         pl.aa.gcol = a.gcol, pl.aa.start = start, pl.aa.ent = ent;
         pl.aa.S = reinterpret_cast<float *>(ws + pl.o_S);
-        hipLaunchKernelGGL(dcn_anchor_sum_kernel, dim3(pl.aa.NA), dim3(256), 0, st, pl.aa);
+        if (pl.na_long > 0)
+            hipLaunchKernelGGL(dcn_anchor_sum_kernel<4>, dim3(pl.na_long), dim3(256), 0, st, pl.aa, 0, pl.na_long);
+        if (pl.aa.NA > pl.na_long)
+            hipLaunchKernelGGL(dcn_anchor_sum_kernel<1>, dim3(cdiv(pl.aa.NA - pl.na_long, 4)), dim3(256), 0, st, pl.aa,
+                               pl.na_long, pl.aa.NA - pl.na_long);
         hipLaunchKernelGGL(dcn_anchor_combine_kernel, dim3(cdiv(pl.anchor_pixels, 4)), dim3(256), 0, st, pl.aa, pl.anchor_pixels);
     }
     if (pl.ga.NB > 0) {
@@ -561,6 +688,9 @@ static int launch_bwd_colbuf(DcnArgs &a, GatherPlan &pl, unsigned char *ws, hipS
         else
             hipLaunchKernelGGL(dcn_gather_kernel<1>, dim3(cdiv(pl.ga.NB, 4)), dim3(256), 0, st, pl.ga);
     }
+    if (Hb)
+        hipLaunchKernelGGL(dcn_offgrad_kernel, dim3(cdiv(pl.nsamples, 256)), dim3(256), 0, st, a, pl.nsamples,
+                           reinterpret_cast<const float4 *>(Hb));
     LSN_HIP(hipGetLastError());
     return 0;
 }
@@ -577,11 +707,12 @@ static int launch_bwd_data(DcnArgs &a, void *gather_ws, size_t gather_ws_bytes, 
             return np == 6 ? launch_bwd_colbuf<6>(a, pl, reinterpret_cast<unsigned char *>(gather_ws), st)
                            : launch_bwd_colbuf<3>(a, pl, reinterpret_cast<unsigned char *>(gather_ws), st);
     }
+    if (a.mm) return fail(LSN_ERR_RUNTIME, "deformable backward: fragment-order weights without the gather path");
     a.gcol = nullptr, a.gtap = nullptr;
     for (int i = 0; i < a.nlv; ++i)   // the scatter kernels accumulate: start from zero (once per buffer is enough)
         if (a.lv[i].gx)
             LSN_HIP(hipMemsetAsync(a.lv[i].gx, 0, sizeof(float) * (size_t)a.lv[i].B * a.lv[i].H * a.lv[i].W * a.C, st));
-    if (bwd_x3_ok(a) && (np == 6 || !bwd_win_ok(a))) {
+    if (bwd_x3_ok(a) && a.Co <= 256 && (np == 6 || !bwd_win_ok(a))) {
         const size_t lds = bwd_xn_lds_bytes(np, a.kh * a.kw * a.dg);
         auto gox = [&](auto kern) -> int {
             if (int rc = set_lds(kern, lds)) return rc;
@@ -697,7 +828,9 @@ static int dcn_forward_impl(const lsn_dcn_shape &s, int n, const lsn_dcn_level *
     }
     a.bias = bias;
     a.wtp = nullptr;
-    if (s.workspace && math_np() && (Cg % 8 == 0) && a.Co / a.groups > 64 && pipe_ok(a)) {
+    if (s.workspace && mm_fwd_ok(a)) {
+        if (int rc = mm_prepare_weights(a, false, s.workspace, st)) return rc;
+    } else if (s.workspace && math_np() && (Cg % 8 == 0) && a.Co / a.groups > 64 && pipe_ok(a)) {
         const size_t nw = (size_t)s.Co * K * Cg;   // split the weights once instead of in every block
         if (math_np() == 6)
             hipLaunchKernelGGL(dcn_prepare_w_kernel<3>, dim3(512), dim3(256), 0, st, a.w,
@@ -769,15 +902,8 @@ static int dcn_backward_impl(const lsn_dcn_shape &s, int n, const lsn_dcn_level 
     if (any_data) {
         a.wtp = nullptr;
         a.gcol = nullptr;
-        if (s.workspace && math_np() && s.groups == 1 && s.Co % 2 == 0) {
-            if (math_np() == 6)
-                hipLaunchKernelGGL(dcn_prepare_wt_kernel<3>, dim3(512), dim3(256), 0, st, a.w,
-                                   reinterpret_cast<unsigned short *>(s.workspace), s.Co, K, s.C);
-            else
-                hipLaunchKernelGGL(dcn_prepare_wt_kernel<2>, dim3(512), dim3(256), 0, st, a.w,
-                                   reinterpret_cast<unsigned short *>(s.workspace), s.Co, K, s.C);
-            a.wtp = reinterpret_cast<const unsigned short *>(s.workspace);
-        }
+        const bool can_split = s.workspace && math_np() && s.groups == 1 && s.Co % 2 == 0;
+        if (can_split) a.wtp = reinterpret_cast<const unsigned short *>(s.workspace);   // (format: decided below)
         void *gws = s.gather_workspace;
         size_t gws_bytes = (size_t)(s.gather_workspace_bytes > 0 ? s.gather_workspace_bytes : 0);
         if (!gws && layout == LSN_NCHW && a.wtp && bwd_colbuf_env()) {   // reference-layout entry points: own scratch
@@ -785,6 +911,23 @@ static int dcn_backward_impl(const lsn_dcn_shape &s, int n, const lsn_dcn_level 
             DcnArgs probe = a;
             gather_plan(probe, pl);
             if (pl.ok && (gws = ws.get(pl.bytes / 4 + 64)) != nullptr) gws_bytes = pl.bytes;
+        }
+        bool mm = false;   // the GEMM of dcn_mm_kernels.h: only together with the gather pass
+        if (can_split && gws && bwd_colbuf_env() && mm_bwd_ok(a) && bwd_x3_ok(a)) {
+            GatherPlan pl;
+            DcnArgs probe = a;
+            gather_plan(probe, pl);
+            mm = pl.ok && pl.bytes <= gws_bytes;
+        }
+        if (mm) {
+            if (int rc = mm_prepare_weights(a, true, s.workspace, st)) return rc;
+        } else if (can_split) {
+            if (math_np() == 6)
+                hipLaunchKernelGGL(dcn_prepare_wt_kernel<3>, dim3(512), dim3(256), 0, st, a.w,
+                                   reinterpret_cast<unsigned short *>(s.workspace), s.Co, K, s.C);
+            else
+                hipLaunchKernelGGL(dcn_prepare_wt_kernel<2>, dim3(512), dim3(256), 0, st, a.w,
+                                   reinterpret_cast<unsigned short *>(s.workspace), s.Co, K, s.C);
         }
         if (int rc = launch_bwd_data(a, gws, gws_bytes, st)) return rc;
     }

@@ -70,6 +70,7 @@ DCN_CASES = [
     dict(name='pyr_head', C=256, Co=256, mask=False, hw=(25, 42), dst=(13, 21)),
     dict(name='v2_g2', C=64, Co=128, groups=2, hw=(8, 8)),
     dict(name='v2_dg4', C=128, Co=64, dg=4, hw=(6, 10)),
+    dict(name='v2_dg2_wide', C=512, Co=128, dg=2, hw=(9, 12)),     # two deformable groups of 256 channels (dcn_mm_kernels.h)
     # backbone-shaped calls of BASELINE configs 3 / 4: R-101-DCN conv2 (g = 1, first block of a stage
     # stride 2) and X-101-64x4d-DCN conv2 (g = 64: 8 / 16 / 32 channels per group, no bias)
     dict(name='r101_l2_s2', C=128, Co=128, stride=2, hw=(50, 84), bias=False),
@@ -120,6 +121,7 @@ KERNEL_CHOICES = {
     # same two bits as "scalar loads" / "compute the sampling table instead of copying the launch-wide one", so those two
     # choices also cover its fallback paths.
     'default': ('bf16x6', 0),                       # fp32-equivalent products, atomic-free grad_input
+    'x6_first_gemms': ('bf16x6', 1 << 28),          # bit 28: dcn_kernels.h GEMMs where dcn_mm_kernels.h would serve
     'x6_atomic': ('bf16x6', 1 << 23),
     'x3_gather': ('bf16x3', 0),
     'x3_first_kernel': ('bf16x3', (1 << 23) | (1 << 25)),

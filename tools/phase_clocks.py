@@ -87,7 +87,7 @@ elif len(sys.argv) > 1 and sys.argv[1] == 'bwd1':
     for blk in (0, 300, 600):
         run(lambda: be.dcn_backward(xs, offs, msks, w, gos, cfg, need), blk, 'backward-data (split kernel)')
 elif len(sys.argv) > 1 and sys.argv[1] == 'bwd':
-    for name, fl in (('full', 0), ('no atomics', 1 << 26), ('no offset/mask grads', 1 << 27), ('no x loads', 1 << 28),
+    for name, fl in (('full', 0), ('no atomics', 1 << 26), ('no offset/mask grads', 1 << 27),
                      ('neither atomics nor offset grads', 3 << 26)):
         run(lambda: be.dcn_backward(xs, offs, msks, w, gos, cfg, need), 300, f'backward-data {name}', fl)
 elif len(sys.argv) > 1 and sys.argv[1] == 'ablate':
