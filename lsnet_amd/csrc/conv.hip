@@ -442,10 +442,27 @@ static int launch_wgrad_cfg(WgArgs &a, float *gw, float *gb, int accumulate, hip
     const size_t thr = n4 * LS;
     const int rb = (int)((thr + 255) / 256 < 4096 ? (thr + 255) / 256 : 4096);
     hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(rb > 0 ? rb : 1), dim3(256), 0, st, a.part, gw, nW, a.part_b, gb, a.Co, S,
-                       accumulate, LS);
+                       S, accumulate, LS);
     LSN_HIP(hipGetLastError());
     return 0;
 }
+
+// dcn.hip: gw (+)= sum of `splits` partial gradients of n floats (n % 4 == 0), gb (+)= sum of splits_b partial rows of nb
+int conv_wgrad_reduce(const float *part, float *gw, size_t n, const float *part_b, float *gb, int nb, int splits, int splits_b,
+                      int accumulate, hipStream_t st)
+{
+    int LS = 1;
+    while (LS < 64 && LS * 8 <= splits) LS <<= 1;
+    const size_t thr = n / 4 * LS;
+    const int rb = (int)((thr + 255) / 256 < 4096 ? (thr + 255) / 256 : 4096);
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(rb > 0 ? rb : 1), dim3(256), 0, st, part, gw, n, part_b, gb, nb, splits,
+                       splits_b, accumulate, LS);
+    LSN_HIP(hipGetLastError());
+    return 0;
+}
+
+// library-owned scratch (also for dcn.hip's weight-gradient pass): grows, never shrinks
+int conv_scratch(size_t floats, float **p) { return part_buffer(floats, p); }
 
 // Returns 1 when the shape is not served here (more than nine taps, C % 4 != 0, 64-bit offsets): the caller keeps the
 // general kernel of dcn.hip.

@@ -153,6 +153,15 @@ __global__ void conv_wfrag_multi_kernel(const WfragJob *__restrict__ jobs, int n
     }
 }
 
+// ds_read_b64_tr_b16: within a 16-lane group lane i supplies the address of 8-byte chunk i, chunks 4r .. 4r+3 are row r,
+// and lane i receives [row 0..3][column i] (tools/ubench/tr16_probe.hip)
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ s16x4 lds_tr16(const unsigned char *p)
+{
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (s16x4 __attribute__((address_space(3))) *)((__attribute__((address_space(3))) const unsigned char *)p));
+}
+
 __device__ __forceinline__ float4 cv_load4(__amdgpu_buffer_rsrc_t rs, int voff, int soff)
 {
     auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);

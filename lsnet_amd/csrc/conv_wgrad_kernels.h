@@ -49,14 +49,6 @@ struct WgArgs {
     int want_bias;
 };
 
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ s16x4 lds_tr16(const unsigned char *p)
-{
-    return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-        (s16x4 __attribute__((address_space(3))) *)((__attribute__((address_space(3))) const unsigned char *)p));
-}
-
 // TI x TJ tiles of 32 ci x 32 co per wave and tap, TG taps (9: a 3x3 kernel, 1: one tap), waves WI (ci) x WJ (co).
 // GUNAL: Co % 4 != 0 (27-channel offset / mask convolutions): grad_output rows are fetched with guarded 4-byte loads.
 // PMAX: patch pixels the instantiation stages, rounded up to whole passes of the 256 threads (54 = 3 x 18: stride-1
@@ -334,12 +326,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgArgs a)
 }
 
 // gw[e] (+)= sum_s part[s][e] over n elements (n % 4 == 0); the bias part likewise (nb elements) -- one launch for
-// both.  LS (a power of two <= 64) adjacent lanes share one float4 of the gradient and take every LS-th split each, then
+// both (the bias partials may come in their own number, splits_b).  LS (a power of two <= 64) adjacent lanes share one float4 of the gradient and take every LS-th split each, then
 // meet by xor-shuffles: a small gradient under many splits (64 x 64 weights, 512 pixel ranges) is then summed by
 // 64 lanes x 8 loads instead of one thread walking 512 dependent loads.
-__global__ void conv_wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ gw, size_t n,
-                                         const float *__restrict__ part_b, float *__restrict__ gb, int nb, int splits,
-                                         int accumulate, int LS)
+static __global__ void conv_wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ gw, size_t n,
+                                                const float *__restrict__ part_b, float *__restrict__ gb, int nb, int splits,
+                                                int splits_b, int accumulate, int LS)
 {
     const size_t n4 = n / 4;
     const size_t gid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -369,11 +361,11 @@ __global__ void conv_wgrad_reduce_kernel(const float *__restrict__ part, float *
         for (int e = threadIdx.x; e < nb; e += blockDim.x) {
             float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
             int z = 0;
-            for (; z + 3 < splits; z += 4) {
+            for (; z + 3 < splits_b; z += 4) {
                 s0 += part_b[(size_t)z * nb + e], s1 += part_b[(size_t)(z + 1) * nb + e];
                 s2 += part_b[(size_t)(z + 2) * nb + e], s3 += part_b[(size_t)(z + 3) * nb + e];
             }
-            for (; z < splits; ++z) s0 += part_b[(size_t)z * nb + e];
+            for (; z < splits_b; ++z) s0 += part_b[(size_t)z * nb + e];
             const float s = (s0 + s1) + (s2 + s3);
             gb[e] = accumulate ? gb[e] + s : s;
         }

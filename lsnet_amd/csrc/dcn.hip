@@ -752,8 +752,61 @@ static int wgrad_vec_bits(const DcnArgs &a)
     return (vx ? 1 : 0) | (vg ? 2 : 0);
 }
 
+// ---- weight gradient on the kernels of dcn_mm_kernels.h: grad_output in fragment order, split partial tiles ----
+int conv_wgrad_reduce(const float *part, float *gw, size_t n, const float *part_b, float *gb, int nb, int splits, int splits_b,
+                      int accumulate, hipStream_t st);
+int conv_scratch(size_t floats, float **p);
+
+static bool mm_wgrad_ok(const DcnArgs &a)
+{
+    if (!mm_common_ok(a) || a.Co % 256 != 0 || (a.C / a.dg) % 64 != 0) return false;
+    if (a.gtap == nullptr || (reinterpret_cast<uintptr_t>(a.gtap) & 15) != 0) return false;
+    return true;
+}
+
+static int launch_wgrad_mm(const DcnArgs &a, int nchunks, bool accumulate, hipStream_t st)
+{
+    const int K = a.kh * a.kw, npl = mm_npl();
+    const size_t nW = (size_t)a.Co * K * a.C;
+    const size_t img_bytes = (size_t)nchunks * 2 * (a.Co / 32) * npl * 1024;
+    if (img_bytes >= ((size_t)1 << 31)) return 1;
+    const int ncol = K * (a.C / 64), nz = a.Co / 256;
+    int S = (512 + ncol * nz / 2) / (ncol * nz);
+    if (S > nchunks / 4) S = nchunks / 4;   // a split should run long enough to amortise its prologue and its partial tile
+    static const int force_s = [] { const char *e = getenv("LSNET_DCN_WGRAD_SPLITS"); return e ? atoi(e) : 0; }();
+    if (force_s > 0) S = force_s < nchunks ? force_s : nchunks;
+    if (S < 1) S = 1;
+    const int nsteps16 = 2 * nchunks;
+    int spb = cdiv(nsteps16, 256);            // pre-pass: ~256 step ranges x (Co / 128) tile groups
+    if (spb < 4) spb = 4;
+    const int nblk_s = cdiv(nsteps16, spb);
+    const size_t img_f = (img_bytes + 15) / 16 * 4, part_f = (size_t)S * nW, pb_f = ((size_t)nblk_s * a.Co + 3) & ~(size_t)3;
+    float *base = nullptr;
+    if (int rc = conv_scratch(img_f + part_f + pb_f + (size_t)nchunks * 8 + 64, &base)) return rc;
+    unsigned short *img = reinterpret_cast<unsigned short *>(base);
+    float *part = base + img_f, *part_b = part + part_f;
+    int *meta = reinterpret_cast<int *>(part_b + pb_f);
+    hipLaunchKernelGGL(dcn_chunk_meta_kernel, dim3(cdiv(nchunks, 256)), dim3(256), 0, st, a, nchunks, meta);
+    ProfScope prof(PROF_WGRAD, a, st);
+    auto pre = npl == 3 ? dcn_gout_frag_kernel<3> : dcn_gout_frag_kernel<2>;
+    hipLaunchKernelGGL(pre, dim3(nblk_s, a.Co / 128), dim3(256), 0, st, a, nsteps16, spb, img, a.gb ? part_b : nullptr);
+    const size_t lds = dcn_wgrad_mm_lds_bytes(npl);
+    auto go = [&](auto kern) -> int {
+        if (int rc = set_lds(kern, lds)) return rc;
+        hipLaunchKernelGGL(kern, dim3(ncol, S, nz), dim3(256), lds, st, a, nchunks, img, (int)img_bytes, part, meta);
+        LSN_HIP(hipGetLastError());
+        return 0;
+    };
+    if (int rc = (math_np() == 6 ? go(dcn_wgrad_mm_kernel<6>) : go(dcn_wgrad_mm_kernel<3>))) return rc;
+    return conv_wgrad_reduce(part, a.gw, nW, part_b, a.gb, a.Co, S, nblk_s, accumulate ? 1 : 0, st);
+}
+
 static int launch_wgrad(const DcnArgs &a_in, int nsteps, bool accumulate, hipStream_t st)
 {
+    if (mm_wgrad_ok(a_in)) {
+        const int rc = launch_wgrad_mm(a_in, nsteps, accumulate, st);
+        if (rc != 1) return rc;   // 1: not served (sizes), fall through
+    }
     DcnArgs a = a_in;
     a.wg_vec = wgrad_vec_bits(a);
     if ((reinterpret_cast<uintptr_t>(a.gtap) & 15) != 0) a.gtap = nullptr;

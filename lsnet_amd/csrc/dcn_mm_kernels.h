@@ -251,4 +251,286 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_mm_kernel(const DcnArgs a, con
     }
 }
 
+// =============================================================================================
+// Weight gradient   gw[co][k][c] = sum_p gout[p][co] * col[p][k, c]   (deform_conv_cuda.cpp:1126-1131): the reduction
+// index is the pixel.
+//   * grad_output plays the part the weights play in the forward kernels: dcn_gout_frag_kernel writes it ONCE per launch
+//     as bf16 planes in MFMA fragment order ([16-pixel k-step][32-co tile][plane][lane: co = lane & 31, pixels
+//     8 (lane >> 5) .. + 7]), and every workgroup of the 36 column blocks fetches its fragments from L2 straight into
+//     registers -- instead of each of them loading, splitting and transposing the same fp32 rows through LDS.  The same
+//     pass sums the bias gradient.
+//   * the sampled columns (one tap, 64 channels per workgroup) are blended from their four corners, split and stored as
+//     natural [pixel][channel] rows of 128 B; ds_read_b64_tr_b16 delivers the pixel-major fragments.
+//   * workgroup = 256 co x 64 columns, wave = 64 x 64; 32-pixel chunks, two LDS stages, staging of chunk t + 1 and the
+//     corner loads of chunk t + 2 between the MFMAs of chunk t (the schedule of conv_mm_kernel).
+//   * the pixel range is split over blockIdx.y; each split stores its partial tile, conv_wgrad_reduce_kernel adds them in
+//     a fixed order: no atomics, deterministic.
+// Conditions (dcn.hip mm_wgrad_ok): groups == 1, 256 | Co, 64 | C / deformable_groups, the launch-wide sampling table of
+// the backward-data pass (a.gtap).
+// =============================================================================================
+template <int NPL>
+__global__ __launch_bounds__(256) void dcn_gout_frag_kernel(const DcnArgs a, int nsteps16, int steps_per_block,
+                                                            unsigned short *__restrict__ img, float *__restrict__ part_b)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int NT = a.Co / 32;
+    const int tile = blockIdx.y * 4 + wave;   // (Co % 128 == 0)
+    const int co = tile * 32 + (lane & 31), h = lane >> 5;
+    const int s0 = blockIdx.x * steps_per_block, s1 = min(s0 + steps_per_block, nsteps16);
+    float bsum = 0.f;
+    for (int s = s0; s < s1; ++s) {
+        const Lvl &L = find_level(a, s >> 1);            // level tables count 32-pixel chunks
+        const int p0 = (s - 2 * L.tile0) * 16 + 8 * h;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int pp = p0 + e;
+            v[e] = pp < L.P ? L.gout[(size_t)pp * a.Co + co] : 0.f;
+            bsum += v[e];
+        }
+        unsigned pl[4][NPL];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split_planes<NPL>(v[2 * e], v[2 * e + 1], pl[e]);
+        unsigned short *dst = img + ((size_t)s * NT + tile) * NPL * 512 + (size_t)lane * 8;
+#pragma unroll
+        for (int q = 0; q < NPL; ++q)
+            *reinterpret_cast<uint4 *>(dst + (size_t)q * 512) = make_uint4(pl[0][q], pl[1][q], pl[2][q], pl[3][q]);
+    }
+    if (part_b != nullptr) {
+        bsum += __shfl_xor(bsum, 32);
+        if (lane < 32) part_b[(size_t)blockIdx.x * a.Co + co] = bsum;
+    }
+}
+
+// Per 32-pixel chunk: where it lives -- {input base lo, hi, input bytes, first row of the launch-wide sampling table, valid
+// pixels, -, -, -}.  The weight-gradient kernel reads it with scalar loads: a level lookup per iteration in the kernel
+// itself (dynamic indexing of the by-value argument struct) compiled to vector loads from the argument copy with full
+// vmcnt(0) waits in the middle of the software pipeline.
+__global__ void dcn_chunk_meta_kernel(const DcnArgs a, int nchunks, int *__restrict__ meta)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nchunks) return;
+    const Lvl &L = find_level(a, t);
+    const unsigned long long p = reinterpret_cast<unsigned long long>(L.x);
+    const int p0 = (t - L.tile0) * 32;
+    int4 m0, m1;
+    m0.x = (int)(unsigned)p, m0.y = (int)(unsigned)(p >> 32), m0.z = L.B * L.H * L.W * a.C * 4, m0.w = L.prow0 + p0;
+    m1.x = max(0, min(32, L.P - p0)), m1.y = m1.z = m1.w = 0;
+    reinterpret_cast<int4 *>(meta)[2 * t] = m0;
+    reinterpret_cast<int4 *>(meta)[2 * t + 1] = m1;
+}
+
+__host__ __device__ inline size_t dcn_wgrad_mm_lds_bytes(int npl) { return (size_t)2 * npl * 32 * 128 + 4 * 32 * sizeof(Tap); }
+
+template <int NP>
+__global__ __launch_bounds__(256, 2) void dcn_wgrad_mm_kernel(const DcnArgs a, int nchunks, const unsigned short *__restrict__ gimg,
+                                                              int gimg_bytes, float *__restrict__ part, const int *__restrict__ meta)
+{
+    using SC = SplitCfg<NP>;
+    constexpr int NPL = SC::NPL;
+    constexpr int TI = 2, TJ = 2;                  // wave: 64 columns x 64 output channels
+    constexpr int RBX = 128, XPL = 32 * RBX, STAGE = NPL * XPL;
+    extern __shared__ __align__(16) unsigned char smem[];   // 2 x STAGE, then the sampling table: 4 slots x 32 entries
+    Tap *tab = reinterpret_cast<Tap *>(smem + 2 * STAGE);
+
+    const int tid = threadIdx.x, lane = tid & 63, wj = tid >> 6;
+    const int K = a.kh * a.kw, KD = K * a.dg;
+    const int ncolb = a.C / 64;                    // column blocks per tap
+    const int ncol = (int)gridDim.x, nsplit = (int)gridDim.y;
+    const int work = xcd_remap(blockIdx.y * ncol + blockIdx.x, ncol * nsplit);
+    const int split = work / ncol, bcol = work - split * ncol;
+    const int k = bcol / ncolb, c0 = (bcol - k * ncolb) * 64;
+    const int kd = (c0 / (a.C / a.dg)) * K + k;
+    const int co_blk = blockIdx.z * 256;
+    const int NT = a.Co / 32;
+    // (readfirstlane: the 64-bit divisions run on the vector ALU; left in VGPRs, every level lookup below became a
+    // vector load from the kernel arguments with a full vmcnt(0) wait in the middle of the software pipeline)
+    const int t_begin = __builtin_amdgcn_readfirstlane((int)((long long)nchunks * split / nsplit));
+    const int T = __builtin_amdgcn_readfirstlane((int)((long long)nchunks * (split + 1) / nsplit)) - t_begin;
+
+    const __amdgpu_buffer_rsrc_t grs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(gimg), 0, gimg_bytes, 0x00020000);
+
+    // ---- sampling table: the chunk's 32 entries are 1 KB contiguous in the k-major launch-wide table; lane l of wave 0
+    // moves 16-byte half (l & 1) of entry (l >> 1); pixels past the level's end take the all-zero entry behind the table
+    typedef const int __attribute__((address_space(4))) *cmeta_t;   // constant address space: uniform address -> s_load
+    cmeta_t cmeta = (cmeta_t)(unsigned long long)meta;
+    auto gtap_load = [&](int t) -> uint4 {
+        const int grow = cmeta[8 * t + 3], valid = cmeta[8 * t + 4];
+        const int pix = lane >> 1;
+        const size_t ent = pix < valid ? (size_t)kd * a.gtap_rows + grow + pix : (size_t)KD * a.gtap_rows;
+        return reinterpret_cast<const uint4 *>(a.gtap)[ent * 2 + (lane & 1)];
+    };
+    auto gtap_put = [&](int slot, uint4 v) { reinterpret_cast<uint4 *>(tab + slot * 32)[lane] = v; };
+
+    // ---- sampled columns: thread = (float4 slot xc4 of the 64-channel slab, pixel q of a 16-pixel pass), two passes ----
+    const int xc4 = tid & 15, xq = tid >> 4;
+    int xlds[2];
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+        const int pix = ps * 16 + xq;
+        const int sl = (xc4 >> 2) ^ (2 * ((pix >> 1) & 1));   // 32-byte slot swizzle of the 128-byte rows
+        xlds[ps] = pix * RBX + sl * 32 + (xc4 & 3) * 8;
+    }
+    float4 xv[2][4];
+    __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.lv[0].x), 0, 0, 0x00020000);
+    auto open_chunk = [&](int t) {   // buffer descriptor of the level chunk t lies in
+        // (readfirstlane: hipcc kept a descriptor that changes inside the loop in VGPRs and wrapped every corner load in a
+        // waterfall loop)
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)cmeta[8 * t]), hi = __builtin_amdgcn_readfirstlane((unsigned)cmeta[8 * t + 1]);
+        const int nrec = __builtin_amdgcn_readfirstlane(cmeta[8 * t + 2]);
+        xrs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float *>(((unsigned long long)hi << 32) | lo), 0, nrec, 0x00020000);
+    };
+    auto issue_slice = [&](int ps, int slot) {
+        const int4 idx = *reinterpret_cast<const int4 *>(&tab[slot * 32 + ps * 16 + xq]);
+        const int cq = (c0 + 4 * xc4) * 4;
+        xv[ps][0] = cv_load4(xrs, idx.x * 4 + cq, 0);
+        xv[ps][1] = cv_load4(xrs, idx.y * 4 + cq, 0);
+        xv[ps][2] = cv_load4(xrs, idx.z * 4 + cq, 0);
+        xv[ps][3] = cv_load4(xrs, idx.w * 4 + cq, 0);
+    };
+    auto commit_slice = [&](int ps, int slot, unsigned char *buf) {
+        const Tap tp = tab[slot * 32 + ps * 16 + xq];
+        float b00, b01, b10, b11;
+        corner_weights(tp, b00, b01, b10, b11);
+        b00 *= tp.m, b01 *= tp.m, b10 *= tp.m, b11 *= tp.m;
+        float v[4];
+        v[0] = b00 * xv[ps][0].x + b01 * xv[ps][1].x + b10 * xv[ps][2].x + b11 * xv[ps][3].x;
+        v[1] = b00 * xv[ps][0].y + b01 * xv[ps][1].y + b10 * xv[ps][2].y + b11 * xv[ps][3].y;
+        v[2] = b00 * xv[ps][0].z + b01 * xv[ps][1].z + b10 * xv[ps][2].z + b11 * xv[ps][3].z;
+        v[3] = b00 * xv[ps][0].w + b01 * xv[ps][1].w + b10 * xv[ps][2].w + b11 * xv[ps][3].w;
+        unsigned p0[NPL], p1[NPL];
+        split_planes<NPL>(v[0], v[1], p0);
+        split_planes<NPL>(v[2], v[3], p1);
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) *reinterpret_cast<uint2 *>(buf + q * XPL + xlds[ps]) = make_uint2(p0[q], p1[q]);
+    };
+
+    // ---- grad_output fragments: chunk t, k-step ks, tile, plane: (((t * 2 + ks) * NT + tile) * NPL + q) * 1024 + lane * 16
+    const int gvoff = lane * 16 + (co_blk / 32 + wj * TJ) * NPL * 1024;
+    const int gsstep = NT * NPL * 1024;
+    bf16x8 Gf[2][TJ][NPL];
+    auto issue_g = [&](int t, int ks) {   // t saturates at the last chunk (a repeated L2 hit, never used)
+        const int soff = __builtin_amdgcn_readfirstlane(((t_begin + (t < T ? t : T - 1)) * 2 + ks) * gsstep);
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) Gf[ks][j][q] = cv_load_frag(grs, gvoff + (j * NPL + q) * 1024, soff);
+    };
+
+    // ---- column fragment addresses: lane: column group g of the 32-wide tile, 8-byte piece cq of block row rb; pixels
+    // m = 8 (lane >> 5) + 4 h + rb of k-step ks for the two tr-reads h = 0, 1 ----
+    const int fg = (lane >> 4) & 1, frb = (lane >> 2) & 3, fcq = lane & 3;
+    int xaddr[2][TI][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int pp = ks * 16 + 8 * (lane >> 5) + 4 * h + frb;
+                const int sl = (2 * i + fg) ^ (2 * ((pp >> 1) & 1));
+                xaddr[ks][i][h] = pp * RBX + sl * 32 + fcq * 8;
+            }
+    auto frag = [&](const unsigned char *p0, const unsigned char *p1) {
+        const s16x4 lo = lds_tr16(p0), hi = lds_tr16(p1);
+        short v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        bf16x8 f;
+        __builtin_memcpy(&f, v, 16);
+        return f;
+    };
+
+    f32x16 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (T > 0) {
+        // ---- prologue: table slots of chunks 0 .. 2 (slot = chunk % 4; chunk 3 is in flight); chunk 0 -> stage 0; corners
+        // of chunk 1 and the grad_output fragments of chunk 0 in flight ----
+        auto sat = [&](int t) { return __builtin_amdgcn_readfirstlane(t_begin + (t < T ? t : T - 1)); };
+        if (wj == 0) {
+            gtap_put(0, gtap_load(sat(0)));
+            gtap_put(1, gtap_load(sat(1)));
+            gtap_put(2, gtap_load(sat(2)));
+        }
+        uint4 tq = gtap_load(sat(3));
+        __syncthreads();
+        open_chunk(sat(0));
+        issue_slice(0, 0);
+        issue_slice(1, 0);
+        commit_slice(0, 0, smem);
+        commit_slice(1, 0, smem);
+        open_chunk(sat(1));
+        issue_slice(0, 1);
+        issue_slice(1, 1);
+        issue_g(0, 0);
+        issue_g(0, 1);
+        __syncthreads();
+
+        for (int t = 0; t < T; ++t) {
+            const unsigned char *bc = smem + (t & 1) * STAGE;
+            unsigned char *bn = smem + ((t & 1) ^ 1) * STAGE;
+            const int slot1 = (t + 1) & 3, slot2 = (t + 2) & 3, slot3 = (t + 3) & 3;
+            // slot3 held chunk t - 1, last read before the barrier that ended it; its new entries (chunk t + 3) are first
+            // read in iteration t + 1, behind the barrier that ends this one
+            if (wj == 0) gtap_put(slot3, tq);
+            tq = gtap_load(sat(t + 4));
+            bf16x8 Xf[2][TI][NPL];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int q = 0; q < NPL; ++q)
+                        Xf[ks][i][q] = frag(bc + q * XPL + xaddr[ks][i][0], bc + q * XPL + xaddr[ks][i][1]);
+            open_chunk(sat(t + 2));
+            __builtin_amdgcn_sched_barrier(0);
+            constexpr int NM = NP * TI * TJ;
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps) {
+#pragma unroll
+                for (int m = ps * NM / 2; m < (ps + 1) * NM / 2; ++m) {
+                    const int prod = m / (TI * TJ), i = (m / TJ) % TI, j = m % TJ;
+                    acc[i][j] = mfma_bf16(Xf[0][i][SC::pa(prod)], Gf[0][j][SC::pb(prod)], acc[i][j]);
+                }
+                if (t + 1 < T) commit_slice(ps, slot1, bn);   // registers hold the corners of chunk t + 1
+                issue_slice(ps, slot2);                       // chunk t + 2 (saturated: a repeated fetch, never committed)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            issue_g(t + 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int prod = 0; prod < NP; ++prod)
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j)
+                        acc[i][j] = mfma_bf16(Xf[1][i][SC::pa(prod)], Gf[1][j][SC::pb(prod)], acc[i][j]);
+            issue_g(t + 1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: D[column][co]: lane = co (lane & 31) of tile j, columns 8 q + 4 (lane >> 5) + (0..3) of tile i ----
+    const size_t nW = (size_t)a.Co * K * a.C;
+    float *pw = part + (size_t)split * nW;
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+        const int co = co_blk + (wj * TJ + j) * 32 + (lane & 31);
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = c0 + i * 32 + 8 * q + 4 * (lane >> 5);
+                *reinterpret_cast<float4 *>(pw + ((size_t)co * K + k) * a.C + c) =
+                    make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+            }
+    }
+}
+
 }  // namespace lsn

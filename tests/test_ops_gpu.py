@@ -71,6 +71,7 @@ DCN_CASES = [
     dict(name='v2_g2', C=64, Co=128, groups=2, hw=(8, 8)),
     dict(name='v2_dg4', C=128, Co=64, dg=4, hw=(6, 10)),
     dict(name='v2_dg2_wide', C=512, Co=128, dg=2, hw=(9, 12)),     # two deformable groups of 256 channels (dcn_mm_kernels.h)
+    dict(name='v2_dg2_co256', C=128, Co=256, dg=2, hw=(9, 12)),    # 64-channel deformable groups under the 256-co weight-gradient tile
     # backbone-shaped calls of BASELINE configs 3 / 4: R-101-DCN conv2 (g = 1, first block of a stage
     # stride 2) and X-101-64x4d-DCN conv2 (g = 64: 8 / 16 / 32 channels per group, no bias)
     dict(name='r101_l2_s2', C=128, Co=128, stride=2, hw=(50, 84), bias=False),
