@@ -256,8 +256,16 @@ static bool mm_common_ok(const DcnArgs &a)
 
 static int mm_npl() { return math_np() == 6 ? 3 : 2; }
 
+// LSNET_DCN_MM_PARTS: bit 0 forward, bit 1 backward-data, bit 2 weight gradient (default 7; A/B runs)
+static int dcn_mm_parts()
+{
+    static const int v = [] { const char *e = getenv("LSNET_DCN_MM_PARTS"); return e ? atoi(e) : 7; }();
+    return v;
+}
+
 static bool mm_fwd_ok(const DcnArgs &a)
 {
+    if (!(dcn_mm_parts() & 1)) return false;
     if (!mm_common_ok(a) || (a.C / a.dg) % 32 != 0 || a.Co % 128 != 0) return false;
     if (dcn_fwd_mm_lds_bytes(mm_npl(), a.kh * a.kw * a.dg) > 80 * 1024) return false;
     return cv_wfrag_bytes(a.Co, a.kh * a.kw, a.C, mm_npl()) < ((size_t)1 << 31);
@@ -270,6 +278,7 @@ int conv_mm_rows(int n, const float *const *x, float *const *out, const int *row
                  hipStream_t st);
 static bool mm_bwd_ok(const DcnArgs &a)
 {
+    if (!(dcn_mm_parts() & 2)) return false;
     if (!mm_common_ok(a) || a.C % 4 != 0 || a.Co % 4 != 0) return false;
     for (int i = 0; i < a.nlv; ++i)
         if ((a.lv[i].goff || a.lv[i].gmsk) && !a.lv[i].gx) return false;
@@ -412,15 +421,24 @@ static int launch_bwd_data_t(const DcnArgs &a, hipStream_t st)
 static bool bwd_x3_ok(const DcnArgs &a)
 {
     if (math_np() == 0 || a.wtp == nullptr || a.groups != 1) return false;
-    const bool mm = mm_bwd_ok(a);   // (its GEMM has no limit on the reduction length Co)
-    if (!mm && a.Co > 256) return false;
-    if ((!mm && a.Co % 8 != 0) || a.C % 4 != 0) return false;
+    if (a.Co > 256 || a.Co % 8 != 0 || a.C % 4 != 0) return false;
     if ((int64_t)a.kh * a.kw * a.C * a.Co * 6 >= ((int64_t)1 << 31)) return false;
-    if (!mm && bwd_xn_lds_bytes(math_np(), a.kh * a.kw * a.dg) > 80 * 1024) return false;
+    if (bwd_xn_lds_bytes(math_np(), a.kh * a.kw * a.dg) > 80 * 1024) return false;
     for (int i = 0; i < a.nlv; ++i) {   // 32-bit buffer offsets into the input and the level's column-gradient rows
         if ((int64_t)a.lv[i].B * a.lv[i].H * a.lv[i].W * a.C * 4 >= ((int64_t)1 << 31)) return false;
         if ((int64_t)a.lv[i].P * a.kh * a.kw * a.C * 4 >= ((int64_t)1 << 31)) return false;
     }
+    return true;
+}
+
+// the atomic-free path (column gradients + gather): served by the dense GEMM (mm_bwd_ok: any Co) or by round 2's GEMM
+static bool bwd_gather_ok(const DcnArgs &a)
+{
+    if (a.wtp == nullptr) return false;
+    if (bwd_x3_ok(a)) return true;
+    if (!mm_bwd_ok(a)) return false;
+    for (int i = 0; i < a.nlv; ++i)   // 32-bit offsets into the level's column-gradient rows
+        if ((int64_t)a.lv[i].P * a.kh * a.kw * a.C * 4 >= ((int64_t)1 << 31)) return false;
     return true;
 }
 
@@ -700,7 +718,7 @@ static int launch_bwd_data(DcnArgs &a, void *gather_ws, size_t gather_ws_bytes, 
 {
     ProfScope prof(PROF_BWD_DATA, a, st);
     const int np = math_np();
-    if (bwd_x3_ok(a) && gather_ws && bwd_colbuf_env()) {
+    if ((a.mm || bwd_x3_ok(a)) && gather_ws && bwd_colbuf_env()) {
         GatherPlan pl;
         gather_plan(a, pl);
         if (pl.ok && pl.bytes <= gather_ws_bytes)
@@ -712,7 +730,7 @@ static int launch_bwd_data(DcnArgs &a, void *gather_ws, size_t gather_ws_bytes, 
     for (int i = 0; i < a.nlv; ++i)   // the scatter kernels accumulate: start from zero (once per buffer is enough)
         if (a.lv[i].gx)
             LSN_HIP(hipMemsetAsync(a.lv[i].gx, 0, sizeof(float) * (size_t)a.lv[i].B * a.lv[i].H * a.lv[i].W * a.C, st));
-    if (bwd_x3_ok(a) && a.Co <= 256 && (np == 6 || !bwd_win_ok(a))) {
+    if (bwd_x3_ok(a) && (np == 6 || !bwd_win_ok(a))) {
         const size_t lds = bwd_xn_lds_bytes(np, a.kh * a.kw * a.dg);
         auto gox = [&](auto kern) -> int {
             if (int rc = set_lds(kern, lds)) return rc;
@@ -759,6 +777,7 @@ int conv_scratch(size_t floats, float **p);
 
 static bool mm_wgrad_ok(const DcnArgs &a)
 {
+    if (!(dcn_mm_parts() & 4)) return false;
     if (!mm_common_ok(a) || a.Co % 256 != 0 || (a.C / a.dg) % 64 != 0) return false;
     if (a.gtap == nullptr || (reinterpret_cast<uintptr_t>(a.gtap) & 15) != 0) return false;
     return true;
@@ -966,7 +985,7 @@ static int dcn_backward_impl(const lsn_dcn_shape &s, int n, const lsn_dcn_level 
             if (pl.ok && (gws = ws.get(pl.bytes / 4 + 64)) != nullptr) gws_bytes = pl.bytes;
         }
         bool mm = false;   // the GEMM of dcn_mm_kernels.h: only together with the gather pass
-        if (can_split && gws && bwd_colbuf_env() && mm_bwd_ok(a) && bwd_x3_ok(a)) {
+        if (can_split && gws && bwd_colbuf_env() && mm_bwd_ok(a) && bwd_gather_ok(a)) {
             GatherPlan pl;
             DcnArgs probe = a;
             gather_plan(probe, pl);
@@ -1139,7 +1158,7 @@ int64_t lsn_dcn_backward_workspace_bytes(const lsn_dcn_shape *shape, int n_level
     if (fill_levels(a, *shape, n_levels, levels, BWD_BM) != 0) return 0;
     for (int i = 0; i < n_levels; ++i) a.lv[i].gx = levels[i].grad_input;
     a.wtp = reinterpret_cast<const unsigned short *>(shape);   // any non-NULL value: the caller passes `workspace` too
-    if (!bwd_x3_ok(a)) return 0;
+    if (!bwd_gather_ok(a)) return 0;
     GatherPlan pl;
     gather_plan(a, pl);
     return pl.ok ? (int64_t)pl.bytes : 0;

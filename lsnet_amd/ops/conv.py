@@ -68,12 +68,21 @@ def _refresh_stale(mode):
         items.append((key, ent, w))
     if not items:
         return
-    arr = (_lib.ConvWprep * len(items))()
-    for it, (key, ent, w) in zip(arr, items):
-        Co, C, kh, kw = w.shape
-        it.kind, it.w, it.prepared = key[1], w.data_ptr(), ent[3].data_ptr()
-        it.C, it.Co, it.kh, it.kw, it.stride, it.pad, it.dil = C, Co, kh, kw, key[2], key[3], key[4]
-    _lib.check(_lib.load().lsn_conv2d_prepare_weights_multi(len(items), arr, _stream()))
+    if torch.cuda.is_current_stream_capturing():
+        # the multi-tensor launch uploads its job table when the set of stale images changed (a synchronous copy: not
+        # allowed while a hipGraph is being captured): one launch per image instead, recorded into the graph
+        lib = _lib.load()
+        for key, ent, w in items:
+            Co, C, kh, kw = w.shape
+            _lib.check(lib.lsn_conv2d_prepare_weights(key[1], _p(w), _p(ent[3]), C, Co, kh, kw, key[2], key[3], key[4],
+                                                      _stream()))
+    else:
+        arr = (_lib.ConvWprep * len(items))()
+        for it, (key, ent, w) in zip(arr, items):
+            Co, C, kh, kw = w.shape
+            it.kind, it.w, it.prepared = key[1], w.data_ptr(), ent[3].data_ptr()
+            it.C, it.Co, it.kh, it.kw, it.stride, it.pad, it.dil = C, Co, kh, kw, key[2], key[3], key[4]
+        _lib.check(_lib.load().lsn_conv2d_prepare_weights_multi(len(items), arr, _stream()))
     for key, ent, w in items:
         ent[1], ent[2], ent[4] = w._version, w.data_ptr(), _opt_epoch[0]
 

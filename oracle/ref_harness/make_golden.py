@@ -197,7 +197,7 @@ def curve_cfg():
     return cfg
 
 
-def golden_train_curve():
+def golden_train_curve(lr=0.01, fixture='train_curve'):
     """(8d) loss parity over an SGD run: the REFERENCE's detector, losses, optimizer hook (grad clip 35), SGD and
     step-LR warm-up hooks (mmcv runner, mmcv/runner/hooks/{optimizer,lr_updater}.py) for 12 iterations on one
     seeded synthetic batch per iteration, native ops backed by the CPU oracle.  Stores the loss curves, the learning
@@ -213,7 +213,7 @@ def golden_train_curve():
     model = build_detector(model_cfg, train_cfg=mmcv.Config(dict(cfg.train_cfg)), test_cfg=mmcv.Config(dict(cfg.test_cfg)))
     gu.fill_params(model, seed=11)
     model.train()
-    opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=0.0001)
+    opt = torch.optim.SGD(model.parameters(), lr=lr, momentum=0.9, weight_decay=0.0001)
     logger = logging.getLogger('curve')
     logger.setLevel(logging.ERROR)
     runner = EpochBasedRunner(model, optimizer=opt, work_dir=None, logger=logger)
@@ -234,7 +234,7 @@ def golden_train_curve():
     sd = model.state_dict()
     for name in ('bbox_head.pts_cls_out.weight', 'backbone.layer4.0.conv1.weight', 'neck.fpn_convs.0.conv.weight'):
         gu.pack(f'weight/{name}', sd[name], data, stride=211)
-    _save('train_curve', data)
+    _save(fixture, data)
 
 
 def golden_assign():
@@ -625,7 +625,10 @@ def golden_data_pipeline():
     _save('data_pipeline', data)
 
 
-ALL = dict(backbones_dcn=golden_backbones_dcn, train_curve=golden_train_curve, coco_eval=golden_coco_eval, head_cpv=golden_head_cpv, data_pipeline=golden_data_pipeline, gt_formats=golden_gt_formats, res2net=golden_res2net, vote=golden_vote, head_bbox=lambda: golden_head('bbox'), head_segm=lambda: golden_head('segm'),
+ALL = dict(backbones_dcn=golden_backbones_dcn, train_curve=golden_train_curve,
+           # the same run at a tenth of the learning rate: the loss falls 475 -> 60 instead of 475 -> 1 and rounding
+           # differences between two correct implementations stay at rounding level over all twelve iterations
+           train_curve_lowlr=lambda: golden_train_curve(0.001, 'train_curve_lowlr'), coco_eval=golden_coco_eval, head_cpv=golden_head_cpv, data_pipeline=golden_data_pipeline, gt_formats=golden_gt_formats, res2net=golden_res2net, vote=golden_vote, head_bbox=lambda: golden_head('bbox'), head_segm=lambda: golden_head('segm'),
            head_bbox_256=lambda: golden_head('bbox', 256),
            head_pose_bbox=lambda: golden_head('pose_bbox'), head_pose_kbox=lambda: golden_head('pose_kbox'),
            assign=golden_assign, cross_iou=golden_cross_iou, backbone=golden_backbone, nms=golden_nms)

@@ -77,13 +77,37 @@ def test_training_curve_follows_reference_runner(math):
     the late values vary from run to run.  Tolerances = 3 x the worst measured: early 7.5e-4 for the fp32-equivalent
     and exact modes and 5e-3 for the 3-product mode (1.4e-3 at iteration 3 in one run).  Round 3 (new dense-conv kernels, frozen stage-1
     BatchNorm folded into its convolutions, fused SGD; profiles/r3_gpu_tests.log): iterations 1-6 <= 2.0e-4 / 6.9e-4 / 1.3e-4,
-    iterations 7-12 <= 2.8e-2 / 1.2e-2 / 4.7e-2: late tolerance 0.12 (round 2: 0.27).  Teacher-forcing every iteration from
-    the reference's weights would remove the chaos, but the fixture would have to carry 12 x 38 M parameters."""
+    iterations 7-12 <= 2.8e-2 / 1.2e-2 / 4.7e-2 in one run, 3.4e-2 / 3.9e-2 / 3.2e-1 (loss_cls of the exact mode at
+    iteration 8, where the loss has fallen to 1.25) in another with different deformable kernels: the late half of THIS
+    fixture measures chaos, not kernels, and keeps a tolerance of 0.5.  What holds all twelve iterations tight is
+    `test_training_curve_low_learning_rate` below."""
     from lsnet_amd import _lib
     before = _lib.get_math_mode()
     _lib.set_math_mode(math)
     try:
-        worst = gc.train_curve_case(_dev(), early_tol=5e-3 if math == 'bf16x3' else 7.5e-4, late_tol=0.12, rtol_weight=5e-2, channels_last=True)
+        worst = gc.train_curve_case(_dev(), early_tol=5e-3 if math == 'bf16x3' else 7.5e-4, late_tol=0.5, rtol_weight=5e-2, channels_last=True)
     finally:
         _lib.set_math_mode(before)
     print(math, f'worst relative loss deviation {worst:.2e}')
+
+
+@pytest.mark.parametrize('math', ['bf16x6', 'fp32'])
+def test_training_curve_low_learning_rate(math):
+    """The same twelve SGD iterations (detector, runner, clip 35, warm-up + step schedule) at a tenth of the learning rate
+    against the reference's run of that schedule (fixture train_curve_lowlr.npz, oracle/ref_harness/make_golden.py
+    train_curve_lowlr): the loss falls 480 -> 31 without the collapse that makes the other fixture chaotic, so EVERY
+    iteration is held tight in the fp32-equivalent and exact modes ("remove the chaos"): total loss and
+    classification loss to 1e-3 relative, the two regression terms (2 % of the total; one re-assigned point moves them by
+    up to 8e-3 -- measured between this package's host path and the reference on the SAME CPU: 2.8e-4 / 4.7e-5 / 5.0e-4 /
+    8.0e-3) to 2e-2.  Measured on the MI355X (profiles/r3_gpu_tests.log): total / cls <= 6.1e-5, regression terms <=
+    3.6e-4 / 3.2e-3 in both modes.  Weights after the run within 1e-2 of their range."""
+    from lsnet_amd import _lib
+    before = _lib.get_math_mode()
+    _lib.set_math_mode(math)
+    try:
+        tol = dict(loss=1e-3, loss_cls=1e-3, loss_bbox_init=2e-2, loss_bbox_refine=2e-2)
+        worst = gc.train_curve_case(_dev(), early_tol=tol, late_tol=tol, rtol_weight=1e-2, channels_last=True,
+                                    fixture='train_curve_lowlr', lr=0.001)
+    finally:
+        _lib.set_math_mode(before)
+    print(math, f'low-lr curve: worst relative loss deviation {worst:.2e}')

@@ -47,3 +47,11 @@ def test_training_curve_follows_reference_runner(cpu_oracle_backend):
     torch.set_num_threads(8)
     worst = gc.train_curve_case(CPU, early_tol=1e-4, late_tol=0.15, rtol_weight=5e-2, iters=8)   # the GPU test runs all 12
     print(f'worst relative loss deviation over 8 iterations: {worst:.2e}')
+
+
+def test_training_curve_low_learning_rate(cpu_oracle_backend):
+    """A prefix of the non-chaotic fixture (train_curve_lowlr.npz) on the host; the MI355X test runs all twelve iterations."""
+    torch.set_num_threads(8)
+    worst = gc.train_curve_case(CPU, early_tol=1e-4, late_tol=1e-4, rtol_weight=5e-2, iters=5, fixture='train_curve_lowlr',
+                                lr=0.001)
+    print(f'low-lr curve, worst relative loss deviation over 5 iterations: {worst:.2e}')
