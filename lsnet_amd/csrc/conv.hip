@@ -56,7 +56,10 @@ template <int TM, int TN, int WM, int WN, int NP, bool UNAL>
 static int launch_conv_cfg(ConvArgs &a, int ks, hipStream_t st)
 {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    const size_t lds = (size_t)2 * SplitCfg<NP>::NPL * BM * 64;
+    size_t lds = (size_t)2 * SplitCfg<NP>::NPL * BM * 64;
+#ifdef LSNET_CONV_ROW_EPILOGUE
+    if (lds < (size_t)32 * (BN + 4) * 4) lds = (size_t)32 * (BN + 4) * 4;   // the epilogue's 32-pixel transpose image
+#endif
     int tiles = 0;
     for (int i = 0; i < a.nlv; ++i) {
         a.lv[i].tile0 = tiles;

@@ -412,9 +412,72 @@ __global__ __launch_bounds__(256, 2) void conv_mm_kernel(const ConvArgs a)
         __syncthreads();
     }
 
-    // ---- epilogue: lane = pixel (lane & 31) of tile i, output channels 8 g + 4 (lane >> 5) + (0..3) of tile j ----
+    // ---- epilogue ----
     const bool partial = a.ksplit > 1;
     const bool vec_ok = (a.Co & 3) == 0;
+#ifdef LSNET_CONV_ROW_EPILOGUE
+    if (vec_ok) {
+        // Experiment (not the default build).  The accumulators hold D[channel][pixel]: a lane = one pixel, four
+        // consecutive channels per register quad.  Stored from there, a wave instruction writes 32-byte pieces of 64
+        // different output rows and a 128-byte line is completed by four instructions; the counters show a fetch per
+        // written line (backward-data GEMM of the deformable family: 0.34 GB FETCHED by a kernel that reads 27 MB,
+        // beside 0.41 GB written, profiles/r3_pmc_hbm.txt).  Here each 32-pixel slab goes through LDS and is stored row
+        // by row, every line written whole.  Measured on one box (tools/r3_calls/c31.sh): network sums of the step's
+        // layer shapes 6.24 / 5.95 ms against 6.24 / 5.85 ms with the lane-per-pixel stores, step 40.94 against 40.68
+        // ms -- the extra traffic is not on the critical path, the two barriers per slab are.
+        constexpr int EROW = BN + 4;                 // floats per pixel row of the image (16-byte pad)
+        constexpr int LPR = BN / 4, RPI = 64 / LPR;  // lanes per row, rows per wave instruction
+        static_assert(LPR <= 64 && 64 % LPR == 0, "row of float4 per wave instruction");
+        const bool fin2 = !partial;                  // bias, residual and ReLU belong to the finished sum
+        float *E = reinterpret_cast<float *>(smem);
+        const int c4 = (lane % LPR) * 4;             // this lane's channels of a row
+        const int co = co_blk + c4;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (fin2 && a.bias && co < a.Co) bv = *reinterpret_cast<const float4 *>(a.bias + co);
+#pragma unroll
+        for (int slab = 0; slab < WM * TM; ++slab) {
+            if (wm == slab / TM) {                   // (wave-uniform) the waves that own this slab's pixels
+                const int i = slab % TM;
+                float *erow = E + (lane & 31) * EROW + wn * TN * 32 + 4 * (lane >> 5);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        *reinterpret_cast<float4 *>(erow + j * 32 + 8 * g) =
+                            make_float4(acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r0 = 0; r0 < 8; r0 += RPI) {    // a wave stores 8 of the slab's 32 rows
+                const int row = wave * 8 + r0 + lane / LPR;
+                const int pix = tile_p + slab * 32 + row;
+                if (pix < L.P && co < a.Co) {
+                    size_t opix = pix;
+                    if (a.ostep) {
+                        const int HWo = L.Ho * L.Wo;
+                        const int b = pix / HWo, rem = pix - b * HWo;
+                        const int ho = rem / L.Wo, wo = rem - ho * L.Wo;
+                        opix = ((size_t)b * a.OH + a.oy0 + ho * a.ostep) * a.OW + a.ox0 + wo * a.ostep;
+                    }
+                    float4 v = *reinterpret_cast<const float4 *>(E + row * EROW + c4);
+                    if (fin2) {
+                        v.x += bv.x, v.y += bv.y, v.z += bv.z, v.w += bv.w;
+                        if (L.res) {
+                            const float4 rv = *reinterpret_cast<const float4 *>(L.res + opix * a.Co + co);
+                            v.x += rv.x, v.y += rv.y, v.z += rv.z, v.w += rv.w;
+                        }
+                        if (a.relu) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+                    }
+                    float *orow = partial ? a.part + ((size_t)blockIdx.z * L.P + pix) * a.Co : L.out + opix * a.Co;
+                    *reinterpret_cast<float4 *>(orow + co) = v;
+                }
+            }
+            if (slab + 1 < WM * TM) __syncthreads();
+        }
+        return;
+    }
+#endif
+    // lane = pixel (lane & 31) of tile i, output channels 8 g + 4 (lane >> 5) + (0..3) of tile j
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int pix = tile_p + wm * TM * 32 + i * 32 + (lane & 31);

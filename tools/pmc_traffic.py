@@ -10,10 +10,15 @@ from collections import defaultdict
 
 fetch_dir, write_dir, out_json = sys.argv[1:4]
 math = sys.argv[4] if len(sys.argv) > 4 else 'bf16x6'
-FAMILY = [('dcn_fwd_', 'dcn_fwd'), ('dcn_prepare_w_kernel', 'dcn_fwd'), ('dcn_wgrad_', 'dcn_wgrad'),
+FAMILY = [('dcn_fwd_', 'dcn_fwd'), ('dcn_prepare_w_kernel', 'dcn_fwd'), ('wfrag#fwd', 'dcn_fwd'),
+          ('dcn_wgrad_', 'dcn_wgrad'), ('dcn_gout_frag', 'dcn_wgrad'), ('dcn_chunk_meta', 'dcn_wgrad'),
+          ('conv_wgrad_reduce', 'dcn_wgrad'),
           ('dcn_bwd_data', 'dcn_bwd_data'), ('dcn_gather', 'dcn_bwd_data'), ('dcn_bin', 'dcn_bwd_data'),
           ('dcn_fill', 'dcn_bwd_data'), ('dcn_sort_lists', 'dcn_bwd_data'), ('dcn_prepare_wt', 'dcn_bwd_data'),
-          ('rocprim', 'dcn_bwd_data')]
+          ('rocprim', 'dcn_bwd_data'), ('conv_mm_kernel', 'dcn_bwd_data'), ('dcn_anchor', 'dcn_bwd_data'),
+          ('dcn_offgrad', 'dcn_bwd_data'), ('conv_splitk_reduce', 'dcn_bwd_data'), ('wfrag#bwd', 'dcn_bwd_data')]
+# (round 3: the replay contains no dense convolution, so every conv_mm_kernel dispatch is the backward-data GEMM of a
+# deformable call; each call builds one weight image with conv_wfrag_kernel: forward, backward, forward, ...)
 
 
 def family(name):
@@ -39,9 +44,17 @@ def by_launch(rows):
     groups are tower launches, odd ones pyramid launches.  (Kernel names no longer appear in both kinds of launch --
     the gather has a short-list and a long-list variant -- so alternation by name is not enough.)"""
     out = defaultdict(lambda: {'tower': [], 'pyramid': []})
-    group = -1
+    group, nfrag = -1, 0
     for _, name, v in rows:
-        if 'dcn_prepare_w_kernel' in name:
+        if 'conv_wfrag' in name:   # image i: call i // 2 (a forward and a backward per launch group), forward first
+            g, name = nfrag // 2, 'conv_wfrag_kernel wfrag#' + ('fwd' if nfrag % 2 == 0 else 'bwd')
+            nfrag += 1
+            out[name]['tower' if g % 2 == 0 else 'pyramid'].append(v)
+            continue
+        if 'dcn_prepare_w_kernel' in name:   # (round-2 forward: its plane preparation precedes the forward kernel)
+            out[name]['tower' if (group + 1) % 2 == 0 else 'pyramid'].append(v)
+            continue
+        if 'dcn_fwd_' in name:
             group += 1
         if group >= 0:
             out[name]['tower' if group % 2 == 0 else 'pyramid'].append(v)
@@ -56,7 +69,7 @@ KIB = 1024 / 1e9
 fam = defaultdict(lambda: {'tower': [0.0, 0.0], 'pyramid': [0.0, 0.0]})
 print(f'{"kernel":64s} {"n":>3s} | tower: FETCHx2 + WRITE (MB) | pyramid: FETCHx2 + WRITE (MB)   (per launch of that kind)')
 # per launch of a kind = sum over the kernel's dispatches of that kind / number of launches of that kind
-prep = next(n for n in fetch if 'dcn_prepare_w_kernel' in n)
+prep = next(n for n in fetch if 'dcn_fwd_' in n)
 n_launch = {k: max(len(fetch[prep][k]), 1) for k in ('tower', 'pyramid')}
 for name in sorted(set(fetch) | set(write)):
     f, w = fetch.get(name, {'tower': [], 'pyramid': []}), write.get(name, {'tower': [], 'pyramid': []})
@@ -80,7 +93,7 @@ for fa, d in fam.items():
         'tower_fetch_write_gb': [round(v, 4) for v in d['tower']], 'pyramid_fetch_write_gb': [round(v, 4) for v in d['pyramid']],
         'note': f'rocprofv3 FETCH_SIZE x2 + WRITE_SIZE over all kernels of the family; tower launch (5 levels, 52.8 GFLOP) '
                 f'{t:.3f} GB, pyramid launch (15 pairs, 158.5 GFLOP) {p:.3f} GB, step mean (6 tower + 2 pyramid) / 8; '
-                f'profiles/r2_pmc_hbm.txt'}
+                f'profiles/r3_pmc_hbm.txt'}
     print(f'{fa}: tower {t:.3f} GB (fetch {d["tower"][0]:.3f} + write {d["tower"][1]:.3f}), pyramid {p:.3f} GB '
           f'(fetch {d["pyramid"][0]:.3f} + write {d["pyramid"][1]:.3f}); mean launch of the step {mean:.3f} GB')
 json.dump(res, open(out_json, 'w'), indent=1)
