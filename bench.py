@@ -91,11 +91,14 @@ _COMMON_NOTES = {
 }
 KERNEL_NOTES = {
     'split': dict(_COMMON_NOTES, **{
-        'dcn_fwd': 'lsn::dcn_fwd_xn_kernel (fused bilinear gather + split-bf16 MFMA implicit GEMM, forward)',
-        'dcn_bwd_data': 'lsn::dcn_bwd_data_xn_kernel + dcn_gather_kernel (gout x W^T as split-bf16 MFMA -> grad offset/mask '
-                        'and mask-weighted column gradients; grad input by an atomic-free gather over per-anchor sample '
-                        'lists: dcn_bin / scan / fill / sort_lists kernels, all inside the timed bracket)',
-        'dcn_wgrad': 'lsn::dcn_wgrad_xn_kernel (gathered columns^T x gout as split-bf16 MFMA: grad weight/bias)',
+        'dcn_fwd': 'lsn::dcn_fwd_mm_kernel (bilinear gather fused into the dense split-bf16 implicit-GEMM skeleton: two '
+                   'workgroups per CU, weights as MFMA fragments from L2)',
+        'dcn_bwd_data': 'lsn::conv_mm_kernel as a 1x1 convolution of grad_output (gout x W^T -> unweighted column gradients) '
+                        '+ dcn_anchor_sum_kernel / dcn_anchor_combine_kernel (atomic-free grad input from per-anchor sample '
+                        'lists, corner sums of grad offset/mask formed from the same rows) + dcn_offgrad_kernel; list '
+                        'building (dcn_bin / scan / fill / sort_lists) inside the timed bracket',
+        'dcn_wgrad': 'lsn::dcn_gout_frag_kernel + dcn_wgrad_mm_kernel + conv_wgrad_reduce_kernel (gathered columns^T x gout '
+                     'as split-bf16 MFMA, grad_output pre-arranged in fragment order, split partial tiles: grad weight/bias)',
     }),
     'fp32': dict(_COMMON_NOTES, **{
         'dcn_fwd': 'lsn::dcn_fwd_pipe_kernel (fused bilinear gather + fp32 MFMA implicit GEMM, forward)',
@@ -109,7 +112,8 @@ MATH_NOTES = {
               'rounding of an fp32 product), fp32 accumulation: fp32-equivalent, <= 1e-6 of the output range against the '
               'exact-fp32 MFMA kernels (tests/test_ops_gpu.py::test_split6_matches_exact_fp32)',
     'bf16x3': 'fp32 tensors; products as 3 bf16 MFMA terms of 2-way splits (hh+hl+lh), fp32 accumulation, rel. err 5e-6',
-    'fp32': 'exact fp32 MFMA for the deformable family, MIOpen fp32 for dense convolutions',
+    'fp32': 'exact fp32 MFMA for the deformable family; dense convolutions on the 6-term split kernels (fp32-equivalent): no '
+            'vendor convolution in any mode',
 }
 
 

@@ -74,9 +74,10 @@ typedef struct {
                         * conv_offset output to the op as ONE tensor (offset = first 2/3 of the channels,
                         * mask = last 1/3, deform_conv.py:527-530) and get ONE gradient tensor back. */
     void *workspace;   /* optional device scratch of >= Co*kh*kw*(C/groups)*8 bytes: in the split-bf16 math modes
-                        * the pre-split (backward: also transposed) weight planes go there and the matrix-pipe
-                        * kernels run; NULL: weights are split inside every block (forward) / the fp32 MFMA
-                        * backward-data kernel runs.  Contents undefined afterwards. */
+                        * the call's weight image goes there (MFMA fragment order for the shapes the kernels of
+                        * csrc/dcn_mm_kernels.h serve, pre-split -- backward: also transposed -- bf16 planes
+                        * otherwise) and the matrix-pipe kernels run; NULL: weights are split inside every block
+                        * (forward) / the fp32 MFMA backward-data kernel runs.  Contents undefined afterwards. */
     void *gather_workspace;          /* optional device scratch for lsn_dcn_backward's atomic-free grad_input path */
     int64_t gather_workspace_bytes;  /* (>= lsn_dcn_backward_workspace_bytes()); NULL / too small: fp32 atomics.   */
     int accumulate_param_grads;      /* lsn_dcn_backward: 1 = ADD grad_weight / grad_bias to the buffers' contents (see
@@ -132,10 +133,12 @@ int lsn_dcn_backward(const lsn_dcn_shape *shape, int n_levels, const lsn_dcn_lev
                      const float *weight, float *grad_weight, float *grad_bias, lsn_layout layout,
                      lsn_stream_t stream);
 
-/* Bytes of `gather_workspace` that let lsn_dcn_backward form grad_input without atomics (per-anchor sample lists +
- * a column-gradient buffer of sum(B*Ho*Wo) * kh*kw * C floats, written and read once); 0 when that path does not
- * apply to the shape (groups > 1, Co > 256, exact-fp32 mode, no grad_input requested).  Levels whose grad_input
- * pointers are EQUAL accumulate into that one buffer (several offset fields sampling one source map). */
+/* Bytes of `gather_workspace` that let lsn_dcn_backward form grad_input without atomics (per-anchor sample lists, a
+ * column-gradient buffer of sum(B*Ho*Wo) * kh*kw * C floats written and read once, per-anchor corner sums and the
+ * corner products of the offset / mask gradients); 0 when that path does not apply to the shape (groups > 1,
+ * exact-fp32 mode, no grad_input requested).  Levels whose grad_input pointers are EQUAL accumulate into that one
+ * buffer (several offset fields sampling one source map).  With this scratch the whole backward pass -- grad_input,
+ * grad_offset, grad_mask, grad_weight, grad_bias -- is free of floating-point atomics: bit-identical run to run. */
 int64_t lsn_dcn_backward_workspace_bytes(const lsn_dcn_shape *shape, int n_levels, const lsn_dcn_level *levels);
 
 /* ---- one-to-one replacements of the reference extension's functions ----------------------- */
@@ -251,7 +254,7 @@ int lsn_nms(const float *dets, const int64_t *order, int n, float iou_thr, int64
  * forward_pitched: the row-merged form for shallow inputs (the 7x7 stem on 3(+1) channels): `xpitch` floats separate
  * adjacent pixels while a tap spans C = n * xpitch consecutive floats (n pixels of the same row), kw = 1, pad = 0;
  * w is (Co, kh, 1, C) = the memory image of a (Co, kh, n, xpitch) weight.  The caller pads the image spatially. */
-/* Batched forms: up to 8 input maps of different sizes that share one weight (the FPN levels under LSHead's shared
+/* Batched forms: up to 16 input maps of different sizes that share one weight (the FPN levels under LSHead's shared
  * convolutions, lsnet_head.py:502-513) in ONE launch each way.  forward: x -> out.  backward_data: x = grad_out
  * (B,Ho,Wo,Co), out = grad_in (B,H,W,C), and B/H/W are the forward INPUT sizes; stride 1 when n_levels > 1.
  * backward_weight: x = forward input, grad_out; the weight / bias gradients are summed over the levels. */
