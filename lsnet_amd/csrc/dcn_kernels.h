@@ -184,16 +184,6 @@ __device__ __forceinline__ float row16_sum(float v)
 }
 #undef LSN_DPP_ADD
 
-// compile-time loop: f(std::integral_constant<int, I>) for I in [I0, N)
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F &&f)
-{
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-
 // Branch-free guarded load of 4 consecutive floats p[0..3] of which the first `rem` (may be <= 0)
 // are valid.  hipcc turns `if (cond) v = *ptr` into a branch with a full vmcnt(0) wait per load
 // (cdna_hip_programming.md section 5, trap (c)), which serialises a staging phase into dependent L2
@@ -1819,7 +1809,6 @@ __global__ __launch_bounds__(256) void dcn_sort_lists_kernel(int nanchors, const
 // that corner's input pixel (the H sums of grad_offset / grad_mask, dcn_offgrad_kernel): the row is in registers anyway.
 // Fixed order: anchors row-major, entries by sample id.
 constexpr int GT = 4;   // block edge
-constexpr int GU1 = 4, GU4 = 4;   // column-gradient rows a wave keeps in flight (NW = 1, NW = 4)
 // NW = 1: one wave per 4x4 pixel block (four blocks per workgroup) -- short lists, e.g. the tower launch with ~140 entries
 //   per block.
 // NW = 4: one workgroup per pixel block.  Its four waves share the block's entries -- wave w takes every 4th group of GU
