@@ -276,8 +276,18 @@ typedef struct lsn_conv_wprep {
     const float *w;
     void *prepared;
     int C, Co, kh, kw, stride, pad, dil;
+    /* Optional (kind 0 only; all NULL otherwise): an eval-mode BatchNorm behind the convolution, folded into the image.
+     * Every weight of output channel co is multiplied by a[co] = bn_gamma[co] / sqrt(bn_var[co] + bn_eps), and
+     * shift_out[co] = bn_beta[co] - bn_mean[co] * a[co] (Co floats) is written for the `bias` argument of
+     * lsn_conv2d_forward_prepared: relu(bn(conv(x)) + residual) of a ResNet block (resnet.py:261-301) is then ONE launch,
+     * with the affine parameters still trainable (lsn_bn_eval_act_backward_folded gives their gradients). */
+    const float *bn_gamma, *bn_var, *bn_beta, *bn_mean;
+    float *shift_out;
+    float bn_eps;
 } lsn_conv_wprep;
 int lsn_conv2d_prepare_weights_multi(int n_items, const lsn_conv_wprep *items, lsn_stream_t stream);
+/* One item, launched directly (no job table: usable while a hipGraph is being captured). */
+int lsn_conv2d_prepare_weights_item(const lsn_conv_wprep *item, lsn_stream_t stream);
 int lsn_conv2d_forward_prepared(int n_levels, const lsn_conv_level *levels, const void *prepared, const float *bias,
                                 int C, int xpitch, int Co, int kh, int kw, int stride, int pad, int dil, int relu,
                                 lsn_stream_t stream);
@@ -371,6 +381,18 @@ int lsn_bn_eval_act_backward(const float *grad_y, const float *y, const float *x
                              const float *running_var, const float *gamma, float eps, int relu, float *grad_x,
                              float *grad_residual, float *grad_gamma, float *grad_beta, void *workspace, int N,
                              int C, int accumulate, lsn_stream_t stream);
+/* Backward of the FOLDED form y = act(conv(x, w a) + b (+ residual)) (lsn_conv_wprep: the BatchNorm rides in the
+ * convolution, whose raw output is never stored): same results as above with x_hat taken from y -- where the gate is
+ * open, (conv - mean_c) / sqrt(var_c + eps) = (y - residual - beta_c) / gamma_c; where it is closed dz = 0.  `y` is
+ * always needed, `residual` when it was added and grad_gamma is wanted.  grad_x is the gradient w.r.t. the RAW
+ * convolution output (dz a_c): feed it to lsn_conv2d_backward_data / _backward_weight with the UNscaled weight.  A
+ * channel with gamma_c == 0 gets grad_gamma_c = 0 (its x_hat is not recoverable from y).  Parameter gradients of both
+ * entry points are summed in a fixed order: bit-identical run to run. */
+int lsn_bn_eval_act_backward_folded(const float *grad_y, const float *y, const float *residual,
+                                    const float *running_var, const float *gamma, const float *beta, float eps,
+                                    int relu, float *grad_x, float *grad_residual, float *grad_gamma,
+                                    float *grad_beta, void *workspace, int N, int C, int accumulate,
+                                    lsn_stream_t stream);
 
 /* ---- diagnostics ---------------------------------------------------------------------------- */
 /* When set to a device buffer of 512 int64 (NULL disables), thread 0 of workgroup `block` of the

@@ -44,7 +44,9 @@ class ConvLevel(ctypes.Structure):
 class ConvWprep(ctypes.Structure):
     _fields_ = [('kind', ctypes.c_int), ('w', ctypes.c_void_p), ('prepared', ctypes.c_void_p), ('C', ctypes.c_int),
                 ('Co', ctypes.c_int), ('kh', ctypes.c_int), ('kw', ctypes.c_int), ('stride', ctypes.c_int),
-                ('pad', ctypes.c_int), ('dil', ctypes.c_int)]
+                ('pad', ctypes.c_int), ('dil', ctypes.c_int),
+                ('bn_gamma', ctypes.c_void_p), ('bn_var', ctypes.c_void_p), ('bn_beta', ctypes.c_void_p),
+                ('bn_mean', ctypes.c_void_p), ('shift_out', ctypes.c_void_p), ('bn_eps', ctypes.c_float)]
 
 
 class GnLevel(ctypes.Structure):
@@ -71,11 +73,13 @@ EXPORTS = [
     'lsn_group_norm_workspace_bytes', 'lsn_group_norm_forward', 'lsn_group_norm_backward',
     'lsn_set_math_mode', 'lsn_get_math_mode', 'lsn_conv2d_forward', 'lsn_conv2d_forward_pitched', 'lsn_conv2d_backward_data',
     'lsn_conv2d_prepared_bytes', 'lsn_conv2d_prepare_weights', 'lsn_conv2d_prepare_weights_multi',
+    'lsn_conv2d_prepare_weights_item',
     'lsn_conv2d_forward_prepared',
     'lsn_conv2d_backward_data_prepared',
     'lsn_conv2d_forward_multi', 'lsn_conv2d_backward_data_multi', 'lsn_conv2d_backward_weight_multi', 'lsn_conv2d_backward_weight',
     'lsn_grouped_conv2d_forward', 'lsn_grouped_conv2d_backward_data', 'lsn_grouped_conv2d_backward_weight',
     'lsn_bn_eval_act_forward', 'lsn_bn_eval_act_backward', 'lsn_bn_eval_act_workspace_bytes',
+    'lsn_bn_eval_act_backward_folded',
     'lsn_image_prep_u8', 'lsn_cross_iou_bbox_forward', 'lsn_cross_iou_bbox_backward',
     'lsn_cross_iou_bbox_stage_forward', 'lsn_cross_iou_bbox_stage_backward',
     'lsn_cross_iou_rows_forward', 'lsn_cross_iou_rows_backward',

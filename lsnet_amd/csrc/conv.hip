@@ -165,15 +165,32 @@ int conv_mm_rows(int n, const float *const *x, float *const *out, const int *row
     return conv_forward(a, st);
 }
 
-static void conv_wfrag(const float *w, unsigned short *out, int Co, int K, int C, int flipT, const TapSub &ts, hipStream_t st)
+// optional folded BatchNorm of a prepare call (all NULL: a plain weight)
+struct BnFold {
+    const float *gamma = nullptr, *var = nullptr, *beta = nullptr, *mean = nullptr;
+    float *shift_out = nullptr;
+    float eps = 0.f;
+};
+
+static void wfrag_job(WfragJob &j, const float *w, unsigned short *out, int Co, int K, int C, int flipT, const TapSub &ts,
+                      const BnFold &bn)
 {
-    const int Kd = flipT ? ts.ni * ts.nj : K;
-    const long long total = (long long)Kd * cv_ncc(C) * cv_nt(Co) * 2 * 64;
+    j = WfragJob{};
+    j.w = w, j.out = out, j.Co = Co, j.K = K, j.C = C, j.flipT = flipT, j.ts = ts;
+    j.bn_gamma = bn.gamma, j.bn_var = bn.var, j.bn_beta = bn.beta, j.bn_mean = bn.mean, j.shift_out = bn.shift_out, j.bn_eps = bn.eps;
+}
+
+static void conv_wfrag(const float *w, unsigned short *out, int Co, int K, int C, int flipT, const TapSub &ts, hipStream_t st,
+                       const BnFold &bn = BnFold())
+{
+    WfragJob j;
+    wfrag_job(j, w, out, Co, K, C, flipT, ts, bn);
+    const long long total = wfrag_threads(j);
     const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
     if (conv_npl() == 2)
-        hipLaunchKernelGGL(conv_wfrag_kernel<2>, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, st, w, out, Co, K, C, flipT, ts);
+        hipLaunchKernelGGL(conv_wfrag_kernel<2>, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, st, j);
     else
-        hipLaunchKernelGGL(conv_wfrag_kernel<3>, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, st, w, out, Co, K, C, flipT, ts);
+        hipLaunchKernelGGL(conv_wfrag_kernel<3>, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, st, j);
 }
 
 // prof.h span of one launch: 2 P Co C K flops; every operand once (the strided backward-data pass counts grad_out once
@@ -375,15 +392,26 @@ static int64_t prepared_bytes(int kind, int C, int Co, int kh, int kw, int strid
     return (int64_t)pl.bytes;
 }
 
+static int bn_fold_of(const lsn_conv_wprep &p, BnFold *bn)
+{
+    *bn = BnFold();
+    if (!p.bn_gamma) return 0;
+    LSN_CHECK(p.kind == 0, "conv2d prepare: a BatchNorm is folded into the FORWARD image only");
+    LSN_CHECK(p.bn_var && p.bn_beta && p.bn_mean && p.shift_out, "conv2d prepare: incomplete BatchNorm description");
+    bn->gamma = p.bn_gamma, bn->var = p.bn_var, bn->beta = p.bn_beta, bn->mean = p.bn_mean, bn->shift_out = p.shift_out;
+    bn->eps = p.bn_eps;
+    return 0;
+}
+
 static int prepare_weights(int kind, const float *w, void *prepared, int C, int Co, int kh, int kw, int stride, int pad,
-                           int dil, hipStream_t st)
+                           int dil, hipStream_t st, const BnFold &bn = BnFold())
 {
     LSN_CHECK(w && prepared, "conv2d prepare: NULL pointer");
     LSN_CHECK(C > 0 && Co > 0 && kh > 0 && kw > 0 && kh * kw <= 64, "conv2d prepare: bad weight shape");
     if (prepared_bytes(kind, C, Co, kh, kw, stride, pad, dil) >= ((int64_t)1 << 31))
         return fail(LSN_ERR_UNSUPPORTED, "conv2d: weight too large for 32-bit buffer offsets");
     if (kind == 0) {
-        conv_wfrag(w, reinterpret_cast<unsigned short *>(prepared), Co, kh * kw, C, 0, TapSub{}, st);
+        conv_wfrag(w, reinterpret_cast<unsigned short *>(prepared), Co, kh * kw, C, 0, TapSub{}, st, bn);
     } else {
         BwdPlan pl;
         if (int rc = bwd_plan(C, Co, kh, kw, stride, pad, dil, &pl)) return rc;
@@ -526,20 +554,23 @@ static int prepare_weights_multi(int n, const lsn_conv_wprep *it, hipStream_t st
                   "conv2d prepare: bad item %d", i);
         if (prepared_bytes(p.kind, p.C, p.Co, p.kh, p.kw, p.stride, p.pad, p.dil) >= ((int64_t)1 << 31))
             return fail(LSN_ERR_UNSUPPORTED, "conv2d: weight too large for 32-bit buffer offsets");
+        BnFold bn;
+        if (int rc = bn_fold_of(p, &bn)) return rc;
         if (p.kind == 0) {
-            WfragJob j = {};
-            j.w = p.w, j.out = reinterpret_cast<unsigned short *>(p.prepared);
-            j.Co = p.Co, j.K = p.kh * p.kw, j.C = p.C, j.flipT = 0, j.start = total;
-            total += (long long)j.K * cv_ncc(j.C) * cv_nt(j.Co) * 2 * 64;
+            WfragJob j;
+            wfrag_job(j, p.w, reinterpret_cast<unsigned short *>(p.prepared), p.Co, p.kh * p.kw, p.C, 0, TapSub{}, bn);
+            j.start = total;
+            total += wfrag_threads(j);
             jobs.push_back(j);
         } else {
             BwdPlan pl;
             if (int rc = bwd_plan(p.C, p.Co, p.kh, p.kw, p.stride, p.pad, p.dil, &pl)) return rc;
             for (int c = 0; c < pl.ncls; ++c) {
-                WfragJob j = {};
-                j.w = p.w, j.out = reinterpret_cast<unsigned short *>(reinterpret_cast<unsigned char *>(p.prepared) + pl.cls[c].wf_off);
-                j.Co = p.C, j.K = p.kh * p.kw, j.C = p.Co, j.flipT = 1, j.ts = pl.cls[c].ts, j.start = total;
-                total += (long long)j.ts.ni * j.ts.nj * cv_ncc(j.C) * cv_nt(j.Co) * 2 * 64;
+                WfragJob j;
+                wfrag_job(j, p.w, reinterpret_cast<unsigned short *>(reinterpret_cast<unsigned char *>(p.prepared) + pl.cls[c].wf_off),
+                          p.C, p.kh * p.kw, p.Co, 1, pl.cls[c].ts, BnFold());
+                j.start = total;
+                total += wfrag_threads(j);
                 jobs.push_back(j);
             }
         }
@@ -588,6 +619,15 @@ int lsn_conv2d_prepare_weights(int kind, const float *w, void *prepared, int C, 
                                int pad, int dil, lsn_stream_t stream)
 {
     return lsn::prepare_weights(kind, w, prepared, C, Co, kh, kw, stride, pad, dil, reinterpret_cast<hipStream_t>(stream));
+}
+
+int lsn_conv2d_prepare_weights_item(const lsn_conv_wprep *item, lsn_stream_t stream)
+{
+    LSN_CHECK(item != nullptr, "conv2d prepare: NULL item");
+    lsn::BnFold bn;
+    if (int rc = lsn::bn_fold_of(*item, &bn)) return rc;
+    return lsn::prepare_weights(item->kind, item->w, item->prepared, item->C, item->Co, item->kh, item->kw, item->stride,
+                                item->pad, item->dil, reinterpret_cast<hipStream_t>(stream), bn);
 }
 
 int lsn_conv2d_forward_prepared(int n_levels, const lsn_conv_level *levels, const void *prepared, const float *bias, int C,

@@ -74,15 +74,35 @@ __host__ __device__ inline size_t cv_wfrag_bytes(int Co, int Kd, int C, int npl)
     return (size_t)Kd * cv_ncc(C) * cv_nt(Co) * 2 * npl * 1024;
 }
 
-// w -> fragment order.  GEMM view of the convolution the main kernel runs: output column n (< Co), reduction index
-// (tap, c) with c < C.  flipT = 0: Wt[n][tap][c] = w[(n * K + tap) * C + c].  flipT = 1 (backward-data): the source is the
-// forward weight (Cs = C of this GEMM = forward Co... see conv.hip), Wt[n][tap'][c] = w[(c * K + tap(tap')) * Co + n] with
-// the tap subset reversed.  Element (t, nt, ks, q, lane, e): n = nt * 32 + (lane & 31), k = ks * 16 + 8 * (lane >> 5) + e,
-// value = plane q of Wt[n][tap(t)][cc(t) * 32 + k] (0 beyond Co / C).
+// One weight -> fragment order.  GEMM view of the convolution the main kernel runs: output column n (< Co), reduction
+// index (tap, c) with c < C.  flipT = 0: Wt[n][tap][c] = w[(n * K + tap) * C + c].  flipT = 1 (backward-data): the source is
+// the forward weight (this GEMM's C = forward Co), Wt[n][tap'][c] = w[(c * K + tap(tap')) * Co + n] with the tap subset
+// reversed.  Element (t, nt, ks, q, lane, e): n = nt * 32 + (lane & 31), k = ks * 16 + 8 * (lane >> 5) + e, value = plane q
+// of Wt[n][tap(t)][cc(t) * 32 + k] (0 beyond Co / C).
+// Optional per-output-channel scale of an eval-mode BatchNorm folded into the convolution (bn_gamma != NULL): every
+// weight of FORWARD output channel co is multiplied by gamma[co] / sqrt(var[co] + eps) on the way, and (shift_out != NULL)
+// shift[co] = beta[co] - mean[co] * that scale is written for the convolution's bias slot.
+struct WfragJob {
+    const float *w;
+    unsigned short *out;
+    int Co, K, C, flipT;
+    TapSub ts;
+    long long start;     // first thread id of this job in a multi-job launch
+    const float *bn_gamma, *bn_var, *bn_beta, *bn_mean;
+    float *shift_out;
+    float bn_eps;
+};
+
 template <int NPL>
-__device__ __forceinline__ void wfrag_item(const float *__restrict__ w, unsigned short *__restrict__ out, int Co, int K,
-                                           int C, int flipT, const TapSub &ts, long long id)
+__device__ __forceinline__ void wfrag_item(const WfragJob &jb, long long id)
 {
+    const float *__restrict__ w = jb.w;
+    const int Co = jb.Co, K = jb.K, C = jb.C, flipT = jb.flipT;
+    const TapSub &ts = jb.ts;
+    if (jb.shift_out != nullptr && id < (flipT ? C : Co)) {   // (a launch has at least 128 threads per 32 output columns)
+        const int co = (int)id;
+        jb.shift_out[co] = jb.bn_beta[co] - jb.bn_mean[co] * (jb.bn_gamma[co] * rsqrtf(jb.bn_var[co] + jb.bn_eps));
+    }
     const int ncc = cv_ncc(C), NT = cv_nt(Co);
     const int lane = (int)(id & 63);
     long long r = id >> 6;
@@ -99,46 +119,46 @@ __device__ __forceinline__ void wfrag_item(const float *__restrict__ w, unsigned
         const int c = c0 + e;
         float val = 0.f;
         if (n < Co && c < C) {
+            int cof;   // forward output channel of this weight
             if (!flipT) {
                 val = w[((size_t)n * K + tap) * C + c];
+                cof = n;
             } else {
                 // transposed convolution: this GEMM's (n, c) = forward (ci, co); source layout (Co_f = C, K, C_f = Co)
                 const int m = tap / ts.nj, nn = tap - m * ts.nj;
                 const int i = ts.i0 + (ts.ni - 1 - m) * ts.istep, j = ts.j0 + (ts.nj - 1 - nn) * ts.jstep;
                 val = w[((size_t)c * K + i * ts.kw + j) * Co + n];
+                cof = c;
             }
+            if (jb.bn_gamma != nullptr) val *= jb.bn_gamma[cof] * rsqrtf(jb.bn_var[cof] + jb.bn_eps);
         }
         v[e] = val;
     }
     unsigned pl[4][NPL];
 #pragma unroll
     for (int e = 0; e < 4; ++e) split_planes<NPL>(v[2 * e], v[2 * e + 1], pl[e]);
-    unsigned short *dst = out + ((((size_t)t * NT + nt) * 2 + ks) * NPL) * 512 + (size_t)lane * 8;
+    unsigned short *dst = jb.out + ((((size_t)t * NT + nt) * 2 + ks) * NPL) * 512 + (size_t)lane * 8;
 #pragma unroll
     for (int q = 0; q < NPL; ++q)
         *reinterpret_cast<uint4 *>(dst + (size_t)q * 512) = make_uint4(pl[0][q], pl[1][q], pl[2][q], pl[3][q]);
 }
 
-template <int NPL>
-__global__ void conv_wfrag_kernel(const float *__restrict__ w, unsigned short *__restrict__ out, int Co, int K, int C,
-                                  int flipT, TapSub ts)
+__host__ __device__ inline long long wfrag_threads(const WfragJob &jb)
 {
-    const int Kd = flipT ? ts.ni * ts.nj : K;
-    const long long total = (long long)Kd * cv_ncc(C) * cv_nt(Co) * 2 * 64;   // one thread per (t, nt, ks, lane)
+    const int Kd = jb.flipT ? jb.ts.ni * jb.ts.nj : jb.K;
+    return (long long)Kd * cv_ncc(jb.C) * cv_nt(jb.Co) * 2 * 64;   // one thread per (t, nt, ks, lane)
+}
+
+template <int NPL>
+__global__ void conv_wfrag_kernel(const WfragJob jb)
+{
+    const long long total = wfrag_threads(jb);
     for (long long id = blockIdx.x * (long long)blockDim.x + threadIdx.x; id < total; id += (long long)gridDim.x * blockDim.x)
-        wfrag_item<NPL>(w, out, Co, K, C, flipT, ts, id);
+        wfrag_item<NPL>(jb, id);
 }
 
 // Many weights in ONE launch (the images of every trainable convolution after an optimizer step): job j owns the
 // thread ids [start_j, start_{j+1}).
-struct WfragJob {
-    const float *w;
-    unsigned short *out;
-    int Co, K, C, flipT;
-    TapSub ts;
-    long long start;
-};
-
 template <int NPL>
 __global__ void conv_wfrag_multi_kernel(const WfragJob *__restrict__ jobs, int njobs, long long total)
 {
@@ -149,7 +169,7 @@ __global__ void conv_wfrag_multi_kernel(const WfragJob *__restrict__ jobs, int n
             if (jobs[mid].start <= id) lo = mid; else hi = mid - 1;
         }
         const WfragJob jb = jobs[lo];
-        wfrag_item<NPL>(jb.w, jb.out, jb.Co, jb.K, jb.C, jb.flipT, jb.ts, id - jb.start);
+        wfrag_item<NPL>(jb, id - jb.start);
     }
 }
 

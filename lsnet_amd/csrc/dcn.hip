@@ -293,13 +293,15 @@ static int mm_prepare_weights(DcnArgs &a, bool backward, void *dst, hipStream_t 
     const int K = a.kh * a.kw;
     const int Co = backward ? K * a.C : a.Co, Kd = backward ? 1 : K, C = backward ? a.Co : a.C;
     TapSub ts = {0, 1, 1, 0, 1, 1, 1};
-    const long long total = (long long)Kd * cv_ncc(C) * cv_nt(Co) * 2 * 64;
-    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     unsigned short *out = reinterpret_cast<unsigned short *>(dst);
+    WfragJob j = {};
+    j.w = a.w, j.out = out, j.Co = Co, j.K = Kd, j.C = C, j.flipT = backward ? 1 : 0, j.ts = ts;
+    const long long total = wfrag_threads(j);
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     if (mm_npl() == 3)
-        hipLaunchKernelGGL(conv_wfrag_kernel<3>, dim3(blocks), dim3(256), 0, st, a.w, out, Co, Kd, C, backward ? 1 : 0, ts);
+        hipLaunchKernelGGL(conv_wfrag_kernel<3>, dim3(blocks), dim3(256), 0, st, j);
     else
-        hipLaunchKernelGGL(conv_wfrag_kernel<2>, dim3(blocks), dim3(256), 0, st, a.w, out, Co, Kd, C, backward ? 1 : 0, ts);
+        hipLaunchKernelGGL(conv_wfrag_kernel<2>, dim3(blocks), dim3(256), 0, st, j);
     LSN_HIP(hipGetLastError());
     a.wtp = out;
     a.wtp_bytes = (int)cv_wfrag_bytes(Co, Kd, C, mm_npl());

@@ -299,7 +299,7 @@ static int gn_fill(GnArgs &a, int n, const lsn_gn_level *lv, int C, int G, int *
 // end in one fp32 atomic per channel and block.
 // ---------------------------------------------------------------------------------------------------------
 struct BnArgs {
-    const float *x, *res, *dy, *y_in;
+    const float *x, *res, *dy, *y_in;   // backward with x == NULL: "folded" form, x_hat from y (see lsn_bn_eval_act_backward_folded)
     float *y, *dx, *dres;
     const float *mean, *var, *gamma, *beta;
     float *dgamma, *dbeta;
@@ -348,23 +348,39 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const BnArgs a)
     const float r0 = rsqrtf(va.x + a.eps), r1 = rsqrtf(va.y + a.eps), r2 = rsqrtf(va.z + a.eps),
                 r3 = rsqrtf(va.w + a.eps);
     const float a0 = ga.x * r0, a1 = ga.y * r1, a2 = ga.z * r2, a3 = ga.w * r3;
+    // folded form (a.x == NULL): the convolution wrote y = act(a_c conv + b_c (+ res)) directly and its raw output was
+    // never stored.  Where the gate is open, x_hat = (conv - mean) rstd = (y - res - beta) / gamma; where it is closed
+    // dz = 0 and the value does not matter.  `mu` then holds beta and the final factor is 1 / gamma instead of rstd.
+    const bool folded = a.beta != nullptr;   // (only the folded entry point passes beta to the backward kernel)
+    float4 be = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (folded) be = *reinterpret_cast<const float4 *>(a.beta + q * 4);
     float sg[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
     const int p0 = blockIdx.x * BN_PIX, p1 = min(p0 + BN_PIX, a.N);
 #pragma unroll 4
     for (int px = p0 + row; px < p1; px += rows) {
         const size_t o = (size_t)px * a.C + q * 4;
         float4 d = *reinterpret_cast<const float4 *>(a.dy + o);
+        float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.relu || (folded && a.dgamma)) y = *reinterpret_cast<const float4 *>(a.y_in + o);
         if (a.relu) {
-            const float4 y = *reinterpret_cast<const float4 *>(a.y_in + o);
             d.x = y.x > 0.f ? d.x : 0.f, d.y = y.y > 0.f ? d.y : 0.f, d.z = y.z > 0.f ? d.z : 0.f,
             d.w = y.w > 0.f ? d.w : 0.f;
         }
         if (a.dres) *reinterpret_cast<float4 *>(a.dres + o) = d;
         if (a.dx) *reinterpret_cast<float4 *>(a.dx + o) = make_float4(d.x * a0, d.y * a1, d.z * a2, d.w * a3);
         if (a.dgamma) {
-            const float4 v = *reinterpret_cast<const float4 *>(a.x + o);
-            sg[0] += d.x * (v.x - mu.x), sg[1] += d.y * (v.y - mu.y), sg[2] += d.z * (v.z - mu.z),
-                sg[3] += d.w * (v.w - mu.w);
+            float4 v;
+            if (!folded) {
+                v = *reinterpret_cast<const float4 *>(a.x + o);
+                v.x -= mu.x, v.y -= mu.y, v.z -= mu.z, v.w -= mu.w;
+            } else {
+                v = make_float4(y.x - be.x, y.y - be.y, y.z - be.z, y.w - be.w);
+                if (a.res) {
+                    const float4 e = *reinterpret_cast<const float4 *>(a.res + o);
+                    v.x -= e.x, v.y -= e.y, v.z -= e.z, v.w -= e.w;
+                }
+            }
+            sg[0] += d.x * v.x, sg[1] += d.y * v.y, sg[2] += d.z * v.z, sg[3] += d.w * v.w;
             sb[0] += d.x, sb[1] += d.y, sb[2] += d.z, sb[3] += d.w;
         }
     }
@@ -384,27 +400,60 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const BnArgs a)
         // per-block partials, summed by bn_param_reduce_kernel: thousands of blocks adding atomically to the same
         // 2 C addresses cost more than the streaming pass itself (C = 64: 230 us against 50 us of traffic)
         float *dst = a.part + (size_t)blockIdx.x * 2 * a.C + (qb + threadIdx.x) * 4;
-        *reinterpret_cast<float4 *>(dst) = make_float4(t[0] * r0, t[1] * r1, t[2] * r2, t[3] * r3);
+        float f0 = r0, f1 = r1, f2 = r2, f3 = r3;
+        if (folded) {   // (gamma == 0: the channel's output does not depend on the convolution; its x_hat is not recoverable)
+            f0 = ga.x != 0.f ? 1.f / ga.x : 0.f, f1 = ga.y != 0.f ? 1.f / ga.y : 0.f;
+            f2 = ga.z != 0.f ? 1.f / ga.z : 0.f, f3 = ga.w != 0.f ? 1.f / ga.w : 0.f;
+        }
+        *reinterpret_cast<float4 *>(dst) = make_float4(t[0] * f0, t[1] * f1, t[2] * f2, t[3] * f3);
         *reinterpret_cast<float4 *>(dst + a.C) = make_float4(t[4], t[5], t[6], t[7]);
     }
 }
 
-// dgamma[c] = sum_blocks part[b][c], dbeta[c] = sum_blocks part[b][C + c]; grid.y splits the block range
-__global__ __launch_bounds__(256) void bn_param_reduce_kernel(const BnArgs a, int blocks)
+// dgamma[c] (+)= sum_blocks part[b][c], dbeta[c] (+)= sum_blocks part[b][C + c].  A workgroup owns 32 of the 2 C partial
+// columns; its eight groups of 32 threads take every eighth block each and meet in LDS in a fixed order: no atomics, the
+// same bits on every run (round 2 split the block range over grid.y and met in fp32 atomics).
+__global__ __launch_bounds__(256) void bn_param_reduce_kernel(const BnArgs a, int blocks, int accumulate)
 {
-    const int c = blockIdx.x * 256 + threadIdx.x;   // index into the 2 C partial columns
-    if (c >= 2 * a.C) return;
-    const int b0 = (int)((long long)blocks * blockIdx.y / gridDim.y), b1 = (int)((long long)blocks * (blockIdx.y + 1) / gridDim.y);
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int b = b0;
-    for (; b + 3 < b1; b += 4) {
-        s0 += a.part[(size_t)b * 2 * a.C + c];
-        s1 += a.part[(size_t)(b + 1) * 2 * a.C + c];
-        s2 += a.part[(size_t)(b + 2) * 2 * a.C + c];
-        s3 += a.part[(size_t)(b + 3) * 2 * a.C + c];
+    __shared__ float red[8][32];
+    const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + col;   // index into the 2 C partial columns
+    float s0 = 0.f, s1 = 0.f;
+    if (c < 2 * a.C) {
+        int b = grp;
+        for (; b + 8 < blocks; b += 16) {
+            s0 += a.part[(size_t)b * 2 * a.C + c];
+            s1 += a.part[(size_t)(b + 8) * 2 * a.C + c];
+        }
+        if (b < blocks) s0 += a.part[(size_t)b * 2 * a.C + c];
     }
-    for (; b < b1; ++b) s0 += a.part[(size_t)b * 2 * a.C + c];
-    atomic_add_f32((c < a.C ? a.dgamma : a.dbeta - a.C) + c, (s0 + s1) + (s2 + s3));
+    red[grp][col] = s0 + s1;
+    __syncthreads();
+    if (grp == 0 && c < 2 * a.C) {
+        const float s = ((red[0][col] + red[1][col]) + (red[2][col] + red[3][col])) +
+                        ((red[4][col] + red[5][col]) + (red[6][col] + red[7][col]));
+        float *dst = (c < a.C ? a.dgamma : a.dbeta - a.C) + c;
+        *dst = accumulate ? *dst + s : s;
+    }
+}
+
+static int bn_check(int N, int C);
+
+// shared tail of the two backward entry points; `reads`: tensors of N x C floats the kernel reads
+static int bn_backward_launch(BnArgs &a, void *workspace, int accumulate, int reads, hipStream_t st)
+{
+    const int N = a.N, C = a.C;
+    const int blocks = (N + BN_PIX - 1) / BN_PIX;
+    if (a.dgamma) {
+        LSN_CHECK(workspace != nullptr, "batch norm backward: grad_gamma needs the workspace");
+        a.part = reinterpret_cast<float *>(workspace);
+    }
+    ProfSpan prof(PROF_NORM, 6.0 * N * C, 4.0 * N * C * (reads + (a.dx ? 1 : 0) + (a.dres ? 1 : 0)), st);
+    hipLaunchKernelGGL(bn_act_bwd_kernel, dim3(blocks, (C / 4 + 255) / 256), dim3(256), 0, st, a);
+    if (a.dgamma)
+        hipLaunchKernelGGL(bn_param_reduce_kernel, dim3((2 * C + 31) / 32), dim3(256), 0, st, a, blocks, accumulate ? 1 : 0);
+    LSN_HIP(hipGetLastError());
+    return 0;
 }
 
 static int bn_check(int N, int C)
@@ -525,24 +574,24 @@ int lsn_bn_eval_act_backward(const float *grad_y, const float *y, const float *x
     a.dy = grad_y, a.y_in = y, a.x = x, a.mean = running_mean, a.var = running_var, a.gamma = gamma;
     a.dx = grad_x, a.dres = grad_residual, a.dgamma = grad_gamma, a.dbeta = grad_beta;
     a.eps = eps, a.N = N, a.C = C, a.relu = relu;
-    const int blocks = (N + BN_PIX - 1) / BN_PIX;
-    if (grad_gamma) {
-        LSN_CHECK(workspace != nullptr, "batch norm backward: grad_gamma needs the workspace");
-        a.part = reinterpret_cast<float *>(workspace);
-        if (!accumulate) {
-            LSN_HIP(hipMemsetAsync(grad_gamma, 0, sizeof(float) * C, st));
-            LSN_HIP(hipMemsetAsync(grad_beta, 0, sizeof(float) * C, st));
-        }
-    }
-    ProfSpan prof(PROF_NORM, 6.0 * N * C,
-                  4.0 * N * C * (1 + (relu ? 1 : 0) + (grad_gamma ? 1 : 0) + (grad_x ? 1 : 0) + (grad_residual ? 1 : 0)), st);
-    hipLaunchKernelGGL(bn_act_bwd_kernel, dim3(blocks, (C / 4 + 255) / 256), dim3(256), 0, st, a);
-    if (grad_gamma) {
-        const int splits = blocks >= 512 ? 16 : (blocks >= 64 ? 4 : 1);
-        hipLaunchKernelGGL(bn_param_reduce_kernel, dim3((2 * C + 255) / 256, splits), dim3(256), 0, st, a, blocks);
-    }
-    LSN_HIP(hipGetLastError());
-    return 0;
+    return bn_backward_launch(a, workspace, accumulate, 1 + (relu ? 1 : 0) + (grad_gamma ? 1 : 0), st);
+}
+
+int lsn_bn_eval_act_backward_folded(const float *grad_y, const float *y, const float *residual, const float *running_var,
+                                    const float *gamma, const float *beta, float eps, int relu, float *grad_x,
+                                    float *grad_residual, float *grad_gamma, float *grad_beta, void *workspace, int N,
+                                    int C, int accumulate, lsn_stream_t stream)
+{
+    using namespace lsn;
+    if (int rc = bn_check(N, C)) return rc;
+    LSN_CHECK(grad_y && y && running_var && gamma && beta, "batch norm (folded) backward: NULL argument");
+    LSN_CHECK((grad_gamma == nullptr) == (grad_beta == nullptr), "grad_gamma and grad_beta come together");
+    BnArgs a = {};
+    a.dy = grad_y, a.y_in = y, a.x = nullptr, a.res = residual, a.mean = beta, a.var = running_var, a.gamma = gamma, a.beta = beta;
+    a.dx = grad_x, a.dres = grad_residual, a.dgamma = grad_gamma, a.dbeta = grad_beta;
+    a.eps = eps, a.N = N, a.C = C, a.relu = relu;
+    return bn_backward_launch(a, workspace, accumulate, 2 + ((grad_gamma && residual) ? 1 : 0),
+                              reinterpret_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -12,14 +12,20 @@ from torch.nn.modules.batchnorm import _BatchNorm
 
 from ...cnn import build_conv_layer, build_norm_layer, constant_init, kaiming_init
 from ...ops.batch_norm import bn_act
-from ...ops.conv import conv_bn_act_frozen
+from ...ops.conv import conv_bn_act, conv_bn_act_frozen
 from ..builder import BACKBONES
 
 
 def _conv_bn(conv, bn, x, relu, residual=None):
-    """act(bn(conv(x)) + residual): one fused launch for a frozen pair (ops/conv.py conv_bn_act_frozen), else the
-    convolution followed by the fused norm + add + ReLU pass."""
-    out = conv_bn_act_frozen(conv, bn, x, relu, residual) if isinstance(bn, _BatchNorm) else None
+    """act(bn(conv(x)) + residual): one fused forward launch for a dense convolution + eval-mode BatchNorm pair -- frozen
+    (ops/conv.py conv_bn_act_frozen: no backward at all) or trainable (conv_bn_act: the norm folded into the weight image
+    of the step) -- else the convolution followed by the fused norm + add + ReLU pass (deformable conv2, GroupNorm,
+    training-mode statistics)."""
+    out = None
+    if isinstance(bn, _BatchNorm):
+        out = conv_bn_act_frozen(conv, bn, x, relu, residual)
+        if out is None:
+            out = conv_bn_act(conv, bn, x, relu, residual)
     return out if out is not None else bn_act(bn, conv(x), relu=relu, residual=residual)
 
 

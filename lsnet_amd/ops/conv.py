@@ -38,7 +38,8 @@ def _pad_channels(t, c_to):
     return out
 
 
-_images = {}    # (id(weight), kind, stride, pad, dil, math mode) -> [weakref, version, data_ptr, image, optimizer epoch]
+_images = {}    # (id(weight), kind, stride, pad, dil, math mode, id(bn) or 0) -> [weakref, version, data_ptr, image,
+#                  optimizer epoch, weakref(bn) or None, shift tensor or None, bn versions]
 _opt_epoch = [0]
 
 
@@ -53,62 +54,96 @@ from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_post
 _reg_post_step(_after_optimizer_step)
 
 
+def _bn_versions(bn):
+    return (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
+            bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.eps))
+
+
 def _stale(ent, w):
-    return ent[1] != w._version or ent[2] != w.data_ptr() or (w.requires_grad and ent[4] != _opt_epoch[0])
+    if ent[1] != w._version or ent[2] != w.data_ptr():
+        return True
+    bn = ent[5]() if ent[5] is not None else None
+    if ent[5] is not None and (bn is None or ent[7] != _bn_versions(bn)):
+        return True
+    trainable = w.requires_grad or (bn is not None and (bn.weight.requires_grad or bn.bias.requires_grad))
+    return trainable and ent[4] != _opt_epoch[0]
+
+
+def _fill_item(it, key, ent, w):
+    Co, C, kh, kw = w.shape
+    it.kind, it.w, it.prepared = key[1], w.data_ptr(), ent[3].data_ptr()
+    it.C, it.Co, it.kh, it.kw, it.stride, it.pad, it.dil = C, Co, kh, kw, key[2], key[3], key[4]
+    bn = ent[5]() if ent[5] is not None else None
+    if bn is not None:   # a BatchNorm folded into the forward image (lsn_conv_wprep)
+        it.bn_gamma, it.bn_var, it.bn_beta, it.bn_mean = bn.weight.data_ptr(), bn.running_var.data_ptr(), \
+            bn.bias.data_ptr(), bn.running_mean.data_ptr()
+        it.shift_out, it.bn_eps = ent[6].data_ptr(), float(bn.eps)
+
+
+def _mark_fresh(ent, w):
+    ent[1], ent[2], ent[4] = w._version, w.data_ptr(), _opt_epoch[0]
+    if ent[5] is not None and ent[5]() is not None:
+        ent[7] = _bn_versions(ent[5]())
 
 
 def _refresh_stale(mode):
-    """Rebuild EVERY cached image whose weight has moved on (all trainable convolutions after an optimizer step) in one
-    launch (lsn_conv2d_prepare_weights_multi): called when the first stale image of a step is asked for."""
+    """Rebuild EVERY cached image whose weight (or folded BatchNorm) has moved on -- all trainable convolutions after an
+    optimizer step -- in one launch (lsn_conv2d_prepare_weights_multi): called when the first stale image of a step is
+    asked for."""
     items = []
     for key, ent in _images.items():
         w = ent[0]()
-        if w is None or key[5] != mode or not _stale(ent, w):
+        if w is None or key[5] != mode or (ent[5] is not None and ent[5]() is None) or not _stale(ent, w):
             continue
         items.append((key, ent, w))
     if not items:
         return
+    lib = _lib.load()
     if torch.cuda.is_current_stream_capturing():
         # the multi-tensor launch uploads its job table when the set of stale images changed (a synchronous copy: not
         # allowed while a hipGraph is being captured): one launch per image instead, recorded into the graph
-        lib = _lib.load()
         for key, ent, w in items:
-            Co, C, kh, kw = w.shape
-            _lib.check(lib.lsn_conv2d_prepare_weights(key[1], _p(w), _p(ent[3]), C, Co, kh, kw, key[2], key[3], key[4],
-                                                      _stream()))
+            it = _lib.ConvWprep()
+            _fill_item(it, key, ent, w)
+            _lib.check(lib.lsn_conv2d_prepare_weights_item(ctypes.byref(it), _stream()))
     else:
         arr = (_lib.ConvWprep * len(items))()
         for it, (key, ent, w) in zip(arr, items):
-            Co, C, kh, kw = w.shape
-            it.kind, it.w, it.prepared = key[1], w.data_ptr(), ent[3].data_ptr()
-            it.C, it.Co, it.kh, it.kw, it.stride, it.pad, it.dil = C, Co, kh, kw, key[2], key[3], key[4]
-        _lib.check(_lib.load().lsn_conv2d_prepare_weights_multi(len(items), arr, _stream()))
+            _fill_item(it, key, ent, w)
+        _lib.check(lib.lsn_conv2d_prepare_weights_multi(len(items), arr, _stream()))
     for key, ent, w in items:
-        ent[1], ent[2], ent[4] = w._version, w.data_ptr(), _opt_epoch[0]
+        _mark_fresh(ent, w)
 
 
-def weight_image(w, kind, stride=1, pad=0, dil=1):
+def weight_image(w, kind, stride=1, pad=0, dil=1, bn=None):
     """The prepared image (lsn_conv2d_prepare_weights) of a channels-last (Co, C, kh, kw) weight for the forward
     (kind 0) or backward-data (kind 1) pass.  Cached per tensor OBJECT; stale when the tensor's version counter or
     storage moved, or -- for a trainable weight -- when any optimizer has stepped since.  The stale images of all
     parameters are rebuilt together, once per optimizer step, when the first of them is needed; a temporary (padded
-    view, test tensor) gets a fresh one and drops it when it dies."""
+    view, test tensor) gets a fresh one and drops it when it dies.
+    bn (kind 0): an eval-mode BatchNorm2d folded into the image; returns (image, shift) -- the shift goes into the
+    convolution's bias slot."""
     lib = _lib.load()
     mode = lib.lsn_get_math_mode()
-    key = (id(w), kind, stride, pad, dil, mode)
+    key = (id(w), kind, stride, pad, dil, mode, id(bn) if bn is not None else 0)
     ent = _images.get(key)
-    if ent is not None and ent[0]() is w:
+    if ent is not None and ent[0]() is w and (bn is None or (ent[5] is not None and ent[5]() is bn)):
         if _stale(ent, w):
             _refresh_stale(mode)
-        return ent[3]
+        return ent[3] if bn is None else (ent[3], ent[6])
     Co, C, kh, kw = w.shape
     nbytes = lib.lsn_conv2d_prepared_bytes(kind, C, Co, kh, kw, stride, pad, dil)
     if nbytes < 0:
         _lib.check(-2)
     img = torch.empty(nbytes, device=w.device, dtype=torch.uint8)
-    _lib.check(lib.lsn_conv2d_prepare_weights(kind, _p(w), _p(img), C, Co, kh, kw, stride, pad, dil, _stream()))
-    _images[key] = [weakref.ref(w, lambda _, k=key: _images.pop(k, None)), w._version, w.data_ptr(), img, _opt_epoch[0]]
-    return img
+    shift = torch.empty(Co, device=w.device, dtype=torch.float32) if bn is not None else None
+    ent = [weakref.ref(w, lambda _, k=key: _images.pop(k, None)), w._version, w.data_ptr(), img, _opt_epoch[0],
+           weakref.ref(bn) if bn is not None else None, shift, _bn_versions(bn) if bn is not None else None]
+    it = _lib.ConvWprep()
+    _fill_item(it, key, ent, w)
+    _lib.check(lib.lsn_conv2d_prepare_weights_item(ctypes.byref(it), _stream()))
+    _images[key] = ent
+    return img if bn is None else (img, shift)
 
 
 def _levels(n):
@@ -447,6 +482,107 @@ def conv_bn_act_frozen(conv, bn, x, relu=True, residual=None):
     _lib.check(lib.lsn_conv2d_forward_prepared(1, lv, _p(weight_image(w, 0)), _p(shift), C, C, Co, kh, kw, stride, pad,
                                                dil, 1 if relu else 0, _stream()))
     return out
+
+
+class _ConvBnActFn(torch.autograd.Function):
+    """y = act(bn(conv(x)) + residual) with the eval-mode BatchNorm FOLDED into the convolution (one launch, the raw
+    convolution output is never stored) and every gradient -- input, residual, weight, gamma, beta -- from the library:
+    lsn_bn_eval_act_backward_folded turns grad_y into the gradient w.r.t. the raw convolution output (taking x_hat from
+    y), the dense backward kernels take it from there with the UNscaled weight."""
+
+    @staticmethod
+    def forward(ctx, x, w, gamma, beta, residual, bn, stride, pad, dil, relu):
+        lib = _lib.load()
+        B, C, H, W = x.shape
+        Co, _, kh, kw = w.shape
+        Ho = (H + 2 * pad - (dil * (kh - 1) + 1)) // stride + 1
+        Wo = (W + 2 * pad - (dil * (kw - 1) + 1)) // stride + 1
+        img, shift = weight_image(w, 0, bn=bn)
+        out = torch.empty((B, Co, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=_CL)
+        lv = _levels(1)
+        lv[0].x, lv[0].out, lv[0].B, lv[0].H, lv[0].W, lv[0].residual = _p(x), _p(out), B, H, W, _p(residual)
+        _lib.check(lib.lsn_conv2d_forward_prepared(1, lv, _p(img), _p(shift), C, C, Co, kh, kw, stride, pad, dil,
+                                                   1 if relu else 0, _stream()))
+        ctx.save_for_backward(x, w, out, residual, gamma, bn.running_var)
+        ctx.cfg = (stride, pad, dil, relu, float(bn.eps))
+        ctx.beta_ref = beta
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        x, w, y, residual, gamma, var = ctx.saved_tensors
+        stride, pad, dil, relu, eps = ctx.cfg
+        beta = ctx.beta_ref
+        lib = _lib.load()
+        gy = gy.contiguous(memory_format=_CL)
+        B, C, H, W = x.shape
+        Co, _, kh, kw = w.shape
+        N = y.shape[0] * y.shape[2] * y.shape[3]
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        need_g, need_b = ctx.needs_input_grad[2], ctx.needs_input_grad[3]
+        need_res = residual is not None and ctx.needs_input_grad[4]
+        need_p = need_g or need_b
+        gz = torch.empty_like(y, memory_format=_CL) if (need_x or need_w) else None   # w.r.t. the raw convolution output
+        gres = torch.empty_like(y, memory_format=_CL) if need_res else None
+        sg = grad_sink.sink(gamma) if need_g else None
+        sb = grad_sink.sink(beta) if need_b else None
+        acc = 1 if (sg is not None and sb is not None) else 0
+        if acc:
+            dg, db = sg, sb
+        else:
+            dg = torch.empty_like(gamma) if need_p else None
+            db = torch.empty_like(gamma) if need_p else None
+        ws = torch.empty(lib.lsn_bn_eval_act_workspace_bytes(N, Co), device=x.device, dtype=torch.uint8) if need_p else None
+        _lib.check(lib.lsn_bn_eval_act_backward_folded(_p(gy), _p(y), _p(residual), _p(var), _p(gamma), _p(beta),
+                                                       ctypes.c_float(eps), 1 if relu else 0, _p(gz), _p(gres), _p(dg),
+                                                       _p(db), _p(ws), N, Co, acc, _stream()))
+        if acc:
+            grad_sink.done(gamma)
+            grad_sink.done(beta)
+            dg = db = None
+        gx = gw = None
+        if need_x:
+            gx = torch.empty_like(x, memory_format=_CL)
+            lv = _levels(1)
+            lv[0].x, lv[0].out, lv[0].B, lv[0].H, lv[0].W = _p(gz), _p(gx), B, H, W
+            _lib.check(lib.lsn_conv2d_backward_data_prepared(1, lv, _p(weight_image(w, 1, stride, pad, dil)), C, Co, kh, kw,
+                                                             stride, pad, dil, _stream()))
+        if need_w:
+            gw, _, wacc = _param_grad_buffers(w, None, True, False)
+            _lib.check(lib.lsn_conv2d_backward_weight(_p(x), _p(gz), _p(gw), None, B, H, W, C, Co, kh, kw, stride, pad, dil,
+                                                      wacc, _stream()))
+            gw, _ = _param_grad_results(w, None, gw, None, wacc, True)
+        return gx, gw, (dg if need_g else None), (db if need_b else None), gres, None, None, None, None, None
+
+
+def conv_bn_act(conv, bn, x, relu=True, residual=None):
+    """relu(bn(conv(x)) + residual) in ONE forward launch for a TRAINABLE convolution + eval-mode BatchNorm pair (stages
+    2 - 4 of the LSNet backbones: `norm_eval=True` keeps the statistics fixed while gamma / beta train,
+    resnet.py:636-645): the norm's scale is folded into the weight image that is rebuilt after every optimizer step
+    anyway, its shift rides in the bias slot, residual add and ReLU in the epilogue.  Saves the normalisation pass over
+    every backbone activation (a read and a write) and the storage of the raw convolution output.  Returns None when the
+    pair does not qualify (the caller then runs conv and bn_act separately)."""
+    if not isinstance(conv, Conv2d) or conv.bias is not None or conv.groups != 1 or bn.training or not bn.affine \
+            or not bn.track_running_stats or not isinstance(bn, nn.BatchNorm2d):
+        return None
+    if not hip_conv_ok(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups, conv.padding_mode):
+        return None
+    Co, C, kh, kw = conv.weight.shape
+    if C % 4 or Co % 4 or not (256 % (Co // 4) == 0 if Co <= 1024 else Co % 1024 == 0):
+        return None
+    if not conv.weight.is_contiguous(memory_format=_CL):
+        return None
+    x = _as_cl(x)
+    stride, pad, dil = conv.stride[0], conv.padding[0], conv.dilation[0]
+    B, _, H, W = x.shape
+    Ho = (H + 2 * pad - (dil * (kh - 1) + 1)) // stride + 1
+    Wo = (W + 2 * pad - (dil * (kw - 1) + 1)) // stride + 1
+    if residual is not None:
+        if not (tuple(residual.shape) == (B, Co, Ho, Wo) and residual.dtype == torch.float32):
+            return None
+        residual = _as_cl(residual)
+    return _ConvBnActFn.apply(x, conv.weight, bn.weight, bn.bias, residual, bn, stride, pad, dil, bool(relu))
 
 
 class Conv2d(nn.Conv2d):

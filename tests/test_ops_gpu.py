@@ -465,6 +465,56 @@ def test_conv2d_matches_torch(B, C, Co, k, s, p, d, H, W, bias, split_mode):
         assert _err(g.double(), r) < tol, (n, _err(g.double(), r))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('C,Co,k,s,res,relu', [(64, 256, 1, 1, True, True), (128, 128, 3, 2, False, True),
+                                                (256, 512, 1, 2, False, False), (512, 2048, 1, 1, True, True)])
+def test_conv_bn_act_folded(C, Co, k, s, res, relu, split_mode):
+    """relu(bn(conv(x)) + residual) with the eval-mode BatchNorm folded into the convolution's weight image (one forward
+    launch, the raw convolution output never stored; ops/conv.py conv_bn_act) against an fp64 evaluation of the reference's
+    three operators (resnet.py:261-301): output, and the gradients of input, residual, weight, gamma and beta -- the
+    last two formed from y instead of the convolution output (lsn_bn_eval_act_backward_folded)."""
+    from lsnet_amd.ops.conv import Conv2d, conv_bn_act
+    torch.manual_seed(5)
+    dev = _dev()
+    tol = 5e-6 if split_mode == 'bf16x6' else 5e-4   # (3-product mode: 5e-6 relative per product, 2048-wide sums)
+    B, H, W = 2, 19, 23
+    conv = Conv2d(C, Co, k, stride=s, padding=k // 2, bias=False).to(dev).to(memory_format=torch.channels_last)
+    bn = torch.nn.BatchNorm2d(Co).to(dev).eval()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(Co) + 0.5)
+        bn.bias.copy_(torch.randn(Co) * 0.3)
+        bn.running_mean.copy_(torch.randn(Co) * 0.2)
+        bn.running_var.copy_(torch.rand(Co) + 0.5)
+    x = torch.randn(B, C, H, W, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_()
+    Ho, Wo = (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
+    r = torch.randn(B, Co, Ho, Wo, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_() if res else None
+    y = conv_bn_act(conv, bn, x, relu=relu, residual=r)
+    assert y is not None and y.is_contiguous(memory_format=torch.channels_last)
+    go = torch.randn_like(y)
+    wrt = [x, conv.weight, bn.weight, bn.bias] + ([r] if res else [])
+    grads = torch.autograd.grad(y, wrt, go)
+    d = lambda t: t.detach().double().cpu()
+    xr, wr, gr, br = d(x).requires_grad_(), d(conv.weight).contiguous().requires_grad_(), d(bn.weight).requires_grad_(), \
+        d(bn.bias).requires_grad_()
+    rr = d(r).requires_grad_() if res else None
+    z = F.batch_norm(F.conv2d(xr, wr, None, s, k // 2), d(bn.running_mean), d(bn.running_var), gr, br, False, 0.0, bn.eps)
+    if res:
+        z = z + rr
+    yr = F.relu(z) if relu else z
+    gref = torch.autograd.grad(yr, [xr, wr, gr, br] + ([rr] if res else []), go.double().cpu())
+    assert _err(y.double(), yr) < tol
+    for g, ref, n in zip(grads, gref, ('gx', 'gw', 'ggamma', 'gbeta', 'gres')):
+        e = _err(g.double(), ref)
+        if split_mode == 'bf16x3' and relu and e >= tol:
+            # an output within the 3-product mode's 5e-5 of zero has its ReLU gate on the other side than in fp64: that
+            # one element of the pre-activation gradient is then all or nothing (measured: 1.4e-2 of the range of gx
+            # under a 2048-wide sum).  Legitimate kink behaviour -- held to a share of elements, not by the maximum.
+            rel = (g.double().cpu() - ref).abs() / ref.abs().max()
+            assert float((rel > tol).double().mean()) < 0.01 and float(rel.max()) < 0.1, (n, e)
+            continue
+        assert e < tol, (n, e)
+
+
 GROUP_CONV_CASES = [
     # B, C (= Co), groups, k, stride, pad, dil, H, W, bias
     (2, 256, 64, 3, 1, 1, 1, 50, 84, False),     # ResNeXt-101 64x4d layer1 conv2 (4 channels per group)
