@@ -569,7 +569,8 @@ static void gather_plan(DcnArgs &a, GatherPlan &pl)
             const int64_t nblk = (int64_t)G.B * cdiv(G.H, GT) * cdiv(G.W, GT);
             const int64_t nanch = (int64_t)G.B * (G.H + 1) * (G.W + 1);
             to_anchor[j] = all_anchor || (anchor_thr > 0 && gsamp[j] > (int64_t)anchor_thr * nblk);
-            is_long[j] = !all_anchor || gsamp[j] > 40 * nanch;
+            static const int long_thr = [] { const char *e = getenv("LSNET_ANCHOR_LONG"); return e ? atoi(e) : 40; }();
+            is_long[j] = !all_anchor || gsamp[j] > (int64_t)long_thr * nanch;   // mean list length (upper bound)
         }
         for (int pass = 0; pass < 2; ++pass) {
             for (int j = 0; j < ga.ng; ++j) {
