@@ -25,6 +25,16 @@
 
 #include "common.h"
 
+// Experiment (off by default): raise the wave's issue priority while it feeds the matrix pipe, so that the partner
+// workgroup's staging VALU work does not take the issue slot in front of an MFMA.  Measured on one box
+// (tools/r3_calls/c37.sh): network sums of the step's layer shapes 6.25 / 5.86 ms against 6.16 / 5.76 ms without -- the
+// partner's staging is what feeds ITS next MFMAs, delaying it costs as much as it buys.
+#ifdef LSNET_CONV_SETPRIO
+#define LSN_MFMA_PRIO(p) __builtin_amdgcn_s_setprio(p)
+#else
+#define LSN_MFMA_PRIO(p) ((void)0)
+#endif
+
 namespace lsn {
 
 constexpr int CV_MAXLV = 16;   // (the pyramid deformable op batches 15 (level, source) pairs)
@@ -415,18 +425,22 @@ __global__ __launch_bounds__(256, 2) void conv_mm_kernel(const ConvArgs a)
         constexpr int NM = NP * TN * TM;
 #pragma unroll
         for (int ps = 0; ps < NLD; ++ps) {
+            LSN_MFMA_PRIO(1);
 #pragma unroll
             for (int m = ps * NM / NLD; m < (ps + 1) * NM / NLD; ++m) {
                 const int prod = m / (TN * TM), j = (m / TM) % TN, i = m % TM;
                 acc[j][i] = mfma_bf16(Wf[0][j][SC::pb(prod)], Xf[0][i][SC::pa(prod)], acc[j][i]);
             }
+            LSN_MFMA_PRIO(0);
             if (t + 1 < T) commit_slice(ps, bn);   // registers hold the raw pixels of chunk t + 1
             issue_slice(ps);
             __builtin_amdgcn_sched_barrier(0);
         }
         issue_w(t + 1, 0);
         __builtin_amdgcn_sched_barrier(0);
+        LSN_MFMA_PRIO(1);
         mfma_block(1);
+        LSN_MFMA_PRIO(0);
         issue_w(t + 1, 1);
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
