@@ -73,3 +73,42 @@ for it in range(ncase):
     print(f'case {it}: C={C} Co={Co} dg={dg} s={stride} d={dil} mask={has_mask} B={B} levels={sizes}', 'OK' if not bad else f'FAIL {bad}',
           flush=True)
 print('worst', worst)
+
+# ---- pyramid mode: several offset grids of other resolutions sample ONE source map (shared grad_input buffer) ----
+for it in range(max(ncase // 3, 1)):
+    C = int(rng.choice([32, 64, 256]))
+    Co = int(rng.choice([64, 128, 256]))
+    B = int(rng.integers(1, 3))
+    nsrc = int(rng.integers(1, 4))
+    g = torch.Generator().manual_seed(5000 + it)
+    w = torch.randn(Co, C, 3, 3, generator=g) / (3 * C ** 0.5)
+    srcs = [torch.randn(B, C, int(rng.integers(4, 30)), int(rng.integers(4, 30)), generator=g) for _ in range(nsrc)]
+    pairs = [(int(rng.integers(0, nsrc)), (int(rng.integers(3, 26)), int(rng.integers(3, 26)))) for _ in range(int(rng.integers(2, 7)))]
+    offs, gos, scales = [], [], []
+    gx_ref = [torch.zeros_like(s) for s in srcs]
+    gw_ref = torch.zeros_like(w)
+    out_refs, goff_refs = [], []
+    for si, (Ho, Wo) in pairs:
+        H, W = srcs[si].shape[2:]
+        sh, sw = H / Ho, W / Wo
+        off = (torch.rand(B, 18, Ho, Wo, generator=g) * 4 - 2) * max(sh, 1.0)
+        go = torch.randn(B, Co, Ho, Wo, generator=g)
+        out_refs.append(orc.deform_conv_forward(srcs[si], w, None, off, None, 1, 1, 1, 1, 1, sh, sw, out_hw=(Ho, Wo)))
+        gr = orc.deform_conv_backward(srcs[si], w, off, None, go, 1, 1, 1, 1, 1, sh, sw)
+        gx_ref[si] += gr['gx']
+        gw_ref += gr['gw']
+        goff_refs.append(gr['goff'])
+        offs.append(off), gos.append(go), scales.append((sh, sw))
+    sd = [s.to(dev).contiguous(memory_format=cl).requires_grad_() for s in srcs]
+    od = [o.to(dev).contiguous(memory_format=cl).requires_grad_() for o in offs]
+    wd = w.to(dev).contiguous(memory_format=cl).requires_grad_()
+    outs = ops.dcn_multi([sd[si] for si, _ in pairs], od, None, wd, None, 1, 1, 1, scales=scales, pyramid=True)
+    used = sorted({si for si, _ in pairs})
+    grads = torch.autograd.grad(outs, [wd] + [sd[i] for i in used] + od, [go.to(dev).contiguous(memory_format=cl) for go in gos])
+    e = {'out': max(err(o, r) for o, r in zip(outs, out_refs)), 'gw': err(grads[0], gw_ref),
+         'gx': max(err(grads[1 + j], gx_ref[i]) for j, i in enumerate(used)),
+         'goff': max(err(grads[1 + len(used) + j], goff_refs[j]) for j in range(len(pairs)))}
+    bad = {n: v for n, v in e.items() if not v < TOL}
+    worst = max(worst, max(e.values()))
+    print(f'pyramid {it}: C={C} Co={Co} B={B} sources={[tuple(s.shape[2:]) for s in srcs]} pairs={pairs}', 'OK' if not bad else f'FAIL {bad}', flush=True)
+print('worst incl. pyramid', worst)
