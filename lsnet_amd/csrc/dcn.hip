@@ -221,6 +221,7 @@ static int fill_levels(DcnArgs &a, const lsn_dcn_shape &s, int n, const lsn_dcn_
     a.wg_vec = 0;
     a.mm = 0;
     a.wtp_bytes = 0;
+    a.wg_part = a.wg_part_b = nullptr;
     a.dbg = g_dbg_buf;
     a.dbg_block = g_dbg_block;
     a.w = a.bias = nullptr;
@@ -502,7 +503,7 @@ struct GatherPlan {
     int nsamples = 0, nanchors = 0;
     size_t scan_tmp = 0;
     size_t o_gcol = 0, o_cnt = 0, o_start = 0, o_anchor = 0, o_rank = 0, o_frac = 0, o_ent = 0, o_tmp = 0, o_gtap = 0, bytes = 0;
-    size_t o_S = 0, o_H = 0;
+    size_t o_S = 0, o_H = 0, o_ent2 = 0;
     GatherArgs ga;        // groups gathered per 4x4 pixel block
     AnchorArgs aa;        // groups with long lists: gathered per anchor (dcn_anchor_sum / combine)
     int anchor_pixels = 0;
@@ -616,6 +617,7 @@ static void gather_plan(DcnArgs &a, GatherPlan &pl)
     pl.o_gtap = o, o = align256(o + ((size_t)pl.nsamples + 1) * sizeof(Tap));   // + the all-zero entry
     pl.o_S = o, o = align256(o + (size_t)pl.aa.NA * 4 * a.C * sizeof(float));
     pl.o_H = o, o = align256(o + (size_t)pl.nsamples * 4 * sizeof(float));   // corner sums (dcn_offgrad_kernel)
+    pl.o_ent2 = o, o = align256(o + (size_t)pl.nsamples * sizeof(GEntry));   // ordering of the lists above 64 entries
     pl.bytes = o;
     pl.ok = true;
 }
@@ -666,7 +668,8 @@ static int launch_bwd_colbuf(DcnArgs &a, GatherPlan &pl, unsigned char *ws, hipS
                        srank, sfrac, ent, gtap, a.kh * a.kw * a.dg, a.gtap_rows);
     int sort_blocks = cdiv(pl.nanchors, 4);
     if (sort_blocks > 4096) sort_blocks = 4096;
-    hipLaunchKernelGGL(dcn_sort_lists_kernel, dim3(sort_blocks), dim3(256), 0, st, pl.nanchors, start, ent);
+    hipLaunchKernelGGL(dcn_sort_lists_kernel, dim3(sort_blocks), dim3(256), 0, st, pl.nanchors, start, ent,
+                       reinterpret_cast<GEntry *>(ws + pl.o_ent2));
     float *Hb = nullptr;
     if (a.mm) {   // the dense kernel writes the unweighted column gradients; everything else happens in the gather pass
         const float *xs[MAXLV];
@@ -840,11 +843,29 @@ static int launch_wgrad(const DcnArgs &a_in, int nsteps, bool accumulate, hipStr
     if (splits < 1) splits = 1;
     if (splits > 65535) splits = 65535;
     const size_t lds = (size_t)WG_BP * (WG_BM + WG_BN) * 4 + 2 * WG_BP * sizeof(Tap);
-    if (!accumulate) {
-        LSN_HIP(hipMemsetAsync(a.gw, 0, sizeof(float) * (size_t)a.Co * K * Cg, st));
+    // split-bf16 kernels: one partial gradient per pixel split + an ordered reduce instead of fp32 atomics (deterministic);
+    // a block that runs no step still stores its zero tile, so every partial element is written
+    const size_t nW = (size_t)a.Co * K * Cg;
+    const bool ordered = math_np() && !((g_dbg_block >> 30) & 1) && nW % 4 == 0 &&
+                         (size_t)splits * (nW + a.Co) * sizeof(float) <= ((size_t)256 << 20);
+    if (ordered) {
+        float *base = nullptr;
+        if (int rc = conv_scratch((size_t)splits * (nW + a.Co) + 16, &base)) return rc;
+        a.wg_part = base;
+        a.wg_part_b = a.gb ? base + (((size_t)splits * nW + 3) & ~(size_t)3) : nullptr;
+    } else if (!accumulate) {
+        LSN_HIP(hipMemsetAsync(a.gw, 0, sizeof(float) * nW, st));
         if (a.gb) LSN_HIP(hipMemsetAsync(a.gb, 0, sizeof(float) * (size_t)a.Co, st));
     }
     ProfScope prof(PROF_WGRAD, a, st);
+    if (ordered) {
+        const size_t ldsn = math_np() == 6 ? wgrad_xn_lds_bytes<6>() : wgrad_xn_lds_bytes<3>();
+        auto kern = math_np() == 6 ? dcn_wgrad_xn_kernel<false, 6> : dcn_wgrad_xn_kernel<false, 3>;
+        if (int rc = set_lds(kern, ldsn)) return rc;
+        hipLaunchKernelGGL(kern, dim3(ncol, splits, nz), dim3(256), ldsn, st, a, nsteps);
+        LSN_HIP(hipGetLastError());
+        return conv_wgrad_reduce(a.wg_part, a.gw, nW, a.wg_part_b, a.gb, a.Co, splits, splits, accumulate ? 1 : 0, st);
+    }
     if (math_np() && !((g_dbg_block >> 30) & 1)) {   // bit 30: force the fp32 MFMA kernel
         if (math_np() == 6) {
             const size_t ldsn = wgrad_xn_lds_bytes<6>();
@@ -1077,18 +1098,31 @@ static int make_single(lsn_dcn_shape &s, lsn_dcn_level &L, int B, int C, int H, 
 // weight gradient of a dense convolution through the deformable-conv weight-gradient kernel (PLAIN: no offsets), summed
 // over up to MAXLV input maps that share the weight
 template <int NP, int BMW>
-static int conv_wgrad_launch(const DcnArgs &a, int nsteps, int C, int Co, int K, hipStream_t st)
+static int conv_wgrad_launch(DcnArgs a, int nsteps, int C, int Co, int K, bool accumulate, hipStream_t st)
 {
     const int ncc = cdiv(C, WG_BN), ncol = K * ncc, nz = cdiv(Co, BMW);
     int splits = wgrad_splits(ncol * nz, BMW == 256 ? 2 : 3);   // resident blocks per CU: registers (246 / 142 VGPRs)
     if (splits > nsteps) splits = nsteps;
     if (splits < 1) splits = 1;
     if (splits > 65535) splits = 65535;
+    // one partial gradient per pixel split + an ordered reduce (deterministic) where the sizes allow; else fp32 atomics
+    const size_t nW = (size_t)Co * K * C;
+    const bool ordered = nW % 4 == 0 && (size_t)splits * (nW + Co) * sizeof(float) <= ((size_t)256 << 20);
+    if (ordered) {
+        float *base = nullptr;
+        if (int rc = conv_scratch((size_t)splits * (nW + Co) + 16, &base)) return rc;
+        a.wg_part = base;
+        a.wg_part_b = a.gb ? base + (((size_t)splits * nW + 3) & ~(size_t)3) : nullptr;
+    } else if (!accumulate) {
+        LSN_HIP(hipMemsetAsync(a.gw, 0, sizeof(float) * nW, st));
+        if (a.gb) LSN_HIP(hipMemsetAsync(a.gb, 0, sizeof(float) * (size_t)Co, st));
+    }
     const size_t ldsn = wgrad_xn_lds_bytes<NP, BMW>();
     auto k = dcn_wgrad_xn_kernel<true, NP, BMW>;
     if (int rc = set_lds(k, ldsn)) return rc;
     hipLaunchKernelGGL(k, dim3(ncol, splits, nz), dim3(256), ldsn, st, a, nsteps);
     LSN_HIP(hipGetLastError());
+    if (ordered) return conv_wgrad_reduce(a.wg_part, a.gw, nW, a.wg_part_b, a.gb, Co, splits, splits, accumulate ? 1 : 0, st);
     return 0;
 }
 
@@ -1124,16 +1158,14 @@ static int conv_wgrad_xn(int n, const lsn_conv_level *lv, float *gw, float *gb, 
     a.gw = gw, a.gb = gb;
     a.wg_vec = wgrad_vec_bits(a);
     const int K = kh * kw;
-    if (!accumulate) {
-        LSN_HIP(hipMemsetAsync(gw, 0, sizeof(float) * (size_t)Co * K * C, st));
-        if (gb) LSN_HIP(hipMemsetAsync(gb, 0, sizeof(float) * (size_t)Co, st));
-    }
     double px = 0, in_el = 0;
     for (int i = 0; i < n; ++i) px += (double)a.lv[i].P, in_el += (double)a.lv[i].B * a.lv[i].H * a.lv[i].W * C;
     ProfSpan prof(PROF_CONV_WGRAD, 2.0 * px * Co * C * K, 4.0 * (in_el + px * Co + (double)Co * K * C), st);
     const bool x3 = math_np() == 3;   // exact-mode callers get the fp32-equivalent split: there is no fp32-MFMA dense wgrad
-    if (Co <= 64) return x3 ? conv_wgrad_launch<3, 64>(a, steps, C, Co, K, st) : conv_wgrad_launch<6, 64>(a, steps, C, Co, K, st);
-    return x3 ? conv_wgrad_launch<3, 256>(a, steps, C, Co, K, st) : conv_wgrad_launch<6, 256>(a, steps, C, Co, K, st);
+    if (Co <= 64)
+        return x3 ? conv_wgrad_launch<3, 64>(a, steps, C, Co, K, accumulate, st) : conv_wgrad_launch<6, 64>(a, steps, C, Co, K, accumulate, st);
+    return x3 ? conv_wgrad_launch<3, 256>(a, steps, C, Co, K, accumulate, st)
+              : conv_wgrad_launch<6, 256>(a, steps, C, Co, K, accumulate, st);
 }
 
 }  // namespace lsn

@@ -51,6 +51,8 @@ struct DcnArgs {
     int wg_vec;               // weight gradient: tensors admit 8-byte buffer loads (bit 0: input, bit 1: grad_output)
     int gtap_rows;            // [kd * gtap_rows + prow0 + pix], gtap_rows = pixel rows of all levels (written once by
                               // dcn_bin_kernel; the backward kernels copy instead of recomputing)
+    float *wg_part, *wg_part_b;   // weight gradient (dcn_wgrad_xn_kernel): per-pixel-split partial gradients [split][Co K Cg] and
+                                  // [split][Co], added up by conv_wgrad_reduce_kernel in a fixed order; NULL: fp32 atomics into gw
     int mm;                   // a.wtp is in MFMA fragment order (conv_wfrag_kernel) for the kernels of dcn_mm_kernels.h
     int wtp_bytes;
     long long *dbg;  // optional phase timestamps of block `dbg_block`, wave 0 (lsn_debug_phase_clocks)
@@ -1779,15 +1781,37 @@ __global__ void dcn_fill_kernel(int nsamples, const int *__restrict__ start, con
     ent[start[an] + srank[s]] = e;
 }
 
-// one wave per anchor list: lists of 2..64 entries are rewritten in ascending sample order (longer lists, hundreds of
-// samples converging on one landmark in the pyramid op, keep their arrival order)
-__global__ __launch_bounds__(256) void dcn_sort_lists_kernel(int nanchors, const int *__restrict__ start, GEntry *__restrict__ ent)
+// one wave per anchor list: every list is rewritten in ascending sample order (the arrival order is that of the integer
+// atomics of dcn_bin_kernel: different on every run).  Up to 64 entries: ranks by 64 lane reads.  Longer lists (hundreds of
+// samples converging on one landmark in the pyramid op): a lane ranks its every-64th entries against the whole list, 64
+// keys at a time, writes them in order to `tmp` and the wave copies the range back -- n^2 / 64 compares per lane, ~10 us
+// for 700 entries.  tmp == NULL: long lists keep their arrival order (round 2's behaviour).
+__global__ __launch_bounds__(256) void dcn_sort_lists_kernel(int nanchors, const int *__restrict__ start, GEntry *__restrict__ ent,
+                                                             GEntry *__restrict__ tmp)
 {
     const int lane = threadIdx.x & 63;
     const int wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
     for (int an = wid; an < nanchors; an += nw) {
         const int b = start[an], n = start[an + 1] - b;
-        if (n < 2 || n > 64) continue;
+        if (n < 2) continue;
+        if (n > 64) {
+            if (tmp == nullptr) continue;
+            for (int i0 = 0; i0 < n; i0 += 64) {          // this lane's entry i0 + lane
+                const bool mine = i0 + lane < n;
+                GEntry e = {};
+                if (mine) e = ent[b + i0 + lane];
+                int rank = 0;
+                for (int j0 = 0; j0 < n; j0 += 64) {      // against keys j0 .. j0 + 63
+                    const int kj = j0 + lane < n ? ent[b + j0 + lane].s : 0x7fffffff;
+                    const int m = min(64, n - j0);
+                    for (int j = 0; j < m; ++j) rank += (__builtin_amdgcn_readlane(kj, j) < e.s) ? 1 : 0;
+                }
+                if (mine) tmp[b + rank] = e;
+            }
+            __threadfence();
+            for (int i = lane; i < n; i += 64) ent[b + i] = tmp[b + i];
+            continue;
+        }
         GEntry e = {};
         if (lane < n) e = ent[b + lane];
         const int key = lane < n ? e.s : 0x7fffffff;
@@ -3366,6 +3390,9 @@ _Pragma("unroll")                                                               
 #undef LSN_WG_LOADS
 #undef LSN_WG_GAP
 
+    // every element of the gradient belongs to exactly one (column block, co block): with a partial buffer per pixel
+    // split the epilogue is a plain store and the splits are added in a fixed order afterwards
+    float *pw = a.wg_part ? a.wg_part + (size_t)bsplit * a.Co * Kdim : nullptr;
 #pragma unroll
     for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -3375,12 +3402,29 @@ _Pragma("unroll")                                                               
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = row0 + i * 32 + mfma32_row(r, lane);
-                if (row < nco)
-                    atomic_add_f32(a.gw + (size_t)(co_base + row) * Kdim + ch.k * Cg + ch.c0 + col, acc[i][j][r]);
+                if (row >= nco) continue;
+                const size_t e = (size_t)(co_base + row) * Kdim + ch.k * Cg + ch.c0 + col;
+                if (pw)
+                    pw[e] = acc[i][j][r];
+                else
+                    atomic_add_f32(a.gw + e, acc[i][j][r]);
             }
         }
-    if (do_bias && gval0) atomic_add_f32(a.gb + co_base + 2 * gcp, bias_acc0);
-    if (do_bias && gval1) atomic_add_f32(a.gb + co_base + 2 * gcp + 1, bias_acc1);
+    if (a.wg_part_b) {   // (kernel-argument condition: every thread takes the barriers)
+        // a channel pair's sum sits in two threads (one per half of a step's pixels): meet in LDS, store once
+        __syncthreads();
+        float *bred = reinterpret_cast<float *>(smem);
+        if (gact) bred[(gph * CP + gcp) * 2] = bias_acc0, bred[(gph * CP + gcp) * 2 + 1] = bias_acc1;
+        __syncthreads();
+        if (do_bias && gact && gph == 0) {
+            const float s0 = bred[gcp * 2] + bred[(CP + gcp) * 2], s1 = bred[gcp * 2 + 1] + bred[(CP + gcp) * 2 + 1];
+            if (gval0) a.wg_part_b[(size_t)bsplit * a.Co + co_base + 2 * gcp] = s0;
+            if (gval1) a.wg_part_b[(size_t)bsplit * a.Co + co_base + 2 * gcp + 1] = s1;
+        }
+    } else {
+        if (do_bias && gval0) atomic_add_f32(a.gb + co_base + 2 * gcp, bias_acc0);
+        if (do_bias && gval1) atomic_add_f32(a.gb + co_base + 2 * gcp + 1, bias_acc1);
+    }
 }
 
 }  // namespace lsn

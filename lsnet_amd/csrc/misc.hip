@@ -68,10 +68,12 @@ __device__ __forceinline__ float block_sum_256(float v)
     return part[0] + part[1] + part[2] + part[3];
 }
 
-// loss_sum += sum_n w[n] * sum_c FL(n,c)
+// loss_sum = sum_n w[n] * sum_c FL(n,c).  At most 256 blocks; each leaves its sum in part[] and takes a ticket, the block
+// that draws the last one adds the partials up with the same fixed tree: no floating-point atomics, the same bits on
+// every run (round 2: one fp32 atomic per block).
 __global__ void focal_sum_kernel(const float *__restrict__ logits, const int64_t *__restrict__ targets,
                                  const float *__restrict__ weight, float *loss_sum, int N, int C, float gamma,
-                                 float alpha)
+                                 float alpha, float *part, unsigned *ticket)
 {
     const size_t total = (size_t)N * C;
     float s = 0.f;
@@ -83,7 +85,22 @@ __global__ void focal_sum_kernel(const float *__restrict__ logits, const int64_t
         s += w * fl_forward_one(logits[i], t == d, (t >= 0) & (t != d), gamma, alpha);
     }
     s = block_sum_256(s);
-    if (threadIdx.x == 0) atomic_add_f32(loss_sum, s);
+    __shared__ int last;
+    if (threadIdx.x == 0) {
+        part[blockIdx.x] = s;
+        __threadfence();
+        last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    const float v = threadIdx.x < gridDim.x ? __builtin_nontemporal_load(part + threadIdx.x) : 0.f;
+    __syncthreads();   // (block_sum_256 reuses its LDS words)
+    const float tot = block_sum_256(v);
+    if (threadIdx.x == 0) {
+        *loss_sum = tot;
+        *ticket = 0;   // ready for the next launch on this stream
+    }
 }
 
 // d_logits = (*scale) * w[n] * dFL/dx
@@ -239,10 +256,22 @@ int lsn_sigmoid_focal_loss_sum(const float *logits, const int64_t *targets, cons
                                int N, int C, float gamma, float alpha, lsn_stream_t stream)
 {
     LSN_CHECK(N >= 0 && C > 0, "invalid focal loss shape (%d, %d)", N, C);
-    LSN_HIP(hipMemsetAsync(loss_sum, 0, sizeof(float), stream));
-    if (N == 0) return 0;
-    hipLaunchKernelGGL(focal_sum_kernel, dim3(ew_grid((size_t)N * C)), dim3(256), 0, stream, logits, targets,
-                       weight, loss_sum, N, C, gamma, alpha);
+    if (N == 0) {
+        LSN_HIP(hipMemsetAsync(loss_sum, 0, sizeof(float), stream));
+        return 0;
+    }
+    // library-owned scratch of the two-stage sum (one stream at a time, like the other scratch buffers of the library)
+    static float *part = nullptr;
+    static unsigned *ticket = nullptr;
+    if (!part) {
+        LSN_HIP(hipMalloc(reinterpret_cast<void **>(&part), 256 * sizeof(float) + sizeof(unsigned)));
+        ticket = reinterpret_cast<unsigned *>(part + 256);
+        LSN_HIP(hipMemset(ticket, 0, sizeof(unsigned)));
+    }
+    int grid = ew_grid((size_t)N * C);
+    if (grid > 256) grid = 256;
+    hipLaunchKernelGGL(focal_sum_kernel, dim3(grid), dim3(256), 0, stream, logits, targets, weight, loss_sum, N, C, gamma,
+                       alpha, part, ticket);
     LSN_HIP(hipGetLastError());
     return 0;
 }

@@ -38,7 +38,8 @@ struct GnArgs {
     const float *gamma, *beta;
     double *sums;      // [images][G][2]   shifted sum, shifted sum of squares   (zero-filled by the launcher)
     float *mean_rstd;  // [images][G][2]
-    float *ab;         // [images][C][2]   backward: sum dy*xhat, sum dy          (zero-filled by the launcher)
+    float *ab;         // [images][C][2]   backward: sum dy*xhat, sum dy
+    float *part;       // [blocks][C][2]   backward: the same per 64-pixel block (summed per image in a fixed order)
     float *dgamma, *dbeta;
 };
 
@@ -190,13 +191,41 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const GnArgs a)
         for (int r = 0; r < p.rows; ++r)
 #pragma unroll
             for (int j = 0; j < 8; ++j) s[j] += red[(r * qn + threadIdx.x) * 8 + j];
-        float *dst = a.ab + ((size_t)(L.img0 + p.b) * a.C + threadIdx.x * 4) * 2;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            atomic_add_f32(dst + j * 2, s[j]);
-            atomic_add_f32(dst + j * 2 + 1, s[4 + j]);
-        }
+        // per-block partials, summed per image by gn_bwd_imgsum_kernel in a fixed order (round 2: fp32 atomics of up to
+        // 263 blocks per address: contended, and different bits on every run)
+        float *dst = a.part + ((size_t)blockIdx.x * a.C + threadIdx.x * 4) * 2;
+        *reinterpret_cast<float4 *>(dst) = make_float4(s[0], s[4], s[1], s[5]);
+        *reinterpret_cast<float4 *>(dst + 4) = make_float4(s[2], s[6], s[3], s[7]);
     }
+}
+
+// ab[image][c][2] = sum over the image's blocks of part[block][c][2].  grid = (image slots, 2 C / 32); the eight groups of
+// 32 threads take every eighth block each and meet in LDS in a fixed order.
+__global__ __launch_bounds__(256) void gn_bwd_imgsum_kernel(const GnArgs a)
+{
+    __shared__ float red[8][32];
+    const int im = blockIdx.x;
+    int li = 0;
+    while (li + 1 < a.nlv && im >= a.lv[li + 1].img0) ++li;
+    const GnLvl &L = a.lv[li];
+    const int tpi = (L.HW + GN_PIX - 1) / GN_PIX;
+    const int t0 = L.tile0 + (im - L.img0) * tpi;
+    const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int c2 = blockIdx.y * 32 + col;   // index into the 2 C interleaved (A, B) columns
+    float s0 = 0.f, s1 = 0.f;
+    if (c2 < 2 * a.C) {
+        int b = grp;
+        for (; b + 8 < tpi; b += 16) {
+            s0 += a.part[(size_t)(t0 + b) * 2 * a.C + c2];
+            s1 += a.part[(size_t)(t0 + b + 8) * 2 * a.C + c2];
+        }
+        if (b < tpi) s0 += a.part[(size_t)(t0 + b) * 2 * a.C + c2];
+    }
+    red[grp][col] = s0 + s1;
+    __syncthreads();
+    if (grp == 0 && c2 < 2 * a.C)
+        a.ab[(size_t)im * 2 * a.C + c2] = ((red[0][col] + red[1][col]) + (red[2][col] + red[3][col])) +
+                                          ((red[4][col] + red[5][col]) + (red[6][col] + red[7][col]));
 }
 
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const GnArgs a)
@@ -473,8 +502,11 @@ int64_t lsn_group_norm_workspace_bytes(int n_levels, const lsn_gn_level *levels,
 {
     int64_t images = 0;
     for (int i = 0; i < n_levels; ++i) images += levels[i].B;
-    // forward: sums (double [images][G][2]); backward: ab (float [images][C][2]); sized for the larger
-    const int64_t f = images * G * 2 * (int64_t)sizeof(double), b = images * C * 2 * (int64_t)sizeof(float);
+    int64_t tiles = 0;
+    for (int i = 0; i < n_levels; ++i) tiles += (int64_t)levels[i].B * ((levels[i].HW + lsn::GN_PIX - 1) / lsn::GN_PIX);
+    // forward: sums (double [images][G][2]); backward: ab (float [images][C][2]) + per-block partials (float
+    // [blocks][C][2]); sized for the larger
+    const int64_t f = images * G * 2 * (int64_t)sizeof(double), b = (images + tiles) * C * 2 * (int64_t)sizeof(float);
     return f > b ? f : b;
 }
 
@@ -522,13 +554,14 @@ int lsn_group_norm_backward(int n_levels, const lsn_gn_level *levels, int C, int
     a.relu = relu;
     a.mean_rstd = const_cast<float *>(mean_rstd);
     a.ab = reinterpret_cast<float *>(workspace);
+    a.part = a.ab + (size_t)images * C * 2;
     a.dgamma = grad_gamma;
     a.dbeta = grad_beta;
-    LSN_HIP(hipMemsetAsync(a.ab, 0, sizeof(float) * (size_t)images * C * 2, st));
     double el = 0;
     for (int i = 0; i < n_levels; ++i) el += (double)levels[i].B * levels[i].HW * C;
     ProfSpan prof(PROF_NORM, 16.0 * el, 4.0 * 3 * el, st);   // x, dy read, dx written
     hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(tiles), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(gn_bwd_imgsum_kernel, dim3(images, (2 * C + 31) / 32), dim3(256), 0, st, a);
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(tiles), dim3(256), 0, st, a);
     if (grad_gamma || grad_beta)
         hipLaunchKernelGGL(gn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, st, a, images, accumulate);

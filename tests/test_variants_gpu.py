@@ -87,3 +87,32 @@ def test_full_size_pose_inference_batch():
         assert boxes.shape[0] == labels.shape[0] == vectors.shape[0] and boxes.shape[0] > 0
         assert torch.isfinite(boxes).all() and torch.isfinite(vectors).all()
         assert boxes.shape[1] == 5 and int(labels.min()) >= 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('task,backbone', [('bbox', 'r50'), ('bbox', 'r101-dcn')])
+def test_training_step_is_bit_reproducible(task, backbone):
+    """The same model, the same batch, twice: the loss and EVERY parameter gradient must come back with the same bits.
+    What it takes: anchor lists sorted by sample id whatever their length, split partial tiles +
+    ordered reduce in every weight-gradient kernel, block partials instead of fp32 atomics in the GroupNorm / BatchNorm
+    parameter sums and the focal-loss sum.  (The reference scatters grad_input with fp32 atomics,
+    deform_conv_cuda_kernel.cu:913-970: it is not reproducible.)"""
+    dev = torch.device('cuda:0')
+
+    def run():
+        torch.manual_seed(3)
+        model, _ = build_lsnet(task, backbone)
+        model = model.to(dev).to(memory_format=torch.channels_last).train()
+        data = synthetic_batch(task, 2, 384, 480, boxes_per_img=5, num_classes=80, seed=11, device='cuda:0', channels_last=True)
+        losses = model(**data)
+        loss = sum(v if torch.is_tensor(v) else sum(v) for k, v in losses.items() if 'loss' in k)
+        loss.backward()
+        torch.cuda.synchronize()
+        return loss.detach().clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    l1, g1 = run()
+    l2, g2 = run()
+    assert torch.equal(l1, l2), (float(l1), float(l2))
+    assert len(g1) > 100
+    diff = [n for n in g1 if not torch.equal(g1[n], g2[n])]
+    assert not diff, f'{len(diff)} of {len(g1)} parameter gradients differ between two identical steps, e.g. {diff[:4]}'
