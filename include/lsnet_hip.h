@@ -137,9 +137,9 @@ int lsn_dcn_backward(const lsn_dcn_shape *shape, int n_levels, const lsn_dcn_lev
  * column-gradient buffer of sum(B*Ho*Wo) * kh*kw * C floats written and read once, per-anchor corner sums and the
  * corner products of the offset / mask gradients); 0 when that path does not apply to the shape (groups > 1,
  * exact-fp32 mode, no grad_input requested).  Levels whose grad_input pointers are EQUAL accumulate into that one
- * buffer (several offset fields sampling one source map).  With this scratch grad_input, grad_offset and grad_mask are
- * free of floating-point atomics, and so are grad_weight / grad_bias for the shapes csrc/dcn_mm_kernels.h serves
- * (groups = 1, 256 | Co, 64 | C / deformable_groups): bit-identical run to run. */
+ * buffer (several offset fields sampling one source map).  With this scratch the whole backward pass -- grad_input,
+ * grad_offset, grad_mask, grad_weight, grad_bias -- is free of floating-point atomics in the split-bf16 math modes
+ * (groups = 1): bit-identical run to run. */
 int64_t lsn_dcn_backward_workspace_bytes(const lsn_dcn_shape *shape, int n_levels, const lsn_dcn_level *levels);
 
 /* ---- one-to-one replacements of the reference extension's functions ----------------------- */
