@@ -54,7 +54,7 @@ static const char *const kProfNames[PROF_N] = {"dcn_fwd", "dcn_bwd_data", "dcn_w
                                                "conv_wgrad", "norm", "gconv"};
 static unsigned g_prof_mask = 0;   // bit f: family f records events
 static std::vector<ProfRec> g_prof;
-bool prof_on(int fam) { return (g_prof_mask >> fam) & 1u; }
+bool prof_on(int fam) { return fam >= 0 && fam < 32 && ((g_prof_mask >> fam) & 1u); }
 void prof_push(const ProfRec &r) { g_prof.push_back(r); }
 
 static double dcn_flops(const DcnArgs &a)
@@ -789,8 +789,11 @@ static bool mm_wgrad_ok(const DcnArgs &a)
     return true;
 }
 
-static int launch_wgrad_mm(const DcnArgs &a, int nchunks, bool accumulate, hipStream_t st)
+// dense: a dense convolution's weight gradient (levels without offsets, no backward-data pass before this one): the
+// sampling table is built here, and the launch is accounted to the caller's family
+static int launch_wgrad_mm(const DcnArgs &a_in, int nchunks, bool accumulate, hipStream_t st, bool dense = false)
 {
+    DcnArgs a = a_in;
     const int K = a.kh * a.kw, npl = mm_npl();
     const size_t nW = (size_t)a.Co * K * a.C;
     const size_t img_bytes = (size_t)nchunks * 2 * (a.Co / 32) * npl * 1024;
@@ -806,13 +809,33 @@ static int launch_wgrad_mm(const DcnArgs &a, int nchunks, bool accumulate, hipSt
     if (spb < 4) spb = 4;
     const int nblk_s = cdiv(nsteps16, spb);
     const size_t img_f = (img_bytes + 15) / 16 * 4, part_f = (size_t)S * nW, pb_f = ((size_t)nblk_s * a.Co + 3) & ~(size_t)3;
+    const size_t meta_f = ((size_t)nchunks * 8 + 64 + 3) & ~(size_t)3;
+    size_t tap_entries = 0;
+    if (dense) {
+        int64_t rows = 0;
+        for (int i = 0; i < a.nlv; ++i) {
+            a.lv[i].prow0 = (int)rows;
+            rows += a.lv[i].P;
+        }
+        if (rows * K * a.dg >= ((int64_t)1 << 26)) return 1;   // (a 2 GB table)
+        a.gtap_rows = (int)rows;
+        tap_entries = (size_t)rows * K * a.dg;
+    }
     float *base = nullptr;
-    if (int rc = conv_scratch(img_f + part_f + pb_f + (size_t)nchunks * 8 + 64, &base)) return rc;
+    if (int rc = conv_scratch(img_f + part_f + pb_f + meta_f + (tap_entries ? (tap_entries + 1) * (sizeof(Tap) / 4) : 0), &base))
+        return rc;
     unsigned short *img = reinterpret_cast<unsigned short *>(base);
     float *part = base + img_f, *part_b = part + part_f;
     int *meta = reinterpret_cast<int *>(part_b + pb_f);
-    hipLaunchKernelGGL(dcn_chunk_meta_kernel, dim3(cdiv(nchunks, 256)), dim3(256), 0, st, a, nchunks, meta);
-    ProfScope prof(PROF_WGRAD, a, st);
+    if (dense) {
+        Tap *tab = reinterpret_cast<Tap *>(part_b + pb_f + meta_f);
+        const int n = (int)tap_entries > nchunks ? (int)tap_entries : nchunks;
+        hipLaunchKernelGGL(dcn_tap_table_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, a, (int)tap_entries, tab, nchunks, meta);
+        a.gtap = tab;
+    } else {
+        hipLaunchKernelGGL(dcn_chunk_meta_kernel, dim3(cdiv(nchunks, 256)), dim3(256), 0, st, a, nchunks, meta);
+    }
+    ProfScope prof(dense ? -1 : PROF_WGRAD, a, st);
     auto pre = npl == 3 ? dcn_gout_frag_kernel<3> : dcn_gout_frag_kernel<2>;
     hipLaunchKernelGGL(pre, dim3(nblk_s, a.Co / 128), dim3(256), 0, st, a, nsteps16, spb, img, a.gb ? part_b : nullptr);
     const size_t lds = dcn_wgrad_mm_lds_bytes(npl);
@@ -822,7 +845,11 @@ static int launch_wgrad_mm(const DcnArgs &a, int nchunks, bool accumulate, hipSt
         LSN_HIP(hipGetLastError());
         return 0;
     };
-    if (int rc = (math_np() == 6 ? go(dcn_wgrad_mm_kernel<6>) : go(dcn_wgrad_mm_kernel<3>))) return rc;
+    if (dense) {
+        if (int rc = (math_np() == 6 ? go(dcn_wgrad_mm_kernel<6, true>) : go(dcn_wgrad_mm_kernel<3, true>))) return rc;
+    } else if (int rc = (math_np() == 6 ? go(dcn_wgrad_mm_kernel<6>) : go(dcn_wgrad_mm_kernel<3>))) {
+        return rc;
+    }
     return conv_wgrad_reduce(part, a.gw, nW, part_b, a.gb, a.Co, S, nblk_s, accumulate ? 1 : 0, st);
 }
 
@@ -1129,9 +1156,65 @@ static int conv_wgrad_launch(DcnArgs a, int nsteps, int C, int Co, int K, bool a
 int conv_wgrad_mm(int n, const lsn_conv_level *lv, float *gw, float *gb, int C, int Co, int kh, int kw, int stride, int pad,
                   int dil, int accumulate, hipStream_t st);   // conv.hip
 
+// LSNET_CONV_WGRAD_MM: 0 off, 1 every shape the kernel serves, unset (2): the shapes it won on (conv_wgrad_dense_mm)
+static int conv_wgrad_mm_env()
+{
+    static const int v = [] { const char *e = getenv("LSNET_CONV_WGRAD_MM"); return e ? atoi(e) : 2; }();
+    return v;
+}
+
+// The weight gradient of a dense convolution through dcn_wgrad_mm_kernel<NP, DENSE> (grad_output pre-split once into MFMA
+// fragment order, the regular grid as the sampling table).  Returns 1 when the shape is not served (256 | Co, 64 | C,
+// 32-bit byte offsets, a split-bf16 math mode) or is faster on the patch kernel of conv_wgrad_kernels.h.  Measured on the
+// layer shapes of the benchmark step (tools/ubench/wgrad_ab.hip, profiles/r3_wgrad_ab.txt; batch 2): 3x3 at >= 4096
+// output pixels 84 vs 96 us (layer 3), 262 vs 272 (FPN P3), 320 vs 380 (five head levels in one launch); 1x1 from >= 1024
+// channels to >= 512: 75 vs 89, 53 vs 56; strided 1x1 from >= 512 channels: 83 vs 89, 78 vs 89.  Slower on the 1x1 layers
+// with few input channels and many pixels (76 vs 52 us on 128 -> 512 at 100 x 168), which stay where they were.
+static int conv_wgrad_dense_mm(int n, const lsn_conv_level *lv, float *gw, float *gb, int C, int Co, int kh, int kw, int stride,
+                               int pad, int dil, bool accumulate, hipStream_t st)
+{
+    if (!conv_wgrad_mm_env() || n < 1 || n > MAXLV || !lv || !gw || Co % 256 != 0 || C % 64 != 0) return 1;
+    if (conv_wgrad_mm_env() != 1) {
+        int64_t px = 0;
+        for (int i = 0; i < n; ++i) {
+            const int Ho = (lv[i].H + 2 * pad - (dil * (kh - 1) + 1)) / stride + 1, Wo = (lv[i].W + 2 * pad - (dil * (kw - 1) + 1)) / stride + 1;
+            px += (int64_t)lv[i].B * (Ho > 0 ? Ho : 0) * (Wo > 0 ? Wo : 0);
+        }
+        const bool win = kh * kw >= 9 ? px >= 4096 : ((C >= 1024 && Co >= 512) || (stride >= 2 && C >= 512));
+        if (!win) return 1;
+    }
+    DcnArgs a = {};
+    int chunks = 0;
+    for (int i = 0; i < n; ++i) {
+        Lvl &L = a.lv[i];
+        const int B = lv[i].B, H = lv[i].H, W = lv[i].W;
+        if (!lv[i].x || !lv[i].grad_out || B <= 0 || H <= 0 || W <= 0) return 1;
+        const int Ho = (H + 2 * pad - (dil * (kh - 1) + 1)) / stride + 1, Wo = (W + 2 * pad - (dil * (kw - 1) + 1)) / stride + 1;
+        if (Ho <= 0 || Wo <= 0) return 1;
+        if ((int64_t)B * H * W * C * 4 >= ((int64_t)1 << 31) || (int64_t)B * Ho * Wo * Co * 4 >= ((int64_t)1 << 31)) return 1;
+        L.x = lv[i].x, L.gout = lv[i].grad_out, L.off = nullptr, L.msk = nullptr;
+        L.B = B, L.H = H, L.W = W, L.Ho = Ho, L.Wo = Wo, L.P = B * Ho * Wo, L.sh = L.sw = 1.f;
+        L.tile0 = chunks;
+        chunks += cdiv(L.P, WG_BP);
+    }
+    a.nlv = n;
+    a.C = C, a.Co = Co, a.kh = kh, a.kw = kw, a.stride = stride, a.pad = pad, a.dil = dil, a.groups = 1, a.dg = 1;
+    a.SL = C;
+    a.gw = gw, a.gb = gb;
+    if (!mm_common_ok(a) || chunks < 8) return 1;
+    double px = 0, in_el = 0;
+    for (int i = 0; i < n; ++i) px += (double)a.lv[i].P, in_el += (double)a.lv[i].B * a.lv[i].H * a.lv[i].W * C;
+    ProfSpan prof(PROF_CONV_WGRAD, 2.0 * px * Co * C * kh * kw, 4.0 * (in_el + px * Co + (double)Co * kh * kw * C), st);
+    return launch_wgrad_mm(a, chunks, accumulate, st, true);
+}
+
 static int conv_wgrad_xn(int n, const lsn_conv_level *lv, float *gw, float *gb, int C, int Co, int kh, int kw, int stride,
                          int pad, int dil, bool accumulate, hipStream_t st)
 {
+    {   // wide layers: the fragment-order kernel of the deformable family with the regular grid as its sampling table
+        const int rc = conv_wgrad_dense_mm(n, lv, gw, gb, C, Co, kh, kw, stride, pad, dil, accumulate, st);
+        if (rc != 1) return rc;
+    }
     {   // the patch kernel of conv_wgrad_kernels.h serves up to nine taps; anything else stays here
         const int rc = conv_wgrad_mm(n, lv, gw, gb, C, Co, kh, kw, stride, pad, dil, accumulate ? 1 : 0, st);
         if (rc != 1) return rc;

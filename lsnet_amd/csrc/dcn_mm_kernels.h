@@ -302,14 +302,35 @@ __global__ __launch_bounds__(256) void dcn_gout_frag_kernel(const DcnArgs a, int
     }
 }
 
+// The launch-wide sampling table (layout of dcn_bin_kernel: k-major, [kd * gtap_rows + prow0 + pix], the all-zero "no
+// sample" entry behind it) for a launch without a backward-data pass: the weight gradient of a dense convolution (Lvl.off
+// == NULL: the regular grid, every position integral) through dcn_wgrad_mm_kernel<NP, DENSE = true>.  The same launch
+// writes the per-chunk table of dcn_chunk_meta_kernel (meta != NULL).
+__device__ __forceinline__ void dcn_chunk_meta_item(const DcnArgs &a, int t, int *__restrict__ meta);
+__global__ void dcn_tap_table_kernel(const DcnArgs a, int nentries, Tap *__restrict__ gtap, int nchunks, int *__restrict__ meta)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int K = a.kh * a.kw;
+    if (e == 0) {
+        Tap z = {};
+        gtap[nentries] = z;
+    }
+    if (meta != nullptr && e < nchunks) dcn_chunk_meta_item(a, e, meta);
+    if (e >= nentries) return;
+    const int kd = e / a.gtap_rows, prow = e - kd * a.gtap_rows;
+    const int dgi = kd / K, k = kd - dgi * K;
+    int li = 0;
+    while (li + 1 < a.nlv && prow >= a.lv[li + 1].prow0) ++li;
+    const Lvl &L = a.lv[li];
+    gtap[e] = make_tap(a, L, prow - L.prow0, k, dgi);
+}
+
 // Per 32-pixel chunk: where it lives -- {input base lo, hi, input bytes, first row of the launch-wide sampling table, valid
 // pixels, -, -, -}.  The weight-gradient kernel reads it with scalar loads: a level lookup per iteration in the kernel
 // itself (dynamic indexing of the by-value argument struct) compiled to vector loads from the argument copy with full
 // vmcnt(0) waits in the middle of the software pipeline.
-__global__ void dcn_chunk_meta_kernel(const DcnArgs a, int nchunks, int *__restrict__ meta)
+__device__ __forceinline__ void dcn_chunk_meta_item(const DcnArgs &a, int t, int *__restrict__ meta)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nchunks) return;
     const Lvl &L = find_level(a, t);
     const unsigned long long p = reinterpret_cast<unsigned long long>(L.x);
     const int p0 = (t - L.tile0) * 32;
@@ -319,10 +340,17 @@ __global__ void dcn_chunk_meta_kernel(const DcnArgs a, int nchunks, int *__restr
     reinterpret_cast<int4 *>(meta)[2 * t] = m0;
     reinterpret_cast<int4 *>(meta)[2 * t + 1] = m1;
 }
+__global__ void dcn_chunk_meta_kernel(const DcnArgs a, int nchunks, int *__restrict__ meta)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < nchunks) dcn_chunk_meta_item(a, t, meta);
+}
 
 __host__ __device__ inline size_t dcn_wgrad_mm_lds_bytes(int npl) { return (size_t)2 * npl * 32 * 128 + 4 * 32 * sizeof(Tap); }
 
-template <int NP>
+// DENSE: every sampling position is a grid point (weights 1, 0, 0, 0): one load per position instead of four, and the value
+// itself (times the validity of the position: zero padding) instead of the blend.
+template <int NP, bool DENSE = false>
 __global__ __launch_bounds__(256, 2) void dcn_wgrad_mm_kernel(const DcnArgs a, int nchunks, const unsigned short *__restrict__ gimg,
                                                               int gimg_bytes, float *__restrict__ part, const int *__restrict__ meta)
 {
@@ -385,20 +413,28 @@ __global__ __launch_bounds__(256, 2) void dcn_wgrad_mm_kernel(const DcnArgs a, i
         const int4 idx = *reinterpret_cast<const int4 *>(&tab[slot * 32 + ps * 16 + xq]);
         const int cq = (c0 + 4 * xc4) * 4;
         xv[ps][0] = cv_load4(xrs, idx.x * 4 + cq, 0);
-        xv[ps][1] = cv_load4(xrs, idx.y * 4 + cq, 0);
-        xv[ps][2] = cv_load4(xrs, idx.z * 4 + cq, 0);
-        xv[ps][3] = cv_load4(xrs, idx.w * 4 + cq, 0);
+        if (!DENSE) {
+            xv[ps][1] = cv_load4(xrs, idx.y * 4 + cq, 0);
+            xv[ps][2] = cv_load4(xrs, idx.z * 4 + cq, 0);
+            xv[ps][3] = cv_load4(xrs, idx.w * 4 + cq, 0);
+        }
     };
     auto commit_slice = [&](int ps, int slot, unsigned char *buf) {
         const Tap tp = tab[slot * 32 + ps * 16 + xq];
-        float b00, b01, b10, b11;
-        corner_weights(tp, b00, b01, b10, b11);
-        b00 *= tp.m, b01 *= tp.m, b10 *= tp.m, b11 *= tp.m;
         float v[4];
-        v[0] = b00 * xv[ps][0].x + b01 * xv[ps][1].x + b10 * xv[ps][2].x + b11 * xv[ps][3].x;
-        v[1] = b00 * xv[ps][0].y + b01 * xv[ps][1].y + b10 * xv[ps][2].y + b11 * xv[ps][3].y;
-        v[2] = b00 * xv[ps][0].z + b01 * xv[ps][1].z + b10 * xv[ps][2].z + b11 * xv[ps][3].z;
-        v[3] = b00 * xv[ps][0].w + b01 * xv[ps][1].w + b10 * xv[ps][2].w + b11 * xv[ps][3].w;
+        if (DENSE) {
+            const bool in = (tp.flags & 1) != 0;   // a padding position (or a pixel past the level's end): zero
+            v[0] = in ? xv[ps][0].x : 0.f, v[1] = in ? xv[ps][0].y : 0.f;
+            v[2] = in ? xv[ps][0].z : 0.f, v[3] = in ? xv[ps][0].w : 0.f;
+        } else {
+            float b00, b01, b10, b11;
+            corner_weights(tp, b00, b01, b10, b11);
+            b00 *= tp.m, b01 *= tp.m, b10 *= tp.m, b11 *= tp.m;
+            v[0] = b00 * xv[ps][0].x + b01 * xv[ps][1].x + b10 * xv[ps][2].x + b11 * xv[ps][3].x;
+            v[1] = b00 * xv[ps][0].y + b01 * xv[ps][1].y + b10 * xv[ps][2].y + b11 * xv[ps][3].y;
+            v[2] = b00 * xv[ps][0].z + b01 * xv[ps][1].z + b10 * xv[ps][2].z + b11 * xv[ps][3].z;
+            v[3] = b00 * xv[ps][0].w + b01 * xv[ps][1].w + b10 * xv[ps][2].w + b11 * xv[ps][3].w;
+        }
         unsigned p0[NPL], p1[NPL];
         split_planes<NPL>(v[0], v[1], p0);
         split_planes<NPL>(v[2], v[3], p1);

@@ -1,0 +1,217 @@
+// A/B of the dense-convolution weight gradient: the patch kernel of conv_wgrad_kernels.h (debug bit 28 set: the kernels of
+// dcn_mm_kernels.h are off) against dcn_wgrad_mm_kernel<NP, DENSE> behind LSNET_CONV_WGRAD_MM=1, on the layer shapes of
+// the benchmark step (tools/bench_convs.py SH), through the C ABI only (no torch: the binary starts in a second).
+// Each result is also checked against a double-precision sum on the host for 48 sampled weight elements.
+//   hipcc --offload-arch=gfx950 -O2 tools/ubench/wgrad_ab.hip -o tools/ubench/wgrad_ab -ldl
+//   tools/ubench/wgrad_ab [path to liblsnet_hip.so]
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "../../include/lsnet_hip.h"
+
+#define CK(x)                                                                          \
+    do {                                                                               \
+        hipError_t e_ = (x);                                                           \
+        if (e_ != hipSuccess) {                                                        \
+            printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+            exit(2);                                                                   \
+        }                                                                              \
+    } while (0)
+
+__global__ void fill_kernel(float *p, size_t n, unsigned seed, float scale)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned h = (unsigned)i * 2654435761u ^ seed;
+        h ^= h >> 16, h *= 0x7feb352du, h ^= h >> 15, h *= 0x846ca68bu, h ^= h >> 16;
+        p[i] = ((float)(h & 0xffffff) / 8388608.f - 1.f) * scale;
+    }
+}
+
+typedef int (*wgrad_fn)(int, const lsn_conv_level *, float *, float *, int, int, int, int, int, int, int, int, lsn_stream_t);
+typedef int (*dbg_fn)(long long *, int);
+typedef const char *(*err_fn)(void);
+
+struct Shape {
+    const char *name;
+    int C, Co, k, stride;
+    int nlv;
+    int H[5], W[5];
+    int count;   // occurrences per training step
+    int accumulate, bias;
+};
+
+int main(int argc, char **argv)
+{
+    setenv("LSNET_CONV_WGRAD_MM", "1", 0);   // (LSNET_CONV_WGRAD_MM=2 in the environment: the library's own selection)
+    const char *so = argc > 1 ? argv[1] : "lsnet_amd/csrc/liblsnet_hip.so";
+    void *h = dlopen(so, RTLD_NOW);
+    if (!h) {
+        printf("dlopen: %s\n", dlerror());
+        return 2;
+    }
+    wgrad_fn wgrad = (wgrad_fn)dlsym(h, "lsn_conv2d_backward_weight_multi");
+    dbg_fn dbg = (dbg_fn)dlsym(h, "lsn_debug_phase_clocks");
+    err_fn lasterr = (err_fn)dlsym(h, "lsn_last_error");
+    if (!wgrad || !dbg || !lasterr) return 2;
+    const int B = 2;
+    const Shape shapes[] = {
+        {"l2 1x1 128->512", 128, 512, 1, 1, 1, {100}, {168}, 4, 0, 0},
+        {"l2 ds 1x1 s2 256->512", 256, 512, 1, 2, 1, {200}, {336}, 1, 0, 0},
+        {"l3 1x1 512->256", 512, 256, 1, 1, 1, {100}, {168}, 1, 0, 0},
+        {"l3 3x3 s2 256", 256, 256, 3, 2, 1, {100}, {168}, 1, 0, 0},
+        {"l3 3x3 256", 256, 256, 3, 1, 1, {50}, {84}, 5, 0, 0},
+        {"l3 1x1 256->1024", 256, 1024, 1, 1, 1, {50}, {84}, 6, 0, 0},
+        {"l3 1x1 1024->256", 1024, 256, 1, 1, 1, {50}, {84}, 5, 0, 0},
+        {"l3 ds 1x1 s2 512->1024", 512, 1024, 1, 2, 1, {100}, {168}, 1, 0, 0},
+        {"l4 1x1 1024->512", 1024, 512, 1, 1, 1, {50}, {84}, 1, 0, 0},
+        {"l4 3x3 s2 512", 512, 512, 3, 2, 1, {50}, {84}, 1, 0, 0},
+        {"l4 3x3 512", 512, 512, 3, 1, 1, {25}, {42}, 2, 0, 0},
+        {"l4 1x1 512->2048", 512, 2048, 1, 1, 1, {25}, {42}, 3, 0, 0},
+        {"l4 1x1 2048->512", 2048, 512, 1, 1, 1, {25}, {42}, 2, 0, 0},
+        {"l4 ds 1x1 s2 1024->2048", 1024, 2048, 1, 2, 1, {50}, {84}, 1, 0, 0},
+        {"fpn lat 512->256 P3", 512, 256, 1, 1, 1, {100}, {168}, 1, 0, 1},
+        {"fpn lat 1024->256 P4", 1024, 256, 1, 1, 1, {50}, {84}, 1, 0, 1},
+        {"fpn lat 2048->256 P5", 2048, 256, 1, 1, 1, {25}, {42}, 1, 0, 1},
+        {"fpn 3x3 256 P3", 256, 256, 3, 1, 1, {100}, {168}, 1, 0, 1},
+        {"fpn 3x3 s2 256 P5->P6", 256, 256, 3, 2, 1, {25}, {42}, 1, 0, 1},
+        {"head 3x3 256, 5 levels, accumulate", 256, 256, 3, 1, 5, {100, 50, 25, 13, 7}, {168, 84, 42, 21, 11}, 2, 1, 1},
+        {"edge 3x3 256 13x21 (546 px)", 256, 256, 3, 1, 1, {13}, {21}, 0, 0, 1},
+    };
+    double tot_old = 0, tot_new = 0;
+    printf("%-38s %9s %7s %9s %7s %9s %9s %9s %s\n", "shape", "old us", "TF", "new us", "TF", "new-old", "old-ref", "new-ref", "");
+    for (const Shape &s : shapes) {
+        const int K = s.k * s.k, pad = s.k / 2;
+        float *x[5], *go[5];
+        int Ho[5], Wo[5];
+        lsn_conv_level lv[5] = {};
+        double px = 0;
+        for (int i = 0; i < s.nlv; ++i) {
+            Ho[i] = (s.H[i] + 2 * pad - s.k) / s.stride + 1, Wo[i] = (s.W[i] + 2 * pad - s.k) / s.stride + 1;
+            const size_t nx = (size_t)B * s.H[i] * s.W[i] * s.C, ng = (size_t)B * Ho[i] * Wo[i] * s.Co;
+            CK(hipMalloc(&x[i], nx * 4));
+            CK(hipMalloc(&go[i], ng * 4));
+            hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, 0, x[i], nx, 17u + i, 1.f);
+            hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, 0, go[i], ng, 91u + i, 1.f);
+            lv[i].x = x[i], lv[i].grad_out = go[i], lv[i].B = B, lv[i].H = s.H[i], lv[i].W = s.W[i];
+            px += (double)B * Ho[i] * Wo[i];
+        }
+        const size_t nW = (size_t)s.Co * K * s.C;
+        float *gw[2], *gb[2];
+        std::vector<float> hw[2], hb[2];
+        double us[2] = {0, 0};
+        for (int mode = 0; mode < 2; ++mode) {   // 0: old kernels, 1: new
+            dbg(nullptr, mode == 0 ? (1 << 28) : 0);
+            CK(hipMalloc(&gw[mode], nW * 4));
+            CK(hipMalloc(&gb[mode], (size_t)s.Co * 4));
+            auto run = [&]() {
+                const int rc = wgrad(s.nlv, lv, gw[mode], s.bias ? gb[mode] : nullptr, s.C, s.Co, s.k, s.k, s.stride, pad, 1,
+                                     s.accumulate, nullptr);
+                if (rc != 0) {
+                    printf("%s: mode %d rc %d: %s\n", s.name, mode, rc, lasterr());
+                    exit(3);
+                }
+            };
+            hipEvent_t e0, e1;
+            CK(hipEventCreate(&e0));
+            CK(hipEventCreate(&e1));
+            for (int i = 0; i < 2; ++i) run();
+            CK(hipEventRecord(e0, 0));
+            const int reps = 10;
+            for (int i = 0; i < reps; ++i) run();
+            CK(hipEventRecord(e1, 0));
+            CK(hipEventSynchronize(e1));
+            float ms = 0;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            us[mode] = ms * 1000.0 / reps;
+            // the checked run: from a known start (accumulate adds to it)
+            hipLaunchKernelGGL(fill_kernel, dim3(256), dim3(256), 0, 0, gw[mode], nW, 5u, 0.25f);
+            hipLaunchKernelGGL(fill_kernel, dim3(4), dim3(256), 0, 0, gb[mode], (size_t)s.Co, 6u, 0.25f);
+            run();
+            CK(hipDeviceSynchronize());
+            hw[mode].resize(nW), hb[mode].resize(s.Co);
+            CK(hipMemcpy(hw[mode].data(), gw[mode], nW * 4, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(hb[mode].data(), gb[mode], (size_t)s.Co * 4, hipMemcpyDeviceToHost));
+        }
+        // host reference on sampled elements
+        std::vector<float> start(nW), startb(s.Co);
+        {
+            float *tmp;
+            CK(hipMalloc(&tmp, nW * 4));
+            hipLaunchKernelGGL(fill_kernel, dim3(256), dim3(256), 0, 0, tmp, nW, 5u, 0.25f);
+            CK(hipMemcpy(start.data(), tmp, nW * 4, hipMemcpyDeviceToHost));
+            hipLaunchKernelGGL(fill_kernel, dim3(4), dim3(256), 0, 0, tmp, (size_t)s.Co, 6u, 0.25f);
+            CK(hipMemcpy(startb.data(), tmp, (size_t)s.Co * 4, hipMemcpyDeviceToHost));
+            CK(hipFree(tmp));
+        }
+        std::vector<std::vector<float>> hx(s.nlv), hg(s.nlv);
+        for (int i = 0; i < s.nlv; ++i) {
+            hx[i].resize((size_t)B * s.H[i] * s.W[i] * s.C), hg[i].resize((size_t)B * Ho[i] * Wo[i] * s.Co);
+            CK(hipMemcpy(hx[i].data(), x[i], hx[i].size() * 4, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(hg[i].data(), go[i], hg[i].size() * 4, hipMemcpyDeviceToHost));
+        }
+        double err_ref[2] = {0, 0}, scale = 0, errb[2] = {0, 0}, scaleb = 0;
+        unsigned rng = 12345u;
+        for (int t = 0; t < 48; ++t) {
+            rng = rng * 1664525u + 1013904223u;
+            const int co = (rng >> 8) % s.Co;
+            rng = rng * 1664525u + 1013904223u;
+            const int kk = t < K ? t : (rng >> 8) % K;   // every tap at least once
+            rng = rng * 1664525u + 1013904223u;
+            const int c = (rng >> 8) % s.C;
+            const int ky = kk / s.k, kx = kk % s.k;
+            double acc = 0;
+            for (int i = 0; i < s.nlv; ++i)
+                for (int b = 0; b < B; ++b)
+                    for (int oy = 0; oy < Ho[i]; ++oy) {
+                        const int iy = oy * s.stride - pad + ky;
+                        if (iy < 0 || iy >= s.H[i]) continue;
+                        for (int ox = 0; ox < Wo[i]; ++ox) {
+                            const int ix = ox * s.stride - pad + kx;
+                            if (ix < 0 || ix >= s.W[i]) continue;
+                            acc += (double)hg[i][((size_t)(b * Ho[i] + oy) * Wo[i] + ox) * s.Co + co] *
+                                   (double)hx[i][((size_t)(b * s.H[i] + iy) * s.W[i] + ix) * s.C + c];
+                        }
+                    }
+            const size_t wi = ((size_t)co * K + kk) * s.C + c;
+            const double want = acc + (s.accumulate ? start[wi] : 0.0);
+            scale = fmax(scale, fabs(want));
+            for (int m = 0; m < 2; ++m) err_ref[m] = fmax(err_ref[m], fabs(hw[m][wi] - want));
+            if (s.bias && t < 8) {
+                double sb = 0;
+                for (int i = 0; i < s.nlv; ++i)
+                    for (size_t p = 0; p < (size_t)B * Ho[i] * Wo[i]; ++p) sb += hg[i][p * s.Co + co];
+                const double wb = sb + (s.accumulate ? startb[co] : 0.0);
+                scaleb = fmax(scaleb, fabs(wb));
+                for (int m = 0; m < 2; ++m) errb[m] = fmax(errb[m], fabs(hb[m][co] - wb));
+            }
+        }
+        double dmax = 0, wmax = 0;
+        bool same = true;
+        for (size_t i = 0; i < nW; ++i) {
+            dmax = fmax(dmax, fabs((double)hw[0][i] - hw[1][i]));
+            wmax = fmax(wmax, fabs((double)hw[0][i]));
+            same = same && hw[0][i] == hw[1][i];
+        }
+        const double fl = 2.0 * px * s.C * s.Co * K;
+        printf("%-38s %9.1f %7.1f %9.1f %7.1f %9.1e %9.1e %9.1e", s.name, us[0], fl / us[0] * 1e-6, us[1], fl / us[1] * 1e-6,
+               dmax / wmax, err_ref[0] / scale, err_ref[1] / scale);
+        if (s.bias) printf("  bias %.1e %.1e", errb[0] / scaleb, errb[1] / scaleb);
+        printf("%s\n", same ? "  (bit-identical: the patch kernel ran both times)" : "");
+        fflush(stdout);
+        tot_old += us[0] * s.count, tot_new += us[1] * s.count;
+        for (int i = 0; i < s.nlv; ++i) {
+            CK(hipFree(x[i]));
+            CK(hipFree(go[i]));
+        }
+        for (int m = 0; m < 2; ++m) {
+            CK(hipFree(gw[m]));
+            CK(hipFree(gb[m]));
+        }
+    }
+    printf("per step (counts of the benchmark step): old %.0f us, new %.0f us\n", tot_old, tot_new);
+    return 0;
+}
