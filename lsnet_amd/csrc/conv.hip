@@ -502,7 +502,7 @@ int conv_wgrad_mm(int n, const lsn_conv_level *lv, float *gw, float *gb, int C, 
 {
     static const int off = [] { const char *e = getenv("LSNET_WGRAD_OLD"); return e ? atoi(e) : 0; }();
     // 3x3 / stride 1 / dilation 1 and 1x1 (any stride) run here.  (A strided 3x3 needs a 3 x 33 patch: one workgroup per
-    // CU and 2-way bank-conflicted tr-reads -- the general kernel of dcn.hip was faster, profiles/r3_wgrad_table.txt.)
+    // CU and 2-way bank-conflicted tr-reads -- the general kernel of dcn.hip was faster.)
     const bool k33 = kh == 3 && kw == 3 && stride == 1 && dil == 1, k11 = kh == 1 && kw == 1;
     if (off || n < 1 || n > CV_MAXLV || !(k33 || k11) || C % 4 != 0) return 1;
     WgArgs a = {};
