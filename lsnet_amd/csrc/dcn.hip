@@ -1180,7 +1180,8 @@ static int conv_wgrad_dense_mm(int n, const lsn_conv_level *lv, float *gw, float
             const int Ho = (lv[i].H + 2 * pad - (dil * (kh - 1) + 1)) / stride + 1, Wo = (lv[i].W + 2 * pad - (dil * (kw - 1) + 1)) / stride + 1;
             px += (int64_t)lv[i].B * (Ho > 0 ? Ho : 0) * (Wo > 0 ? Wo : 0);
         }
-        const bool win = kh * kw >= 9 ? px >= 4096 : ((C >= 1024 && Co >= 512) || (stride >= 2 && C >= 512));
+        // (all of them measured at >= 2100 output pixels; smaller launches stay where they were)
+        const bool win = kh * kw >= 9 ? px >= 4096 : px >= 2048 && ((C >= 1024 && Co >= 512) || (stride >= 2 && C >= 512));
         if (!win) return 1;
     }
     DcnArgs a = {};
