@@ -79,13 +79,14 @@ def test_training_curve_follows_reference_runner(math):
     BatchNorm folded into its convolutions, fused SGD; profiles/r3_gpu_tests.log): iterations 1-6 <= 2.0e-4 / 6.9e-4 / 1.3e-4,
     iterations 7-12 <= 2.8e-2 / 1.2e-2 / 4.7e-2 in one run, 3.4e-2 / 3.9e-2 / 3.2e-1 (loss_cls of the exact mode at
     iteration 8, where the loss has fallen to 1.25) in another with different deformable kernels: the late half of THIS
-    fixture measures chaos, not kernels, and keeps a tolerance of 0.5.  What holds all twelve iterations tight is
+    fixture measures chaos, not kernels, and only has to stay within a factor of two (tolerance 1.0; 0.5 left the 0.32 of
+    that run a margin of 1.5 in a suite the driver runs with -x).  What holds all twelve iterations tight is
     `test_training_curve_low_learning_rate` below."""
     from lsnet_amd import _lib
     before = _lib.get_math_mode()
     _lib.set_math_mode(math)
     try:
-        worst = gc.train_curve_case(_dev(), early_tol=5e-3 if math == 'bf16x3' else 7.5e-4, late_tol=0.5, rtol_weight=5e-2, channels_last=True)
+        worst = gc.train_curve_case(_dev(), early_tol=5e-3 if math == 'bf16x3' else 7.5e-4, late_tol=1.0, rtol_weight=5e-2, channels_last=True)
     finally:
         _lib.set_math_mode(before)
     print(math, f'worst relative loss deviation {worst:.2e}')
