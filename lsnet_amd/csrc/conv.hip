@@ -528,6 +528,16 @@ int conv_wgrad_mm(int n, const lsn_conv_level *lv, float *gw, float *gb, int C, 
     for (int i = 0; i < n; ++i) px += (double)a.lv[i].B * a.lv[i].Ho * a.lv[i].Wo, in_el += (double)a.lv[i].B * a.lv[i].H * a.lv[i].W * C;
     ProfSpan prof(PROF_CONV_WGRAD, 2.0 * px * Co * C * kh * kw, 4.0 * (in_el + px * Co + (double)Co * kh * kw * C), st);
     if (kh * kw == 1) {   // one tap: 32 .. 64 channels per wave on either side, by the layer's width
+        // LSNET_WGRAD_TILE=11|12|21|22 forces the (ci, co) tiles per wave (A/B runs of tools/ubench/wgrad_ab: smaller tiles
+        // mean more blocks, fewer pixel splits and a smaller partial-tile round trip)
+        static const int force_t = [] { const char *e = getenv("LSNET_WGRAD_TILE"); return e ? atoi(e) : 0; }();
+        switch (force_t) {
+        case 11: return launch_wgrad_cfg<1, 1, 1, 2, 2, 16, false>(a, gw, gb, accumulate, st);
+        case 12: return launch_wgrad_cfg<1, 2, 1, 2, 2, 16, false>(a, gw, gb, accumulate, st);
+        case 21: return launch_wgrad_cfg<2, 1, 1, 2, 2, 16, false>(a, gw, gb, accumulate, st);
+        case 22: return launch_wgrad_cfg<2, 2, 1, 2, 2, 16, false>(a, gw, gb, accumulate, st);
+        default: break;
+        }
         if (C <= 64)
             return Co <= 64 ? launch_wgrad_cfg<1, 1, 1, 2, 2, 16, false>(a, gw, gb, accumulate, st)
                             : launch_wgrad_cfg<1, 2, 1, 2, 2, 16, false>(a, gw, gb, accumulate, st);
