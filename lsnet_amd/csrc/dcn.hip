@@ -1190,6 +1190,7 @@ static int conv_wgrad_dense_mm(int n, const lsn_conv_level *lv, float *gw, float
         Lvl &L = a.lv[i];
         const int B = lv[i].B, H = lv[i].H, W = lv[i].W;
         if (!lv[i].x || !lv[i].grad_out || B <= 0 || H <= 0 || W <= 0) return 1;
+        if (((reinterpret_cast<uintptr_t>(lv[i].x) | reinterpret_cast<uintptr_t>(lv[i].grad_out)) & 15) != 0) return 1;   // 16-byte loads
         const int Ho = (H + 2 * pad - (dil * (kh - 1) + 1)) / stride + 1, Wo = (W + 2 * pad - (dil * (kw - 1) + 1)) / stride + 1;
         if (Ho <= 0 || Wo <= 0) return 1;
         if ((int64_t)B * H * W * C * 4 >= ((int64_t)1 << 31) || (int64_t)B * Ho * Wo * Co * 4 >= ((int64_t)1 << 31)) return 1;
