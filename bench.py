@@ -83,8 +83,9 @@ _COMMON_NOTES = {
     'conv_bwd_data': 'lsn::conv_mm_kernel on grad_output with transposed / flipped weight images (one launch per residue '
                      'class of a strided convolution)',
     'conv_wgrad': 'lsn::conv_wgrad_kernel + conv_wgrad_reduce_kernel (3x3 / 1x1: input patch + grad_output rows staged once '
-                  'per 16-pixel segment, ds_read_b64_tr_b16 fragments, split-pixel partial tiles); strided 3x3 and other tap '
-                  'counts: dcn_wgrad_xn_kernel<PLAIN>',
+                  'per 16-pixel segment, ds_read_b64_tr_b16 fragments, split-pixel partial tiles); wide 3x3 / deep 1x1 layers: '
+                  'dcn_tap_table_kernel + dcn_gout_frag_kernel + dcn_wgrad_mm_kernel<NP, DENSE> (grad_output pre-split once into '
+                  'fragment order); other strided 3x3 and tap counts: dcn_wgrad_xn_kernel<PLAIN>',
     'norm': 'lsn::bn_act_fwd / bn_act_bwd / bn_param_reduce and gn_stats / gn_apply / gn_bwd_reduce / gn_bwd_apply / '
             'gn_param_grad kernels (frozen-statistics BatchNorm + add + ReLU, GroupNorm + ReLU; streaming passes)',
     'gconv': 'lsn::gconv_kernel / gconv_wgrad_kernel (grouped convolution, exact fp32)',
