@@ -51,6 +51,10 @@ class BucketedGradReducer:
     def __init__(self, params, bucket_mb=25.0, process_group=None):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # collectives are skipped on a single rank -- unless asked for: LSNET_FORCE_COLLECTIVES=1 sends the buckets
+        # through a one-rank group all the same, which is how a 1-GPU box executes the RCCL side of this class
+        # (async work objects, stream ordering against the kernels that fill the buckets, the wait in finish())
+        self.collective = self.world > 1 or (dist.is_initialized() and os.environ.get('LSNET_FORCE_COLLECTIVES') == '1')
         self.params = [p for p in params if p.requires_grad]
         self.buckets = []          # dict(flat, params, views, pending, work)
         cap = int(bucket_mb * 1024 * 1024 / 4)
@@ -109,7 +113,7 @@ class BucketedGradReducer:
         self._zeroed = True
 
     def _launch_ready(self):
-        if self.world == 1:
+        if not self.collective:
             return
         while self._next < len(self.buckets) and self.buckets[self._next]['pending'] == 0:
             b = self.buckets[self._next]
@@ -158,14 +162,15 @@ class BucketedGradReducer:
                     v.copy_(p.grad)
                     p.grad = v
             b['pending'] = 0
-            if self.world == 1:
+            if not self.collective:
                 self._next += 1
             else:
                 self._launch_ready()
-        if self.world > 1:
+        if self.collective:
             for b in self.buckets:
                 b['work'].wait()
-                b['flat'].div_(self.world)
+                if self.world > 1:
+                    b['flat'].div_(self.world)
         self._expected = dict(self._events)
         self._zeroed = False
         self.reset()

@@ -207,6 +207,64 @@ def test_two_rank_data_parallel_equals_large_batch_sgd(bucket_mb):
     assert torch.equal(sd[0]['unused'], torch.zeros(3))
 
 
+def _one_rank_worker(rank, world, port, out_dir, backend, device):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
+                      LSNET_FORCE_COLLECTIVES='1')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    if device != 'cpu':
+        torch.cuda.set_device(0)
+    dist.init_process_group(backend, rank=0, world_size=1)
+    try:
+        torch.manual_seed(100)
+        model = DataParallelModel(Toy().to(device), bucket_mb=0.0002)
+        assert model.reducer.collective and model.reducer.world == 1
+        opt = build_optimizer(model, dict(type='SGD', lr=0.1, momentum=0.9))
+        r = EpochBasedRunner(model, optimizer=opt, logger=lambda s: None)
+        r.register_training_hooks(dict(policy='step', step=[100]), dict(grad_clip=dict(max_norm=35, norm_type=2)),
+                                  None, dict(interval=1000, hooks=[]))
+        launched = []
+        orig = dist.all_reduce
+
+        def counting(*a, **k):
+            launched.append(1)
+            return orig(*a, **k)
+        dist.all_reduce = counting
+        try:
+            r.run([[{k: v.to(device) for k, v in b.items()} for b in _batches(5, 10)]], [('train', 1)], 2)
+        finally:
+            dist.all_reduce = orig
+        assert len(launched) >= 10 * len(model.reducer.buckets), len(launched)   # every bucket of every step went out
+        torch.save({k: v.detach().cpu().clone() for k, v in model.module.state_dict().items()},
+                   os.path.join(out_dir, 'rank0.pt'))
+    finally:
+        dist.destroy_process_group()
+
+
+def one_rank_forced_collectives_case(backend, device):
+    """LSNET_FORCE_COLLECTIVES=1: a one-rank group still all-reduces every bucket (hook-driven launches during backward,
+    the wait in finish()); the training run equals plain SGD.  With backend 'nccl' this is an RCCL execution of the
+    reducer on a 1-GPU box (tests/test_rccl_gpu.py)."""
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_one_rank_worker, args=(1, _free_port(), d, backend, device), nprocs=1, join=True)
+        sd = torch.load(os.path.join(d, 'rank0.pt'))
+    torch.manual_seed(100)
+    ref = Toy()
+    opt = torch.optim.SGD(ref.parameters(), lr=0.1, momentum=0.9)
+    data = _batches(5, 10)
+    for _ in range(2):
+        for i in range(5):
+            opt.zero_grad()
+            ref.train_step(data[i], None)['loss'].backward()
+            torch.nn.utils.clip_grad_norm_([p for p in ref.parameters() if p.requires_grad and p.grad is not None], 35)
+            opt.step()
+    for k, v in ref.state_dict().items():
+        assert torch.allclose(sd[k], v, rtol=1e-4, atol=1e-5), k
+
+
+def test_one_rank_group_with_forced_collectives_equals_plain_sgd():
+    one_rank_forced_collectives_case('gloo', 'cpu')
+
+
 # ---------------------------------------------------------------------------------------------------
 # GraphedForwardBackward: without a GPU it runs its eager path -- gradient-view buckets, in-place accumulation,
 # bucket all-reduce -- which is everything except the hipGraph capture itself (covered by the gpu tests).
