@@ -52,7 +52,7 @@ static int part_buffer(size_t floats, float **p)
     return 0;
 }
 
-template <int TM, int TN, int WM, int WN, int NP, bool UNAL>
+template <int TM, int TN, int WM, int WN, int NP, bool UNAL, int OCC = 2>
 static int launch_conv_cfg(ConvArgs &a, int ks, hipStream_t st)
 {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -71,7 +71,7 @@ static int launch_conv_cfg(ConvArgs &a, int ks, hipStream_t st)
     if (ks > 1)
         if (int rc = part_buffer(n * ks, &a.part)) return rc;
     dim3 grid(tiles, (a.Co + BN - 1) / BN, ks);
-    auto k = conv_mm_kernel<TM, TN, WM, WN, NP, UNAL>;
+    auto k = conv_mm_kernel<TM, TN, WM, WN, NP, UNAL, OCC>;
     static bool attr_set = false;   // per instantiation
     if (!attr_set) {
         LSN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -85,6 +85,14 @@ static int launch_conv_cfg(ConvArgs &a, int ks, hipStream_t st)
     }
     LSN_HIP(hipGetLastError());
     return 0;
+}
+
+// Experimental fat tiles (one workgroup per CU, one wave per SIMD): aligned slabs only.
+template <int TM, int TN, int WM, int WN>
+static int launch_conv_fat(ConvArgs &a, int ks, hipStream_t st)
+{
+    return conv_np() == 3 ? launch_conv_cfg<TM, TN, WM, WN, 3, false, 1>(a, ks, st)
+                          : launch_conv_cfg<TM, TN, WM, WN, 6, false, 1>(a, ks, st);
 }
 
 template <int TM, int TN, int WM, int WN>
@@ -124,8 +132,10 @@ static int conv_forward(ConvArgs &a, hipStream_t st)
     if (a.Co % 256 == 0 && a.C % 4 == 0 && blocks(64, 256) >= 512) cfg = 5;
     if ((force == 1 || force == 2) && a.Co > 64) cfg = force;   // (the weight image is padded for the natural width only)
     if (force == 5 && a.Co % 256 == 0 && a.C % 4 == 0) cfg = 5;
+    // 7: 256 px x 128 co, 8: 128 px x 256 co -- the fat register tiles (A/B runs only: never chosen here)
+    if ((force == 7 || force == 8) && a.Co % 256 == 0 && a.C % 4 == 0 && a.xpitch % 4 == 0) cfg = force;
     const int nb = cfg == 1 ? blocks(128, 128) : cfg == 2 ? blocks(64, 128) : cfg == 3 ? blocks(128, 64)
-                 : cfg == 5 ? blocks(64, 256) : blocks(128, 32);
+                 : cfg == 5 ? blocks(64, 256) : cfg == 7 ? blocks(256, 128) : cfg == 8 ? blocks(128, 256) : blocks(128, 32);
     const int Tall = a.kh * a.kw * cv_ncc(a.C);
     int ks = 1;
     if (a.nlv == 1 && !a.ostep && nb <= 320 && Tall >= 16) {
@@ -140,6 +150,8 @@ static int conv_forward(ConvArgs &a, hipStream_t st)
     case 2: return launch_conv<1, 2, 2, 2>(a, ks, st);
     case 3: return launch_conv<1, 2, 4, 1>(a, ks, st);
     case 5: return launch_conv<2, 2, 1, 4>(a, ks, st);
+    case 7: return launch_conv_fat<4, 2, 2, 2>(a, ks, st);
+    case 8: return launch_conv_fat<2, 4, 2, 2>(a, ks, st);
     default: return launch_conv<1, 1, 4, 1>(a, ks, st);
     }
 }

@@ -210,8 +210,11 @@ __device__ __forceinline__ bf16x8 cv_load_frag(__amdgpu_buffer_rsrc_t rs, int vo
 // UNAL: the reduction channel count is not a multiple of 4 (the data gradient of LSHead's 27-channel offset / mask
 // convolutions): a pixel's slab is then neither 16-byte aligned nor a whole number of float4, so the pixel operand is
 // fetched with four 4-byte loads per lane, each with its own channel guard.
-template <int TM, int TN, int WM, int WN, int NP, bool UNAL = false>
-__global__ __launch_bounds__(256, 2) void conv_mm_kernel(const ConvArgs a)
+// OCC: workgroups per CU the register allocation aims at.  2 for the tiles of the step (<= 256 registers per lane); 1 for
+// the experimental fat tiles (4 x 2 / 2 x 4 register tiles of 32 x 32: 346 / 322 registers, one wave per SIMD, half the
+// weight-fragment or LDS traffic per MFMA), reachable with LSNET_CONV_TILE=7 / 8 only.
+template <int TM, int TN, int WM, int WN, int NP, bool UNAL = false, int OCC = 2>
+__global__ __launch_bounds__(256, OCC) void conv_mm_kernel(const ConvArgs a)
 {
     using SC = SplitCfg<NP>;
     constexpr int NPL = SC::NPL;
