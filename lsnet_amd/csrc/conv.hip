@@ -88,11 +88,11 @@ static int launch_conv_cfg(ConvArgs &a, int ks, hipStream_t st)
 }
 
 // Experimental fat tiles (one workgroup per CU, one wave per SIMD): aligned slabs only.
-template <int TM, int TN, int WM, int WN>
+template <int TM, int TN, int WM, int WN, int OCC = 1>
 static int launch_conv_fat(ConvArgs &a, int ks, hipStream_t st)
 {
-    return conv_np() == 3 ? launch_conv_cfg<TM, TN, WM, WN, 3, false, 1>(a, ks, st)
-                          : launch_conv_cfg<TM, TN, WM, WN, 6, false, 1>(a, ks, st);
+    return conv_np() == 3 ? launch_conv_cfg<TM, TN, WM, WN, 3, false, OCC>(a, ks, st)
+                          : launch_conv_cfg<TM, TN, WM, WN, 6, false, OCC>(a, ks, st);
 }
 
 template <int TM, int TN, int WM, int WN>
@@ -133,9 +133,11 @@ static int conv_forward(ConvArgs &a, hipStream_t st)
     if ((force == 1 || force == 2) && a.Co > 64) cfg = force;   // (the weight image is padded for the natural width only)
     if (force == 5 && a.Co % 256 == 0 && a.C % 4 == 0) cfg = 5;
     // 7: 256 px x 128 co, 8: 128 px x 256 co -- the fat register tiles (A/B runs only: never chosen here)
-    if ((force == 7 || force == 8) && a.Co % 256 == 0 && a.C % 4 == 0 && a.xpitch % 4 == 0) cfg = force;
-    const int nb = cfg == 1 ? blocks(128, 128) : cfg == 2 ? blocks(64, 128) : cfg == 3 ? blocks(128, 64)
-                 : cfg == 5 ? blocks(64, 256) : cfg == 7 ? blocks(256, 128) : cfg == 8 ? blocks(128, 256) : blocks(128, 32);
+    // 9 / 10: the 64 x 256 / 64 x 128 tiles with the fine MFMA / staging interleave (OCC = 0 of conv_mm_kernel)
+    if (force >= 7 && force <= 10 && a.Co % 256 == 0 && a.C % 4 == 0 && a.xpitch % 4 == 0) cfg = force;
+    const int nb = cfg == 1 ? blocks(128, 128) : (cfg == 2 || cfg == 10) ? blocks(64, 128) : cfg == 3 ? blocks(128, 64)
+                 : (cfg == 5 || cfg == 9) ? blocks(64, 256) : cfg == 7 ? blocks(256, 128) : cfg == 8 ? blocks(128, 256)
+                 : blocks(128, 32);
     const int Tall = a.kh * a.kw * cv_ncc(a.C);
     int ks = 1;
     if (a.nlv == 1 && !a.ostep && nb <= 320 && Tall >= 16) {
@@ -152,6 +154,8 @@ static int conv_forward(ConvArgs &a, hipStream_t st)
     case 5: return launch_conv<2, 2, 1, 4>(a, ks, st);
     case 7: return launch_conv_fat<4, 2, 2, 2>(a, ks, st);
     case 8: return launch_conv_fat<2, 4, 2, 2>(a, ks, st);
+    case 9: return launch_conv_fat<2, 2, 1, 4, 0>(a, ks, st);
+    case 10: return launch_conv_fat<1, 2, 2, 2, 0>(a, ks, st);
     default: return launch_conv<1, 1, 4, 1>(a, ks, st);
     }
 }

@@ -213,8 +213,10 @@ __device__ __forceinline__ bf16x8 cv_load_frag(__amdgpu_buffer_rsrc_t rs, int vo
 // OCC: workgroups per CU the register allocation aims at.  2 for the tiles of the step (<= 256 registers per lane); 1 for
 // the experimental fat tiles (4 x 2 / 2 x 4 register tiles of 32 x 32: 346 / 322 registers, one wave per SIMD, half the
 // weight-fragment or LDS traffic per MFMA), reachable with LSNET_CONV_TILE=7 / 8 only.
+// OCC = 0: two workgroups per CU like the default, with the fine MFMA / staging interleave of the fat tiles (see the
+// slice loop; LSNET_CONV_TILE=9 / 10: the 64 x 256 and 64 x 128 tiles in that form).
 template <int TM, int TN, int WM, int WN, int NP, bool UNAL = false, int OCC = 2>
-__global__ __launch_bounds__(256, OCC) void conv_mm_kernel(const ConvArgs a)
+__global__ __launch_bounds__(256, OCC ? OCC : 2) void conv_mm_kernel(const ConvArgs a)
 {
     using SC = SplitCfg<NP>;
     constexpr int NPL = SC::NPL;
@@ -435,8 +437,19 @@ __global__ __launch_bounds__(256, OCC) void conv_mm_kernel(const ConvArgs a)
                 acc[j][i] = mfma_bf16(Wf[0][j][SC::pb(prod)], Xf[0][i][SC::pa(prod)], acc[j][i]);
             }
             LSN_MFMA_PRIO(0);
-            if (t + 1 < T) commit_slice(ps, bn);   // registers hold the raw pixels of chunk t + 1
+            // (OCC != 2: unconditional -- the last iteration writes zeros into the buffer nobody reads again.  The branch
+            // makes the slice two basic blocks, and the scheduler interleaves inside one only: with it the six MFMAs of a
+            // slice issue back to back and its ~38 staging instructions after them, which a second wave on the SIMD
+            // covers and a lone wave does not; without it hipcc emits M vvvvvv M vvvvvv ... as the group barriers ask)
+            if (OCC != 2 || t + 1 < T) commit_slice(ps, bn);   // registers hold the raw pixels of chunk t + 1
             issue_slice(ps);
+            if constexpr (OCC != 2) {
+#pragma unroll
+                for (int g = 0; g < NM / NLD; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x006, OCC == 1 ? 6 : 3, 0);   // vector / scalar ALU instructions
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         issue_w(t + 1, 0);
