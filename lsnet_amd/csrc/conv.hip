@@ -471,7 +471,11 @@ static int launch_wgrad_cfg(WgArgs &a, float *gw, float *gb, int accumulate, hip
         return 0;
     };
     int rc;
-    if constexpr (UN_OK) {
+    static const int fine = [] { const char *e = getenv("LSNET_WGRAD_FINE"); return e ? atoi(e) : 0; }();   // A/B runs
+    if (fine && !un && !(TG == 9 && WI == 4)) {   // (the 4 x 1 wave layout of the narrow 3x3 form spills in this variant)
+        rc = npl == 2 ? launch(conv_wgrad_kernel<TI, TJ, TG, WI, WJ, 3, false, PMAX, true>)
+                      : launch(conv_wgrad_kernel<TI, TJ, TG, WI, WJ, 6, false, PMAX, true>);
+    } else if constexpr (UN_OK) {
         if (un)
             rc = npl == 2 ? launch(conv_wgrad_kernel<TI, TJ, TG, WI, WJ, 3, true, PMAX>)
                           : launch(conv_wgrad_kernel<TI, TJ, TG, WI, WJ, 6, true, PMAX>);

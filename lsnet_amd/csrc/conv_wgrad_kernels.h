@@ -53,7 +53,10 @@ struct WgArgs {
 // GUNAL: Co % 4 != 0 (27-channel offset / mask convolutions): grad_output rows are fetched with guarded 4-byte loads.
 // PMAX: patch pixels the instantiation stages, rounded up to whole passes of the 256 threads (54 = 3 x 18: stride-1
 // 3x3 with dilation 1; 16: one tap) -- every thread always fetches, splits and stores its slots: no exec-masked branches.
-template <int TI, int TJ, int TG, int WI, int WJ, int NP, bool GUNAL, int PMAX>
+// FINE (experiment, LSNET_WGRAD_FINE=1): as in conv_mm_kernel -- slice commits without their `t + 1 < T` branch (past the last
+// segment the loads are out-of-bounds zeros: harmless, also for the bias sum) + sched_group_barrier groups, so that the
+// split instructions of a slice sit between the MFMAs instead of behind them.
+template <int TI, int TJ, int TG, int WI, int WJ, int NP, bool GUNAL, int PMAX, bool FINE = false>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgArgs a)
 {
     using SC = SplitCfg<NP>;
@@ -167,7 +170,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgArgs a)
             for (int q = 0; q < NPL; ++q) *reinterpret_cast<uint2 *>(buf + q * XPL + xlds[it]) = make_uint2(p0[q], p1[q]);
         } else {
             const int it = sl - XL;
-            if (do_bias) bacc[0] += gv[it].x, bacc[1] += gv[it].y, bacc[2] += gv[it].z, bacc[3] += gv[it].w;
+            if constexpr (FINE) {   // branch-free: a branch would end the basic block the scheduler interleaves in
+                const float bm = do_bias ? 1.f : 0.f;
+                bacc[0] += bm * gv[it].x, bacc[1] += bm * gv[it].y, bacc[2] += bm * gv[it].z, bacc[3] += bm * gv[it].w;
+            } else if (do_bias) {
+                bacc[0] += gv[it].x, bacc[1] += gv[it].y, bacc[2] += gv[it].z, bacc[3] += gv[it].w;
+            }
             split_planes<NPL>(gv[it].x, gv[it].y, p0);
             split_planes<NPL>(gv[it].z, gv[it].w, p1);
 #pragma unroll
@@ -249,6 +257,25 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgArgs a)
             for (int q = 0; q < NPL; ++q) Xf[0][i][q] = frag(bc + q * XPL + xaddr[0][i][0], bc + q * XPL + xaddr[0][i][1]);
         open_seg(s_begin + t + 2, t + 2 < T);
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (FINE && TG == 1) {   // one tap: its MFMAs in NSL parts, one staging slice behind each (conv_mm_kernel)
+            constexpr int NMt = NP * TI * TJ;
+#pragma unroll
+            for (int sl = 0; sl < NSL; ++sl) {
+#pragma unroll
+                for (int m = sl * NMt / NSL; m < (sl + 1) * NMt / NSL; ++m) {
+                    const int prod = m / (TI * TJ), i = (m / TJ) % TI, j = m % TJ;
+                    acc[0][i][j] = mfma_bf16(Xf[0][i][SC::pa(prod)], Gf[j][SC::pb(prod)], acc[0][i][j]);
+                }
+                commit_slice(sl, bn);
+                issue_slice(sl);
+#pragma unroll
+                for (int g = 0; g < NMt / NSL; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);   // vector / scalar ALU instructions
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else
 #pragma unroll
         for (int tp = 0; tp < TG; ++tp) {
             if (tp + 1 < TG) {
@@ -268,14 +295,21 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgArgs a)
             // staging slices: TG == 9 spreads them over the taps, a single tap carries them all
 #pragma unroll
             for (int sl = (TG == 1 ? 0 : tp); sl < (TG == 1 ? NSL : (tp < NSL ? tp + 1 : 0)); ++sl) {
-                if (t + 1 < T) commit_slice(sl, bn);
+                if (FINE || t + 1 < T) commit_slice(sl, bn);
                 issue_slice(sl);
             }
             if (TG == 9 && tp == TG - 1) {   // slices that did not fit behind a tap (never with 5 slices and 9 taps)
 #pragma unroll
                 for (int sl = TG; sl < NSL; ++sl) {
-                    if (t + 1 < T) commit_slice(sl, bn);
+                    if (FINE || t + 1 < T) commit_slice(sl, bn);
                     issue_slice(sl);
+                }
+            }
+            if constexpr (FINE) {
+#pragma unroll
+                for (int g = 0; g < NP * TI * TJ; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);   // vector / scalar ALU instructions
                 }
             }
             __builtin_amdgcn_sched_barrier(0);

@@ -310,10 +310,10 @@ static int mm_prepare_weights(DcnArgs &a, bool backward, void *dst, hipStream_t 
     return 0;
 }
 
-template <int TM, int TN, int WM, int WN, int NP>
+template <int TM, int TN, int WM, int WN, int NP, bool FINE = false>
 static int launch_fwd_mm_cfg(const DcnArgs &a, hipStream_t st)
 {
-    auto k = dcn_fwd_mm_kernel<TM, TN, WM, WN, NP>;
+    auto k = dcn_fwd_mm_kernel<TM, TN, WM, WN, NP, FINE>;
     const size_t lds = dcn_fwd_mm_lds_bytes(SplitCfg<NP>::NPL, a.kh * a.kw * a.dg);
     if (int rc = set_lds(k, lds)) return rc;
     const int blocks = a.ntiles * (a.Co / (WN * TN * 32));
@@ -326,6 +326,9 @@ static int launch_forward_mm(const DcnArgs &a, hipStream_t st)
 {
     ProfScope prof(PROF_FWD, a, st);
     const bool wide = a.Co % 256 == 0;
+    static const int fine = [] { const char *e = getenv("LSNET_DCN_FWD_FINE"); return e ? atoi(e) : 0; }();   // A/B runs
+    if (fine && wide)
+        return math_np() == 6 ? launch_fwd_mm_cfg<2, 2, 1, 4, 6, true>(a, st) : launch_fwd_mm_cfg<2, 2, 1, 4, 3, true>(a, st);
     if (math_np() == 6) return wide ? launch_fwd_mm_cfg<2, 2, 1, 4, 6>(a, st) : launch_fwd_mm_cfg<1, 2, 2, 2, 6>(a, st);
     return wide ? launch_fwd_mm_cfg<2, 2, 1, 4, 3>(a, st) : launch_fwd_mm_cfg<1, 2, 2, 2, 3>(a, st);
 }
@@ -845,7 +848,14 @@ static int launch_wgrad_mm(const DcnArgs &a_in, int nchunks, bool accumulate, hi
         LSN_HIP(hipGetLastError());
         return 0;
     };
-    if (dense) {
+    static const int fine = [] { const char *e = getenv("LSNET_DCN_WGRAD_FINE"); return e ? atoi(e) : 0; }();   // A/B runs
+    if (fine) {
+        if (dense) {
+            if (int rc = (math_np() == 6 ? go(dcn_wgrad_mm_kernel<6, true, true>) : go(dcn_wgrad_mm_kernel<3, true, true>))) return rc;
+        } else if (int rc = (math_np() == 6 ? go(dcn_wgrad_mm_kernel<6, false, true>) : go(dcn_wgrad_mm_kernel<3, false, true>))) {
+            return rc;
+        }
+    } else if (dense) {
         if (int rc = (math_np() == 6 ? go(dcn_wgrad_mm_kernel<6, true>) : go(dcn_wgrad_mm_kernel<3, true>))) return rc;
     } else if (int rc = (math_np() == 6 ? go(dcn_wgrad_mm_kernel<6>) : go(dcn_wgrad_mm_kernel<3>))) {
         return rc;

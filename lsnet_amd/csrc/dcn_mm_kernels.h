@@ -30,7 +30,9 @@ struct __align__(16) FTap {
 
 __host__ __device__ inline size_t dcn_fwd_mm_lds_bytes(int npl, int KD) { return (size_t)2 * npl * 64 * 64 + (size_t)64 * KD * sizeof(FTap); }
 
-template <int TM, int TN, int WM, int WN, int NP>
+// FINE (experiment, LSNET_DCN_FWD_FINE=1): as in conv_mm_kernel -- the slice commit without its branch + sched_group_barrier
+// groups put the blend / split instructions of a slice between its MFMAs instead of behind them.
+template <int TM, int TN, int WM, int WN, int NP, bool FINE = false>
 __global__ __launch_bounds__(256, 2) void dcn_fwd_mm_kernel(const DcnArgs a, const unsigned short *__restrict__ wf,
                                                             int wf_bytes)
 {
@@ -217,8 +219,15 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_mm_kernel(const DcnArgs a, con
                 const int prod = m / (TN * TM), j = (m / TM) % TN, i = m % TM;
                 acc[j][i] = mfma_bf16(Wf[0][j][SC::pb(prod)], Xf[0][i][SC::pa(prod)], acc[j][i]);
             }
-            if (t + 1 < T) commit_slice(ps, bn);
+            if (FINE || t + 1 < T) commit_slice(ps, bn);   // (FINE: the last iteration commits a repeated chunk nobody reads)
             issue_slice(ps);
+            if constexpr (FINE) {
+#pragma unroll
+                for (int g = 0; g < NM / NLD; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);   // vector / scalar ALU instructions
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         cm = ci;
@@ -350,7 +359,10 @@ __host__ __device__ inline size_t dcn_wgrad_mm_lds_bytes(int npl) { return (size
 
 // DENSE: every sampling position is a grid point (weights 1, 0, 0, 0): one load per position instead of four, and the value
 // itself (times the validity of the position: zero padding) instead of the blend.
-template <int NP, bool DENSE = false>
+// FINE (experiment, LSNET_DCN_WGRAD_FINE=1): the slice commit without its `t + 1 < T` branch (the last iteration commits a
+// repeated chunk into the stage nobody reads again) + sched_group_barrier groups, so that the ~75 blend / split
+// instructions of a slice sit BETWEEN its 12 MFMAs instead of behind them (see conv_mm_kernel).
+template <int NP, bool DENSE = false, bool FINE = false>
 __global__ __launch_bounds__(256, 2) void dcn_wgrad_mm_kernel(const DcnArgs a, int nchunks, const unsigned short *__restrict__ gimg,
                                                               int gimg_bytes, float *__restrict__ part, const int *__restrict__ meta)
 {
@@ -533,8 +545,15 @@ __global__ __launch_bounds__(256, 2) void dcn_wgrad_mm_kernel(const DcnArgs a, i
                     const int prod = m / (TI * TJ), i = (m / TJ) % TI, j = m % TJ;
                     acc[i][j] = mfma_bf16(Xf[0][i][SC::pa(prod)], Gf[0][j][SC::pb(prod)], acc[i][j]);
                 }
-                if (t + 1 < T) commit_slice(ps, slot1, bn);   // registers hold the corners of chunk t + 1
+                if (FINE || t + 1 < T) commit_slice(ps, slot1, bn);   // registers hold the corners of chunk t + 1
                 issue_slice(ps, slot2);                       // chunk t + 2 (saturated: a repeated fetch, never committed)
+                if constexpr (FINE) {
+#pragma unroll
+                    for (int g = 0; g < NM / 2; ++g) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  // one MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x006, DENSE ? 4 : 6, 0);      // vector / scalar ALU instructions
+                    }
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
             issue_g(t + 1, 0);
