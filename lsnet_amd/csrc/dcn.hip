@@ -662,13 +662,22 @@ static int launch_bwd_colbuf(DcnArgs &a, GatherPlan &pl, unsigned char *ws, hipS
     Tap *gtap = reinterpret_cast<Tap *>(ws + pl.o_gtap);   // also read by the GEMM below and by the weight-gradient pass
     a.gtap_rows = pl.nsamples / (a.kh * a.kw * a.dg);
     LSN_HIP(hipMemsetAsync(cnt, 0, ((size_t)pl.nanchors + 1) * sizeof(int), st));
-    hipLaunchKernelGGL(dcn_bin_kernel, dim3(cdiv(pl.nsamples, 256)), dim3(256), 0, st, a, pl.nsamples, cnt, sanchor,
-                       srank, sfrac, gtap);
+    static const int kmajor = [] { const char *e = getenv("LSNET_BIN_KMAJOR"); return e ? atoi(e) : 0; }();   // A/B runs
+    if (kmajor)
+        hipLaunchKernelGGL(dcn_bin_kernel<true>, dim3(cdiv(pl.nsamples, 256)), dim3(256), 0, st, a, pl.nsamples, cnt, sanchor,
+                           srank, sfrac, gtap);
+    else
+        hipLaunchKernelGGL(dcn_bin_kernel<false>, dim3(cdiv(pl.nsamples, 256)), dim3(256), 0, st, a, pl.nsamples, cnt, sanchor,
+                           srank, sfrac, gtap);
     a.gtap = gtap;
     size_t tmp = pl.scan_tmp;
     LSN_HIP(rocprim::exclusive_scan(ws + pl.o_tmp, tmp, cnt, start, 0, (size_t)pl.nanchors + 1, rocprim::plus<int>(), st));
-    hipLaunchKernelGGL(dcn_fill_kernel, dim3(cdiv(pl.nsamples, 256)), dim3(256), 0, st, pl.nsamples, start, sanchor,
-                       srank, sfrac, ent, gtap, a.kh * a.kw * a.dg, a.gtap_rows);
+    if (kmajor)
+        hipLaunchKernelGGL(dcn_fill_kernel<true>, dim3(cdiv(pl.nsamples, 256)), dim3(256), 0, st, pl.nsamples, start, sanchor,
+                           srank, sfrac, ent, gtap, a.kh * a.kw * a.dg, a.gtap_rows);
+    else
+        hipLaunchKernelGGL(dcn_fill_kernel<false>, dim3(cdiv(pl.nsamples, 256)), dim3(256), 0, st, pl.nsamples, start, sanchor,
+                           srank, sfrac, ent, gtap, a.kh * a.kw * a.dg, a.gtap_rows);
     int sort_blocks = cdiv(pl.nanchors, 4);
     if (sort_blocks > 4096) sort_blocks = 4096;
     hipLaunchKernelGGL(dcn_sort_lists_kernel, dim3(sort_blocks), dim3(256), 0, st, pl.nanchors, start, ent,

@@ -16,3 +16,9 @@ for t in 0 9 10; do
     LSNET_CONV_TILE=$t timeout 40 tools/ubench/conv_step 10 >> $L 2>&1
 done
 grep "==\|per step\|forward .* us  backward\|dcn_fwd \|dcn_wgrad \|against the host" $L
+# list building: threads tap-major like the table they write (coalesced 32-byte entries, atomics spread over neighbouring anchors)
+for v in 0 1; do
+    echo "== deformable launches, LSNET_BIN_KMAJOR=$v" >> $L
+    LSNET_BIN_KMAJOR=$v timeout 60 tools/ubench/dcn_step both 5 2>&1 | grep -v "^    default vs old" | grep -v "debug bit 28" >> $L
+done
+grep -A6 "LSNET_BIN_KMAJOR" $L | grep "==\|backward\|dcn_bwd_data\|against the host\|twice"
