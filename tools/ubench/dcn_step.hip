@@ -2,8 +2,8 @@
 // with fused offset | mask-logit tensors, and a pyramid launch of 15 (level, source) pairs; B = 2, 800 x 1344, 256 -> 256,
 // 3x3) replayed through the C ABI only -- no torch, the binary starts in a second -- with
 //   * forward / backward wall time per launch (HIP events) and the library's own per-family times (lsn_prof_*),
-//   * every result checked against a double-precision evaluation on the host for sampled elements
-//     (deform_conv_cuda_kernel.cu:84-188, 227-290, 392-448, 913-970 semantics, restated here: tools may not link oracle/),
+//   * every result checked against a double-precision evaluation on the host for sampled elements (tools/ubench/dcn_ref.h,
+//     itself pinned against the oracle on CPU by tests/test_ubench_ref.py: tools may not link oracle/),
 //   * the backward run twice and compared bit for bit,
 //   * the same launches with debug bit 28 set (the kernels of dcn_kernels.h) as the A/B partner.
 //   hipcc --offload-arch=gfx950 -O2 tools/ubench/dcn_step.hip -o tools/ubench/dcn_step -ldl
@@ -17,6 +17,7 @@
 #include <string>
 #include <vector>
 #include "../../include/lsnet_hip.h"
+#include "dcn_ref.h"   // the host evaluation (pinned against the oracle on CPU: tests/test_ubench_ref.py)
 
 static inline int ck_(hipError_t e, const char *file, int line)
 {
@@ -79,55 +80,10 @@ struct Launch {
 
 static Buf feats[5];
 
-// ---- host reference (double precision) ----
-struct Pos {
-    bool in;
-    int y0, x0;
-    double ly, lx;
-    bool v[4];   // corner validity: (y0,x0) (y0,x1) (y1,x0) (y1,x1)
-};
-static Pos position(const Level &L, int b, int ho, int wo, int k)
+// ---- host reference: tools/ubench/dcn_ref.h over the host copies of this launch's tensors ----
+static dcnref::Lv view(const Level &L)
 {
-    const int i = k / KH, j = k % KH;
-    const float *o = &L.off.h[((size_t)(b * L.Ho + ho) * L.Wo + wo) * L.och];
-    // float arithmetic as in the kernels (deform_conv_cuda_kernel.cu:281-282): base * scale + offset
-    const float py = (float)(ho - PAD + i) * L.sh + o[2 * k], px = (float)(wo - PAD + j) * L.sw + o[2 * k + 1];
-    Pos p = {};
-    p.in = py > -1.f && px > -1.f && py < (float)L.H && px < (float)L.W;
-    if (!p.in) return p;
-    const float fy = floorf(py), fx = floorf(px);
-    p.y0 = (int)fy, p.x0 = (int)fx, p.ly = (double)(py - fy), p.lx = (double)(px - fx);
-    p.v[0] = p.y0 >= 0 && p.x0 >= 0, p.v[1] = p.y0 >= 0 && p.x0 + 1 <= L.W - 1;
-    p.v[2] = p.y0 + 1 <= L.H - 1 && p.x0 >= 0, p.v[3] = p.y0 + 1 <= L.H - 1 && p.x0 + 1 <= L.W - 1;
-    return p;
-}
-static double mask_of(const Launch &la, const Level &L, int b, int ho, int wo, int k)
-{
-    if (!la.fused) return 1.0;
-    const double m = L.off.h[((size_t)(b * L.Ho + ho) * L.Wo + wo) * L.och + 2 * K + k];
-    return 1.0 / (1.0 + exp(-m));
-}
-static inline double xat(const Level &L, int b, int y, int x, int c) { return feats[L.src].h[((size_t)(b * L.H + y) * L.W + x) * C + c]; }
-static void corner_w(const Pos &p, double w[4])
-{
-    w[0] = (1 - p.ly) * (1 - p.lx), w[1] = (1 - p.ly) * p.lx, w[2] = p.ly * (1 - p.lx), w[3] = p.ly * p.lx;
-}
-static double sample(const Level &L, const Pos &p, int b, int c)
-{
-    if (!p.in) return 0.0;
-    double w[4];
-    corner_w(p, w);
-    double v = 0;
-    for (int q = 0; q < 4; ++q)
-        if (p.v[q]) v += w[q] * xat(L, b, p.y0 + (q >> 1), p.x0 + (q & 1), c);
-    return v;
-}
-static double gcol_at(const Launch &la, const Level &L, int b, int ho, int wo, int k, int c)
-{
-    const float *g = &L.gout.h[((size_t)(b * L.Ho + ho) * L.Wo + wo) * Co];
-    double s = 0;
-    for (int co = 0; co < Co; ++co) s += (double)g[co] * la.w.h[((size_t)co * K + k) * C + c];
-    return s;
+    return dcnref::Lv{B, L.H, L.W, L.Ho, L.Wo, L.och, L.sh, L.sw, feats[L.src].h.data(), L.off.h.data(), L.gout.h.data()};
 }
 
 struct Err {
@@ -148,32 +104,22 @@ static void check_forward(const Launch &la, Err &e)
     for (int t = 0; t < 96; ++t) {
         const Level &L = la.lv[rnd((int)la.lv.size())];
         const int b = rnd(B), ho = rnd(L.Ho), wo = rnd(L.Wo), co = rnd(Co);
-        double s = la.bias.d ? la.bias.h[co] : 0.0;
-        for (int k = 0; k < K; ++k) {
-            const Pos p = position(L, b, ho, wo, k);
-            if (!p.in) continue;
-            const double m = mask_of(la, L, b, ho, wo, k);
-            for (int c = 0; c < C; ++c) s += la.w.h[((size_t)co * K + k) * C + c] * m * sample(L, p, b, c);
-        }
+        const double s = dcnref::forward_at(view(L), la.w.h.data(), la.bias.d ? la.bias.h.data() : nullptr, C, Co, b, ho, wo, co);
         e.add(L.out.h[((size_t)(b * L.Ho + ho) * L.Wo + wo) * Co + co], s);
     }
 }
 
 static void check_backward(const Launch &la, Err &ew, Err &eb, Err &eo, Err &em, Err &ex)
 {
-    // weight / bias gradient
+    // weight / bias gradient: summed over the levels
     for (int t = 0; t < 24; ++t) {
         const int co = rnd(Co), k = t < K ? t : rnd(K), c = rnd(C);
         double s = 0, sb = 0;
-        for (const Level &L : la.lv)
-            for (int b = 0; b < B; ++b)
-                for (int ho = 0; ho < L.Ho; ++ho)
-                    for (int wo = 0; wo < L.Wo; ++wo) {
-                        const double g = L.gout.h[((size_t)(b * L.Ho + ho) * L.Wo + wo) * Co + co];
-                        sb += g;
-                        const Pos p = position(L, b, ho, wo, k);
-                        if (p.in) s += g * mask_of(la, L, b, ho, wo, k) * sample(L, p, b, c);
-                    }
+        for (const Level &L : la.lv) {
+            double a, ab;
+            dcnref::gw_at(view(L), C, Co, co, k, c, &a, &ab);
+            s += a, sb += ab;
+        }
         ew.add(la.gw.h[((size_t)co * K + k) * C + c], s);
         if (la.gb.d && t < 6) eb.add(la.gb.h[co], sb);
     }
@@ -181,46 +127,21 @@ static void check_backward(const Launch &la, Err &ew, Err &eb, Err &eo, Err &em,
     for (int t = 0; t < 48; ++t) {
         const Level &L = la.lv[rnd((int)la.lv.size())];
         const int b = rnd(B), ho = rnd(L.Ho), wo = rnd(L.Wo), k = rnd(K);
-        const Pos p = position(L, b, ho, wo, k);
-        const double m = mask_of(la, L, b, ho, wo, k);
-        double gy = 0, gx = 0, gm = 0;
-        if (p.in) {
-            for (int c = 0; c < C; ++c) {
-                const double g = gcol_at(la, L, b, ho, wo, k, c);
-                double v[4];
-                for (int q = 0; q < 4; ++q) v[q] = p.v[q] ? xat(L, b, p.y0 + (q >> 1), p.x0 + (q & 1), c) : 0.0;
-                gy += g * m * (-(1 - p.lx) * v[0] - p.lx * v[1] + (1 - p.lx) * v[2] + p.lx * v[3]);
-                gx += g * m * (-(1 - p.ly) * v[0] + (1 - p.ly) * v[1] - p.ly * v[2] + p.ly * v[3]);
-                double w[4];
-                corner_w(p, w);
-                gm += g * (w[0] * v[0] + w[1] * v[1] + w[2] * v[2] + w[3] * v[3]);
-            }
-        }
+        double gy, gx, gm;
+        dcnref::goff_at(view(L), la.w.h.data(), C, Co, b, ho, wo, k, &gy, &gx, &gm);
         const float *go = &L.goff.h[((size_t)(b * L.Ho + ho) * L.Wo + wo) * L.och];
         eo.add(go[2 * k], gy), eo.add(go[2 * k + 1], gx);
-        if (la.fused) em.add(go[2 * K + k], gm * m * (1 - m));
+        if (la.fused) em.add(go[2 * K + k], gm);
     }
-    // input gradient: sampled (source, b, y, x, c); every sample of every level that reads the source is visited
+    // input gradient: sampled (source, b, y, x, c); every level that reads the source contributes
     for (int t = 0; t < 10; ++t) {
         int src;
         do src = rnd(5); while (!la.src_used[src]);
         const int H = SZ[src][0], W = SZ[src][1];
         const int b = rnd(B), y = rnd(H), x = rnd(W), c = rnd(C);
         double s = 0;
-        for (const Level &L : la.lv) {
-            if (L.src != src) continue;
-            for (int ho = 0; ho < L.Ho; ++ho)
-                for (int wo = 0; wo < L.Wo; ++wo)
-                    for (int k = 0; k < K; ++k) {
-                        const Pos p = position(L, b, ho, wo, k);
-                        if (!p.in) continue;
-                        const int dy = y - p.y0, dx = x - p.x0;
-                        if (dy < 0 || dy > 1 || dx < 0 || dx > 1 || !p.v[dy * 2 + dx]) continue;
-                        double w[4];
-                        corner_w(p, w);
-                        s += w[dy * 2 + dx] * mask_of(la, L, b, ho, wo, k) * gcol_at(la, L, b, ho, wo, k, c);
-                    }
-        }
+        for (const Level &L : la.lv)
+            if (L.src == src) s += dcnref::gx_at(view(L), la.w.h.data(), C, Co, b, y, x, c);
         ex.add(la.gxs[src].h[((size_t)(b * H + y) * W + x) * C + c], s);
     }
 }
