@@ -404,6 +404,23 @@ def main():
             gs._fwd_bwd(data)
         ks = timer.stop()
     comm = allreduce_probe(model, dev, world) if world > 1 else None
+    comm1 = None
+    if world == 1 and not args.no_extra:
+        # the same buckets through a ONE-rank RCCL group: what a stand-alone gradient all-reduce of this step costs on this
+        # box before any second GPU is involved (launch + RCCL's own kernels; tests/test_rccl_single_gpu.py runs the
+        # hook-driven path the same way).  Reported under config, never part of `value`.
+        try:
+            os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+            import socket
+            with socket.socket() as sk:
+                sk.bind(('127.0.0.1', 0))
+                port = sk.getsockname()[1]
+            dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1)
+            comm1 = allreduce_probe(model, dev, 1)
+            comm1['rccl_ranks'] = dist.get_world_size()
+            dist.destroy_process_group()
+        except Exception as ex:   # must never take the bench line down
+            comm1 = {'allreduce_ms_per_step_standalone': None, 'error': f'{type(ex).__name__}: {ex}'}
 
     extra = {}
     if world == 1 and not use_graph and not args.no_extra:
@@ -435,7 +452,9 @@ def main():
             'data': 'synthetic',
             'config': {'workload': f'LSNet {args.backbone.upper()}-FPN {args.task} (conv_module_type=dcn), '
                                    f'{args.batch} img/GPU 3x{args.height}x{args.width} (1333x800 padded to /32), '
-                                   f'7 gt/img, fwd+bwd+RCCL grad all-reduce+clip35+SGD',
+                                   f'7 gt/img, fwd+bwd+' +
+                                   ('RCCL grad all-reduce (bucketed, overlapped with backward)+' if world > 1 else
+                                    'gradient arena (the reducer\'s buckets, no collective on one rank)+') + 'clip35+SGD',
                        'global_batch': args.batch * world, 'parallelism': f'dp{world}', 'world_size': world,
                        'memory_format': 'nchw' if args.nchw else 'channels_last',
                        'launch': 'hipGraph replay of forward+backward; all-reduce, clip, SGD eager' if use_graph
@@ -443,6 +462,8 @@ def main():
                        'math': MATH_NOTES[args.math]},
             'loss': {k: round(v, 5) for k, v in losses.items()},
         }
+        if comm1 is not None:
+            res['config']['one_rank_rccl'] = comm1
         if world > 1:
             try:
                 res['config']['rccl_version'] = '.'.join(str(v) for v in torch.cuda.nccl.version())

@@ -264,9 +264,15 @@ typedef struct lsn_conv_level {
     float *out;
     const float *grad_out;   /* backward_weight only */
     int B, H, W;
-    const float *residual;   /* forward only, optional: a tensor of the output's shape ADDED before the ReLU -- the
-                              * `relu(bn(conv(x)) + identity)` tail of a ResNet block whose frozen BatchNorm has been
-                              * folded into the weight and bias (resnet.py:261-301) */
+    const float *residual;   /* forward / backward_data, optional: a tensor of the output's shape ADDED before the ReLU --
+                              * the `relu(bn(conv(x)) + identity)` tail of a ResNet block whose BatchNorm has been folded
+                              * into the weight and bias (resnet.py:261-301); in backward_data the gradient that reaches
+                              * the same tensor along another path (the identity branch).  May alias `out` (accumulate) */
+    const float *gate;       /* forward / backward_data, optional: a tensor of the output's shape; the finished element
+                              * (after bias, residual, ReLU) is set to 0 where gate <= 0 -- the ReLU gate of the activation
+                              * whose gradient a backward_data launch produces, applied in its epilogue instead of by a
+                              * pass of its own.  backward_data with stride > 1 takes residual / gate only when every
+                              * residue class of input pixels has a tap (3x3 stride 2: yes; 1x1 stride 2: no) */
 } lsn_conv_level;
 int64_t lsn_conv2d_prepared_bytes(int kind, int C, int Co, int kh, int kw, int stride, int pad, int dil);
 int lsn_conv2d_prepare_weights(int kind, const float *w, void *prepared, int C, int Co, int kh, int kw, int stride,
@@ -277,11 +283,13 @@ typedef struct lsn_conv_wprep {
     const float *w;
     void *prepared;
     int C, Co, kh, kw, stride, pad, dil;
-    /* Optional (kind 0 only; all NULL otherwise): an eval-mode BatchNorm behind the convolution, folded into the image.
-     * Every weight of output channel co is multiplied by a[co] = bn_gamma[co] / sqrt(bn_var[co] + bn_eps), and
-     * shift_out[co] = bn_beta[co] - bn_mean[co] * a[co] (Co floats) is written for the `bias` argument of
+    /* Optional (all NULL otherwise): an eval-mode BatchNorm behind the convolution, folded into the image.
+     * Every weight of (forward) output channel co is multiplied by a[co] = bn_gamma[co] / sqrt(bn_var[co] + bn_eps), and
+     * (kind 0) shift_out[co] = bn_beta[co] - bn_mean[co] * a[co] (Co floats) is written for the `bias` argument of
      * lsn_conv2d_forward_prepared: relu(bn(conv(x)) + residual) of a ResNet block (resnet.py:261-301) is then ONE launch,
-     * with the affine parameters still trainable (lsn_bn_eval_act_backward_folded gives their gradients). */
+     * with the affine parameters still trainable.  kind 1 (shift_out NULL): the backward-data image of the SCALED weight,
+     * so that lsn_conv2d_backward_data_prepared takes the gated upstream gradient as it is; the parameter gradients come
+     * from lsn_conv2d_backward_weight_bn. */
     const float *bn_gamma, *bn_var, *bn_beta, *bn_mean;
     float *shift_out;
     float bn_eps;
@@ -317,6 +325,20 @@ int lsn_conv2d_backward_data(const float *grad_out, const float *w, float *grad_
 int lsn_conv2d_backward_weight(const float *x, const float *grad_out, float *grad_w, float *grad_bias, int B, int H,
                                int W, int C, int Co, int kh, int kw, int stride, int pad, int dil, int accumulate,
                                lsn_stream_t stream);
+/* Parameter gradients of y = bn_eval(conv(x, w)) with the BatchNorm folded into the convolution (lsn_conv_wprep): the
+ * reference runs aten::convolution_backward and the backward of F.batch_norm in eval mode (resnet.py:261-301).  g = the
+ * upstream gradient w.r.t. the NORMALISED output (after the ReLU gate), a_c = gamma_c / sqrt(var_c + eps):
+ *   G[co][k][c]     = sum_p g[p][co] x[p @ k][c]                      (the weight gradient of the raw convolution under g)
+ *   grad_w          (+)= a_co G[co]
+ *   grad_beta[co]   (+)= sum_p g[p][co]
+ *   grad_gamma[co]  (+)= (sum_{k,c} w[co][k][c] G[co][k][c] - mean_co sum_p g[p][co]) / sqrt(var_co + eps)
+ * -- sum_p g (conv - mean) rstd with conv = w . x pulled out of the pixel sum: exact for EVERY gamma, zero included
+ * (zero_init_residual), where recovering x_hat from the stored activation as (y - residual - beta) / gamma cannot be.  One
+ * weight-gradient launch plus its ordered reduce; bit-identical run to run. */
+int lsn_conv2d_backward_weight_bn(const float *x, const float *g, const float *w, const float *bn_gamma,
+                                  const float *bn_mean, const float *bn_var, float bn_eps, float *grad_w,
+                                  float *grad_gamma, float *grad_beta, int B, int H, int W, int C, int Co, int kh, int kw,
+                                  int stride, int pad, int dil, int accumulate, lsn_stream_t stream);
 
 /* ---- Grouped convolution (ResNeXt bottlenecks) -------------------------------------------------
  * Reference: torch.nn.Conv2d(groups = G) as built by mmdet/models/backbones/resnext.py:11-83 (Bottleneck.conv2:
@@ -382,18 +404,13 @@ int lsn_bn_eval_act_backward(const float *grad_y, const float *y, const float *x
                              const float *running_var, const float *gamma, float eps, int relu, float *grad_x,
                              float *grad_residual, float *grad_gamma, float *grad_beta, void *workspace, int N,
                              int C, int accumulate, lsn_stream_t stream);
-/* Backward of the FOLDED form y = act(conv(x, w a) + b (+ residual)) (lsn_conv_wprep: the BatchNorm rides in the
- * convolution, whose raw output is never stored): same results as above with x_hat taken from y -- where the gate is
- * open, (conv - mean_c) / sqrt(var_c + eps) = (y - residual - beta_c) / gamma_c; where it is closed dz = 0.  `y` is
- * always needed, `residual` when it was added and grad_gamma is wanted.  grad_x is the gradient w.r.t. the RAW
- * convolution output (dz a_c): feed it to lsn_conv2d_backward_data / _backward_weight with the UNscaled weight.  A
- * channel with gamma_c == 0 gets grad_gamma_c = 0 (its x_hat is not recoverable from y).  Parameter gradients of both
- * entry points are summed in a fixed order: bit-identical run to run. */
-int lsn_bn_eval_act_backward_folded(const float *grad_y, const float *y, const float *residual,
-                                    const float *running_var, const float *gamma, const float *beta, float eps,
-                                    int relu, float *grad_x, float *grad_residual, float *grad_gamma,
-                                    float *grad_beta, void *workspace, int N, int C, int accumulate,
-                                    lsn_stream_t stream);
+/* grad[i] = y[i] > 0 ? grad_y[i] : 0 over n floats (n % 4 == 0, 16-byte aligned): the gradient through a ReLU whose
+ * OUTPUT y was stored (F.relu's backward, resnet.py:261-301).  The only stand-alone pass left of the backward of a
+ * conv + eval-BatchNorm (+ residual) + ReLU block whose norm is folded into the convolution (lsn_conv_wprep): the scale
+ * a_c rides in the backward-data image, the parameter gradients come from lsn_conv2d_backward_weight_bn, and where the
+ * gradient is produced by one of this library's backward-data launches the gate rides in its epilogue instead
+ * (lsn_conv_level.gate). */
+int lsn_relu_gate(const float *grad_y, const float *y, float *grad, int64_t n, lsn_stream_t stream);
 
 /* ---- diagnostics ---------------------------------------------------------------------------- */
 /* When set to a device buffer of 512 int64 (NULL disables), thread 0 of workgroup `block` of the

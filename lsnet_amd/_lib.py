@@ -38,7 +38,8 @@ class DcnLevel(ctypes.Structure):
 
 class ConvLevel(ctypes.Structure):
     _fields_ = [('x', ctypes.c_void_p), ('out', ctypes.c_void_p), ('grad_out', ctypes.c_void_p),
-                ('B', ctypes.c_int), ('H', ctypes.c_int), ('W', ctypes.c_int), ('residual', ctypes.c_void_p)]
+                ('B', ctypes.c_int), ('H', ctypes.c_int), ('W', ctypes.c_int), ('residual', ctypes.c_void_p),
+                ('gate', ctypes.c_void_p)]
 
 
 class ConvWprep(ctypes.Structure):
@@ -79,7 +80,7 @@ EXPORTS = [
     'lsn_conv2d_forward_multi', 'lsn_conv2d_backward_data_multi', 'lsn_conv2d_backward_weight_multi', 'lsn_conv2d_backward_weight',
     'lsn_grouped_conv2d_forward', 'lsn_grouped_conv2d_backward_data', 'lsn_grouped_conv2d_backward_weight',
     'lsn_bn_eval_act_forward', 'lsn_bn_eval_act_backward', 'lsn_bn_eval_act_workspace_bytes',
-    'lsn_bn_eval_act_backward_folded',
+    'lsn_relu_gate', 'lsn_conv2d_backward_weight_bn',
     'lsn_image_prep_u8', 'lsn_cross_iou_bbox_forward', 'lsn_cross_iou_bbox_backward',
     'lsn_cross_iou_bbox_stage_forward', 'lsn_cross_iou_bbox_stage_backward',
     'lsn_cross_iou_rows_forward', 'lsn_cross_iou_rows_backward',

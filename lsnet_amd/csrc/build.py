@@ -25,22 +25,63 @@ def _hipcc():
     raise RuntimeError('hipcc not found: liblsnet_hip.so cannot be built')
 
 
-def needs_build():
-    if not os.path.exists(SO):
+OBJ_DIR = os.path.join(HERE, 'build')
+# headers each translation unit includes (an object is rebuilt when its source or one of these is newer)
+UNIT_HEADERS = {
+    'dcn.hip': ['common.h', 'dcn_kernels.h', 'dcn_mm_kernels.h', 'dcn_fused_kernels.h', 'conv_kernels.h', 'prof.h'],
+    'conv.hip': ['common.h', 'conv_kernels.h', 'conv_wgrad_kernels.h', 'prof.h'],
+    'misc.hip': ['common.h', 'prof.h'], 'norm.hip': ['common.h', 'prof.h'], 'gconv.hip': ['common.h', 'prof.h'],
+    'image.hip': ['common.h'], 'loss.hip': ['common.h', 'cross_iou_row.h'],
+}
+API_HEADER = os.path.join('..', '..', 'include', 'lsnet_hip.h')
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(SO)
-    deps = [os.path.join(HERE, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps)
+    t = os.path.getmtime(target)
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    if not force and not needs_build():
-        return SO
-    cmd = [_hipcc()] + FLAGS + [os.path.join(HERE, s) for s in SOURCES] + ['-o', SO]
+def _unit_deps(src):
+    return [os.path.join(HERE, f) for f in [src] + UNIT_HEADERS.get(src, HEADERS) + [API_HEADER]] + [os.path.abspath(__file__)]
+
+
+def needs_build(so=None, obj_dir=None):
+    so = so or SO
+    obj_dir = obj_dir or OBJ_DIR
+    if not os.path.exists(so):
+        return True
+    return any(_stale(os.path.join(obj_dir, s + '.o'), _unit_deps(s)) for s in SOURCES) or \
+        _stale(so, [os.path.join(obj_dir, s + '.o') for s in SOURCES])
+
+
+def build(force=False, verbose=False, defines=(), so=None):
+    """One object per translation unit (compiled in parallel, only the stale ones), then the link.  `defines` / `so`: an
+    A/B variant of the library beside the product one (tools/r4_calls), with its own object directory."""
+    so = so or SO
+    obj_dir = OBJ_DIR if so == SO else so + '.build'
+    if not force and not needs_build(so, obj_dir):
+        return so
+    os.makedirs(obj_dir, exist_ok=True)
+    cc = _hipcc()
+    cflags = [f for f in FLAGS if f != '-shared'] + ['-D' + d for d in defines]
+    jobs = []
+    for s in SOURCES:
+        obj = os.path.join(obj_dir, s + '.o')
+        if force or _stale(obj, _unit_deps(s)):
+            cmd = [cc] + cflags + ['-c', os.path.join(HERE, s), '-o', obj]
+            if verbose:
+                print(' '.join(cmd), file=sys.stderr)
+            jobs.append((s, subprocess.Popen(cmd, cwd=HERE)))
+    failed = [s for s, p in jobs if p.wait() != 0]
+    if failed:
+        raise RuntimeError('hipcc failed for ' + ', '.join(failed))
+    cmd = [cc, '--offload-arch=gfx950', '-shared', '-fPIC'] + [os.path.join(obj_dir, s + '.o') for s in SOURCES] + ['-o', so]
     if verbose:
         print(' '.join(cmd), file=sys.stderr)
     subprocess.check_call(cmd, cwd=HERE)
-    return SO
+    return so
 
 
 HOST_SO = os.path.join(HERE, 'liblsnet_host.so')
@@ -65,5 +106,9 @@ def build_host(force=False, verbose=False):
 
 
 if __name__ == '__main__':
+    if '--ab' in sys.argv:   # the A/B variant: python build.py --ab [-DNAME ...]
+        print(build(force='--force' in sys.argv, verbose=True, defines=['LSNET_AB=1'] + [a[2:] for a in sys.argv if a.startswith('-D')],
+                    so=os.path.join(HERE, 'liblsnet_hip_ab.so')))
+        sys.exit(0)
     print(build(force='--force' in sys.argv, verbose=True))
     print(build_host(force='--force' in sys.argv, verbose=True))

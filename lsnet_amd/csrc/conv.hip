@@ -52,14 +52,11 @@ static int part_buffer(size_t floats, float **p)
     return 0;
 }
 
-template <int TM, int TN, int WM, int WN, int NP, bool UNAL, int OCC = 2>
+template <int TM, int TN, int WM, int WN, int NP, bool UNAL, bool FINE, bool TRANS = false>
 static int launch_conv_cfg(ConvArgs &a, int ks, hipStream_t st)
 {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    size_t lds = (size_t)2 * SplitCfg<NP>::NPL * BM * 64;
-#ifdef LSNET_CONV_ROW_EPILOGUE
-    if (lds < (size_t)32 * (BN + 4) * 4) lds = (size_t)32 * (BN + 4) * 4;   // the epilogue's 32-pixel transpose image
-#endif
+    const size_t lds = (size_t)2 * SplitCfg<NP>::NPL * BM * 64;
     int tiles = 0;
     for (int i = 0; i < a.nlv; ++i) {
         a.lv[i].tile0 = tiles;
@@ -71,7 +68,7 @@ static int launch_conv_cfg(ConvArgs &a, int ks, hipStream_t st)
     if (ks > 1)
         if (int rc = part_buffer(n * ks, &a.part)) return rc;
     dim3 grid(tiles, (a.Co + BN - 1) / BN, ks);
-    auto k = conv_mm_kernel<TM, TN, WM, WN, NP, UNAL, OCC>;
+    auto k = conv_mm_kernel<TM, TN, WM, WN, NP, UNAL, FINE, TRANS>;
     static bool attr_set = false;   // per instantiation
     if (!attr_set) {
         LSN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -81,63 +78,51 @@ static int launch_conv_cfg(ConvArgs &a, int ks, hipStream_t st)
     if (ks > 1) {
         const int blocks = (int)((n / 4 + 255) / 256 < 1024 ? (n / 4 + 255) / 256 : 1024);
         hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, st, a.part, a.lv[0].out, a.bias,
-                           a.lv[0].res, (int)n, a.Co, ks, a.relu);
+                           a.lv[0].res, a.lv[0].gate, (int)n, a.Co, ks, a.relu);
     }
     LSN_HIP(hipGetLastError());
     return 0;
 }
 
-// Experimental fat tiles (one workgroup per CU, one wave per SIMD): aligned slabs only.
-template <int TM, int TN, int WM, int WN, int OCC = 1>
-static int launch_conv_fat(ConvArgs &a, int ks, hipStream_t st)
-{
-    return conv_np() == 3 ? launch_conv_cfg<TM, TN, WM, WN, 3, false, OCC>(a, ks, st)
-                          : launch_conv_cfg<TM, TN, WM, WN, 6, false, OCC>(a, ks, st);
-}
-
-template <int TM, int TN, int WM, int WN>
+// FINE: the fine MFMA / staging interleave (conv_kernels.h) -- adopted for the two wide tiles after the round-4 sweep; for
+// the two narrow ones (Co <= 64) it measured no difference (4216 / 3095 vs 4218 / 3105 us, profiles/r4_conv_tiles.txt)
+template <int TM, int TN, int WM, int WN, bool FINE>
 static int launch_conv(ConvArgs &a, int ks, hipStream_t st)
 {
-    if constexpr (TN == 2 && WN == 2) {   // the unaligned-slab variant exists for the two wide tiles
+    if constexpr (TN == 2 && WN == 2) {   // the unaligned-slab variant exists for the 64 x 128 tile
         if (a.C % 4 != 0 || a.xpitch % 4 != 0)
-            return conv_np() == 3 ? launch_conv_cfg<TM, TN, WM, WN, 3, true>(a, ks, st)
-                                  : launch_conv_cfg<TM, TN, WM, WN, 6, true>(a, ks, st);
+            return conv_np() == 3 ? launch_conv_cfg<TM, TN, WM, WN, 3, true, false>(a, ks, st)
+                                  : launch_conv_cfg<TM, TN, WM, WN, 6, true, false>(a, ks, st);
     }
     if (a.C % 4 != 0 || a.xpitch % 4 != 0)
         return fail(LSN_ERR_UNSUPPORTED, "conv2d: C %% 4 != 0 needs more than 64 output channels");
-    return conv_np() == 3 ? launch_conv_cfg<TM, TN, WM, WN, 3, false>(a, ks, st)
-                          : launch_conv_cfg<TM, TN, WM, WN, 6, false>(a, ks, st);
+    return conv_np() == 3 ? launch_conv_cfg<TM, TN, WM, WN, 3, false, FINE>(a, ks, st)
+                          : launch_conv_cfg<TM, TN, WM, WN, 6, false, FINE>(a, ks, st);
 }
 
-// Tile choice.  Two workgroups share a CU, so the chip holds 512 of them at once.  128 x 128 tiles (half the weight
-// traffic per flop of the 64-pixel tile) are taken when they still make ~1.4 rounds of workgroups; otherwise 64 x 128.
+// Tile choice (pixels x output channels per workgroup; two workgroups share a CU, so the chip holds 512 of them at
+// once).  Round-4 sweep over the step's layer shapes (tools/ubench/conv_step, profiles/r4_conv_tiles.txt):
+//   * 64 x 256 (a pixel slab is fetched and split ONCE for 256 output channels: half the split work per MFMA of the
+//     128-wide tiles) wins wherever Co is a multiple of 256 and the reduction is deep (3x3) or the launch fills a round;
+//   * 64 x 128 otherwise for Co > 64; 128 x 64 / 128 x 32 for the narrow outputs;
+//   * 128 x 128 lost on every row (fewer, longer workgroups) and the one-workgroup-per-CU fat register tiles
+//     (256 x 128, 128 x 256) lost by 30 %: both are gone.
 // When even the narrow tile leaves most of the chip idle (few pixels under a deep reduction: layer 4, FPN P5 .. P7) the
 // chunk range is split over blockIdx.z into partial tiles that a second small kernel adds up
-// (profiles/r3_conv_ksplit.txt: sweep of both knobs).
+// (profiles/r3_conv_ksplit.txt; forcing other split counts lost on every row of the round-4 sweep).
 static int conv_forward(ConvArgs &a, hipStream_t st)
 {
-    static const int force = [] { const char *e = getenv("LSNET_CONV_TILE"); return e ? atoi(e) : 0; }();   // tile sweeps
-    static const int force_ks = [] { const char *e = getenv("LSNET_CONV_KSPLIT"); return e ? atoi(e) : 0; }();
     auto blocks = [&](int bm, int bn) {
         int t = 0;
         for (int i = 0; i < a.nlv; ++i) t += (a.lv[i].P + bm - 1) / bm;
         return t * ((a.Co + bn - 1) / bn);
     };
-    int cfg;   // 1: 128 x 128, 2: 64 x 128, 3: 128 x 64, 4: 128 x 32, 5: 64 x 256
+    int cfg;   // 2: 64 x 128, 3: 128 x 64, 4: 128 x 32, 5: 64 x 256
     if (a.Co <= 32) cfg = 4;
     else if (a.Co <= 64) cfg = 3;
-    else cfg = blocks(128, 128) >= 700 ? 1 : 2;
-    // 64 x 256 (a pixel slab is fetched and split ONCE for 256 output channels; half the split work per MFMA of the 128-wide
-    // tiles): +6 .. 8 % on the head's 3x3 256 -> 256 launches (profiles/r3_conv_ksplit.txt), taken when it fills a round
-    if (a.Co % 256 == 0 && a.C % 4 == 0 && blocks(64, 256) >= 512) cfg = 5;
-    if ((force == 1 || force == 2) && a.Co > 64) cfg = force;   // (the weight image is padded for the natural width only)
-    if (force == 5 && a.Co % 256 == 0 && a.C % 4 == 0) cfg = 5;
-    // 7: 256 px x 128 co, 8: 128 px x 256 co -- the fat register tiles (A/B runs only: never chosen here)
-    // 9 / 10: the 64 x 256 / 64 x 128 tiles with the fine MFMA / staging interleave (OCC = 0 of conv_mm_kernel)
-    if (force >= 7 && force <= 10 && a.Co % 256 == 0 && a.C % 4 == 0 && a.xpitch % 4 == 0) cfg = force;
-    const int nb = cfg == 1 ? blocks(128, 128) : (cfg == 2 || cfg == 10) ? blocks(64, 128) : cfg == 3 ? blocks(128, 64)
-                 : (cfg == 5 || cfg == 9) ? blocks(64, 256) : cfg == 7 ? blocks(256, 128) : cfg == 8 ? blocks(128, 256)
-                 : blocks(128, 32);
+    else cfg = 2;
+    if (a.Co % 256 == 0 && a.C % 4 == 0 && a.xpitch % 4 == 0 && (a.kh * a.kw > 1 || blocks(64, 256) >= 512)) cfg = 5;
+    const int nb = cfg == 2 ? blocks(64, 128) : cfg == 3 ? blocks(128, 64) : cfg == 5 ? blocks(64, 256) : blocks(128, 32);
     const int Tall = a.kh * a.kw * cv_ncc(a.C);
     int ks = 1;
     if (a.nlv == 1 && !a.ostep && nb <= 320 && Tall >= 16) {
@@ -146,17 +131,11 @@ static int conv_forward(ConvArgs &a, hipStream_t st)
         if (ks > 16) ks = 16;
         if (ks < 1) ks = 1;
     }
-    if (force_ks && a.nlv == 1 && !a.ostep) ks = force_ks < Tall ? force_ks : Tall;
     switch (cfg) {
-    case 1: return launch_conv<2, 2, 2, 2>(a, ks, st);
-    case 2: return launch_conv<1, 2, 2, 2>(a, ks, st);
-    case 3: return launch_conv<1, 2, 4, 1>(a, ks, st);
-    case 5: return launch_conv<2, 2, 1, 4>(a, ks, st);
-    case 7: return launch_conv_fat<4, 2, 2, 2>(a, ks, st);
-    case 8: return launch_conv_fat<2, 4, 2, 2>(a, ks, st);
-    case 9: return launch_conv_fat<2, 2, 1, 4, 0>(a, ks, st);
-    case 10: return launch_conv_fat<1, 2, 2, 2, 0>(a, ks, st);
-    default: return launch_conv<1, 1, 4, 1>(a, ks, st);
+    case 2: return launch_conv<1, 2, 2, 2, true>(a, ks, st);
+    case 3: return launch_conv<1, 2, 4, 1, false>(a, ks, st);
+    case 5: return launch_conv<2, 2, 1, 4, true>(a, ks, st);
+    default: return launch_conv<1, 1, 4, 1, false>(a, ks, st);
     }
 }
 
@@ -178,6 +157,14 @@ int conv_mm_rows(int n, const float *const *x, float *const *out, const int *row
     a.wf_bytes = (int)cv_wfrag_bytes(N, 1, Cr, conv_npl());
     a.C = Cr, a.Co = N, a.kh = a.kw = 1, a.stride = 1, a.pad_h = a.pad_w = 0, a.dil = 1;
     a.xpitch = Cr;
+    if (N % 256 == 0) {   // the 64 x 256 tile with whole-line stores (conv_kernels.h TRANS); plain output, one split
+#ifdef LSNET_AB
+        return conv_forward(a, st);
+#else
+        return conv_np() == 3 ? launch_conv_cfg<2, 2, 1, 4, 3, false, true, true>(a, 1, st)
+                              : launch_conv_cfg<2, 2, 1, 4, 6, false, true, true>(a, 1, st);
+#endif
+    }
     return conv_forward(a, st);
 }
 
@@ -282,7 +269,7 @@ static int conv_forward_impl(int n, const lsn_conv_level *lv, const void *prepar
             LSN_CHECK(L.Wo > 0, "conv2d: output size is too small");
         }
         L.x = lv[i].x, L.out = lv[i].out, L.B = lv[i].B, L.H = lv[i].H, L.W = lv[i].W;
-        L.res = lv[i].residual;
+        L.res = lv[i].residual, L.gate = lv[i].gate;
         L.P = L.B * L.Ho * L.Wo;
     }
     a.bias = bias;
@@ -374,6 +361,11 @@ static int conv_backward_data_impl(int n, const lsn_conv_level *lv, const void *
     BwdPlan pl;
     if (int rc = bwd_plan(C, Co, kh, kw, s, pad, dil, &pl)) return rc;
     const int H = lv[0].H, W = lv[0].W, B = lv[0].B;
+    bool epi = false;   // a residual (another path's gradient of the same tensor) / ReLU gate in the epilogue
+    for (int i = 0; i < n; ++i) epi = epi || lv[i].residual || lv[i].gate;
+    if (epi && pl.need_zero)
+        return fail(LSN_ERR_UNSUPPORTED, "conv2d backward-data: residual / gate with residue classes that have no tap");
+    if (epi && C % 4 != 0) return fail(LSN_ERR_UNSUPPORTED, "conv2d backward-data: residual / gate need C %% 4 == 0");
     if (pl.need_zero) LSN_HIP(hipMemsetAsync(lv[0].out, 0, sizeof(float) * (size_t)B * H * W * C, st));
     for (int ci = 0; ci < pl.ncls; ++ci) {
         const BwdClass &c = pl.cls[ci];
@@ -385,7 +377,7 @@ static int conv_backward_data_impl(int n, const lsn_conv_level *lv, const void *
         a.nlv = n;
         for (int i = 0; i < n; ++i) {
             ConvLvl &L = a.lv[i];
-            L.x = lv[i].x, L.out = lv[i].out;
+            L.x = lv[i].x, L.out = lv[i].out, L.res = lv[i].residual, L.gate = lv[i].gate;
             L.B = lv[i].B, L.H = Ho[i], L.W = Wo[i];
             L.Ho = s > 1 ? Hc : lv[i].H, L.Wo = s > 1 ? Wc : lv[i].W;
             L.P = L.B * L.Ho * L.Wo;
@@ -412,8 +404,11 @@ static int bn_fold_of(const lsn_conv_wprep &p, BnFold *bn)
 {
     *bn = BnFold();
     if (!p.bn_gamma) return 0;
-    LSN_CHECK(p.kind == 0, "conv2d prepare: a BatchNorm is folded into the FORWARD image only");
-    LSN_CHECK(p.bn_var && p.bn_beta && p.bn_mean && p.shift_out, "conv2d prepare: incomplete BatchNorm description");
+    LSN_CHECK(p.bn_var, "conv2d prepare: incomplete BatchNorm description");
+    if (p.kind == 0)
+        LSN_CHECK(p.bn_beta && p.bn_mean && p.shift_out, "conv2d prepare: incomplete BatchNorm description");
+    else
+        LSN_CHECK(!p.shift_out, "conv2d prepare: the shift belongs to the forward image");
     bn->gamma = p.bn_gamma, bn->var = p.bn_var, bn->beta = p.bn_beta, bn->mean = p.bn_mean, bn->shift_out = p.shift_out;
     bn->eps = p.bn_eps;
     return 0;
@@ -433,13 +428,15 @@ static int prepare_weights(int kind, const float *w, void *prepared, int C, int 
         if (int rc = bwd_plan(C, Co, kh, kw, stride, pad, dil, &pl)) return rc;
         for (int ci = 0; ci < pl.ncls; ++ci)
             conv_wfrag(w, reinterpret_cast<unsigned short *>(reinterpret_cast<unsigned char *>(prepared) + pl.cls[ci].wf_off),
-                       C, kh * kw, Co, 1, pl.cls[ci].ts, st);
+                       C, kh * kw, Co, 1, pl.cls[ci].ts, st, bn);
     }
     LSN_HIP(hipGetLastError());
     return 0;
 }
 
 // ---- weight / bias gradient (conv_wgrad_kernels.h) ----
+int conv_wgrad_reduce(const float *part, float *gw, size_t n, const float *part_b, float *gb, int nb, int splits, int splits_b,
+                      int accumulate, hipStream_t st);
 template <int TI, int TJ, int TG, int WI, int WJ, int PMAX, bool UN_OK>
 static int launch_wgrad_cfg(WgArgs &a, float *gw, float *gb, int accumulate, hipStream_t st)
 {
@@ -453,8 +450,6 @@ static int launch_wgrad_cfg(WgArgs &a, float *gw, float *gb, int accumulate, hip
     const size_t cap = ((size_t)192 << 20) / 4 / (nW + a.Co);   // partial tiles: at most 192 MB
     if ((size_t)S > cap) S = (int)cap;
     if (S > a.nseg / 6) S = a.nseg / 6;   // a split should run long enough to amortise its prologue and its partial tile
-    static const int force_s = [] { const char *e = getenv("LSNET_WGRAD_SPLITS"); return e ? atoi(e) : 0; }();
-    if (force_s > 0) S = force_s < a.nseg ? force_s : a.nseg;
     if (S < 1) S = 1;
     float *part = nullptr;
     if (int rc = part_buffer((size_t)S * (nW + a.Co) + 16, &part)) return rc;
@@ -471,39 +466,43 @@ static int launch_wgrad_cfg(WgArgs &a, float *gw, float *gb, int accumulate, hip
         return 0;
     };
     int rc;
-    static const int fine = [] { const char *e = getenv("LSNET_WGRAD_FINE"); return e ? atoi(e) : 0; }();   // A/B runs
-    if (fine && !un && !(TG == 9 && WI == 4)) {   // (the 4 x 1 wave layout of the narrow 3x3 form spills in this variant)
-        rc = npl == 2 ? launch(conv_wgrad_kernel<TI, TJ, TG, WI, WJ, 3, false, PMAX, true>)
-                      : launch(conv_wgrad_kernel<TI, TJ, TG, WI, WJ, 6, false, PMAX, true>);
-    } else if constexpr (UN_OK) {
+    // the fine MFMA / staging interleave (conv_wgrad_kernels.h FINE; round-4 A/B over the step's layer shapes 3.57 -> 3.41 ms)
+    // wherever it compiles without spills: not the unaligned form, not the 4 x 1 wave layout of the narrow 3x3 form
+    constexpr bool FINE = !(TG == 9 && WI == 4);
+    if constexpr (UN_OK) {
         if (un)
-            rc = npl == 2 ? launch(conv_wgrad_kernel<TI, TJ, TG, WI, WJ, 3, true, PMAX>)
-                          : launch(conv_wgrad_kernel<TI, TJ, TG, WI, WJ, 6, true, PMAX>);
+            rc = npl == 2 ? launch(conv_wgrad_kernel<TI, TJ, TG, WI, WJ, 3, true, PMAX, false>)
+                          : launch(conv_wgrad_kernel<TI, TJ, TG, WI, WJ, 6, true, PMAX, false>);
         else
-            rc = npl == 2 ? launch(conv_wgrad_kernel<TI, TJ, TG, WI, WJ, 3, false, PMAX>)
-                          : launch(conv_wgrad_kernel<TI, TJ, TG, WI, WJ, 6, false, PMAX>);
+            rc = npl == 2 ? launch(conv_wgrad_kernel<TI, TJ, TG, WI, WJ, 3, false, PMAX, FINE>)
+                          : launch(conv_wgrad_kernel<TI, TJ, TG, WI, WJ, 6, false, PMAX, FINE>);
     } else {
-        rc = npl == 2 ? launch(conv_wgrad_kernel<TI, TJ, TG, WI, WJ, 3, false, PMAX>)
-                      : launch(conv_wgrad_kernel<TI, TJ, TG, WI, WJ, 6, false, PMAX>);
+        rc = npl == 2 ? launch(conv_wgrad_kernel<TI, TJ, TG, WI, WJ, 3, false, PMAX, FINE>)
+                      : launch(conv_wgrad_kernel<TI, TJ, TG, WI, WJ, 6, false, PMAX, FINE>);
     }
     if (rc) return rc;
-    const size_t n4 = nW / 4;
-    int LS = 1;
-    while (LS < 64 && LS * 8 <= S) LS <<= 1;   // >= 4 loads per lane; a wave's lanes share 64 / LS elements
-    const size_t thr = n4 * LS;
-    const int rb = (int)((thr + 255) / 256 < 4096 ? (thr + 255) / 256 : 4096);
-    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(rb > 0 ? rb : 1), dim3(256), 0, st, a.part, gw, nW, a.part_b, gb, a.Co, S,
-                       S, accumulate, LS);
-    LSN_HIP(hipGetLastError());
-    return 0;
+    return conv_wgrad_reduce(a.part, gw, nW, a.part_b, gb, a.Co, S, S, accumulate, st);
 }
 
 // dcn.hip: gw (+)= sum of `splits` partial gradients of n floats (n % 4 == 0), gb (+)= sum of splits_b partial rows of nb
+// With a BatchNorm fold pending (lsn_conv2d_backward_weight_bn set g_wg_fold for the duration of its weight-gradient
+// call) the reduce also applies the norm's scale and forms grad_gamma / grad_beta (conv_wgrad_reduce_bn_kernel); gb is then
+// the entry point's dummy bias gradient (it only makes the main kernels write the per-channel sums of g).
+static thread_local const WgFold *g_wg_fold = nullptr;
+bool conv_wgrad_fold_pending() { return g_wg_fold != nullptr; }
+
 int conv_wgrad_reduce(const float *part, float *gw, size_t n, const float *part_b, float *gb, int nb, int splits, int splits_b,
                       int accumulate, hipStream_t st)
 {
     int LS = 1;
-    while (LS < 64 && LS * 8 <= splits) LS <<= 1;
+    while (LS < 64 && LS * 8 <= splits) LS <<= 1;   // >= 4 loads per lane; a wave's lanes share 64 / LS elements
+    if (g_wg_fold) {
+        LSN_CHECK(part_b && nb > 0 && n % ((size_t)nb * 4) == 0, "conv2d backward-weight (folded norm): bad partial layout");
+        hipLaunchKernelGGL(conv_wgrad_reduce_bn_kernel, dim3(nb), dim3(256), 0, st, part, gw, (int)(n / nb), nb, part_b,
+                           splits, splits_b, accumulate, LS, *g_wg_fold);
+        LSN_HIP(hipGetLastError());
+        return 0;
+    }
     const size_t thr = n / 4 * LS;
     const int rb = (int)((thr + 255) / 256 < 4096 ? (thr + 255) / 256 : 4096);
     hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(rb > 0 ? rb : 1), dim3(256), 0, st, part, gw, n, part_b, gb, nb, splits,
@@ -520,11 +519,10 @@ int conv_scratch(size_t floats, float **p) { return part_buffer(floats, p); }
 int conv_wgrad_mm(int n, const lsn_conv_level *lv, float *gw, float *gb, int C, int Co, int kh, int kw, int stride, int pad,
                   int dil, int accumulate, hipStream_t st)
 {
-    static const int off = [] { const char *e = getenv("LSNET_WGRAD_OLD"); return e ? atoi(e) : 0; }();
     // 3x3 / stride 1 / dilation 1 and 1x1 (any stride) run here.  (A strided 3x3 needs a 3 x 33 patch: one workgroup per
     // CU and 2-way bank-conflicted tr-reads -- the general kernel of dcn.hip was faster.)
     const bool k33 = kh == 3 && kw == 3 && stride == 1 && dil == 1, k11 = kh == 1 && kw == 1;
-    if (off || n < 1 || n > CV_MAXLV || !(k33 || k11) || C % 4 != 0) return 1;
+    if (n < 1 || n > CV_MAXLV || !(k33 || k11) || C % 4 != 0) return 1;
     WgArgs a = {};
     int seg = 0;
     for (int i = 0; i < n; ++i) {
@@ -548,16 +546,8 @@ int conv_wgrad_mm(int n, const lsn_conv_level *lv, float *gw, float *gb, int C, 
     for (int i = 0; i < n; ++i) px += (double)a.lv[i].B * a.lv[i].Ho * a.lv[i].Wo, in_el += (double)a.lv[i].B * a.lv[i].H * a.lv[i].W * C;
     ProfSpan prof(PROF_CONV_WGRAD, 2.0 * px * Co * C * kh * kw, 4.0 * (in_el + px * Co + (double)Co * kh * kw * C), st);
     if (kh * kw == 1) {   // one tap: 32 .. 64 channels per wave on either side, by the layer's width
-        // LSNET_WGRAD_TILE=11|12|21|22 forces the (ci, co) tiles per wave (A/B runs of tools/ubench/wgrad_ab: smaller tiles
-        // mean more blocks, fewer pixel splits and a smaller partial-tile round trip)
-        static const int force_t = [] { const char *e = getenv("LSNET_WGRAD_TILE"); return e ? atoi(e) : 0; }();
-        switch (force_t) {
-        case 11: return launch_wgrad_cfg<1, 1, 1, 2, 2, 16, false>(a, gw, gb, accumulate, st);
-        case 12: return launch_wgrad_cfg<1, 2, 1, 2, 2, 16, false>(a, gw, gb, accumulate, st);
-        case 21: return launch_wgrad_cfg<2, 1, 1, 2, 2, 16, false>(a, gw, gb, accumulate, st);
-        case 22: return launch_wgrad_cfg<2, 2, 1, 2, 2, 16, false>(a, gw, gb, accumulate, st);
-        default: break;
-        }
+        // (round-4 sweep, profiles/r4_wgrad_tiles.txt: forcing any one of the four tiles on every layer loses to this
+        // width rule by 0 .. 25 %)
         if (C <= 64)
             return Co <= 64 ? launch_wgrad_cfg<1, 1, 1, 2, 2, 16, false>(a, gw, gb, accumulate, st)
                             : launch_wgrad_cfg<1, 2, 1, 2, 2, 16, false>(a, gw, gb, accumulate, st);
@@ -598,7 +588,7 @@ static int prepare_weights_multi(int n, const lsn_conv_wprep *it, hipStream_t st
             for (int c = 0; c < pl.ncls; ++c) {
                 WfragJob j;
                 wfrag_job(j, p.w, reinterpret_cast<unsigned short *>(reinterpret_cast<unsigned char *>(p.prepared) + pl.cls[c].wf_off),
-                          p.C, p.kh * p.kw, p.Co, 1, pl.cls[c].ts, BnFold());
+                          p.C, p.kh * p.kw, p.Co, 1, pl.cls[c].ts, bn);
                 j.start = total;
                 total += wfrag_threads(j);
                 jobs.push_back(j);
@@ -634,6 +624,24 @@ static int prepare_weights_multi(int n, const lsn_conv_wprep *it, hipStream_t st
 }  // namespace lsn
 
 extern "C" {
+
+int lsn_conv2d_backward_weight_bn(const float *x, const float *g, const float *w, const float *bn_gamma, const float *bn_mean,
+                                  const float *bn_var, float bn_eps, float *grad_w, float *grad_gamma, float *grad_beta, int B,
+                                  int H, int W, int C, int Co, int kh, int kw, int stride, int pad, int dil, int accumulate,
+                                  lsn_stream_t stream)
+{
+    LSN_CHECK(x && g && w && bn_gamma && bn_mean && bn_var && grad_w && grad_gamma && grad_beta,
+              "conv2d backward-weight (folded norm): NULL pointer");
+    if (((size_t)kh * kw * C) % 4 != 0)
+        return lsn::fail(LSN_ERR_UNSUPPORTED, "conv2d backward-weight (folded norm): kh * kw * C %% 4 != 0");
+    lsn::WgFold f = {w, bn_gamma, bn_mean, bn_var, grad_gamma, grad_beta, bn_eps};
+    lsn::g_wg_fold = &f;
+    // grad_beta stands in as the bias gradient: the main kernels then write the per-channel partial sums of g, and the
+    // fold-aware reduce is the only writer of grad_w / grad_gamma / grad_beta
+    const int rc = lsn_conv2d_backward_weight(x, g, grad_w, grad_beta, B, H, W, C, Co, kh, kw, stride, pad, dil, accumulate, stream);
+    lsn::g_wg_fold = nullptr;
+    return rc;
+}
 
 int lsn_conv2d_prepare_weights_multi(int n_items, const lsn_conv_wprep *items, lsn_stream_t stream)
 {

@@ -25,16 +25,6 @@
 
 #include "common.h"
 
-// Experiment (off by default): raise the wave's issue priority while it feeds the matrix pipe, so that the partner
-// workgroup's staging VALU work does not take the issue slot in front of an MFMA.  Measured on one box
-// (tools/r3_calls/c37.sh): network sums of the step's layer shapes 6.25 / 5.86 ms against 6.16 / 5.76 ms without -- the
-// partner's staging is what feeds ITS next MFMAs, delaying it costs as much as it buys.
-#ifdef LSNET_CONV_SETPRIO
-#define LSN_MFMA_PRIO(p) __builtin_amdgcn_s_setprio(p)
-#else
-#define LSN_MFMA_PRIO(p) ((void)0)
-#endif
-
 namespace lsn {
 
 constexpr int CV_MAXLV = 16;   // (the pyramid deformable op batches 15 (level, source) pairs)
@@ -42,7 +32,9 @@ constexpr int CV_MAXLV = 16;   // (the pyramid deformable op batches 15 (level, 
 // One input map of a batched launch: the FPN levels that share a convolution's weights (LSHead) go into ONE launch.
 struct ConvLvl {
     const float *x;
-    const float *res;   // optional residual of the output's shape, added before the ReLU (dense output only)
+    const float *res;   // optional residual of the output's shape, added before the ReLU (may alias `out`: accumulate)
+    const float *gate;  // optional tensor of the output's shape: the finished element is zeroed where gate <= 0 (the ReLU
+                        // gate of the activation whose gradient this launch produces, fused into a backward-data pass)
     float *out;
     int B, H, W, Ho, Wo;
     int P;       // B * Ho * Wo
@@ -210,13 +202,19 @@ __device__ __forceinline__ bf16x8 cv_load_frag(__amdgpu_buffer_rsrc_t rs, int vo
 // UNAL: the reduction channel count is not a multiple of 4 (the data gradient of LSHead's 27-channel offset / mask
 // convolutions): a pixel's slab is then neither 16-byte aligned nor a whole number of float4, so the pixel operand is
 // fetched with four 4-byte loads per lane, each with its own channel guard.
-// OCC: workgroups per CU the register allocation aims at.  2 for the tiles of the step (<= 256 registers per lane); 1 for
-// the experimental fat tiles (4 x 2 / 2 x 4 register tiles of 32 x 32: 346 / 322 registers, one wave per SIMD, half the
-// weight-fragment or LDS traffic per MFMA), reachable with LSNET_CONV_TILE=7 / 8 only.
-// OCC = 0: two workgroups per CU like the default, with the fine MFMA / staging interleave of the fat tiles (see the
-// slice loop; LSNET_CONV_TILE=9 / 10: the 64 x 256 and 64 x 128 tiles in that form).
-template <int TM, int TN, int WM, int WN, int NP, bool UNAL = false, int OCC = 2>
-__global__ __launch_bounds__(256, OCC ? OCC : 2) void conv_mm_kernel(const ConvArgs a)
+// FINE: the staging slices are interleaved with the MFMAs of their part instruction by instruction (the slice commits
+// lose their branch -- the last iteration then writes zeros into the buffer nobody reads again -- and
+// sched_group_barrier groups ask for M vvv M vvv ...).  With the branch a slice is two basic blocks, hipcc interleaves
+// inside one only, and the MFMAs of a slice issue back to back with its ~38 staging instructions behind them.
+// Measured over the step's layer shapes (tools/ubench/conv_step, profiles/r4_conv_tiles.txt): forward 4.39 -> 4.23 ms,
+// data gradient 3.29 -> 3.12 ms for the 64 x 256 tile, the same sign for 64 x 128.
+// TRANS: the MFMA operands swapped back (D rows = pixels, columns = output channels): a lane owns ONE channel and sixteen
+// pixels, and every store instruction writes two whole 128-byte lines (32 consecutive channels of one pixel per half-wave).
+// For the backward-data GEMM of the deformable family (conv_mm_rows: N = K C = 2304 columns, plain stores, no epilogue
+// terms), whose lane-per-pixel stores -- 32-byte pieces of 64 different rows per instruction -- made the L2 fetch every
+// partially written line: 0.68 GB fetched by a kernel that reads 27 MB (profiles/r3_pmc_hbm.txt).
+template <int TM, int TN, int WM, int WN, int NP, bool UNAL = false, bool FINE = false, bool TRANS = false>
+__global__ __launch_bounds__(256, 2) void conv_mm_kernel(const ConvArgs a)
 {
     using SC = SplitCfg<NP>;
     constexpr int NPL = SC::NPL;
@@ -388,7 +386,8 @@ __global__ __launch_bounds__(256, OCC ? OCC : 2) void conv_mm_kernel(const ConvA
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
-                    acc[j][i] = mfma_bf16(Wf[ks][j][SC::pb(prod)], Xf[ks][i][SC::pa(prod)], acc[j][i]);
+                    acc[j][i] = TRANS ? mfma_bf16(Xf[ks][i][SC::pa(prod)], Wf[ks][j][SC::pb(prod)], acc[j][i])
+                                      : mfma_bf16(Wf[ks][j][SC::pb(prod)], Xf[ks][i][SC::pa(prod)], acc[j][i]);
     };
 
     // One iteration = one chunk.  The fences pin the order of its phases; inside a phase hipcc schedules freely.  Left
@@ -403,22 +402,6 @@ __global__ __launch_bounds__(256, OCC ? OCC : 2) void conv_mm_kernel(const ConvA
     for (int t = 0; t < T; ++t) {
         const unsigned char *bc = smem + (t & 1) * BUF;
         unsigned char *bn = smem + ((t & 1) ^ 1) * BUF;
-#ifdef LSNET_CONV_NO_ILV   // diagnostic build: staging in front of the MFMAs instead of between them
-        read_x(bc, 0);
-        if (t + 1 < T) commit_x(bn);
-        if (t + 2 < T) next(c1);
-        issue_x(c1, t + 2 < T);
-        __builtin_amdgcn_sched_barrier(0);
-        read_x(bc, 1);
-        mfma_block(0);
-        issue_w(t + 1, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_block(1);
-        issue_w(t + 1, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-        continue;
-#endif
         read_x(bc, 0);
         read_x(bc, 1);
         if (t + 2 < T) next(c1);
@@ -430,33 +413,26 @@ __global__ __launch_bounds__(256, OCC ? OCC : 2) void conv_mm_kernel(const ConvA
         constexpr int NM = NP * TN * TM;
 #pragma unroll
         for (int ps = 0; ps < NLD; ++ps) {
-            LSN_MFMA_PRIO(1);
 #pragma unroll
             for (int m = ps * NM / NLD; m < (ps + 1) * NM / NLD; ++m) {
                 const int prod = m / (TN * TM), j = (m / TM) % TN, i = m % TM;
-                acc[j][i] = mfma_bf16(Wf[0][j][SC::pb(prod)], Xf[0][i][SC::pa(prod)], acc[j][i]);
+                acc[j][i] = TRANS ? mfma_bf16(Xf[0][i][SC::pa(prod)], Wf[0][j][SC::pb(prod)], acc[j][i])
+                                  : mfma_bf16(Wf[0][j][SC::pb(prod)], Xf[0][i][SC::pa(prod)], acc[j][i]);
             }
-            LSN_MFMA_PRIO(0);
-            // (OCC != 2: unconditional -- the last iteration writes zeros into the buffer nobody reads again.  The branch
-            // makes the slice two basic blocks, and the scheduler interleaves inside one only: with it the six MFMAs of a
-            // slice issue back to back and its ~38 staging instructions after them, which a second wave on the SIMD
-            // covers and a lone wave does not; without it hipcc emits M vvvvvv M vvvvvv ... as the group barriers ask)
-            if (OCC != 2 || t + 1 < T) commit_slice(ps, bn);   // registers hold the raw pixels of chunk t + 1
+            if (FINE || t + 1 < T) commit_slice(ps, bn);   // registers hold the raw pixels of chunk t + 1
             issue_slice(ps);
-            if constexpr (OCC != 2) {
+            if constexpr (FINE) {
 #pragma unroll
                 for (int g = 0; g < NM / NLD; ++g) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  // one MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x006, OCC == 1 ? 6 : 3, 0);   // vector / scalar ALU instructions
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x006, 3, 0);   // three vector / scalar ALU instructions
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
         issue_w(t + 1, 0);
         __builtin_amdgcn_sched_barrier(0);
-        LSN_MFMA_PRIO(1);
         mfma_block(1);
-        LSN_MFMA_PRIO(0);
         issue_w(t + 1, 1);
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
@@ -465,68 +441,23 @@ __global__ __launch_bounds__(256, OCC ? OCC : 2) void conv_mm_kernel(const ConvA
     // ---- epilogue ----
     const bool partial = a.ksplit > 1;
     const bool vec_ok = (a.Co & 3) == 0;
-#ifdef LSNET_CONV_ROW_EPILOGUE
-    if (vec_ok) {
-        // Experiment (not the default build).  The accumulators hold D[channel][pixel]: a lane = one pixel, four
-        // consecutive channels per register quad.  Stored from there, a wave instruction writes 32-byte pieces of 64
-        // different output rows and a 128-byte line is completed by four instructions; the counters show a fetch per
-        // written line (backward-data GEMM of the deformable family: 0.34 GB FETCHED by a kernel that reads 27 MB,
-        // beside 0.41 GB written, profiles/r3_pmc_hbm.txt).  Here each 32-pixel slab goes through LDS and is stored row
-        // by row, every line written whole.  Measured on one box (tools/r3_calls/c31.sh): network sums of the step's
-        // layer shapes 6.24 / 5.95 ms against 6.24 / 5.85 ms with the lane-per-pixel stores, step 40.94 against 40.68
-        // ms -- the extra traffic is not on the critical path, the two barriers per slab are.
-        constexpr int EROW = BN + 4;                 // floats per pixel row of the image (16-byte pad)
-        constexpr int LPR = BN / 4, RPI = 64 / LPR;  // lanes per row, rows per wave instruction
-        static_assert(LPR <= 64 && 64 % LPR == 0, "row of float4 per wave instruction");
-        const bool fin2 = !partial;                  // bias, residual and ReLU belong to the finished sum
-        float *E = reinterpret_cast<float *>(smem);
-        const int c4 = (lane % LPR) * 4;             // this lane's channels of a row
-        const int co = co_blk + c4;
-        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (fin2 && a.bias && co < a.Co) bv = *reinterpret_cast<const float4 *>(a.bias + co);
+    if constexpr (TRANS) {
+        // lane = output channel (lane & 31) of tile j, pixels mfma32_row(r, lane) of tile i: plain stores, whole lines
 #pragma unroll
-        for (int slab = 0; slab < WM * TM; ++slab) {
-            if (wm == slab / TM) {                   // (wave-uniform) the waves that own this slab's pixels
-                const int i = slab % TM;
-                float *erow = E + (lane & 31) * EROW + wn * TN * 32 + 4 * (lane >> 5);
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
+            for (int r = 0; r < 16; ++r) {
+                const int pix = tile_p + wm * TM * 32 + i * 32 + mfma32_row(r, lane);
+                if (pix >= L.P) continue;
+                float *orow = L.out + (size_t)pix * a.Co;
 #pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        *reinterpret_cast<float4 *>(erow + j * 32 + 8 * g) =
-                            make_float4(acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]);
-            }
-            __syncthreads();
-#pragma unroll
-            for (int r0 = 0; r0 < 8; r0 += RPI) {    // a wave stores 8 of the slab's 32 rows
-                const int row = wave * 8 + r0 + lane / LPR;
-                const int pix = tile_p + slab * 32 + row;
-                if (pix < L.P && co < a.Co) {
-                    size_t opix = pix;
-                    if (a.ostep) {
-                        const int HWo = L.Ho * L.Wo;
-                        const int b = pix / HWo, rem = pix - b * HWo;
-                        const int ho = rem / L.Wo, wo = rem - ho * L.Wo;
-                        opix = ((size_t)b * a.OH + a.oy0 + ho * a.ostep) * a.OW + a.ox0 + wo * a.ostep;
-                    }
-                    float4 v = *reinterpret_cast<const float4 *>(E + row * EROW + c4);
-                    if (fin2) {
-                        v.x += bv.x, v.y += bv.y, v.z += bv.z, v.w += bv.w;
-                        if (L.res) {
-                            const float4 rv = *reinterpret_cast<const float4 *>(L.res + opix * a.Co + co);
-                            v.x += rv.x, v.y += rv.y, v.z += rv.z, v.w += rv.w;
-                        }
-                        if (a.relu) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
-                    }
-                    float *orow = partial ? a.part + ((size_t)blockIdx.z * L.P + pix) * a.Co : L.out + opix * a.Co;
-                    *reinterpret_cast<float4 *>(orow + co) = v;
+                for (int j = 0; j < TN; ++j) {
+                    const int co = co_blk + (wn * TN + j) * 32 + (lane & 31);
+                    if (co < a.Co) orow[co] = acc[j][i][r];
                 }
             }
-            if (slab + 1 < WM * TM) __syncthreads();
-        }
         return;
     }
-#endif
     // lane = pixel (lane & 31) of tile i, output channels 8 g + 4 (lane >> 5) + (0..3) of tile j
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -562,6 +493,11 @@ __global__ __launch_bounds__(256, OCC ? OCC : 2) void conv_mm_kernel(const ConvA
                     if (fin && a.relu)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    if (fin && L.gate) {
+                        const float4 gv = *reinterpret_cast<const float4 *>(L.gate + opix * a.Co + co);
+                        v[0] = gv.x > 0.f ? v[0] : 0.f, v[1] = gv.y > 0.f ? v[1] : 0.f;
+                        v[2] = gv.z > 0.f ? v[2] : 0.f, v[3] = gv.w > 0.f ? v[3] : 0.f;
+                    }
                     *reinterpret_cast<float4 *>(orow + co) = make_float4(v[0], v[1], v[2], v[3]);
                 } else {
 #pragma unroll
@@ -570,6 +506,7 @@ __global__ __launch_bounds__(256, OCC ? OCC : 2) void conv_mm_kernel(const ConvA
                         float u = v[e] + ((fin && a.bias) ? a.bias[co + e] : 0.f);
                         if (fin && L.res) u += L.res[opix * a.Co + co + e];
                         if (fin && a.relu) u = fmaxf(u, 0.f);
+                        if (fin && L.gate && !(L.gate[opix * a.Co + co + e] > 0.f)) u = 0.f;
                         orow[co + e] = u;
                     }
                 }
@@ -578,9 +515,9 @@ __global__ __launch_bounds__(256, OCC ? OCC : 2) void conv_mm_kernel(const ConvA
 }
 
 // out[e] = sum_z part[z * n + e] + bias[e % Co] (ReLU): the second pass of a split reduction; n = P * Co
-static __global__ void conv_splitk_reduce_kernel(const float *__restrict__ part, float *__restrict__ out,
-                                          const float *__restrict__ bias, const float *__restrict__ res, int n, int Co,
-                                          int ks, int relu)
+static __global__ void conv_splitk_reduce_kernel(const float *__restrict__ part, float *out, const float *__restrict__ bias,
+                                                 const float *res, const float *__restrict__ gate, int n, int Co, int ks,
+                                                 int relu)
 {
     const bool v4 = (n & 3) == 0 && (Co & 3) == 0;
     if (v4) {
@@ -599,6 +536,10 @@ static __global__ void conv_splitk_reduce_kernel(const float *__restrict__ part,
                 s.x += r.x, s.y += r.y, s.z += r.z, s.w += r.w;
             }
             if (relu) s.x = fmaxf(s.x, 0.f), s.y = fmaxf(s.y, 0.f), s.z = fmaxf(s.z, 0.f), s.w = fmaxf(s.w, 0.f);
+            if (gate) {
+                const float4 g = *reinterpret_cast<const float4 *>(gate + e);
+                s.x = g.x > 0.f ? s.x : 0.f, s.y = g.y > 0.f ? s.y : 0.f, s.z = g.z > 0.f ? s.z : 0.f, s.w = g.w > 0.f ? s.w : 0.f;
+            }
             *reinterpret_cast<float4 *>(out + e) = s;
         }
     } else {
@@ -607,7 +548,9 @@ static __global__ void conv_splitk_reduce_kernel(const float *__restrict__ part,
             for (int z = 1; z < ks; ++z) s += part[(size_t)z * n + e];
             if (bias) s += bias[e % Co];
             if (res) s += res[e];
-            out[e] = relu ? fmaxf(s, 0.f) : s;
+            if (relu) s = fmaxf(s, 0.f);
+            if (gate && !(gate[e] > 0.f)) s = 0.f;
+            out[e] = s;
         }
     }
 }

@@ -405,4 +405,71 @@ static __global__ void conv_wgrad_reduce_kernel(const float *__restrict__ part, 
         }
 }
 
+// The reduce of a weight gradient whose convolution carries a folded eval-mode BatchNorm (lsn_conv2d_backward_weight_bn):
+// part holds the partial gradients G' of the RAW convolution under the gated upstream gradient g, part_b the partial sums
+// of g per output channel.  One workgroup per output channel co (row of R = K C floats, R % 4 == 0):
+//   G[co][:]       = sum_s part[s][co][:]
+//   gw[co][:]      (+)= a_co G[co][:],                 a_co = gamma_co / sqrt(var_co + eps)
+//   dbeta[co]      (+)= sum_s part_b[s][co]
+//   dgamma[co]     (+)= (w[co][:] . G[co][:] - mean_co dbeta_co) / sqrt(var_co + eps)
+// LS adjacent lanes share one float4 and take every LS-th split each (as in conv_wgrad_reduce_kernel); the dot product
+// and the channel sum meet by xor-shuffles in a fixed order: the same bits on every run.
+struct WgFold {
+    const float *w, *gamma, *mean, *var;
+    float *dgamma, *dbeta;
+    float eps;
+};
+
+static __global__ __launch_bounds__(256) void conv_wgrad_reduce_bn_kernel(const float *__restrict__ part, float *gw, int R, int Co,
+                                                                           const float *__restrict__ part_b, int splits,
+                                                                           int splits_b, int accumulate, int LS,
+                                                                           const WgFold f)
+{
+    // one workgroup per output channel (a first version with one WAVE per channel ran 32 .. 512 waves through up to 32
+    // dependent passes each: +1.9 ms per step over the plain reduce, profiles/r4_bench_c03.log)
+    __shared__ float red[2][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int co = blockIdx.x;
+    const size_t n = (size_t)Co * R;
+    const int sl = tid % LS, el = tid / LS, EP = 256 / LS;   // split lane, element lane, elements per pass (LS | 64)
+    const float rstd = rsqrtf(f.var[co] + f.eps), ac = f.gamma[co] * rstd;
+    const int R4 = R / 4;
+    float dot = 0.f;
+    for (int e0 = 0; e0 < R4; e0 += EP) {
+        const bool live = e0 + el < R4;
+        const size_t e = (size_t)co * R4 + (live ? e0 + el : 0);
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int z = sl; z < splits; z += LS) {
+            const float4 p = reinterpret_cast<const float4 *>(part + (size_t)z * n)[e];
+            s.x += p.x, s.y += p.y, s.z += p.z, s.w += p.w;
+        }
+        for (int m = 1; m < LS; m <<= 1) {
+            s.x += __shfl_xor(s.x, m), s.y += __shfl_xor(s.y, m), s.z += __shfl_xor(s.z, m), s.w += __shfl_xor(s.w, m);
+        }
+        if (live && sl == 0) {
+            const float4 wv = reinterpret_cast<const float4 *>(f.w)[e];
+            dot += (wv.x * s.x + wv.y * s.y) + (wv.z * s.z + wv.w * s.w);
+            float4 *d = reinterpret_cast<float4 *>(gw) + e;
+            float4 o = make_float4(ac * s.x, ac * s.y, ac * s.z, ac * s.w);
+            if (accumulate) {
+                const float4 q = *d;
+                o.x += q.x, o.y += q.y, o.z += q.z, o.w += q.w;
+            }
+            *d = o;
+        }
+    }
+    float sb = 0.f;
+    for (int z = tid; z < splits_b; z += 256) sb += part_b[(size_t)z * Co + co];
+    for (int m = 1; m < 64; m <<= 1) dot += __shfl_xor(dot, m), sb += __shfl_xor(sb, m);
+    if (lane == 0) red[0][wave] = dot, red[1][wave] = sb;
+    __syncthreads();
+    if (tid == 0) {
+        const float d4 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        const float b4 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        const float dg = (d4 - f.mean[co] * b4) * rstd;
+        f.dbeta[co] = accumulate ? f.dbeta[co] + b4 : b4;
+        f.dgamma[co] = accumulate ? f.dgamma[co] + dg : dg;
+    }
+}
+
 }  // namespace lsn

@@ -240,9 +240,7 @@ static bool vec_ok(const DcnArgs &a)
 // ---- the kernels of dcn_mm_kernels.h (dense-convolution skeleton): conditions, weight image, launches ----
 static bool dcn_mm_env()
 {
-    static const int v = [] { const char *e = getenv("LSNET_DCN_MM"); return e ? atoi(e) : 1; }();
-    if ((g_dbg_block >> 28) & 1) return false;   // bit 28 of the debug word: the kernels of dcn_kernels.h only (tests)
-    return v != 0;   // LSNET_DCN_MM=0: likewise (A/B runs)
+    return !((g_dbg_block >> 28) & 1);   // bit 28 of the debug word: the kernels of dcn_kernels.h only (tests, A/B runs)
 }
 
 static bool mm_common_ok(const DcnArgs &a)
@@ -257,16 +255,8 @@ static bool mm_common_ok(const DcnArgs &a)
 
 static int mm_npl() { return math_np() == 6 ? 3 : 2; }
 
-// LSNET_DCN_MM_PARTS: bit 0 forward, bit 1 backward-data, bit 2 weight gradient (default 7; A/B runs)
-static int dcn_mm_parts()
-{
-    static const int v = [] { const char *e = getenv("LSNET_DCN_MM_PARTS"); return e ? atoi(e) : 7; }();
-    return v;
-}
-
 static bool mm_fwd_ok(const DcnArgs &a)
 {
-    if (!(dcn_mm_parts() & 1)) return false;
     if (!mm_common_ok(a) || (a.C / a.dg) % 32 != 0 || a.Co % 128 != 0) return false;
     if (dcn_fwd_mm_lds_bytes(mm_npl(), a.kh * a.kw * a.dg) > 80 * 1024) return false;
     return cv_wfrag_bytes(a.Co, a.kh * a.kw, a.C, mm_npl()) < ((size_t)1 << 31);
@@ -279,7 +269,6 @@ int conv_mm_rows(int n, const float *const *x, float *const *out, const int *row
                  hipStream_t st);
 static bool mm_bwd_ok(const DcnArgs &a)
 {
-    if (!(dcn_mm_parts() & 2)) return false;
     if (!mm_common_ok(a) || a.C % 4 != 0 || a.Co % 4 != 0) return false;
     for (int i = 0; i < a.nlv; ++i)
         if ((a.lv[i].goff || a.lv[i].gmsk) && !a.lv[i].gx) return false;
@@ -325,12 +314,11 @@ static int launch_fwd_mm_cfg(const DcnArgs &a, hipStream_t st)
 static int launch_forward_mm(const DcnArgs &a, hipStream_t st)
 {
     ProfScope prof(PROF_FWD, a, st);
+    // (the 64 x 256 tile in the fine MFMA / staging interleave, dcn_mm_kernels.h FINE: tower launch 310 -> 280 us, pyramid
+    // 818 -> 780 us in the round-4 A/B, profiles/r4_fine.txt)
     const bool wide = a.Co % 256 == 0;
-    static const int fine = [] { const char *e = getenv("LSNET_DCN_FWD_FINE"); return e ? atoi(e) : 0; }();   // A/B runs
-    if (fine && wide)
-        return math_np() == 6 ? launch_fwd_mm_cfg<2, 2, 1, 4, 6, true>(a, st) : launch_fwd_mm_cfg<2, 2, 1, 4, 3, true>(a, st);
-    if (math_np() == 6) return wide ? launch_fwd_mm_cfg<2, 2, 1, 4, 6>(a, st) : launch_fwd_mm_cfg<1, 2, 2, 2, 6>(a, st);
-    return wide ? launch_fwd_mm_cfg<2, 2, 1, 4, 3>(a, st) : launch_fwd_mm_cfg<1, 2, 2, 2, 3>(a, st);
+    if (math_np() == 6) return wide ? launch_fwd_mm_cfg<2, 2, 1, 4, 6, true>(a, st) : launch_fwd_mm_cfg<1, 2, 2, 2, 6>(a, st);
+    return wide ? launch_fwd_mm_cfg<2, 2, 1, 4, 3, true>(a, st) : launch_fwd_mm_cfg<1, 2, 2, 2, 3>(a, st);
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -455,9 +443,6 @@ static bool bwd_win_ok(const DcnArgs &a)
     if (bwd_win_lds_bytes(RED, KD) > 160 * 1024) return false;
     for (int i = 0; i < a.nlv; ++i)
         if (a.lv[i].H > 32767 || a.lv[i].W > 32767) return false;   // 15-bit packed window coordinates
-    static const int env_win = [] { const char *e = getenv("LSNET_BWD_WIN"); return e ? atoi(e) : -1; }();
-    if (env_win == 0) return false;   // LSNET_BWD_WIN=0/1: A/B switch for whole-step measurements
-    if (env_win == 1) return true;
     if ((g_dbg_block >> 25) & 1) return false;   // bits 25 / 24 of the debug word force one kernel (A/B runs)
     if ((g_dbg_block >> 24) & 1) return true;
     // Measured in the LSNet step (profiles/, bench.py kernel timers).  Exact fp32: the windowed kernel beat the first
@@ -555,8 +540,8 @@ static void gather_plan(DcnArgs &a, GatherPlan &pl)
     pl.nsamples = (int)(prow * KD);
     pl.nanchors = (int)anchors;
     // Groups with more than ~400 samples per 4x4 pixel block go to the per-anchor gather (the pyramid op's coarse source
-    // levels); the others keep the block walk.  LSNET_GATHER_ANCHOR=0 keeps every group on the block walk (A/B runs).
-    static const int anchor_thr = [] { const char *e = getenv("LSNET_GATHER_ANCHOR"); return e ? atoi(e) : 400; }();
+    // levels); the others keep the block walk.
+    constexpr int anchor_thr = 400;
     AnchorArgs &aa = pl.aa;
     aa.ng = 0, aa.NA = 0;
     pl.anchor_pixels = 0, pl.block_samples = 0;
@@ -573,7 +558,7 @@ static void gather_plan(DcnArgs &a, GatherPlan &pl)
             const int64_t nblk = (int64_t)G.B * cdiv(G.H, GT) * cdiv(G.W, GT);
             const int64_t nanch = (int64_t)G.B * (G.H + 1) * (G.W + 1);
             to_anchor[j] = all_anchor || (anchor_thr > 0 && gsamp[j] > (int64_t)anchor_thr * nblk);
-            static const int long_thr = [] { const char *e = getenv("LSNET_ANCHOR_LONG"); return e ? atoi(e) : 40; }();
+            constexpr int long_thr = 40;
             is_long[j] = !all_anchor || gsamp[j] > (int64_t)long_thr * nanch;   // mean list length (upper bound)
         }
         for (int pass = 0; pass < 2; ++pass) {
@@ -627,9 +612,7 @@ static void gather_plan(DcnArgs &a, GatherPlan &pl)
 
 static bool bwd_colbuf_env()
 {
-    static const int v = [] { const char *e = getenv("LSNET_BWD_GATHER"); return e ? atoi(e) : 1; }();
-    if ((g_dbg_block >> 23) & 1) return false;   // bit 23 of the debug word forces the atomic scatter kernels (tests)
-    return v != 0;   // LSNET_BWD_GATHER=0: keep the atomic scatter kernels (A/B runs)
+    return !((g_dbg_block >> 23) & 1);   // bit 23 of the debug word forces the atomic scatter kernels (tests)
 }
 
 // Tap groups of the split backward-data GEMM (grid.y): the launch runs in ceil(tiles x groups / 512) rounds of the 512
@@ -638,9 +621,7 @@ static bool bwd_colbuf_env()
 // rounds / groups x (1 + 0.05 groups).
 static int bwd_tap_groups(const DcnArgs &a)
 {
-    static const int force = [] { const char *e = getenv("LSNET_BWD_TAP_GROUPS"); return e ? atoi(e) : 0; }();
     const int K = a.kh * a.kw;
-    if (force > 0) return force <= K ? force : K;
     int best = 1;
     double best_cost = 1e30;
     for (int g = 1; g <= K; ++g) {
@@ -662,22 +643,13 @@ static int launch_bwd_colbuf(DcnArgs &a, GatherPlan &pl, unsigned char *ws, hipS
     Tap *gtap = reinterpret_cast<Tap *>(ws + pl.o_gtap);   // also read by the GEMM below and by the weight-gradient pass
     a.gtap_rows = pl.nsamples / (a.kh * a.kw * a.dg);
     LSN_HIP(hipMemsetAsync(cnt, 0, ((size_t)pl.nanchors + 1) * sizeof(int), st));
-    static const int kmajor = [] { const char *e = getenv("LSNET_BIN_KMAJOR"); return e ? atoi(e) : 0; }();   // A/B runs
-    if (kmajor)
-        hipLaunchKernelGGL(dcn_bin_kernel<true>, dim3(cdiv(pl.nsamples, 256)), dim3(256), 0, st, a, pl.nsamples, cnt, sanchor,
-                           srank, sfrac, gtap);
-    else
-        hipLaunchKernelGGL(dcn_bin_kernel<false>, dim3(cdiv(pl.nsamples, 256)), dim3(256), 0, st, a, pl.nsamples, cnt, sanchor,
-                           srank, sfrac, gtap);
+    hipLaunchKernelGGL(dcn_bin_kernel, dim3(cdiv(pl.nsamples, 256)), dim3(256), 0, st, a, pl.nsamples, cnt, sanchor, srank, sfrac,
+                       gtap);
     a.gtap = gtap;
     size_t tmp = pl.scan_tmp;
     LSN_HIP(rocprim::exclusive_scan(ws + pl.o_tmp, tmp, cnt, start, 0, (size_t)pl.nanchors + 1, rocprim::plus<int>(), st));
-    if (kmajor)
-        hipLaunchKernelGGL(dcn_fill_kernel<true>, dim3(cdiv(pl.nsamples, 256)), dim3(256), 0, st, pl.nsamples, start, sanchor,
-                           srank, sfrac, ent, gtap, a.kh * a.kw * a.dg, a.gtap_rows);
-    else
-        hipLaunchKernelGGL(dcn_fill_kernel<false>, dim3(cdiv(pl.nsamples, 256)), dim3(256), 0, st, pl.nsamples, start, sanchor,
-                           srank, sfrac, ent, gtap, a.kh * a.kw * a.dg, a.gtap_rows);
+    hipLaunchKernelGGL(dcn_fill_kernel, dim3(cdiv(pl.nsamples, 256)), dim3(256), 0, st, pl.nsamples, start, sanchor, srank, sfrac,
+                       ent, gtap, a.kh * a.kw * a.dg, a.gtap_rows);
     int sort_blocks = cdiv(pl.nanchors, 4);
     if (sort_blocks > 4096) sort_blocks = 4096;
     hipLaunchKernelGGL(dcn_sort_lists_kernel, dim3(sort_blocks), dim3(256), 0, st, pl.nanchors, start, ent,
@@ -717,8 +689,7 @@ static int launch_bwd_colbuf(DcnArgs &a, GatherPlan &pl, unsigned char *ws, hipS
     }
     if (pl.ga.NB > 0) {
         // medium lists: four waves per pixel block; short ones (the tower launch, ~140 entries per block): one
-        static const int force_nw = [] { const char *e = getenv("LSNET_GATHER_NW"); return e ? atoi(e) : 0; }();
-        const bool split = force_nw ? force_nw == 4 : pl.block_samples > (int64_t)300 * pl.ga.NB;
+        const bool split = pl.block_samples > (int64_t)300 * pl.ga.NB;
         if (split)
             hipLaunchKernelGGL(dcn_gather_kernel<4>, dim3(pl.ga.NB), dim3(256), 0, st, pl.ga);
         else
@@ -771,8 +742,7 @@ static int launch_bwd_data(DcnArgs &a, void *gather_ws, size_t gather_ws_bytes, 
 static int wgrad_splits(int cols, int per_cu)
 {
     const int slots = 256 * per_cu;
-    static const int rounds = [] { const char *e = getenv("LSNET_WGRAD_ROUNDS"); return e ? atoi(e) : 1; }();
-    int s = slots * (rounds > 0 ? rounds : 1) / cols;
+    int s = slots / cols;
     return s < 1 ? 1 : s;
 }
 
@@ -791,11 +761,11 @@ static int wgrad_vec_bits(const DcnArgs &a)
 // ---- weight gradient on the kernels of dcn_mm_kernels.h: grad_output in fragment order, split partial tiles ----
 int conv_wgrad_reduce(const float *part, float *gw, size_t n, const float *part_b, float *gb, int nb, int splits, int splits_b,
                       int accumulate, hipStream_t st);
+bool conv_wgrad_fold_pending();   // conv.hip: lsn_conv2d_backward_weight_bn is the caller
 int conv_scratch(size_t floats, float **p);
 
 static bool mm_wgrad_ok(const DcnArgs &a)
 {
-    if (!(dcn_mm_parts() & 4)) return false;
     if (!mm_common_ok(a) || a.Co % 256 != 0 || (a.C / a.dg) % 64 != 0) return false;
     if (a.gtap == nullptr || (reinterpret_cast<uintptr_t>(a.gtap) & 15) != 0) return false;
     return true;
@@ -813,8 +783,6 @@ static int launch_wgrad_mm(const DcnArgs &a_in, int nchunks, bool accumulate, hi
     const int ncol = K * (a.C / 64), nz = a.Co / 256;
     int S = (512 + ncol * nz / 2) / (ncol * nz);
     if (S > nchunks / 4) S = nchunks / 4;   // a split should run long enough to amortise its prologue and its partial tile
-    static const int force_s = [] { const char *e = getenv("LSNET_DCN_WGRAD_SPLITS"); return e ? atoi(e) : 0; }();
-    if (force_s > 0) S = force_s < nchunks ? force_s : nchunks;
     if (S < 1) S = 1;
     const int nsteps16 = 2 * nchunks;
     int spb = cdiv(nsteps16, 256);            // pre-pass: ~256 step ranges x (Co / 128) tile groups
@@ -857,16 +825,10 @@ static int launch_wgrad_mm(const DcnArgs &a_in, int nchunks, bool accumulate, hi
         LSN_HIP(hipGetLastError());
         return 0;
     };
-    static const int fine = [] { const char *e = getenv("LSNET_DCN_WGRAD_FINE"); return e ? atoi(e) : 0; }();   // A/B runs
-    if (fine) {
-        if (dense) {
-            if (int rc = (math_np() == 6 ? go(dcn_wgrad_mm_kernel<6, true, true>) : go(dcn_wgrad_mm_kernel<3, true, true>))) return rc;
-        } else if (int rc = (math_np() == 6 ? go(dcn_wgrad_mm_kernel<6, false, true>) : go(dcn_wgrad_mm_kernel<3, false, true>))) {
-            return rc;
-        }
-    } else if (dense) {
-        if (int rc = (math_np() == 6 ? go(dcn_wgrad_mm_kernel<6, true>) : go(dcn_wgrad_mm_kernel<3, true>))) return rc;
-    } else if (int rc = (math_np() == 6 ? go(dcn_wgrad_mm_kernel<6>) : go(dcn_wgrad_mm_kernel<3>))) {
+    // (FINE = the fine MFMA / staging interleave: tower 360 -> 345 us, pyramid 941 -> 916 us, profiles/r4_fine.txt)
+    if (dense) {
+        if (int rc = (math_np() == 6 ? go(dcn_wgrad_mm_kernel<6, true, true>) : go(dcn_wgrad_mm_kernel<3, true, true>))) return rc;
+    } else if (int rc = (math_np() == 6 ? go(dcn_wgrad_mm_kernel<6, false, true>) : go(dcn_wgrad_mm_kernel<3, false, true>))) {
         return rc;
     }
     return conv_wgrad_reduce(part, a.gw, nW, part_b, a.gb, a.Co, S, nblk_s, accumulate ? 1 : 0, st);
@@ -1154,6 +1116,8 @@ static int conv_wgrad_launch(DcnArgs a, int nsteps, int C, int Co, int K, bool a
     // one partial gradient per pixel split + an ordered reduce (deterministic) where the sizes allow; else fp32 atomics
     const size_t nW = (size_t)Co * K * C;
     const bool ordered = nW % 4 == 0 && (size_t)splits * (nW + Co) * sizeof(float) <= ((size_t)256 << 20);
+    if (!ordered && conv_wgrad_fold_pending())
+        return fail(LSN_ERR_UNSUPPORTED, "conv2d backward-weight (folded norm): the gradient is too large for the ordered reduce");
     if (ordered) {
         float *base = nullptr;
         if (int rc = conv_scratch((size_t)splits * (nW + Co) + 16, &base)) return rc;
@@ -1175,12 +1139,9 @@ static int conv_wgrad_launch(DcnArgs a, int nsteps, int C, int Co, int K, bool a
 int conv_wgrad_mm(int n, const lsn_conv_level *lv, float *gw, float *gb, int C, int Co, int kh, int kw, int stride, int pad,
                   int dil, int accumulate, hipStream_t st);   // conv.hip
 
-// LSNET_CONV_WGRAD_MM: 0 off, 1 every shape the kernel serves, unset (2): the shapes it won on (conv_wgrad_dense_mm)
-static int conv_wgrad_mm_env()
-{
-    static const int v = [] { const char *e = getenv("LSNET_CONV_WGRAD_MM"); return e ? atoi(e) : 2; }();
-    return v;
-}
+// bits 26 / 27 of the debug word (tools/ubench/wgrad_ab: A/B runs): 0 never, 1 every shape the kernel serves; default (2):
+// the shapes it won on (conv_wgrad_dense_mm)
+static int conv_wgrad_mm_env() { return ((g_dbg_block >> 26) & 1) ? 0 : ((g_dbg_block >> 27) & 1) ? 1 : 2; }
 
 // The weight gradient of a dense convolution through dcn_wgrad_mm_kernel<NP, DENSE> (grad_output pre-split once into MFMA
 // fragment order, the regular grid as the sampling table).  Returns 1 when the shape is not served (256 | Co, 64 | C,

@@ -328,7 +328,7 @@ static int gn_fill(GnArgs &a, int n, const lsn_gn_level *lv, int C, int G, int *
 // end in one fp32 atomic per channel and block.
 // ---------------------------------------------------------------------------------------------------------
 struct BnArgs {
-    const float *x, *res, *dy, *y_in;   // backward with x == NULL: "folded" form, x_hat from y (see lsn_bn_eval_act_backward_folded)
+    const float *x, *res, *dy, *y_in;
     float *y, *dx, *dres;
     const float *mean, *var, *gamma, *beta;
     float *dgamma, *dbeta;
@@ -377,12 +377,6 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const BnArgs a)
     const float r0 = rsqrtf(va.x + a.eps), r1 = rsqrtf(va.y + a.eps), r2 = rsqrtf(va.z + a.eps),
                 r3 = rsqrtf(va.w + a.eps);
     const float a0 = ga.x * r0, a1 = ga.y * r1, a2 = ga.z * r2, a3 = ga.w * r3;
-    // folded form (a.x == NULL): the convolution wrote y = act(a_c conv + b_c (+ res)) directly and its raw output was
-    // never stored.  Where the gate is open, x_hat = (conv - mean) rstd = (y - res - beta) / gamma; where it is closed
-    // dz = 0 and the value does not matter.  `mu` then holds beta and the final factor is 1 / gamma instead of rstd.
-    const bool folded = a.beta != nullptr;   // (only the folded entry point passes beta to the backward kernel)
-    float4 be = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (folded) be = *reinterpret_cast<const float4 *>(a.beta + q * 4);
     float sg[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
     const int p0 = blockIdx.x * BN_PIX, p1 = min(p0 + BN_PIX, a.N);
 #pragma unroll 4
@@ -390,7 +384,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const BnArgs a)
         const size_t o = (size_t)px * a.C + q * 4;
         float4 d = *reinterpret_cast<const float4 *>(a.dy + o);
         float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a.relu || (folded && a.dgamma)) y = *reinterpret_cast<const float4 *>(a.y_in + o);
+        if (a.relu) y = *reinterpret_cast<const float4 *>(a.y_in + o);
         if (a.relu) {
             d.x = y.x > 0.f ? d.x : 0.f, d.y = y.y > 0.f ? d.y : 0.f, d.z = y.z > 0.f ? d.z : 0.f,
             d.w = y.w > 0.f ? d.w : 0.f;
@@ -398,17 +392,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const BnArgs a)
         if (a.dres) *reinterpret_cast<float4 *>(a.dres + o) = d;
         if (a.dx) *reinterpret_cast<float4 *>(a.dx + o) = make_float4(d.x * a0, d.y * a1, d.z * a2, d.w * a3);
         if (a.dgamma) {
-            float4 v;
-            if (!folded) {
-                v = *reinterpret_cast<const float4 *>(a.x + o);
-                v.x -= mu.x, v.y -= mu.y, v.z -= mu.z, v.w -= mu.w;
-            } else {
-                v = make_float4(y.x - be.x, y.y - be.y, y.z - be.z, y.w - be.w);
-                if (a.res) {
-                    const float4 e = *reinterpret_cast<const float4 *>(a.res + o);
-                    v.x -= e.x, v.y -= e.y, v.z -= e.z, v.w -= e.w;
-                }
-            }
+            float4 v = *reinterpret_cast<const float4 *>(a.x + o);
+            v.x -= mu.x, v.y -= mu.y, v.z -= mu.z, v.w -= mu.w;
             sg[0] += d.x * v.x, sg[1] += d.y * v.y, sg[2] += d.z * v.z, sg[3] += d.w * v.w;
             sb[0] += d.x, sb[1] += d.y, sb[2] += d.z, sb[3] += d.w;
         }
@@ -429,12 +414,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const BnArgs a)
         // per-block partials, summed by bn_param_reduce_kernel: thousands of blocks adding atomically to the same
         // 2 C addresses cost more than the streaming pass itself (C = 64: 230 us against 50 us of traffic)
         float *dst = a.part + (size_t)blockIdx.x * 2 * a.C + (qb + threadIdx.x) * 4;
-        float f0 = r0, f1 = r1, f2 = r2, f3 = r3;
-        if (folded) {   // (gamma == 0: the channel's output does not depend on the convolution; its x_hat is not recoverable)
-            f0 = ga.x != 0.f ? 1.f / ga.x : 0.f, f1 = ga.y != 0.f ? 1.f / ga.y : 0.f;
-            f2 = ga.z != 0.f ? 1.f / ga.z : 0.f, f3 = ga.w != 0.f ? 1.f / ga.w : 0.f;
-        }
-        *reinterpret_cast<float4 *>(dst) = make_float4(t[0] * f0, t[1] * f1, t[2] * f2, t[3] * f3);
+        *reinterpret_cast<float4 *>(dst) = make_float4(t[0] * r0, t[1] * r1, t[2] * r2, t[3] * r3);
         *reinterpret_cast<float4 *>(dst + a.C) = make_float4(t[4], t[5], t[6], t[7]);
     }
 }
@@ -466,9 +446,19 @@ __global__ __launch_bounds__(256) void bn_param_reduce_kernel(const BnArgs a, in
     }
 }
 
+// grad = grad_y where y > 0, else 0 (the gradient through a ReLU whose output y is what was stored)
+__global__ __launch_bounds__(256) void relu_gate_kernel(const float4 *__restrict__ gy, const float4 *__restrict__ y,
+                                                        float4 *__restrict__ g, int64_t n4)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 d = gy[i], v = y[i];
+        g[i] = make_float4(v.x > 0.f ? d.x : 0.f, v.y > 0.f ? d.y : 0.f, v.z > 0.f ? d.z : 0.f, v.w > 0.f ? d.w : 0.f);
+    }
+}
+
 static int bn_check(int N, int C);
 
-// shared tail of the two backward entry points; `reads`: tensors of N x C floats the kernel reads
+// shared tail of the backward entry point; `reads`: tensors of N x C floats the kernel reads
 static int bn_backward_launch(BnArgs &a, void *workspace, int accumulate, int reads, hipStream_t st)
 {
     const int N = a.N, C = a.C;
@@ -610,21 +600,18 @@ int lsn_bn_eval_act_backward(const float *grad_y, const float *y, const float *x
     return bn_backward_launch(a, workspace, accumulate, 1 + (relu ? 1 : 0) + (grad_gamma ? 1 : 0), st);
 }
 
-int lsn_bn_eval_act_backward_folded(const float *grad_y, const float *y, const float *residual, const float *running_var,
-                                    const float *gamma, const float *beta, float eps, int relu, float *grad_x,
-                                    float *grad_residual, float *grad_gamma, float *grad_beta, void *workspace, int N,
-                                    int C, int accumulate, lsn_stream_t stream)
+int lsn_relu_gate(const float *grad_y, const float *y, float *grad, int64_t n, lsn_stream_t stream)
 {
     using namespace lsn;
-    if (int rc = bn_check(N, C)) return rc;
-    LSN_CHECK(grad_y && y && running_var && gamma && beta, "batch norm (folded) backward: NULL argument");
-    LSN_CHECK((grad_gamma == nullptr) == (grad_beta == nullptr), "grad_gamma and grad_beta come together");
-    BnArgs a = {};
-    a.dy = grad_y, a.y_in = y, a.x = nullptr, a.res = residual, a.mean = beta, a.var = running_var, a.gamma = gamma, a.beta = beta;
-    a.dx = grad_x, a.dres = grad_residual, a.dgamma = grad_gamma, a.dbeta = grad_beta;
-    a.eps = eps, a.N = N, a.C = C, a.relu = relu;
-    return bn_backward_launch(a, workspace, accumulate, 2 + ((grad_gamma && residual) ? 1 : 0),
-                              reinterpret_cast<hipStream_t>(stream));
+    LSN_CHECK(grad_y && y && grad && n > 0 && n % 4 == 0, "relu gate: bad arguments");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    ProfSpan prof(PROF_NORM, 1.0 * n, 12.0 * n, st);
+    const int64_t n4 = n / 4;
+    const int blocks = (int)((n4 + 255) / 256 < 16384 ? (n4 + 255) / 256 : 16384);
+    hipLaunchKernelGGL(relu_gate_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float4 *>(grad_y),
+                       reinterpret_cast<const float4 *>(y), reinterpret_cast<float4 *>(grad), n4);
+    LSN_HIP(hipGetLastError());
+    return 0;
 }
 
 }  // extern "C"

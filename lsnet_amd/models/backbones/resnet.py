@@ -6,12 +6,14 @@ Module and parameter names are the reference's (`conv1`, `bn1`, `layerN.M.conv2.
 serves both families: ResNeXt is the grouped-width case."""
 import math
 
+import torch
 import torch.nn as nn
 import torch.utils.checkpoint as cp
 from torch.nn.modules.batchnorm import _BatchNorm
 
 from ...cnn import build_conv_layer, build_norm_layer, constant_init, kaiming_init
 from ...ops.batch_norm import bn_act
+from ...ops import resblock
 from ...ops.conv import conv_bn_act, conv_bn_act_frozen
 from ..builder import BACKBONES
 
@@ -120,12 +122,34 @@ class Bottleneck(nn.Module):
         # relu(bn3(conv3) + identity): norm, residual add and activation in one pass (resnet.py:261-301)
         return _conv_bn(self.conv3, self.norm3, out, relu=True, residual=_shortcut(self.downsample, x))
 
-    def forward(self, x):
+    def forward(self, x, pregate_in=False, gy_pregated=False):
+        """pregate_in / gy_pregated: set by ResLayer.forward for neighbouring blocks that both run as the fused autograd
+        node of ops/resblock.py (the ReLU gate of a block's output then rides in the NEXT block's backward-data launch)."""
+        if fused_block_ok(self, x):
+            return resblock.bottleneck(self, x.contiguous(memory_format=torch.channels_last), pregate_in, gy_pregated)
+        assert not (pregate_in or gy_pregated), 'ResLayer.forward pairs the flags of fused blocks only'
         return cp.checkpoint(self._body, x) if (self.with_cp and x.requires_grad) else self._body(x)
+
+
+def fused_block_ok(blk, x):
+    """The whole bottleneck as one autograd node (ops/resblock.py): a trainable dense block behind eval-mode norms, on a
+    device fp32 tensor small enough for 32-bit byte offsets in every map of the block (the widest is 4 x the input)."""
+    return (type(blk) is Bottleneck and torch.is_tensor(x) and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32
+            and x.numel() * 16 < 2 ** 31 and resblock.bottleneck_ok(blk))
 
 
 class ResLayer(nn.Sequential):
     """One stage: the first block carries the stride and the projection shortcut."""
+
+    def forward(self, x):
+        blocks = list(self)
+        ok = [fused_block_ok(b, x) for b in blocks]   # (a fused block hands a tensor of the same kind to the next one)
+        for i, b in enumerate(blocks):
+            if ok[i]:
+                x = b(x, pregate_in=i > 0 and ok[i - 1], gy_pregated=i + 1 < len(blocks) and ok[i + 1])
+            else:
+                x = b(x)
+        return x
 
     def __init__(self, block, inplanes, planes, num_blocks, stride=1, avg_down=False, conv_cfg=None,
                  norm_cfg=dict(type='BN'), **kwargs):

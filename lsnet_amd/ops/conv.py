@@ -54,6 +54,19 @@ from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_post
 _reg_post_step(_after_optimizer_step)
 
 
+def invalidate_weight_images():
+    """Mark EVERY cached image stale (frozen weights included).  Staleness is otherwise inferred from the tensors' version
+    counters, their storage pointers and the global optimizer post-step hook -- in-place updates through `p.data`
+    (checkpoint loading, the parameter broadcast of DataParallelModel, EMA / weight-surgery hooks, optimizers that do not
+    derive from torch.optim.Optimizer) are invisible to all three: whoever writes parameters that way calls this.
+    GraphedForwardBackward also calls it right before a capture, so that the image-rebuild launches are ALWAYS recorded
+    into the graph (captured with fresh images, every replay would run forward and data gradient on the capture-time
+    weights while the optimizer keeps moving them)."""
+    _opt_epoch[0] += 1
+    for ent in _images.values():
+        ent[1] = -1
+
+
 def _bn_versions(bn):
     return (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
             bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.eps))
@@ -74,10 +87,10 @@ def _fill_item(it, key, ent, w):
     it.kind, it.w, it.prepared = key[1], w.data_ptr(), ent[3].data_ptr()
     it.C, it.Co, it.kh, it.kw, it.stride, it.pad, it.dil = C, Co, kh, kw, key[2], key[3], key[4]
     bn = ent[5]() if ent[5] is not None else None
-    if bn is not None:   # a BatchNorm folded into the forward image (lsn_conv_wprep)
+    if bn is not None:   # a BatchNorm folded into the image (lsn_conv_wprep); the shift belongs to the forward image
         it.bn_gamma, it.bn_var, it.bn_beta, it.bn_mean = bn.weight.data_ptr(), bn.running_var.data_ptr(), \
             bn.bias.data_ptr(), bn.running_mean.data_ptr()
-        it.shift_out, it.bn_eps = ent[6].data_ptr(), float(bn.eps)
+        it.shift_out, it.bn_eps = (ent[6].data_ptr() if ent[6] is not None else None), float(bn.eps)
 
 
 def _mark_fresh(ent, w):
@@ -121,8 +134,9 @@ def weight_image(w, kind, stride=1, pad=0, dil=1, bn=None):
     storage moved, or -- for a trainable weight -- when any optimizer has stepped since.  The stale images of all
     parameters are rebuilt together, once per optimizer step, when the first of them is needed; a temporary (padded
     view, test tensor) gets a fresh one and drops it when it dies.
-    bn (kind 0): an eval-mode BatchNorm2d folded into the image; returns (image, shift) -- the shift goes into the
-    convolution's bias slot."""
+    bn: an eval-mode BatchNorm2d folded into the image (every weight of forward output channel co scaled by gamma /
+    sqrt(var + eps)).  kind 0 returns (image, shift) -- the shift goes into the convolution's bias slot; kind 1 returns
+    the backward-data image of the scaled weight."""
     lib = _lib.load()
     mode = lib.lsn_get_math_mode()
     key = (id(w), kind, stride, pad, dil, mode, id(bn) if bn is not None else 0)
@@ -130,20 +144,20 @@ def weight_image(w, kind, stride=1, pad=0, dil=1, bn=None):
     if ent is not None and ent[0]() is w and (bn is None or (ent[5] is not None and ent[5]() is bn)):
         if _stale(ent, w):
             _refresh_stale(mode)
-        return ent[3] if bn is None else (ent[3], ent[6])
+        return ent[3] if (bn is None or kind == 1) else (ent[3], ent[6])
     Co, C, kh, kw = w.shape
     nbytes = lib.lsn_conv2d_prepared_bytes(kind, C, Co, kh, kw, stride, pad, dil)
     if nbytes < 0:
         _lib.check(-2)
     img = torch.empty(nbytes, device=w.device, dtype=torch.uint8)
-    shift = torch.empty(Co, device=w.device, dtype=torch.float32) if bn is not None else None
+    shift = torch.empty(Co, device=w.device, dtype=torch.float32) if (bn is not None and kind == 0) else None
     ent = [weakref.ref(w, lambda _, k=key: _images.pop(k, None)), w._version, w.data_ptr(), img, _opt_epoch[0],
            weakref.ref(bn) if bn is not None else None, shift, _bn_versions(bn) if bn is not None else None]
     it = _lib.ConvWprep()
     _fill_item(it, key, ent, w)
     _lib.check(lib.lsn_conv2d_prepare_weights_item(ctypes.byref(it), _stream()))
     _images[key] = ent
-    return img if bn is None else (img, shift)
+    return img if (bn is None or kind == 1) else (img, shift)
 
 
 def _levels(n):
@@ -171,6 +185,70 @@ def _param_grad_results(w, bias, gw, gb, acc, want_w):
             grad_sink.done(bias)
         return None, None
     return (gw if want_w else None), gb
+
+
+# ---- kernel-level primitives (one C call each; the autograd Functions below and ops/resblock.py compose them) ----------
+def relu_gate(gy, y):
+    """grad_y where y > 0, else 0 -- the gradient through a ReLU whose output was stored (lsn_relu_gate)."""
+    g = torch.empty_like(y, memory_format=_CL)
+    _lib.check(_lib.load().lsn_relu_gate(_p(gy), _p(y), _p(g), ctypes.c_int64(y.numel()), _stream()))
+    return g
+
+
+def dgrad(g, w, in_shape, stride, pad, dil, bn=None, residual=None, gate=None, out=None):
+    """Data gradient of conv(x, w [scaled by the folded eval-mode BatchNorm `bn`]) under the upstream gradient g
+    (channels-last).  In the epilogue of the launch: `residual` (another path's gradient of the same tensor; may be
+    `out` itself) is added and `gate` (the stored ReLU output whose gradient this is) zeroes the closed elements."""
+    B, C, H, W = in_shape
+    Co, _, kh, kw = w.shape
+    if out is None:
+        out = torch.empty(in_shape, device=g.device, dtype=torch.float32, memory_format=_CL)
+    lv = _levels(1)
+    lv[0].x, lv[0].out, lv[0].B, lv[0].H, lv[0].W = _p(g), _p(out), B, H, W
+    lv[0].residual, lv[0].gate = _p(residual), _p(gate)
+    _lib.check(_lib.load().lsn_conv2d_backward_data_prepared(1, lv, _p(weight_image(w, 1, stride, pad, dil, bn=bn)), C, Co, kh,
+                                                             kw, stride, pad, dil, _stream()))
+    return out
+
+
+def wgrad_bn(x, g, w, bn, stride, pad, dil, need=(True, True, True)):
+    """Parameter gradients of bn_eval(conv(x, w)) under g = the (gated) gradient w.r.t. the normalised output
+    (lsn_conv2d_backward_weight_bn: exact for every gamma).  Accumulates into the three gradient sinks when all three
+    parameters have one (returns (None, None, None) to autograd), else returns fresh (grad_w, grad_gamma, grad_beta)
+    with None for the entries `need` does not ask for."""
+    B, C, H, W = x.shape
+    Co, _, kh, kw = w.shape
+    gamma, beta = bn.weight, bn.bias
+    sw, sg, sb = grad_sink.sink(w), grad_sink.sink(gamma), grad_sink.sink(beta)
+    acc = 1 if (all(need) and sw is not None and sg is not None and sb is not None and sw.stride() == w.stride()) else 0
+    if acc:
+        gw, dg, db = sw, sg, sb
+    else:
+        gw, dg, db = torch.empty_like(w), torch.empty_like(gamma), torch.empty_like(beta)
+    _lib.check(_lib.load().lsn_conv2d_backward_weight_bn(
+        _p(x), _p(g), _p(w), _p(gamma), _p(bn.running_mean), _p(bn.running_var), ctypes.c_float(float(bn.eps)), _p(gw),
+        _p(dg), _p(db), B, H, W, C, Co, kh, kw, stride, pad, dil, acc, _stream()))
+    if acc:
+        grad_sink.done(w)
+        grad_sink.done(gamma)
+        grad_sink.done(beta)
+        return None, None, None
+    return (gw if need[0] else None), (dg if need[1] else None), (db if need[2] else None)
+
+
+def conv_fwd_bn(x, w, bn, stride, pad, dil, relu, residual=None):
+    """act(bn_eval(conv(x, w)) + residual) in one launch (the norm folded into the prepared image)."""
+    B, C, H, W = x.shape
+    Co, _, kh, kw = w.shape
+    Ho = (H + 2 * pad - (dil * (kh - 1) + 1)) // stride + 1
+    Wo = (W + 2 * pad - (dil * (kw - 1) + 1)) // stride + 1
+    img, shift = weight_image(w, 0, bn=bn)
+    out = torch.empty((B, Co, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=_CL)
+    lv = _levels(1)
+    lv[0].x, lv[0].out, lv[0].B, lv[0].H, lv[0].W, lv[0].residual = _p(x), _p(out), B, H, W, _p(residual)
+    _lib.check(_lib.load().lsn_conv2d_forward_prepared(1, lv, _p(img), _p(shift), C, C, Co, kh, kw, stride, pad, dil,
+                                                       1 if relu else 0, _stream()))
+    return out
 
 
 class _ConvFn(torch.autograd.Function):
@@ -203,7 +281,7 @@ class _ConvFn(torch.autograd.Function):
         lib = _lib.load()
         go = go.contiguous(memory_format=_CL)
         if relu:
-            go = go * (out > 0)
+            go = relu_gate(go, out) if out.numel() % 4 == 0 else go * (out > 0)
         B, C, H, W = x.shape
         Co, _, kh, kw = w.shape
         gx = gw = gb = None
@@ -324,7 +402,7 @@ class _ConvMultiFn(torch.autograd.Function):
         Co, C, kh, kw = w.shape
         gos = [g.contiguous(memory_format=_CL) for g in gos]
         if relu:
-            gos = [g * (o > 0) for g, o in zip(gos, outs)]
+            gos = [relu_gate(g, o) if o.numel() % 4 == 0 else g * (o > 0) for g, o in zip(gos, outs)]
         need_x = [ctx.needs_input_grad[3 + i] for i in range(n)]
         gxs = [None] * n
         if any(need_x):
@@ -486,74 +564,36 @@ def conv_bn_act_frozen(conv, bn, x, relu=True, residual=None):
 
 class _ConvBnActFn(torch.autograd.Function):
     """y = act(bn(conv(x)) + residual) with the eval-mode BatchNorm FOLDED into the convolution (one launch, the raw
-    convolution output is never stored) and every gradient -- input, residual, weight, gamma, beta -- from the library:
-    lsn_bn_eval_act_backward_folded turns grad_y into the gradient w.r.t. the raw convolution output (taking x_hat from
-    y), the dense backward kernels take it from there with the UNscaled weight."""
+    convolution output is never stored) and every gradient -- input, residual, weight, gamma, beta -- from the library.
+    Backward: g = ReLU gate of grad_y (one streaming pass; g is also the residual's gradient); the data gradient runs
+    on the backward image of the SCALED weight; lsn_conv2d_backward_weight_bn forms grad_w, grad_gamma and grad_beta from
+    ONE weight-gradient launch with conv = w . x pulled out of the pixel sum -- exact for every gamma (a zero-initialised
+    norm3, `zero_init_residual`, learns; nothing is divided by gamma)."""
 
     @staticmethod
     def forward(ctx, x, w, gamma, beta, residual, bn, stride, pad, dil, relu):
-        lib = _lib.load()
-        B, C, H, W = x.shape
-        Co, _, kh, kw = w.shape
-        Ho = (H + 2 * pad - (dil * (kh - 1) + 1)) // stride + 1
-        Wo = (W + 2 * pad - (dil * (kw - 1) + 1)) // stride + 1
-        img, shift = weight_image(w, 0, bn=bn)
-        out = torch.empty((B, Co, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=_CL)
-        lv = _levels(1)
-        lv[0].x, lv[0].out, lv[0].B, lv[0].H, lv[0].W, lv[0].residual = _p(x), _p(out), B, H, W, _p(residual)
-        _lib.check(lib.lsn_conv2d_forward_prepared(1, lv, _p(img), _p(shift), C, C, Co, kh, kw, stride, pad, dil,
-                                                   1 if relu else 0, _stream()))
-        ctx.save_for_backward(x, w, out, residual, gamma, bn.running_var)
-        ctx.cfg = (stride, pad, dil, relu, float(bn.eps))
-        ctx.beta_ref = beta
+        out = conv_fwd_bn(x, w, bn, stride, pad, dil, relu, residual)
+        ctx.save_for_backward(x, w, out if relu else None)
+        ctx.cfg = (stride, pad, dil, relu, residual is not None)
+        ctx.bn = bn
         return out
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, gy):
-        x, w, y, residual, gamma, var = ctx.saved_tensors
-        stride, pad, dil, relu, eps = ctx.cfg
-        beta = ctx.beta_ref
-        lib = _lib.load()
+        x, w, y = ctx.saved_tensors
+        stride, pad, dil, relu, has_res = ctx.cfg
+        bn = ctx.bn
         gy = gy.contiguous(memory_format=_CL)
-        B, C, H, W = x.shape
-        Co, _, kh, kw = w.shape
-        N = y.shape[0] * y.shape[2] * y.shape[3]
-        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        need_g, need_b = ctx.needs_input_grad[2], ctx.needs_input_grad[3]
-        need_res = residual is not None and ctx.needs_input_grad[4]
-        need_p = need_g or need_b
-        gz = torch.empty_like(y, memory_format=_CL) if (need_x or need_w) else None   # w.r.t. the raw convolution output
-        gres = torch.empty_like(y, memory_format=_CL) if need_res else None
-        sg = grad_sink.sink(gamma) if need_g else None
-        sb = grad_sink.sink(beta) if need_b else None
-        acc = 1 if (sg is not None and sb is not None) else 0
-        if acc:
-            dg, db = sg, sb
-        else:
-            dg = torch.empty_like(gamma) if need_p else None
-            db = torch.empty_like(gamma) if need_p else None
-        ws = torch.empty(lib.lsn_bn_eval_act_workspace_bytes(N, Co), device=x.device, dtype=torch.uint8) if need_p else None
-        _lib.check(lib.lsn_bn_eval_act_backward_folded(_p(gy), _p(y), _p(residual), _p(var), _p(gamma), _p(beta),
-                                                       ctypes.c_float(eps), 1 if relu else 0, _p(gz), _p(gres), _p(dg),
-                                                       _p(db), _p(ws), N, Co, acc, _stream()))
-        if acc:
-            grad_sink.done(gamma)
-            grad_sink.done(beta)
-            dg = db = None
-        gx = gw = None
+        need_x, need_w, need_g, need_b = ctx.needs_input_grad[:4]
+        need_res = has_res and ctx.needs_input_grad[4]
+        g = relu_gate(gy, y) if relu else gy
+        gx = gw = dg = db = None
         if need_x:
-            gx = torch.empty_like(x, memory_format=_CL)
-            lv = _levels(1)
-            lv[0].x, lv[0].out, lv[0].B, lv[0].H, lv[0].W = _p(gz), _p(gx), B, H, W
-            _lib.check(lib.lsn_conv2d_backward_data_prepared(1, lv, _p(weight_image(w, 1, stride, pad, dil)), C, Co, kh, kw,
-                                                             stride, pad, dil, _stream()))
-        if need_w:
-            gw, _, wacc = _param_grad_buffers(w, None, True, False)
-            _lib.check(lib.lsn_conv2d_backward_weight(_p(x), _p(gz), _p(gw), None, B, H, W, C, Co, kh, kw, stride, pad, dil,
-                                                      wacc, _stream()))
-            gw, _ = _param_grad_results(w, None, gw, None, wacc, True)
-        return gx, gw, (dg if need_g else None), (db if need_b else None), gres, None, None, None, None, None
+            gx = dgrad(g, w, x.shape, stride, pad, dil, bn=bn)
+        if need_w or need_g or need_b:
+            gw, dg, db = wgrad_bn(x, g, w, bn, stride, pad, dil, (need_w, need_g, need_b))
+        return gx, gw, dg, db, (g if need_res else None), None, None, None, None, None
 
 
 def conv_bn_act(conv, bn, x, relu=True, residual=None):

@@ -1,0 +1,141 @@
+"""One ResNet bottleneck as ONE autograd node (the reference: mmdet/models/backbones/resnet.py:261-301 -- conv1 / bn1 /
+relu, conv2 / bn2 / relu, conv3 / bn3, + identity, relu as ten ATen operators, each with its own backward kernel).
+
+Forward is what `models/backbones/resnet.py: _conv_bn` already launched: one convolution per conv + eval-BatchNorm
+(+ residual) + ReLU group, the norm folded into the prepared weight image (ops/conv.py).  What the single node buys is
+the BACKWARD: with the whole block in hand no elementwise pass and no gradient accumulation is left between the
+convolutions --
+
+  * the ReLU gates ride in the epilogue of the backward-data launch that PRODUCES the gated gradient
+    (lsn_conv_level.gate): grad(h2) = gate_h2(dgrad3(g3)), grad(h1) = gate_h1(dgrad2(g2));
+  * the identity branch's gradient is the `residual` of conv1's backward-data launch (grad_x = dgrad1(g1) + g3, the
+    projection shortcut's data gradient likewise, in place) instead of an autograd accumulation;
+  * inside a stage the block also applies the gate of the PREVIOUS block's output ReLU to the gradient it hands back
+    (`pregate_in`: its input IS that output and it is the only consumer), and the previous block then takes its grad_y as
+    already gated (`gy_pregated`) -- models/backbones/resnet.py: ResLayer.forward sets the two flags for neighbouring
+    fused blocks.  One `lsn_relu_gate` pass per stage (its last block) is all that remains of the 16 gate / scale passes
+    and 13 accumulations of an R-50 step;
+  * the norm's scale a_c rides in the backward-data image, and lsn_conv2d_backward_weight_bn returns grad_w, grad_gamma
+    and grad_beta from one weight-gradient launch, exact for every gamma (zero-initialised norm3 included).
+
+The composition is written against the primitives of ops/conv.py (conv_fwd_bn, relu_gate, dgrad, wgrad_bn) through the
+module attribute `K`, so that tests/test_resblock.py can run the very same orchestration on the CPU with torch
+statements of the four primitives and compare it with autograd over the plain modules."""
+import torch
+
+from . import conv as K   # the primitives; tests swap this attribute for a torch restatement
+
+
+def epilogue_ok(k, stride, pad, dil):
+    """Can a backward-data launch of this convolution carry residual / gate in its epilogue?  Every residue class of
+    input pixels must have a tap (csrc/conv.hip bwd_plan: classes without one are memset, not computed)."""
+    for p in range(stride):
+        if not any((p + pad - t * dil) % stride == 0 for t in range(k)):
+            return False
+    return True
+
+
+def _cfg(conv):
+    return conv.stride[0], conv.padding[0], conv.dilation[0]
+
+
+class _BottleneckFn(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, x, blk, pregate_in, gy_pregated, *params):
+        # params: (w1, gamma1, beta1, w2, gamma2, beta2, w3, gamma3, beta3[, wd, gammad, betad]) -- autograd's handles on
+        # the parameters; the kernels read them through the modules
+        c1, c2, c3 = blk.conv1, blk.conv2, blk.conv3
+        n1, n2, n3 = blk.norm1, blk.norm2, blk.norm3
+        h1 = K.conv_fwd_bn(x, c1.weight, n1, *_cfg(c1), True)
+        h2 = K.conv_fwd_bn(h1, c2.weight, n2, *_cfg(c2), True)
+        if blk.downsample is not None:
+            cd, nd = blk.downsample[-2], blk.downsample[-1]
+            idt = K.conv_fwd_bn(x, cd.weight, nd, *_cfg(cd), False)
+        else:
+            idt = x
+        y = K.conv_fwd_bn(h2, c3.weight, n3, *_cfg(c3), True, idt)
+        ctx.save_for_backward(x, h1, h2, y)
+        ctx.blk, ctx.flags = blk, (bool(pregate_in), bool(gy_pregated))
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        x, h1, h2, y = ctx.saved_tensors
+        blk = ctx.blk
+        pregate_in, gy_pregated = ctx.flags
+        c1, c2, c3 = blk.conv1, blk.conv2, blk.conv3
+        n1, n2, n3 = blk.norm1, blk.norm2, blk.norm3
+        need_x = ctx.needs_input_grad[0]
+        gy = gy.contiguous(memory_format=torch.channels_last)
+        g3 = gy if gy_pregated else K.relu_gate(gy, y)
+        grads = []
+
+        def fused_dgrad(g, conv, bn, in_shape, gate, residual=None, out=None):
+            k = conv.kernel_size[0]
+            s, p, d = _cfg(conv)
+            if epilogue_ok(k, s, p, d):
+                return K.dgrad(g, conv.weight, in_shape, s, p, d, bn=bn, residual=residual, gate=gate, out=out)
+            r = K.dgrad(g, conv.weight, in_shape, s, p, d, bn=bn)       # (1x1 stride 2 in front: classes without a tap)
+            if residual is not None:
+                r = r.add_(residual)
+            return K.relu_gate(r, gate) if gate is not None else r
+
+        g2 = fused_dgrad(g3, c3, n3, h2.shape, h2)
+        grads.append(K.wgrad_bn(h2, g3, c3.weight, n3, *_cfg(c3)))
+        g1 = fused_dgrad(g2, c2, n2, h1.shape, h1)
+        grads.insert(0, K.wgrad_bn(h1, g2, c2.weight, n2, *_cfg(c2)))
+        gx = None
+        gd = None
+        if blk.downsample is not None:
+            cd, nd = blk.downsample[-2], blk.downsample[-1]
+            if need_x:
+                gx = K.dgrad(g3, cd.weight, x.shape, *_cfg(cd), bn=nd)      # projection shortcut first, conv1 adds onto it
+            gd = K.wgrad_bn(x, g3, cd.weight, nd, *_cfg(cd))
+        if need_x:
+            res = gx if gx is not None else g3
+            gx = fused_dgrad(g1, c1, n1, x.shape, x if pregate_in else None, residual=res, out=gx)
+        grads.insert(0, K.wgrad_bn(x, g1, c1.weight, n1, *_cfg(c1)))
+        flat = [t for trip in grads for t in trip]
+        if gd is not None:
+            flat += list(gd)
+        return (gx, None, None, None) + tuple(flat)
+
+
+def bottleneck_ok(blk):
+    """Module-level conditions of the fused node: three dense convolutions without bias, each behind an eval-mode affine
+    BatchNorm with running statistics, every parameter trainable, the projection shortcut (if any) a conv + norm pair."""
+    from torch.nn.modules.batchnorm import _BatchNorm
+    pairs = [(blk.conv1, blk.norm1), (blk.conv2, blk.norm2), (blk.conv3, blk.norm3)]
+    if blk.downsample is not None:
+        mods = list(blk.downsample)
+        if len(mods) != 2:
+            return False
+        pairs.append((mods[0], mods[1]))
+    if getattr(blk, 'with_cp', False) or getattr(blk, 'with_dcn', False):
+        return False
+    for conv, bn in pairs:
+        if type(conv) is not K.Conv2d or conv.bias is not None or conv.groups != 1 or conv.padding_mode != 'zeros':
+            return False
+        if not isinstance(bn, _BatchNorm) or bn.training or not bn.affine or not bn.track_running_stats:
+            return False
+        if not (conv.weight.requires_grad and bn.weight.requires_grad and bn.bias.requires_grad):
+            return False
+        Co, C, kh, kw = conv.weight.shape
+        if C % 4 or Co % 4 or kh != kw or conv.stride[0] != conv.stride[1] or conv.padding[0] != conv.padding[1] \
+                or conv.dilation[0] != conv.dilation[1] or not conv.weight.is_contiguous(memory_format=torch.channels_last):
+            return False
+    return True
+
+
+def bottleneck(blk, x, pregate_in=False, gy_pregated=False):
+    """relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1(x)))))))) + shortcut(x)) as one autograd node (x: channels-last fp32 on
+    the device; the caller checked bottleneck_ok(blk))."""
+    params = []
+    pairs = [(blk.conv1, blk.norm1), (blk.conv2, blk.norm2), (blk.conv3, blk.norm3)]
+    if blk.downsample is not None:
+        pairs.append((blk.downsample[-2], blk.downsample[-1]))
+    for conv, bn in pairs:
+        params += [conv.weight, bn.weight, bn.bias]
+    return _BottleneckFn.apply(x, blk, pregate_in, gy_pregated, *params)

@@ -60,11 +60,11 @@ class BucketedGradReducer:
         cap = int(bucket_mb * 1024 * 1024 / 4)
         cur, size = [], 0
         for p in reversed(self.params):
-            if cur and size + p.numel() > cap:
+            if cur and size + self._slot(p.numel()) > cap:
                 self._close(cur)
                 cur, size = [], 0
             cur.append(p)
-            size += p.numel()
+            size += self._slot(p.numel())
         if cur:
             self._close(cur)
         self._where = {}
@@ -77,8 +77,15 @@ class BucketedGradReducer:
         self._zeroed = False
         self.reset()
 
+    @staticmethod
+    def _slot(n):
+        """Floats a parameter occupies in its bucket: rounded up to 16 bytes, so that every gradient sink starts on a
+        16-byte boundary (the weight-gradient reduce kernels load and store float4 on it) whatever the odd-sized
+        parameters (27-channel biases, ...) in front of it.  The pad floats stay zero and travel with the bucket."""
+        return (n + 3) // 4 * 4
+
     def _close(self, plist):
-        n = sum(p.numel() for p in plist)
+        n = sum(self._slot(p.numel()) for p in plist)
         flat = torch.zeros(n, dtype=plist[0].dtype, device=plist[0].device)
         views, o = [], 0
         for p in plist:
@@ -86,7 +93,7 @@ class BucketedGradReducer:
             # same memory layout as the parameter (channels-last conv weights): autograd then adds in place
             dense = p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))
             views.append(seg.as_strided(p.shape, p.stride()) if dense else seg.view_as(p))
-            o += p.numel()
+            o += self._slot(p.numel())
         self.buckets.append(dict(flat=flat, params=list(plist), views=views, pending=0, work=None))
 
     def reset(self):
@@ -188,6 +195,8 @@ class DataParallelModel(nn.Module):
         if dist.is_initialized() and dist.get_world_size() > 1 and broadcast_params:
             for t in list(module.parameters()) + list(module.buffers()):
                 dist.broadcast(t.data, src=0)
+            from ..ops.conv import invalidate_weight_images
+            invalidate_weight_images()    # (written through .data: invisible to the image cache's version checks)
         self.reducer = BucketedGradReducer(module.parameters(), bucket_mb)
 
     def forward(self, *args, **kwargs):

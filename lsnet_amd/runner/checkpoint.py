@@ -38,6 +38,8 @@ def load_checkpoint(model, filename, map_location='cpu', strict=False, logger=No
         state = ckpt['state_dict']
     target = model.module if hasattr(model, 'module') else model
     load_state_dict(target, _strip_module(state), strict, logger)
+    from ..ops.conv import invalidate_weight_images
+    invalidate_weight_images()    # the parameters changed under the prepared weight images (ops/conv.py)
     return ckpt
 
 

@@ -15,6 +15,7 @@ import torch
 import torch.distributed as dist
 
 from ..ops import grad_sink
+from ..parallel.reducer import BucketedGradReducer
 
 
 def _walk(obj, fn, path=()):
@@ -63,7 +64,8 @@ class GraphedForwardBackward:
             self._close(cur)
 
     def _close(self, plist):
-        flat = torch.zeros(sum(p.numel() for p in plist), dtype=plist[0].dtype, device=plist[0].device)
+        slot = BucketedGradReducer._slot    # 16-byte aligned gradient sinks (parallel/reducer.py)
+        flat = torch.zeros(sum(slot(p.numel()) for p in plist), dtype=plist[0].dtype, device=plist[0].device)
         o = 0
         for p in plist:
             seg = flat[o:o + p.numel()]
@@ -72,7 +74,7 @@ class GraphedForwardBackward:
             dense = p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))
             p.grad = seg.as_strided(p.shape, p.stride()) if dense else seg.view_as(p)
             grad_sink.register(p, p.grad)    # the weight-gradient kernels add straight into the bucket
-            o += p.numel()
+            o += slot(p.numel())
         self.buckets.append(flat)
 
     # ------------------------------------------------------------------------------------------
@@ -90,6 +92,10 @@ class GraphedForwardBackward:
 
     def _capture(self, data):
         self.static_in = data
+        # every prepared weight image is rebuilt INSIDE the capture (ops/conv.py): a replay then always starts from the
+        # current parameters, whether or not an optimizer step ran between the last warm-up call and this one
+        from ..ops.conv import invalidate_weight_images
+        invalidate_weight_images()
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, stream=self.stream):

@@ -471,8 +471,10 @@ def test_conv2d_matches_torch(B, C, Co, k, s, p, d, H, W, bias, split_mode):
 def test_conv_bn_act_folded(C, Co, k, s, res, relu, split_mode):
     """relu(bn(conv(x)) + residual) with the eval-mode BatchNorm folded into the convolution's weight image (one forward
     launch, the raw convolution output never stored; ops/conv.py conv_bn_act) against an fp64 evaluation of the reference's
-    three operators (resnet.py:261-301): output, and the gradients of input, residual, weight, gamma and beta -- the
-    last two formed from y instead of the convolution output (lsn_bn_eval_act_backward_folded)."""
+    three operators (resnet.py:261-301): output, and the gradients of input, residual, weight, gamma and beta -- the data
+    gradient on the backward image of the SCALED weight, the three parameter gradients from ONE weight-gradient launch
+    (lsn_conv2d_backward_weight_bn: conv = w . x pulled out of the pixel sum).  Channels with gamma = 0 and gamma = 1e-6
+    are part of every case: nothing divides by gamma (round 3 recovered x_hat as (y - residual - beta) / gamma)."""
     from lsnet_amd.ops.conv import Conv2d, conv_bn_act
     torch.manual_seed(5)
     dev = _dev()
@@ -482,6 +484,9 @@ def test_conv_bn_act_folded(C, Co, k, s, res, relu, split_mode):
     bn = torch.nn.BatchNorm2d(Co).to(dev).eval()
     with torch.no_grad():
         bn.weight.copy_(torch.rand(Co) + 0.5)
+        bn.weight[:4] = 0.0       # zero_init_residual (resnet.py:607-612)
+        bn.weight[4:8] = 1e-6
+        bn.weight[8:12] *= -1.0
         bn.bias.copy_(torch.randn(Co) * 0.3)
         bn.running_mean.copy_(torch.randn(Co) * 0.2)
         bn.running_var.copy_(torch.rand(Co) + 0.5)

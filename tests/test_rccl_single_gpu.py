@@ -1,20 +1,78 @@
 """RCCL on a 1-GPU box: a one-rank 'nccl' process group with LSNET_FORCE_COLLECTIVES=1 sends every gradient bucket of the
 hook-driven reducer through RCCL (async work objects on RCCL's stream, ordered against the kernels that fill the
 buckets, waited for in finish()) -- the part of the data-parallel path that tests/test_rccl_gpu.py can only run with two
-GPUs.  The gloo twin of this test runs on every CPU run (tests/test_runner_dist.py).
-
-Opt-in (LSNET_RCCL_SINGLE=1) until it has been seen green on the pool's boxes: the driver runs the suite with -x."""
+GPUs (mmcv/parallel/distributed.py:10-53, mmdet/apis/train.py:74-78).  The gloo twin runs on every CPU run
+(tests/test_runner_dist.py).  Seen green on the pool's boxes in round 4 (profiles/r4_rccl_single.log): on by default."""
 import os
+import tempfile
 
 import pytest
 import torch
+import torch.multiprocessing as mp
 
-from tests.test_runner_dist import one_rank_forced_collectives_case
+from tests.test_runner_dist import _free_port, one_rank_forced_collectives_case
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(not torch.cuda.is_available(), reason='needs a GPU'),
-              pytest.mark.skipif(os.environ.get('LSNET_RCCL_SINGLE') != '1', reason='opt-in: LSNET_RCCL_SINGLE=1')]
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not torch.cuda.is_available(), reason='needs a GPU')]
 
 
 def test_one_rank_rccl_group_runs_every_bucket():
     one_rank_forced_collectives_case('nccl', 'cuda:0')
+
+
+def _detector_worker(_, collective, port, out_path):
+    """Two training iterations of the real LSNet R-50 bbox detector (gradient sinks, fused SGD, the runner's own hooks)."""
+    import torch.distributed as dist
+    os.environ['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+    if collective:
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1',
+                          LSNET_FORCE_COLLECTIVES='1')
+        torch.cuda.set_device(0)
+        dist.init_process_group('nccl', rank=0, world_size=1)
+    else:
+        os.environ.pop('LSNET_FORCE_COLLECTIVES', None)
+    try:
+        from lsnet_amd.data import synthetic_batch
+        from lsnet_amd.model_zoo import build_lsnet
+        from lsnet_amd.parallel import DataParallelModel
+        from lsnet_amd.runner import EpochBasedRunner, build_optimizer
+        dev = torch.device('cuda:0')
+        torch.manual_seed(0)
+        model, cfg = build_lsnet('bbox', 'r50')
+        model = DataParallelModel(model.to(dev).to(memory_format=torch.channels_last).train(), bucket_mb=25.0)
+        assert model.reducer.collective == bool(collective)
+        opt = build_optimizer(model, cfg.optimizer)
+        runner = EpochBasedRunner(model, optimizer=opt, logger=lambda m: None)
+        runner.register_training_hooks(cfg.lr_config, cfg.optimizer_config, None, dict(interval=10 ** 9, hooks=[]))
+        runner.epoch_len = 10 ** 9
+        runner.call_hook('before_run')
+        runner.call_hook('before_train_epoch')
+        data = synthetic_batch('bbox', 2, 384, 480, boxes_per_img=5, num_classes=80, seed=7, device=dev, channels_last=True)
+        losses = []
+        for _ in range(2):
+            runner.call_hook('before_train_iter')
+            runner.outputs = runner.run_iter(data)
+            runner.call_hook('after_train_iter')
+            runner.iter += 1
+            losses.append(float(runner.outputs['loss']))
+        torch.cuda.synchronize()
+        nb = len(model.reducer.buckets)
+        torch.save({'state': {k: v.detach().cpu() for k, v in model.module.state_dict().items()}, 'losses': losses,
+                    'buckets': nb}, out_path)
+    finally:
+        if collective:
+            dist.destroy_process_group()
+
+
+def test_real_detector_through_one_rank_rccl_equals_plain_step_bit_for_bit():
+    """The all-reduce of one rank is the identity: two iterations of the real detector with every bucket sent through RCCL
+    must leave exactly the parameters of the same two iterations without a process group -- any mis-ordering between the
+    kernels that fill a bucket (weight-gradient sinks), its all-reduce and the optimizer would show."""
+    with tempfile.TemporaryDirectory() as d:
+        a, b = os.path.join(d, 'rccl.pt'), os.path.join(d, 'plain.pt')
+        mp.spawn(_detector_worker, args=(True, _free_port(), a), nprocs=1, join=True)
+        mp.spawn(_detector_worker, args=(False, 0, b), nprocs=1, join=True)
+        ra, rb = torch.load(a), torch.load(b)
+    assert ra['buckets'] >= 4
+    assert ra['losses'] == rb['losses'], (ra['losses'], rb['losses'])
+    diff = [k for k in rb['state'] if not torch.equal(ra['state'][k], rb['state'][k])]
+    assert not diff, f'{len(diff)} tensors differ, e.g. {diff[:4]}'

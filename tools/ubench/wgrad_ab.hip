@@ -1,9 +1,11 @@
 // A/B of the dense-convolution weight gradient: the patch kernel of conv_wgrad_kernels.h (debug bit 28 set: the kernels of
-// dcn_mm_kernels.h are off) against dcn_wgrad_mm_kernel<NP, DENSE> behind LSNET_CONV_WGRAD_MM=1, on the layer shapes of
+// dcn_mm_kernels.h are off) against dcn_wgrad_mm_kernel<NP, DENSE> forced with debug bit 27 (or, "rule": as the library routes), on the layer shapes of
 // the benchmark step (tools/bench_convs.py SH), through the C ABI only (no torch: the binary starts in a second).
 // Each result is also checked against a double-precision sum on the host for 48 sampled weight elements.
 //   hipcc --offload-arch=gfx950 -O2 tools/ubench/wgrad_ab.hip -o tools/ubench/wgrad_ab -ldl
-//   tools/ubench/wgrad_ab [path to liblsnet_hip.so]
+//   tools/ubench/wgrad_ab [path to liblsnet_hip.so] [rule | bn]
+// "bn": the plain weight gradient (library routing) against lsn_conv2d_backward_weight_bn on the single-map shapes -- the
+// cost of the folded-norm reduce -- with grad_w = a G, grad_beta and grad_gamma checked against the plain call's results
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <cmath>
@@ -32,6 +34,8 @@ __global__ void fill_kernel(float *p, size_t n, unsigned seed, float scale)
 }
 
 typedef int (*wgrad_fn)(int, const lsn_conv_level *, float *, float *, int, int, int, int, int, int, int, int, lsn_stream_t);
+typedef int (*wgrad_bn_fn)(const float *, const float *, const float *, const float *, const float *, const float *, float, float *,
+                           float *, float *, int, int, int, int, int, int, int, int, int, int, int, lsn_stream_t);
 typedef int (*dbg_fn)(long long *, int);
 typedef const char *(*err_fn)(void);
 
@@ -46,7 +50,7 @@ struct Shape {
 
 int main(int argc, char **argv)
 {
-    setenv("LSNET_CONV_WGRAD_MM", "1", 0);   // (LSNET_CONV_WGRAD_MM=2 in the environment: the library's own selection)
+    const bool rule = argc > 2 && !strcmp(argv[2], "rule");   // "new" = the library's own routing instead of the forced kernel
     const char *so = argc > 1 ? argv[1] : "lsnet_amd/csrc/liblsnet_hip.so";
     void *h = dlopen(so, RTLD_NOW);
     if (!h) {
@@ -56,7 +60,9 @@ int main(int argc, char **argv)
     wgrad_fn wgrad = (wgrad_fn)dlsym(h, "lsn_conv2d_backward_weight_multi");
     dbg_fn dbg = (dbg_fn)dlsym(h, "lsn_debug_phase_clocks");
     err_fn lasterr = (err_fn)dlsym(h, "lsn_last_error");
-    if (!wgrad || !dbg || !lasterr) return 2;
+    const bool bnmode = argc > 2 && !strcmp(argv[2], "bn");
+    wgrad_bn_fn wgrad_bn = (wgrad_bn_fn)dlsym(h, "lsn_conv2d_backward_weight_bn");
+    if (!wgrad || !dbg || !lasterr || !wgrad_bn) return 2;
     const int B = 2;
     const Shape shapes[] = {
         {"l2 1x1 128->512", 128, 512, 1, 1, 1, {100}, {168}, 4, 0, 0},
@@ -83,7 +89,12 @@ int main(int argc, char **argv)
     };
     double tot_old = 0, tot_new = 0;
     printf("%-38s %9s %7s %9s %7s %9s %9s %9s %s\n", "shape", "old us", "TF", "new us", "TF", "new-old", "old-ref", "new-ref", "");
-    for (const Shape &s : shapes) {
+    for (const Shape &s0 : shapes) {
+        Shape s = s0;
+        if (bnmode) {
+            if (s.nlv != 1) continue;
+            s.bias = 1, s.accumulate = 0;
+        }
         const int K = s.k * s.k, pad = s.k / 2;
         float *x[5], *go[5];
         int Ho[5], Wo[5];
@@ -103,11 +114,30 @@ int main(int argc, char **argv)
         float *gw[2], *gb[2];
         std::vector<float> hw[2], hb[2];
         double us[2] = {0, 0};
+        float *wdev = nullptr, *bnp = nullptr, *dgam = nullptr;   // bn mode: weight, (gamma | mean | var), grad_gamma
+        if (bnmode) {
+            CK(hipMalloc(&wdev, nW * 4));
+            CK(hipMalloc(&bnp, (size_t)3 * s.Co * 4));
+            CK(hipMalloc(&dgam, (size_t)s.Co * 4));
+            hipLaunchKernelGGL(fill_kernel, dim3(256), dim3(256), 0, 0, wdev, nW, 41u, 0.05f);
+            hipLaunchKernelGGL(fill_kernel, dim3(8), dim3(256), 0, 0, bnp, (size_t)2 * s.Co, 42u, 1.f);          // gamma, mean in (-1, 1)
+            hipLaunchKernelGGL(fill_kernel, dim3(8), dim3(256), 0, 0, bnp + 2 * s.Co, (size_t)s.Co, 43u, 0.4f);   // var - 1
+        }
         for (int mode = 0; mode < 2; ++mode) {   // 0: old kernels, 1: new
-            dbg(nullptr, mode == 0 ? (1 << 28) : 0);
+            dbg(nullptr, bnmode ? 0 : mode == 0 ? (1 << 28) : rule ? 0 : (1 << 27));
             CK(hipMalloc(&gw[mode], nW * 4));
             CK(hipMalloc(&gb[mode], (size_t)s.Co * 4));
             auto run = [&]() {
+                if (bnmode && mode == 1) {
+                    // (var = 1 + fill: the eps argument carries the 1)
+                    const int rc = wgrad_bn(x[0], go[0], wdev, bnp, bnp + s.Co, bnp + 2 * s.Co, 1.0f, gw[1], dgam, gb[1], B, s.H[0],
+                                            s.W[0], s.C, s.Co, s.k, s.k, s.stride, pad, 1, 0, nullptr);
+                    if (rc != 0) {
+                        printf("%s: wgrad_bn rc %d: %s\n", s.name, rc, lasterr());
+                        exit(3);
+                    }
+                    return;
+                }
                 const int rc = wgrad(s.nlv, lv, gw[mode], s.bias ? gb[mode] : nullptr, s.C, s.Co, s.k, s.k, s.stride, pad, 1,
                                      s.accumulate, nullptr);
                 if (rc != 0) {
@@ -135,6 +165,33 @@ int main(int argc, char **argv)
             hw[mode].resize(nW), hb[mode].resize(s.Co);
             CK(hipMemcpy(hw[mode].data(), gw[mode], nW * 4, hipMemcpyDeviceToHost));
             CK(hipMemcpy(hb[mode].data(), gb[mode], (size_t)s.Co * 4, hipMemcpyDeviceToHost));
+        }
+        if (bnmode) {   // grad_w = a G, grad_beta = the plain bias gradient, grad_gamma = (w . G - mean grad_beta) rstd
+            std::vector<float> hwt(nW), hbn((size_t)3 * s.Co), hdg(s.Co);
+            CK(hipMemcpy(hwt.data(), wdev, nW * 4, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(hbn.data(), bnp, hbn.size() * 4, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(hdg.data(), dgam, hdg.size() * 4, hipMemcpyDeviceToHost));
+            double ew = 0, sw = 0, eg = 0, sg = 0, eb = 0, sbm = 0;
+            const size_t R = (size_t)K * s.C;
+            for (int co = 0; co < s.Co; ++co) {
+                const double rstd = 1.0 / sqrt((double)hbn[2 * s.Co + co] + 1.0), a = hbn[co] * rstd;
+                double dot = 0;
+                for (size_t e = 0; e < R; ++e) {
+                    const double G = hw[0][co * R + e];
+                    dot += (double)hwt[co * R + e] * G;
+                    ew = fmax(ew, fabs(hw[1][co * R + e] - a * G)), sw = fmax(sw, fabs(a * G));
+                }
+                const double dg = (dot - (double)hbn[s.Co + co] * hb[0][co]) * rstd;
+                eg = fmax(eg, fabs(hdg[co] - dg)), sg = fmax(sg, fabs(dg));
+                eb = fmax(eb, fabs((double)hb[1][co] - hb[0][co])), sbm = fmax(sbm, fabs((double)hb[0][co]));
+            }
+            const double fl = 2.0 * px * s.C * s.Co * K;
+            printf("%-38s %9.1f %7.1f %9.1f %7.1f   bn: gw %.1e  dgamma %.1e  dbeta %.1e\n", s.name, us[0], fl / us[0] * 1e-6, us[1],
+                   fl / us[1] * 1e-6, ew / sw, eg / sg, eb / sbm);
+            fflush(stdout);
+            tot_old += us[0] * s.count, tot_new += us[1] * s.count;
+            for (float *q : {wdev, bnp, dgam, x[0], go[0], gw[0], gw[1], gb[0], gb[1]}) CK(hipFree(q));
+            continue;
         }
         // host reference on sampled elements
         std::vector<float> start(nW), startb(s.Co);
