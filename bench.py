@@ -265,6 +265,34 @@ def timed_steps(step, data, n, warm):
     return (time.perf_counter() - t0) / n
 
 
+ITER0_FIXTURE = os.path.join(ROOT, 'tests', 'golden', 'bench_iter0.npz')
+
+
+def iteration0_losses(model, data):
+    """The losses of the untouched model on the bench batch (one forward, no update), as the reference's
+    `_parse_losses` (detectors/base.py:176-209) reports them."""
+    with torch.no_grad():
+        mod = model.module if hasattr(model, 'module') else model
+        _, log_vars = mod._parse_losses(model(**data))
+    return {k: float(v) for k, v in log_vars.items()}
+
+
+def iteration0_parity(args, iter0):
+    """iter0 against tests/golden/bench_iter0.npz = the REFERENCE's detector on the same weights and batch (one CPU forward
+    in the build container, oracle/ref_harness/make_golden.py::golden_bench_iter0).  Only the default workload has one."""
+    if iter0 is None or (args.task, args.backbone, args.batch, args.height, args.width) != ('bbox', 'r50', 2, 800, 1344):
+        return None
+    try:
+        import numpy as np
+        ref = np.load(ITER0_FIXTURE)
+    except OSError:
+        return None
+    keys = ('loss_cls', 'loss_bbox_init', 'loss_bbox_refine', 'loss')
+    want = {k: float(ref[k]) for k in keys}
+    return {'loss_iter0': {k: round(iter0[k], 6) for k in keys}, 'loss_iter0_ref': {k: round(want[k], 6) for k in keys},
+            'loss_ref_rel_err': max(abs(iter0[k] - want[k]) / abs(want[k]) for k in keys)}
+
+
 def allreduce_probe(model, dev, world, reps=5):
     """Stand-alone time of one gradient all-reduce of the step (all buckets, back to back, nothing to overlap with)."""
     flats = [b['flat'] for b in model.reducer.buckets]
@@ -333,6 +361,7 @@ def main():
     step, runner = build_step(model, cfg)
     data = synthetic_batch(args.task, args.batch, args.height, args.width, seed=1234 + rank, device=dev,
                            channels_last=not args.nchw)
+    iter0 = iteration0_losses(model, data) if rank == 0 else None   # before any update: SURVEY 8(d) "Loss parity"
     timer = None if args.no_kernel_timing else KernelTimer()
     survey, dominant = {}, None
     use_graph = args.graph
@@ -462,6 +491,9 @@ def main():
                        'math': MATH_NOTES[args.math]},
             'loss': {k: round(v, 5) for k, v in losses.items()},
         }
+        par = iteration0_parity(args, iter0)
+        if par:
+            res.update(par)   # iteration-0 losses vs the reference's on the same weights / batch (tolerance 1e-3)
         if comm1 is not None:
             res['config']['one_rank_rccl'] = comm1
         if world > 1:

@@ -32,23 +32,38 @@ int split_np();   // dcn.hip: bf16 products per fp32 product of the current math
 static int conv_np() { return split_np() == 3 ? 3 : 6; }   // these kernels have no fp32-MFMA variant: exact mode gets x6
 static int conv_npl() { return conv_np() == 3 ? 2 : 3; }
 
-// Library-owned scratch for the partial tiles of split reductions: grown on demand (never inside a stream capture once
-// the shapes of a step have been seen), reused by every later call on the launch stream.  Not thread-safe.
-static float *g_part = nullptr;
-static size_t g_part_floats = 0;
-static int part_buffer(size_t floats, float **p)
+// Library-owned scratch for the partial tiles of split reductions: ONE block PER STREAM (callers on different streams must
+// not share partial tiles), grown on demand.  A block that is outgrown is
+// RETIRED, not freed: a captured hipGraph may hold its address, and no device synchronisation is needed.
+// Growing while the stream is being captured is refused -- run the step eagerly once first (the graph wrapper's warm-up
+// calls do).  Host-side bookkeeping is not thread-safe (one Python thread drives the library).
+struct Scratch {
+    hipStream_t st;
+    float *p;
+    size_t floats;
+};
+static Scratch g_scr[16];
+static int g_nscr = 0;
+static int part_buffer(size_t floats, float **p, hipStream_t st)
 {
-    if (floats > g_part_floats) {
-        if (g_part) {
-            LSN_HIP(hipDeviceSynchronize());
-            LSN_HIP(hipFree(g_part));
-            g_part = nullptr, g_part_floats = 0;
-        }
-        const size_t want = floats + floats / 4;
-        LSN_HIP(hipMalloc(reinterpret_cast<void **>(&g_part), want * sizeof(float)));
-        g_part_floats = want;
+    Scratch *sc = nullptr;
+    for (int i = 0; i < g_nscr; ++i)
+        if (g_scr[i].st == st) sc = &g_scr[i];
+    if (!sc) {
+        if (g_nscr == 16) return fail(LSN_ERR_RUNTIME, "scratch: more than 16 streams use the library");
+        sc = &g_scr[g_nscr++];
+        *sc = Scratch{st, nullptr, 0};
     }
-    *p = g_part;
+    if (floats > sc->floats) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+            return fail(LSN_ERR_RUNTIME, "scratch would grow inside a stream capture: run the step eagerly once before capturing");
+        const size_t want = floats + floats / 4;
+        float *np = nullptr;
+        LSN_HIP(hipMalloc(reinterpret_cast<void **>(&np), want * sizeof(float)));
+        sc->p = np, sc->floats = want;   // (the old block stays allocated: see above)
+    }
+    *p = sc->p;
     return 0;
 }
 
@@ -66,7 +81,7 @@ static int launch_conv_cfg(ConvArgs &a, int ks, hipStream_t st)
     a.ksplit = ks;
     const size_t n = (size_t)a.lv[0].P * a.Co;
     if (ks > 1)
-        if (int rc = part_buffer(n * ks, &a.part)) return rc;
+        if (int rc = part_buffer(n * ks, &a.part, st)) return rc;
     dim3 grid(tiles, (a.Co + BN - 1) / BN, ks);
     auto k = conv_mm_kernel<TM, TN, WM, WN, NP, UNAL, FINE, TRANS>;
     static bool attr_set = false;   // per instantiation
@@ -452,7 +467,7 @@ static int launch_wgrad_cfg(WgArgs &a, float *gw, float *gb, int accumulate, hip
     if (S > a.nseg / 6) S = a.nseg / 6;   // a split should run long enough to amortise its prologue and its partial tile
     if (S < 1) S = 1;
     float *part = nullptr;
-    if (int rc = part_buffer((size_t)S * (nW + a.Co) + 16, &part)) return rc;
+    if (int rc = part_buffer((size_t)S * (nW + a.Co) + 16, &part, st)) return rc;
     a.part = part;
     a.part_b = part + (((size_t)S * nW + 3) & ~(size_t)3);
     a.want_bias = gb != nullptr;
@@ -512,7 +527,7 @@ int conv_wgrad_reduce(const float *part, float *gw, size_t n, const float *part_
 }
 
 // library-owned scratch (also for dcn.hip's weight-gradient pass): grows, never shrinks
-int conv_scratch(size_t floats, float **p) { return part_buffer(floats, p); }
+int conv_scratch(size_t floats, float **p, hipStream_t st) { return part_buffer(floats, p, st); }
 
 // Returns 1 when the shape is not served here (more than nine taps, C % 4 != 0, 64-bit offsets): the caller keeps the
 // general kernel of dcn.hip.
@@ -600,11 +615,7 @@ static int prepare_weights_multi(int n, const lsn_conv_wprep *it, hipStream_t st
     const bool same = jobs.size() == g_jobs_host.size() && memcmp(jobs.data(), g_jobs_host.data(), bytes) == 0;
     if (!same) {   // the table changes only when the set of weights does (first steps): upload then, reuse afterwards
         if (jobs.size() > g_jobs_cap) {
-            if (g_jobs_dev) {
-                LSN_HIP(hipDeviceSynchronize());
-                LSN_HIP(hipFree(g_jobs_dev));
-                g_jobs_dev = nullptr, g_jobs_cap = 0;
-            }
+            // (an outgrown table is retired, not freed: a captured graph may hold its address)
             LSN_HIP(hipMalloc(reinterpret_cast<void **>(&g_jobs_dev), (jobs.size() + 64) * sizeof(WfragJob)));
             g_jobs_cap = jobs.size() + 64;
         }

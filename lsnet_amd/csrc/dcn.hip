@@ -762,7 +762,7 @@ static int wgrad_vec_bits(const DcnArgs &a)
 int conv_wgrad_reduce(const float *part, float *gw, size_t n, const float *part_b, float *gb, int nb, int splits, int splits_b,
                       int accumulate, hipStream_t st);
 bool conv_wgrad_fold_pending();   // conv.hip: lsn_conv2d_backward_weight_bn is the caller
-int conv_scratch(size_t floats, float **p);
+int conv_scratch(size_t floats, float **p, hipStream_t st);
 
 static bool mm_wgrad_ok(const DcnArgs &a)
 {
@@ -802,7 +802,7 @@ static int launch_wgrad_mm(const DcnArgs &a_in, int nchunks, bool accumulate, hi
         tap_entries = (size_t)rows * K * a.dg;
     }
     float *base = nullptr;
-    if (int rc = conv_scratch(img_f + part_f + pb_f + meta_f + (tap_entries ? (tap_entries + 1) * (sizeof(Tap) / 4) : 0), &base))
+    if (int rc = conv_scratch(img_f + part_f + pb_f + meta_f + (tap_entries ? (tap_entries + 1) * (sizeof(Tap) / 4) : 0), &base, st))
         return rc;
     unsigned short *img = reinterpret_cast<unsigned short *>(base);
     float *part = base + img_f, *part_b = part + part_f;
@@ -858,7 +858,7 @@ static int launch_wgrad(const DcnArgs &a_in, int nsteps, bool accumulate, hipStr
                          (size_t)splits * (nW + a.Co) * sizeof(float) <= ((size_t)256 << 20);
     if (ordered) {
         float *base = nullptr;
-        if (int rc = conv_scratch((size_t)splits * (nW + a.Co) + 16, &base)) return rc;
+        if (int rc = conv_scratch((size_t)splits * (nW + a.Co) + 16, &base, st)) return rc;
         a.wg_part = base;
         a.wg_part_b = a.gb ? base + (((size_t)splits * nW + 3) & ~(size_t)3) : nullptr;
     } else if (!accumulate) {
@@ -1120,7 +1120,7 @@ static int conv_wgrad_launch(DcnArgs a, int nsteps, int C, int Co, int K, bool a
         return fail(LSN_ERR_UNSUPPORTED, "conv2d backward-weight (folded norm): the gradient is too large for the ordered reduce");
     if (ordered) {
         float *base = nullptr;
-        if (int rc = conv_scratch((size_t)splits * (nW + Co) + 16, &base)) return rc;
+        if (int rc = conv_scratch((size_t)splits * (nW + Co) + 16, &base, st)) return rc;
         a.wg_part = base;
         a.wg_part_b = a.gb ? base + (((size_t)splits * nW + 3) & ~(size_t)3) : nullptr;
     } else if (!accumulate) {

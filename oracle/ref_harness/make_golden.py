@@ -78,7 +78,9 @@ def golden_head(task, channels=32):
         total = total + sum(v)
     total.backward()
     for i, f in enumerate(feats):
-        gu.pack(f'grad/feat/{i}', f.grad, data)
+        # the two smallest levels are stored WHOLE (a strided sample cannot see an error confined to one residue class
+        # of channels; gu.FEAT_GRAD_STRIDE is shared with the checking side)
+        gu.pack(f'grad/feat/{i}', f.grad, data, stride=gu.FEAT_GRAD_STRIDE(i))
     for name, p in sorted(head.named_parameters()):
         if p.grad is not None:
             gu.pack(f'grad/param/{name}', p.grad, data, stride=7)
@@ -237,6 +239,37 @@ def golden_train_curve(lr=0.01, fixture='train_curve'):
     _save(fixture, data)
 
 
+def golden_bench_iter0():
+    """SURVEY 8(d) "Loss parity" at the BENCHMARK shape: the reference's detector (mmdet LSDetector from
+    configs/lsnet/lsnet_bbox_r50_fpn_1x_coco.py's model dict, native ops backed by the CPU oracle) on the very batch and
+    the very weights `python bench.py` starts from -- torch.manual_seed(0), this package's model construction (the
+    reference's init_weights semantics), synthetic_batch('bbox', 2, 800, 1344, seed=1234) -- one forward pass on the CPU.
+    Stores the iteration-0 loss triplet and total; bench.py prints its own iteration-0 losses against them
+    (`loss_ref_rel_err`) and tests/test_golden_gpu.py asserts 1e-3."""
+    import mmcv
+    from mmdet.models import build_detector
+    from lsnet_amd.data import synthetic_batch
+    from lsnet_amd.model_zoo import build_lsnet, lsnet_config
+    torch.manual_seed(0)
+    own, _ = build_lsnet('bbox', 'r50')
+    cfg = lsnet_config('bbox', 'r50')
+    model_cfg = mmcv.Config(copy.deepcopy(cfg.model.to_dict() if hasattr(cfg.model, 'to_dict') else dict(cfg.model)))._cfg_dict
+    model = build_detector(model_cfg, train_cfg=mmcv.Config(dict(cfg.train_cfg)), test_cfg=mmcv.Config(dict(cfg.test_cfg)))
+    missing = model.load_state_dict(own.state_dict(), strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    model.train()
+    data = synthetic_batch('bbox', 2, 800, 1344, seed=1234, device='cpu', channels_last=False)
+    with torch.no_grad():
+        losses = model(**data)
+        _, log_vars = model._parse_losses(losses)
+    out = {k: np.float64(float(v)) for k, v in log_vars.items()}
+    out['per_level/loss_cls'] = np.array([float(v) for v in losses['loss_cls']], dtype=np.float64)
+    out['per_level/loss_bbox_init'] = np.array([float(v) for v in losses['loss_bbox_init']], dtype=np.float64)
+    out['per_level/loss_bbox_refine'] = np.array([float(v) for v in losses['loss_bbox_refine']], dtype=np.float64)
+    print({k: v for k, v in out.items() if not k.startswith('per_level')})
+    _save('bench_iter0', out)
+
+
 def golden_assign():
     """(6) CentroidAssigner + ATSSAssigner gt indices on the 800x800 grid (13 343 points)."""
     from mmdet.core import build_assigner
@@ -318,7 +351,7 @@ def golden_backbone():
 
 def golden_res2net():
     """(f-3) Res2Net-50 (26w x 4s, DCNv2 in c3-c5: the structure of the headline res2_101 configs at a testable
-    depth) forward on a 1x3x96x128 input with name-keyed weights, plus the sorted state-dict keys."""
+    depth) forward and backward on a 1x3x96x128 input with name-keyed weights, plus the sorted state-dict keys."""
     from mmdet.models import build_backbone
     bb = build_backbone(dict(type='Res2Net', depth=50, scales=4, base_width=26, num_stages=4, out_indices=(0, 1, 2, 3),
                              frozen_stages=1, norm_cfg=dict(type='BN', requires_grad=True), norm_eval=True,
@@ -326,12 +359,22 @@ def golden_res2net():
                              stage_with_dcn=(False, True, True, True)))
     gu.fill_params(bb, seed=8)
     bb.train()
-    x = torch.randn(1, 3, 96, 128, generator=gu.gen(31))
+    x = torch.randn(1, 3, 96, 128, generator=gu.gen(31)).requires_grad_()
     data = {'keys': np.array(sorted(bb.state_dict().keys())),
             'nparams': np.array(sum(p.numel() for p in bb.parameters()))}
-    with torch.no_grad():
-        for i, t in enumerate(bb(x)):
-            gu.pack(f'c/{i}', t, data)
+    feats = bb(x)
+    for i, t in enumerate(feats):
+        gu.pack(f'c/{i}', t, data)
+    # round 4: gradients of a fixed random projection of the four maps w.r.t. the image and parameters of every stage
+    # (hierarchical 3x3 convs, the scale split / concat, average-pool shortcuts in backward)
+    proj = sum((f * torch.randn(f.shape, generator=gu.gen(60 + i))).sum() / f.numel() ** 0.5 for i, f in enumerate(feats))
+    names = gu.res2net_grad_names(bb)
+    params = dict(bb.named_parameters())
+    grads = torch.autograd.grad(proj, [x] + [params[n] for n in names])
+    gu.pack('gx', grads[0], data)
+    for n, g in zip(names, grads[1:]):
+        gu.pack(f'g/{n}', g, data, stride=257)
+    data['grad_names'] = np.array(names)
     _save('res2net50_dcn', data)
 
 
@@ -625,7 +668,7 @@ def golden_data_pipeline():
     _save('data_pipeline', data)
 
 
-ALL = dict(backbones_dcn=golden_backbones_dcn, train_curve=golden_train_curve,
+ALL = dict(backbones_dcn=golden_backbones_dcn, bench_iter0=golden_bench_iter0, train_curve=golden_train_curve,
            # the same run at a tenth of the learning rate: the loss falls 475 -> 60 instead of 475 -> 1 and rounding
            # differences between two correct implementations stay at rounding level over all twelve iterations
            train_curve_lowlr=lambda: golden_train_curve(0.001, 'train_curve_lowlr'), coco_eval=golden_coco_eval, head_cpv=golden_head_cpv, data_pipeline=golden_data_pipeline, gt_formats=golden_gt_formats, res2net=golden_res2net, vote=golden_vote, head_bbox=lambda: golden_head('bbox'), head_segm=lambda: golden_head('segm'),

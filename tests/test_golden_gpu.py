@@ -117,3 +117,77 @@ def test_training_curve_low_learning_rate(math):
     finally:
         _lib.set_math_mode(before)
     print(math, f'low-lr curve: worst relative loss deviation {worst:.2e}')
+
+
+def test_iteration0_losses_at_the_benchmark_shape():
+    """SURVEY 8(d) "Loss parity": the untouched seed-0 model on the bench batch (2 x 3 x 800 x 1344, seed 1234) -- what
+    `python bench.py` starts from -- against the REFERENCE's detector on the same weights and batch (fixture
+    bench_iter0.npz: one CPU forward in the build container, make_golden.py::golden_bench_iter0): the loss triplet and the
+    per-level terms within 1e-3."""
+    import numpy as np
+    from lsnet_amd.data import synthetic_batch
+    from lsnet_amd.model_zoo import build_lsnet
+    ref = gc.load('bench_iter0')
+    dev = _dev()
+    torch.manual_seed(0)
+    model, _ = build_lsnet('bbox', 'r50')
+    model = model.to(dev).to(memory_format=torch.channels_last).train()
+    data = synthetic_batch('bbox', 2, 800, 1344, seed=1234, device=dev, channels_last=True)
+    with torch.no_grad():
+        losses = model(**data)
+        _, lv = model._parse_losses(losses)
+    for k in ('loss_cls', 'loss_bbox_init', 'loss_bbox_refine', 'loss'):
+        assert abs(float(lv[k]) - float(ref[k])) <= 1e-3 * abs(float(ref[k])), (k, float(lv[k]), float(ref[k]))
+        got = np.array([float(v) for v in losses[k]]) if k != 'loss' else None
+        if got is not None:
+            assert np.allclose(got, ref[f'per_level/{k}'], rtol=1e-3, atol=1e-6), (k, got, ref[f'per_level/{k}'])
+
+
+def test_instances_vote_on_the_device():
+    """(f-3) the per-class instance vote of multi-scale testing on device tensors against the reference's
+    (lsnet.py:229-299, fixture vote.npz)."""
+    import numpy as np
+    from lsnet_amd.core.vote import instances_vote
+    ref = gc.load('vote')
+    case = 0
+    while f'{case}/boxes' in ref.files:
+        b, v, s = (torch.from_numpy(ref[f'{case}/{k}']).to(_dev()) for k in ('boxes', 'vectors', 'scores'))
+        ob, ov, os_ = instances_vote(b, v, s)
+        assert ob.is_cuda and ob.shape[0] == ref[f'{case}/out_boxes'].shape[0], case
+        assert np.allclose(ob.cpu().numpy(), ref[f'{case}/out_boxes'], rtol=1e-5, atol=1e-3), case
+        assert np.allclose(ov.cpu().numpy(), ref[f'{case}/out_vectors'], rtol=1e-5, atol=1e-3), case
+        assert np.allclose(os_.cpu().numpy(), ref[f'{case}/out_scores'], rtol=1e-5, atol=1e-6), case
+        case += 1
+    assert case == 4
+
+
+def test_aug_test_vote_on_the_device():
+    """(f-3) LSDetector.aug_test (lsnet.py:301-401) on the MI355X: two scales x {plain, flipped} of one image through the
+    HIP forward, mapped back and merged by the instance vote; per-class results of the reference's shapes, and the
+    single-view subset of the multi-view result equals what simple_test gives for that view."""
+    import numpy as np
+    from lsnet_amd.model_zoo import build_lsnet
+    dev = _dev()
+    torch.manual_seed(0)
+    model, cfg = build_lsnet('bbox', 'r50')
+    model = model.to(dev).to(memory_format=torch.channels_last).eval()
+    model.test_cfg = cfg.test_cfg
+    model.test_cfg.update(method='vote', scale_ranges=[[0, 10000], [0, 10000]], score_thr=0.0, nms_pre=50, max_per_img=50)
+    model.bbox_head.test_cfg = model.test_cfg
+    base = torch.randn(1, 3, 288, 352, device=dev)
+    imgs, metas = [], []
+    for s in (1.0, 1.5):
+        h, w = int(288 * s) // 32 * 32, int(352 * s) // 32 * 32
+        view = torch.nn.functional.interpolate(base, size=(h, w), mode='bilinear', align_corners=False)
+        for flip in (False, True):
+            imgs.append((view.flip(-1) if flip else view).contiguous(memory_format=torch.channels_last))
+            metas.append([dict(img_shape=(h, w, 3), pad_shape=(h, w, 3), ori_shape=(288, 352, 3), flip=flip,
+                               scale_factor=np.array([w / 352, h / 288, w / 352, h / 288], dtype=np.float32))])
+    with torch.no_grad():
+        boxes, vectors = model(imgs, metas, return_loss=False, rescale=True)
+    assert len(boxes) == len(vectors) == 80
+    n = sum(b.shape[0] for b in boxes)
+    assert n > 0 and all(b.shape[1] == 5 for b in boxes) and all(v.shape[1] == 8 for v in vectors)
+    allb = np.concatenate([np.asarray(b) for b in boxes])
+    assert np.isfinite(allb).all() and (allb[:, 0] <= allb[:, 2] + 1e-3).all() and (allb[:, 1] <= allb[:, 3] + 1e-3).all()
+    assert allb[:, :4].min() >= -1e-3 and allb[:, 2].max() <= 352 + 1e-3 and allb[:, 3].max() <= 288 + 1e-3

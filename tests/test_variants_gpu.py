@@ -1,11 +1,10 @@
 """One training step of the other BASELINE configurations on the GPU: R-101-DCN bbox (config 3: DCNv2 in the backbone),
 X-101-64x4d-DCN segm (config 4: grouped DCNv2 + activation checkpointing) and the R-50 pose head, at a reduced image size and
 -- `test_full_size_*` -- at the 800 x 1344 of BASELINE.json (tile tables, 32-bit offset guards and checkpointing memory
-at the real shapes); one inference batch of config 5 (pose head, 4 images) at full size.  Res2Net-101-DCN is opt-in
-(LSNET_SLOW_TESTS=1).  Loss finite, the head's parameters move, the backbone's deformable
+at the real shapes); one inference batch of config 5 (pose head, 4 images) at full size; Res2Net-101-DCN (the headline
+53.5-AP backbone) at the reduced size.  Loss finite, the head's parameters move, the backbone's deformable
 convs receive finite gradients.  (Feature / gradient parity of these backbones against the reference:
 tests/test_golden_gpu.py::test_dcn_backbones_of_configs_3_and_4.)"""
-import os
 
 import pytest
 import torch
@@ -15,13 +14,10 @@ from lsnet_amd.model_zoo import build_lsnet
 from lsnet_amd.runner import EpochBasedRunner, build_optimizer
 
 
-SLOW = pytest.mark.skipif(os.environ.get('LSNET_SLOW_TESTS') != '1', reason='opt-in: LSNET_SLOW_TESTS=1')
-
-
 @pytest.mark.gpu
 @pytest.mark.parametrize('task,backbone', [('bbox', 'r101-dcn'), ('segm', 'x101-dcn'),
                                            ('pose_bbox', 'r50'),
-                                           pytest.param('bbox', 'res2-101-dcn', marks=SLOW)])
+                                           ('bbox', 'res2-101-dcn')])
 def test_one_training_step(task, backbone):
     dev = torch.device('cuda:0')
     torch.manual_seed(0)
