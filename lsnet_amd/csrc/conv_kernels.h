@@ -523,6 +523,7 @@ static __global__ void conv_splitk_reduce_kernel(const float *__restrict__ part,
     if (v4) {
         for (int e = (blockIdx.x * blockDim.x + threadIdx.x) * 4; e < n; e += gridDim.x * blockDim.x * 4) {
             float4 s = *reinterpret_cast<const float4 *>(part + e);
+#pragma unroll 4
             for (int z = 1; z < ks; ++z) {
                 const float4 p = *reinterpret_cast<const float4 *>(part + (size_t)z * n + e);
                 s.x += p.x, s.y += p.y, s.z += p.z, s.w += p.w;

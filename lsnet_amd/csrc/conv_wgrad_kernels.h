@@ -375,7 +375,20 @@ static __global__ void conv_wgrad_reduce_kernel(const float *__restrict__ part, 
         const bool live = e0 < n4;
         const size_t e = live ? e0 : 0;
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int z = sl; z < splits; z += LS) {
+        int z = sl;
+        // four partial tiles in flight per lane (the summation order stays z, z + LS, ...: the same bits as a rolled loop,
+        // whose every addition waited for its own load -- 8 dependent memory latencies for 32 splits under LS = 4)
+        for (; z + 3 * LS < splits; z += 4 * LS) {
+            const float4 p0 = reinterpret_cast<const float4 *>(part + (size_t)z * n)[e];
+            const float4 p1 = reinterpret_cast<const float4 *>(part + (size_t)(z + LS) * n)[e];
+            const float4 p2 = reinterpret_cast<const float4 *>(part + (size_t)(z + 2 * LS) * n)[e];
+            const float4 p3 = reinterpret_cast<const float4 *>(part + (size_t)(z + 3 * LS) * n)[e];
+            s.x += p0.x, s.y += p0.y, s.z += p0.z, s.w += p0.w;
+            s.x += p1.x, s.y += p1.y, s.z += p1.z, s.w += p1.w;
+            s.x += p2.x, s.y += p2.y, s.z += p2.z, s.w += p2.w;
+            s.x += p3.x, s.y += p3.y, s.z += p3.z, s.w += p3.w;
+        }
+        for (; z < splits; z += LS) {
             const float4 p = reinterpret_cast<const float4 *>(part + (size_t)z * n)[e];
             s.x += p.x, s.y += p.y, s.z += p.z, s.w += p.w;
         }
@@ -439,7 +452,20 @@ static __global__ __launch_bounds__(256) void conv_wgrad_reduce_bn_kernel(const 
         const bool live = e0 + el < R4;
         const size_t e = (size_t)co * R4 + (live ? e0 + el : 0);
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int z = sl; z < splits; z += LS) {
+        int z = sl;
+        // four partial tiles in flight per lane (the summation order stays z, z + LS, ...: the same bits as a rolled loop,
+        // whose every addition waited for its own load -- 8 dependent memory latencies for 32 splits under LS = 4)
+        for (; z + 3 * LS < splits; z += 4 * LS) {
+            const float4 p0 = reinterpret_cast<const float4 *>(part + (size_t)z * n)[e];
+            const float4 p1 = reinterpret_cast<const float4 *>(part + (size_t)(z + LS) * n)[e];
+            const float4 p2 = reinterpret_cast<const float4 *>(part + (size_t)(z + 2 * LS) * n)[e];
+            const float4 p3 = reinterpret_cast<const float4 *>(part + (size_t)(z + 3 * LS) * n)[e];
+            s.x += p0.x, s.y += p0.y, s.z += p0.z, s.w += p0.w;
+            s.x += p1.x, s.y += p1.y, s.z += p1.z, s.w += p1.w;
+            s.x += p2.x, s.y += p2.y, s.z += p2.z, s.w += p2.w;
+            s.x += p3.x, s.y += p3.y, s.z += p3.z, s.w += p3.w;
+        }
+        for (; z < splits; z += LS) {
             const float4 p = reinterpret_cast<const float4 *>(part + (size_t)z * n)[e];
             s.x += p.x, s.y += p.y, s.z += p.z, s.w += p.w;
         }

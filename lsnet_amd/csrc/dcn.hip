@@ -677,7 +677,7 @@ static int launch_bwd_colbuf(DcnArgs &a, GatherPlan &pl, unsigned char *ws, hipS
     pl.ga.raw = pl.aa.raw = a.mm ? 1 : 0;
     pl.ga.Hb = pl.aa.Hb = Hb;
     pl.ga.gcol = a.gcol, pl.ga.start = start, pl.ga.ent = ent;
-    if (pl.aa.ng > 0) {   // long-list groups: per-anchor sums, then four of them per pixel
+    if (pl.aa.ng > 0) {   // per-anchor sums of all four corners, then four of them per pixel
         pl.aa.gcol = a.gcol, pl.aa.start = start, pl.aa.ent = ent;
         pl.aa.S = reinterpret_cast<float *>(ws + pl.o_S);
         if (pl.na_long > 0)

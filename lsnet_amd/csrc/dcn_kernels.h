@@ -2143,6 +2143,9 @@ __global__ __launch_bounds__(256) void dcn_anchor_combine_kernel(const AnchorArg
     }
 }
 
+// (Round 4 tried the gather per PIXEL instead -- one wave per input pixel walks the lists of the four anchors it is a
+// corner of and writes grad_input straight from registers: no S round trip (0.37 GB per tower launch), each row read four
+// times (L2).  It lost: tower backward 638 vs 600 us, pyramid 2031 vs 1603 us (profiles/r4_pixel_gather.txt); removed.)
 // grad_offset / grad_mask from the corner sums Hb[sample][4] the gather pass left (kernel.cu:973-1044): one thread per
 // sample.  A corner that lies outside the map has no list entry and no sum: its flag bit selects zero.
 __global__ void dcn_offgrad_kernel(const DcnArgs a, int nsamples, const float4 *__restrict__ Hb)

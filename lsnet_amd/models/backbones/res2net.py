@@ -15,6 +15,7 @@ import torch.utils.checkpoint as cp
 
 from ...cnn import build_conv_layer, build_norm_layer, constant_init
 from ...ops.batch_norm import bn_act
+from ...ops.pool import avg_pool_nchw
 from ..builder import BACKBONES
 from .resnet import Bottleneck, ResNet, _shortcut
 
@@ -60,7 +61,7 @@ class Bottle2neck(Bottleneck):
             parts.append(sp)
         last = spx[self.scales - 1]
         if not (self.stage_type == 'normal' or self.conv2_stride == 1):
-            last = self.pool(last)
+            last = avg_pool_nchw(last, self.pool)    # (ops/pool.py: ATen's channels-last backward is wrong on this stack)
         out = torch.cat(parts + [last], 1)
         return bn_act(self.norm3, self.conv3(out), relu=True, residual=_shortcut(self.downsample, x))
 

@@ -15,6 +15,7 @@ from ...cnn import build_conv_layer, build_norm_layer, constant_init, kaiming_in
 from ...ops.batch_norm import bn_act
 from ...ops import resblock
 from ...ops.conv import conv_bn_act, conv_bn_act_frozen
+from ...ops.pool import avg_pool_nchw
 from ..builder import BACKBONES
 
 
@@ -38,7 +39,7 @@ def _shortcut(downsample, x):
     mods = list(downsample)
     if isinstance(mods[-1], _BatchNorm):
         for m in mods[:-2]:
-            x = m(x)
+            x = avg_pool_nchw(x, m) if isinstance(m, nn.AvgPool2d) else m(x)   # (avg_down shortcuts: ops/pool.py)
         if len(mods) >= 2:
             return _conv_bn(mods[-2], mods[-1], x, relu=False)
         return bn_act(mods[-1], x, relu=False)
@@ -272,7 +273,7 @@ class ResNet(nn.Module):
                 constant_init(m, 1)
         if self.dcn is not None:
             for m in self.modules():
-                if isinstance(m, Bottleneck) and hasattr(m.conv2, 'conv_offset'):
+                if isinstance(m, Bottleneck) and hasattr(getattr(m, 'conv2', None), 'conv_offset'):   # (Bottle2neck: `convs`)
                     constant_init(m.conv2.conv_offset, 0)
         if self.zero_init_residual:
             for m in self.modules():

@@ -81,12 +81,16 @@ def test_training_curve_follows_reference_runner(math):
     iteration 8, where the loss has fallen to 1.25) in another with different deformable kernels: the late half of THIS
     fixture measures chaos, not kernels, and only has to stay within a factor of two (tolerance 1.0; 0.5 left the 0.32 of
     that run a margin of 1.5 in a suite the driver runs with -x).  What holds all twelve iterations tight is
-    `test_training_curve_low_learning_rate` below."""
+    `test_training_curve_low_learning_rate` below.
+    Round 4: the fixture was regenerated with the tie-free parameter fill (golden_util.fill_params) and is no longer the
+    475 -> 1 collapse: the loss goes 2.41 -> 1.29 and the trajectory stays tame.  Measured (profiles/r4_gpu_tests.log,
+    fp32-equivalent mode): total loss <= 9.1e-5 over iterations 1 - 6 and <= 6.7e-3 over 7 - 12; the refine term (where one
+    re-assigned point shows) 9.3e-4 / 1.8e-2.  Tolerances: early 3e-3 (5e-3 in the 3-product mode), late 0.1 (round 3: 1.0)."""
     from lsnet_amd import _lib
     before = _lib.get_math_mode()
     _lib.set_math_mode(math)
     try:
-        worst = gc.train_curve_case(_dev(), early_tol=5e-3 if math == 'bf16x3' else 7.5e-4, late_tol=1.0, rtol_weight=5e-2, channels_last=True)
+        worst = gc.train_curve_case(_dev(), early_tol=5e-3 if math == 'bf16x3' else 3e-3, late_tol=0.1, rtol_weight=5e-2, channels_last=True)
     finally:
         _lib.set_math_mode(before)
     print(math, f'worst relative loss deviation {worst:.2e}')
@@ -189,5 +193,7 @@ def test_aug_test_vote_on_the_device():
     n = sum(b.shape[0] for b in boxes)
     assert n > 0 and all(b.shape[1] == 5 for b in boxes) and all(v.shape[1] == 8 for v in vectors)
     allb = np.concatenate([np.asarray(b) for b in boxes])
-    assert np.isfinite(allb).all() and (allb[:, 0] <= allb[:, 2] + 1e-3).all() and (allb[:, 1] <= allb[:, 3] + 1e-3).all()
-    assert allb[:, :4].min() >= -1e-3 and allb[:, 2].max() <= 352 + 1e-3 and allb[:, 3].max() <= 288 + 1e-3
+    # (random weights: a "box" of the untrained head may have its corners in any order; what is checked is that every
+    # view's detections came back in the ORIGINAL image's frame -- inside 352 x 288 after rescaling and un-flipping)
+    assert np.isfinite(allb).all()
+    assert allb[:, :4].min() >= -1e-2 and allb[:, [0, 2]].max() <= 352 + 1e-2 and allb[:, [1, 3]].max() <= 288 + 1e-2

@@ -80,6 +80,12 @@ DCN_CASES = [
     dict(name='x101_l2_s2', C=512, Co=512, groups=64, stride=2, hw=(50, 84), bias=False),
     dict(name='x101_l3', C=1024, Co=1024, groups=64, hw=(13, 21), bias=False),
     dict(name='x101_l4', C=2048, Co=2048, groups=64, hw=(7, 11), bias=False),
+    # Res2Net-50/101 26w x 4s (the headline 53.5-AP backbone): per-scale widths 52 / 104 / 208, the first block of a stage
+    # with stride 2 (round 4: the backbone's gradient fixture localised a device-only error to these calls)
+    dict(name='r2_l2_s2', C=52, Co=52, stride=2, hw=(24, 32), bias=False),
+    dict(name='r2_l3_s2', C=104, Co=104, stride=2, hw=(12, 16), bias=False),
+    dict(name='r2_l4_s2', C=208, Co=208, stride=2, hw=(6, 8), bias=False),
+    dict(name='r2_l4', C=208, Co=208, hw=(3, 4), bias=False),
 ]
 
 
@@ -435,6 +441,10 @@ CONV_CASES = [
     (1, 256, 256, 1, 1, 0, 1, 184, 180, True),    # >= 512 tiles of 64 px x 256 channels: the 64x256 configuration
     (2, 256, 27, 3, 1, 1, 1, 100, 168, True),     # conv_offset at the P3 size: its data gradient reduces over 27 channels
                                                   # into 256 (unaligned slabs, which the 64x256 configuration lacks)
+    (2, 256, 27, 3, 2, 1, 1, 26, 42, True),       # conv_offset of a STRIDED DCNv2 pack (first block of a DCN stage)
+    (1, 208, 27, 3, 2, 1, 1, 6, 8, True),         # ... at the Res2Net per-scale widths
+    (1, 104, 27, 3, 2, 1, 1, 12, 16, True),
+    (1, 52, 27, 3, 2, 1, 1, 24, 32, True),
 ]
 
 
@@ -921,3 +931,25 @@ def test_gather_backward_is_deterministic():
     c = _dcn_all(ops, x, w, b, off, mask, go, cfg, dev)
     for k in ('out', 'gx', 'goff', 'gmask'):
         assert torch.equal(a[k], c[k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('k,s,p,ceil,cip', [(3, 2, 1, False, True), (2, 2, 0, True, False)])
+def test_avg_pool_backward(k, s, p, ceil, cip):
+    """ops/pool.py: the Res2Net pools (Bottle2neck's 3x3 stride-2 pool of the last scale, res2net.py:80-99; the avg_down
+    shortcut's 2x2 ceil-mode pool, :213-231) on a strided channel slice of a channels-last tensor against the host, forward
+    and backward.  (ATen's own channels-last backward is off by 0.68 of the range for the first configuration on this
+    stack -- which is why these run through the NCHW kernels.)"""
+    from lsnet_amd.ops.pool import avg_pool_nchw
+    torch.manual_seed(0)
+    pool = torch.nn.AvgPool2d(k, s, p, ceil_mode=ceil, count_include_pad=cip)
+    x = torch.randn(2, 832, 13, 17)
+    xh = x.clone().requires_grad_()
+    yh = pool(xh[:, 624:])
+    go = torch.randn_like(yh)
+    yh.backward(go)
+    xd = x.to(_dev()).contiguous(memory_format=torch.channels_last).requires_grad_()
+    yd = avg_pool_nchw(xd[:, 624:], pool)
+    yd.backward(go.to(_dev()).contiguous(memory_format=torch.channels_last))
+    assert torch.allclose(yd.cpu(), yh.detach(), rtol=1e-6, atol=1e-6)
+    assert torch.allclose(xd.grad.cpu(), xh.grad, rtol=1e-6, atol=1e-6)
