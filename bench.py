@@ -254,6 +254,25 @@ def infer_leg(dev):
                 ms_per_batch=dt * 1e3, img_per_s=B / dt, detections_img0=int(dets[0][0].shape[0]))
 
 
+def config_leg(dev, task, backbone, n=3, warm=2):
+    """Another BASELINE config through the same step (runner hooks, gradient arena, clip, SGD) at 2 x 3x800x1344:
+    config 4 = X-101-64x4d-DCN segm (grouped DCNv2 in c3-c5, 36-landmark polygon head, activation checkpointing)."""
+    from lsnet_amd.data import synthetic_batch
+    from lsnet_amd.model_zoo import build_lsnet
+    from lsnet_amd.parallel import DataParallelModel
+    torch.manual_seed(0)
+    model, cfg = build_lsnet(task, backbone)
+    model = DataParallelModel(model.to(dev).to(memory_format=torch.channels_last).train())
+    step, _ = build_step(model, cfg)
+    data = synthetic_batch(task, 2, 800, 1344, seed=1234, device=dev, channels_last=True)
+    dt = timed_steps(step, data, n, warm)
+    out = dict(metric=f'img/s train LSNet {backbone.upper()} {task}, 2 x 3x800x1344', value=2 / dt, unit='img/s',
+               ms_per_step=dt * 1e3, steps=n)
+    del model, step, data
+    torch.cuda.empty_cache()
+    return out
+
+
 def timed_steps(step, data, n, warm):
     for _ in range(warm):
         step(data)
@@ -465,6 +484,10 @@ def main():
             extra['infer_pose_bs4'] = infer_leg(dev)
         except Exception as ex:   # an extra leg must never take the bench line down
             extra['infer_pose_bs4'] = {'error': f'{type(ex).__name__}: {ex}'}
+        try:
+            extra['config4_segm_x101_dcn'] = config_leg(dev, 'segm', 'x101-dcn')
+        except Exception as ex:
+            extra['config4_segm_x101_dcn'] = {'error': f'{type(ex).__name__}: {ex}'}
 
     if rank == 0:
         imgs = args.batch * world * args.steps

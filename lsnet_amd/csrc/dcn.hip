@@ -425,9 +425,28 @@ static bool bwd_x3_ok(const DcnArgs &a)
     return true;
 }
 
+static bool bwd_colbuf_env()
+{
+    return !((g_dbg_block >> 23) & 1);   // bit 23 of the debug word forces the atomic scatter kernels (tests)
+}
+
+// grouped calls (config 4: 64 groups) on the atomic-free path: dcn_gcol_grouped_kernel in front of the gather pass.  Every
+// math mode (the kernel is exact fp32); levels that want offset / mask gradients must want grad_input (anchor lists).
+static bool bwd_grouped_ok(const DcnArgs &a)
+{
+    if (a.groups <= 1 || a.C % a.groups != 0 || a.Co % a.groups != 0 || (a.C / a.groups) % 4 != 0 || a.C % a.dg != 0) return false;
+    if ((a.C / a.dg) % 4 != 0 || !bwd_colbuf_env()) return false;
+    for (int i = 0; i < a.nlv; ++i) {
+        if ((a.lv[i].goff || a.lv[i].gmsk) && !a.lv[i].gx) return false;
+        if ((int64_t)a.lv[i].B * a.lv[i].H * a.lv[i].W * a.C * 4 >= ((int64_t)1 << 31)) return false;
+    }
+    return true;
+}
+
 // the atomic-free path (column gradients + gather): served by the dense GEMM (mm_bwd_ok: any Co) or by round 2's GEMM
 static bool bwd_gather_ok(const DcnArgs &a)
 {
+    if (bwd_grouped_ok(a)) return true;
     if (a.wtp == nullptr) return false;
     if (bwd_x3_ok(a)) return true;
     if (!mm_bwd_ok(a)) return false;
@@ -548,7 +567,7 @@ static void gather_plan(DcnArgs &a, GatherPlan &pl)
     {
         // anchor path: every group when the unweighted-GEMM pipeline serves the call (its corner sums are cheapest per
         // anchor), otherwise the groups above the threshold.  Long-list groups first: they get four waves per anchor.
-        const bool all_anchor = mm_bwd_ok(a);
+        const bool all_anchor = mm_bwd_ok(a) || bwd_grouped_ok(a);
         GatherGrp keep[MAXLV];
         bool to_anchor[MAXLV], is_long[MAXLV];
         int nk = 0;
@@ -610,10 +629,6 @@ static void gather_plan(DcnArgs &a, GatherPlan &pl)
     pl.ok = true;
 }
 
-static bool bwd_colbuf_env()
-{
-    return !((g_dbg_block >> 23) & 1);   // bit 23 of the debug word forces the atomic scatter kernels (tests)
-}
 
 // Tap groups of the split backward-data GEMM (grid.y): the launch runs in ceil(tiles x groups / 512) rounds of the 512
 // resident blocks (2 per CU) with blocks 1 / groups as long, plus a per-block prologue (gout tile -> registers, sampling
@@ -655,7 +670,14 @@ static int launch_bwd_colbuf(DcnArgs &a, GatherPlan &pl, unsigned char *ws, hipS
     hipLaunchKernelGGL(dcn_sort_lists_kernel, dim3(sort_blocks), dim3(256), 0, st, pl.nanchors, start, ent,
                        reinterpret_cast<GEntry *>(ws + pl.o_ent2));
     float *Hb = nullptr;
-    if (a.mm) {   // the dense kernel writes the unweighted column gradients; everything else happens in the gather pass
+    const bool grouped = a.groups > 1;
+    if (grouped) {   // exact-fp32 column gradients per group, unweighted; the gather pass does the rest as for the dense GEMM
+        const long long nquads = (long long)pl.nsamples / a.dg * (a.C / 4);
+        const int blocks = (int)((nquads + 255) / 256 < 16384 ? (nquads + 255) / 256 : 16384);
+        hipLaunchKernelGGL(dcn_gcol_grouped_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, st, a, nquads);
+        for (int i = 0; i < a.nlv; ++i)
+            if (a.lv[i].goff || a.lv[i].gmsk) Hb = reinterpret_cast<float *>(ws + pl.o_H);
+    } else if (a.mm) {   // the dense kernel writes the unweighted column gradients; everything else happens in the gather pass
         const float *xs[MAXLV];
         float *outs[MAXLV];
         int rows[MAXLV];
@@ -674,7 +696,7 @@ static int launch_bwd_colbuf(DcnArgs &a, GatherPlan &pl, unsigned char *ws, hipS
         if (int rc = set_lds(dcn_bwd_data_xn_kernel<NP, true>, lds)) return rc;
         hipLaunchKernelGGL((dcn_bwd_data_xn_kernel<NP, true>), dim3(a.ntiles, bwd_tap_groups(a)), dim3(256), lds, st, a);
     }
-    pl.ga.raw = pl.aa.raw = a.mm ? 1 : 0;
+    pl.ga.raw = pl.aa.raw = (a.mm || grouped) ? 1 : 0;
     pl.ga.Hb = pl.aa.Hb = Hb;
     pl.ga.gcol = a.gcol, pl.ga.start = start, pl.ga.ent = ent;
     if (pl.aa.ng > 0) {   // per-anchor sums of all four corners, then four of them per pixel
@@ -707,12 +729,12 @@ static int launch_bwd_data(DcnArgs &a, void *gather_ws, size_t gather_ws_bytes, 
 {
     ProfScope prof(PROF_BWD_DATA, a, st);
     const int np = math_np();
-    if ((a.mm || bwd_x3_ok(a)) && gather_ws && bwd_colbuf_env()) {
+    if ((a.mm || bwd_x3_ok(a) || bwd_grouped_ok(a)) && gather_ws && bwd_colbuf_env()) {
         GatherPlan pl;
         gather_plan(a, pl);
         if (pl.ok && pl.bytes <= gather_ws_bytes)
-            return np == 6 ? launch_bwd_colbuf<6>(a, pl, reinterpret_cast<unsigned char *>(gather_ws), st)
-                           : launch_bwd_colbuf<3>(a, pl, reinterpret_cast<unsigned char *>(gather_ws), st);
+            return np == 3 ? launch_bwd_colbuf<3>(a, pl, reinterpret_cast<unsigned char *>(gather_ws), st)
+                           : launch_bwd_colbuf<6>(a, pl, reinterpret_cast<unsigned char *>(gather_ws), st);
     }
     if (a.mm) return fail(LSN_ERR_RUNTIME, "deformable backward: fragment-order weights without the gather path");
     a.gcol = nullptr, a.gtap = nullptr;
@@ -1010,7 +1032,7 @@ static int dcn_backward_impl(const lsn_dcn_shape &s, int n, const lsn_dcn_level 
         if (can_split) a.wtp = reinterpret_cast<const unsigned short *>(s.workspace);   // (format: decided below)
         void *gws = s.gather_workspace;
         size_t gws_bytes = (size_t)(s.gather_workspace_bytes > 0 ? s.gather_workspace_bytes : 0);
-        if (!gws && layout == LSN_NCHW && a.wtp && bwd_colbuf_env()) {   // reference-layout entry points: own scratch
+        if (!gws && layout == LSN_NCHW && (a.wtp || bwd_grouped_ok(a)) && bwd_colbuf_env()) {   // reference-layout entry points: own scratch
             GatherPlan pl;
             DcnArgs probe = a;
             gather_plan(probe, pl);
@@ -1252,11 +1274,12 @@ int lsn_version(void) { return 100; }
 int64_t lsn_dcn_backward_workspace_bytes(const lsn_dcn_shape *shape, int n_levels, const lsn_dcn_level *levels)
 {
     using namespace lsn;
-    if (!shape || !levels || math_np() == 0 || shape->groups != 1 || !bwd_colbuf_env()) return 0;
+    if (!shape || !levels || !bwd_colbuf_env()) return 0;
+    if (shape->groups == 1 && math_np() == 0) return 0;   // (exact mode, dense: the fp32-MFMA scatter kernels)
     if (check_shape(*shape) != 0) return 0;
     DcnArgs a;
     if (fill_levels(a, *shape, n_levels, levels, BWD_BM) != 0) return 0;
-    for (int i = 0; i < n_levels; ++i) a.lv[i].gx = levels[i].grad_input;
+    for (int i = 0; i < n_levels; ++i) a.lv[i].gx = levels[i].grad_input, a.lv[i].goff = levels[i].grad_offset, a.lv[i].gmsk = levels[i].grad_mask;
     a.wtp = reinterpret_cast<const unsigned short *>(shape);   // any non-NULL value: the caller passes `workspace` too
     if (!bwd_gather_ok(a)) return 0;
     GatherPlan pl;

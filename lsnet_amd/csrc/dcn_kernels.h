@@ -1708,6 +1708,35 @@ __device__ __forceinline__ const Lvl &find_level_by_row(const DcnArgs &a, int pr
     return a.lv[li];
 }
 
+// Column gradients of a GROUPED deformable convolution (ResNeXt-101 64x4d-DCN, BASELINE config 4: 64 groups of 8 / 16 /
+// 32 channels; resnext.py:11-83 + deform_conv_cuda.cpp:747-748 per group):
+//   gcol[(prow, k)][c] = sum_{j < Co / groups} gout[prow][g Cog + j] * w[g Cog + j][k][c - g Cg],   g = c / Cg
+// -- UNWEIGHTED, for the gather pass above (anchor lists, per-anchor corner sums, offset / mask gradients from the same
+// rows), which serves grouped calls with this kernel in front instead of the dense GEMM.  Per group the product is 8 ..
+// 32 wide: 1/16 .. 1 of one MFMA tile and 0.5 .. 2 MAC per gathered byte, so exact fp32 fmaf chains on the vector ALUs
+// (reference arithmetic, every math mode); the launch is bound by writing gcol.  Replaces round 1's atomic scatter for
+// these calls: grad_input of config 4 is bit-reproducible.  A thread = four consecutive channels of one (pixel, tap) row.
+__global__ __launch_bounds__(256) void dcn_gcol_grouped_kernel(const DcnArgs a, long long nquads)
+{
+    const int K = a.kh * a.kw, C = a.C, Cg = C / a.groups, Cog = a.Co / a.groups, C4 = C >> 2;
+    for (long long id = blockIdx.x * (long long)blockDim.x + threadIdx.x; id < nquads; id += (long long)gridDim.x * blockDim.x) {
+        const long long row = id / C4;                  // (launch-wide pixel row, tap)
+        const int c = (int)(id - row * C4) * 4;
+        const int prow = (int)(row / K), k = (int)(row - (long long)prow * K);
+        const Lvl &L = find_level_by_row(a, prow);
+        const int g = c / Cg, ci = c - g * Cg;
+        const float *go = L.gout + (size_t)(prow - L.prow0) * a.Co + (size_t)g * Cog;
+        const float *w = a.w + ((size_t)g * Cog * K + k) * Cg + ci;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < Cog; ++j) {
+            const float gv = go[j];
+            const float4 wv = *reinterpret_cast<const float4 *>(w + (size_t)j * K * Cg);
+            s.x = fmaf(gv, wv.x, s.x), s.y = fmaf(gv, wv.y, s.y), s.z = fmaf(gv, wv.z, s.z), s.w = fmaf(gv, wv.w, s.w);
+        }
+        *reinterpret_cast<float4 *>(a.gcol + (size_t)row * C + c) = s;
+    }
+}
+
 // one thread per sample: anchor, rank inside the anchor's list, fractions
 // (Walking the samples tap-major like the table -- coalesced 32-byte stores, the integer atomics of a wave spread over 64
 // neighbouring anchors -- measured no difference in the round-4 A/B: 604.9 vs 607.0 us per tower backward.)

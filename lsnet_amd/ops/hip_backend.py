@@ -203,8 +203,11 @@ class HipBackend:
         if cfg['groups'] == 1 and _lib.split_math():
             ws = torch.empty(2 * w.numel(), device=w.device, dtype=torch.float32)   # split + transposed weight planes
             shape.workspace = ws.data_ptr()
+        if cfg['groups'] > 1 or _lib.split_math():
+            # column-gradient buffer + anchor lists of the atomic-free grad_input path (dense: split-bf16 modes; grouped
+            # calls -- ResNeXt-DCN, config 4 -- in every mode: their column gradients are exact fp32)
             nbytes = int(lib.lsn_dcn_backward_workspace_bytes(ctypes.byref(shape), n, levels))
-            if nbytes > 0:   # column-gradient buffer + anchor lists of the atomic-free grad_input path
+            if nbytes > 0:
                 gws = torch.empty(nbytes, device=w.device, dtype=torch.uint8)
                 shape.gather_workspace, shape.gather_workspace_bytes = gws.data_ptr(), nbytes
         sinks = need.get('sinks') if (nhwc and w is weight) else None

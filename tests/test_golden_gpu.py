@@ -58,7 +58,7 @@ def test_dcn_backbones_of_configs_3_and_4(name, channels_last):
     try:
         # measured (profiles/r2_gpu_tests.log): R-101-DCN 4.9e-6 of the range in every sampled element; X-101-64x4d-DCN
         # 1.8e-3 (0.3 % of the input-gradient samples beyond 1e-3: ReLU kinks of a 101-layer grouped network)
-        gc.backbone_dcn_case(name, _dev(), channels_last, grad_rtol=1e-4 if name == 'r101-dcn' else 6e-3, outliers=0.0)
+        gc.backbone_dcn_case(name, _dev(), channels_last, grad_rtol=1e-4 if name == 'r101-dcn' else 3e-3, outliers=0.0)
     finally:
         print(name, 'channels_last' if channels_last else 'contiguous', gu.stats_report())
 

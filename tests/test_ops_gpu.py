@@ -934,6 +934,27 @@ def test_gather_backward_is_deterministic():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('mode', ['bf16x6', 'fp32'])
+def test_grouped_backward_is_deterministic(mode):
+    """BASELINE config 4 (ResNeXt-101 64x4d-DCN: 64 groups): grad_input / grad_offset / grad_mask through
+    dcn_gcol_grouped_kernel + the anchor-list gather -- no atomics, in EVERY math mode (round 3: fp32 atomic scatter):
+    two runs are bitwise equal."""
+    from lsnet_amd import _lib, ops
+    dev = _dev()
+    before = _lib.get_math_mode()
+    _lib.set_math_mode(mode)
+    try:
+        case = dict(name='det_g64', C=512, Co=512, groups=64, stride=2, hw=(50, 84), bias=False)
+        x, w, b, off, mask, go, cfg = _make(case, dev, seed=4)
+        a = _dcn_all(ops, x, w, b, off, mask, go, cfg, dev)
+        c = _dcn_all(ops, x, w, b, off, mask, go, cfg, dev)
+        for k in ('out', 'gx', 'goff', 'gmask'):
+            assert torch.equal(a[k], c[k]), k
+    finally:
+        _lib.set_math_mode(before)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('k,s,p,ceil,cip', [(3, 2, 1, False, True), (2, 2, 0, True, False)])
 def test_avg_pool_backward(k, s, p, ceil, cip):
     """ops/pool.py: the Res2Net pools (Bottle2neck's 3x3 stride-2 pool of the last scale, res2net.py:80-99; the avg_down

@@ -86,7 +86,7 @@ def test_full_size_pose_inference_batch():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('task,backbone', [('bbox', 'r50'), ('bbox', 'r101-dcn')])
+@pytest.mark.parametrize('task,backbone', [('bbox', 'r50'), ('bbox', 'r101-dcn'), ('segm', 'x101-dcn')])
 def test_training_step_is_bit_reproducible(task, backbone):
     """The same model, the same batch, twice: the loss and EVERY parameter gradient must come back with the same bits.
     What it takes: anchor lists sorted by sample id whatever their length, split partial tiles +
