@@ -162,19 +162,13 @@ class HipBackend:
     def dcn_backward(self, inputs, offsets, masks, weight, grad_outs, cfg, need):
         """need: dict(input=[bool]*n, offset=[bool]*n, mask=[bool]*n, weight=bool, bias=bool).
         Returns (grad_inputs, grad_offsets, grad_masks, grad_weight, grad_bias)."""
-        lib = _lib.load()
         nhwc, xs, offs, msks, w = self._prep(inputs, offsets, masks, weight)
         n = len(xs)
-        shape = self._shape(w, cfg)
-        levels = (_lib.DcnLevel * n)()
-        gxs, goffs, gmsks, keep = [], [], [], []
+        gos = [(g.contiguous(memory_format=_CL) if nhwc else g.contiguous()) for g in grad_outs]
+        gxs, goffs, gmsks = [], [], []
         shared = {}   # levels sampling ONE source map (pyramid op) accumulate into one grad_input buffer
+        bufs = []     # per level: the grad_input buffer the kernels write (shared ones appear several times)
         for i in range(n):
-            B, C, H, W = xs[i].shape
-            go = grad_outs[i]
-            go = go.contiguous(memory_format=_CL) if nhwc else go.contiguous()
-            keep.append(go)
-            Ho, Wo = go.shape[2], go.shape[3]
             gx = gx_ret = None
             if need['input'][i]:
                 key = (xs[i].data_ptr(), tuple(xs[i].shape)) if nhwc else i
@@ -183,9 +177,35 @@ class HipBackend:
                 else:
                     gx = gx_ret = shared[key] = torch.empty_like(xs[i])
             want_om = need['offset'][i] or (msks[i] is not None and need['mask'][i])
-            goff = torch.empty_like(offs[i]) if want_om else None
-            gmsk = torch.empty_like(msks[i]) if (want_om and msks[i] is not None) else None
-            gxs.append(gx_ret); goffs.append(goff); gmsks.append(gmsk)
+            goffs.append(torch.empty_like(offs[i]) if want_om else None)
+            gmsks.append(torch.empty_like(msks[i]) if (want_om and msks[i] is not None) else None)
+            gxs.append(gx_ret)
+            bufs.append(gx)
+        sinks = need.get('sinks') if (nhwc and w is weight) else None
+        if sinks is not None:     # accumulate into the caller's gradient arena (ops/grad_sink.py)
+            gw, gb = sinks
+            acc = 1
+            need['sunk'] = True
+        else:
+            gw = torch.empty_like(w) if (need['weight'] or need['bias']) else None
+            gb = torch.empty(w.shape[0], device=w.device, dtype=torch.float32) if need['bias'] else None
+            acc = 0
+        # (One call per image -- the column gradients of ONE image of a tower launch, 207 MB, fit the 256 MB Infinity Cache,
+        # those of the batch, 413 MB, do not -- was measured SLOWER: deformable backward-data 7.6 vs 6.8 ms per step,
+        # profiles/r4_per_image.txt: half-size launches lose more to their tails than the cache returns.)
+        self._dcn_backward_call(xs, offs, msks, w, gos, bufs, goffs, gmsks, gw, gb, acc, cfg, nhwc)
+        return gxs, goffs, gmsks, gw, gb
+
+    def _dcn_backward_call(self, xs, offs, msks, w, gos, gx_bufs, goffs, gmsks, gw, gb, accumulate, cfg, nhwc):
+        """One lsn_dcn_backward call over the given (level) tensors; every output buffer is the caller's."""
+        lib = _lib.load()
+        n = len(xs)
+        shape = self._shape(w, cfg)
+        levels = (_lib.DcnLevel * n)()
+        for i in range(n):
+            B, C, H, W = xs[i].shape
+            go, gx, goff, gmsk = gos[i], gx_bufs[i], goffs[i], gmsks[i]
+            Ho, Wo = go.shape[2], go.shape[3]
             L = levels[i]
             L.input, L.offset, L.mask = _ptr(xs[i]), _ptr(offs[i]), _ptr(msks[i])
             L.grad_output, L.grad_input, L.grad_offset, L.grad_mask = _ptr(go), _ptr(gx), _ptr(goff), _ptr(gmsk)
@@ -210,17 +230,9 @@ class HipBackend:
             if nbytes > 0:
                 gws = torch.empty(nbytes, device=w.device, dtype=torch.uint8)
                 shape.gather_workspace, shape.gather_workspace_bytes = gws.data_ptr(), nbytes
-        sinks = need.get('sinks') if (nhwc and w is weight) else None
-        if sinks is not None:     # accumulate into the caller's gradient arena (ops/grad_sink.py)
-            gw, gb = sinks
-            shape.accumulate_param_grads = 1
-            need['sunk'] = True
-        else:
-            gw = torch.empty_like(w) if (need['weight'] or need['bias']) else None
-            gb = torch.empty(w.shape[0], device=w.device, dtype=torch.float32) if need['bias'] else None
+        shape.accumulate_param_grads = 1 if accumulate else 0
         _lib.check(lib.lsn_dcn_backward(ctypes.byref(shape), n, levels, _ptr(w), _ptr(gw), _ptr(gb),
                                         1 if nhwc else 0, _stream()))
-        return gxs, goffs, gmsks, gw, gb
 
     # ------------------------------------------------------------------ sigmoid focal loss
     def focal_forward(self, logits, targets, gamma, alpha):
