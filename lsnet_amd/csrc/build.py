@@ -18,6 +18,18 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-ffp
          '-fno-slp-vectorize', '-Wno-unused-result']
 
 
+def kernel_signature():
+    """sha-256 (16 hex digits) over the sources of the deformable / dense kernel families: the counter files under profiles/
+    carry the signature of the library they were measured on, and bench.py reports `roofline.traffic` only while it still
+    matches (a counter reading of other kernels is not a measurement of these)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ('common.h', 'conv_kernels.h', 'conv_wgrad_kernels.h', 'conv.hip', 'dcn_kernels.h', 'dcn_mm_kernels.h', 'dcn.hip'):
+        with open(os.path.join(HERE, f), 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def _hipcc():
     for c in (shutil.which('hipcc'), '/opt/rocm/bin/hipcc'):
         if c and os.path.exists(c):

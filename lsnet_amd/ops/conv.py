@@ -363,74 +363,98 @@ def hip_group_conv_ok(x, weight, stride, padding, dilation, groups, padding_mode
     return x.numel() < 2 ** 31 and Co * x.shape[0] * x.shape[2] * x.shape[3] < 2 ** 31
 
 
+def conv_multi_fwd(xs, w, bias, pad, dil, relu):
+    """[conv2d(x, w, bias, 1, pad, dil) for x in xs] in ONE launch (channels-last device tensors; no autograd)."""
+    Co, C, kh, kw = w.shape
+    n = len(xs)
+    levels = (_lib.ConvLevel * n)()
+    outs = []
+    for i, x in enumerate(xs):
+        B, _, H, W = x.shape
+        Ho, Wo = H + 2 * pad - (dil * (kh - 1) + 1) + 1, W + 2 * pad - (dil * (kw - 1) + 1) + 1
+        out = torch.empty((B, Co, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=_CL)
+        outs.append(out)
+        L = levels[i]
+        L.x, L.out, L.B, L.H, L.W = _p(x), _p(out), B, H, W
+    _lib.check(_lib.load().lsn_conv2d_forward_prepared(n, levels, _p(weight_image(w, 0)), _p(bias), C, C, Co, kh, kw, 1, pad, dil,
+                                                       1 if relu else 0, _stream()))
+    return outs
+
+
+def conv_multi_dgrad(gos, w, xs, pad, dil, accumulate_into=None):
+    """Data gradients of conv_multi_fwd for every map in ONE launch.  accumulate_into: per-map tensors of the inputs' shape
+    that already hold another path's gradient of the same input -- the results are ADDED to them in the epilogue of the
+    launch (lsn_conv_level.residual aliasing out) and they are returned."""
+    Co, C, kh, kw = w.shape
+    n = len(xs)
+    w8, Co8, gos8 = w, Co, gos
+    if Co % 4 and C <= 64:    # (narrow tiles read grad_output in 4-channel pieces: zero filters are free)
+        Co8 = (Co + 3) // 4 * 4
+        gos8 = [_pad_channels(g, Co8) for g in gos]
+        w8 = w.new_zeros((Co8, C, kh, kw)).contiguous(memory_format=_CL)
+        w8[:Co] = w
+    levels = (_lib.ConvLevel * n)()
+    gxs = []
+    for i, x in enumerate(xs):
+        gx = accumulate_into[i] if accumulate_into is not None else torch.empty_like(x, memory_format=_CL)
+        gxs.append(gx)
+        L = levels[i]
+        L.x, L.out, L.B, L.H, L.W = _p(gos8[i]), _p(gx), x.shape[0], x.shape[2], x.shape[3]
+        if accumulate_into is not None:
+            L.residual = _p(gx)
+    _lib.check(_lib.load().lsn_conv2d_backward_data_prepared(n, levels, _p(weight_image(w8, 1, 1, pad, dil)), C, Co8, kh, kw, 1,
+                                                             pad, dil, _stream()))
+    return gxs
+
+
+def conv_multi_wgrad(xs, gos, w, bias, pad, dil, want_w=True, want_b=True):
+    """Weight / bias gradient summed over the maps in ONE launch; into the parameters' gradient sinks when they have them
+    (then (None, None) goes back to autograd)."""
+    Co, C, kh, kw = w.shape
+    n = len(xs)
+    levels = (_lib.ConvLevel * n)()
+    for i, x in enumerate(xs):
+        L = levels[i]
+        L.x, L.grad_out, L.B, L.H, L.W = _p(x), _p(gos[i]), x.shape[0], x.shape[2], x.shape[3]
+    want_b = want_b and bias is not None
+    gw, gb, acc = _param_grad_buffers(w, bias if want_b else None, want_w, want_b)
+    _lib.check(_lib.load().lsn_conv2d_backward_weight_multi(n, levels, _p(gw), _p(gb), C, Co, kh, kw, 1, pad, dil, acc, _stream()))
+    return _param_grad_results(w, bias if want_b else None, gw, gb, acc, want_w)
+
+
 class _ConvMultiFn(torch.autograd.Function):
     """Several input maps of different sizes under ONE weight (the FPN levels of LSHead's shared convolutions):
     forward, data gradients and the weight / bias gradient (summed over the maps) in one launch each.  Stride 1."""
 
     @staticmethod
     def forward(ctx, w, bias, cfg, *xs):
-        lib = _lib.load()
         pad, dil, relu = cfg
-        Co, C, kh, kw = w.shape
         w = w.contiguous(memory_format=_CL)
-        n = len(xs)
-        levels = (_lib.ConvLevel * n)()
-        outs = []
-        for i, x in enumerate(xs):
-            B, _, H, W = x.shape
-            Ho, Wo = H + 2 * pad - (dil * (kh - 1) + 1) + 1, W + 2 * pad - (dil * (kw - 1) + 1) + 1
-            out = torch.empty((B, Co, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=_CL)
-            outs.append(out)
-            L = levels[i]
-            L.x, L.out, L.B, L.H, L.W = _p(x), _p(out), B, H, W
-        _lib.check(lib.lsn_conv2d_forward_prepared(n, levels, _p(weight_image(w, 0)), _p(bias), C, C, Co, kh, kw, 1, pad,
-                                                   dil, 1 if relu else 0, _stream()))
+        outs = conv_multi_fwd(xs, w, bias, pad, dil, relu)
         ctx.save_for_backward(w, *xs, *(outs if relu else []))
-        ctx.cfg, ctx.n, ctx.has_bias = cfg, n, bias is not None
+        ctx.cfg, ctx.n, ctx.has_bias = cfg, len(xs), bias is not None
         ctx.bias_ref = bias
         return tuple(outs)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, *gos):
-        lib = _lib.load()
         pad, dil, relu = ctx.cfg
         n = ctx.n
         saved = ctx.saved_tensors
         w, xs = saved[0], saved[1:1 + n]
         outs = saved[1 + n:] if relu else None
-        Co, C, kh, kw = w.shape
         gos = [g.contiguous(memory_format=_CL) for g in gos]
         if relu:
             gos = [relu_gate(g, o) if o.numel() % 4 == 0 else g * (o > 0) for g, o in zip(gos, outs)]
         need_x = [ctx.needs_input_grad[3 + i] for i in range(n)]
         gxs = [None] * n
         if any(need_x):
-            w8, Co8, gos8 = w, Co, gos
-            if Co % 4 and C <= 64:
-                Co8 = (Co + 3) // 4 * 4
-                gos8 = [_pad_channels(g, Co8) for g in gos]
-                w8 = w.new_zeros((Co8, C, kh, kw)).contiguous(memory_format=_CL)
-                w8[:Co] = w
-            levels = (_lib.ConvLevel * n)()
-            for i, x in enumerate(xs):
-                gxs[i] = torch.empty_like(x, memory_format=_CL)
-                L = levels[i]
-                L.x, L.out, L.B, L.H, L.W = _p(gos8[i]), _p(gxs[i]), x.shape[0], x.shape[2], x.shape[3]
-            _lib.check(lib.lsn_conv2d_backward_data_prepared(n, levels, _p(weight_image(w8, 1, 1, pad, dil)), C, Co8, kh, kw,
-                                                             1, pad, dil, _stream()))
-            gxs = [g if need else None for g, need in zip(gxs, need_x)]
+            gxs = [g if need else None for g, need in zip(conv_multi_dgrad(gos, w, xs, pad, dil), need_x)]
         gw = gb = None
         if ctx.needs_input_grad[0] or (ctx.has_bias and ctx.needs_input_grad[1]):
-            levels = (_lib.ConvLevel * n)()
-            for i, x in enumerate(xs):
-                L = levels[i]
-                L.x, L.grad_out, L.B, L.H, L.W = _p(x), _p(gos[i]), x.shape[0], x.shape[2], x.shape[3]
-            want_b = ctx.has_bias and ctx.needs_input_grad[1]
-            gw, gb, acc = _param_grad_buffers(w, ctx.bias_ref if want_b else None, ctx.needs_input_grad[0], want_b)
-            _lib.check(lib.lsn_conv2d_backward_weight_multi(n, levels, _p(gw), _p(gb), C, Co, kh, kw, 1, pad, dil, acc,
-                                                            _stream()))
-            gw, gb = _param_grad_results(w, ctx.bias_ref if want_b else None, gw, gb, acc, ctx.needs_input_grad[0])
+            gw, gb = conv_multi_wgrad(xs, gos, w, ctx.bias_ref, pad, dil, ctx.needs_input_grad[0],
+                                      ctx.has_bias and ctx.needs_input_grad[1])
         return (gw, gb, None, *gxs)
 
 

@@ -5,8 +5,11 @@ step_shapes.py replays (tower launch, pyramid launch) pairs, so the dispatches o
 tower, ...; a step has 6 tower and 2 pyramid launches of each family: mean launch = (6 tower + 2 pyramid) / 8.
 Units and corrections (MI355X_MICROARCH.md, HBM section): rocprofv3 reports both counters in KiB; on gfx950 FETCH_SIZE
 tallies the 128-byte requests of wide coalesced reads at 64 bytes, so it is DOUBLED; WRITE_SIZE is taken as reported."""
-import csv, glob, json, sys
+import csv, glob, json, os, sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from lsnet_amd.csrc.build import kernel_signature  # noqa: E402
 
 fetch_dir, write_dir, out_json = sys.argv[1:4]
 math = sys.argv[4] if len(sys.argv) > 4 else 'bf16x6'
@@ -83,7 +86,7 @@ for name in sorted(set(fetch) | set(write)):
         fam[fa]['tower'][1] += wt * KIB
         fam[fa]['pyramid'][0] += fp * KIB
         fam[fa]['pyramid'][1] += wp * KIB
-res = {'math': math, 'source': 'tools/pmc_step_shapes.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over '
+res = {'math': math, 'kernel_signature': kernel_signature(), 'source': 'tools/pmc_step_shapes.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over '
                                'tools/step_shapes.py; FETCH_SIZE x 2 (gfx950), KiB -> bytes', 'kernels': {}}
 for fa, d in fam.items():
     t, p = sum(d['tower']), sum(d['pyramid'])
@@ -93,7 +96,7 @@ for fa, d in fam.items():
         'tower_fetch_write_gb': [round(v, 4) for v in d['tower']], 'pyramid_fetch_write_gb': [round(v, 4) for v in d['pyramid']],
         'note': f'rocprofv3 FETCH_SIZE x2 + WRITE_SIZE over all kernels of the family; tower launch (5 levels, 52.8 GFLOP) '
                 f'{t:.3f} GB, pyramid launch (15 pairs, 158.5 GFLOP) {p:.3f} GB, step mean (6 tower + 2 pyramid) / 8; '
-                f'profiles/r3_pmc_hbm.txt'}
+                f'profiles/{os.path.basename(out_json).split("_")[0]}_pmc_hbm.txt'}
     print(f'{fa}: tower {t:.3f} GB (fetch {d["tower"][0]:.3f} + write {d["tower"][1]:.3f}), pyramid {p:.3f} GB '
           f'(fetch {d["pyramid"][0]:.3f} + write {d["pyramid"][1]:.3f}); mean launch of the step {mean:.3f} GB')
 json.dump(res, open(out_json, 'w'), indent=1)

@@ -1,8 +1,7 @@
-// Forward and data gradient of every dense-convolution shape of the benchmark step (tools/bench_convs.py SH; B = 2,
+// Forward and data gradient of every dense-convolution shape of the benchmark step (B = 2,
 // 800 x 1344) through the C ABI with prepared weight images -- no torch, the binary starts in a second.  Per shape: time
 // per launch (HIP events), TFLOP/s, and the results checked against a double-precision sum on the host for sampled
-// elements; at the end the sums weighted by the shape's count in one step.  The tile / split choices of conv.hip can be
-// forced per process (LSNET_CONV_TILE=1|2|5, LSNET_CONV_KSPLIT=n): one run per setting is a sweep.
+// elements; at the end the sums weighted by the shape's count in one step.
 //   hipcc --offload-arch=gfx950 -O2 tools/ubench/conv_step.hip -o tools/ubench/conv_step -ldl
 //   tools/ubench/conv_step [reps]
 #include <hip/hip_runtime.h>
