@@ -312,6 +312,17 @@ def iteration0_parity(args, iter0):
             'loss_ref_rel_err': max(abs(iter0[k] - want[k]) / abs(want[k]) for k in keys)}
 
 
+def flush_c_stdio():
+    """RCCL writes its version banner with C stdio (fully buffered when stdout is a file: it would surface at process
+    exit, AFTER the JSON line).  Everything buffered so far goes out now, so that the JSON line stays the last line."""
+    import ctypes
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
 def allreduce_probe(model, dev, world, reps=5):
     """Stand-alone time of one gradient all-reduce of the step (all buckets, back to back, nothing to overlap with)."""
     flats = [b['flat'] for b in model.reducer.buckets]
@@ -452,6 +463,7 @@ def main():
             gs._fwd_bwd(data)
         ks = timer.stop()
     comm = allreduce_probe(model, dev, world) if world > 1 else None
+    flush_c_stdio()   # (the communicators exist by now: RCCL's banner, if any, is out before the JSON line)
     comm1 = None
     if world == 1 and not args.no_extra:
         # the same buckets through a ONE-rank RCCL group: what a stand-alone gradient all-reduce of this step costs on this
@@ -467,6 +479,7 @@ def main():
             comm1 = allreduce_probe(model, dev, 1)
             comm1['rccl_ranks'] = dist.get_world_size()
             dist.destroy_process_group()
+            flush_c_stdio()
         except Exception as ex:   # must never take the bench line down
             comm1 = {'allreduce_ms_per_step_standalone': None, 'error': f'{type(ex).__name__}: {ex}'}
 
@@ -577,9 +590,12 @@ def main():
             except Exception as ex:   # the baseline must never take the bench line down
                 res['cpu_baseline'] = {'value': None, 'unit': 'img/s', 'cores': 0, 'kind': 'port',
                                        'sample': f'failed: {type(ex).__name__}: {ex}'}
-        print(json.dumps(res))
+        flush_c_stdio()
+        print(json.dumps(res), flush=True)
     if world > 1:
+        flush_c_stdio()
         dist.destroy_process_group()
+        flush_c_stdio()
 
 
 if __name__ == '__main__':
