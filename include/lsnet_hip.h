@@ -82,6 +82,13 @@ typedef struct {
     int64_t gather_workspace_bytes;  /* (>= lsn_dcn_backward_workspace_bytes()); NULL / too small: fp32 atomics.   */
     int accumulate_param_grads;      /* lsn_dcn_backward: 1 = ADD grad_weight / grad_bias to the buffers' contents (see
                                       * lsn_conv2d_backward_weight), 0 = overwrite */
+    int out_pitch;                   /* LSN_NHWC only: floats from one pixel of `output` (forward) / `grad_output`
+                                      * (backward) to the next, for every level; 0 = Co (dense).  With Co < out_pitch the
+                                      * levels' outputs are channel slices of wider tensors: LSHead concatenates the three
+                                      * maps a level gathers from its neighbours (lsnet_head.py:640-647) -- the op writes them
+                                      * side by side and reads their gradient where the next convolution left it, no
+                                      * concatenation or slice copy in between.  Served by the matrix-pipe kernels only:
+                                      * ask lsn_dcn_pitched_ok() first, the calls fail with LSN_ERR_UNSUPPORTED otherwise. */
 } lsn_dcn_shape;
 
 /* One (source map, offset field, output) triple of a batched launch.  All levels of a launch
@@ -141,6 +148,9 @@ int lsn_dcn_backward(const lsn_dcn_shape *shape, int n_levels, const lsn_dcn_lev
  * grad_offset, grad_mask, grad_weight, grad_bias -- is free of floating-point atomics in the split-bf16 math modes
  * (groups = 1): bit-identical run to run. */
 int64_t lsn_dcn_backward_workspace_bytes(const lsn_dcn_shape *shape, int n_levels, const lsn_dcn_level *levels);
+/* 1 when lsn_dcn_forward (backward == 0) / lsn_dcn_backward (backward != 0) would serve this call with
+ * shape->out_pitch != Co in the current math mode (shape->workspace / gather_workspace as they will be passed), else 0. */
+int lsn_dcn_pitched_ok(const lsn_dcn_shape *shape, int n_levels, const lsn_dcn_level *levels, int backward);
 
 /* ---- one-to-one replacements of the reference extension's functions ----------------------- */
 /* Each takes contiguous NCHW tensors like the reference and the same scalar arguments in the
@@ -220,6 +230,16 @@ int lsn_sigmoid_focal_loss_sum(const float *logits, const int64_t *targets, cons
 int lsn_sigmoid_focal_loss_backward_weighted(const float *logits, const int64_t *targets,
                                              const float *weight, const float *scale, float *d_logits,
                                              int N, int C, float gamma, float alpha, lsn_stream_t stream);
+
+/* ---- k nearest per column: centroid_assigner.py:74, atss_assigner.py:103-111 ----------------- */
+/* x: row-major (P, G) matrix on the device, row pitch ldx floats (the assigners' points x gts distance matrix).  For
+ * every column g and every row segment s = [seg_start[s], seg_start[s] + seg_len[s]) (host arrays, 1 <= nseg <= 8,
+ * seg_len >= k) the k smallest (largest != 0: largest) entries, in that order, equal values by ascending row:
+ *   values[(s * k + r) * G + g], indices[(s * k + r) * G + g] (row index in [0, P), int64)
+ * -- `torch.topk(x[start:start + n], k, dim=0, largest=False)` of every segment in one launch (the reference calls it
+ * once per FPN level and image; NaN orders as the largest value, as in torch).  [fused: replaces ATen's topk] */
+int lsn_topk_columns(const float *x, int P, int G, int ldx, int nseg, const int *seg_start, const int *seg_len, int k,
+                     int largest, float *values, int64_t *indices, lsn_stream_t stream);
 
 /* ---- NMS: nms_ext.cpp:18-29 ---------------------------------------------------------------- */
 /* dets (n,5) = x1,y1,x2,y2,score on the device.  keep (capacity n, int64, device) receives the

@@ -24,7 +24,8 @@ class DcnShape(ctypes.Structure):
                 ('dil', ctypes.c_int), ('groups', ctypes.c_int), ('deformable_groups', ctypes.c_int),
                 ('scale_h', ctypes.c_float), ('scale_w', ctypes.c_float), ('mask_is_logit', ctypes.c_int),
                 ('workspace', ctypes.c_void_p), ('gather_workspace', ctypes.c_void_p),
-                ('gather_workspace_bytes', ctypes.c_int64), ('accumulate_param_grads', ctypes.c_int)]
+                ('gather_workspace_bytes', ctypes.c_int64), ('accumulate_param_grads', ctypes.c_int),
+                ('out_pitch', ctypes.c_int)]
 
 
 class DcnLevel(ctypes.Structure):
@@ -62,14 +63,14 @@ class ProfEntry(ctypes.Structure):
 
 # every symbol include/lsnet_hip.h declares (checked by tests/test_capi.py without a GPU)
 EXPORTS = [
-    'lsn_last_error', 'lsn_version', 'lsn_dcn_forward', 'lsn_dcn_backward', 'lsn_dcn_backward_workspace_bytes',
+    'lsn_last_error', 'lsn_version', 'lsn_dcn_forward', 'lsn_dcn_backward', 'lsn_dcn_backward_workspace_bytes', 'lsn_dcn_pitched_ok',
     'lsn_deform_conv_forward', 'lsn_deform_conv_backward_input', 'lsn_deform_conv_backward_parameters',
     'lsn_modulated_deform_conv_forward', 'lsn_modulated_deform_conv_backward',
     'lsn_pyramid_deform_conv_forward', 'lsn_pyramid_deform_conv_backward_input',
     'lsn_pyramid_deform_conv_backward_parameters',
     'lsn_sigmoid_focal_loss_forward', 'lsn_sigmoid_focal_loss_backward', 'lsn_sigmoid_focal_loss_sum',
     'lsn_sigmoid_focal_loss_backward_weighted',
-    'lsn_nms_workspace_bytes', 'lsn_nms', 'lsn_selftest_mfma', 'lsn_debug_phase_clocks',
+    'lsn_nms_workspace_bytes', 'lsn_nms', 'lsn_topk_columns', 'lsn_selftest_mfma', 'lsn_debug_phase_clocks',
     'lsn_prof_enable', 'lsn_prof_read',
     'lsn_group_norm_workspace_bytes', 'lsn_group_norm_forward', 'lsn_group_norm_backward',
     'lsn_set_math_mode', 'lsn_get_math_mode', 'lsn_conv2d_forward', 'lsn_conv2d_forward_pitched', 'lsn_conv2d_backward_data',

@@ -74,6 +74,25 @@ class AssignResult:
         return len(self.gt_inds)
 
 
+def topk_columns(x, k, segments=None, largest=False):
+    """(values, indices), both (nseg * k, G): for every row segment (start, n) of the (P, G) matrix `x` what
+    `x[start:start + n].topk(k, dim=0, largest=largest)` returns, indices counted from row 0 of `x` -- the per-level
+    candidate search of the assigners (atss_assigner.py:103-111, centroid_assigner.py:74).  On the device all segments
+    are one launch of lsn_topk_columns (ATen runs one single-block radix select per column and call); elsewhere torch."""
+    if segments is None:
+        segments = [(0, x.shape[0])]
+    if x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and len(segments) <= 8 and x.shape[1] > 0 \
+            and all(n >= k for _, n in segments):
+        from ..ops.backend import get_backend
+        return get_backend(x).topk_columns(x, k, [s for s, _ in segments], [n for _, n in segments], largest)
+    vals, idxs = [], []
+    for start, n in segments:
+        v, i = x[start:start + n].topk(k, dim=0, largest=largest)
+        vals.append(v)
+        idxs.append(i + start)
+    return torch.cat(vals, dim=0), torch.cat(idxs, dim=0)
+
+
 def _labels_of(gt_inds, gt_labels):
     if gt_labels is None:
         return None
@@ -112,7 +131,7 @@ class CentroidAssigner:
         gt_lvl = torch.clamp(gt_lvl, min=lvl_min, max=lvl_max)
         dist = ((xy[:, None, :] - centers[None, :, :]) / wh[None, :, :]).norm(dim=2)
         dist = torch.where(lvl[:, None] != gt_lvl[None, :], INF, dist)
-        near_d, near_i = torch.topk(dist, self.pos_num, dim=0, largest=False)
+        near_d, near_i = topk_columns(dist, self.pos_num)
         claimed = torch.full_like(dist, INF).scatter_(0, near_i, near_d)
         best_d, best_gt = claimed.min(dim=1)
         gt_inds = torch.where(best_d != INF, best_gt + 1, 0)
@@ -247,12 +266,11 @@ class ATSSAssigner:
         box_c = torch.stack((cx, cy), dim=1)
         dist = (box_c[:, None, :] - gt_c[None, :, :]).pow(2).sum(-1).sqrt()
 
-        cand, start = [], 0
+        segments, start = [], 0
         for n in num_level_bboxes:  # k nearest per level and gt
-            _, idx = dist[start:start + n, :].topk(self.topk, dim=0, largest=False)
-            cand.append(idx + start)
+            segments.append((start, n))
             start += n
-        cand = torch.cat(cand, dim=0)                                           # (L*k, G)
+        _, cand = topk_columns(dist, self.topk, segments)                       # (L*k, G)
         gcol = torch.arange(num_gt, device=bboxes.device)
         cand_iou = overlaps[cand, gcol]
         thr = cand_iou.mean(0) + cand_iou.std(0)

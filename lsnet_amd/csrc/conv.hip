@@ -157,10 +157,10 @@ static int conv_forward(ConvArgs &a, hipStream_t st)
 // dcn.hip: out_i[r][0 .. N) = x_i[r][0 .. Cr) . Wt for row blocks i (the backward-data GEMM of the deformable
 // convolutions: a 1x1 convolution of grad_output whose N = K * C output columns are the column gradients); wf = the
 // fragment image of the (N, 1, Cr) GEMM view.  No profiling span of its own: it runs inside the caller's.
-int conv_mm_rows(int n, const float *const *x, float *const *out, const int *rows, int Cr, int N, const unsigned short *wf,
-                 hipStream_t st)
+int conv_mm_rows(int n, const float *const *x, float *const *out, const int *rows, int Cr, int xpitch, int N,
+                 const unsigned short *wf, hipStream_t st)
 {
-    LSN_CHECK(n >= 1 && n <= CV_MAXLV && Cr % 4 == 0, "conv_mm_rows: bad arguments");
+    LSN_CHECK(n >= 1 && n <= CV_MAXLV && Cr % 4 == 0 && xpitch % 4 == 0 && xpitch >= Cr, "conv_mm_rows: bad arguments");
     ConvArgs a = {};
     a.nlv = n;
     for (int i = 0; i < n; ++i) {
@@ -171,7 +171,7 @@ int conv_mm_rows(int n, const float *const *x, float *const *out, const int *row
     a.wf = wf;
     a.wf_bytes = (int)cv_wfrag_bytes(N, 1, Cr, conv_npl());
     a.C = Cr, a.Co = N, a.kh = a.kw = 1, a.stride = 1, a.pad_h = a.pad_w = 0, a.dil = 1;
-    a.xpitch = Cr;
+    a.xpitch = xpitch;
     if (N % 256 == 0) {   // the 64 x 256 tile with whole-line stores (conv_kernels.h TRANS); plain output, one split
 #ifdef LSNET_AB
         return conv_forward(a, st);

@@ -161,6 +161,8 @@ static int check_shape(const lsn_dcn_shape &s)
     if (s.kh * s.kw * s.deformable_groups > 64)
         return fail(LSN_ERR_UNSUPPORTED, "kh*kw*deformable_groups = %d > 64 is not supported",
                     s.kh * s.kw * s.deformable_groups);
+    LSN_CHECK(s.out_pitch == 0 || (s.out_pitch >= s.Co && s.out_pitch % 4 == 0),
+              "out_pitch %d: 0 or a multiple of 4 >= Co = %d", s.out_pitch, s.Co);
     return 0;
 }
 
@@ -220,6 +222,7 @@ static int fill_levels(DcnArgs &a, const lsn_dcn_shape &s, int n, const lsn_dcn_
     a.gtap_rows = 0;
     a.wg_vec = 0;
     a.mm = 0;
+    a.opitch = s.out_pitch > 0 ? s.out_pitch : s.Co;
     a.wtp_bytes = 0;
     a.wg_part = a.wg_part_b = nullptr;
     a.dbg = g_dbg_buf;
@@ -248,7 +251,7 @@ static bool mm_common_ok(const DcnArgs &a)
     if (math_np() == 0 || a.groups != 1 || a.dg < 1 || a.C % a.dg != 0 || !dcn_mm_env()) return false;
     for (int i = 0; i < a.nlv; ++i) {   // 32-bit buffer offsets
         if ((int64_t)a.lv[i].B * a.lv[i].H * a.lv[i].W * a.C * 4 >= ((int64_t)1 << 31)) return false;
-        if ((int64_t)a.lv[i].P * a.Co * 4 >= ((int64_t)1 << 31)) return false;
+        if ((int64_t)a.lv[i].P * a.opitch * 4 >= ((int64_t)1 << 31)) return false;
     }
     return true;
 }
@@ -265,8 +268,8 @@ static bool mm_fwd_ok(const DcnArgs &a)
 // backward-data GEMM as a 1x1 convolution (conv.hip conv_mm_rows) + corner sums in the gather pass: every level that
 // wants offset / mask gradients must also want grad_input (its samples are then on the anchor lists); the fragment image
 // has to fit the caller's weight workspace (8 bytes per weight element, include/lsnet_hip.h)
-int conv_mm_rows(int n, const float *const *x, float *const *out, const int *rows, int Cr, int N, const unsigned short *wf,
-                 hipStream_t st);
+int conv_mm_rows(int n, const float *const *x, float *const *out, const int *rows, int Cr, int xpitch, int N,
+                 const unsigned short *wf, hipStream_t st);
 static bool mm_bwd_ok(const DcnArgs &a)
 {
     if (!mm_common_ok(a) || a.C % 4 != 0 || a.Co % 4 != 0) return false;
@@ -647,8 +650,48 @@ static int bwd_tap_groups(const DcnArgs &a)
     return best;
 }
 
+// A second stream per launch stream for the list building of the backward-data path.  bin -> scan -> fill -> sort are
+// latency-bound kernels of a few thousand short workgroups (50 - 60 us each on the tower launch, 0.1 - 0.2 of the chip's
+// wave slots busy) that depend on the offsets only; the column-gradient GEMM beside them depends on grad_output only and
+// leaves ~100 VGPRs per SIMD and 110 KB of LDS per CU free.  Fork after the workspace is known, join before the
+// per-anchor sums.  (Not the same experiment as the weight gradients on a side stream, profiles/r4_side_stream.txt: two
+// MFMA kernels take the matrix pipe from each other; these kernels wait on memory while the GEMM computes.)
+// (The TAIL of the path -- per-anchor sums, combine, offset gradients -- on this stream beside the weight-gradient pass of the
+// same call was tried as well, profiles/r4_side_lists.txt: nothing on the tower launch, 995 vs 992 us per backward call (the
+// gathers take the CUs from the weight gradient's workgroups instead of sharing them), -120 us on the pyramid launch,
+// 0.25 ms per step -- and two kernel families that can no longer be timed apart.  Removed.)
+struct SideStream {
+    hipStream_t main = nullptr, side = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+static SideStream g_side[16];
+static int g_nside = 0;
+static int side_stream(hipStream_t st, SideStream **out)
+{
+    for (int i = 0; i < g_nside; ++i)
+        if (g_side[i].main == st) {
+            *out = &g_side[i];
+            return 0;
+        }
+    if (g_nside == 16) return fail(LSN_ERR_RUNTIME, "side streams: more than 16 streams use the library");
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+        return fail(LSN_ERR_RUNTIME, "side stream would be created inside a stream capture: run the step eagerly once before capturing");
+    SideStream &S = g_side[g_nside];
+    int lo = 0, hi = 0;
+    LSN_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));   // hi = the numerically lowest = most urgent
+    LSN_HIP(hipStreamCreateWithPriority(&S.side, hipStreamNonBlocking, hi));
+    LSN_HIP(hipEventCreateWithFlags(&S.fork, hipEventDisableTiming));
+    LSN_HIP(hipEventCreateWithFlags(&S.join, hipEventDisableTiming));
+    S.main = st;
+    ++g_nside;
+    *out = &S;
+    return 0;
+}
+static bool side_lists_env() { return !((g_dbg_block >> 21) & 1); }   // debug bit 21: lists on the launch stream (A/B)
+
 template <int NP>
-static int launch_bwd_colbuf(DcnArgs &a, GatherPlan &pl, unsigned char *ws, hipStream_t st)
+static int launch_bwd_colbuf(DcnArgs &a, GatherPlan &pl, unsigned char *ws, hipStream_t st_main)
 {
     a.gcol = reinterpret_cast<float *>(ws + pl.o_gcol);
     int *cnt = reinterpret_cast<int *>(ws + pl.o_cnt), *start = reinterpret_cast<int *>(ws + pl.o_start);
@@ -657,6 +700,15 @@ static int launch_bwd_colbuf(DcnArgs &a, GatherPlan &pl, unsigned char *ws, hipS
     GEntry *ent = reinterpret_cast<GEntry *>(ws + pl.o_ent);
     Tap *gtap = reinterpret_cast<Tap *>(ws + pl.o_gtap);   // also read by the GEMM below and by the weight-gradient pass
     a.gtap_rows = pl.nsamples / (a.kh * a.kw * a.dg);
+    // lists on the side stream only beside the dense GEMM (the other column-gradient kernels read the tap table)
+    SideStream *side = nullptr;
+    if (a.mm && a.groups == 1 && side_lists_env())
+        if (int rc = side_stream(st_main, &side)) return rc;
+    hipStream_t st = side ? side->side : st_main;
+    if (side) {
+        LSN_HIP(hipEventRecord(side->fork, st_main));
+        LSN_HIP(hipStreamWaitEvent(side->side, side->fork, 0));
+    }
     LSN_HIP(hipMemsetAsync(cnt, 0, ((size_t)pl.nanchors + 1) * sizeof(int), st));
     hipLaunchKernelGGL(dcn_bin_kernel, dim3(cdiv(pl.nsamples, 256)), dim3(256), 0, st, a, pl.nsamples, cnt, sanchor, srank, sfrac,
                        gtap);
@@ -669,6 +721,10 @@ static int launch_bwd_colbuf(DcnArgs &a, GatherPlan &pl, unsigned char *ws, hipS
     if (sort_blocks > 4096) sort_blocks = 4096;
     hipLaunchKernelGGL(dcn_sort_lists_kernel, dim3(sort_blocks), dim3(256), 0, st, pl.nanchors, start, ent,
                        reinterpret_cast<GEntry *>(ws + pl.o_ent2));
+    if (side) {
+        LSN_HIP(hipEventRecord(side->join, side->side));
+        st = st_main;
+    }
     float *Hb = nullptr;
     const bool grouped = a.groups > 1;
     if (grouped) {   // exact-fp32 column gradients per group, unweighted; the gather pass does the rest as for the dense GEMM
@@ -688,7 +744,8 @@ static int launch_bwd_colbuf(DcnArgs &a, GatherPlan &pl, unsigned char *ws, hipS
             rows[i] = a.lv[i].P;
             any_off = any_off || a.lv[i].goff || a.lv[i].gmsk;
         }
-        if (int rc = conv_mm_rows(a.nlv, xs, outs, rows, a.Co, a.kh * a.kw * a.C, a.wtp, st)) return rc;
+        if (int rc = conv_mm_rows(a.nlv, xs, outs, rows, a.Co, a.opitch, a.kh * a.kw * a.C, a.wtp, st)) return rc;
+        if (side) LSN_HIP(hipStreamWaitEvent(st_main, side->join, 0));
         if (any_off) Hb = reinterpret_cast<float *>(ws + pl.o_H);
     } else {
         size_t lds = bwd_xn_lds_bytes(NP, a.kh * a.kw * a.dg);
@@ -732,9 +789,11 @@ static int launch_bwd_data(DcnArgs &a, void *gather_ws, size_t gather_ws_bytes, 
     if ((a.mm || bwd_x3_ok(a) || bwd_grouped_ok(a)) && gather_ws && bwd_colbuf_env()) {
         GatherPlan pl;
         gather_plan(a, pl);
-        if (pl.ok && pl.bytes <= gather_ws_bytes)
-            return np == 3 ? launch_bwd_colbuf<3>(a, pl, reinterpret_cast<unsigned char *>(gather_ws), st)
-                           : launch_bwd_colbuf<6>(a, pl, reinterpret_cast<unsigned char *>(gather_ws), st);
+        if (pl.ok && pl.bytes <= gather_ws_bytes) {
+            const int rc = np == 3 ? launch_bwd_colbuf<3>(a, pl, reinterpret_cast<unsigned char *>(gather_ws), st)
+                                   : launch_bwd_colbuf<6>(a, pl, reinterpret_cast<unsigned char *>(gather_ws), st);
+            return rc;
+        }
     }
     if (a.mm) return fail(LSN_ERR_RUNTIME, "deformable backward: fragment-order weights without the gather path");
     a.gcol = nullptr, a.gtap = nullptr;
@@ -862,6 +921,8 @@ static int launch_wgrad(const DcnArgs &a_in, int nsteps, bool accumulate, hipStr
         const int rc = launch_wgrad_mm(a_in, nsteps, accumulate, st);
         if (rc != 1) return rc;   // 1: not served (sizes), fall through
     }
+    if (a_in.opitch != a_in.Co)
+        return fail(LSN_ERR_UNSUPPORTED, "deformable weight gradient: out_pitch outside the fragment-order kernel");
     DcnArgs a = a_in;
     a.wg_vec = wgrad_vec_bits(a);
     if ((reinterpret_cast<uintptr_t>(a.gtap) & 15) != 0) a.gtap = nullptr;
@@ -954,6 +1015,9 @@ static int dcn_forward_impl(const lsn_dcn_shape &s, int n, const lsn_dcn_level *
     }
     a.bias = bias;
     a.wtp = nullptr;
+    if (a.opitch != a.Co && !(layout == LSN_NHWC && s.workspace && mm_fwd_ok(a)))
+        return fail(LSN_ERR_UNSUPPORTED, "deformable forward: out_pitch %d != Co %d outside the matrix-pipe kernels "
+                    "(lsn_dcn_pitched_ok)", a.opitch, a.Co);
     if (s.workspace && mm_fwd_ok(a)) {
         if (int rc = mm_prepare_weights(a, false, s.workspace, st)) return rc;
     } else if (s.workspace && math_np() && (Cg % 8 == 0) && a.Co / a.groups > 64 && pipe_ok(a)) {
@@ -1045,6 +1109,9 @@ static int dcn_backward_impl(const lsn_dcn_shape &s, int n, const lsn_dcn_level 
             gather_plan(probe, pl);
             mm = pl.ok && pl.bytes <= gws_bytes;
         }
+        if (a.opitch != a.Co && !(mm && layout == LSN_NHWC))
+            return fail(LSN_ERR_UNSUPPORTED, "deformable backward: out_pitch %d != Co %d outside the matrix-pipe kernels "
+                        "(lsn_dcn_pitched_ok)", a.opitch, a.Co);
         if (mm) {
             if (int rc = mm_prepare_weights(a, true, s.workspace, st)) return rc;
         } else if (can_split) {
@@ -1056,6 +1123,8 @@ static int dcn_backward_impl(const lsn_dcn_shape &s, int n, const lsn_dcn_level 
                                    reinterpret_cast<unsigned short *>(s.workspace), s.Co, K, s.C);
         }
         if (int rc = launch_bwd_data(a, gws, gws_bytes, st)) return rc;
+    } else if (a.opitch != a.Co) {
+        return fail(LSN_ERR_UNSUPPORTED, "deformable backward: out_pitch without a data-gradient pass");
     }
     if (a.gw) {
         DcnArgs w = a;  // same levels, step (32-pixel) indexing
@@ -1204,6 +1273,7 @@ static int conv_wgrad_dense_mm(int n, const lsn_conv_level *lv, float *gw, float
     a.nlv = n;
     a.C = C, a.Co = Co, a.kh = kh, a.kw = kw, a.stride = stride, a.pad = pad, a.dil = dil, a.groups = 1, a.dg = 1;
     a.SL = C;
+    a.opitch = Co;
     a.gw = gw, a.gb = gb;
     if (!mm_common_ok(a) || chunks < 8) return 1;
     double px = 0, in_el = 0;
@@ -1242,6 +1312,7 @@ static int conv_wgrad_xn(int n, const lsn_conv_level *lv, float *gw, float *gb, 
     a.nlv = n;
     a.C = C, a.Co = Co, a.kh = kh, a.kw = kw, a.stride = stride, a.pad = pad, a.dil = dil, a.groups = 1, a.dg = 1;
     a.SL = C;
+    a.opitch = Co;
     a.gw = gw, a.gb = gb;
     a.wg_vec = wgrad_vec_bits(a);
     const int K = kh * kw;
@@ -1285,6 +1356,31 @@ int64_t lsn_dcn_backward_workspace_bytes(const lsn_dcn_shape *shape, int n_level
     GatherPlan pl;
     gather_plan(a, pl);
     return pl.ok ? (int64_t)pl.bytes : 0;
+}
+
+int lsn_dcn_pitched_ok(const lsn_dcn_shape *shape, int n_levels, const lsn_dcn_level *levels, int backward)
+{
+    using namespace lsn;
+    if (!shape || !levels || !shape->workspace || check_shape(*shape) != 0) return 0;
+    DcnArgs a;
+    if (fill_levels(a, *shape, n_levels, levels, backward ? BWD_BM : 64) != 0) return 0;
+    if (!backward) return mm_fwd_ok(a) ? 1 : 0;
+    bool any_data = false;
+    for (int i = 0; i < n_levels; ++i) {
+        a.lv[i].gx = levels[i].grad_input, a.lv[i].goff = levels[i].grad_offset, a.lv[i].gmsk = levels[i].grad_mask;
+        any_data = any_data || levels[i].grad_input || levels[i].grad_offset || levels[i].grad_mask;
+    }
+    a.wtp = reinterpret_cast<const unsigned short *>(shape->workspace);
+    if (!any_data || !shape->gather_workspace || !bwd_colbuf_env() || a.Co % 2 != 0) return 0;
+    if (!mm_bwd_ok(a) || !bwd_gather_ok(a)) return 0;
+    GatherPlan pl;
+    gather_plan(a, pl);
+    if (!pl.ok || (int64_t)pl.bytes > shape->gather_workspace_bytes) return 0;
+    // the weight gradient on the fragment-order kernel (launch_wgrad_mm)
+    if (a.Co % 256 != 0 || (a.C / a.dg) % 64 != 0) return 0;
+    int64_t steps = 0;
+    for (int i = 0; i < n_levels; ++i) steps += cdiv(a.lv[i].P, WG_BP);
+    return steps * 2 * (a.Co / 32) * mm_npl() * 1024 < ((int64_t)1 << 31) ? 1 : 0;
 }
 
 int lsn_set_math_mode(int mode)

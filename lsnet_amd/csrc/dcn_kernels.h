@@ -54,6 +54,7 @@ struct DcnArgs {
     float *wg_part, *wg_part_b;   // weight gradient (dcn_wgrad_xn_kernel): per-pixel-split partial gradients [split][Co K Cg] and
                                   // [split][Co], added up by conv_wgrad_reduce_kernel in a fixed order; NULL: fp32 atomics into gw
     int mm;                   // a.wtp is in MFMA fragment order (conv_wfrag_kernel) for the kernels of dcn_mm_kernels.h
+    int opitch;               // floats per pixel of out / gout (>= Co; the kernels of dcn_mm_kernels.h and conv_mm_rows only)
     int wtp_bytes;
     long long *dbg;  // optional phase timestamps of block `dbg_block`, wave 0 (lsn_debug_phase_clocks)
     int dbg_block;

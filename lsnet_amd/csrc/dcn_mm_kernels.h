@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_mm_kernel(const DcnArgs a, con
     for (int i = 0; i < TM; ++i) {
         const int pix = tile_p + wm * TM * 32 + i * 32 + (lane & 31);
         if (pix >= L.P) continue;
-        float *orow = L.out + (size_t)pix * a.Co;
+        float *orow = L.out + (size_t)pix * a.opitch;
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256) void dcn_gout_frag_kernel(const DcnArgs a, int
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int pp = p0 + e;
-            v[e] = pp < L.P ? L.gout[(size_t)pp * a.Co + co] : 0.f;
+            v[e] = pp < L.P ? L.gout[(size_t)pp * a.opitch + co] : 0.f;
             bsum += v[e];
         }
         unsigned pl[4][NPL];

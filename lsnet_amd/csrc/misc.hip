@@ -224,6 +224,74 @@ __global__ void selftest16_kernel(const float *A, const float *B, float *D, int 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// The k smallest (or largest) entries of every COLUMN of a row-major (P, G) matrix, per row segment: what
+// `torch.topk(dist[start:start + n], k, dim=0, largest=False)` returns for the assigners' (points x gts) distance
+// matrices (centroid_assigner.py:74, atss_assigner.py:103-111) -- there as one single-block radix select per column and
+// call (37 - 100 us each, 12 calls per step); here one workgroup per (column, segment), all segments in one launch.
+// A column segment is read once into LDS as order-preserving 32-bit keys (NaN above everything, as torch orders it);
+// k rounds of a workgroup-wide minimum over (key, row) pairs then emit the entries in ascending order, equal values in
+// ascending row order (torch leaves the order of equal values unspecified).
+// ---------------------------------------------------------------------------------------------
+struct TopkSegs {
+    int start[8], len[8];
+};
+
+__device__ __forceinline__ unsigned topk_key(float v, bool largest)
+{
+    unsigned u = __float_as_uint(v);
+    u = (v != v) ? 0xffffffffu                                       // NaN: the largest value, as torch orders it
+                 : ((u & 0x80000000u) ? ~u : (u | 0x80000000u));     // ascending float order as unsigned order
+    return largest ? ~u : u;
+}
+
+__global__ __launch_bounds__(256) void topk_cols_kernel(const float *__restrict__ x, int ldx, int G, TopkSegs segs, int k, int largest,
+                                                        float *__restrict__ vals, long long *__restrict__ idx, int cap)
+{
+    extern __shared__ unsigned keys[];      // min(len, cap) keys of the segment's column
+    __shared__ unsigned long long red[4];
+    const int g = blockIdx.x, sg = blockIdx.y;
+    const int start = segs.start[sg], n = segs.len[sg];
+    const int tid = threadIdx.x;
+    const float *col = x + (size_t)start * ldx + g;
+    const int nc = n < cap ? n : cap;
+    for (int i = tid; i < nc; i += 256) keys[i] = topk_key(col[(size_t)i * ldx], largest != 0);
+    __syncthreads();
+    unsigned long long last = 0;            // (key << 32 | row) of the previous pick; picks are strictly increasing
+    bool first = true;
+    for (int r = 0; r < k; ++r) {
+        unsigned long long best = ~0ull;
+        for (int i = tid; i < n; i += 256) {
+            const unsigned key = i < nc ? keys[i] : topk_key(col[(size_t)i * ldx], largest != 0);
+            const unsigned long long c = ((unsigned long long)key << 32) | (unsigned)i;
+            if ((first || c > last) && c < best) best = c;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long t = __shfl_xor(best, o);
+            best = t < best ? t : best;
+        }
+        if ((tid & 63) == 0) red[tid >> 6] = best;
+        __syncthreads();
+        best = red[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) best = red[w] < best ? red[w] : best;
+        __syncthreads();
+        if (tid == 0) {
+            const size_t o = ((size_t)sg * k + r) * G + g;
+            if (best == ~0ull) {            // fewer than k rows: cannot happen (checked by the host)
+                vals[o] = 0.f, idx[o] = -1;
+            } else {
+                const int row = (int)(best & 0xffffffffu);
+                vals[o] = col[(size_t)row * ldx];
+                idx[o] = start + row;
+            }
+        }
+        last = best, first = false;
+    }
+}
+
 }  // namespace lsn
 
 using namespace lsn;
@@ -321,6 +389,33 @@ int lsn_selftest_mfma(const float *A, const float *B, float *D, int M, int N, in
         hipLaunchKernelGGL(selftest32_kernel, dim3(cdiv(N, 32), cdiv(M, 32)), dim3(64), 0, stream, A, B, D, M, N, K);
     else
         hipLaunchKernelGGL(selftest16_kernel, dim3(cdiv(N, 16), cdiv(M, 16)), dim3(64), 0, stream, A, B, D, M, N, K);
+    LSN_HIP(hipGetLastError());
+    return 0;
+}
+
+int lsn_topk_columns(const float *x, int P, int G, int ldx, int nseg, const int *seg_start, const int *seg_len, int k, int largest,
+                     float *values, int64_t *indices, lsn_stream_t stream)
+{
+    LSN_CHECK(P >= 0 && G >= 0 && ldx >= G && k > 0, "topk: invalid shape (P %d, G %d, ldx %d, k %d)", P, G, ldx, k);
+    LSN_CHECK(nseg >= 1 && nseg <= 8, "topk: %d segments (1 .. 8)", nseg);
+    lsn::TopkSegs segs;
+    for (int i = 0; i < nseg; ++i) {
+        LSN_CHECK(seg_start[i] >= 0 && seg_len[i] >= k && seg_start[i] + seg_len[i] <= P,
+                  "topk: segment %d = [%d, +%d) of %d rows with k = %d", i, seg_start[i], seg_len[i], P, k);
+        segs.start[i] = seg_start[i], segs.len[i] = seg_len[i];
+    }
+    if (G == 0) return 0;
+    int nmax = 0;
+    for (int i = 0; i < nseg; ++i) nmax = seg_len[i] > nmax ? seg_len[i] : nmax;
+    const int cap = nmax < 36 * 1024 ? nmax : 36 * 1024;       // <= 144 KB of keys; longer columns re-read the rest from L2
+    static bool attr_set = false;
+    if (!attr_set) {
+        LSN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(lsn::topk_cols_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    36 * 1024 * 4));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(lsn::topk_cols_kernel, dim3(G, nseg), dim3(256), (size_t)cap * 4, stream, x, ldx, G, segs, k, largest,
+                       values, reinterpret_cast<long long *>(indices), cap);
     LSN_HIP(hipGetLastError());
     return 0;
 }

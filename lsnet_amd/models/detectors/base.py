@@ -69,14 +69,26 @@ class BaseDetector(nn.Module):
         """dict of tensors / lists of tensors -> (total loss, log_vars).  Keys containing 'loss'
         are summed into the total (base.py:176-209)."""
         log_vars = LazyScalars()
+
+        def mean(v):     # the mean of a 0-dim tensor is the tensor: no launch for it
+            return v if v.dim() == 0 else v.mean()
+
+        def total(vals):   # Python's sum() without its leading `0 +` (exact either way, one launch less per list)
+            vals = list(vals)
+            if not vals:
+                return 0
+            acc = vals[0]
+            for v in vals[1:]:
+                acc = acc + v
+            return acc
         for name, value in losses.items():
             if isinstance(value, torch.Tensor):
-                log_vars[name] = value.mean()
+                log_vars[name] = mean(value)
             elif isinstance(value, list):
-                log_vars[name] = sum(v.mean() for v in value)
+                log_vars[name] = total(mean(v) for v in value)
             else:
                 raise TypeError(f'{name} is not a tensor or list of tensors')
-        loss = sum(v for k, v in log_vars.items() if 'loss' in k)
+        loss = total(v for k, v in log_vars.items() if 'loss' in k)
         log_vars['loss'] = loss
         capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
         # `_log_reduce_elsewhere`: a GraphedForwardBackward owns the ONE reduction of the log scalars of its steps -- warm-up,

@@ -67,6 +67,9 @@ class _DCNFunction(Function):
         ctx.mask_none = [m is None for m in masks]
         ctx.save_for_backward(weight, *inputs, *offsets, *[m for m in masks if m is not None])
         outs = backend.dcn_forward(list(inputs), list(offsets), list(masks), weight, bias, cfg, out_hw)
+        cat = int(cfg.get('concat') or 0)
+        if cat > 1 and len(outs) == n:   # a backend that left the levels apart
+            outs = [torch.cat(outs[j:j + cat], dim=1) for j in range(0, n, cat)]
         return tuple(outs)
 
     @staticmethod
@@ -83,7 +86,17 @@ class _DCNFunction(Function):
                     offset=[nig[4 + n + i] for i in range(n)],
                     mask=[nig[4 + 2 * n + i] for i in range(n)])
         gos = []
-        for i, g in enumerate(grad_outs):
+        cat = int(cfg.get('concat') or 0)
+        if cat > 1:   # one gradient per group of `cat` levels: the levels read their channel slices of it
+            Co = weight.shape[0]
+            for j, g in enumerate(grad_outs):
+                x, off = inputs[j * cat], offsets[j * cat]
+                if g is None:
+                    g = x.new_zeros((x.shape[0], cat * Co, off.shape[2], off.shape[3]))
+                if x.is_contiguous(memory_format=torch.channels_last):
+                    g = g.contiguous(memory_format=torch.channels_last)
+                gos += [g.narrow(1, q * Co, Co) for q in range(cat)]
+        for i, g in enumerate(grad_outs if cat <= 1 else ()):
             if g is None:  # this level's output was not used downstream
                 x, off = inputs[i], offsets[i]
                 g = x.new_zeros((x.shape[0], weight.shape[0], off.shape[2], off.shape[3]))
@@ -171,7 +184,7 @@ class _DCNPackFn(Function):
 
 
 def dcn_multi(inputs, offsets, masks, weight, bias=None, stride=1, padding=0, dilation=1, groups=1,
-              deformable_groups=1, scales=None, pyramid=False, fused_om=False):
+              deformable_groups=1, scales=None, pyramid=False, fused_om=False, concat=0):
     """Batched deformable convolution: out_i = DCN(inputs[i], offsets[i], masks[i]; weight, bias).
 
     masks may be None (DCNv1 / pyramid) or a list with None entries.  scales: per-level
@@ -180,7 +193,10 @@ def dcn_multi(inputs, offsets, masks, weight, bias=None, stride=1, padding=0, di
 
     fused_om=True: `offsets[i]` is the raw (B, 3*dg*kh*kw, H, W) output of a DCNv2 pack's conv_offset
     (offsets in the first two thirds of the channels, mask LOGITS in the last third); the sigmoid and
-    its derivative are applied inside the kernels and ONE gradient tensor comes back."""
+    its derivative are applied inside the kernels and ONE gradient tensor comes back.
+
+    concat=g > 1: returns len(inputs) / g tensors, torch.cat(out[j g : (j + 1) g], dim=1) -- the outputs of g consecutive
+    levels (same batch and output size) side by side, written there by the kernels where they can."""
     n = len(inputs)
     if masks is None:
         masks = [None] * n
@@ -191,7 +207,8 @@ def dcn_multi(inputs, offsets, masks, weight, bias=None, stride=1, padding=0, di
             raise ValueError(f'Expected 4D tensor as input, got {x.dim()}D tensor instead.')
     cfg = dict(stride=_same_int(stride, 'stride'), pad=_same_int(padding, 'padding'),
                dil=_same_int(dilation, 'dilation'), groups=int(groups), dg=int(deformable_groups),
-               scales=[(float(a), float(b)) for a, b in scales], pyramid=bool(pyramid), fused_om=bool(fused_om))
+               scales=[(float(a), float(b)) for a, b in scales], pyramid=bool(pyramid), fused_om=bool(fused_om),
+               concat=int(concat) if concat and concat > 1 else 0)
     return list(_DCNFunction.apply(weight, bias, cfg, n, *inputs, *offsets, *masks))
 
 
@@ -424,13 +441,20 @@ class PyramidDeformConv(nn.Module):
     def forward(self, x, offset, scale_h, scale_w):
         return self.forward_multi([x], [offset], [(scale_h, scale_w)])[0]
 
-    def forward_multi(self, xs, offsets, scales, weight=None):
-        """`weight`: a zero-padded view of `self.weight` for sources whose channels were rounded up."""
+    def forward_multi(self, xs, offsets, scales, weight=None, concat=0):
+        """`weight`: a zero-padded view of `self.weight` for sources whose channels were rounded up.
+        `concat` = g > 1: the outputs of g consecutive pairs (one destination level) come back as ONE tensor, concatenated
+        along the channels (lsnet_head.py:640-647 concatenates them right away)."""
         prepped = [self._pad_small(x, o) for x, o in zip(xs, offsets)]
+        if concat and concat > 1 and any(p[2] or p[3] for p in prepped):   # padded tiny sources: per pair, then concatenate
+            outs = self.forward_multi(xs, offsets, scales, weight)
+            return [torch.cat(outs[j:j + concat], dim=1) for j in range(0, len(outs), concat)]
         outs = dcn_multi([p[0] for p in prepped], [p[1] for p in prepped], None,
                          self.weight if weight is None else weight, None, self.stride,
                          self.padding, self.dilation, self.groups, self.deformable_groups,
-                         scales=[_pair(s) for s in scales], pyramid=True)
+                         scales=[_pair(s) for s in scales], pyramid=True, concat=concat)
+        if concat and concat > 1:
+            return outs
         res = []
         for out, (_, _, pad_h, pad_w) in zip(outs, prepped):
             if pad_h or pad_w:

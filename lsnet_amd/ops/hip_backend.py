@@ -35,6 +35,18 @@ def _dense(t, nhwc):
     return t.contiguous(memory_format=_CL) if nhwc else t.contiguous()
 
 
+def _pixel_pitch(t):
+    """Floats from one pixel to the next when `t` (B, C, H, W) is a channel slice of a dense channels-last tensor (or a
+    dense one itself), else None."""
+    if t.dim() != 4 or t.stride(1) != 1:
+        return None
+    B, C, H, W = t.shape
+    p = t.stride(3)
+    if p < C or p % 4 or t.stride(2) != W * p or (B > 1 and t.stride(0) != H * W * p):
+        return None
+    return p
+
+
 def _strides(t):
     s = t.stride()
     return _lib.Strides4(s[0], s[1], s[2], s[3])
@@ -136,11 +148,25 @@ class HipBackend:
         shape = self._shape(w, cfg)
         levels = (_lib.DcnLevel * n)()
         outs = []
+        # cfg['concat'] = g: the outputs of g consecutive levels are wanted side by side in ONE (B, g Co, Ho, Wo) tensor (LSHead:
+        # the three maps a level gathers, lsnet_head.py:640-647).  The kernels write them there (lsn_dcn_shape.out_pitch)
+        # when they can; otherwise the levels get their own buffers and ATen concatenates.
+        g = int(cfg.get('concat') or 0)
+        Co = w.shape[0]
+        wide = None
+        if g > 1:
+            assert n % g == 0 and all(out_hw[i] == out_hw[i - i % g] and xs[i].shape[0] == xs[i - i % g].shape[0] for i in range(n))
+            if nhwc and (g * Co) % 4 == 0:
+                wide = [torch.empty((xs[j].shape[0], g * Co) + tuple(out_hw[j]), device=xs[j].device, dtype=torch.float32,
+                                    memory_format=_CL) for j in range(0, n, g)]
         for i in range(n):
             B, C, H, W = xs[i].shape
             Ho, Wo = out_hw[i]
-            out = torch.empty((B, w.shape[0], Ho, Wo), device=xs[i].device, dtype=torch.float32,
-                              memory_format=_CL if nhwc else torch.contiguous_format)
+            if wide is not None:
+                out = wide[i // g].narrow(1, (i % g) * Co, Co)
+            else:
+                out = torch.empty((B, Co, Ho, Wo), device=xs[i].device, dtype=torch.float32,
+                                  memory_format=_CL if nhwc else torch.contiguous_format)
             outs.append(out)
             L = levels[i]
             L.input, L.offset, L.mask, L.output = _ptr(xs[i]), _ptr(offs[i]), _ptr(msks[i]), _ptr(out)
@@ -155,8 +181,18 @@ class HipBackend:
         if _lib.split_math():
             ws = torch.empty(2 * w.numel(), device=w.device, dtype=torch.float32)   # pre-split weight planes
             shape.workspace = ws.data_ptr()
+        if wide is not None:
+            shape.out_pitch = g * Co
+            if not lib.lsn_dcn_pitched_ok(ctypes.byref(shape), n, levels, 0):   # (exact-fp32 mode, odd channel counts)
+                shape.out_pitch = 0
+                wide = None
+                outs = [torch.empty(tuple(o.shape), device=o.device, dtype=torch.float32, memory_format=_CL) for o in outs]
+                for i in range(n):
+                    levels[i].output = _ptr(outs[i])
         _lib.check(lib.lsn_dcn_forward(ctypes.byref(shape), n, levels, _ptr(w), _ptr(b), 1 if nhwc else 0,
                                        _stream()))
+        if g > 1:
+            return wide if wide is not None else [torch.cat(outs[j:j + g], dim=1) for j in range(0, n, g)]
         return outs
 
     def dcn_backward(self, inputs, offsets, masks, weight, grad_outs, cfg, need):
@@ -164,7 +200,13 @@ class HipBackend:
         Returns (grad_inputs, grad_offsets, grad_masks, grad_weight, grad_bias)."""
         nhwc, xs, offs, msks, w = self._prep(inputs, offsets, masks, weight)
         n = len(xs)
-        gos = [(g.contiguous(memory_format=_CL) if nhwc else g.contiguous()) for g in grad_outs]
+        # channel slices of wider channels-last tensors (the gradient of a concatenation) are read where they lie when the
+        # kernels can (lsn_dcn_shape.out_pitch): _dcn_backward_call falls back to dense copies otherwise
+        pitches = {_pixel_pitch(g) for g in grad_outs} if nhwc else {None}
+        if len(pitches) == 1 and None not in pitches and pitches != {w.shape[0]}:
+            gos = list(grad_outs)
+        else:
+            gos = [(g.contiguous(memory_format=_CL) if nhwc else g.contiguous()) for g in grad_outs]
         gxs, goffs, gmsks = [], [], []
         shared = {}   # levels sampling ONE source map (pyramid op) accumulate into one grad_input buffer
         bufs = []     # per level: the grad_input buffer the kernels write (shared ones appear several times)
@@ -231,6 +273,14 @@ class HipBackend:
                 gws = torch.empty(nbytes, device=w.device, dtype=torch.uint8)
                 shape.gather_workspace, shape.gather_workspace_bytes = gws.data_ptr(), nbytes
         shape.accumulate_param_grads = 1 if accumulate else 0
+        pitch = _pixel_pitch(gos[0]) if nhwc else None
+        if pitch is not None and pitch != w.shape[0]:
+            shape.out_pitch = pitch
+            if not lib.lsn_dcn_pitched_ok(ctypes.byref(shape), n, levels, 1):
+                shape.out_pitch = 0
+                gos = [g.contiguous(memory_format=_CL) for g in gos]
+                for i in range(n):
+                    levels[i].grad_output = _ptr(gos[i])
         _lib.check(lib.lsn_dcn_backward(ctypes.byref(shape), n, levels, _ptr(w), _ptr(gw), _ptr(gb),
                                         1 if nhwc else 0, _stream()))
 
@@ -295,6 +345,24 @@ class HipBackend:
         _lib.check(lib.lsn_nms(_ptr(dets), _ptr(order), n, ctypes.c_float(iou_thr), _ptr(keep), _ptr(num),
                                _ptr(ws), _stream()))
         return keep[:int(num.item())]
+
+    # ------------------------------------------------------------------ k nearest per column (assigners)
+    def topk_columns(self, x, k, seg_start, seg_len, largest=False):
+        """x (P, G) float32 on the device -> (values, indices), both (nseg * k, G): per row segment the k smallest
+        (largest) entries of every column in that order -- torch.topk(x[s:s + n], k, dim=0) of every segment, one launch."""
+        lib = _lib.load()
+        x = _f32(x, 'x')
+        if x.stride(1) != 1 or x.stride(0) < x.shape[1]:
+            x = x.contiguous()
+        P, G = x.shape
+        nseg = len(seg_start)
+        vals = torch.empty((nseg * k, G), dtype=torch.float32, device=x.device)
+        idx = torch.empty((nseg * k, G), dtype=torch.int64, device=x.device)
+        starts = (ctypes.c_int * nseg)(*[int(v) for v in seg_start])
+        lens = (ctypes.c_int * nseg)(*[int(v) for v in seg_len])
+        _lib.check(lib.lsn_topk_columns(_ptr(x), P, G, x.stride(0), nseg, starts, lens, int(k), 1 if largest else 0,
+                                        _ptr(vals), _ptr(idx), _stream()))
+        return vals, idx
 
     def selftest_mfma(self, A, B, variant):
         lib = _lib.load()

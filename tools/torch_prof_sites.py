@@ -26,6 +26,7 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stac
     torch.cuda.synchronize()
 agg = defaultdict(lambda: [0, 0.0])
 shapes = defaultdict(lambda: [0, 0.0])
+detail = defaultdict(lambda: [0, 0.0])
 for e in prof.events():
     dt = getattr(e, 'self_device_time_total', None)
     if dt is None:
@@ -44,6 +45,10 @@ for e in prof.events():
     a = agg[(e.name, site)]
     a[0] += 1
     a[1] += dt
+    if e.name in ('aten::copy_', 'aten::fill_', 'aten::cat', 'aten::mul', 'aten::add', 'aten::index'):
+        d = detail[(e.name, site[:60], str(getattr(e, 'input_shapes', None))[:100])]
+        d[0] += 1
+        d[1] += dt
 rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
 tot_n = sum(v[0] for v in agg.values()); tot_t = sum(v[1] for v in agg.values())
 print(f'ATen ops with device time in one step: {tot_n} launches, {tot_t / 1e3:.2f} ms')
@@ -52,3 +57,6 @@ for (name, site), (n, t) in rows[:70]:
 print('--- ops launched from backward() / the autograd engine, by input shapes')
 for (name, shp), (n, t) in sorted(shapes.items(), key=lambda kv: -kv[1][1])[:45]:
     print(f'{n:5d} {t / 1e3:8.3f} ms  {name:24s} {shp}')
+print('--- copies / fills / cats / muls by site and input shapes')
+for (name, site, shp), (n, t) in sorted(detail.items(), key=lambda kv: -kv[1][1])[:60]:
+    print(f'{n:5d} {t / 1e3:8.3f} ms  {name:14s} {site:60s} {shp}')

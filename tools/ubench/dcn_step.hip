@@ -236,7 +236,7 @@ int main(int argc, char **argv)
         };
         std::vector<float> keep[2];   // every gradient of mode 1 (new) and mode 0 (debug bit 28), concatenated
         for (int mode = 1; mode >= 0; --mode) {
-            api.dbg(nullptr, mode ? 0 : (1 << 28));
+            api.dbg(nullptr, mode ? (getenv("DCN_STEP_DBG") ? atoi(getenv("DCN_STEP_DBG")) : 0) : (1 << 28));   // DCN_STEP_DBG: debug bits of the default arm (A/B)
             const int64_t gbytes = api.ws_bytes(&s, n, lv.data());
             void *gws = nullptr;
             if (gbytes > 0) CK(hipMalloc(&gws, (size_t)gbytes));
