@@ -231,6 +231,25 @@ int lsn_sigmoid_focal_loss_backward_weighted(const float *logits, const int64_t 
                                              const float *weight, const float *scale, float *d_logits,
                                              int N, int C, float gamma, float alpha, lsn_stream_t stream);
 
+/* ---- LSHead's cumulative offset rescaling: lsnet_head.py:622-638 ------------------------------ [fused]
+ * The reference multiplies a level's offset field IN PLACE by (scale_h, scale_w) of each of the three source levels it
+ * visits, so the pyramid convolutions of a destination level see off*m1, off*m1*m2, off*m1*m2*m3 (y channels by mh, x
+ * channels by mw; channel order y0 x0 y1 x1 ...).  One launch produces the three fields of every level; the backward
+ * launch returns goff = ((g3 m3 + g2) m2 + g1) m1 -- every product and sum a separately rounded fp32 operation, i.e.
+ * bit-identical to the sequence of ATen multiplications / autograd additions it replaces.
+ * Tensors: channels-last (B, C, H, W) with C = 2 * taps; `off` may have any image pitch (a slice of the concatenated
+ * levels), everything else is dense.  forward reads off / writes out[3]; backward reads gout[3] (NULL = zero) / writes goff. */
+typedef struct {
+    const float *off;
+    float *out[3];
+    const float *gout[3];
+    float *goff;
+    int64_t images, per_image, off_image_pitch;   /* B, H*W*C, floats between the images of `off` */
+    float mh[3], mw[3];
+} lsn_offset_chain_level;
+int lsn_offset_chain_forward(int n_levels, const lsn_offset_chain_level *levels, int C, lsn_stream_t stream);
+int lsn_offset_chain_backward(int n_levels, const lsn_offset_chain_level *levels, int C, lsn_stream_t stream);
+
 /* ---- k nearest per column: centroid_assigner.py:74, atss_assigner.py:103-111 ----------------- */
 /* x: row-major (P, G) matrix on the device, row pitch ldx floats (the assigners' points x gts distance matrix).  For
  * every column g and every row segment s = [seg_start[s], seg_start[s] + seg_len[s]) (host arrays, 1 <= nseg <= 8,

@@ -37,6 +37,12 @@ class DcnLevel(ctypes.Structure):
                 ('Wo', ctypes.c_int), ('scale_h', ctypes.c_float), ('scale_w', ctypes.c_float)]
 
 
+class OffsetChainLevel(ctypes.Structure):
+    _fields_ = [('off', ctypes.c_void_p), ('out', ctypes.c_void_p * 3), ('gout', ctypes.c_void_p * 3), ('goff', ctypes.c_void_p),
+                ('images', ctypes.c_int64), ('per_image', ctypes.c_int64), ('off_image_pitch', ctypes.c_int64),
+                ('mh', ctypes.c_float * 3), ('mw', ctypes.c_float * 3)]
+
+
 class ConvLevel(ctypes.Structure):
     _fields_ = [('x', ctypes.c_void_p), ('out', ctypes.c_void_p), ('grad_out', ctypes.c_void_p),
                 ('B', ctypes.c_int), ('H', ctypes.c_int), ('W', ctypes.c_int), ('residual', ctypes.c_void_p),
@@ -70,7 +76,7 @@ EXPORTS = [
     'lsn_pyramid_deform_conv_backward_parameters',
     'lsn_sigmoid_focal_loss_forward', 'lsn_sigmoid_focal_loss_backward', 'lsn_sigmoid_focal_loss_sum',
     'lsn_sigmoid_focal_loss_backward_weighted',
-    'lsn_nms_workspace_bytes', 'lsn_nms', 'lsn_topk_columns', 'lsn_selftest_mfma', 'lsn_debug_phase_clocks',
+    'lsn_nms_workspace_bytes', 'lsn_nms', 'lsn_topk_columns', 'lsn_offset_chain_forward', 'lsn_offset_chain_backward', 'lsn_selftest_mfma', 'lsn_debug_phase_clocks',
     'lsn_prof_enable', 'lsn_prof_read',
     'lsn_group_norm_workspace_bytes', 'lsn_group_norm_forward', 'lsn_group_norm_backward',
     'lsn_set_math_mode', 'lsn_get_math_mode', 'lsn_conv2d_forward', 'lsn_conv2d_forward_pitched', 'lsn_conv2d_backward_data',

@@ -292,6 +292,51 @@ __global__ __launch_bounds__(256) void topk_cols_kernel(const float *__restrict_
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// The offsets LSHead hands to its pyramid convolutions (lsnet_head.py:622-638): a level's offset field is rescaled IN
+// PLACE while the three source levels are visited, so the three fields are off m1, (off m1) m2, ((off m1) m2) m3 with
+// m_k = (scale_h, scale_w) of source k on the (y, x) channel pairs.  In torch that is 3 multiplications per level forward
+// and 3 multiplications + 2 additions backward -- 15 + 25 launches of a few microseconds per step; here one launch per
+// direction over all levels.  Every product and sum is a separately rounded fp32 operation (no fma): bit-identical to the
+// operator sequence.
+// ---------------------------------------------------------------------------------------------
+struct ChainArgs {
+    lsn_offset_chain_level lv[8];
+    long long first[9];   // first element of every level in the launch-wide numbering
+    int n, C;
+};
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void offset_chain_kernel(const ChainArgs a)
+{
+    const long long total = a.first[a.n];
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        int l = 0;
+        while (l + 1 < a.n && e >= a.first[l + 1]) ++l;
+        const lsn_offset_chain_level &L = a.lv[l];
+        const long long i = e - a.first[l];                 // element of the dense (B, H, W, C) tensors
+        const bool x = ((int)(i % a.C) & 1) != 0;           // channels: y0 x0 y1 x1 ...
+        const float m0 = x ? L.mw[0] : L.mh[0], m1 = x ? L.mw[1] : L.mh[1], m2 = x ? L.mw[2] : L.mh[2];
+        if (!BWD) {
+            const long long b = i / L.per_image;
+            const float v = L.off[b * L.off_image_pitch + (i - b * L.per_image)];
+            const float o0 = v * m0, o1 = o0 * m1, o2 = o1 * m2;
+            L.out[0][i] = o0, L.out[1][i] = o1, L.out[2][i] = o2;
+        } else {
+            // products through an asm statement: hipcc's __fmul_rn / __fadd_rn are plain operators, and -ffp-contract=fast fuses
+            // them with the additions (and does not honour `#pragma clang fp contract(off)`)
+            const float g0 = L.gout[0] ? L.gout[0][i] : 0.f, g1 = L.gout[1] ? L.gout[1][i] : 0.f, g2 = L.gout[2] ? L.gout[2][i] : 0.f;
+            float p2, p1;
+            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(p2) : "v"(g2), "v"(m2));
+            const float t1 = g1 + p2;
+            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(p1) : "v"(t1), "v"(m1));
+            const float t0 = g0 + p1;
+            L.goff[i] = t0 * m0;
+        }
+    }
+}
+
 }  // namespace lsn
 
 using namespace lsn;
@@ -418,6 +463,43 @@ int lsn_topk_columns(const float *x, int P, int G, int ldx, int nseg, const int 
                        values, reinterpret_cast<long long *>(indices), cap);
     LSN_HIP(hipGetLastError());
     return 0;
+}
+
+static int offset_chain_launch(int n_levels, const lsn_offset_chain_level *levels, int C, bool bwd, lsn_stream_t stream)
+{
+    LSN_CHECK(n_levels >= 1 && n_levels <= 8 && levels && C >= 2 && C % 2 == 0, "offset chain: bad arguments");
+    lsn::ChainArgs a;
+    a.n = n_levels, a.C = C;
+    long long tot = 0;
+    for (int i = 0; i < n_levels; ++i) {
+        const lsn_offset_chain_level &L = levels[i];
+        LSN_CHECK(L.images > 0 && L.per_image > 0 && L.per_image % C == 0, "offset chain: level %d: bad sizes", i);
+        if (bwd)
+            LSN_CHECK(L.goff != nullptr, "offset chain: level %d: grad_offset is NULL", i);
+        else
+            LSN_CHECK(L.off && L.out[0] && L.out[1] && L.out[2] && L.off_image_pitch >= L.per_image, "offset chain: level %d: bad pointers", i);
+        a.lv[i] = L;
+        a.first[i] = tot;
+        tot += (long long)L.images * L.per_image;
+    }
+    a.first[n_levels] = tot;
+    const int blocks = (int)((tot + 255) / 256 < 2048 ? (tot + 255) / 256 : 2048);
+    if (bwd)
+        hipLaunchKernelGGL(lsn::offset_chain_kernel<true>, dim3(blocks), dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL(lsn::offset_chain_kernel<false>, dim3(blocks), dim3(256), 0, stream, a);
+    LSN_HIP(hipGetLastError());
+    return 0;
+}
+
+int lsn_offset_chain_forward(int n_levels, const lsn_offset_chain_level *levels, int C, lsn_stream_t stream)
+{
+    return offset_chain_launch(n_levels, levels, C, false, stream);
+}
+
+int lsn_offset_chain_backward(int n_levels, const lsn_offset_chain_level *levels, int C, lsn_stream_t stream)
+{
+    return offset_chain_launch(n_levels, levels, C, true, stream);
 }
 
 }  // extern "C"

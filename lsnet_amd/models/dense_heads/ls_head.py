@@ -28,6 +28,7 @@ from ...ops.conv import Conv2d
 from ...ops.group_norm import GroupNorm
 from ...core import PointGenerator, build_assigner, build_sampler, multiclass_nms_lsvr
 from ...ops import ModulatedDeformConvPack, PyramidDeformConv
+from ...ops.dcn import offset_scale_chain
 from ...ops import cross_iou as fused_ciou
 from ..builder import HEADS, build_loss
 
@@ -308,7 +309,7 @@ class LSHead(nn.Module):
             init_conv, init_out = getattr(self, f'pts_{b}_init_conv'), getattr(self, f'pts_{b}_init_out')
             n_sp = self._out_dims(b)[1]
             # 3x3 conv per level; everything after it is pixel-wise: one pass over the concatenated levels
-            raw = init_out(self.relu(self._cat_px(init_conv.forward_multi(tower))))
+            raw = init_out(self._cat_px(init_conv.forward_multi(tower, relu=True)))   # (ReLU in the 3x3 launch's epilogue)
             sp = self.softplus(raw[:, :n_sp])
             reg = self.get_pred_reg(sp, raw[:, n_sp:] if raw.shape[1] > n_sp else None)
             reg = (1 - self.gradient_mul) * reg.detach() + self.gradient_mul * reg
@@ -320,17 +321,17 @@ class LSHead(nn.Module):
         # level_list [l, l-1, l+1] -> y offsets x [s0, s0*s1, s0*s1*s2] (lsnet_head.py:622-638).
         # Reproduced with out-of-place multiplies in the same order (same values, same gradients).
         pairs = []   # (dst level, src level, scale_h, scale_w)
-        scaled = {b: [] for b in self.branches}
+        mults = []
         for l in range(nl):
             bh, bw = cls_feats[l].shape[2:]
-            cur = {b: st[b]['off'][l] for b in self.branches}
+            trio = []
             for s in self._level_list(l, nl):
                 sh, sw = cls_feats[s].shape[2] / bh, cls_feats[s].shape[3] / bw
-                mult = self._scale_const(sh, sw, cur[self.branches[0]])
-                for b in self.branches:
-                    cur[b] = cur[b] * mult
-                    scaled[b].append(cur[b])
+                trio.append((sh, sw))
                 pairs.append((l, s, sh, sw))
+            mults.append(trio)
+        # (one launch per branch and direction on the device; three multiplications per level elsewhere)
+        scaled = {b: [t for trio in offset_scale_chain(st[b]['off'], mults) for t in trio] for b in self.branches}
         scales = [(p[2], p[3]) for p in pairs]
 
         def gather(conv, src_feats, offsets):

@@ -183,6 +183,46 @@ class _DCNPackFn(Function):
                 *[g if nx else None for g, nx in zip(gxs, need_x)])
 
 
+class _OffsetChainFn(Function):
+    """forward(mults, off_0 .. off_{n-1}) -> 3 n tensors: for level l the fields off_l m1, (off_l m1) m2, ((off_l m1) m2) m3
+    with m_k = mults[l][k] = (scale_h, scale_w) on the (y, x) channel pairs -- one launch forward, one backward."""
+
+    @staticmethod
+    def forward(ctx, mults, *offs):
+        be = get_backend(offs[0])
+        ctx.mults, ctx.be, ctx.device = mults, be, offs[0].device
+        ctx.shapes = [tuple(o.shape) for o in offs]
+        return tuple(t for trio in be.offset_chain(list(offs), mults) for t in trio)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *grads):
+        gs = [grads[3 * l:3 * l + 3] for l in range(len(ctx.shapes))]
+        return (None, *ctx.be.offset_chain_backward(ctx.shapes, ctx.device, ctx.mults, gs))
+
+
+def offset_scale_chain(offs, mults):
+    """LSHead's cumulative offset rescaling (lsnet_head.py:622-638; the in-place `*=` of the reference accumulates over the
+    three source levels of a destination level).  offs: per-level (B, 2 taps, H, W) fields; mults[l]: three (scale_h, scale_w)
+    pairs.  Returns per level the three fields [off m1, off m1 m2, off m1 m2 m3] -- each product rounded on its own, as the
+    three multiplications of the reference are."""
+    offs = list(offs)
+    if offs and all(o.is_cuda for o in offs) and len(offs) <= 8 and all(len(m) == 3 for m in mults):
+        be = get_backend(offs[0])
+        if all(be.offset_chain_ok(o) for o in offs):
+            flat = _OffsetChainFn.apply(tuple(tuple((float(a), float(b)) for a, b in m) for m in mults), *offs)
+            return [list(flat[3 * l:3 * l + 3]) for l in range(len(offs))]
+    res = []
+    for off, m in zip(offs, mults):
+        cur, trio = off, []
+        for sh, sw in m:
+            mult = off.new_tensor([sh, sw]).repeat(off.shape[1] // 2).view(1, -1, 1, 1)
+            cur = cur * mult
+            trio.append(cur)
+        res.append(trio)
+    return res
+
+
 def dcn_multi(inputs, offsets, masks, weight, bias=None, stride=1, padding=0, dilation=1, groups=1,
               deformable_groups=1, scales=None, pyramid=False, fused_om=False, concat=0):
     """Batched deformable convolution: out_i = DCN(inputs[i], offsets[i], masks[i]; weight, bias).

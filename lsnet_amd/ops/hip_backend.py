@@ -364,6 +364,57 @@ class HipBackend:
                                         _ptr(vals), _ptr(idx), _stream()))
         return vals, idx
 
+    # ------------------------------------------------------------------ LSHead's cumulative offset rescaling
+    @staticmethod
+    def offset_chain_ok(off):
+        """(B, C, H, W) fp32 with channels innermost and pixels back to back inside an image (any image pitch)."""
+        if not (off.is_cuda and off.dtype == torch.float32 and off.dim() == 4 and off.shape[1] % 2 == 0):
+            return False
+        B, C, H, W = off.shape
+        return off.stride(1) == 1 and off.stride(3) == C and (H == 1 or off.stride(2) == W * C) and \
+            (B == 1 or off.stride(0) >= H * W * C)
+
+    def offset_chain(self, offs, mults):
+        """offs: per-level offset fields; mults[l] = ((sh, sw) x 3) -> per level the three rescaled fields."""
+        lib = _lib.load()
+        n, C = len(offs), offs[0].shape[1]
+        lv = (_lib.OffsetChainLevel * n)()
+        res = []
+        for l, off in enumerate(offs):
+            B, _, H, W = off.shape
+            L = lv[l]
+            L.images, L.per_image = B, H * W * C
+            L.off, L.off_image_pitch = _ptr(off), (off.stride(0) if B > 1 else H * W * C)
+            outs = [torch.empty((B, C, H, W), device=off.device, dtype=torch.float32, memory_format=_CL) for _ in range(3)]
+            for k in range(3):
+                L.mh[k], L.mw[k] = mults[l][k]
+                L.out[k] = outs[k].data_ptr()
+            res.append(outs)
+        _lib.check(lib.lsn_offset_chain_forward(n, lv, C, _stream()))
+        return res
+
+    def offset_chain_backward(self, shapes, device, mults, grads):
+        """grads[l]: the gradients of level l's three fields (entries may be None) -> per level the offset field's gradient."""
+        lib = _lib.load()
+        n, C = len(shapes), shapes[0][1]
+        lv = (_lib.OffsetChainLevel * n)()
+        keep, res = [], []
+        for l, (B, _, H, W) in enumerate(shapes):
+            L = lv[l]
+            L.images, L.per_image = B, H * W * C
+            for k in range(3):
+                L.mh[k], L.mw[k] = mults[l][k]
+                g = grads[l][k]
+                if g is not None:
+                    g = _f32(g, 'grad').contiguous(memory_format=_CL)
+                    keep.append(g)
+                    L.gout[k] = g.data_ptr()
+            goff = torch.empty((B, C, H, W), device=device, dtype=torch.float32, memory_format=_CL)
+            L.goff = goff.data_ptr()
+            res.append(goff)
+        _lib.check(lib.lsn_offset_chain_backward(n, lv, C, _stream()))
+        return res
+
     def selftest_mfma(self, A, B, variant):
         lib = _lib.load()
         A, B = A.contiguous(), B.contiguous()

@@ -331,6 +331,46 @@ def test_topk_columns_matches_torch():
     assert i[:, 1].cpu().tolist()[0] == 3 and torch.isnan(v[0, 1])             # NaN is the largest value, as in torch
 
 
+def test_offset_scale_chain_bitwise():
+    """lsn_offset_chain_forward / _backward against the operator sequence they replace (lsnet_head.py:622-638: three
+    multiplications per level, autograd's additions behind them): the same bits, for slices of a concatenated tensor too."""
+    from lsnet_amd.ops.dcn import offset_scale_chain
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    shapes = [(25, 42), (13, 21), (7, 11)]
+    B, C = 2, 18
+    n_all = sum(h * w for h, w in shapes)
+    flat = torch.randn(B, n_all, C, generator=g).to(dev).requires_grad_()
+    mults = [((13 / 25, 21 / 42), (25 / 13, 2.0), (0.28, 11 / 42)), ((1.0, 1.0), (25 / 13, 42 / 21), (7 / 13, 11 / 21)),
+             ((1.0, 1.0), (13 / 7, 21 / 11), (25 / 13, 2.0))]
+    ws = [[torch.randn(B, C, h, w, generator=g).to(dev) for _ in range(3)] for h, w in shapes]
+
+    def run(fused):
+        flat.grad = None
+        offs, o = [], 0
+        for h, w in shapes:
+            offs.append(flat[:, o:o + h * w].reshape(B, h, w, C).permute(0, 3, 1, 2))
+            o += h * w
+        if fused:
+            res = offset_scale_chain(offs, mults)
+        else:
+            res = []
+            for off, m in zip(offs, mults):
+                cur, trio = off, []
+                for sh, sw in m:
+                    cur = cur * off.new_tensor([sh, sw]).repeat(C // 2).view(1, -1, 1, 1)
+                    trio.append(cur)
+                res.append(trio)
+        loss = sum((t * w).sum() for trio, wt in zip(res, ws) for t, w in zip(trio[:2], wt[:2])) + (res[0][2] * ws[0][2]).sum()
+        loss.backward()    # (the third field of levels 1 and 2 stays unused: a None gradient)
+        return [t.detach().clone() for trio in res for t in trio], flat.grad.clone()
+
+    o_ref, g_ref = run(False)
+    o, gr = run(True)
+    assert all(torch.equal(a, b) for a, b in zip(o, o_ref))
+    assert torch.equal(gr, g_ref)
+
+
 def test_nms_bit_exact():
     from lsnet_amd import ops
     dev = _dev()
