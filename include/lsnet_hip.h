@@ -379,6 +379,19 @@ int lsn_conv2d_backward_weight_bn(const float *x, const float *g, const float *w
                                   float *grad_gamma, float *grad_beta, int B, int H, int W, int C, int Co, int kh, int kw,
                                   int stride, int pad, int dil, int accumulate, lsn_stream_t stream);
 
+/* The same for up to 8 convolutions of ONE geometry (B, H, W, C, Co, kernel, stride, pad, dil) with their own tensors --
+ * the identical bottlenecks of a ResNet stage (resnet.py:ResLayer builds blocks 1 .. n-1 alike): one launch instead of
+ * n_jobs small ones.  A stage-3 1x1 weight gradient alone has 16 output tiles and needs ~32 pixel splits to fill the
+ * chip; five of them together need ~6, with a fifth of the partial-tile traffic per job.  Results as from n_jobs calls of
+ * lsn_conv2d_backward_weight_bn up to the summation order over pixels. */
+typedef struct {
+    const float *x, *g, *w, *bn_gamma, *bn_mean, *bn_var;
+    float bn_eps;
+    float *grad_w, *grad_gamma, *grad_beta;
+} lsn_wgrad_bn_job;
+int lsn_conv2d_backward_weight_bn_jobs(int n_jobs, const lsn_wgrad_bn_job *jobs, int B, int H, int W, int C, int Co, int kh,
+                                       int kw, int stride, int pad, int dil, int accumulate, lsn_stream_t stream);
+
 /* ---- Grouped convolution (ResNeXt bottlenecks) -------------------------------------------------
  * Reference: torch.nn.Conv2d(groups = G) as built by mmdet/models/backbones/resnext.py:11-83 (Bottleneck.conv2:
  * 3x3, G = 64, width / G = 4 .. 32 channels per group), i.e. ATen's grouped convolution and its backward

@@ -43,6 +43,12 @@ class OffsetChainLevel(ctypes.Structure):
                 ('mh', ctypes.c_float * 3), ('mw', ctypes.c_float * 3)]
 
 
+class WgradBnJob(ctypes.Structure):
+    _fields_ = [('x', ctypes.c_void_p), ('g', ctypes.c_void_p), ('w', ctypes.c_void_p), ('bn_gamma', ctypes.c_void_p),
+                ('bn_mean', ctypes.c_void_p), ('bn_var', ctypes.c_void_p), ('bn_eps', ctypes.c_float),
+                ('grad_w', ctypes.c_void_p), ('grad_gamma', ctypes.c_void_p), ('grad_beta', ctypes.c_void_p)]
+
+
 class ConvLevel(ctypes.Structure):
     _fields_ = [('x', ctypes.c_void_p), ('out', ctypes.c_void_p), ('grad_out', ctypes.c_void_p),
                 ('B', ctypes.c_int), ('H', ctypes.c_int), ('W', ctypes.c_int), ('residual', ctypes.c_void_p),
@@ -87,7 +93,7 @@ EXPORTS = [
     'lsn_conv2d_forward_multi', 'lsn_conv2d_backward_data_multi', 'lsn_conv2d_backward_weight_multi', 'lsn_conv2d_backward_weight',
     'lsn_grouped_conv2d_forward', 'lsn_grouped_conv2d_backward_data', 'lsn_grouped_conv2d_backward_weight',
     'lsn_bn_eval_act_forward', 'lsn_bn_eval_act_backward', 'lsn_bn_eval_act_workspace_bytes',
-    'lsn_relu_gate', 'lsn_conv2d_backward_weight_bn',
+    'lsn_relu_gate', 'lsn_conv2d_backward_weight_bn', 'lsn_conv2d_backward_weight_bn_jobs',
     'lsn_image_prep_u8', 'lsn_cross_iou_bbox_forward', 'lsn_cross_iou_bbox_backward',
     'lsn_cross_iou_bbox_stage_forward', 'lsn_cross_iou_bbox_stage_backward',
     'lsn_cross_iou_rows_forward', 'lsn_cross_iou_rows_backward',

@@ -452,6 +452,10 @@ static int prepare_weights(int kind, const float *w, void *prepared, int C, int 
 // ---- weight / bias gradient (conv_wgrad_kernels.h) ----
 int conv_wgrad_reduce(const float *part, float *gw, size_t n, const float *part_b, float *gb, int nb, int splits, int splits_b,
                       int accumulate, hipStream_t st);
+// (state of a folded-norm weight-gradient call, see conv_wgrad_reduce below)
+static thread_local const WgFoldJobs *g_wg_fold = nullptr;
+bool conv_wgrad_fold_pending() { return g_wg_fold != nullptr; }
+static int wg_jobs() { return g_wg_fold ? g_wg_fold->njobs : 1; }
 template <int TI, int TJ, int TG, int WI, int WJ, int PMAX, bool UN_OK>
 static int launch_wgrad_cfg(WgArgs &a, float *gw, float *gb, int accumulate, hipStream_t st)
 {
@@ -461,11 +465,13 @@ static int launch_wgrad_cfg(WgArgs &a, float *gw, float *gb, int accumulate, hip
     const int npl = conv_npl(), K = a.kh * a.kw;
     const int blocks = cdiv(a.Co, BM) * cdiv(a.C, BN);
     const size_t nW = (size_t)a.Co * K * a.C;
-    int S = (512 + blocks / 2) / blocks;
-    const size_t cap = ((size_t)192 << 20) / 4 / (nW + a.Co);   // partial tiles: at most 192 MB
+    const int nj = wg_jobs();   // > 1: the levels are jobs with their own outputs; every split stays inside one level
+    int S = (512 + blocks * nj / 2) / (blocks * nj);
+    const size_t cap = ((size_t)192 << 20) / 4 / (nW + a.Co) / nj;   // partial tiles: at most 192 MB
     if ((size_t)S > cap) S = (int)cap;
-    if (S > a.nseg / 6) S = a.nseg / 6;   // a split should run long enough to amortise its prologue and its partial tile
+    if (S > a.nseg / nj / 6) S = a.nseg / nj / 6;   // a split should run long enough to amortise its prologue and its partial tile
     if (S < 1) S = 1;
+    S *= nj;
     float *part = nullptr;
     if (int rc = part_buffer((size_t)S * (nW + a.Co) + 16, &part, st)) return rc;
     a.part = part;
@@ -503,8 +509,6 @@ static int launch_wgrad_cfg(WgArgs &a, float *gw, float *gb, int accumulate, hip
 // With a BatchNorm fold pending (lsn_conv2d_backward_weight_bn set g_wg_fold for the duration of its weight-gradient
 // call) the reduce also applies the norm's scale and forms grad_gamma / grad_beta (conv_wgrad_reduce_bn_kernel); gb is then
 // the entry point's dummy bias gradient (it only makes the main kernels write the per-channel sums of g).
-static thread_local const WgFold *g_wg_fold = nullptr;
-bool conv_wgrad_fold_pending() { return g_wg_fold != nullptr; }
 
 int conv_wgrad_reduce(const float *part, float *gw, size_t n, const float *part_b, float *gb, int nb, int splits, int splits_b,
                       int accumulate, hipStream_t st)
@@ -512,9 +516,13 @@ int conv_wgrad_reduce(const float *part, float *gw, size_t n, const float *part_
     int LS = 1;
     while (LS < 64 && LS * 8 <= splits) LS <<= 1;   // >= 4 loads per lane; a wave's lanes share 64 / LS elements
     if (g_wg_fold) {
-        LSN_CHECK(part_b && nb > 0 && n % ((size_t)nb * 4) == 0, "conv2d backward-weight (folded norm): bad partial layout");
-        hipLaunchKernelGGL(conv_wgrad_reduce_bn_kernel, dim3(nb), dim3(256), 0, st, part, gw, (int)(n / nb), nb, part_b,
-                           splits, splits_b, accumulate, LS, *g_wg_fold);
+        const int nj = g_wg_fold->njobs;   // (splits / splits_b count ALL jobs' partial tiles)
+        LSN_CHECK(part_b && nb > 0 && n % ((size_t)nb * 4) == 0 && splits % nj == 0 && splits_b % nj == 0,
+                  "conv2d backward-weight (folded norm): bad partial layout");
+        LS = 1;
+        while (LS < 64 && LS * 8 <= splits / nj) LS <<= 1;
+        hipLaunchKernelGGL(conv_wgrad_reduce_bn_kernel, dim3(nb, nj), dim3(256), 0, st, part, gw, (int)(n / nb), nb, part_b,
+                           splits / nj, splits_b / nj, accumulate, LS, *g_wg_fold);
         LSN_HIP(hipGetLastError());
         return 0;
     }
@@ -645,13 +653,47 @@ int lsn_conv2d_backward_weight_bn(const float *x, const float *g, const float *w
               "conv2d backward-weight (folded norm): NULL pointer");
     if (((size_t)kh * kw * C) % 4 != 0)
         return lsn::fail(LSN_ERR_UNSUPPORTED, "conv2d backward-weight (folded norm): kh * kw * C %% 4 != 0");
-    lsn::WgFold f = {w, bn_gamma, bn_mean, bn_var, grad_gamma, grad_beta, bn_eps};
+    lsn::WgFoldJobs f = {};
+    f.f[0] = lsn::WgFold{w, bn_gamma, bn_mean, bn_var, grad_gamma, grad_beta, bn_eps};
+    f.gw[0] = grad_w, f.njobs = 1;
     lsn::g_wg_fold = &f;
     // grad_beta stands in as the bias gradient: the main kernels then write the per-channel partial sums of g, and the
     // fold-aware reduce is the only writer of grad_w / grad_gamma / grad_beta
     const int rc = lsn_conv2d_backward_weight(x, g, grad_w, grad_beta, B, H, W, C, Co, kh, kw, stride, pad, dil, accumulate, stream);
     lsn::g_wg_fold = nullptr;
     return rc;
+}
+
+int lsn_conv2d_backward_weight_bn_jobs(int n_jobs, const lsn_wgrad_bn_job *jobs, int B, int H, int W, int C, int Co, int kh, int kw,
+                                       int stride, int pad, int dil, int accumulate, lsn_stream_t stream)
+{
+    LSN_CHECK(n_jobs >= 1 && n_jobs <= 8 && jobs, "conv2d backward-weight jobs: 1 .. 8 jobs");
+    lsn::WgFoldJobs f = {};
+    lsn_conv_level lv[8] = {};
+    for (int j = 0; j < n_jobs; ++j) {
+        const lsn_wgrad_bn_job &q = jobs[j];
+        LSN_CHECK(q.x && q.g && q.w && q.bn_gamma && q.bn_mean && q.bn_var && q.grad_w && q.grad_gamma && q.grad_beta,
+                  "conv2d backward-weight jobs: NULL pointer in job %d", j);
+        f.f[j] = lsn::WgFold{q.w, q.bn_gamma, q.bn_mean, q.bn_var, q.grad_gamma, q.grad_beta, q.bn_eps};
+        f.gw[j] = q.grad_w;
+        lv[j].x = q.x, lv[j].grad_out = q.g, lv[j].B = B, lv[j].H = H, lv[j].W = W;
+    }
+    f.njobs = n_jobs;
+    int rc = 1;
+    if (n_jobs > 1 && ((size_t)kh * kw * C) % 4 == 0) {   // the patch kernel with the jobs as levels; 1: shape not served there
+        lsn::g_wg_fold = &f;
+        rc = lsn::conv_wgrad_mm(n_jobs, lv, jobs[0].grad_w, jobs[0].grad_beta, C, Co, kh, kw, stride, pad, dil, accumulate,
+                                reinterpret_cast<hipStream_t>(stream));
+        lsn::g_wg_fold = nullptr;
+    }
+    if (rc != 1) return rc;
+    for (int j = 0; j < n_jobs; ++j) {
+        const lsn_wgrad_bn_job &q = jobs[j];
+        if (int r = lsn_conv2d_backward_weight_bn(q.x, q.g, q.w, q.bn_gamma, q.bn_mean, q.bn_var, q.bn_eps, q.grad_w, q.grad_gamma,
+                                                  q.grad_beta, B, H, W, C, Co, kh, kw, stride, pad, dil, accumulate, stream))
+            return r;
+    }
+    return 0;
 }
 
 int lsn_conv2d_prepare_weights_multi(int n_items, const lsn_conv_wprep *items, lsn_stream_t stream)

@@ -432,12 +432,24 @@ struct WgFold {
     float *dgamma, *dbeta;
     float eps;
 };
+// Several convolutions of ONE geometry in one launch (lsn_conv2d_backward_weight_bn_jobs: the identical bottlenecks of a
+// ResNet stage): job j is level j of the main kernel, the pixel splits [j S, (j + 1) S) are its partial tiles, and
+// blockIdx.y of the reduce is the job.
+struct WgFoldJobs {
+    WgFold f[8];
+    float *gw[8];
+    int njobs;
+};
 
 static __global__ __launch_bounds__(256) void conv_wgrad_reduce_bn_kernel(const float *__restrict__ part, float *gw, int R, int Co,
                                                                            const float *__restrict__ part_b, int splits,
                                                                            int splits_b, int accumulate, int LS,
-                                                                           const WgFold f)
+                                                                           const WgFoldJobs J)
 {
+    const WgFold &f = J.f[blockIdx.y];
+    gw = J.njobs > 1 ? J.gw[blockIdx.y] : gw;
+    part += (size_t)blockIdx.y * splits * ((size_t)Co * R);
+    part_b += (size_t)blockIdx.y * splits_b * Co;
     // one workgroup per output channel (a first version with one WAVE per channel ran 32 .. 512 waves through up to 32
     // dependent passes each: +1.9 ms per step over the plain reduce, profiles/r4_bench_c03.log)
     __shared__ float red[2][4];

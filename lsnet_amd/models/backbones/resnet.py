@@ -123,12 +123,14 @@ class Bottleneck(nn.Module):
         # relu(bn3(conv3) + identity): norm, residual add and activation in one pass (resnet.py:261-301)
         return _conv_bn(self.conv3, self.norm3, out, relu=True, residual=_shortcut(self.downsample, x))
 
-    def forward(self, x, pregate_in=False, gy_pregated=False):
+    def forward(self, x, pregate_in=False, gy_pregated=False, wg_queue=None, wg_flush=False):
         """pregate_in / gy_pregated: set by ResLayer.forward for neighbouring blocks that both run as the fused autograd
-        node of ops/resblock.py (the ReLU gate of a block's output then rides in the NEXT block's backward-data launch)."""
+        node of ops/resblock.py (the ReLU gate of a block's output then rides in the NEXT block's backward-data launch).
+        wg_queue / wg_flush: the stage's identical blocks share their weight-gradient launches (ops/resblock.py)."""
         if fused_block_ok(self, x):
-            return resblock.bottleneck(self, x.contiguous(memory_format=torch.channels_last), pregate_in, gy_pregated)
-        assert not (pregate_in or gy_pregated), 'ResLayer.forward pairs the flags of fused blocks only'
+            return resblock.bottleneck(self, x.contiguous(memory_format=torch.channels_last), pregate_in, gy_pregated,
+                                       wg_queue, wg_flush)
+        assert not (pregate_in or gy_pregated or wg_queue is not None), 'ResLayer.forward pairs the flags of fused blocks only'
         return cp.checkpoint(self._body, x) if (self.with_cp and x.requires_grad) else self._body(x)
 
 
@@ -145,9 +147,14 @@ class ResLayer(nn.Sequential):
     def forward(self, x):
         blocks = list(self)
         ok = [fused_block_ok(b, x) for b in blocks]   # (a fused block hands a tensor of the same kind to the next one)
+        # blocks 1 .. n-1 are built alike (__init__ below): when all of them run fused, their weight gradients of one layer
+        # position are ONE launch, issued by block 1's backward -- the last of the group to run
+        group = len(blocks) > 2 and all(ok[1:]) and torch.is_grad_enabled()
+        queue = {} if group else None
         for i, b in enumerate(blocks):
             if ok[i]:
-                x = b(x, pregate_in=i > 0 and ok[i - 1], gy_pregated=i + 1 < len(blocks) and ok[i + 1])
+                x = b(x, pregate_in=i > 0 and ok[i - 1], gy_pregated=i + 1 < len(blocks) and ok[i + 1],
+                      wg_queue=queue if i >= 1 else None, wg_flush=group and i == 1)
             else:
                 x = b(x)
         return x

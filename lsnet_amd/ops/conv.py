@@ -236,6 +236,36 @@ def wgrad_bn(x, g, w, bn, stride, pad, dil, need=(True, True, True)):
     return (gw if need[0] else None), (dg if need[1] else None), (db if need[2] else None)
 
 
+def wgrad_bn_deferrable(w, bn):
+    """Can this layer's parameter gradients be produced LATER, by a launch shared with other layers (wgrad_bn_jobs)?  Only
+    into gradient sinks: autograd wants a returned gradient now."""
+    sw = grad_sink.sink(w)
+    return sw is not None and grad_sink.sink(bn.weight) is not None and grad_sink.sink(bn.bias) is not None \
+        and sw.stride() == w.stride() and w.is_cuda
+
+
+def wgrad_bn_jobs(jobs, stride, pad, dil):
+    """jobs: [(x, g, w, bn)] of ONE geometry, every parameter with a sink (wgrad_bn_deferrable): one launch
+    (lsn_conv2d_backward_weight_bn_jobs) adds every job's (grad_w, grad_gamma, grad_beta) to its sinks."""
+    x0, _, w0, _ = jobs[0]
+    B, C, H, W = x0.shape
+    Co, _, kh, kw = w0.shape
+    lib = _lib.load()
+    for i in range(0, len(jobs), 8):
+        part = jobs[i:i + 8]
+        arr = (_lib.WgradBnJob * len(part))()
+        for q, (x, g, w, bn) in zip(arr, part):
+            assert x.shape == x0.shape and w.shape == w0.shape
+            q.x, q.g, q.w = _p(x), _p(g), _p(w)
+            q.bn_gamma, q.bn_mean, q.bn_var, q.bn_eps = _p(bn.weight), _p(bn.running_mean), _p(bn.running_var), float(bn.eps)
+            q.grad_w, q.grad_gamma, q.grad_beta = _p(grad_sink.sink(w)), _p(grad_sink.sink(bn.weight)), _p(grad_sink.sink(bn.bias))
+        _lib.check(lib.lsn_conv2d_backward_weight_bn_jobs(len(part), arr, B, H, W, C, Co, kh, kw, stride, pad, dil, 1, _stream()))
+    for _, _, w, bn in jobs:
+        grad_sink.done(w)
+        grad_sink.done(bn.weight)
+        grad_sink.done(bn.bias)
+
+
 def conv_fwd_bn(x, w, bn, stride, pad, dil, relu, residual=None):
     """act(bn_eval(conv(x, w)) + residual) in one launch (the norm folded into the prepared image)."""
     B, C, H, W = x.shape

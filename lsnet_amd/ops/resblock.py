@@ -42,7 +42,7 @@ def _cfg(conv):
 class _BottleneckFn(torch.autograd.Function):
 
     @staticmethod
-    def forward(ctx, x, blk, pregate_in, gy_pregated, *params):
+    def forward(ctx, x, blk, pregate_in, gy_pregated, wg_queue, wg_flush, *params):
         # params: (w1, gamma1, beta1, w2, gamma2, beta2, w3, gamma3, beta3[, wd, gammad, betad]) -- autograd's handles on
         # the parameters; the kernels read them through the modules
         c1, c2, c3 = blk.conv1, blk.conv2, blk.conv3
@@ -57,6 +57,7 @@ class _BottleneckFn(torch.autograd.Function):
         y = K.conv_fwd_bn(h2, c3.weight, n3, *_cfg(c3), True, idt)
         ctx.save_for_backward(x, h1, h2, y)
         ctx.blk, ctx.flags = blk, (bool(pregate_in), bool(gy_pregated))
+        ctx.wg = (wg_queue, bool(wg_flush))
         return y
 
     @staticmethod
@@ -82,16 +83,24 @@ class _BottleneckFn(torch.autograd.Function):
                 r = r.add_(residual)
             return K.relu_gate(r, gate) if gate is not None else r
 
-        def wgrad(xin, g, conv, bn):
+        queue, flush = ctx.wg
+
+        def wgrad(xin, g, conv, bn, slot=None):
             # (On a second HIP stream beside the data gradients these launches LOST: 37.05 vs 35.98 ms per step, weight
             # gradients 8.1 vs 6.6 ms, data gradients 5.8 vs 4.9 -- profiles/r4_side_stream.txt.  Both kernel streams fill
             # the chip on their own; sharing it costs each more than the overlap of their tails returns.)
+            # The identical blocks of a stage queue their three layers instead (gradient sinks only: nothing to hand to
+            # autograd): the stage's last backward launches conv1 / conv2 / conv3 of all of them together.
+            if queue is not None and slot is not None and getattr(K, 'wgrad_bn_deferrable', None) \
+                    and K.wgrad_bn_deferrable(conv.weight, bn):
+                queue.setdefault(slot, []).append((xin, g, conv.weight, bn, _cfg(conv)))
+                return None, None, None
             return K.wgrad_bn(xin, g, conv.weight, bn, *_cfg(conv))
 
         g2 = fused_dgrad(g3, c3, n3, h2.shape, h2)
-        grads.append(wgrad(h2, g3, c3, n3))
+        grads.append(wgrad(h2, g3, c3, n3, 'conv3'))
         g1 = fused_dgrad(g2, c2, n2, h1.shape, h1)
-        grads.insert(0, wgrad(h1, g2, c2, n2))
+        grads.insert(0, wgrad(h1, g2, c2, n2, 'conv2'))
         gx = None
         gd = None
         if blk.downsample is not None:
@@ -102,11 +111,27 @@ class _BottleneckFn(torch.autograd.Function):
         if need_x:
             res = gx if gx is not None else g3
             gx = fused_dgrad(g1, c1, n1, x.shape, x if pregate_in else None, residual=res, out=gx)
-        grads.insert(0, wgrad(x, g1, c1, n1))
+        grads.insert(0, wgrad(x, g1, c1, n1, 'conv1'))
         flat = [t for trip in grads for t in trip]
         if gd is not None:
             flat += list(gd)
-        return (gx, None, None, None) + tuple(flat)
+        if flush and queue:
+            flush_wgrad_queue(queue)
+        return (gx, None, None, None, None, None) + tuple(flat)
+
+
+def flush_wgrad_queue(queue):
+    """The queued weight-gradient jobs of a stage's identical blocks, one launch per layer position."""
+    for slot in ('conv3', 'conv2', 'conv1'):
+        jobs = queue.pop(slot, [])
+        if not jobs:
+            continue
+        cfg = jobs[0][4]
+        if len(jobs) > 1 and all(j[4] == cfg and j[0].shape == jobs[0][0].shape and j[2].shape == jobs[0][2].shape for j in jobs):
+            K.wgrad_bn_jobs([j[:4] for j in jobs], *cfg)
+        else:
+            for xin, g, w, bn, c in jobs:
+                K.wgrad_bn(xin, g, w, bn, *c)
 
 
 def bottleneck_ok(blk):
@@ -135,13 +160,15 @@ def bottleneck_ok(blk):
     return True
 
 
-def bottleneck(blk, x, pregate_in=False, gy_pregated=False):
+def bottleneck(blk, x, pregate_in=False, gy_pregated=False, wg_queue=None, wg_flush=False):
     """relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1(x)))))))) + shortcut(x)) as one autograd node (x: channels-last fp32 on
-    the device; the caller checked bottleneck_ok(blk))."""
+    the device; the caller checked bottleneck_ok(blk)).  wg_queue: a dict shared by the identical blocks of a stage for
+    this forward pass -- their weight gradients wait in it (when they go to gradient sinks) until the block with wg_flush
+    (the first of them, whose backward runs last) launches them together."""
     params = []
     pairs = [(blk.conv1, blk.norm1), (blk.conv2, blk.norm2), (blk.conv3, blk.norm3)]
     if blk.downsample is not None:
         pairs.append((blk.downsample[-2], blk.downsample[-1]))
     for conv, bn in pairs:
         params += [conv.weight, bn.weight, bn.bias]
-    return _BottleneckFn.apply(x, blk, pregate_in, gy_pregated, *params)
+    return _BottleneckFn.apply(x, blk, pregate_in, gy_pregated, wg_queue, wg_flush, *params)

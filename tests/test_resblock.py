@@ -158,3 +158,50 @@ def test_frozen_or_foreign_blocks_keep_the_modular_path(torch_prims):
 def test_epilogue_ok_matches_the_residue_classes():
     assert resblock.epilogue_ok(3, 2, 1, 1) and resblock.epilogue_ok(1, 1, 0, 1) and resblock.epilogue_ok(3, 1, 1, 1)
     assert not resblock.epilogue_ok(1, 2, 0, 1)
+
+
+class SinkPrims(TorchPrims):
+    """TorchPrims whose weight gradients go to the parameters' own .grad (what the gradient sinks of the data-parallel
+    wrapper are for the HIP primitives) -- the condition under which the identical blocks of a stage queue their weight
+    gradients and block 1's backward launches them together (ops/resblock.py flush_wgrad_queue)."""
+    batches = []
+
+    @staticmethod
+    def wgrad_bn_deferrable(w, bn):
+        return True
+
+    @staticmethod
+    def wgrad_bn(x, g, w, bn, stride, pad, dil, need=(True, True, True)):
+        for p, gr in zip((w, bn.weight, bn.bias), TorchPrims.wgrad_bn(x, g, w, bn, stride, pad, dil)):
+            p.grad = gr.clone() if p.grad is None else p.grad + gr
+        return None, None, None
+
+    @staticmethod
+    def wgrad_bn_jobs(jobs, stride, pad, dil):
+        SinkPrims.batches.append(len(jobs))
+        for x, g, w, bn in jobs:
+            SinkPrims.wgrad_bn(x, g, w, bn, stride, pad, dil)
+
+
+def test_identical_blocks_share_their_weight_gradient_launches(monkeypatch, torch_prims):
+    SinkPrims.calls, SinkPrims.batches = [], []
+    monkeypatch.setattr(resblock, 'K', SinkPrims)
+    layer = _make_layer(16, 8, 4, 2)                 # block 0 with the projection + three identical blocks
+    x = torch.randn(2, 16, 12, 10, dtype=torch.float64).contiguous(memory_format=CL)
+    y0, gx0, gp0 = _run(layer, x, fused=False)
+    y1, gx1, gp1 = _run(layer, x, fused=True)
+    assert torch.allclose(y0, y1, rtol=1e-10, atol=1e-10) and torch.allclose(gx0, gx1, rtol=1e-9, atol=1e-10)
+    for k in gp0:
+        assert torch.allclose(gp0[k], gp1[k], rtol=1e-9, atol=1e-9), k
+    assert SinkPrims.batches == [3, 3, 3]            # conv3, conv2, conv1 of blocks 1 .. 3, one launch each
+    # two identical blocks only in a three-block stage; a two-block stage has no group
+    SinkPrims.batches = []
+    layer = _make_layer(16, 8, 3, 1)
+    _, _, gp0 = _run(layer, x, fused=False)
+    _, _, gp1 = _run(layer, x, fused=True)
+    assert all(torch.allclose(gp0[k], gp1[k], rtol=1e-9, atol=1e-9) for k in gp0) and SinkPrims.batches == [2, 2, 2]
+    SinkPrims.batches = []
+    layer = _make_layer(16, 8, 2, 1)
+    _, _, gp0 = _run(layer, x, fused=False)
+    _, _, gp1 = _run(layer, x, fused=True)
+    assert all(torch.allclose(gp0[k], gp1[k], rtol=1e-9, atol=1e-9) for k in gp0) and SinkPrims.batches == []

@@ -96,3 +96,55 @@ def test_fused_stage_equals_fp64_autograd(inplanes, planes, n, stride):
         assert _err(p.grad, pr[k].grad) < 2e-5, (k, _err(p.grad, pr[k].grad))
     # the zero-initialised norm3 of the last block learns
     assert float(layer[-1].norm3.weight.grad[:5].abs().min()) > 0
+
+
+def test_identical_blocks_batched_weight_gradients():
+    """With gradient sinks registered the identical blocks of a stage queue their weight gradients and block 1's backward
+    launches each layer position once for all of them (lsn_conv2d_backward_weight_bn_jobs): against fp64 autograd on the
+    host, every parameter gradient -- at a size where the jobs need pixel splits, accumulated ONTO a non-zero sink."""
+    from lsnet_amd.models.backbones import resnet as R
+    from lsnet_amd.ops import grad_sink, resblock
+    dev = torch.device('cuda:0')
+    torch.manual_seed(4)
+    layer = R.ResLayer(R.Bottleneck, 128, 64, 4, stride=2)
+    for m in layer.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.weight.data.uniform_(-1.0, 1.5)
+            m.bias.data.normal_(0, 0.3)
+            m.running_mean.normal_(0, 0.5)
+            m.running_var.uniform_(0.5, 2.0)
+    ref = copy.deepcopy(layer).double()
+    layer = layer.to(dev).to(memory_format=CL).train()
+    for L in (layer, ref):
+        L.train()
+        for m in L.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.eval()
+    seed = {}
+    for k, p in layer.named_parameters():        # the sinks: p.grad itself, holding something already
+        p.grad = torch.full_like(p, 0.25)
+        seed[k] = 0.25
+        grad_sink.register(p, p.grad)
+    launches = []
+    real = resblock.K.wgrad_bn_jobs
+    try:
+        resblock.K.wgrad_bn_jobs = lambda jobs, *cfg: (launches.append(len(jobs)), real(jobs, *cfg))[1]
+        x = torch.randn(2, 128, 96, 80)
+        xd = x.to(dev).contiguous(memory_format=CL).requires_grad_()
+        y = layer(xd)
+        go = torch.randn(y.shape)
+        y.backward(go.to(dev))
+    finally:
+        resblock.K.wgrad_bn_jobs = real
+        for p in layer.parameters():
+            grad_sink.unregister(p)
+    assert launches == [3, 3, 3]
+    xr = x.double().requires_grad_()
+    yr = xr
+    for b in ref:
+        yr = b._body(yr)
+    yr.backward(go.double())
+    pr = dict(ref.named_parameters())
+    for k, p in layer.named_parameters():
+        assert _err(p.grad - seed[k], pr[k].grad) < 2e-5, (k, _err(p.grad - seed[k], pr[k].grad))
+    assert _err(xd.grad, xr.grad) < 2e-5
