@@ -231,6 +231,29 @@ int lsn_sigmoid_focal_loss_backward_weighted(const float *logits, const int64_t 
                                              const float *weight, const float *scale, float *d_logits,
                                              int N, int C, float gamma, float alpha, lsn_stream_t stream);
 
+/* ---- gradient clipping + SGD: mmcv/runner/hooks/optimizer.py:8-28 ----------------------------- [fused]
+ * clip_grad_norm_(parameters, max_norm, norm_type = 2) followed by torch.optim.SGD.step() (momentum, weight decay; no
+ * dampening, no Nesterov) over all parameter tensors in three launches instead of ATen's dozen multi-tensor ones.
+ * `tensors_dev`: DEVICE array of n_tensors entries in ascending first_chunk order: a tensor of numel floats owns the
+ * ceil(numel / 4096) chunks from first_chunk on (param / grad / momentum_buf: dense tensors of identical strides, 16-byte
+ * aligned); total_chunks = their sum.  groups[t.group] = that parameter group's (lr, momentum, weight_decay).
+ * max_norm > 0: stats[0] = the total gradient norm, stats[1] = min(1, max_norm / (norm + 1e-6)) and the gradients are
+ * scaled by it IN PLACE when it is below 1 (as the reference leaves p.grad); max_norm <= 0: no clipping, stats untouched.
+ * Per element every operation is rounded as the operator sequence of torch rounds it (csrc/misc.hip).  A zero-filled
+ * momentum buffer makes the first step what torch's is.  `workspace`: lsn_clip_sgd_workspace_bytes() bytes.
+ * Everything is device-side: no host read of the norm. */
+typedef struct {
+    float *param, *grad, *momentum_buf;
+    int64_t numel, first_chunk;
+    int group;
+} lsn_sgd_tensor;
+typedef struct {
+    float lr, momentum, weight_decay;
+} lsn_sgd_group;
+int64_t lsn_clip_sgd_workspace_bytes(void);
+int lsn_clip_sgd_step(int n_tensors, const lsn_sgd_tensor *tensors_dev, int64_t total_chunks, int n_groups,
+                      const lsn_sgd_group *groups, float max_norm, void *workspace, float *stats, lsn_stream_t stream);
+
 /* ---- LSHead's cumulative offset rescaling: lsnet_head.py:622-638 ------------------------------ [fused]
  * The reference multiplies a level's offset field IN PLACE by (scale_h, scale_w) of each of the three source levels it
  * visits, so the pyramid convolutions of a destination level see off*m1, off*m1*m2, off*m1*m2*m3 (y channels by mh, x

@@ -49,6 +49,15 @@ class WgradBnJob(ctypes.Structure):
                 ('grad_w', ctypes.c_void_p), ('grad_gamma', ctypes.c_void_p), ('grad_beta', ctypes.c_void_p)]
 
 
+class SgdTensor(ctypes.Structure):
+    _fields_ = [('param', ctypes.c_void_p), ('grad', ctypes.c_void_p), ('momentum_buf', ctypes.c_void_p),
+                ('numel', ctypes.c_int64), ('first_chunk', ctypes.c_int64), ('group', ctypes.c_int)]
+
+
+class SgdGroup(ctypes.Structure):
+    _fields_ = [('lr', ctypes.c_float), ('momentum', ctypes.c_float), ('weight_decay', ctypes.c_float)]
+
+
 class ConvLevel(ctypes.Structure):
     _fields_ = [('x', ctypes.c_void_p), ('out', ctypes.c_void_p), ('grad_out', ctypes.c_void_p),
                 ('B', ctypes.c_int), ('H', ctypes.c_int), ('W', ctypes.c_int), ('residual', ctypes.c_void_p),
@@ -82,7 +91,7 @@ EXPORTS = [
     'lsn_pyramid_deform_conv_backward_parameters',
     'lsn_sigmoid_focal_loss_forward', 'lsn_sigmoid_focal_loss_backward', 'lsn_sigmoid_focal_loss_sum',
     'lsn_sigmoid_focal_loss_backward_weighted',
-    'lsn_nms_workspace_bytes', 'lsn_nms', 'lsn_topk_columns', 'lsn_offset_chain_forward', 'lsn_offset_chain_backward', 'lsn_selftest_mfma', 'lsn_debug_phase_clocks',
+    'lsn_nms_workspace_bytes', 'lsn_nms', 'lsn_topk_columns', 'lsn_offset_chain_forward', 'lsn_offset_chain_backward', 'lsn_clip_sgd_workspace_bytes', 'lsn_clip_sgd_step', 'lsn_selftest_mfma', 'lsn_debug_phase_clocks',
     'lsn_prof_enable', 'lsn_prof_read',
     'lsn_group_norm_workspace_bytes', 'lsn_group_norm_forward', 'lsn_group_norm_backward',
     'lsn_set_math_mode', 'lsn_get_math_mode', 'lsn_conv2d_forward', 'lsn_conv2d_forward_pitched', 'lsn_conv2d_backward_data',
@@ -117,6 +126,7 @@ def load():
     lib.lsn_group_norm_workspace_bytes.restype = ctypes.c_int64
     lib.lsn_bn_eval_act_workspace_bytes.restype = ctypes.c_int64
     lib.lsn_dcn_backward_workspace_bytes.restype = ctypes.c_int64
+    lib.lsn_clip_sgd_workspace_bytes.restype = ctypes.c_int64
     lib.lsn_conv2d_prepared_bytes.restype = ctypes.c_int64
     for name in EXPORTS:
         getattr(lib, name)  # AttributeError here means header and library disagree

@@ -165,10 +165,15 @@ template <int NPL>
 __global__ void conv_wfrag_multi_kernel(const WfragJob *__restrict__ jobs, int njobs, long long total)
 {
     for (long long id = blockIdx.x * (long long)blockDim.x + threadIdx.x; id < total; id += (long long)gridDim.x * blockDim.x) {
-        int lo = 0, hi = njobs - 1;   // last job with start <= id
+        // a job's thread count is a multiple of 128 (wfrag_threads), so the 64 consecutive ids of a wave share their job:
+        // the search runs on the wave's first id, in scalar registers (per-lane it was eight dependent vector loads)
+        const unsigned lo32 = __builtin_amdgcn_readfirstlane((unsigned)(id & 0xffffffffll));
+        const unsigned hi32 = __builtin_amdgcn_readfirstlane((unsigned)(id >> 32));
+        const long long id0 = ((long long)hi32 << 32) | lo32;
+        int lo = 0, hi = njobs - 1;   // last job with start <= id0
         while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;
-            if (jobs[mid].start <= id) lo = mid; else hi = mid - 1;
+            if (jobs[mid].start <= id0) lo = mid; else hi = mid - 1;
         }
         const WfragJob jb = jobs[lo];
         wfrag_item<NPL>(jb, id - jb.start);

@@ -246,23 +246,33 @@ __device__ __forceinline__ unsigned topk_key(float v, bool largest)
     return largest ? ~u : u;
 }
 
-__global__ __launch_bounds__(256) void topk_cols_kernel(const float *__restrict__ x, int ldx, int G, TopkSegs segs, int k, int largest,
-                                                        float *__restrict__ vals, long long *__restrict__ idx, int cap)
+__global__ __launch_bounds__(1024) void topk_cols_kernel(const float *__restrict__ x, int ldx, int G, TopkSegs segs, int k, int largest,
+                                                         float *__restrict__ vals, long long *__restrict__ idx, int cap)
 {
+    // 1024 threads: the column is read with a stride of G floats -- one element per 4 x G bytes, nothing to coalesce -- so
+    // the read is a latency problem: 16 waves with 8 independent loads each in flight (256 threads and a rolled loop took
+    // 75 us for the centroid assigner's 22 400-row columns, profiles/r4c_kernel_stats.txt)
     extern __shared__ unsigned keys[];      // min(len, cap) keys of the segment's column
-    __shared__ unsigned long long red[4];
+    __shared__ unsigned long long red[16];
     const int g = blockIdx.x, sg = blockIdx.y;
     const int start = segs.start[sg], n = segs.len[sg];
     const int tid = threadIdx.x;
     const float *col = x + (size_t)start * ldx + g;
     const int nc = n < cap ? n : cap;
-    for (int i = tid; i < nc; i += 256) keys[i] = topk_key(col[(size_t)i * ldx], largest != 0);
+    for (int i0 = tid; i0 < nc; i0 += 8 * 1024) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = i0 + u * 1024 < nc ? col[(size_t)(i0 + u * 1024) * ldx] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (i0 + u * 1024 < nc) keys[i0 + u * 1024] = topk_key(v[u], largest != 0);
+    }
     __syncthreads();
     unsigned long long last = 0;            // (key << 32 | row) of the previous pick; picks are strictly increasing
     bool first = true;
     for (int r = 0; r < k; ++r) {
         unsigned long long best = ~0ull;
-        for (int i = tid; i < n; i += 256) {
+        for (int i = tid; i < n; i += 1024) {
             const unsigned key = i < nc ? keys[i] : topk_key(col[(size_t)i * ldx], largest != 0);
             const unsigned long long c = ((unsigned long long)key << 32) | (unsigned)i;
             if ((first || c > last) && c < best) best = c;
@@ -276,7 +286,7 @@ __global__ __launch_bounds__(256) void topk_cols_kernel(const float *__restrict_
         __syncthreads();
         best = red[0];
 #pragma unroll
-        for (int w = 1; w < 4; ++w) best = red[w] < best ? red[w] : best;
+        for (int w = 1; w < 16; ++w) best = red[w] < best ? red[w] : best;
         __syncthreads();
         if (tid == 0) {
             const size_t o = ((size_t)sg * k + r) * G + g;
@@ -291,7 +301,6 @@ __global__ __launch_bounds__(256) void topk_cols_kernel(const float *__restrict_
         last = best, first = false;
     }
 }
-
 
 // ---------------------------------------------------------------------------------------------
 // The offsets LSHead hands to its pyramid convolutions (lsnet_head.py:622-638): a level's offset field is rescaled IN
@@ -333,6 +342,125 @@ __global__ __launch_bounds__(256) void offset_chain_kernel(const ChainArgs a)
             asm volatile("v_mul_f32 %0, %1, %2" : "=v"(p1) : "v"(t1), "v"(m1));
             const float t0 = g0 + p1;
             L.goff[i] = t0 * m0;
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Gradient clipping + SGD step (mmcv/runner/hooks/optimizer.py:8-28: clip_grad_norm_(params, max_norm, 2) then
+// torch.optim.SGD.step()) over every parameter tensor in three launches: partial sums of squares, their ordered sum -> the
+// total norm and the clip coefficient (device scalars, no host read), the update.  Per element, with every operation
+// rounded as the torch operator sequence rounds it (multiplication by the coefficient; grad.add(param, alpha = wd) and
+// param.add_(buf, alpha = -lr) as fused multiply-adds, which is how ATen's `a + alpha * b` compiles; buf.mul_(momentum)
+// and the addition behind it separately):
+//     g' = g c,   d = fma(wd, p, g'),   buf = (buf m) + d,   p = fma(-lr, buf, p)
+// A zero-filled momentum buffer gives the first step's buf = d, as torch's clone of the gradient does.
+// ---------------------------------------------------------------------------------------------
+struct SgdArgs {
+    const lsn_sgd_tensor *t;      // device table, sorted by `start`
+    int n;
+    long long chunks;             // 1024-float4 chunks of all tensors
+    lsn_sgd_group g[8];
+    float max_norm;
+    double *partial;              // [gridDim.x] sums of squares
+    float *stats;                 // [0] total norm, [1] clip coefficient (1 without clipping)
+};
+
+__device__ __forceinline__ int sgd_find(const SgdArgs &a, long long chunk)
+{
+    int lo = 0, hi = a.n - 1;     // last tensor with first_chunk <= chunk (wave-uniform: a workgroup owns a chunk)
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (a.t[mid].first_chunk <= chunk) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void sgd_sqnorm_kernel(const SgdArgs a)
+{
+    __shared__ double red[4];
+    double acc = 0.0;
+    for (long long c = blockIdx.x; c < a.chunks; c += gridDim.x) {
+        const lsn_sgd_tensor T = a.t[sgd_find(a, c)];
+        const long long e0 = (c - T.first_chunk) * 4096 + threadIdx.x * 4;
+        float s = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long e = e0 + u * 1024;
+            if (e + 3 < T.numel) {
+                const float4 v = *reinterpret_cast<const float4 *>(T.grad + e);
+                s += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+            } else {
+                for (long long q = e; q < T.numel && q < e + 4; ++q) s += T.grad[q] * T.grad[q];
+            }
+        }
+        acc += (double)s;
+    }
+    for (int m = 1; m < 64; m <<= 1) acc += __shfl_xor(acc, m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) a.partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void sgd_coef_kernel(const SgdArgs a, int nparts)
+{
+    __shared__ double red[4];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) acc += a.partial[i];
+    for (int m = 1; m < 64; m <<= 1) acc += __shfl_xor(acc, m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float total = (float)sqrt((red[0] + red[1]) + (red[2] + red[3]));
+        const float coef = a.max_norm / (total + 1e-6f);      // clip_grad_norm_: clip_coef, clamped to <= 1
+        a.stats[0] = total;
+        a.stats[1] = coef < 1.f ? coef : 1.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void sgd_step_kernel(const SgdArgs a)
+{
+    const float coef = a.max_norm > 0.f ? a.stats[1] : 1.f;
+    const bool scaled = coef != 1.f;      // torch scales the gradients in place: keep p.grad as the reference leaves it
+    for (long long c = blockIdx.x; c < a.chunks; c += gridDim.x) {
+        const lsn_sgd_tensor T = a.t[sgd_find(a, c)];
+        const lsn_sgd_group G = a.g[T.group];
+        const float nlr = -G.lr;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long e = (c - T.first_chunk) * 4096 + u * 1024 + threadIdx.x * 4;
+            if (e >= T.numel) continue;
+            const int cnt = T.numel - e >= 4 ? 4 : (int)(T.numel - e);
+            float g[4], p[4], b[4];
+            if (cnt == 4) {
+                const float4 gv = *reinterpret_cast<const float4 *>(T.grad + e), pv = *reinterpret_cast<const float4 *>(T.param + e);
+                const float4 bv = *reinterpret_cast<const float4 *>(T.momentum_buf + e);
+                g[0] = gv.x, g[1] = gv.y, g[2] = gv.z, g[3] = gv.w, p[0] = pv.x, p[1] = pv.y, p[2] = pv.z, p[3] = pv.w;
+                b[0] = bv.x, b[1] = bv.y, b[2] = bv.z, b[3] = bv.w;
+            } else {
+                for (int q = 0; q < 4; ++q) g[q] = q < cnt ? T.grad[e + q] : 0.f, p[q] = q < cnt ? T.param[e + q] : 0.f, b[q] = q < cnt ? T.momentum_buf[e + q] : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float gs, bm;
+                asm volatile("v_mul_f32 %0, %1, %2" : "=v"(gs) : "v"(g[q]), "v"(coef));          // g' = g c          (rounded)
+                const float d = G.weight_decay != 0.f ? __builtin_fmaf(G.weight_decay, p[q], gs) : gs;
+                asm volatile("v_mul_f32 %0, %1, %2" : "=v"(bm) : "v"(b[q]), "v"(G.momentum));     // buf m             (rounded)
+                float bn;
+                asm volatile("v_add_f32 %0, %1, %2" : "=v"(bn) : "v"(bm), "v"(d));               // + d               (rounded)
+                g[q] = gs, b[q] = bn, p[q] = __builtin_fmaf(nlr, bn, p[q]);
+            }
+            if (cnt == 4) {
+                *reinterpret_cast<float4 *>(T.param + e) = make_float4(p[0], p[1], p[2], p[3]);
+                *reinterpret_cast<float4 *>(T.momentum_buf + e) = make_float4(b[0], b[1], b[2], b[3]);
+                if (scaled) *reinterpret_cast<float4 *>(T.grad + e) = make_float4(g[0], g[1], g[2], g[3]);
+            } else {
+                for (int q = 0; q < cnt; ++q) {
+                    T.param[e + q] = p[q], T.momentum_buf[e + q] = b[q];
+                    if (scaled) T.grad[e + q] = g[q];
+                }
+            }
         }
     }
 }
@@ -459,7 +587,7 @@ int lsn_topk_columns(const float *x, int P, int G, int ldx, int nseg, const int 
                                     36 * 1024 * 4));
         attr_set = true;
     }
-    hipLaunchKernelGGL(lsn::topk_cols_kernel, dim3(G, nseg), dim3(256), (size_t)cap * 4, stream, x, ldx, G, segs, k, largest,
+    hipLaunchKernelGGL(lsn::topk_cols_kernel, dim3(G, nseg), dim3(1024), (size_t)cap * 4, stream, x, ldx, G, segs, k, largest,
                        values, reinterpret_cast<long long *>(indices), cap);
     LSN_HIP(hipGetLastError());
     return 0;
@@ -500,6 +628,28 @@ int lsn_offset_chain_forward(int n_levels, const lsn_offset_chain_level *levels,
 int lsn_offset_chain_backward(int n_levels, const lsn_offset_chain_level *levels, int C, lsn_stream_t stream)
 {
     return offset_chain_launch(n_levels, levels, C, true, stream);
+}
+
+int64_t lsn_clip_sgd_workspace_bytes(void) { return 2048 * 8 + 64; }
+
+int lsn_clip_sgd_step(int n_tensors, const lsn_sgd_tensor *tensors_dev, int64_t total_chunks, int n_groups,
+                      const lsn_sgd_group *groups, float max_norm, void *workspace, float *stats, lsn_stream_t stream)
+{
+    LSN_CHECK(n_tensors >= 1 && tensors_dev && total_chunks >= 1 && n_groups >= 1 && n_groups <= 8 && groups && workspace && stats,
+              "clip + SGD step: bad arguments");
+    lsn::SgdArgs a;
+    a.t = tensors_dev, a.n = n_tensors, a.chunks = total_chunks, a.max_norm = max_norm;
+    for (int i = 0; i < n_groups; ++i) a.g[i] = groups[i];
+    a.partial = reinterpret_cast<double *>(workspace);
+    a.stats = stats;
+    const int blocks = (int)(total_chunks < 2048 ? total_chunks : 2048);
+    if (max_norm > 0.f) {
+        hipLaunchKernelGGL(lsn::sgd_sqnorm_kernel, dim3(blocks), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(lsn::sgd_coef_kernel, dim3(1), dim3(256), 0, stream, a, blocks);
+    }
+    hipLaunchKernelGGL(lsn::sgd_step_kernel, dim3(blocks), dim3(256), 0, stream, a);
+    LSN_HIP(hipGetLastError());
+    return 0;
 }
 
 }  // extern "C"

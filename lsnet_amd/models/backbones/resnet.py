@@ -147,14 +147,14 @@ class ResLayer(nn.Sequential):
     def forward(self, x):
         blocks = list(self)
         ok = [fused_block_ok(b, x) for b in blocks]   # (a fused block hands a tensor of the same kind to the next one)
-        # blocks 1 .. n-1 are built alike (__init__ below): when all of them run fused, their weight gradients of one layer
-        # position are ONE launch, issued by block 1's backward -- the last of the group to run
-        group = len(blocks) > 2 and all(ok[1:]) and torch.is_grad_enabled()
+        # blocks 1 .. n-1 are built alike (__init__ below), and block 0's conv3 has their conv3's geometry: when the whole
+        # stage runs fused, the weight gradients of one geometry are ONE launch, issued by block 0's backward -- the last
+        group = len(blocks) > 2 and all(ok) and torch.is_grad_enabled()
         queue = {} if group else None
         for i, b in enumerate(blocks):
             if ok[i]:
                 x = b(x, pregate_in=i > 0 and ok[i - 1], gy_pregated=i + 1 < len(blocks) and ok[i + 1],
-                      wg_queue=queue if i >= 1 else None, wg_flush=group and i == 1)
+                      wg_queue=queue, wg_flush=group and i == 0)
             else:
                 x = b(x)
         return x

@@ -89,11 +89,13 @@ class _BottleneckFn(torch.autograd.Function):
             # (On a second HIP stream beside the data gradients these launches LOST: 37.05 vs 35.98 ms per step, weight
             # gradients 8.1 vs 6.6 ms, data gradients 5.8 vs 4.9 -- profiles/r4_side_stream.txt.  Both kernel streams fill
             # the chip on their own; sharing it costs each more than the overlap of their tails returns.)
-            # The identical blocks of a stage queue their three layers instead (gradient sinks only: nothing to hand to
-            # autograd): the stage's last backward launches conv1 / conv2 / conv3 of all of them together.
+            # The fused blocks of a stage queue their layers instead (gradient sinks only: nothing to hand to autograd): the
+            # stage's last backward launches the layers of one geometry together -- conv1 / conv2 / conv3 of the identical
+            # blocks 1 .. n-1, block 0's conv3 with them.
             if queue is not None and slot is not None and getattr(K, 'wgrad_bn_deferrable', None) \
                     and K.wgrad_bn_deferrable(conv.weight, bn):
-                queue.setdefault(slot, []).append((xin, g, conv.weight, bn, _cfg(conv)))
+                key = (tuple(xin.shape), tuple(conv.weight.shape), _cfg(conv))     # one launch per geometry
+                queue.setdefault(key, []).append((xin, g, conv.weight, bn))
                 return None, None, None
             return K.wgrad_bn(xin, g, conv.weight, bn, *_cfg(conv))
 
@@ -121,17 +123,15 @@ class _BottleneckFn(torch.autograd.Function):
 
 
 def flush_wgrad_queue(queue):
-    """The queued weight-gradient jobs of a stage's identical blocks, one launch per layer position."""
-    for slot in ('conv3', 'conv2', 'conv1'):
-        jobs = queue.pop(slot, [])
-        if not jobs:
-            continue
-        cfg = jobs[0][4]
-        if len(jobs) > 1 and all(j[4] == cfg and j[0].shape == jobs[0][0].shape and j[2].shape == jobs[0][2].shape for j in jobs):
-            K.wgrad_bn_jobs([j[:4] for j in jobs], *cfg)
+    """The queued weight-gradient jobs of a stage, one launch per geometry (layers of one geometry: conv1 / conv2 / conv3 of
+    the identical blocks, and block 0's conv3 with them)."""
+    for key in list(queue):
+        jobs = queue.pop(key)
+        cfg = key[2]
+        if len(jobs) > 1:
+            K.wgrad_bn_jobs(jobs, *cfg)
         else:
-            for xin, g, w, bn, c in jobs:
-                K.wgrad_bn(xin, g, w, bn, *c)
+            K.wgrad_bn(*jobs[0], *cfg)
 
 
 def bottleneck_ok(blk):

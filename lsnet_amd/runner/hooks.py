@@ -122,11 +122,28 @@ class OptimizerHook(Hook):
             runner.outputs['loss'].backward()
             if hasattr(runner.model, 'reduce_gradients'):
                 runner.model.reduce_gradients()
+        fused = self._fused_step(runner)
+        if fused is not None:      # clip + SGD in the library (runner/fused_sgd.py): same operations, three launches
+            norm = fused.step()
+            if norm is not None:
+                runner.log_buffer_update({'grad_norm': norm.clone()}, runner.outputs['num_samples'])
+            return
         if self.grad_clip is not None:
             norm = self.clip_grads(runner.model.parameters())
             if norm is not None:
                 runner.log_buffer_update({'grad_norm': norm.detach()}, runner.outputs['num_samples'])
         runner.optimizer.step()
+
+    def _fused_step(self, runner):
+        """The library's clip + SGD plan for this runner, or None (not SGD with plain momentum, gradients that are not stable
+        views of the all-reduce buckets, CPU)."""
+        if not hasattr(runner.model, 'zero_grad_buckets') or not torch.cuda.is_available():
+            return None
+        plan = getattr(runner, '_clip_sgd', None)
+        if plan is None or plan.opt is not runner.optimizer or (plan.ok and not plan.still_valid()):
+            from .fused_sgd import ClipSGD
+            plan = runner._clip_sgd = ClipSGD(runner.optimizer, self.grad_clip)
+        return plan if plan.ok else None
 
 
 @HOOKS.register_module()

@@ -193,13 +193,13 @@ def test_identical_blocks_share_their_weight_gradient_launches(monkeypatch, torc
     assert torch.allclose(y0, y1, rtol=1e-10, atol=1e-10) and torch.allclose(gx0, gx1, rtol=1e-9, atol=1e-10)
     for k in gp0:
         assert torch.allclose(gp0[k], gp1[k], rtol=1e-9, atol=1e-9), k
-    assert SinkPrims.batches == [3, 3, 3]            # conv3, conv2, conv1 of blocks 1 .. 3, one launch each
-    # two identical blocks only in a three-block stage; a two-block stage has no group
+    assert SinkPrims.batches == [4, 3, 3]            # conv3 of all four blocks; conv2, conv1 of the identical blocks 1 .. 3
+    # stride 1: block 0's conv2 has the others' geometry too; a two-block stage has no group
     SinkPrims.batches = []
     layer = _make_layer(16, 8, 3, 1)
     _, _, gp0 = _run(layer, x, fused=False)
     _, _, gp1 = _run(layer, x, fused=True)
-    assert all(torch.allclose(gp0[k], gp1[k], rtol=1e-9, atol=1e-9) for k in gp0) and SinkPrims.batches == [2, 2, 2]
+    assert all(torch.allclose(gp0[k], gp1[k], rtol=1e-9, atol=1e-9) for k in gp0) and SinkPrims.batches == [3, 3, 2]
     SinkPrims.batches = []
     layer = _make_layer(16, 8, 2, 1)
     _, _, gp0 = _run(layer, x, fused=False)
