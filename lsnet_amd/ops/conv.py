@@ -49,6 +49,12 @@ def _after_optimizer_step(*_):
     _opt_epoch[0] += 1
 
 
+def parameters_updated():
+    """For optimizers that do not derive from torch.optim.Optimizer (runner/fused_sgd.py writes the parameters from its own
+    kernel): the trainable weights moved -- what the global post-step hook tells the cache for torch's optimizers."""
+    _after_optimizer_step()
+
+
 from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_post_step  # noqa: E402
 
 _reg_post_step(_after_optimizer_step)

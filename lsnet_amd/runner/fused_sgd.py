@@ -12,6 +12,7 @@ import ctypes
 import torch
 
 from .. import _lib
+from ..ops import conv as _conv
 
 
 def _dense_like(a, b):
@@ -83,4 +84,5 @@ class ClipSGD:
         _lib.check(lib.lsn_clip_sgd_step(len(self.entries), ctypes.c_void_p(self.table.data_ptr()), self.chunks, len(self.groups),
                                          self.groups, ctypes.c_float(self.max_norm), ctypes.c_void_p(self.ws.data_ptr()),
                                          ctypes.c_void_p(self.stats.data_ptr()), stream))
+        _conv.parameters_updated()      # the cached weight images of the convolutions are stale now
         return self.stats[0] if self.max_norm > 0 else None

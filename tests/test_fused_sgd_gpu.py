@@ -64,3 +64,70 @@ def test_clip_sgd_step_matches_torch(max_norm):
                 assert float((a.detach() - b.detach()).abs().max()) <= 2e-6 * float(b.detach().abs().max()) + 1e-9, (kind, step)
                 if clipped:         # the gradients were scaled in place, as clip_grad_norm_ leaves them
                     assert float((a.grad - b.grad).abs().max()) <= 2e-6 * float(b.grad.abs().max())
+
+
+def test_fused_step_invalidates_the_weight_images():
+    """The convolutions read prepared weight images (ops/conv.py); an optimizer that writes the parameters from its own
+    kernel has to tell the cache (conv.parameters_updated) -- round 4's first version did not, and every dense convolution
+    ran on the weights of step 0 while the benchmark got 0.25 ms faster."""
+    import torch.nn.functional as F
+    from lsnet_amd.ops.conv import Conv2d
+    from lsnet_amd.runner.fused_sgd import ClipSGD
+    dev = torch.device('cuda:0')
+    torch.manual_seed(0)
+    conv = Conv2d(64, 128, 3, padding=1, bias=False).to(dev).to(memory_format=torch.channels_last)
+    x = torch.randn(2, 64, 20, 24, device=dev).contiguous(memory_format=torch.channels_last)
+    y0 = conv(x)                                                  # builds the image of the initial weight
+    w0 = conv.weight.detach().clone()
+    conv.weight.grad = torch.randn_like(conv.weight)
+    opt = torch.optim.SGD(conv.parameters(), lr=0.5, momentum=0.9, weight_decay=0.0)
+    plan = ClipSGD(opt, dict(max_norm=1e9, norm_type=2))
+    assert plan.ok
+    plan.step()
+    assert float((conv.weight.detach() - w0).abs().max()) > 0.1    # the weight moved ...
+    y1 = conv(x)
+    ref = F.conv2d(x.double(), conv.weight.detach().double(), None, 1, 1)
+    assert float((y1.double() - ref).abs().max()) < 1e-4 * float(ref.abs().max())   # ... and the convolution saw it
+    assert float((y1 - y0).abs().max()) > 0.1
+
+
+def test_runner_steps_equal_torch_optimizer_steps():
+    """Four iterations of the runner on the real detector (data-parallel wrapper: gradients in the reducer's buckets, so the
+    hook takes the library path) against the same four with clip_grad_norm_ + torch.optim.SGD.step(): the same losses --
+    at the full base learning rate, where a convolution left on stale weights shows in the second iteration."""
+    import sys
+    import bench
+    from lsnet_amd.data import synthetic_batch
+    from lsnet_amd.model_zoo import build_lsnet
+    from lsnet_amd.parallel import DataParallelModel
+    from lsnet_amd.runner import hooks
+    dev = torch.device('cuda:0')
+
+    def run(fused):
+        torch.manual_seed(0)
+        model, cfg = build_lsnet('bbox', 'r50')
+        cfg.lr_config = dict(policy='step', step=[8, 11])          # no warm-up: lr = 0.01 from the first iteration
+        model = DataParallelModel(model.to(dev).to(memory_format=torch.channels_last).train())
+        real = hooks.OptimizerHook._fused_step
+        used = []
+        try:
+            if fused:
+                hooks.OptimizerHook._fused_step = lambda self, runner: (used.append(1), real(self, runner))[1]
+            else:
+                hooks.OptimizerHook._fused_step = lambda self, runner: None
+            step, runner = bench.build_step(model, cfg)
+            data = synthetic_batch('bbox', 2, 384, 480, seed=5, device=dev)
+            losses = []
+            for _ in range(4):
+                losses.append(float(step(data)['log_vars']['loss']))
+        finally:
+            hooks.OptimizerHook._fused_step = real
+        return losses, len(used)
+
+    ref, _ = run(False)
+    got, n = run(True)
+    assert n == 4 and getattr(hooks, 'OptimizerHook')
+    assert abs(ref[0] - got[0]) < 1e-6 * abs(ref[0])
+    assert abs(ref[1] - ref[0]) > 1e-3 * abs(ref[0])               # the steps move the loss ...
+    for a, b in zip(ref, got):
+        assert abs(a - b) < 2e-4 * abs(a), (ref, got)              # ... and both optimizers move it alike
