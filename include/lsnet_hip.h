@@ -261,11 +261,12 @@ int lsn_clip_sgd_step(int n_tensors, const lsn_sgd_tensor *tensors_dev, int64_t 
  * launch returns goff = ((g3 m3 + g2) m2 + g1) m1 -- every product and sum a separately rounded fp32 operation, i.e.
  * bit-identical to the sequence of ATen multiplications / autograd additions it replaces.
  * Tensors: channels-last (B, C, H, W) with C = 2 * taps; `off` may have any image pitch (a slice of the concatenated
- * levels), everything else is dense.  forward reads off / writes out[3]; backward reads gout[3] (NULL = zero) / writes goff. */
+ * levels), everything else is dense.  forward reads off / writes out[3]; backward reads gout[6] (NULL = zero; gout[k] + gout[3 + k] is field k's gradient, as
+ * autograd would have accumulated it for a field with two consumers) / writes goff. */
 typedef struct {
     const float *off;
     float *out[3];
-    const float *gout[3];
+    const float *gout[6];   /* [0..2]: gradients of the three fields; [3..5]: of a second consumer's aliases of them (NULL = none) */
     float *goff;
     int64_t images, per_image, off_image_pitch;   /* B, H*W*C, floats between the images of `off` */
     float mh[3], mw[3];

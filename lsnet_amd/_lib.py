@@ -38,7 +38,7 @@ class DcnLevel(ctypes.Structure):
 
 
 class OffsetChainLevel(ctypes.Structure):
-    _fields_ = [('off', ctypes.c_void_p), ('out', ctypes.c_void_p * 3), ('gout', ctypes.c_void_p * 3), ('goff', ctypes.c_void_p),
+    _fields_ = [('off', ctypes.c_void_p), ('out', ctypes.c_void_p * 3), ('gout', ctypes.c_void_p * 6), ('goff', ctypes.c_void_p),
                 ('images', ctypes.c_int64), ('per_image', ctypes.c_int64), ('off_image_pitch', ctypes.c_int64),
                 ('mh', ctypes.c_float * 3), ('mw', ctypes.c_float * 3)]
 

@@ -335,7 +335,10 @@ __global__ __launch_bounds__(256) void offset_chain_kernel(const ChainArgs a)
         } else {
             // products through an asm statement: hipcc's __fmul_rn / __fadd_rn are plain operators, and -ffp-contract=fast fuses
             // them with the additions (and does not honour `#pragma clang fp contract(off)`)
-            const float g0 = L.gout[0] ? L.gout[0][i] : 0.f, g1 = L.gout[1] ? L.gout[1][i] : 0.f, g2 = L.gout[2] ? L.gout[2][i] : 0.f;
+            float g0 = L.gout[0] ? L.gout[0][i] : 0.f, g1 = L.gout[1] ? L.gout[1][i] : 0.f, g2 = L.gout[2] ? L.gout[2][i] : 0.f;
+            if (L.gout[3]) g0 = L.gout[0] ? g0 + L.gout[3][i] : L.gout[3][i];   // (the accumulation autograd does for two consumers)
+            if (L.gout[4]) g1 = L.gout[1] ? g1 + L.gout[4][i] : L.gout[4][i];
+            if (L.gout[5]) g2 = L.gout[2] ? g2 + L.gout[5][i] : L.gout[5][i];
             float p2, p1;
             asm volatile("v_mul_f32 %0, %1, %2" : "=v"(p2) : "v"(g2), "v"(m2));
             const float t1 = g1 + p2;

@@ -330,16 +330,22 @@ class LSHead(nn.Module):
                 trio.append((sh, sw))
                 pairs.append((l, s, sh, sw))
             mults.append(trio)
-        # (one launch per branch and direction on the device; three multiplications per level elsewhere)
-        scaled = {b: [t for trio in offset_scale_chain(st[b]['off'], mults) for t in trio] for b in self.branches}
+        # (one launch per branch and direction on the device; three multiplications per level elsewhere.  The last branch's
+        # fields also steer the classification gather: it gets its own handles, so the two gradients meet in the launch)
+        driver = self.branches[-1]
+        scaled, scaled_cls = {}, None
+        for b in self.branches:
+            sets = offset_scale_chain(st[b]['off'], mults, copies=2 if b == driver else 1)
+            scaled[b] = [t for trio in sets[0] for t in trio]
+            if b == driver:
+                scaled_cls = [t for trio in sets[1] for t in trio]
         scales = [(p[2], p[3]) for p in pairs]
 
         def gather(conv, src_feats, offsets):
             # the three maps of a destination level side by side in one tensor (the reference concatenates them next)
             return conv.forward_multi([src_feats[p[1]] for p in pairs], offsets, scales, concat=3)
 
-        driver = self.branches[-1]
-        cls_raw = gather(self.pts_cls_conv, cls_feats, scaled[driver])
+        cls_raw = gather(self.pts_cls_conv, cls_feats, scaled_cls)
         outs = {}
         def fuse(af, fc, raw, feat):
             # relu(1x1 over the three gathered maps of a level) + 3x3 over the level's tower output: each of the two

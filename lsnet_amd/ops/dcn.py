@@ -184,34 +184,44 @@ class _DCNPackFn(Function):
 
 
 class _OffsetChainFn(Function):
-    """forward(mults, off_0 .. off_{n-1}) -> 3 n tensors: for level l the fields off_l m1, (off_l m1) m2, ((off_l m1) m2) m3
-    with m_k = mults[l][k] = (scale_h, scale_w) on the (y, x) channel pairs -- one launch forward, one backward."""
+    """forward(mults, copies, off_0 .. off_{n-1}) -> 3 n copies tensors: for level l the fields off_l m1, (off_l m1) m2,
+    ((off_l m1) m2) m3 with m_k = mults[l][k] = (scale_h, scale_w) on the (y, x) channel pairs -- one launch forward, one
+    backward.  copies = 2: every field comes back twice (the second an alias), one per consumer, and the backward launch adds
+    the two gradients itself -- what autograd's accumulation would have been a launch per field for."""
 
     @staticmethod
-    def forward(ctx, mults, *offs):
+    def forward(ctx, mults, copies, *offs):
         be = get_backend(offs[0])
-        ctx.mults, ctx.be, ctx.device = mults, be, offs[0].device
+        ctx.mults, ctx.be, ctx.device, ctx.copies = mults, be, offs[0].device, copies
         ctx.shapes = [tuple(o.shape) for o in offs]
-        return tuple(t for trio in be.offset_chain(list(offs), mults) for t in trio)
+        res = be.offset_chain(list(offs), mults)
+        out = [t for trio in res for t in trio]
+        if copies == 2:
+            out += [t.view(t.shape) for t in out]
+        return tuple(out)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, *grads):
-        gs = [grads[3 * l:3 * l + 3] for l in range(len(ctx.shapes))]
-        return (None, *ctx.be.offset_chain_backward(ctx.shapes, ctx.device, ctx.mults, gs))
+        n = len(ctx.shapes)
+        gs = [list(grads[3 * l:3 * l + 3]) + (list(grads[3 * n + 3 * l:3 * n + 3 * l + 3]) if ctx.copies == 2 else [])
+              for l in range(n)]
+        return (None, None, *ctx.be.offset_chain_backward(ctx.shapes, ctx.device, ctx.mults, gs))
 
 
-def offset_scale_chain(offs, mults):
+def offset_scale_chain(offs, mults, copies=1):
     """LSHead's cumulative offset rescaling (lsnet_head.py:622-638; the in-place `*=` of the reference accumulates over the
     three source levels of a destination level).  offs: per-level (B, 2 taps, H, W) fields; mults[l]: three (scale_h, scale_w)
-    pairs.  Returns per level the three fields [off m1, off m1 m2, off m1 m2 m3] -- each product rounded on its own, as the
-    three multiplications of the reference are."""
+    pairs.  Returns `copies` lists, each per level the three fields [off m1, off m1 m2, off m1 m2 m3] -- each product rounded
+    on its own, as the three multiplications of the reference are.  copies = 2 hands a second consumer its own handles of
+    the same fields (on the device their two gradients then meet inside the one backward launch)."""
     offs = list(offs)
-    if offs and all(o.is_cuda for o in offs) and len(offs) <= 8 and all(len(m) == 3 for m in mults):
+    if offs and all(o.is_cuda for o in offs) and len(offs) <= 8 and all(len(m) == 3 for m in mults) and copies in (1, 2):
         be = get_backend(offs[0])
         if all(be.offset_chain_ok(o) for o in offs):
-            flat = _OffsetChainFn.apply(tuple(tuple((float(a), float(b)) for a, b in m) for m in mults), *offs)
-            return [list(flat[3 * l:3 * l + 3]) for l in range(len(offs))]
+            n = len(offs)
+            flat = _OffsetChainFn.apply(tuple(tuple((float(a), float(b)) for a, b in m) for m in mults), copies, *offs)
+            return [[list(flat[c * 3 * n + 3 * l:c * 3 * n + 3 * l + 3]) for l in range(n)] for c in range(copies)]
     res = []
     for off, m in zip(offs, mults):
         cur, trio = off, []
@@ -220,7 +230,7 @@ def offset_scale_chain(offs, mults):
             cur = cur * mult
             trio.append(cur)
         res.append(trio)
-    return res
+    return [res] * copies
 
 
 def dcn_multi(inputs, offsets, masks, weight, bias=None, stride=1, padding=0, dilation=1, groups=1,

@@ -394,7 +394,8 @@ class HipBackend:
         return res
 
     def offset_chain_backward(self, shapes, device, mults, grads):
-        """grads[l]: the gradients of level l's three fields (entries may be None) -> per level the offset field's gradient."""
+        """grads[l]: the gradients of level l's three fields, then (optionally) of a second consumer's aliases of them --
+        3 or 6 entries, any of them None -> per level the offset field's gradient."""
         lib = _lib.load()
         n, C = len(shapes), shapes[0][1]
         lv = (_lib.OffsetChainLevel * n)()
@@ -404,7 +405,7 @@ class HipBackend:
             L.images, L.per_image = B, H * W * C
             for k in range(3):
                 L.mh[k], L.mw[k] = mults[l][k]
-                g = grads[l][k]
+            for k, g in enumerate(grads[l]):
                 if g is not None:
                     g = _f32(g, 'grad').contiguous(memory_format=_CL)
                     keep.append(g)

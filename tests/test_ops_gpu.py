@@ -352,7 +352,7 @@ def test_offset_scale_chain_bitwise():
             offs.append(flat[:, o:o + h * w].reshape(B, h, w, C).permute(0, 3, 1, 2))
             o += h * w
         if fused:
-            res = offset_scale_chain(offs, mults)
+            first, second = offset_scale_chain(offs, mults, copies=2)     # two consumers, each with its own handles
         else:
             res = []
             for off, m in zip(offs, mults):
@@ -361,9 +361,11 @@ def test_offset_scale_chain_bitwise():
                     cur = cur * off.new_tensor([sh, sw]).repeat(C // 2).view(1, -1, 1, 1)
                     trio.append(cur)
                 res.append(trio)
-        loss = sum((t * w).sum() for trio, wt in zip(res, ws) for t, w in zip(trio[:2], wt[:2])) + (res[0][2] * ws[0][2]).sum()
-        loss.backward()    # (the third field of levels 1 and 2 stays unused: a None gradient)
-        return [t.detach().clone() for trio in res for t in trio], flat.grad.clone()
+            first = second = res
+        loss = sum((t * w).sum() for trio, wt in zip(first, ws) for t, w in zip(trio[:2], wt[:2])) + (first[0][2] * ws[0][2]).sum()
+        loss = loss + sum((t * w.flip(0)).sum() for trio, wt in zip(second, ws) for t, w in zip(trio[1:], wt[1:]))
+        loss.backward()    # (first consumer: the third field of levels 1 and 2 unused; second: no first field)
+        return [t.detach().clone() for trio in first for t in trio], flat.grad.clone()
 
     o_ref, g_ref = run(False)
     o, gr = run(True)
