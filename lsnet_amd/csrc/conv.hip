@@ -67,22 +67,21 @@ static int part_buffer(size_t floats, float **p, hipStream_t st)
     return 0;
 }
 
-template <int TM, int TN, int WM, int WN, int NP, bool UNAL, bool FINE, bool TRANS = false>
-static int launch_conv_cfg(ConvArgs &a, int ks, hipStream_t st)
+// One launch over the pixel tiles [tile_base, tile_base + ntiles) of the (tiled) levels, `ks` chunk splits.
+template <int TM, int TN, int WM, int WN, int NP, bool UNAL, bool FINE, bool TRANS>
+static int launch_conv_range(ConvArgs &a, int ks, int tile_base, int ntiles, hipStream_t st)
 {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     const size_t lds = (size_t)2 * SplitCfg<NP>::NPL * BM * 64;
-    int tiles = 0;
-    for (int i = 0; i < a.nlv; ++i) {
-        a.lv[i].tile0 = tiles;
-        tiles += (a.lv[i].P + BM - 1) / BM;
-    }
-    a.ntiles = tiles;
     a.ksplit = ks;
-    const size_t n = (size_t)a.lv[0].P * a.Co;
+    a.tile_base = tile_base;
+    const int pix0 = tile_base * BM;   // (ks > 1: one level)
+    const int rows = ks > 1 ? (a.lv[0].P - pix0 < ntiles * BM ? a.lv[0].P - pix0 : ntiles * BM) : 0;
+    a.part_pix0 = pix0, a.part_rows = rows;
+    const size_t n = (size_t)rows * a.Co;
     if (ks > 1)
         if (int rc = part_buffer(n * ks, &a.part, st)) return rc;
-    dim3 grid(tiles, (a.Co + BN - 1) / BN, ks);
+    dim3 grid(ntiles, (a.Co + BN - 1) / BN, ks);
     auto k = conv_mm_kernel<TM, TN, WM, WN, NP, UNAL, FINE, TRANS>;
     static bool attr_set = false;   // per instantiation
     if (!attr_set) {
@@ -92,11 +91,57 @@ static int launch_conv_cfg(ConvArgs &a, int ks, hipStream_t st)
     hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a);
     if (ks > 1) {
         const int blocks = (int)((n / 4 + 255) / 256 < 1024 ? (n / 4 + 255) / 256 : 1024);
-        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, st, a.part, a.lv[0].out, a.bias,
-                           a.lv[0].res, a.lv[0].gate, (int)n, a.Co, ks, a.relu);
+        const size_t o = (size_t)pix0 * a.Co;
+        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, st, a.part, a.lv[0].out + o, a.bias,
+                           a.lv[0].res ? a.lv[0].res + o : nullptr, a.lv[0].gate ? a.lv[0].gate + o : nullptr, (int)n, a.Co, ks,
+                           a.relu);
     }
     LSN_HIP(hipGetLastError());
     return 0;
+}
+
+// Tail split.  The chip holds 512 workgroups at once; a launch of 525 runs 512, then 13 -- 226 us against 177 us for 512
+// (tools/ubench/tile_sweep, profiles/r4_conv_ablation.txt), and every single-level convolution at the 100 x 168 maps of
+// two images sits there (33 600 pixels = 525 tiles of 64: all of stage 2, the FPN's P3 convolutions).  When the last
+// round would be a small remainder, those pixel tiles get their own launch with the REDUCTION split `kt` ways (the
+// split-K machinery of the small layers): kt x remainder workgroups of 1 / kt the length + the partial-tile reduce.
+// Pays under a deep reduction only (tools/ubench/conv_step A/B, profiles/r4_tail_split.txt): FPN 3x3 at P3 249 -> 215 us
+// forward, 243 -> 231 data gradient, a 3x3 256 -> 80 at P3 132 -> 118; the 1x1 layers of stage 1 / 2 (4 .. 16 chunks) LOSE
+// 4 .. 8 us each to the second launch and the reduce -- hence the chunk threshold.
+static int tail_split(int total_wg, int colblocks, int Tall, int *tail_tiles)
+{
+#ifdef LSNET_AB
+    return 1;
+#endif
+    const int rem = total_wg % 512;
+    if (total_wg <= 512 || rem == 0 || rem > 128 || rem % colblocks != 0 || Tall < 48) return 1;
+    int kt = 384 / rem;
+    if (kt > Tall / 4) kt = Tall / 4;
+    if (kt > 16) kt = 16;
+    if (kt < 2) return 1;
+    *tail_tiles = rem / colblocks;
+    return kt;
+}
+
+template <int TM, int TN, int WM, int WN, int NP, bool UNAL, bool FINE, bool TRANS = false>
+static int launch_conv_cfg(ConvArgs &a, int ks, hipStream_t st)
+{
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    int tiles = 0;
+    for (int i = 0; i < a.nlv; ++i) {
+        a.lv[i].tile0 = tiles;
+        tiles += (a.lv[i].P + BM - 1) / BM;
+    }
+    a.ntiles = tiles;
+    const int colblocks = (a.Co + BN - 1) / BN;
+    int tail = 0;
+    const int kt = (a.nlv == 1 && !a.ostep && ks == 1 && !TRANS) ? tail_split(tiles * colblocks, colblocks, a.kh * a.kw * cv_ncc(a.C), &tail)
+                                                                : 1;
+    if (kt > 1) {
+        if (int rc = launch_conv_range<TM, TN, WM, WN, NP, UNAL, FINE, TRANS>(a, 1, 0, tiles - tail, st)) return rc;
+        return launch_conv_range<TM, TN, WM, WN, NP, UNAL, FINE, TRANS>(a, kt, tiles - tail, tail, st);
+    }
+    return launch_conv_range<TM, TN, WM, WN, NP, UNAL, FINE, TRANS>(a, ks, 0, tiles, st);
 }
 
 // FINE: the fine MFMA / staging interleave (conv_kernels.h) -- adopted for the two wide tiles after the round-4 sweep; for

@@ -53,6 +53,8 @@ struct ConvArgs {
                   // pixels under a deep reduction (layer 4, FPN P5 .. P7) would otherwise leave most CUs idle; fp32
                   // atomics into the output were measured 5 - 10 x slower than the whole convolution.
     float *part;
+    int tile_base;              // first pixel tile of this launch (a launch may cover a tile range of the level: conv.hip tail split)
+    int part_pix0, part_rows;   // partial tiles: row r of split z lies at part + (z * part_rows + r - part_pix0) * Co
     const unsigned short *wf;   // weights in fragment order (conv_wfrag_kernel)
     int wf_bytes;
     // output placement: pixel (b, ho, wo) of the (Ho, Wo) grid is stored at (b, oy0 + ho * ostep, ox0 + wo * ostep) of an
@@ -236,12 +238,12 @@ __global__ __launch_bounds__(256, 2) void conv_mm_kernel(const ConvArgs a)
     const int K = a.kh * a.kw;
     // XCD-ordered (pixel tile, column block) with the column blocks of a pixel tile adjacent (same input rows)
     const int work = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
-    const int ptile = work / (int)gridDim.y;
+    const int ptile = work / (int)gridDim.y + a.tile_base;
     int li = 0;
     while (li + 1 < a.nlv && ptile >= a.lv[li + 1].tile0) ++li;
     const ConvLvl &L = a.lv[li];
     const int tile_p = (ptile - L.tile0) * BM;
-    const int co_blk = (work - ptile * (int)gridDim.y) * BN;
+    const int co_blk = (work - (ptile - a.tile_base) * (int)gridDim.y) * BN;
     const int ncc = cv_ncc(a.C), NT = cv_nt(a.Co);
     const int Tall = K * ncc;
     const int t_begin = (int)((long long)Tall * blockIdx.z / gridDim.z);
@@ -478,7 +480,7 @@ __global__ __launch_bounds__(256, 2) void conv_mm_kernel(const ConvArgs a)
             const int ho = rem / L.Wo, wo = rem - ho * L.Wo;
             opix = ((size_t)b * a.OH + a.oy0 + ho * a.ostep) * a.OW + a.ox0 + wo * a.ostep;
         }
-        float *orow = partial ? a.part + ((size_t)blockIdx.z * L.P + pix) * a.Co : L.out + opix * a.Co;
+        float *orow = partial ? a.part + ((size_t)blockIdx.z * a.part_rows + (pix - a.part_pix0)) * a.Co : L.out + opix * a.Co;
         const bool fin = !partial;   // bias and ReLU belong to the finished sum
 #pragma unroll
         for (int j = 0; j < TN; ++j)

@@ -528,6 +528,9 @@ CONV_CASES = [
     (2, 64, 256, 3, 1, 1, 1, 48, 50, True),
     (1, 1024, 512, 1, 1, 0, 1, 50, 48, False),
     (2, 512, 256, 1, 2, 0, 1, 80, 84, True),
+    # 265 pixel tiles x 2 column blocks = 530 workgroups on 512 slots under a deep reduction: the last 9 pixel tiles run as
+    # their own launch with the reduction split (csrc/conv.hip tail_split), forward and data gradient
+    (1, 192, 512, 3, 1, 1, 1, 130, 130, True),
 ]
 
 
