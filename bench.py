@@ -290,9 +290,14 @@ ITER0_FIXTURE = os.path.join(ROOT, 'tests', 'golden', 'bench_iter0.npz')
 def iteration0_losses(model, data):
     """The losses of the untouched model on the bench batch (one forward, no update), as the reference's
     `_parse_losses` (detectors/base.py:176-209) reports them."""
-    with torch.no_grad():
-        mod = model.module if hasattr(model, 'module') else model
-        _, log_vars = mod._parse_losses(model(**data))
+    mod = model.module if hasattr(model, 'module') else model
+    prev = getattr(mod, '_log_reduce_elsewhere', False)
+    mod._log_reduce_elsewhere = True   # rank 0 alone runs this pass: no collective in it (N > 1: _parse_losses would all-reduce)
+    try:
+        with torch.no_grad():
+            _, log_vars = mod._parse_losses(model(**data))
+    finally:
+        mod._log_reduce_elsewhere = prev
     return {k: float(v) for k, v in log_vars.items()}
 
 

@@ -76,3 +76,23 @@ def test_real_detector_through_one_rank_rccl_equals_plain_step_bit_for_bit():
     assert ra['losses'] == rb['losses'], (ra['losses'], rb['losses'])
     diff = [k for k in rb['state'] if not torch.equal(ra['state'][k], rb['state'][k])]
     assert not diff, f'{len(diff)} tensors differ, e.g. {diff[:4]}'
+
+
+def test_bench_two_ranks_share_the_gpu():
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank), on a 1-GPU box through
+    LSNET_BENCH_BACKEND=gloo (the ranks share the device, the buckets travel through the host): every rank must issue the
+    SAME sequence of collectives.  Round 4 added a rank-0-only pass whose loss bookkeeping all-reduced -- the 2-rank run
+    aborted with gloo's size-mismatch error, and only this self-test saw it (the driver's 8-GPU run would have been next)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LSNET_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), 'bench.py', '--gpus', '2', '--steps', '2', '--warmup', '1', '--no-extra',
+           '--no-cpu-baseline', '--height', '384', '--width', '480']
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    line = json.loads(res.stdout.strip().splitlines()[-1])
+    assert line['n_gpus'] == 2 and line['steps'] == 2 and line['value'] > 0 and line['scaling'] == 'weak'
+    assert line['config']['world_size'] == 2
