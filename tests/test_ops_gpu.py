@@ -953,6 +953,52 @@ def test_tower_launch_at_bench_shape(choice):
     assert all(e < TOL for e in errs.values()), errs
 
 
+@pytest.mark.parametrize('mode', ['bf16x6', 'fp32'])
+def test_pyramid_outputs_side_by_side(mode):
+    """`concat=3` of the pyramid op (lsn_dcn_shape.out_pitch: the three maps of a destination level written into one
+    768-channel tensor, their gradient read from where the next operator leaves it) against torch.cat of the separate
+    outputs: the same bits forward and backward in the matrix-pipe mode; the exact-fp32 mode has no pitched kernels and
+    takes the fallback (separate outputs + ATen's concatenation), same result by construction."""
+    from lsnet_amd import _lib, ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(31)
+    C = Co = 256
+    sizes = [(25, 42), (13, 21), (7, 11)]
+    level_lists = [[0, 1, 2], [1, 0, 2], [2, 1, 0]]
+    w = torch.randn(Co, C, 3, 3, generator=g) / (3 * C ** 0.5)
+    feats = [torch.randn(2, C, h, ww, generator=g) for h, ww in sizes]
+    pairs = [(l, s) for l, lst in enumerate(level_lists) for s in lst]
+    offs, scales = [], []
+    for l, s in pairs:
+        h, ww = sizes[l]
+        scales.append((sizes[s][0] / h, sizes[s][1] / ww))
+        offs.append(torch.randn(2, 18, h, ww, generator=g) * 2.0)
+    gos = [torch.randn(2, 3 * Co, h, ww, generator=g) for h, ww in sizes]
+    old = _lib.get_math_mode()
+    _lib.set_math_mode(mode)
+    try:
+        def run(concat):
+            wd = _to(w, dev, True).requires_grad_()
+            fd = [_to(t, dev, True).requires_grad_() for t in feats]
+            od = [_to(t, dev, True).requires_grad_() for t in offs]
+            outs = ops.dcn_multi([fd[s] for _, s in pairs], od, None, wd, None, 1, 1, 1, scales=scales, pyramid=True,
+                                 concat=3 if concat else 0)
+            if not concat:
+                outs = [torch.cat(outs[3 * l:3 * l + 3], dim=1) for l in range(3)]
+            grads = torch.autograd.grad(outs, [wd] + fd + od, [_to(t, dev, True) for t in gos])
+            return [o.detach() for o in outs], grads
+        o1, g1 = run(True)
+        o0, g0 = run(False)
+    finally:
+        _lib.set_math_mode(old)
+    assert all(o.shape[1] == 3 * Co and o.is_contiguous(memory_format=torch.channels_last) for o in o1)
+    assert all(torch.equal(a, b) for a, b in zip(o1, o0))
+    if mode == 'bf16x6':
+        assert all(torch.equal(a, b) for a, b in zip(g1, g0))
+    else:   # (the exact mode scatters its data gradients with fp32 atomics: equal up to their order)
+        assert all(float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) for a, b in zip(g1, g0))
+
+
 @pytest.mark.parametrize('choice', ['default', 'x6_atomic', 'x3_gather', 'x3_windowed_kernel'])
 def test_pyramid_launch_at_bench_shape(choice):
     """One PyramidDeformConv of LSHead.forward_single2 (lsnet_head.py:600-755) at BASELINE config 2: the 15 (level,
