@@ -559,13 +559,21 @@ int conv_wgrad_reduce(const float *part, float *gw, size_t n, const float *part_
                       int accumulate, hipStream_t st)
 {
     int LS = 1;
-    while (LS < 64 && LS * 8 <= splits) LS <<= 1;   // >= 4 loads per lane; a wave's lanes share 64 / LS elements
+    // partial tiles a lane sums on its own before the xor-shuffles (LS = splits / PER_LANE lanes share a float4).  Round-4 sweep
+    // (tools/ubench/wgrad_ab rule / bn, us per step of the benchmark's layer mix): 4: 3374 / 2945, 8: 3284 / 2729,
+    // 16: 3254 / 2650, 32: 3252 / 2642 -- fewer, longer lanes win until the loads in flight run out.
+#ifdef LSNET_PER_LANE
+    constexpr int PER_LANE = LSNET_PER_LANE;
+#else
+    constexpr int PER_LANE = 16;
+#endif
+    while (LS < 64 && LS * PER_LANE <= splits) LS <<= 1;   // >= PER_LANE / 2 loads per lane; a wave's lanes share 64 / LS elements
     if (g_wg_fold) {
         const int nj = g_wg_fold->njobs;   // (splits / splits_b count ALL jobs' partial tiles)
         LSN_CHECK(part_b && nb > 0 && n % ((size_t)nb * 4) == 0 && splits % nj == 0 && splits_b % nj == 0,
                   "conv2d backward-weight (folded norm): bad partial layout");
         LS = 1;
-        while (LS < 64 && LS * 8 <= splits / nj) LS <<= 1;
+        while (LS < 64 && LS * PER_LANE <= splits / nj) LS <<= 1;
         hipLaunchKernelGGL(conv_wgrad_reduce_bn_kernel, dim3(nb, nj), dim3(256), 0, st, part, gw, (int)(n / nb), nb, part_b,
                            splits / nj, splits_b / nj, accumulate, LS, *g_wg_fold);
         LSN_HIP(hipGetLastError());
