@@ -22,7 +22,8 @@ Prints ONE JSON line (rank 0):  value = total images / s over all N GPUs (weak s
                  2516 / 6 TFLOP/s for 'bf16x6', 157.3 for exact fp32 -- or 8 TB/s of HBM (MI355X_MICROARCH.md);
                  `traffic`: HBM bytes of this step's own launch shapes from committed rocprofv3 counter passes.
   kernels      : the survey pass: per family launches, ms per step, TFLOP/s and algorithmic GB/s.
-  extra        : the same step in the other arithmetic modes (bf16x3: 3-term split; fp32: exact fp32 MFMA + MIOpen),
+  extra        : the same step in the other arithmetic modes (bf16x3: 3-term split; fp32: exact fp32 MFMA for the deformable family, the dense
+                 convolutions stay on the fp32-equivalent 6-term split -- no vendor convolution in any mode),
                  5 steps each, and BASELINE config 5 (pose-head inference, bs 4).
   cpu_baseline : BASELINE config 1 (2 x 3x800x800) on the host CPU: this repo's host code with the CPU oracle standing
                  behind the native ops -- the reference has no CPU path for them -- rank 0 at N=1 only.

@@ -40,7 +40,7 @@ def _hipcc():
 OBJ_DIR = os.path.join(HERE, 'build')
 # headers each translation unit includes (an object is rebuilt when its source or one of these is newer)
 UNIT_HEADERS = {
-    'dcn.hip': ['common.h', 'dcn_kernels.h', 'dcn_mm_kernels.h', 'dcn_fused_kernels.h', 'conv_kernels.h', 'prof.h'],
+    'dcn.hip': ['common.h', 'dcn_kernels.h', 'dcn_mm_kernels.h', 'conv_kernels.h', 'prof.h'],
     'conv.hip': ['common.h', 'conv_kernels.h', 'conv_wgrad_kernels.h', 'prof.h'],
     'misc.hip': ['common.h', 'prof.h'], 'norm.hip': ['common.h', 'prof.h'], 'gconv.hip': ['common.h', 'prof.h'],
     'image.hip': ['common.h'], 'loss.hip': ['common.h', 'cross_iou_row.h'],

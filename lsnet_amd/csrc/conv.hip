@@ -67,12 +67,98 @@ static int part_buffer(size_t floats, float **p, hipStream_t st)
     return 0;
 }
 
-// One launch over the pixel tiles [tile_base, tile_base + ntiles) of the (tiled) levels, `ks` chunk splits.
+// Per-stream arrival counters of the stream-K tiles (conv_kernels.h ConvArgs): zeroed once, every launch leaves them zero.
+constexpr int SK_MAX_TILES = 4096;
+struct SkCounters {
+    hipStream_t st;
+    unsigned *p;
+};
+static SkCounters g_skc[16];
+static int g_nskc = 0;
+static int sk_counters(unsigned **p, hipStream_t st)
+{
+    for (int i = 0; i < g_nskc; ++i)
+        if (g_skc[i].st == st) {
+            *p = g_skc[i].p;
+            return 0;
+        }
+    if (g_nskc == 16) return fail(LSN_ERR_RUNTIME, "scratch: more than 16 streams use the library");
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+        return fail(LSN_ERR_RUNTIME, "scratch would grow inside a stream capture: run the step eagerly once before capturing");
+    unsigned *np = nullptr;
+    LSN_HIP(hipMalloc(reinterpret_cast<void **>(&np), SK_MAX_TILES * sizeof(unsigned)));
+    LSN_HIP(hipMemsetAsync(np, 0, SK_MAX_TILES * sizeof(unsigned), st));
+    g_skc[g_nskc++] = SkCounters{st, np};
+    *p = np;
+    return 0;
+}
+
+// Work distribution of one launch (conv_kernels.h ConvArgs).  The chip holds 512 workgroups of these kernels at once, so
+// a launch of W tiles runs in ceil(W / 512) rounds and the last one is rarely full: 525 tiles (every convolution at the
+// 100 x 168 maps of two images) cost 226 us against 177 us for 512 (tools/ubench/tile_sweep), 132 or 33 tiles (stages 3 / 4)
+// leave most of the chip idle.  Rounds 3 / 4 answered with a reduction split over blockIdx.z plus a reduce launch, and a
+// second launch for the tail; both quantise again (the split rule produced 528 workgroups for six layer shapes of the
+// step).  Round 5: the last 512 + r tiles of a launch -- or all of them when there are fewer than 512 -- are divided
+// EVENLY BY CHUNKS over 512 workgroups, whole tiles before them stay one workgroup each.
+// Not for short reductions (< 16 chunks: the layer is bound by its output stream, and a partial tile costs what the tile
+// costs) and not when the last round is nearly full.
+static void sk_plan(int ntw, int Tall, int *n_dp, int *sk_n, int *sk_tiles)
+{
+    *n_dp = ntw, *sk_n = 0, *sk_tiles = 0;
+#ifdef LSNET_AB
+    return;
+#endif
+    constexpr int SLOTS = 512;
+    // (launches of two or more whole rounds lose more to the segment loop's longer prologue in EVERY workgroup than the
+    // last round can return: profiles/r5_sk_policy.txt, layer-1 rows)
+    if (Tall < 8 || ntw >= 2 * SLOTS) return;
+    const int r = ntw % SLOTS;
+    if (r == 0 || r > 448) return;
+    // Pieces per tile: at most four when the pieces are the whole launch (the tile's last arriver adds them on its own), up
+    // to sixteen for the few tiles behind a whole round (the chip is idle otherwise); never shorter than four chunks.
+    int per_tile = Tall / 4;
+    const int cap = ntw > SLOTS ? 16 : 4;
+    if (per_tile > cap) per_tile = cap;
+    const long long pieces = (long long)r * per_tile;
+    const int ns = pieces < SLOTS ? (int)pieces : SLOTS;
+    if (ns <= r) return;
+    *n_dp = ntw - r, *sk_n = ns, *sk_tiles = r;
+}
+
+// Fewer than 512 tiles and more than four pieces per tile (stage 4, FPN P5: 33 pixel tiles under 64 .. 144 chunks): the tile's
+// last arriver would add eight partial tiles on its own while the chip idles -- these keep round 3's blockIdx.z split with its
+// chip-wide reduce launch, rounded DOWN to one round of workgroups (round 3 / 4 rounded to nearest: 528 on 512 slots for six
+// layer shapes of the step).
+static int z_split(int ntw, int Tall)
+{
+    if (ntw >= 128 || Tall < 16) return 1;
+    int ks = 512 / ntw;
+    if (ks > Tall / 8) ks = Tall / 8;
+    if (ks > 16) ks = 16;
+    return ks < 1 ? 1 : ks;
+}
+
+// One launch over the pixel tiles [tile_base, tile_base + ntiles) of the (tiled) levels, `ks` chunk splits (the round-3
+// form with its reduce launch: only where stream-K does not apply).
 template <int TM, int TN, int WM, int WN, int NP, bool UNAL, bool FINE, bool TRANS>
 static int launch_conv_range(ConvArgs &a, int ks, int tile_base, int ntiles, hipStream_t st)
 {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     const size_t lds = (size_t)2 * SplitCfg<NP>::NPL * BM * 64;
+    a.colblocks = (a.Co + BN - 1) / BN;
+    const int ntw = ntiles * a.colblocks;
+    a.n_dp = ntw, a.sk_n = 0, a.sk_tiles = 0, a.sk_part = nullptr, a.sk_cnt = nullptr;
+    if (ks == 1 && !TRANS) {
+        sk_plan(ntw, a.kh * a.kw * cv_ncc(a.C), &a.n_dp, &a.sk_n, &a.sk_tiles);
+        // (the kernel's unit arithmetic is 32-bit: (U + 1) * sk_n must stay below 2^31)
+        if (a.sk_tiles > SK_MAX_TILES || ((long long)a.sk_tiles * a.kh * a.kw * cv_ncc(a.C) + 1) * a.sk_n >= ((long long)1 << 31))
+            a.n_dp = ntw, a.sk_n = 0, a.sk_tiles = 0;
+        if (a.sk_n) {
+            if (int rc = part_buffer((size_t)2 * a.sk_n * BM * BN, &a.sk_part, st)) return rc;
+            if (int rc = sk_counters(&a.sk_cnt, st)) return rc;
+        }
+    }
     a.ksplit = ks;
     a.tile_base = tile_base;
     const int pix0 = tile_base * BM;   // (ks > 1: one level)
@@ -81,14 +167,24 @@ static int launch_conv_range(ConvArgs &a, int ks, int tile_base, int ntiles, hip
     const size_t n = (size_t)rows * a.Co;
     if (ks > 1)
         if (int rc = part_buffer(n * ks, &a.part, st)) return rc;
-    dim3 grid(ntiles, (a.Co + BN - 1) / BN, ks);
-    auto k = conv_mm_kernel<TM, TN, WM, WN, NP, UNAL, FINE, TRANS>;
-    static bool attr_set = false;   // per instantiation
-    if (!attr_set) {
-        LSN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+    dim3 grid(a.n_dp + a.sk_n, 1, ks);
+    if (a.sk_n) {
+        auto k = conv_mm_kernel<TM, TN, WM, WN, NP, UNAL, FINE, TRANS, true>;
+        static bool attr_set = false;   // per instantiation
+        if (!attr_set) {
+            LSN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a);
+    } else {
+        auto k = conv_mm_kernel<TM, TN, WM, WN, NP, UNAL, FINE, TRANS, false>;
+        static bool attr_set = false;
+        if (!attr_set) {
+            LSN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a);
     }
-    hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a);
     if (ks > 1) {
         const int blocks = (int)((n / 4 + 255) / 256 < 1024 ? (n / 4 + 255) / 256 : 1024);
         const size_t o = (size_t)pix0 * a.Co;
@@ -100,19 +196,12 @@ static int launch_conv_range(ConvArgs &a, int ks, int tile_base, int ntiles, hip
     return 0;
 }
 
-// Tail split.  The chip holds 512 workgroups at once; a launch of 525 runs 512, then 13 -- 226 us against 177 us for 512
-// (tools/ubench/tile_sweep, profiles/r4_conv_ablation.txt), and every single-level convolution at the 100 x 168 maps of
-// two images sits there (33 600 pixels = 525 tiles of 64: all of stage 2, the FPN's P3 convolutions).  When the last
-// round would be a small remainder, those pixel tiles get their own launch with the REDUCTION split `kt` ways (the
-// split-K machinery of the small layers): kt x remainder workgroups of 1 / kt the length + the partial-tile reduce.
-// Pays under a deep reduction only (tools/ubench/conv_step A/B, profiles/r4_tail_split.txt): FPN 3x3 at P3 249 -> 215 us
-// forward, 243 -> 231 data gradient, a 3x3 256 -> 80 at P3 132 -> 118; the 1x1 layers of stage 1 / 2 (4 .. 16 chunks) LOSE
-// 4 .. 8 us each to the second launch and the reduce -- hence the chunk threshold.
+#ifdef LSNET_AB
+// Round 4's tail split (the A/B library keeps rounds 3 / 4's work distribution: blockIdx.z splits, this, no stream-K): a
+// single-level launch whose last round would be a small remainder runs its last pixel tiles as a second launch with the
+// reduction split `kt` ways (profiles/r4_tail_split.txt).
 static int tail_split(int total_wg, int colblocks, int Tall, int *tail_tiles)
 {
-#ifdef LSNET_AB
-    return 1;
-#endif
     const int rem = total_wg % 512;
     if (total_wg <= 512 || rem == 0 || rem > 128 || rem % colblocks != 0 || Tall < 48) return 1;
     int kt = 384 / rem;
@@ -122,6 +211,7 @@ static int tail_split(int total_wg, int colblocks, int Tall, int *tail_tiles)
     *tail_tiles = rem / colblocks;
     return kt;
 }
+#endif
 
 template <int TM, int TN, int WM, int WN, int NP, bool UNAL, bool FINE, bool TRANS = false>
 static int launch_conv_cfg(ConvArgs &a, int ks, hipStream_t st)
@@ -133,6 +223,7 @@ static int launch_conv_cfg(ConvArgs &a, int ks, hipStream_t st)
         tiles += (a.lv[i].P + BM - 1) / BM;
     }
     a.ntiles = tiles;
+#ifdef LSNET_AB
     const int colblocks = (a.Co + BN - 1) / BN;
     int tail = 0;
     const int kt = (a.nlv == 1 && !a.ostep && ks == 1 && !TRANS) ? tail_split(tiles * colblocks, colblocks, a.kh * a.kw * cv_ncc(a.C), &tail)
@@ -141,6 +232,7 @@ static int launch_conv_cfg(ConvArgs &a, int ks, hipStream_t st)
         if (int rc = launch_conv_range<TM, TN, WM, WN, NP, UNAL, FINE, TRANS>(a, 1, 0, tiles - tail, st)) return rc;
         return launch_conv_range<TM, TN, WM, WN, NP, UNAL, FINE, TRANS>(a, kt, tiles - tail, tail, st);
     }
+#endif
     return launch_conv_range<TM, TN, WM, WN, NP, UNAL, FINE, TRANS>(a, ks, 0, tiles, st);
 }
 
@@ -185,12 +277,17 @@ static int conv_forward(ConvArgs &a, hipStream_t st)
     const int nb = cfg == 2 ? blocks(64, 128) : cfg == 3 ? blocks(128, 64) : cfg == 5 ? blocks(64, 256) : blocks(128, 32);
     const int Tall = a.kh * a.kw * cv_ncc(a.C);
     int ks = 1;
+#ifdef LSNET_AB
     if (a.nlv == 1 && !a.ostep && nb <= 320 && Tall >= 16) {
         ks = (512 + nb / 2) / nb;
         if (ks > Tall / 8) ks = Tall / 8;
         if (ks > 16) ks = 16;
         if (ks < 1) ks = 1;
     }
+#else
+    // round 5: stream-K pieces (sk_plan) wherever a tile gets at most four of them, blockIdx.z splits + a reduce launch below
+    if (a.nlv == 1 && !a.ostep) ks = z_split(nb, Tall);
+#endif
     switch (cfg) {
     case 2: return launch_conv<1, 2, 2, 2, true>(a, ks, st);
     case 3: return launch_conv<1, 2, 4, 1, false>(a, ks, st);
@@ -511,7 +608,11 @@ static int launch_wgrad_cfg(WgArgs &a, float *gw, float *gb, int accumulate, hip
     const int blocks = cdiv(a.Co, BM) * cdiv(a.C, BN);
     const size_t nW = (size_t)a.Co * K * a.C;
     const int nj = wg_jobs();   // > 1: the levels are jobs with their own outputs; every split stays inside one level
+#ifdef LSNET_AB
     int S = (512 + blocks * nj / 2) / (blocks * nj);
+#else
+    int S = 512 / (blocks * nj);   // one round of workgroups (rounds 3 / 4 rounded to nearest: 516 .. 540 on 512 slots)
+#endif
     const size_t cap = ((size_t)192 << 20) / 4 / (nW + a.Co) / nj;   // partial tiles: at most 192 MB
     if ((size_t)S > cap) S = (int)cap;
     if (S > a.nseg / nj / 6) S = a.nseg / nj / 6;   // a split should run long enough to amortise its prologue and its partial tile

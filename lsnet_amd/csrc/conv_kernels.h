@@ -60,6 +60,16 @@ struct ConvArgs {
     // output placement: pixel (b, ho, wo) of the (Ho, Wo) grid is stored at (b, oy0 + ho * ostep, ox0 + wo * ostep) of an
     // (OH, OW) map.  ostep = 0: the dense case.  Used by the strided backward-data pass (one residue class per launch).
     int ostep, oy0, ox0, OH, OW;
+    // ---- work distribution (conv.hip sk_plan).  The grid is one-dimensional in x: workgroups [0, n_dp) take one whole
+    // (pixel tile, column block) each; workgroups [n_dp, n_dp + sk_n) share the remaining sk_tiles tiles EVENLY BY CHUNKS
+    // ("stream-K"): piece s owns the chunk units [U s / sk_n, U (s + 1) / sk_n) of the tile-major unit space, U = sk_tiles *
+    // (chunks per tile).  A piece that covers only part of a tile leaves its accumulators in slot 2 s (the segment that
+    // opens the piece) or 2 s + 1 (the one that closes it) of sk_part and takes a ticket of the tile's counter; the piece
+    // that draws the LAST ticket adds the tile's slots in chunk order -- a fixed order, whoever arrives last: the same bits
+    // on every run, no second launch -- runs the epilogue and re-arms the counter.  Nobody waits for anybody.
+    int colblocks, n_dp, sk_n, sk_tiles;
+    float *sk_part;
+    unsigned *sk_cnt;   // one counter per stream-K tile, zero between launches
 };
 
 // Tap subset of a transposed convolution: taps i = i0 + m * istep (m < ni), j likewise.
@@ -220,7 +230,9 @@ __device__ __forceinline__ bf16x8 cv_load_frag(__amdgpu_buffer_rsrc_t rs, int vo
 // For the backward-data GEMM of the deformable family (conv_mm_rows: N = K C = 2304 columns, plain stores, no epilogue
 // terms), whose lane-per-pixel stores -- 32-byte pieces of 64 different rows per instruction -- made the L2 fetch every
 // partially written line: 0.68 GB fetched by a kernel that reads 27 MB (profiles/r3_pmc_hbm.txt).
-template <int TM, int TN, int WM, int WN, int NP, bool UNAL = false, bool FINE = false, bool TRANS = false>
+// SK: the launch has stream-K pieces (ConvArgs; conv.hip sk_plan).  A template parameter because the segment loop costs the
+// plain form ~30 spilled scalar registers and 15 - 25 % on the shortest launches (profiles/r5_sk_sc1.txt).
+template <int TM, int TN, int WM, int WN, int NP, bool UNAL = false, bool FINE = false, bool TRANS = false, bool SK = false>
 __global__ __launch_bounds__(256, 2) void conv_mm_kernel(const ConvArgs a)
 {
     using SC = SplitCfg<NP>;
@@ -236,18 +248,42 @@ __global__ __launch_bounds__(256, 2) void conv_mm_kernel(const ConvArgs a)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int K = a.kh * a.kw;
-    // XCD-ordered (pixel tile, column block) with the column blocks of a pixel tile adjacent (same input rows)
-    const int work = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
-    const int ptile = work / (int)gridDim.y + a.tile_base;
+    const int ncc = cv_ncc(a.C), NT = cv_nt(a.Co);
+    const int Tall = K * ncc;
+    // ---- this workgroup's share: one whole tile, or a stream-K piece (ConvArgs) ----
+    const bool is_sk = SK && (int)blockIdx.x >= a.n_dp;
+    // (32-bit unit arithmetic: the host checks U * sk_n < 2^31 -- 64-bit divisions cost dozens of scalar registers here)
+    int sk_u = 0, sk_end = 0, sk_start = 0, sk_U = 0;
+    int sk_s = 0;
+    if (is_sk) {
+        sk_s = xcd_remap((int)blockIdx.x - a.n_dp, a.sk_n);
+        sk_U = a.sk_tiles * Tall;
+        sk_start = sk_u = (int)((unsigned)sk_U * (unsigned)sk_s / (unsigned)a.sk_n);
+        sk_end = (int)((unsigned)sk_U * (unsigned)(sk_s + 1) / (unsigned)a.sk_n);
+    }
+    __shared__ unsigned sk_ticket;
+  for (;;) {   // one pass per segment (plain tiles: exactly one)
+    int work, t_begin, T;
+    bool sk_partial = false;
+    if (!is_sk) {
+        // XCD-ordered (pixel tile, column block) with the column blocks of a pixel tile adjacent (same input rows)
+        work = xcd_remap((int)blockIdx.x, a.n_dp);
+        t_begin = (int)((long long)Tall * blockIdx.z / gridDim.z);
+        T = (int)((long long)Tall * (blockIdx.z + 1) / gridDim.z) - t_begin;
+    } else {
+        const int kt = (int)((unsigned)sk_u / (unsigned)Tall);
+        work = a.n_dp + kt;
+        t_begin = sk_u - kt * Tall;
+        const int te = sk_end - kt * Tall;
+        T = (te < Tall ? te : Tall) - t_begin;
+        sk_partial = T != Tall;
+    }
+    const int ptile = work / a.colblocks + a.tile_base;
     int li = 0;
     while (li + 1 < a.nlv && ptile >= a.lv[li + 1].tile0) ++li;
     const ConvLvl &L = a.lv[li];
     const int tile_p = (ptile - L.tile0) * BM;
-    const int co_blk = (work - (ptile - a.tile_base) * (int)gridDim.y) * BN;
-    const int ncc = cv_ncc(a.C), NT = cv_nt(a.Co);
-    const int Tall = K * ncc;
-    const int t_begin = (int)((long long)Tall * blockIdx.z / gridDim.z);
-    const int T = (int)((long long)Tall * (blockIdx.z + 1) / gridDim.z) - t_begin;
+    const int co_blk = (work - (ptile - a.tile_base) * a.colblocks) * BN;
 
     const __amdgpu_buffer_rsrc_t xrs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(L.x), 0, L.B * L.H * L.W * a.xpitch * 4, 0x00020000);
@@ -448,9 +484,73 @@ __global__ __launch_bounds__(256, 2) void conv_mm_kernel(const ConvArgs a)
         __syncthreads();
     }
 
+    // ---- stream-K: a piece that holds only part of the tile's sum ----
+    // Visibility across the eight L2s without flushing them: the slot is written and read with AGENT-scope accesses (sc1:
+    // written through to / fetched from the coherence point), the writer waits for its stores (vmcnt) before the ticket is
+    // drawn.  A release / acquire FENCE pair instead (__threadfence: buffer_wbl2 + buffer_inv of the whole L2, from 512
+    // workgroups) cost 150 - 250 us per launch (profiles/r5_sk_fence.txt).
+    bool do_out = true;
+    if (SK && sk_partial) {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        constexpr int SLOT = BM * BN;   // floats; element (q, tid) of a slot = float4 number q of thread tid (coalesced)
+        constexpr int SC1 = 16;         // cache-policy bit 4 of the raw buffer intrinsics on gfx940+: agent scope
+        const int kt = work - a.n_dp;
+        const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(a.sk_part, 0, 2 * a.sk_n * SLOT * 4, 0x00020000);
+        {
+            const int soff = (2 * sk_s + (sk_u == sk_start ? 0 : 1)) * (SLOT * 4);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 v = {acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]};
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), prs,
+                                                               (((j * TM + i) * 4 + g) * 256 + tid) * 16, soff, SC1);
+                    }
+        }
+        // contributors of tile kt: the pieces that own its first and its last chunk, and those between
+        const int u_lo = kt * Tall, u_hi = u_lo + Tall - 1;
+        const int s_lo = (int)(((unsigned)(u_lo + 1) * (unsigned)a.sk_n + (unsigned)sk_U - 1u) / (unsigned)sk_U) - 1;
+        const int s_hi = (int)(((unsigned)(u_hi + 1) * (unsigned)a.sk_n + (unsigned)sk_U - 1u) / (unsigned)sk_U) - 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's slot elements have reached the coherence point
+        __syncthreads();
+        if (tid == 0) sk_ticket = __hip_atomic_fetch_add(a.sk_cnt + kt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        do_out = (int)sk_ticket == s_hi - s_lo;
+        if (do_out) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+            for (int c = s_lo; c <= s_hi; ++c) {   // chunk order = piece order
+                const int cs = (int)((unsigned)sk_U * (unsigned)c / (unsigned)a.sk_n);
+                const int soff = (2 * c + (cs >= u_lo ? 0 : 1)) * (SLOT * 4);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    f32x4 pv[TM * 4];   // a column of tiles in flight, then the additions
+#pragma unroll
+                    for (int q = 0; q < TM * 4; ++q)
+                        pv[q] = __builtin_bit_cast(
+                            f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, ((j * TM * 4 + q) * 256 + tid) * 16, soff, SC1));
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[j][i][4 * g + e] += pv[i * 4 + g][e];
+                }
+            }
+            if (tid == 0) __hip_atomic_store(a.sk_cnt + kt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed
+        }
+    }
+
     // ---- epilogue ----
     const bool partial = a.ksplit > 1;
     const bool vec_ok = (a.Co & 3) == 0;
+    if (do_out) {
     if constexpr (TRANS) {
         // lane = output channel (lane & 31) of tile j, pixels mfma32_row(r, lane) of tile i: plain stores, whole lines
 #pragma unroll
@@ -466,8 +566,7 @@ __global__ __launch_bounds__(256, 2) void conv_mm_kernel(const ConvArgs a)
                     if (co < a.Co) orow[co] = acc[j][i][r];
                 }
             }
-        return;
-    }
+    } else {
     // lane = pixel (lane & 31) of tile i, output channels 8 g + 4 (lane >> 5) + (0..3) of tile j
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -522,6 +621,12 @@ __global__ __launch_bounds__(256, 2) void conv_mm_kernel(const ConvArgs a)
                 }
             }
     }
+    }
+    }
+    if (!SK || !is_sk) break;
+    sk_u += T;
+    if (sk_u >= sk_end) break;
+  }
 }
 
 // out[e] = sum_z part[z * n + e] + bias[e % Co] (ReLU): the second pass of a split reduction; n = P * Co

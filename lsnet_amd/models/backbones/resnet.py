@@ -123,22 +123,28 @@ class Bottleneck(nn.Module):
         # relu(bn3(conv3) + identity): norm, residual add and activation in one pass (resnet.py:261-301)
         return _conv_bn(self.conv3, self.norm3, out, relu=True, residual=_shortcut(self.downsample, x))
 
-    def forward(self, x, pregate_in=False, gy_pregated=False, wg_queue=None, wg_flush=False):
+    def forward(self, x, pregate_in=False, gy_pregated=False, wg_queue=None, wg_flush=False, fused=None):
         """pregate_in / gy_pregated: set by ResLayer.forward for neighbouring blocks that both run as the fused autograd
         node of ops/resblock.py (the ReLU gate of a block's output then rides in the NEXT block's backward-data launch).
-        wg_queue / wg_flush: the stage's identical blocks share their weight-gradient launches (ops/resblock.py)."""
-        if fused_block_ok(self, x):
+        wg_queue / wg_flush: the stage's identical blocks share their weight-gradient launches (ops/resblock.py).
+        fused: ResLayer.forward's decision for THIS block's input (it pairs the flags above by it); None: decide here."""
+        if fused is None:
+            fused = fused_block_ok(self, x)
+        if fused:
             return resblock.bottleneck(self, x.contiguous(memory_format=torch.channels_last), pregate_in, gy_pregated,
                                        wg_queue, wg_flush)
         assert not (pregate_in or gy_pregated or wg_queue is not None), 'ResLayer.forward pairs the flags of fused blocks only'
         return cp.checkpoint(self._body, x) if (self.with_cp and x.requires_grad) else self._body(x)
 
 
-def fused_block_ok(blk, x):
+def fused_block_ok(blk, x, numel=None):
     """The whole bottleneck as one autograd node (ops/resblock.py): a trainable dense block behind eval-mode norms, on a
-    device fp32 tensor small enough for 32-bit byte offsets in every map of the block (the widest is 4 x the input)."""
+    device fp32 tensor small enough for 32-bit byte offsets in every map of the block (the widest is 4 x the input).
+    numel: the element count of the block's OWN input when x is only a tensor of the same kind (ResLayer.forward decides
+    for every block of the stage before any of them has run)."""
+    n = x.numel() if numel is None and torch.is_tensor(x) else numel
     return (type(blk) is Bottleneck and torch.is_tensor(x) and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32
-            and x.numel() * 16 < 2 ** 31 and resblock.bottleneck_ok(blk))
+            and n * 16 < 2 ** 31 and resblock.bottleneck_ok(blk))
 
 
 class ResLayer(nn.Sequential):
@@ -146,17 +152,28 @@ class ResLayer(nn.Sequential):
 
     def forward(self, x):
         blocks = list(self)
-        ok = [fused_block_ok(b, x) for b in blocks]   # (a fused block hands a tensor of the same kind to the next one)
+        # Every block is judged on ITS OWN input (blocks 1 .. n-1 of a stage see block 0's output -- in a trainable
+        # stage 1 four times the stage input -- and a block that declined after its neighbours had been told otherwise hit an
+        # assertion): block 0 maps (B, C, H, W) to (B, 4 planes, ceil(H / s), ceil(W / s)), the others keep that shape.
+        numel = [x.numel()] * len(blocks)
+        if torch.is_tensor(x) and x.dim() == 4 and len(blocks) > 1:
+            b0 = blocks[0]
+            s = getattr(b0, 'stride', 1)
+            s = s if isinstance(s, int) else s[0]
+            co = getattr(getattr(b0, 'conv3', None), 'out_channels', None) or getattr(getattr(b0, 'conv2', None), 'out_channels', x.shape[1])
+            n_out = x.shape[0] * co * (-(-x.shape[2] // s)) * (-(-x.shape[3] // s))
+            numel = [x.numel()] + [n_out] * (len(blocks) - 1)
+        ok = [fused_block_ok(b, x, n) for b, n in zip(blocks, numel)]
         # blocks 1 .. n-1 are built alike (__init__ below), and block 0's conv3 has their conv3's geometry: when the whole
         # stage runs fused, the weight gradients of one geometry are ONE launch, issued by block 0's backward -- the last
         group = len(blocks) > 2 and all(ok) and torch.is_grad_enabled()
-        queue = {} if group else None
+        queue = resblock.WgQueue() if group else None
         for i, b in enumerate(blocks):
             if ok[i]:
                 x = b(x, pregate_in=i > 0 and ok[i - 1], gy_pregated=i + 1 < len(blocks) and ok[i + 1],
-                      wg_queue=queue, wg_flush=group and i == 0)
+                      wg_queue=queue, wg_flush=group and i == 0, fused=True)
             else:
-                x = b(x)
+                x = b(x, fused=False) if type(b) is Bottleneck else b(x)
         return x
 
     def __init__(self, block, inplanes, planes, num_blocks, stride=1, avg_down=False, conv_cfg=None,

@@ -23,6 +23,23 @@ from . import grad_sink
 _CL = torch.channels_last
 
 
+_warned_fallbacks = set()
+
+
+def _warn_aten_fallback(what, x, detail):
+    """A device tensor that leaves the library's own kernels for ATen (MIOpen on the device): legal -- shapes the kernels do
+    not serve, tensors of 2 GiB and more, other dtypes -- but never silent (VERDICT r4 #13).  Once per (operator, reason)."""
+    if not (torch.is_tensor(x) and x.is_cuda):
+        return
+    key = (what, detail)
+    if key in _warned_fallbacks:
+        return
+    _warned_fallbacks.add(key)
+    import warnings
+    warnings.warn(f'lsnet_amd.{what}: no HIP kernel of this library serves this call on {x.device} ({detail}); '
+                  'falling back to the ATen operator', RuntimeWarning, stacklevel=3)
+
+
 def _p(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
@@ -709,4 +726,6 @@ class Conv2d(nn.Conv2d):
             return conv2d(_as_cl(x), w, self.bias, self.stride[0], self.padding[0], self.dilation[0], False)
         if hip_group_conv_ok(x, w, self.stride, self.padding, self.dilation, self.groups, self.padding_mode):
             return _GroupConvFn.apply(x, w, self.bias, self.stride[0], self.padding[0], self.dilation[0], self.groups)
+        _warn_aten_fallback('Conv2d', x, f'weight {tuple(w.shape)}, stride {self.stride}, groups {self.groups}, '
+                                           f'padding_mode {self.padding_mode}, input {tuple(x.shape)} {x.dtype}')
         return F.conv2d(x, w, self.bias, self.stride, self.padding, self.dilation, self.groups)

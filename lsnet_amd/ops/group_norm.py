@@ -61,6 +61,11 @@ class GroupNorm(nn.GroupNorm):
         xs = list(xs)
         if self.affine and all(_hip_ok(x, self.num_channels, self.num_groups) for x in xs):
             return list(_GroupNormFn.apply(self.weight, self.bias, self.num_groups, self.eps, bool(relu), *xs))
+        if xs:
+            from .conv import _warn_aten_fallback
+            _warn_aten_fallback('GroupNorm', xs[0], f'{self.num_channels} channels, {self.num_groups} groups, affine {self.affine}, '
+                                                    f'input {tuple(xs[0].shape)} {xs[0].dtype}, channels_last '
+                                                    f'{xs[0].dim() == 4 and xs[0].is_contiguous(memory_format=_CL)}')
         ys = [F.group_norm(x, self.num_groups, self.weight, self.bias, self.eps) for x in xs]
         return [F.relu(y) for y in ys] if relu else ys
 

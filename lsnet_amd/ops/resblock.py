@@ -21,9 +21,50 @@ convolutions --
 The composition is written against the primitives of ops/conv.py (conv_fwd_bn, relu_gate, dgrad, wgrad_bn) through the
 module attribute `K`, so that tests/test_resblock.py can run the very same orchestration on the CPU with torch
 statements of the four primitives and compare it with autograd over the plain modules."""
+import weakref
+
 import torch
 
 from . import conv as K   # the primitives; tests swap this attribute for a torch restatement
+
+# Queues that hold weight-gradient jobs of the backward pass in flight (ResLayer.forward's per-stage dicts).  The stage's
+# first block flushes its queue when its backward runs -- the last of the stage.  If that node never runs (a partial
+# backward: torch.autograd.grad w.r.t. later blocks' parameters, an exception between the blocks), the queued layers have
+# already returned None to autograd: the engine callback registered with the first job of a pass launches whatever is
+# left when the pass ends, and the reducer's finish() refuses to hand out gradients while a queue still holds jobs
+# (VERDICT r4 / ADVICE r4: this loss used to be silent).
+_live_queues = weakref.WeakSet()
+_callback_armed = [False]
+
+
+class WgQueue(dict):
+    """geometry -> [(x, g, weight, norm)]; a dict that can be weakly referenced and kept in a set (by identity)"""
+    __slots__ = ('__weakref__',)
+    __hash__ = object.__hash__
+
+    def __eq__(self, other):
+        return self is other
+
+
+def pending_wgrad_jobs():
+    return sum(len(v) for q in list(_live_queues) for v in q.values())
+
+
+def _flush_pending():
+    _callback_armed[0] = False
+    for q in list(_live_queues):
+        if q:
+            flush_wgrad_queue(q)
+
+
+def _arm_flush_callback():
+    if _callback_armed[0]:
+        return
+    try:   # runs when the autograd engine finishes the pass that is executing this backward node
+        torch.autograd.Variable._execution_engine.queue_callback(_flush_pending)
+        _callback_armed[0] = True
+    except RuntimeError:   # not inside a backward pass (tests that drive the node by hand): the explicit flush stands
+        pass
 
 
 def epilogue_ok(k, stride, pad, dil):
@@ -96,6 +137,9 @@ class _BottleneckFn(torch.autograd.Function):
                     and K.wgrad_bn_deferrable(conv.weight, bn):
                 key = (tuple(xin.shape), tuple(conv.weight.shape), _cfg(conv))     # one launch per geometry
                 queue.setdefault(key, []).append((xin, g, conv.weight, bn))
+                if isinstance(queue, WgQueue):
+                    _live_queues.add(queue)
+                    _arm_flush_callback()
                 return None, None, None
             return K.wgrad_bn(xin, g, conv.weight, bn, *_cfg(conv))
 

@@ -158,6 +158,11 @@ class BucketedGradReducer:
 
     def finish(self):
         """Launch what backward could not (in order), wait, average."""
+        from ..ops import resblock
+        left = resblock.pending_wgrad_jobs()
+        if left:   # (the engine callback of ops/resblock.py flushes at the end of every backward pass: this is a bug trap)
+            raise RuntimeError(f'{left} queued weight-gradient job(s) of fused ResNet stages were never launched: their '
+                               'parameters would be reduced without these contributions')
         while self._next < len(self.buckets):
             b = self.buckets[self._next]
             for p, v in zip(b['params'], b['views']):

@@ -95,6 +95,31 @@ def golden_head(task, channels=32):
     _save(f'head_{task}' + ('' if channels == 32 else f'_{channels}'), data)
 
 
+def golden_decode():
+    """(a19) the REFERENCE's get_bboxes / _get_bboxes_single (lsnet_head.py:1439-1668: per-level top-k, decode, clamp,
+    multiclass NMS, max_per_img) on gu.decode_inputs -- head outputs derived from a seed alone, so the checking side decodes
+    the same bits and every index result is held EXACTLY on every platform (tests/golden_cases.py decode_case)."""
+    import mmcv
+    data = {}
+    for task in ('bbox', 'segm', 'pose_bbox', 'pose_kbox'):
+        head = _ref_head(task)
+        head.eval()
+        with torch.no_grad():
+            outs = head(gu.head_inputs(11))
+            syn, gap = gu.decode_inputs(outs, 77)
+            assert gap > 1e-3, (task, gap)
+            _, _, _, _, _, metas = _gt_for(task)
+            dets = head.get_bboxes(*syn, metas, cfg=mmcv.Config(gu.DECODE_CFG))
+        data[f'{task}/min_gap'] = np.float64(gap)
+        for i, (b, v, l) in enumerate(dets):
+            print(task, 'image', i, len(l), 'detections; top score', float(b[0, 4]) if len(l) else None)
+            assert 20 < len(l) <= gu.DECODE_CFG['max_per_img']
+            data[f'{task}/{i}/bboxes'] = b.numpy()
+            data[f'{task}/{i}/vectors'] = v.numpy()
+            data[f'{task}/{i}/labels'] = l.numpy()
+    _save('decode', data)
+
+
 def golden_head_cpv():
     """(f-4) LSCPVHead.forward + loss (+ gradients) and get_bboxes, reference code end to end
     (mmdet/models/dense_heads/lscpvnet_head.py)."""
@@ -668,7 +693,7 @@ def golden_data_pipeline():
     _save('data_pipeline', data)
 
 
-ALL = dict(backbones_dcn=golden_backbones_dcn, bench_iter0=golden_bench_iter0, train_curve=golden_train_curve,
+ALL = dict(decode=golden_decode, backbones_dcn=golden_backbones_dcn, bench_iter0=golden_bench_iter0, train_curve=golden_train_curve,
            # the same run at a tenth of the learning rate: the loss falls 475 -> 60 instead of 475 -> 1 and rounding
            # differences between two correct implementations stay at rounding level over all twelve iterations
            train_curve_lowlr=lambda: golden_train_curve(0.001, 'train_curve_lowlr'), coco_eval=golden_coco_eval, head_cpv=golden_head_cpv, data_pipeline=golden_data_pipeline, gt_formats=golden_gt_formats, res2net=golden_res2net, vote=golden_vote, head_bbox=lambda: golden_head('bbox'), head_segm=lambda: golden_head('segm'),

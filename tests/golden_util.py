@@ -193,6 +193,64 @@ def head_cfg(task, channels=32, num_classes=8):
     return cfg, train_cfg, test_cfg
 
 
+# ---------------------------------------------------------------------------------------------
+# decode fixture (get_bboxes / _get_bboxes_single -- "bit-exact top-k indices")
+# ---------------------------------------------------------------------------------------------
+DECODE_CFG = dict(nms_pre=48, min_bbox_size=0, score_thr=0.05, nms=dict(type='nms', iou_thr=0.6), max_per_img=100)
+
+
+def decode_inputs(outs, seed, num_classes=8):
+    """Synthetic head outputs of the shapes of `outs` (LSHead.forward's seven lists), derived from a seed alone: both sides
+    of the decode fixture -- the reference's get_bboxes in the build container, this package's on whatever device -- decode
+    the SAME BITS, so every index result (per-level top-k, label, NMS keep order, the max_per_img cut) must agree exactly.
+    What may still differ between two platforms is the last bit of a sigmoid or of a decoded coordinate; the inputs are
+    built so that no decision hangs on one:
+      * classification: a background of logits near -9 (scores ~1e-4, far below score_thr) and, around a few centres per
+        level, candidate (point, class) cells whose SCORES are a random permutation of an evenly spaced grid over
+        [0.06, 0.96] -- any two candidates of an image differ by >= 0.9 / N (checked by the generator: > 1e-3), against
+        the ~1e-7 two sigmoid implementations may disagree by.  Level 0 gets more candidate points than DECODE_CFG's
+        nms_pre, so the per-level top-k cuts real candidates;
+      * regression maps: positive values (the softplus range), uniform in [0.05, 2.55].
+    Returns (outs', min_gap): the same nested structure with CPU tensors, and the smallest score gap between two candidates
+    of one image."""
+    g = gen(seed)
+    new = [[None if t is None else None for t in lv] for lv in outs]
+    for li in range(1, len(outs)):
+        for i, t in enumerate(outs[li]):
+            if t is not None:
+                new[li][i] = torch.rand(tuple(t.shape), generator=g) * 2.5 + 0.05
+    cls = outs[0]
+    B = cls[0].shape[0]
+    maps = [-9.0 - torch.rand(tuple(t.shape), generator=g) for t in cls]
+    min_gap = 1.0
+    for b in range(B):
+        cells = []   # (level, class, y, x)
+        for lvl, t in enumerate(cls):
+            H, W = t.shape[-2:]
+            ncent = max(1, min(16, (H * W) // 48))
+            for _ in range(ncent):
+                cy, cx = int(torch.randint(0, H, (1,), generator=g)), int(torch.randint(0, W, (1,), generator=g))
+                c0 = int(torch.randint(0, num_classes, (1,), generator=g))
+                for dy in (-1, 0, 1):
+                    for dx in (-1, 0, 1):
+                        y, x = cy + dy, cx + dx
+                        if not (0 <= y < H and 0 <= x < W):
+                            continue
+                        c = c0 if float(torch.rand(1, generator=g)) < 0.8 else int(torch.randint(0, num_classes, (1,), generator=g))
+                        cells.append((lvl, c, y, x))
+        cells = sorted(set(cells))
+        n = len(cells)
+        perm = torch.randperm(n, generator=g).double()
+        score = 0.06 + 0.9 * (perm + 0.5) / n
+        logit = torch.log(score / (1 - score)).float()
+        for (lvl, c, y, x), v in zip(cells, logit):
+            maps[lvl][b, c, y, x] = v
+        got = torch.sort(logit.sigmoid().double())[0]
+        min_gap = min(min_gap, float((got[1:] - got[:-1]).min()))
+    new[0] = maps
+    return new, min_gap
+
+
 HEAD_IMG = (384, 512)   # -> grids 48x64, 24x32, 12x16, 6x8, 3x4 (>= 9 cells on every level for ATSS)
 
 

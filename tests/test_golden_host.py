@@ -14,6 +14,11 @@ def test_head_forward_loss_backward_decode(task, cpu_oracle_backend):
     gc.head_case(task, CPU)
 
 
+@pytest.mark.parametrize('task', ['bbox', 'segm', 'pose_bbox', 'pose_kbox'])
+def test_decode_is_exact(task, cpu_oracle_backend):
+    gc.decode_case(task, CPU)
+
+
 def test_assigners_exact():
     gc.assign_case(CPU)
 

@@ -528,9 +528,16 @@ CONV_CASES = [
     (2, 64, 256, 3, 1, 1, 1, 48, 50, True),
     (1, 1024, 512, 1, 1, 0, 1, 50, 48, False),
     (2, 512, 256, 1, 2, 0, 1, 80, 84, True),
-    # 265 pixel tiles x 2 column blocks = 530 workgroups on 512 slots under a deep reduction: the last 9 pixel tiles run as
-    # their own launch with the reduction split (csrc/conv.hip tail_split), forward and data gradient
+    # 265 pixel tiles x 2 column blocks = 530 tiles on 512 workgroup slots under a deep reduction: all 530 are spread evenly by
+    # chunks over 512 workgroups (round 5, csrc/conv.hip sk_plan: stream-K pieces, last arriver of a tile adds its partial
+    # sums in chunk order), forward and data gradient
     (1, 192, 512, 3, 1, 1, 1, 130, 130, True),
+    # the other seams of sk_plan: whole tiles in front of the stream-K part (1048 tiles: 512 plain + 536 shared), few tiles
+    # under a deep reduction (66 tiles, 144 chunks: 512 pieces of ~18 chunks, up to nine partial sums per tile), a strided
+    # data gradient whose residue classes take stream-K pieces with an output step, and pieces over levels of unequal size
+    (1, 64, 512, 3, 1, 1, 1, 184, 182, False),
+    (2, 512, 512, 3, 1, 1, 1, 25, 42, True),
+    (2, 256, 256, 3, 2, 1, 1, 100, 168, False),
 ]
 
 
@@ -711,6 +718,31 @@ def test_conv2d_multi_level_equals_single(C, Co, k, bias, relu, split_mode):
     gr = torch.autograd.grad(yr, xr + pr, [g.double().cpu() for g in gos])
     for a_, b_ in zip(list(outs) + list(g_multi), yr + list(gr)):
         assert _err(a_.double(), b_) < tol
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('C,Co,k,s,H,W', [(512, 512, 3, 1, 25, 42), (256, 256, 3, 1, 50, 84), (192, 512, 3, 1, 130, 130),
+                                          (256, 256, 3, 2, 100, 168)])
+def test_conv2d_stream_k_is_deterministic(C, Co, k, s, H, W):
+    """Stream-K launches (csrc/conv.hip sk_plan) add a tile's partial sums in chunk order whichever workgroup arrives last:
+    the same bits on every run, forward and data gradient, and the arrival counters are left re-armed (the second and third
+    calls would hang short of a tile or double-count otherwise)."""
+    from lsnet_amd.ops.conv import conv2d
+    torch.manual_seed(11)
+    dev = _dev()
+    x = torch.randn(2, C, H, W, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_()
+    w = (torch.randn(Co, C, k, k, device=dev) / (C * k * k) ** 0.5).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(Co, device=dev)
+    ys, gs = [], []
+    for _ in range(3):
+        y = conv2d(x, w, b, s, k // 2, 1)
+        go = torch.ones_like(y) * 0.5 + y.detach() * 0.25
+        ys.append(y.detach().clone())
+        gs.append(torch.autograd.grad(y, x, go)[0].clone())
+    assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2])
+    assert torch.equal(gs[0], gs[1]) and torch.equal(gs[0], gs[2])
+    ref = F.conv2d(x.detach().double().cpu(), w.double().cpu(), b.double().cpu(), s, k // 2)
+    assert _err(ys[0].double(), ref) < 3e-6
 
 
 @pytest.mark.gpu
