@@ -274,6 +274,56 @@ def config_leg(dev, task, backbone, n=3, warm=2):
     return out
 
 
+MS_SHAPES = [(800, 1344), (960, 1344), (640, 1344), (1344, 800), (480, 1344)]
+
+
+def mstrain_leg(dev, n_cycles=2):
+    """BASELINE config 3 the way it trains: R-101-DCN bbox with `img_scale=[(1333, 480), (1333, 960)],
+    multiscale_mode='range'` (configs/lsnet/lsnet_bbox_r50_fpn_mstrain_2x_coco.py:13-15) and GroupSampler's landscape /
+    portrait batches (mmdet/datasets/samplers/group_sampler.py:60-140): the padded batch shape changes EVERY iteration.
+    One pass over MS_SHAPES untimed (scratch buffers and the allocator meet every shape), then n_cycles timed passes;
+    beside it the same model at the fixed 800 x 1344, and what the library asked of the HIP runtime during the timed passes
+    (lsn_scratch_stats: must be nothing)."""
+    from lsnet_amd import _lib
+    from lsnet_amd.data import synthetic_batch
+    from lsnet_amd.model_zoo import build_lsnet
+    from lsnet_amd.parallel import DataParallelModel
+    torch.manual_seed(0)
+    model, cfg = build_lsnet('bbox', 'r101-dcn')
+    model = DataParallelModel(model.to(dev).to(memory_format=torch.channels_last).train())
+    step, _ = build_step(model, cfg)
+    batches = [synthetic_batch('bbox', 2, h, w, seed=1234 + i, device=dev, channels_last=True) for i, (h, w) in enumerate(MS_SHAPES)]
+    fixed = timed_steps(step, batches[0], 3, 2)
+    for b in batches:
+        step(b)
+    torch.cuda.synchronize()
+    s0 = _lib.scratch_stats()
+    a0 = torch.cuda.memory_stats().get('num_device_alloc', 0)
+    t0 = time.perf_counter()
+    for _ in range(n_cycles):
+        for b in batches:
+            out = step(b)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / (n_cycles * len(batches))
+    s1 = _lib.scratch_stats()
+    a1 = torch.cuda.memory_stats().get('num_device_alloc', 0)
+    # image-area weighted: the cycle's mean image has 1.0 x the pixels of 800 x 1344 only by accident of the list
+    px = sum(h * w for h, w in MS_SHAPES) / len(MS_SHAPES) / (800 * 1344)
+    res = dict(metric='img/s train LSNet R101-DCN bbox, 2 img/GPU, padded shape cycling ' + ' / '.join(f'{h}x{w}' for h, w in MS_SHAPES),
+               value=2 / dt, unit='img/s', ms_per_step=dt * 1e3, steps=n_cycles * len(batches),
+               fixed_shape_800x1344={'value': 2 / fixed, 'ms_per_step': fixed * 1e3},
+               mean_pixels_vs_800x1344=px, value_per_800x1344_image=2 / dt * px,
+               ratio_to_fixed_shape_pixel_normalised=(2 / dt * px) / (2 / fixed),
+               library_hipMalloc_calls_during_timed_passes=s1['mallocs'] - s0['mallocs'],
+               library_blocking_syncs_during_timed_passes=s1['blocking_syncs'] - s0['blocking_syncs'],
+               library_scratch_mbytes=s1['held_bytes'] / 2 ** 20,
+               torch_allocator_device_allocs_during_timed_passes=int(a1 - a0),
+               loss=float(out['log_vars']['loss']))
+    del model, step, batches
+    torch.cuda.empty_cache()
+    return res
+
+
 def timed_steps(step, data, n, warm):
     for _ in range(warm):
         step(data)
@@ -507,6 +557,10 @@ def main():
             extra['config4_segm_x101_dcn'] = config_leg(dev, 'segm', 'x101-dcn')
         except Exception as ex:
             extra['config4_segm_x101_dcn'] = {'error': f'{type(ex).__name__}: {ex}'}
+        try:
+            extra['config3_r101_dcn_mstrain'] = mstrain_leg(dev)
+        except Exception as ex:
+            extra['config3_r101_dcn_mstrain'] = {'error': f'{type(ex).__name__}: {ex}'}
 
     if rank == 0:
         imgs = args.batch * world * args.steps

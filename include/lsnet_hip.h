@@ -513,6 +513,14 @@ typedef struct lsn_prof_entry {
 int lsn_prof_enable(int on);
 int lsn_prof_read(lsn_prof_entry *out, int max_entries);
 
+/* What the library itself has asked of the HIP runtime outside kernel launches since it was loaded:
+ *   out4[0] hipMalloc calls (library-owned scratch: partial tiles, stream-K slots and counters, tables -- grown on demand,
+ *           never freed), out4[1] bytes they hold, out4[2] blocking stream synchronisations (a weight-image job table
+ *           that changed), out4[3] stream-ordered pool allocations (hipMallocAsync / hipFreeAsync: no synchronisation).
+ * A training loop whose input shapes change every iteration (the reference's multi-scale training,
+ * configs/lsnet/lsnet_bbox_r50_fpn_mstrain_2x_coco.py:13-15) must reach a state in which out4[0] and out4[2] stay put. */
+int lsn_scratch_stats(long long *out4);
+
 /* D = A(MxK) * B(KxN) through the same MFMA fragment code as the DCN kernels (self-test). */
 int lsn_selftest_mfma(const float *A, const float *B, float *D, int M, int N, int K, int variant,
                       lsn_stream_t stream);

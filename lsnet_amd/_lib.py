@@ -92,7 +92,7 @@ EXPORTS = [
     'lsn_sigmoid_focal_loss_forward', 'lsn_sigmoid_focal_loss_backward', 'lsn_sigmoid_focal_loss_sum',
     'lsn_sigmoid_focal_loss_backward_weighted',
     'lsn_nms_workspace_bytes', 'lsn_nms', 'lsn_topk_columns', 'lsn_offset_chain_forward', 'lsn_offset_chain_backward', 'lsn_clip_sgd_workspace_bytes', 'lsn_clip_sgd_step', 'lsn_selftest_mfma', 'lsn_debug_phase_clocks',
-    'lsn_prof_enable', 'lsn_prof_read',
+    'lsn_prof_enable', 'lsn_prof_read', 'lsn_scratch_stats',
     'lsn_group_norm_workspace_bytes', 'lsn_group_norm_forward', 'lsn_group_norm_backward',
     'lsn_set_math_mode', 'lsn_get_math_mode', 'lsn_conv2d_forward', 'lsn_conv2d_forward_pitched', 'lsn_conv2d_backward_data',
     'lsn_conv2d_prepared_bytes', 'lsn_conv2d_prepare_weights', 'lsn_conv2d_prepare_weights_multi',
@@ -164,6 +164,15 @@ def prof_read():
         check(n)
     return {arr[i].name.decode(): dict(launches=int(arr[i].launches), total_ms=arr[i].total_ms,
                                        flops=arr[i].flops, bytes=arr[i].bytes) for i in range(n)}
+
+
+def scratch_stats():
+    """What the library has asked of the HIP runtime outside launches (lsn_scratch_stats): dict(mallocs, held_bytes,
+    blocking_syncs, pool_allocs)."""
+    import ctypes
+    out = (ctypes.c_longlong * 4)()
+    check(load().lsn_scratch_stats(out))
+    return dict(mallocs=int(out[0]), held_bytes=int(out[1]), blocking_syncs=int(out[2]), pool_allocs=int(out[3]))
 
 
 MATH_FP32, MATH_BF16X3, MATH_BF16X6 = 0, 1, 2

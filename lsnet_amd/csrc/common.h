@@ -31,6 +31,11 @@ int fail(int code, const char *fmt, ...);
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// lsn_scratch_stats counters (conv.hip): what the library itself asks of the HIP runtime outside launches -- a training loop
+// whose shapes change every iteration (multi-scale training) must reach a state in which none of these moves any more
+enum { STAT_MALLOCS = 0, STAT_HELD_BYTES = 1, STAT_BLOCKING_SYNCS = 2, STAT_POOL_ALLOCS = 3 };
+void lib_stat(int which, long long add);
+
 // v_mfma_f32_32x32x2_f32: D(32x32) += A(32x2) * B(2x32).
 //   lane l supplies A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31];
 //   D register r of lane l is D[row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)][col = l & 31].

@@ -37,6 +37,9 @@ static int conv_npl() { return conv_np() == 3 ? 2 : 3; }
 // RETIRED, not freed: a captured hipGraph may hold its address, and no device synchronisation is needed.
 // Growing while the stream is being captured is refused -- run the step eagerly once first (the graph wrapper's warm-up
 // calls do).  Host-side bookkeeping is not thread-safe (one Python thread drives the library).
+static long long g_stat[4] = {0, 0, 0, 0};
+void lib_stat(int which, long long add) { g_stat[which & 3] += add; }
+
 struct Scratch {
     hipStream_t st;
     float *p;
@@ -61,6 +64,7 @@ static int part_buffer(size_t floats, float **p, hipStream_t st)
         const size_t want = floats + floats / 4;
         float *np = nullptr;
         LSN_HIP(hipMalloc(reinterpret_cast<void **>(&np), want * sizeof(float)));
+        lib_stat(STAT_MALLOCS, 1), lib_stat(STAT_HELD_BYTES, (long long)(want * sizeof(float)));
         sc->p = np, sc->floats = want;   // (the old block stays allocated: see above)
     }
     *p = sc->p;
@@ -88,6 +92,7 @@ static int sk_counters(unsigned **p, hipStream_t st)
         return fail(LSN_ERR_RUNTIME, "scratch would grow inside a stream capture: run the step eagerly once before capturing");
     unsigned *np = nullptr;
     LSN_HIP(hipMalloc(reinterpret_cast<void **>(&np), SK_MAX_TILES * sizeof(unsigned)));
+    lib_stat(STAT_MALLOCS, 1), lib_stat(STAT_HELD_BYTES, (long long)(SK_MAX_TILES * sizeof(unsigned)));
     LSN_HIP(hipMemsetAsync(np, 0, SK_MAX_TILES * sizeof(unsigned), st));
     g_skc[g_nskc++] = SkCounters{st, np};
     *p = np;
@@ -397,6 +402,7 @@ struct TempImage {
     int alloc(size_t bytes)
     {
         LSN_HIP(hipMallocAsync(&p, bytes, st));
+        lib_stat(STAT_POOL_ALLOCS, 1);
         return 0;
     }
     ~TempImage()
@@ -779,9 +785,11 @@ static int prepare_weights_multi(int n, const lsn_conv_wprep *it, hipStream_t st
         if (jobs.size() > g_jobs_cap) {
             // (an outgrown table is retired, not freed: a captured graph may hold its address)
             LSN_HIP(hipMalloc(reinterpret_cast<void **>(&g_jobs_dev), (jobs.size() + 64) * sizeof(WfragJob)));
+            lib_stat(STAT_MALLOCS, 1), lib_stat(STAT_HELD_BYTES, (long long)((jobs.size() + 64) * sizeof(WfragJob)));
             g_jobs_cap = jobs.size() + 64;
         }
         LSN_HIP(hipStreamSynchronize(st));   // (an earlier launch may still read the old table)
+        lib_stat(STAT_BLOCKING_SYNCS, 1);
         LSN_HIP(hipMemcpy(g_jobs_dev, jobs.data(), bytes, hipMemcpyHostToDevice));
         g_jobs_host = jobs;
     }
@@ -797,6 +805,13 @@ static int prepare_weights_multi(int n, const lsn_conv_wprep *it, hipStream_t st
 }  // namespace lsn
 
 extern "C" {
+
+int lsn_scratch_stats(long long *out4)
+{
+    LSN_CHECK(out4 != nullptr, "lsn_scratch_stats: NULL pointer");
+    for (int i = 0; i < 4; ++i) out4[i] = lsn::g_stat[i];
+    return 0;
+}
 
 int lsn_conv2d_backward_weight_bn(const float *x, const float *g, const float *w, const float *bn_gamma, const float *bn_mean,
                                   const float *bn_var, float bn_eps, float *grad_w, float *grad_gamma, float *grad_beta, int B,

@@ -134,6 +134,7 @@ struct Scratch {
         void *p = nullptr;
         if (nfloats == 0) nfloats = 1;
         if (hipMallocAsync(&p, nfloats * sizeof(float), st) != hipSuccess) return nullptr;
+        lib_stat(STAT_POOL_ALLOCS, 1);
         ptrs.push_back(p);
         return reinterpret_cast<float *>(p);
     }

@@ -509,6 +509,7 @@ int lsn_sigmoid_focal_loss_sum(const float *logits, const int64_t *targets, cons
     static unsigned *ticket = nullptr;
     if (!part) {
         LSN_HIP(hipMalloc(reinterpret_cast<void **>(&part), 256 * sizeof(float) + sizeof(unsigned)));
+        lsn::lib_stat(lsn::STAT_MALLOCS, 1), lsn::lib_stat(lsn::STAT_HELD_BYTES, 256 * sizeof(float) + sizeof(unsigned));
         ticket = reinterpret_cast<unsigned *>(part + 256);
         LSN_HIP(hipMemset(ticket, 0, sizeof(unsigned)));
     }
@@ -583,13 +584,19 @@ int lsn_topk_columns(const float *x, int P, int G, int ldx, int nseg, const int 
     if (G == 0) return 0;
     int nmax = 0;
     for (int i = 0; i < nseg; ++i) nmax = seg_len[i] > nmax ? seg_len[i] : nmax;
-    const int cap = nmax < 36 * 1024 ? nmax : 36 * 1024;       // <= 144 KB of keys; longer columns re-read the rest from L2
-    static bool attr_set = false;
-    if (!attr_set) {
-        LSN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(lsn::topk_cols_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    36 * 1024 * 4));
-        attr_set = true;
-    }
+    // keys in LDS: as many as the CURRENT device allows a workgroup to opt into (160 KB on gfx950 -> 36 K keys = 144 KB);
+    // longer columns re-read the rest from L2.  The attribute is per device and per process: set it on every call (a
+    // host-side table write) instead of once behind a process-wide flag.
+    int dev = 0, lds_max = 0;
+    LSN_HIP(hipGetDevice(&dev));
+    LSN_HIP(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeSharedMemPerBlockOptin, dev));
+    if (lds_max <= 0) LSN_HIP(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, dev));
+    int cap_max = (lds_max - 4096) / 4;   // (the kernel's static LDS: reduction scratch)
+    if (cap_max > 36 * 1024) cap_max = 36 * 1024;
+    if (cap_max < 1024) return lsn::fail(LSN_ERR_UNSUPPORTED, "topk: device offers %d bytes of LDS per workgroup", lds_max);
+    const int cap = nmax < cap_max ? nmax : cap_max;
+    LSN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(lsn::topk_cols_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                cap_max * 4));
     hipLaunchKernelGGL(lsn::topk_cols_kernel, dim3(G, nseg), dim3(1024), (size_t)cap * 4, stream, x, ldx, G, segs, k, largest,
                        values, reinterpret_cast<long long *>(indices), cap);
     LSN_HIP(hipGetLastError());

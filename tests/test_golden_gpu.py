@@ -24,6 +24,14 @@ def test_head_forward_loss_backward_decode(task, channels_last):
         print(task, 'channels_last' if channels_last else 'contiguous', gu.stats_report())
 
 
+@pytest.mark.parametrize('channels_last', [False, True], ids=['nchw', 'nhwc'])
+@pytest.mark.parametrize('task', ['bbox', 'segm', 'pose_bbox', 'pose_kbox'])
+def test_decode_is_exact_on_the_device(task, channels_last):
+    """SURVEY.md 8 a19: labels, top-k / NMS keep order and the max_per_img cut of get_bboxes equal the reference's EXACTLY
+    (np.array_equal) on the MI355X -- on-device top-k, decode and lsn_nms on bit-identical inputs (fixture decode.npz)."""
+    gc.decode_case(task, _dev(), channels_last)
+
+
 def test_assigners_exact():
     gc.assign_case(_dev())
 
@@ -196,12 +204,4 @@ def test_aug_test_vote_on_the_device():
     # (random weights: a "box" of the untrained head may have its corners in any order; what is checked is that every
     # view's detections came back in the ORIGINAL image's frame -- inside 352 x 288 after rescaling and un-flipping)
     assert np.isfinite(allb).all()
-    assert allb[:, :4].min() >= -1e-2 and allb[:, [0, 2]].max() <= 352 + 1e-2 and allb[:, [1, 3]].max() <= 288 + 1e-2@pytest.mark.parametrize('channels_last', [False, True], ids=['nchw', 'nhwc'])
-@pytest.mark.parametrize('task', ['bbox', 'segm', 'pose_bbox', 'pose_kbox'])
-def test_decode_is_exact_on_the_device(task, channels_last):
-    """SURVEY.md 8 a19: labels, top-k / NMS keep order and the max_per_img cut of get_bboxes equal the reference's EXACTLY
-    (np.array_equal) on the MI355X -- on-device top-k, decode and lsn_nms on bit-identical inputs (fixture decode.npz)."""
-    gc.decode_case(task, _dev(), channels_last)
-
-
-
+    assert allb[:, :4].min() >= -1e-2 and allb[:, [0, 2]].max() <= 352 + 1e-2 and allb[:, [1, 3]].max() <= 288 + 1e-2

@@ -66,6 +66,48 @@ def test_full_size_training_step(task, backbone):
 
 
 @pytest.mark.gpu
+def test_config3_multiscale_training_shapes_change_every_iteration():
+    """BASELINE config 3 the way it trains (configs/lsnet/lsnet_bbox_r50_fpn_mstrain_2x_coco.py:13-15: img_scale 480 .. 960
+    rows, multiscale_mode='range'; group_sampler.py:60-140: landscape and portrait groups): R-101-DCN bbox through the
+    runner for 12 iterations whose padded batch shape cycles 800x1344, 960x1344, 640x1344, 1344x800 (portrait), 480x1344.
+    Tile tables, stream-K plans, 32-bit offset guards, the library's scratch growth and the batched weight gradients all see
+    a new shape every step.  Finite losses, parameters move, and after the first pass over the five shapes the library asks
+    the HIP runtime for NOTHING any more: no hipMalloc, no blocking synchronisation (lsn_scratch_stats)."""
+    from lsnet_amd import _lib
+    from lsnet_amd.parallel import DataParallelModel
+    dev = torch.device('cuda:0')
+    torch.manual_seed(0)
+    model, cfg = build_lsnet('bbox', 'r101-dcn')
+    model = DataParallelModel(model.to(dev).to(memory_format=torch.channels_last).train())
+    opt = build_optimizer(model, cfg.optimizer)
+    r = EpochBasedRunner(model, optimizer=opt, logger=lambda s: None)
+    r.register_training_hooks(cfg.lr_config, cfg.optimizer_config, None, dict(interval=10 ** 9, hooks=[]))
+    shapes = [(800, 1344), (960, 1344), (640, 1344), (1344, 800), (480, 1344)]
+    batches = [synthetic_batch('bbox', 2, h, w, seed=20 + i, device=dev) for i, (h, w) in enumerate(shapes)]
+    before = {k: v.detach().clone() for k, v in model.module.named_parameters() if v.requires_grad}
+    losses, stats = [], []
+
+    from lsnet_amd.runner import Hook
+
+    class Probe(Hook):   # after every iteration (behind the optimizer hook): the loss and the library's counters
+        priority = 99
+
+        def after_train_iter(self, runner):
+            losses.append(float(runner.outputs['log_vars']['loss']))
+            stats.append(_lib.scratch_stats())
+    r.register_hook(Probe())
+    r.run([[batches[i % 5] for i in range(12)]], [('train', 1)], 1)
+    assert len(losses) == 12 and all(l == l and 0 < l < 200 for l in losses), losses
+    moved = sum(int(not torch.equal(before[k], v.detach())) for k, v in model.module.named_parameters() if v.requires_grad)
+    assert moved > 0.9 * len(before), (moved, len(before))
+    assert all(torch.isfinite(p).all() for p in model.parameters())
+    first_pass, last = stats[4], stats[-1]
+    assert last['mallocs'] == first_pass['mallocs'], ('the library allocated after it had seen every shape', first_pass, last)
+    assert last['blocking_syncs'] == first_pass['blocking_syncs'], (first_pass, last)
+    print('config 3 multi-scale: losses', [round(l, 3) for l in losses], 'library scratch', last)
+
+
+@pytest.mark.gpu
 def test_full_size_pose_inference_batch():
     """BASELINE config 5: R-50-FPN pose head, 4 images 3 x 800 x 1344, forward + decode + NMS on the device."""
     dev = torch.device('cuda:0')
