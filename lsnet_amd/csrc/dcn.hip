@@ -661,11 +661,9 @@ static int bwd_tap_groups(const DcnArgs &a)
 // same call was tried as well, profiles/r4_side_lists.txt: nothing on the tower launch, 995 vs 992 us per backward call (the
 // gathers take the CUs from the weight gradient's workgroups instead of sharing them), -120 us on the pyramid launch,
 // 0.25 ms per step -- and two kernel families that can no longer be timed apart.  Removed.)
-constexpr int MAX_BANDS = 12;
 struct SideStream {
     hipStream_t main = nullptr, side = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
-    hipEvent_t band[MAX_BANDS] = {};   // band i of the column-gradient GEMM is written (band pipeline below)
 };
 static SideStream g_side[16];
 static int g_nside = 0;
@@ -686,7 +684,6 @@ static int side_stream(hipStream_t st, SideStream **out)
     LSN_HIP(hipStreamCreateWithPriority(&S.side, hipStreamNonBlocking, hi));
     LSN_HIP(hipEventCreateWithFlags(&S.fork, hipEventDisableTiming));
     LSN_HIP(hipEventCreateWithFlags(&S.join, hipEventDisableTiming));
-    for (int i = 0; i < MAX_BANDS; ++i) LSN_HIP(hipEventCreateWithFlags(&S.band[i], hipEventDisableTiming));
     S.main = st;
     ++g_nside;
     *out = &S;
@@ -694,73 +691,10 @@ static int side_stream(hipStream_t st, SideStream **out)
 }
 static bool side_lists_env() { return !((g_dbg_block >> 21) & 1); }   // debug bit 21: lists on the launch stream (A/B)
 
-// ---- band pipeline of the unweighted-GEMM backward (round 5) ----
-// The column gradients of a launch (413 MB tower, 1.24 GB pyramid) are written by the GEMM and read back once by the
-// per-anchor sums.  Anchor grids of different grad_input maps, and of different IMAGES of one map, are independent: the
-// launch is cut into bands (an anchor range + the GEMM rows that scatter into it), the GEMM runs band after band on the
-// launch stream and the per-anchor sums of band i run on the side stream (behind the list kernels) as soon as band i is
-// written -- beside the GEMM of band i + 1, while band i's column gradients are still in the 256 MB Infinity Cache.
-// The smallest band goes last: its sums are the only ones nothing hides.
-struct Band {
-    int nrows;                     // GEMM row ranges
-    const float *x[MAXLV];
-    float *out[MAXLV];
-    int rows[MAXLV];
-    int a_first, a_count;          // anchor range in the S numbering
-    size_t bytes;
-};
-static bool band_env() { return !((g_dbg_block >> 20) & 1); }   // debug bit 20: one band (A/B)
-
-static int plan_bands(const DcnArgs &a, const GatherPlan &pl, Band *bands)
-{
-    const int K = a.kh * a.kw;
-    const size_t row_bytes = (size_t)K * a.C * sizeof(float);
-    constexpr size_t SPLIT_ABOVE = (size_t)160 << 20, MERGE_UP_TO = (size_t)128 << 20;
-    int nb = 0;
-    for (int gi = 0; gi < pl.aa.ng; ++gi) {
-        const AnchorGrp &G = pl.aa.g[gi];
-        size_t gbytes = 0;
-        for (int i = 0; i < a.nlv; ++i)
-            if (a.lv[i].gx == G.gx) gbytes += (size_t)a.lv[i].P * row_bytes;
-        const int parts = (gbytes > SPLIT_ABOVE && G.B > 1) ? G.B : 1;
-        const int apg = (G.H + 1) * (G.W + 1);   // anchors per image
-        for (int pt = 0; pt < parts; ++pt) {
-            Band nbnd = {};
-            for (int i = 0; i < a.nlv; ++i) {
-                const Lvl &L = a.lv[i];
-                if (L.gx != G.gx) continue;
-                const int per = L.P / L.B;   // rows per image (image-major)
-                const int r0 = parts > 1 ? pt * per : 0, rn = parts > 1 ? per : L.P;
-                if (nbnd.nrows == MAXLV) return 0;
-                nbnd.x[nbnd.nrows] = L.gout + (size_t)r0 * a.opitch;
-                nbnd.out[nbnd.nrows] = a.gcol + ((size_t)L.prow0 + r0) * K * a.C;
-                nbnd.rows[nbnd.nrows] = rn;
-                nbnd.bytes += (size_t)rn * row_bytes;
-                ++nbnd.nrows;
-            }
-            nbnd.a_first = G.a0 + (parts > 1 ? pt * apg : 0);
-            nbnd.a_count = parts > 1 ? apg : G.B * apg;
-            // merge with the previous band when both are small, the anchor ranges touch and neither crosses na_long
-            if (nb > 0 && bands[nb - 1].bytes + nbnd.bytes <= MERGE_UP_TO && bands[nb - 1].a_first + bands[nb - 1].a_count == nbnd.a_first &&
-                (bands[nb - 1].a_first >= pl.na_long) == (nbnd.a_first >= pl.na_long) && bands[nb - 1].nrows + nbnd.nrows <= MAXLV) {
-                Band &P = bands[nb - 1];
-                for (int r = 0; r < nbnd.nrows; ++r) P.x[P.nrows] = nbnd.x[r], P.out[P.nrows] = nbnd.out[r], P.rows[P.nrows] = nbnd.rows[r], ++P.nrows;
-                P.a_count += nbnd.a_count, P.bytes += nbnd.bytes;
-                continue;
-            }
-            if (nb == MAX_BANDS) return 0;
-            bands[nb++] = nbnd;
-        }
-    }
-    // largest first, smallest last (insertion sort: <= 12 entries)
-    for (int i = 1; i < nb; ++i)
-        for (int j = i; j > 0 && bands[j].bytes > bands[j - 1].bytes; --j) {
-            const Band t = bands[j];
-            bands[j] = bands[j - 1], bands[j - 1] = t;
-        }
-    return nb;
-}
-
+// (Round 5 cut the launch into bands -- an anchor range per image of a grad_input map + the GEMM rows that scatter into it --
+// and ran the per-anchor sums of band i on the side stream beside the GEMM of band i + 1, the column gradients of a band
+// still in the Infinity Cache: tower +7 % slower, pyramid unchanged, profiles/r5_band_pipeline.txt.  GEMM and sums are both
+// bound by the memory system; removed.)
 template <int NP>
 static int launch_bwd_colbuf(DcnArgs &a, GatherPlan &pl, unsigned char *ws, hipStream_t st_main)
 {
@@ -814,34 +748,6 @@ static int launch_bwd_colbuf(DcnArgs &a, GatherPlan &pl, unsigned char *ws, hipS
             outs[i] = a.gcol + (size_t)a.lv[i].prow0 * a.kh * a.kw * a.C;
             rows[i] = a.lv[i].P;
             any_off = any_off || a.lv[i].goff || a.lv[i].gmsk;
-        }
-        Band bands[MAX_BANDS];
-        const int nb = (side && band_env() && pl.aa.ng > 0 && pl.ga.NB == 0) ? plan_bands(a, pl, bands) : 0;
-        if (nb > 1) {
-            pl.aa.raw = 1, pl.aa.Hb = any_off ? reinterpret_cast<float *>(ws + pl.o_H) : nullptr;
-            pl.aa.gcol = a.gcol, pl.aa.start = start, pl.aa.ent = ent;
-            pl.aa.S = reinterpret_cast<float *>(ws + pl.o_S);
-            for (int b = 0; b < nb; ++b) {
-                const Band &Bd = bands[b];
-                if (int rc = conv_mm_rows(Bd.nrows, Bd.x, Bd.out, Bd.rows, a.Co, a.opitch, a.kh * a.kw * a.C, a.wtp, st_main)) return rc;
-                LSN_HIP(hipEventRecord(side->band[b], st_main));
-                LSN_HIP(hipStreamWaitEvent(side->side, side->band[b], 0));   // (the side stream is past the list kernels)
-                const int f = Bd.a_first, e = Bd.a_first + Bd.a_count;
-                const int le = e < pl.na_long ? e : pl.na_long;   // anchors below na_long: four waves each
-                if (f < le)
-                    hipLaunchKernelGGL(dcn_anchor_sum_kernel<4>, dim3(le - f), dim3(256), 0, side->side, pl.aa, f, le - f);
-                const int sf = f > pl.na_long ? f : pl.na_long;
-                if (sf < e)
-                    hipLaunchKernelGGL(dcn_anchor_sum_kernel<1>, dim3(cdiv(e - sf, 4)), dim3(256), 0, side->side, pl.aa, sf, e - sf);
-            }
-            LSN_HIP(hipEventRecord(side->join, side->side));
-            LSN_HIP(hipStreamWaitEvent(st_main, side->join, 0));
-            hipLaunchKernelGGL(dcn_anchor_combine_kernel, dim3(cdiv(pl.anchor_pixels, 4)), dim3(256), 0, st_main, pl.aa, pl.anchor_pixels);
-            if (pl.aa.Hb)
-                hipLaunchKernelGGL(dcn_offgrad_kernel, dim3(cdiv(pl.nsamples, 256)), dim3(256), 0, st_main, a, pl.nsamples,
-                                   reinterpret_cast<const float4 *>(pl.aa.Hb));
-            LSN_HIP(hipGetLastError());
-            return 0;
         }
         if (int rc = conv_mm_rows(a.nlv, xs, outs, rows, a.Co, a.opitch, a.kh * a.kw * a.C, a.wtp, st)) return rc;
         if (side) LSN_HIP(hipStreamWaitEvent(st_main, side->join, 0));
