@@ -144,6 +144,22 @@ __device__ __forceinline__ int xcd_remap(int b, int total)
     return x * q + min(x, r) + i;
 }
 
+// ---- handing data to ANOTHER workgroup of the same launch (last-arriver reductions) ----
+// The eight XCDs have their own L2s.  A release / acquire fence pair (__threadfence) makes a workgroup's plain stores visible
+// to the others by writing back and invalidating the WHOLE L2 -- measured at 150 - 250 us per launch when a few hundred
+// workgroups do it (profiles/r5_sk_fence.txt; the first ticketed GroupNorm statistics lost 0.4 ms per step to it).  Instead
+// the handed-over values are written and read with AGENT-scope accesses (sc1: through to / from the coherence point), the
+// writer waits for its stores (vmcnt) before it draws the ticket, and nothing is flushed.
+template <typename T> __device__ __forceinline__ void store_agent(T *p, T v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename T> __device__ __forceinline__ T load_agent(const T *p)
+{
+    return __hip_atomic_load(const_cast<T *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void wait_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // hardware fp32 atomic add without return (global_atomic_add_f32), device scope
 __device__ __forceinline__ void atomic_add_f32(float *p, float v) { unsafeAtomicAdd(p, v); }
 

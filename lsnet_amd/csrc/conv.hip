@@ -73,6 +73,7 @@ static int part_buffer(size_t floats, float **p, hipStream_t st)
 
 // Per-stream arrival counters of the stream-K tiles (conv_kernels.h ConvArgs): zeroed once, every launch leaves them zero.
 constexpr int SK_MAX_TILES = 4096;
+constexpr int LIB_TICKETS = 1024;   // behind the stream-K counters: self-resetting tickets of other kernels (norm.hip)
 struct SkCounters {
     hipStream_t st;
     unsigned *p;
@@ -91,11 +92,20 @@ static int sk_counters(unsigned **p, hipStream_t st)
     if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
         return fail(LSN_ERR_RUNTIME, "scratch would grow inside a stream capture: run the step eagerly once before capturing");
     unsigned *np = nullptr;
-    LSN_HIP(hipMalloc(reinterpret_cast<void **>(&np), SK_MAX_TILES * sizeof(unsigned)));
-    lib_stat(STAT_MALLOCS, 1), lib_stat(STAT_HELD_BYTES, (long long)(SK_MAX_TILES * sizeof(unsigned)));
-    LSN_HIP(hipMemsetAsync(np, 0, SK_MAX_TILES * sizeof(unsigned), st));
+    LSN_HIP(hipMalloc(reinterpret_cast<void **>(&np), (SK_MAX_TILES + LIB_TICKETS) * sizeof(unsigned)));
+    lib_stat(STAT_MALLOCS, 1), lib_stat(STAT_HELD_BYTES, (long long)((SK_MAX_TILES + LIB_TICKETS) * sizeof(unsigned)));
+    LSN_HIP(hipMemsetAsync(np, 0, (SK_MAX_TILES + LIB_TICKETS) * sizeof(unsigned), st));
     g_skc[g_nskc++] = SkCounters{st, np};
     *p = np;
+    return 0;
+}
+
+// norm.hip: LIB_TICKETS zero-initialised, self-resetting ticket counters of this stream (last-arriver reductions)
+int lib_tickets(unsigned **p, hipStream_t st)
+{
+    unsigned *base = nullptr;
+    if (int rc = sk_counters(&base, st)) return rc;
+    *p = base + SK_MAX_TILES;
     return 0;
 }
 
@@ -111,7 +121,7 @@ static int sk_counters(unsigned **p, hipStream_t st)
 static void sk_plan(int ntw, int Tall, int *n_dp, int *sk_n, int *sk_tiles)
 {
     *n_dp = ntw, *sk_n = 0, *sk_tiles = 0;
-#ifdef LSNET_AB
+#ifdef LSNET_AB_DIST   // build.py --ab -DLSNET_AB_DIST: rounds 3 / 4 work distribution (profiles/r5_sk_*.txt)
     return;
 #endif
     constexpr int SLOTS = 512;
@@ -201,7 +211,7 @@ static int launch_conv_range(ConvArgs &a, int ks, int tile_base, int ntiles, hip
     return 0;
 }
 
-#ifdef LSNET_AB
+#ifdef LSNET_AB_DIST   // build.py --ab -DLSNET_AB_DIST: rounds 3 / 4 work distribution (profiles/r5_sk_*.txt)
 // Round 4's tail split (the A/B library keeps rounds 3 / 4's work distribution: blockIdx.z splits, this, no stream-K): a
 // single-level launch whose last round would be a small remainder runs its last pixel tiles as a second launch with the
 // reduction split `kt` ways (profiles/r4_tail_split.txt).
@@ -228,7 +238,7 @@ static int launch_conv_cfg(ConvArgs &a, int ks, hipStream_t st)
         tiles += (a.lv[i].P + BM - 1) / BM;
     }
     a.ntiles = tiles;
-#ifdef LSNET_AB
+#ifdef LSNET_AB_DIST   // build.py --ab -DLSNET_AB_DIST: rounds 3 / 4 work distribution (profiles/r5_sk_*.txt)
     const int colblocks = (a.Co + BN - 1) / BN;
     int tail = 0;
     const int kt = (a.nlv == 1 && !a.ostep && ks == 1 && !TRANS) ? tail_split(tiles * colblocks, colblocks, a.kh * a.kw * cv_ncc(a.C), &tail)
@@ -282,7 +292,7 @@ static int conv_forward(ConvArgs &a, hipStream_t st)
     const int nb = cfg == 2 ? blocks(64, 128) : cfg == 3 ? blocks(128, 64) : cfg == 5 ? blocks(64, 256) : blocks(128, 32);
     const int Tall = a.kh * a.kw * cv_ncc(a.C);
     int ks = 1;
-#ifdef LSNET_AB
+#ifdef LSNET_AB_DIST   // build.py --ab -DLSNET_AB_DIST: rounds 3 / 4 work distribution (profiles/r5_sk_*.txt)
     if (a.nlv == 1 && !a.ostep && nb <= 320 && Tall >= 16) {
         ks = (512 + nb / 2) / nb;
         if (ks > Tall / 8) ks = Tall / 8;
@@ -320,7 +330,7 @@ int conv_mm_rows(int n, const float *const *x, float *const *out, const int *row
     a.C = Cr, a.Co = N, a.kh = a.kw = 1, a.stride = 1, a.pad_h = a.pad_w = 0, a.dil = 1;
     a.xpitch = xpitch;
     if (N % 256 == 0) {   // the 64 x 256 tile with whole-line stores (conv_kernels.h TRANS); plain output, one split
-#ifdef LSNET_AB
+#ifdef LSNET_AB_DIST   // build.py --ab -DLSNET_AB_DIST: rounds 3 / 4 work distribution (profiles/r5_sk_*.txt)
         return conv_forward(a, st);
 #else
         return conv_np() == 3 ? launch_conv_cfg<2, 2, 1, 4, 3, false, true, true>(a, 1, st)
@@ -614,7 +624,7 @@ static int launch_wgrad_cfg(WgArgs &a, float *gw, float *gb, int accumulate, hip
     const int blocks = cdiv(a.Co, BM) * cdiv(a.C, BN);
     const size_t nW = (size_t)a.Co * K * a.C;
     const int nj = wg_jobs();   // > 1: the levels are jobs with their own outputs; every split stays inside one level
-#ifdef LSNET_AB
+#ifdef LSNET_AB_DIST   // build.py --ab -DLSNET_AB_DIST: rounds 3 / 4 work distribution (profiles/r5_sk_*.txt)
     int S = (512 + blocks * nj / 2) / (blocks * nj);
 #else
     int S = 512 / (blocks * nj);   // one round of workgroups (rounds 3 / 4 rounded to nearest: 516 .. 540 on 512 slots)

@@ -445,6 +445,7 @@ __global__ __launch_bounds__(256, 2) void conv_mm_kernel(const ConvArgs a)
     //   D  MFMAs of k-step 1, weight loads of (t + 1, 1); barrier
     // Loads are issued in the order they are consumed, so every counted vmcnt wait leaves the younger ones in flight:
     // each load has at least half an iteration (24 MFMAs of this wave plus the partner workgroup's share of the SIMD).
+#ifdef LSNET_OLD_LOOP
     for (int t = 0; t < T; ++t) {
         const unsigned char *bc = smem + (t & 1) * BUF;
         unsigned char *bn = smem + ((t & 1) ^ 1) * BUF;
@@ -453,9 +454,51 @@ __global__ __launch_bounds__(256, 2) void conv_mm_kernel(const ConvArgs a)
         if (t + 2 < T) next(c1);
         open_x(c1, t + 2 < T);
         __builtin_amdgcn_sched_barrier(0);
-        // k-step 0 in NLD parts; behind each part one staging slice: split 32 pixels of chunk t + 1 into the other LDS
-        // buffer, then fetch the same rows of chunk t + 2 into the freed registers -- the split's VALU work runs in the
-        // shadow of this wave's own MFMAs instead of in front of them
+        constexpr int NM = NP * TN * TM;
+#pragma unroll
+        for (int ps = 0; ps < NLD; ++ps) {
+#pragma unroll
+            for (int m = ps * NM / NLD; m < (ps + 1) * NM / NLD; ++m) {
+                const int prod = m / (TN * TM), j = (m / TM) % TN, i = m % TM;
+                acc[j][i] = TRANS ? mfma_bf16(Xf[0][i][SC::pa(prod)], Wf[0][j][SC::pb(prod)], acc[j][i])
+                                  : mfma_bf16(Wf[0][j][SC::pb(prod)], Xf[0][i][SC::pa(prod)], acc[j][i]);
+            }
+            if (FINE || t + 1 < T) commit_slice(ps, bn);
+            issue_slice(ps);
+            if constexpr (FINE) {
+#pragma unroll
+                for (int g = 0; g < NM / NLD; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x006, 3, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        issue_w(t + 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_block(1);
+        issue_w(t + 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+    }
+#else
+    // Round 5: the barrier sits in the MIDDLE of the iteration and the k-step-0 fragments of chunk t + 1 are read right
+    // behind it, under the MFMAs of k-step 1 (their registers are dead by then); the k-step-1 fragments of chunk t are
+    // read at the top, under the MFMAs of k-step 0.  No MFMA waits for an LDS read issued just in front of it any more.
+    //   top   fragment reads of (t, k-step 1)
+    //   B     MFMAs of k-step 0 in NLD parts; behind each: split 32 pixels of chunk t + 1 -> the other LDS buffer, fetch
+    //         the same rows of chunk t + 2; then the weight loads of (t + 1, 0)
+    //   ----  barrier: buffer t + 1 is complete; nobody reads buffer t any more (its k-step-0 fragments were taken in
+    //         iteration t - 1, its k-step-1 fragments at the top of this one and the barrier waits for them)
+    //   D     fragment reads of (t + 1, k-step 0), MFMAs of k-step 1, weight loads of (t + 1, 1)
+    read_x(smem, 0);   // (chunk 0: the prologue's barrier has passed)
+    for (int t = 0; t < T; ++t) {
+        const unsigned char *bc = smem + (t & 1) * BUF;
+        unsigned char *bn = smem + ((t & 1) ^ 1) * BUF;
+        read_x(bc, 1);
+        if (t + 2 < T) next(c1);
+        open_x(c1, t + 2 < T);
+        __builtin_amdgcn_sched_barrier(0);
         constexpr int NM = NP * TN * TM;
 #pragma unroll
         for (int ps = 0; ps < NLD; ++ps) {
@@ -478,11 +521,14 @@ __global__ __launch_bounds__(256, 2) void conv_mm_kernel(const ConvArgs a)
         }
         issue_w(t + 1, 0);
         __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        read_x(bn, 0);   // (past the last chunk: whatever the buffer holds, never used)
         mfma_block(1);
         issue_w(t + 1, 1);
         __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
     }
+    __syncthreads();   // (the next segment's prologue writes buffer 0: every wave is past its last fragment read)
+#endif
 
     // ---- stream-K: a piece that holds only part of the tile's sum ----
     // Visibility across the eight L2s without flushing them: the slot is written and read with AGENT-scope accesses (sc1:

@@ -68,7 +68,8 @@ __device__ __forceinline__ float block_sum_256(float v)
     return part[0] + part[1] + part[2] + part[3];
 }
 
-// loss_sum = sum_n w[n] * sum_c FL(n,c).  At most 256 blocks; each leaves its sum in part[] and takes a ticket, the block
+// loss_sum = sum_n w[n] * sum_c FL(n,c).  At most 1024 blocks (round 5; 256 until then: 41 transcendental-heavy elements per
+// thread at the P3 level, 19 us per launch for 11 MB -- profiles/r5_pmc_hbm_stream.txt); each leaves its sum in part[] and takes a ticket, the block
 // that draws the last one adds the partials up with the same fixed tree: no floating-point atomics, the same bits on
 // every run (round 2: one fp32 atomic per block).
 __global__ void focal_sum_kernel(const float *__restrict__ logits, const int64_t *__restrict__ targets,
@@ -87,14 +88,14 @@ __global__ void focal_sum_kernel(const float *__restrict__ logits, const int64_t
     s = block_sum_256(s);
     __shared__ int last;
     if (threadIdx.x == 0) {
-        part[blockIdx.x] = s;
-        __threadfence();
+        store_agent(part + blockIdx.x, s);   // (common.h: agent-scope hand-over instead of a fence pair)
+        wait_stores();
         last = atomicAdd(ticket, 1u) == gridDim.x - 1;
     }
     __syncthreads();
     if (!last) return;
-    __threadfence();
-    const float v = threadIdx.x < gridDim.x ? __builtin_nontemporal_load(part + threadIdx.x) : 0.f;
+    float v = 0.f;   // up to four partials per thread, in block order
+    for (unsigned b = threadIdx.x; b < gridDim.x; b += 256) v += load_agent(part + b);
     __syncthreads();   // (block_sum_256 reuses its LDS words)
     const float tot = block_sum_256(v);
     if (threadIdx.x == 0) {
@@ -508,13 +509,13 @@ int lsn_sigmoid_focal_loss_sum(const float *logits, const int64_t *targets, cons
     static float *part = nullptr;
     static unsigned *ticket = nullptr;
     if (!part) {
-        LSN_HIP(hipMalloc(reinterpret_cast<void **>(&part), 256 * sizeof(float) + sizeof(unsigned)));
-        lsn::lib_stat(lsn::STAT_MALLOCS, 1), lsn::lib_stat(lsn::STAT_HELD_BYTES, 256 * sizeof(float) + sizeof(unsigned));
-        ticket = reinterpret_cast<unsigned *>(part + 256);
+        LSN_HIP(hipMalloc(reinterpret_cast<void **>(&part), 1024 * sizeof(float) + sizeof(unsigned)));
+        lsn::lib_stat(lsn::STAT_MALLOCS, 1), lsn::lib_stat(lsn::STAT_HELD_BYTES, 1024 * sizeof(float) + sizeof(unsigned));
+        ticket = reinterpret_cast<unsigned *>(part + 1024);
         LSN_HIP(hipMemset(ticket, 0, sizeof(unsigned)));
     }
     int grid = ew_grid((size_t)N * C);
-    if (grid > 256) grid = 256;
+    if (grid > 1024) grid = 1024;
     hipLaunchKernelGGL(focal_sum_kernel, dim3(grid), dim3(256), 0, stream, logits, targets, weight, loss_sum, N, C, gamma,
                        alpha, part, ticket);
     LSN_HIP(hipGetLastError());

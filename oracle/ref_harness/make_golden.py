@@ -238,7 +238,7 @@ def golden_train_curve(lr=0.01, fixture='train_curve'):
     cfg = curve_cfg()
     model_cfg = mmcv.Config(copy.deepcopy(cfg.model.to_dict() if hasattr(cfg.model, 'to_dict') else dict(cfg.model)))._cfg_dict
     model = build_detector(model_cfg, train_cfg=mmcv.Config(dict(cfg.train_cfg)), test_cfg=mmcv.Config(dict(cfg.test_cfg)))
-    gu.fill_params(model, seed=11)
+    gu.fill_params(model, seed=11, head_norm_shift=0.0, pair_gap=1.0)   # (round 4's fill: golden_util.fill_params)
     model.train()
     opt = torch.optim.SGD(model.parameters(), lr=lr, momentum=0.9, weight_decay=0.0001)
     logger = logging.getLogger('curve')

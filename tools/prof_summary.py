@@ -35,6 +35,33 @@ lines = [f'# source: {files[0]}', f'# {region}: {len(sel)} dispatches, {steps} s
 for name, a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:70]:
     lines.append(f'{a[1] / 1e3 / steps:9.3f} {100 * a[1] / tot:6.2f} {a[0] / steps:10.1f} {a[1] / a[0]:10.1f} {a[2]:9.1f} '
                  f'{a[3]:9.1f}  {name[:160]}')
+# ---- where the GPU waits: idle time between consecutive dispatches of the timed region (union of busy intervals: kernels of
+# the side stream overlap the launch stream's), by the kernel that FOLLOWS the gap ----
+ev = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']) for r in sel)
+gaps = defaultdict(lambda: [0, 0.0])
+idle, busy_end, hist = 0.0, ev[0][1] if ev else 0, [0, 0, 0, 0, 0]
+big = []
+for st, en, name in ev[1:]:
+    if st > busy_end:
+        g = (st - busy_end) / 1e3
+        idle += g
+        key = name.split('(')[0][:90]
+        gaps[key][0] += 1
+        gaps[key][1] += g
+        hist[0 if g < 2 else 1 if g < 5 else 2 if g < 10 else 3 if g < 50 else 4] += 1
+        if g >= 20:
+            big.append((g, name[:100]))
+    busy_end = max(busy_end, en)
+lines.append('')
+lines.append(f'# idle between dispatches: {idle / 1e3 / steps:.2f} ms/step in {sum(hist) / steps:.0f} gaps/step; gaps < 2 us: {hist[0] / steps:.0f}, 2 - 5: '
+             f'{hist[1] / steps:.0f}, 5 - 10: {hist[2] / steps:.0f}, 10 - 50: {hist[3] / steps:.0f}, >= 50: {hist[4] / steps:.0f} per step '
+             '(under the tracer: every dispatch pays its instrumentation)')
+lines.append(f'{"idle ms/step":>13} {"gaps/step":>10} {"avg_us":>8}  kernel that follows the gap')
+for name, g in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:25]:
+    lines.append(f'{g[1] / 1e3 / steps:13.3f} {g[0] / steps:10.1f} {g[1] / g[0]:8.1f}  {name}')
+lines.append('# gaps of 20 us and more (what follows them):')
+for g, name in sorted(big, reverse=True)[:15]:
+    lines.append(f'{g:10.1f} us  {name}')
 text = '\n'.join(lines)
 print(text)
 if out:

@@ -1,0 +1,14 @@
+#!/bin/bash
+# round 5: GroupNorm statistics by ticket (no memset, no atomics), parameter gradients in the image-sum kernel, focal sum on 1024 blocks:
+# operator tests, head fixtures, reproducibility, then the short bench twice
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+mkdir -p gpurun_out
+timeout 900 python -m pytest tests/test_ops_gpu.py tests/test_golden_gpu.py tests/test_variants_gpu.py tests/test_graph_gpu.py -q -m gpu -x \
+  -k "group_norm or focal or head_forward or head_at_256 or bit_reproducible or iteration0 or graph" > gpurun_out/r5_c08_tests.log 2>&1; echo "tests rc $?"
+tail -n 4 gpurun_out/r5_c08_tests.log
+for i in 1 2; do
+  timeout 600 python bench.py --no-cpu-baseline --no-extra 2>gpurun_out/bench_err.log | grep '^{' | python -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+print('img/s', round(d['value'],2), 'ms', round(d['ms_per_step'],2), {k: round(v['ms_per_step'],2) for k,v in d['kernels'].items()}, 'loss', d['loss']['loss'])" || tail -5 gpurun_out/bench_err.log
+done 2>&1 | tee gpurun_out/r5_c08_bench.log
