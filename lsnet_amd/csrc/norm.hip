@@ -38,9 +38,8 @@ struct GnArgs {
     int nlv, C, G, relu;
     float eps;
     const float *gamma, *beta;
-    double *sums;      // [stat blocks][G][2]   shifted sum, shifted sum of squares of one GN_SPIX-pixel block
-    int stat_blocks;
-    unsigned *ticket;  // two self-resetting counters of this stream (conv.hip lib_tickets): forward statistics, backward sums
+    double *sums;      // [images][G][2]   shifted sum, shifted sum of squares   (zero-filled by the launcher)
+    unsigned *ticket;  // self-resetting counters of this stream (conv.hip lib_tickets); [1]: the backward's image sums
     float *mean_rstd;  // [images][G][2]
     float *ab;         // [images][C][2]   backward: sum dy*xhat, sum dy
     float *part;       // [blocks][C][2]   backward: the same per 64-pixel block (summed per image in a fixed order)
@@ -73,95 +72,58 @@ __device__ __forceinline__ GnPos gn_pos(const GnArgs &a, const GnLvl &L)
     return r;
 }
 
-// Statistics, round 5: blocks of GN_SPIX pixels leave their per-group partial sums (fp64) in a.sums and draw a ticket; the block
-// that draws the LAST one adds the partials of every (image, group) in block order and writes mean / rstd.  No atomics on the
-// data, no memset in front (rounds 1 - 4: 64-pixel blocks, two fp64 atomics per block and group into a zero-filled buffer --
-// 45 k atomics on 640 addresses and a fill launch per call: 2.1 TB/s, profiles/r5_pmc_hbm_stream.txt), the same bits on every run.
-constexpr int GN_SPIX = 64;    // (256-pixel blocks: 175 blocks for the head launch, less than one per CU -- slower)
-__device__ __forceinline__ void gn_stat_block(const GnArgs &a, int blk, int &li, int &b, int &p0, int &p1)
-{
-    li = 0;
-    int t = blk;
-    for (;;) {
-        const int tpi = (a.lv[li].HW + GN_SPIX - 1) / GN_SPIX, nb = a.lv[li].B * tpi;
-        if (t < nb || li + 1 == a.nlv) {
-            b = t / tpi;
-            p0 = (t - b * tpi) * GN_SPIX;
-            p1 = min(p0 + GN_SPIX, a.lv[li].HW);
-            return;
-        }
-        t -= nb, ++li;
-    }
-}
-
+// (Round 5 tried the statistics without the fill launch and the fp64 atomics: per-block partials + a ticket, the last block of
+// an image adding them in block order -- correct and bit-stable, but 0.1 ms per step SLOWER than this form, 32.60 vs 32.50 ms,
+// old and new library alternating on one box: the finisher's tail costs more than 16 fills and 45 k atomics.  With
+// __threadfence() instead of agent-scope stores it lost 0.4 ms.  profiles/r5_gn_ticket.txt.)
 __global__ __launch_bounds__(256) void gn_stats_kernel(const GnArgs a)
 {
-    int li, pb, p0, p1;
-    gn_stat_block(a, blockIdx.x, li, pb, p0, p1);
-    const GnLvl &L = a.lv[li];
-    const int qn = a.C >> 2, q = threadIdx.x % qn, row = threadIdx.x / qn, rows = 256 / qn;
-    const int cpg = a.C / a.G, g = (q * 4) / cpg;
-    const float *xb = L.x + (size_t)pb * L.HW * a.C;
+    int li;
+    const GnLvl &L = gn_level(a, blockIdx.x, li);
+    const GnPos p = gn_pos(a, L);
+    const int cpg = a.C / a.G, g = (p.q * 4) / cpg;
+    const float *xb = L.x + (size_t)p.b * L.HW * a.C;
     const float K = xb[g * cpg];   // shift: first element of the group in this image
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll 4
-    for (int px = p0 + row; px < p1; px += rows) {
-        const float4 v = *reinterpret_cast<const float4 *>(xb + (size_t)px * a.C + q * 4);
+    for (int px = p.p0 + p.row; px < p.p1; px += p.rows) {
+        const float4 v = *reinterpret_cast<const float4 *>(xb + (size_t)px * a.C + p.q * 4);
         const float d0 = v.x - K, d1 = v.y - K, d2 = v.z - K, d3 = v.w - K;
         s1 += (d0 + d1) + (d2 + d3);
         s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
     }
     // block reduction per group in fp64 through LDS
     __shared__ double acc[256 * 2];
-    __shared__ unsigned last;
     acc[threadIdx.x * 2] = (double)s1;
     acc[threadIdx.x * 2 + 1] = (double)s2;
     __syncthreads();
-    const int qpg = cpg >> 2;
-    if (threadIdx.x < a.G) {   // threads of one group: quads q with (q*4)/cpg == g, all rows
+    // threads of one group: quads q with (q*4)/cpg == g, all rows.  One thread per group sums them.
+    const int qn = a.C >> 2, qpg = cpg >> 2;
+    if (threadIdx.x < a.G) {
         double t1 = 0.0, t2 = 0.0;
-        for (int r = 0; r < rows; ++r)
+        for (int r = 0; r < p.rows; ++r)
             for (int j = 0; j < qpg; ++j) {
                 const int t = r * qn + threadIdx.x * qpg + j;
                 t1 += acc[t * 2];
                 t2 += acc[t * 2 + 1];
             }
-        double *dst = a.sums + ((size_t)blockIdx.x * a.G + threadIdx.x) * 2;
-        store_agent(dst, t1), store_agent(dst + 1, t2);   // (common.h: agent-scope hand-over, no fence)
+        double *dst = a.sums + ((size_t)(L.img0 + p.b) * a.G + threadIdx.x) * 2;
+        unsafeAtomicAdd(dst, t1);
+        unsafeAtomicAdd(dst + 1, t2);
     }
-    // one ticket per image slot: the image's LAST block finishes its groups (a first version with one ticket per launch left
-    // 320 (image, group) sums of up to 132 partials to ONE block: +22 us per call)
-    const int im = L.img0 + pb, tpi = (L.HW + GN_SPIX - 1) / GN_SPIX;
-    wait_stores();
-    __syncthreads();
-    if (threadIdx.x == 0) last = atomicAdd(a.ticket + 2 + im, 1u) == (unsigned)(tpi - 1);
-    __syncthreads();
-    if (!last) return;
-    // eight lanes per group take every eighth partial each (block order), then meet by xor-shuffles: a fixed order
-    const int blk_first = blockIdx.x - (p0 / GN_SPIX);   // the image's first block
-    for (int g0 = 0; g0 < a.G; g0 += 32) {
-        const int gg = g0 + (threadIdx.x >> 3), sl = threadIdx.x & 7;
-        double t1 = 0.0, t2 = 0.0;
-        if (gg < a.G) {
-            const double *src = a.sums + ((size_t)blk_first * a.G + gg) * 2;
-#pragma unroll 4
-            for (int k = sl; k < tpi; k += 8) {
-                t1 += load_agent(src + (size_t)k * a.G * 2);
-                t2 += load_agent(src + (size_t)k * a.G * 2 + 1);
-            }
-        }
-        for (int m = 1; m < 8; m <<= 1) t1 += __shfl_xor(t1, m), t2 += __shfl_xor(t2, m);
-        if (gg < a.G && sl == 0) {
-            const double n = (double)L.HW * cpg;
-            const double m1 = t1 / n;
-            double var = t2 / n - m1 * m1;
-            if (var < 0.0) var = 0.0;
-            float *mr = a.mean_rstd + ((size_t)im * a.G + gg) * 2;
-            mr[0] = (float)((double)xb[gg * cpg] + m1);
-            mr[1] = (float)(1.0 / sqrt(var + (double)a.eps));
-        }
-    }
-    if (threadIdx.x == 0) a.ticket[2 + im] = 0;   // ready for the next launch on this stream
+}
+
+// mean / rstd of (image, group) from the shifted sums
+__device__ __forceinline__ void gn_moments(const GnArgs &a, const GnLvl &L, int b, int g, float K, float &mean,
+                                           float &rstd)
+{
+    const double n = (double)L.HW * (a.C / a.G);
+    const double *s = a.sums + ((size_t)(L.img0 + b) * a.G + g) * 2;
+    const double m1 = s[0] / n;
+    double var = s[1] / n - m1 * m1;
+    if (var < 0.0) var = 0.0;
+    mean = (float)((double)K + m1);
+    rstd = (float)(1.0 / sqrt(var + (double)a.eps));
 }
 
 __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a)
@@ -172,8 +134,13 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a)
     const int cpg = a.C / a.G, g = (p.q * 4) / cpg;
     const float *xb = L.x + (size_t)p.b * L.HW * a.C;
     float *yb = L.y + (size_t)p.b * L.HW * a.C;
-    const float *mr = a.mean_rstd + ((size_t)(L.img0 + p.b) * a.G + g) * 2;   // (gn_stats_kernel's last block; kept for backward)
-    const float mean = mr[0], rstd = mr[1];
+    float mean, rstd;
+    gn_moments(a, L, p.b, g, xb[g * cpg], mean, rstd);
+    if (p.p0 == 0 && p.row == 0 && (p.q * 4) % cpg == 0) {   // saved for backward
+        float *mr = a.mean_rstd + ((size_t)(L.img0 + p.b) * a.G + g) * 2;
+        mr[0] = mean;
+        mr[1] = rstd;
+    }
     const float4 ga = *reinterpret_cast<const float4 *>(a.gamma + p.q * 4);
     const float4 be = *reinterpret_cast<const float4 *>(a.beta + p.q * 4);
     const float a0 = rstd * ga.x, a1 = rstd * ga.y, a2 = rstd * ga.z, a3 = rstd * ga.w;
@@ -267,7 +234,8 @@ __global__ __launch_bounds__(256) void gn_bwd_imgsum_kernel(const GnArgs a, int 
         store_agent(a.ab + (size_t)im * 2 * a.C + c2, ((red[0][col] + red[1][col]) + (red[2][col] + red[3][col])) +
                                                           ((red[4][col] + red[5][col]) + (red[6][col] + red[7][col])));
     // d gamma[c] = sum_images A[img][c], d beta[c] = sum_images Bc[img][c]: by the block that finishes last (round 5; a launch
-    // of its own -- gn_param_grad_kernel -- until round 4: 16 launches of 5 us per step for 2 KB of output)
+    // of its own -- gn_param_grad_kernel -- until round 4: 16 launches of 5 us per step for 2 KB of output).  Hand-over
+    // through agent-scope accesses, no fence (common.h).
     if (!a.dgamma && !a.dbeta) return;
     __shared__ unsigned last;
     wait_stores();
@@ -358,9 +326,6 @@ static int gn_fill(GnArgs &a, int n, const lsn_gn_level *lv, int C, int G, int *
     a.nlv = n;
     a.C = C;
     a.G = G;
-    a.stat_blocks = 0;
-    for (int i = 0; i < n; ++i) a.stat_blocks += lv[i].B * ((lv[i].HW + GN_SPIX - 1) / GN_SPIX);
-    if (im > 1000) return fail(LSN_ERR_UNSUPPORTED, "group norm: %d (level, image) slots in one launch (at most 1000)", im);
     *tiles = t;
     *images = im;
     return 0;
@@ -542,11 +507,9 @@ int64_t lsn_group_norm_workspace_bytes(int n_levels, const lsn_gn_level *levels,
     for (int i = 0; i < n_levels; ++i) images += levels[i].B;
     int64_t tiles = 0;
     for (int i = 0; i < n_levels; ++i) tiles += (int64_t)levels[i].B * ((levels[i].HW + lsn::GN_PIX - 1) / lsn::GN_PIX);
-    // forward: sums (double [GN_SPIX-pixel blocks][G][2]); backward: ab (float [images][C][2]) + per-block partials (float
+    // forward: sums (double [images][G][2]); backward: ab (float [images][C][2]) + per-block partials (float
     // [blocks][C][2]); sized for the larger
-    int64_t sblocks = 0;
-    for (int i = 0; i < n_levels; ++i) sblocks += (int64_t)levels[i].B * ((levels[i].HW + lsn::GN_SPIX - 1) / lsn::GN_SPIX);
-    const int64_t f = sblocks * G * 2 * (int64_t)sizeof(double), b = (images + tiles) * C * 2 * (int64_t)sizeof(float);
+    const int64_t f = images * G * 2 * (int64_t)sizeof(double), b = (images + tiles) * C * 2 * (int64_t)sizeof(float);
     return f > b ? f : b;
 }
 
@@ -567,11 +530,11 @@ int lsn_group_norm_forward(int n_levels, const lsn_gn_level *levels, int C, int 
     a.relu = relu;
     a.sums = reinterpret_cast<double *>(workspace);
     a.mean_rstd = mean_rstd;
-    if (int rc = lib_tickets(&a.ticket, st)) return rc;
+    LSN_HIP(hipMemsetAsync(a.sums, 0, sizeof(double) * (size_t)images * G * 2, st));
     double el = 0;
     for (int i = 0; i < n_levels; ++i) el += (double)levels[i].B * levels[i].HW * C;
     ProfSpan prof(PROF_NORM, 8.0 * el, 4.0 * 2 * el, st);   // algorithmic: x read once, y written once
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(a.stat_blocks), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(tiles), dim3(256), 0, st, a);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(tiles), dim3(256), 0, st, a);
     LSN_HIP(hipGetLastError());
     return 0;
