@@ -419,7 +419,9 @@ __global__ __launch_bounds__(256) void sgd_coef_kernel(const SgdArgs a, int npar
         const float total = (float)sqrt((red[0] + red[1]) + (red[2] + red[3]));
         const float coef = a.max_norm / (total + 1e-6f);      // clip_grad_norm_: clip_coef, clamped to <= 1
         a.stats[0] = total;
-        a.stats[1] = coef < 1.f ? coef : 1.f;
+        // clamp(coef, max = 1) as torch computes it: a NaN norm gives a NaN coefficient and every gradient becomes NaN
+        // (`coef < 1 ? coef : 1` turned it into 1 and the step went ahead on the unclipped gradients)
+        a.stats[1] = (coef < 1.f || coef != coef) ? coef : 1.f;
     }
 }
 

@@ -226,11 +226,25 @@ def offset_scale_chain(offs, mults, copies=1):
     for off, m in zip(offs, mults):
         cur, trio = off, []
         for sh, sw in m:
-            mult = off.new_tensor([sh, sw]).repeat(off.shape[1] // 2).view(1, -1, 1, 1)
+            mult = _scale_const(float(sh), float(sw), off.shape[1], off.device, off.dtype)
             cur = cur * mult
             trio.append(cur)
         res.append(trio)
     return [res] * copies
+
+
+_SCALE_CONSTS = {}
+
+
+def _scale_const(sh, sw, channels, device, dtype):
+    """The (1, C, 1, 1) multiplier [sh, sw, sh, sw, ...] of the fallback above, cached: `new_tensor` on a device tensor is a
+    synchronous host-to-device copy in the middle of the step, and breaks a stream capture."""
+    key = (sh, sw, channels, str(device), dtype)
+    t = _SCALE_CONSTS.get(key)
+    if t is None:
+        t = torch.tensor([sh, sw], dtype=dtype).repeat(channels // 2).view(1, -1, 1, 1).to(device)
+        _SCALE_CONSTS[key] = t
+    return t
 
 
 def dcn_multi(inputs, offsets, masks, weight, bias=None, stride=1, padding=0, dilation=1, groups=1,

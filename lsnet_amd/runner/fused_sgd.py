@@ -19,11 +19,27 @@ def _dense_like(a, b):
     return a.dtype == torch.float32 and a.is_cuda and a.stride() == b.stride() and a.shape == b.shape
 
 
+def _signature(optimizer):
+    """What a declined plan was declined on: the gradient and momentum-buffer storage of every parameter.  A plan that was
+    declined (gradients not there yet, not yet views of the buckets) is rebuilt when this changes, not cached for ever."""
+    sig = []
+    for grp in optimizer.param_groups:
+        for p in grp['params']:
+            g = p.grad
+            buf = optimizer.state.get(p, {}).get('momentum_buffer') if p in optimizer.state else None
+            sig.append((0 if g is None else g.data_ptr(), 0 if buf is None else buf.data_ptr()))
+    return tuple(sig)
+
+
 class ClipSGD:
-    """Built once per (optimizer, parameter set); `step()` re-validates the pointers it baked into the device table."""
+    """Built once per (optimizer, parameter set); `step()` re-validates the pointers it baked into the device table.
+    The fused step replaces `clip_grad_norm_` + `optimizer.step()`: optimizer step hooks (register_step_pre_hook / _post_hook)
+    and `_step_count` are NOT driven by it, and the norm is taken over the optimizer's parameters (the reference clips
+    `model.parameters()`: the same set in every LSNet config)."""
 
     def __init__(self, optimizer, grad_clip):
         self.opt, self.ok = optimizer, False
+        self.signature = _signature(optimizer)
         self.max_norm = 0.0
         if grad_clip is not None:
             if float(grad_clip.get('norm_type', 2)) != 2.0 or grad_clip.get('error_if_nonfinite') or grad_clip.get('foreach') is False:
@@ -46,16 +62,23 @@ class ClipSGD:
                     return
                 if not (p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))):
                     return
-                st = optimizer.state[p]
-                buf = st.get('momentum_buffer')
-                if buf is None:     # torch's first step clones the gradient: zeros give the same buffer (buf m + d = d)
-                    buf = st['momentum_buffer'] = torch.zeros_like(p)
-                if not _dense_like(buf, p) or (p.data_ptr() | g.data_ptr() | buf.data_ptr()) & 15:
+                buf = optimizer.state[p].get('momentum_buffer') if p in optimizer.state else None
+                if buf is not None and not _dense_like(buf, p):
                     return
-                entries.append((p, g, buf, gi, chunk))
+                if (p.data_ptr() | g.data_ptr() | (0 if buf is None else buf.data_ptr())) & 15:
+                    return
+                entries.append([p, g, buf, gi, chunk])
                 chunk += (p.numel() + 4095) // 4096
         if not entries:
             return
+        # every check has passed: only now touch the optimizer's state (a plan that went on to decline had already
+        # written zero momentum buffers).  torch's first step clones the gradient: zeros give the same buffer (buf m + d = d)
+        for e in entries:
+            if e[2] is None:
+                e[2] = optimizer.state[e[0]]['momentum_buffer'] = torch.zeros_like(e[0])
+                if e[2].data_ptr() & 15:
+                    return
+        entries = [tuple(e) for e in entries]
         self.entries, self.chunks = entries, chunk
         dev = entries[0][0].device
         host = (_lib.SgdTensor * len(entries))()

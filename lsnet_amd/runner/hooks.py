@@ -140,8 +140,9 @@ class OptimizerHook(Hook):
         if not hasattr(runner.model, 'zero_grad_buckets') or not torch.cuda.is_available():
             return None
         plan = getattr(runner, '_clip_sgd', None)
-        if plan is None or plan.opt is not runner.optimizer or (plan.ok and not plan.still_valid()):
-            from .fused_sgd import ClipSGD
+        from .fused_sgd import ClipSGD, _signature
+        if plan is None or plan.opt is not runner.optimizer or (plan.ok and not plan.still_valid()) or \
+                (not plan.ok and plan.signature != _signature(runner.optimizer)):   # a declined plan: retried when what it saw changed
             plan = runner._clip_sgd = ClipSGD(runner.optimizer, self.grad_clip)
         return plan if plan.ok else None
 
