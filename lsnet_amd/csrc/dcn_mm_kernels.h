@@ -191,10 +191,12 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_mm_kernel(const DcnArgs a, con
                     acc[j][i] = mfma_bf16(Wf[ks][j][SC::pb(prod)], Xf[ks][i][SC::pa(prod)], acc[j][i]);
     };
 
+    // (round 5, as in conv_mm_kernel: the barrier sits in the middle of the iteration, the k-step-0 fragments of chunk t + 1 are
+    // read right behind it under the MFMAs of k-step 1, the k-step-1 fragments of chunk t at the top under those of k-step 0)
+    read_x(smem, 0);
     for (int t = 0; t < T; ++t) {
         const unsigned char *bc = smem + (t & 1) * BUF;
         unsigned char *bn = smem + ((t & 1) ^ 1) * BUF;
-        read_x(bc, 0);
         read_x(bc, 1);
         {   // weights of the chunk in xv (t + 1), offsets of the chunk to fetch (t + 2)
             const int kdw = kd_of(cm);
@@ -233,10 +235,11 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_mm_kernel(const DcnArgs a, con
         cm = ci;
         issue_w(t + 1, 0);
         __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        read_x(bn, 0);   // (past the last chunk: never used)
         mfma_block(1);
         issue_w(t + 1, 1);
         __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
     }
 
     // ---- epilogue: lane = pixel (lane & 31) of tile i, output channels 8 g + 4 (lane >> 5) + (0..3) of tile j ----
@@ -519,22 +522,26 @@ __global__ __launch_bounds__(256, 2) void dcn_wgrad_mm_kernel(const DcnArgs a, i
         issue_g(0, 1);
         __syncthreads();
 
+        // (round 5, as in conv_mm_kernel: the barrier sits in the MIDDLE of the iteration; the k-step-0 fragments of chunk t + 1
+        // are read right behind it under the MFMAs of k-step 1, the k-step-1 fragments of chunk t at the top)
+        bf16x8 Xf[2][TI][NPL];
+        auto read_x = [&](const unsigned char *buf, int ks) {
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int q = 0; q < NPL; ++q)
+                    Xf[ks][i][q] = frag(buf + q * XPL + xaddr[ks][i][0], buf + q * XPL + xaddr[ks][i][1]);
+        };
+        read_x(smem, 0);
         for (int t = 0; t < T; ++t) {
             const unsigned char *bc = smem + (t & 1) * STAGE;
             unsigned char *bn = smem + ((t & 1) ^ 1) * STAGE;
             const int slot1 = (t + 1) & 3, slot2 = (t + 2) & 3, slot3 = (t + 3) & 3;
-            // slot3 held chunk t - 1, last read before the barrier that ended it; its new entries (chunk t + 3) are first
-            // read in iteration t + 1, behind the barrier that ends this one
+            // slot3 held chunk t - 1: last read in iteration t - 2 (commit) -- two barriers ago; its new entries (chunk t + 3)
+            // are first read in iteration t + 1 (issue_slice), behind the barrier in the middle of this one
             if (wj == 0) gtap_put(slot3, tq);
             tq = gtap_load(sat(t + 4));
-            bf16x8 Xf[2][TI][NPL];
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int i = 0; i < TI; ++i)
-#pragma unroll
-                    for (int q = 0; q < NPL; ++q)
-                        Xf[ks][i][q] = frag(bc + q * XPL + xaddr[ks][i][0], bc + q * XPL + xaddr[ks][i][1]);
+            read_x(bc, 1);
             open_chunk(sat(t + 2));
             __builtin_amdgcn_sched_barrier(0);
             constexpr int NM = NP * TI * TJ;
@@ -558,6 +565,8 @@ __global__ __launch_bounds__(256, 2) void dcn_wgrad_mm_kernel(const DcnArgs a, i
             }
             issue_g(t + 1, 0);
             __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            read_x(bn, 0);   // (past the last chunk: never used)
 #pragma unroll
             for (int prod = 0; prod < NP; ++prod)
 #pragma unroll
@@ -567,7 +576,6 @@ __global__ __launch_bounds__(256, 2) void dcn_wgrad_mm_kernel(const DcnArgs a, i
                         acc[i][j] = mfma_bf16(Xf[1][i][SC::pa(prod)], Gf[1][j][SC::pb(prod)], acc[i][j]);
             issue_g(t + 1, 1);
             __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();
         }
     }
 
