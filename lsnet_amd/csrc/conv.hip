@@ -288,6 +288,8 @@ static int conv_forward(ConvArgs &a, hipStream_t st)
     if (a.Co <= 32) cfg = 4;
     else if (a.Co <= 64) cfg = 3;
     else cfg = 2;
+    // (round 5, with stream-K filling the chip either way: 64 x 256 for EVERY Co % 256 == 0 lost 3 % over the step's shapes,
+    // forward 3944 -> 4078 us, data gradient 2871 -> 2959 us, tools/ubench/conv_step A/B -- the rule stands)
     if (a.Co % 256 == 0 && a.C % 4 == 0 && a.xpitch % 4 == 0 && (a.kh * a.kw > 1 || blocks(64, 256) >= 512)) cfg = 5;
     const int nb = cfg == 2 ? blocks(64, 128) : cfg == 3 ? blocks(128, 64) : cfg == 5 ? blocks(64, 256) : blocks(128, 32);
     const int Tall = a.kh * a.kw * cv_ncc(a.C);
