@@ -212,7 +212,7 @@ def golden_coco_eval():
     _save('coco_eval', data)
 
 
-CURVE_ITERS, CURVE_HW = 12, (288, 352)
+CURVE_ITERS, CURVE_HW = 20, (288, 352)   # (a 20-iteration SGD curve with warm-up; 12 until round 4)
 
 
 def curve_cfg():
@@ -220,7 +220,7 @@ def curve_cfg():
     shortened to 6 iterations so that 12 iterations reach the full learning rate."""
     from lsnet_amd.model_zoo import lsnet_config
     cfg = lsnet_config('bbox', 'r50')
-    cfg.lr_config = dict(policy='step', warmup='linear', warmup_iters=6, warmup_ratio=0.001, step=[8, 11])
+    cfg.lr_config = dict(policy='step', warmup='linear', warmup_iters=10, warmup_ratio=0.001, step=[14, 18])
     return cfg
 
 
