@@ -521,6 +521,18 @@ int lsn_prof_read(lsn_prof_entry *out, int max_entries);
  * configs/lsnet/lsnet_bbox_r50_fpn_mstrain_2x_coco.py:13-15) must reach a state in which out4[0] and out4[2] stay put. */
 int lsn_scratch_stats(long long *out4);
 
+/* Deferred weight-gradient reduces.  Every weight-gradient entry point of this header (dense, folded-norm, jobs, deformable)
+ * ends in a reduce launch over its partial tiles.  lsn_wgrad_defer(max_mbytes > 0, stream): from now on the calls on `stream`
+ * that ACCUMULATE into their gradient (accumulate = 1: a gradient arena owns the memory and nobody reads it before the step's
+ * gradients are complete) leave their partial tiles in a library arena and queue the reduce; the queue is run -- one launch per
+ * reduce kind for up to 16 gradients, the same arithmetic per element in the same order -- by lsn_wgrad_flush(stream), by a
+ * second call for a gradient that already has a queued one, whenever the arena holds more than max_mbytes, and by
+ * lsn_wgrad_defer(0, stream), which also ends the mode.  Calls with accumulate = 0 are never deferred.  A caller that enables
+ * the mode owes a flush before anything reads the gradients (lsnet_amd/parallel/reducer.py: before a bucket's all-reduce, in
+ * finish()). */
+int lsn_wgrad_defer(int max_mbytes, lsn_stream_t stream);
+int lsn_wgrad_flush(lsn_stream_t stream);
+
 /* D = A(MxK) * B(KxN) through the same MFMA fragment code as the DCN kernels (self-test). */
 int lsn_selftest_mfma(const float *A, const float *B, float *D, int M, int N, int K, int variant,
                       lsn_stream_t stream);

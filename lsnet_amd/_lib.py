@@ -92,7 +92,7 @@ EXPORTS = [
     'lsn_sigmoid_focal_loss_forward', 'lsn_sigmoid_focal_loss_backward', 'lsn_sigmoid_focal_loss_sum',
     'lsn_sigmoid_focal_loss_backward_weighted',
     'lsn_nms_workspace_bytes', 'lsn_nms', 'lsn_topk_columns', 'lsn_offset_chain_forward', 'lsn_offset_chain_backward', 'lsn_clip_sgd_workspace_bytes', 'lsn_clip_sgd_step', 'lsn_selftest_mfma', 'lsn_debug_phase_clocks',
-    'lsn_prof_enable', 'lsn_prof_read', 'lsn_scratch_stats',
+    'lsn_prof_enable', 'lsn_prof_read', 'lsn_scratch_stats', 'lsn_wgrad_defer', 'lsn_wgrad_flush',
     'lsn_group_norm_workspace_bytes', 'lsn_group_norm_forward', 'lsn_group_norm_backward',
     'lsn_set_math_mode', 'lsn_get_math_mode', 'lsn_conv2d_forward', 'lsn_conv2d_forward_pitched', 'lsn_conv2d_backward_data',
     'lsn_conv2d_prepared_bytes', 'lsn_conv2d_prepare_weights', 'lsn_conv2d_prepare_weights_multi',
@@ -164,6 +164,22 @@ def prof_read():
         check(n)
     return {arr[i].name.decode(): dict(launches=int(arr[i].launches), total_ms=arr[i].total_ms,
                                        flops=arr[i].flops, bytes=arr[i].bytes) for i in range(n)}
+
+
+def wgrad_defer(max_mbytes, stream=None):
+    """lsn_wgrad_defer on `stream` (default: torch's current stream): max_mbytes > 0 starts deferring the reduces of accumulating
+    weight-gradient calls, 0 flushes and ends the mode."""
+    import ctypes
+    import torch
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream if stream is None else stream)
+    check(load().lsn_wgrad_defer(int(max_mbytes), st))
+
+
+def wgrad_flush(stream=None):
+    import ctypes
+    import torch
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream if stream is None else stream)
+    check(load().lsn_wgrad_flush(st))
 
 
 def scratch_stats():

@@ -47,8 +47,63 @@ struct Scratch {
 };
 static Scratch g_scr[16];
 static int g_nscr = 0;
-static int part_buffer(size_t floats, float **p, hipStream_t st)
+// ---- deferred weight-gradient reduces (conv_wgrad_kernels.h; include/lsnet_hip.h lsn_wgrad_defer) ----
+// While deferral is on for a stream, the partial tiles of its weight-gradient calls (part_buffer(..., keep = true)) come from an
+// ARENA that is not reused until the flush, and conv_wgrad_reduce() queues a descriptor instead of launching.
+struct RJob {
+    bool fold;
+    const float *part, *part_b;
+    float *gw, *gb;
+    size_t n;
+    int nb, splits, splits_b, R, Co;
+    WgFold f;
+};
+struct Arena {
+    hipStream_t st;
+    float *p;
+    size_t floats, used;
+    long long defer_mb;   // 0: off
+    std::vector<RJob> *jobs;
+};
+static Arena g_arena[16];
+static int g_narena = 0;
+static Arena *arena_of(hipStream_t st, bool create)
 {
+    for (int i = 0; i < g_narena; ++i)
+        if (g_arena[i].st == st) return &g_arena[i];
+    if (!create || g_narena == 16) return nullptr;
+    g_arena[g_narena] = Arena{st, nullptr, 0, 0, 0, new std::vector<RJob>()};
+    return &g_arena[g_narena++];
+}
+static int arena_alloc(Arena *ar, size_t floats, float **p)
+{
+    const size_t off = (ar->used + 63) & ~(size_t)63;
+    if (off + floats > ar->floats) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(ar->st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+            return fail(LSN_ERR_RUNTIME, "scratch would grow inside a stream capture: run the step eagerly once before capturing");
+        // a new block of twice the demand seen so far; the old one stays allocated (queued descriptors and captured graphs
+        // may hold its addresses) and the arena continues at the start of the new block
+        const size_t want = 2 * (off + floats) + ((size_t)16 << 20);
+        float *np = nullptr;
+        LSN_HIP(hipMalloc(reinterpret_cast<void **>(&np), want * sizeof(float)));
+        lib_stat(STAT_MALLOCS, 1), lib_stat(STAT_HELD_BYTES, (long long)(want * sizeof(float)));
+        ar->p = np, ar->floats = want, ar->used = 0;
+        *p = np;
+        ar->used = floats;
+        return 0;
+    }
+    *p = ar->p + off;
+    ar->used = off + floats;
+    return 0;
+}
+
+static int part_buffer(size_t floats, float **p, hipStream_t st, bool keep = false)
+{
+    if (keep) {
+        Arena *ar = arena_of(st, false);
+        if (ar && ar->defer_mb > 0) return arena_alloc(ar, floats, p);
+    }
     Scratch *sc = nullptr;
     for (int i = 0; i < g_nscr; ++i)
         if (g_scr[i].st == st) sc = &g_scr[i];
@@ -637,7 +692,7 @@ static int launch_wgrad_cfg(WgArgs &a, float *gw, float *gb, int accumulate, hip
     if (S < 1) S = 1;
     S *= nj;
     float *part = nullptr;
-    if (int rc = part_buffer((size_t)S * (nW + a.Co) + 16, &part, st)) return rc;
+    if (int rc = part_buffer((size_t)S * (nW + a.Co) + 16, &part, st, true)) return rc;
     a.part = part;
     a.part_b = part + (((size_t)S * nW + 3) & ~(size_t)3);
     a.want_bias = gb != nullptr;
@@ -674,9 +729,59 @@ static int launch_wgrad_cfg(WgArgs &a, float *gw, float *gb, int accumulate, hip
 // call) the reduce also applies the norm's scale and forms grad_gamma / grad_beta (conv_wgrad_reduce_bn_kernel); gb is then
 // the entry point's dummy bias gradient (it only makes the main kernels write the per-channel sums of g).
 
+static int reduce_ls(int splits)
+{
+#ifdef LSNET_PER_LANE
+    constexpr int PER_LANE = LSNET_PER_LANE;
+#else
+    constexpr int PER_LANE = 16;
+#endif
+    int LS = 1;
+    while (LS < 64 && LS * PER_LANE <= splits) LS <<= 1;
+    return LS;
+}
+
+static int wgrad_flush(Arena *ar);
+
 int conv_wgrad_reduce(const float *part, float *gw, size_t n, const float *part_b, float *gb, int nb, int splits, int splits_b,
                       int accumulate, hipStream_t st)
 {
+    Arena *ar = arena_of(st, false);
+    if (ar && ar->defer_mb > 0 && accumulate) {
+        // queue instead of launching.  A gradient that already has a queued job is reduced first: two jobs of one launch must
+        // not add onto the same addresses.
+        const int nj = g_wg_fold ? g_wg_fold->njobs : 1;
+        bool clash = false;
+        for (const RJob &q : *ar->jobs)
+            for (int j = 0; j < nj; ++j) {
+                const float *tw = g_wg_fold ? (nj > 1 ? g_wg_fold->gw[j] : gw) : gw;
+                clash = clash || q.gw == tw || (gb && q.gb == gb) || (g_wg_fold && q.fold && q.f.dgamma == g_wg_fold->f[j].dgamma);
+            }
+        if (clash)
+            if (int rc = wgrad_flush(ar)) return rc;   // (the arena is NOT rewound here: this call's partial tiles are in it)
+        if (g_wg_fold) {
+            LSN_CHECK(part_b && nb > 0 && n % ((size_t)nb * 4) == 0 && splits % nj == 0 && splits_b % nj == 0,
+                      "conv2d backward-weight (folded norm): bad partial layout");
+            for (int j = 0; j < nj; ++j) {
+                RJob q = {};
+                q.fold = true;
+                q.part = part + (size_t)j * (splits / nj) * n, q.part_b = part_b + (size_t)j * (splits_b / nj) * nb;
+                q.gw = nj > 1 ? g_wg_fold->gw[j] : gw;
+                q.n = n, q.nb = nb, q.splits = splits / nj, q.splits_b = splits_b / nj, q.R = (int)(n / nb), q.Co = nb;
+                q.f = g_wg_fold->f[j];
+                ar->jobs->push_back(q);
+            }
+        } else {
+            RJob q = {};
+            q.fold = false, q.part = part, q.part_b = part_b, q.gw = gw, q.gb = gb, q.n = n, q.nb = nb, q.splits = splits, q.splits_b = splits_b;
+            ar->jobs->push_back(q);
+        }
+        if ((long long)(ar->used * sizeof(float)) > (ar->defer_mb << 20)) {
+            if (int rc = wgrad_flush(ar)) return rc;
+            ar->used = 0;   // every queued tile has been consumed (in stream order): the arena starts over
+        }
+        return 0;
+    }
     int LS = 1;
     // partial tiles a lane sums on its own before the xor-shuffles (LS = splits / PER_LANE lanes share a float4).  Round-4 sweep
     // (tools/ubench/wgrad_ab rule / bn, us per step of the benchmark's layer mix): 4: 3374 / 2945, 8: 3284 / 2729,
@@ -706,8 +811,52 @@ int conv_wgrad_reduce(const float *part, float *gw, size_t n, const float *part_
     return 0;
 }
 
+static int wgrad_flush(Arena *ar)
+{
+    std::vector<RJob> &jobs = *ar->jobs;
+    if (jobs.empty()) return 0;
+    hipStream_t st = ar->st;
+    double bytes = 0;
+    for (const RJob &q : jobs) bytes += 4.0 * ((double)q.splits * q.n + 2.0 * q.n);
+    ProfSpan prof(PROF_CONV_WGRAD, 0.0, bytes, st);   // (the family's time includes its reduces, wherever they are launched)
+    RJobsPlain P = {};
+    RJobsFold F = {};
+    int pblk = 0, fblk = 0;
+    auto launch_plain = [&]() {
+        if (P.njobs) hipLaunchKernelGGL(conv_wgrad_reduce_multi_kernel, dim3(pblk), dim3(256), 0, st, P);
+        P.njobs = 0, pblk = 0;
+    };
+    auto launch_fold = [&]() {
+        if (F.njobs) hipLaunchKernelGGL(conv_wgrad_reduce_bn_multi_kernel, dim3(fblk), dim3(256), 0, st, F);
+        F.njobs = 0, fblk = 0;
+    };
+    for (const RJob &q : jobs) {
+        const int LS = reduce_ls(q.splits);
+        if (q.fold) {
+            if (F.njobs == RJ_MAX) launch_fold();
+            RJobFold &d = F.j[F.njobs++];
+            d.part = q.part, d.part_b = q.part_b, d.gw = q.gw, d.f = q.f, d.R = q.R, d.Co = q.Co, d.splits = q.splits,
+            d.splits_b = q.splits_b, d.LS = LS, d.blk0 = fblk;
+            fblk += q.Co;
+        } else {
+            if (P.njobs == RJ_MAX) launch_plain();
+            const size_t thr = q.n / 4 * LS;
+            const int rb = (int)((thr + 255) / 256 < 4096 ? (thr + 255) / 256 : 4096);
+            RJobPlain &d = P.j[P.njobs++];
+            d.part = q.part, d.part_b = q.part_b, d.gw = q.gw, d.gb = q.gb, d.n = q.n, d.nb = q.nb, d.splits = q.splits,
+            d.splits_b = q.splits_b, d.LS = LS, d.blk0 = pblk, d.nblk = rb > 0 ? rb : 1;
+            pblk += d.nblk;
+        }
+    }
+    launch_plain();
+    launch_fold();
+    jobs.clear();
+    LSN_HIP(hipGetLastError());
+    return 0;
+}
+
 // library-owned scratch (also for dcn.hip's weight-gradient pass): grows, never shrinks
-int conv_scratch(size_t floats, float **p, hipStream_t st) { return part_buffer(floats, p, st); }
+int conv_scratch(size_t floats, float **p, hipStream_t st) { return part_buffer(floats, p, st, true); }   // (weight-gradient passes of dcn.hip)
 
 // Returns 1 when the shape is not served here (more than nine taps, C % 4 != 0, 64-bit offsets): the caller keeps the
 // general kernel of dcn.hip.
@@ -817,6 +966,31 @@ static int prepare_weights_multi(int n, const lsn_conv_wprep *it, hipStream_t st
 }  // namespace lsn
 
 extern "C" {
+
+int lsn_wgrad_defer(int max_mbytes, lsn_stream_t stream)
+{
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    lsn::Arena *ar = lsn::arena_of(st, max_mbytes > 0);
+    if (!ar) return max_mbytes > 0 ? lsn::fail(LSN_ERR_RUNTIME, "scratch: more than 16 streams use the library") : 0;
+    if (max_mbytes > 0) {
+        ar->jobs->clear();   // (a step that died half-way may have left descriptors behind: they are dropped, not run)
+        ar->used = 0;
+        ar->defer_mb = max_mbytes;
+        return 0;
+    }
+    const int rc = lsn::wgrad_flush(ar);
+    ar->defer_mb = 0, ar->used = 0;
+    return rc;
+}
+
+int lsn_wgrad_flush(lsn_stream_t stream)
+{
+    lsn::Arena *ar = lsn::arena_of(reinterpret_cast<hipStream_t>(stream), false);
+    if (!ar) return 0;
+    const int rc = lsn::wgrad_flush(ar);
+    ar->used = 0;
+    return rc;
+}
 
 int lsn_scratch_stats(long long *out4)
 {

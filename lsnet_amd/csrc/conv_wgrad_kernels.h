@@ -363,13 +363,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgArgs a)
 // both (the bias partials may come in their own number, splits_b).  LS (a power of two <= 64) adjacent lanes share one float4 of the gradient and take every LS-th split each, then
 // meet by xor-shuffles: a small gradient under many splits (64 x 64 weights, 512 pixel ranges) is then summed by
 // 64 lanes x 8 loads instead of one thread walking 512 dependent loads.
-static __global__ void conv_wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ gw, size_t n,
-                                                const float *__restrict__ part_b, float *__restrict__ gb, int nb, int splits,
-                                                int splits_b, int accumulate, int LS)
+// (vblock of vgrid: the block's place in ITS job's share of the grid -- the single-job kernel passes blockIdx / gridDim, the
+// multi-job kernel of a deferred flush the position inside the job's block range)
+__device__ __forceinline__ void wgrad_reduce_body(const float *__restrict__ part, float *__restrict__ gw, size_t n,
+                                                  const float *__restrict__ part_b, float *__restrict__ gb, int nb, int splits,
+                                                  int splits_b, int accumulate, int LS, unsigned vblock, unsigned vgrid)
 {
     const size_t n4 = n / 4;
-    const size_t gid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    const size_t stride = (size_t)gridDim.x * blockDim.x / LS;
+    const size_t gid = vblock * (size_t)blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)vgrid * blockDim.x / LS;
     const int sl = (int)(gid % LS);
     for (size_t e0 = gid / LS; e0 < ((n4 + stride - 1) / stride) * stride; e0 += stride) {   // (whole waves stay in the loop)
         const bool live = e0 < n4;
@@ -404,7 +406,7 @@ static __global__ void conv_wgrad_reduce_kernel(const float *__restrict__ part, 
             *d = s;
         }
     }
-    if (gb && blockIdx.x == 0)
+    if (gb && vblock == 0)
         for (int e = threadIdx.x; e < nb; e += blockDim.x) {
             float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
             int z = 0;
@@ -416,6 +418,13 @@ static __global__ void conv_wgrad_reduce_kernel(const float *__restrict__ part, 
             const float s = (s0 + s1) + (s2 + s3);
             gb[e] = accumulate ? gb[e] + s : s;
         }
+}
+
+static __global__ void conv_wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ gw, size_t n,
+                                                const float *__restrict__ part_b, float *__restrict__ gb, int nb, int splits,
+                                                int splits_b, int accumulate, int LS)
+{
+    wgrad_reduce_body(part, gw, n, part_b, gb, nb, splits, splits_b, accumulate, LS, blockIdx.x, gridDim.x);
 }
 
 // The reduce of a weight gradient whose convolution carries a folded eval-mode BatchNorm (lsn_conv2d_backward_weight_bn):
@@ -441,20 +450,16 @@ struct WgFoldJobs {
     int njobs;
 };
 
-static __global__ __launch_bounds__(256) void conv_wgrad_reduce_bn_kernel(const float *__restrict__ part, float *gw, int R, int Co,
-                                                                           const float *__restrict__ part_b, int splits,
-                                                                           int splits_b, int accumulate, int LS,
-                                                                           const WgFoldJobs J)
+// one output channel of one job (the single-job kernel: blockIdx.x of job blockIdx.y; the multi-job kernel of a deferred flush:
+// the channel inside the job's block range)
+__device__ __forceinline__ void wgrad_reduce_bn_body(const float *__restrict__ part, float *gw, int R, int Co,
+                                                     const float *__restrict__ part_b, int splits, int splits_b, int accumulate,
+                                                     int LS, const WgFold &f, int co)
 {
-    const WgFold &f = J.f[blockIdx.y];
-    gw = J.njobs > 1 ? J.gw[blockIdx.y] : gw;
-    part += (size_t)blockIdx.y * splits * ((size_t)Co * R);
-    part_b += (size_t)blockIdx.y * splits_b * Co;
     // one workgroup per output channel (a first version with one WAVE per channel ran 32 .. 512 waves through up to 32
     // dependent passes each: +1.9 ms per step over the plain reduce, profiles/r4_bench_c03.log)
     __shared__ float red[2][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int co = blockIdx.x;
     const size_t n = (size_t)Co * R;
     const int sl = tid % LS, el = tid / LS, EP = 256 / LS;   // split lane, element lane, elements per pass (LS | 64)
     const float rstd = rsqrtf(f.var[co] + f.eps), ac = f.gamma[co] * rstd;
@@ -508,6 +513,58 @@ static __global__ __launch_bounds__(256) void conv_wgrad_reduce_bn_kernel(const 
         f.dbeta[co] = accumulate ? f.dbeta[co] + b4 : b4;
         f.dgamma[co] = accumulate ? f.dgamma[co] + dg : dg;
     }
+}
+
+static __global__ __launch_bounds__(256) void conv_wgrad_reduce_bn_kernel(const float *__restrict__ part, float *gw, int R, int Co,
+                                                                           const float *__restrict__ part_b, int splits,
+                                                                           int splits_b, int accumulate, int LS,
+                                                                           const WgFoldJobs J)
+{
+    gw = J.njobs > 1 ? J.gw[blockIdx.y] : gw;
+    part += (size_t)blockIdx.y * splits * ((size_t)Co * R);
+    part_b += (size_t)blockIdx.y * splits_b * Co;
+    wgrad_reduce_bn_body(part, gw, R, Co, part_b, splits, splits_b, accumulate, LS, J.f[blockIdx.y], blockIdx.x);
+}
+
+// ---- deferred reduces (conv.hip: lsn_wgrad_defer / lsn_wgrad_flush).  The 48 reduce launches of a training step read ~2 GB of
+// partial tiles in kernels of 15 - 19 us each -- launch- and latency-bound at 1.8 TB/s, 1.2 ms per step with their gaps
+// (profiles/r5_wgrad_reduce_cost.txt).  While a gradient arena collects the step's gradients (parallel/reducer.py) the calls leave
+// their partial tiles where they are and queue a descriptor; one launch per kind reduces every queued gradient: the same
+// arithmetic per element in the same order (the same bits), one ramp and one tail.
+constexpr int RJ_MAX = 16;
+struct RJobPlain {
+    const float *part, *part_b;
+    float *gw, *gb;
+    unsigned long long n;
+    int nb, splits, splits_b, LS, blk0, nblk;
+};
+struct RJobsPlain {
+    RJobPlain j[RJ_MAX];
+    int njobs;
+};
+static __global__ void conv_wgrad_reduce_multi_kernel(const RJobsPlain J)
+{
+    int ji = 0;
+    while (ji + 1 < J.njobs && (int)blockIdx.x >= J.j[ji + 1].blk0) ++ji;
+    const RJobPlain &q = J.j[ji];
+    wgrad_reduce_body(q.part, q.gw, (size_t)q.n, q.part_b, q.gb, q.nb, q.splits, q.splits_b, 1, q.LS, blockIdx.x - q.blk0, q.nblk);
+}
+struct RJobFold {
+    const float *part, *part_b;
+    float *gw;
+    WgFold f;
+    int R, Co, splits, splits_b, LS, blk0;
+};
+struct RJobsFold {
+    RJobFold j[RJ_MAX];
+    int njobs;
+};
+static __global__ __launch_bounds__(256) void conv_wgrad_reduce_bn_multi_kernel(const RJobsFold J)
+{
+    int ji = 0;
+    while (ji + 1 < J.njobs && (int)blockIdx.x >= J.j[ji + 1].blk0) ++ji;
+    const RJobFold &q = J.j[ji];
+    wgrad_reduce_bn_body(q.part, q.gw, q.R, q.Co, q.part_b, q.splits, q.splits_b, 1, q.LS, q.f, (int)blockIdx.x - q.blk0);
 }
 
 }  // namespace lsn

@@ -31,6 +31,9 @@ def init_dist(backend='nccl', **kwargs):
     return dist.get_rank(), dist.get_world_size()
 
 
+# arena size (MB of partial tiles) at which the library runs its queued weight-gradient reduces on its own; 0: no deferral
+WGRAD_DEFER_MB = int(os.environ.get('LSNET_WGRAD_DEFER_MB', '4096'))
+
 class BucketedGradReducer:
     """Gradient-VIEW buckets: every `p.grad` is a view (in the parameter's own memory layout) into one of a few flat
     tensors, so backward accumulates straight into the communication buffers -- no gradient -> bucket -> gradient
@@ -72,6 +75,7 @@ class BucketedGradReducer:
             for pi, p in enumerate(b['params']):
                 self._where[p] = (bi, pi)
         self._handles = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        self._deferring = False
         self._expected = None      # contributions per parameter and step, learnt from the previous step
         self._events = {}
         self._zeroed = False
@@ -118,12 +122,31 @@ class BucketedGradReducer:
                 if getattr(p, '_lsn_sink', None) is not v:
                     grad_sink.register(p, v, self._on_sink)
         self._zeroed = True
+        self._defer(True)
+
+    def _defer(self, on):
+        """The gradients of this step live in the buckets and nobody reads them before finish() (or a bucket's all-reduce):
+        the library may keep the partial tiles of its weight-gradient kernels and reduce many gradients per launch
+        (include/lsnet_hip.h lsn_wgrad_defer; 48 reduce launches of 15 - 19 us per step otherwise).  on = None: flush only."""
+        if WGRAD_DEFER_MB <= 0 or not self.buckets or not self.buckets[0]['flat'].is_cuda:
+            return
+        from .. import _lib
+        if on is None:
+            if self._deferring:
+                _lib.wgrad_flush()
+        elif on:
+            _lib.wgrad_defer(WGRAD_DEFER_MB)
+            self._deferring = True
+        elif self._deferring:
+            _lib.wgrad_defer(0)
+            self._deferring = False
 
     def _launch_ready(self):
         if not self.collective:
             return
         while self._next < len(self.buckets) and self.buckets[self._next]['pending'] == 0:
             b = self.buckets[self._next]
+            self._defer(None)     # queued weight-gradient reduces write into this bucket: run them before it leaves
             b['work'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self._next += 1
 
@@ -163,6 +186,7 @@ class BucketedGradReducer:
         if left:   # (the engine callback of ops/resblock.py flushes at the end of every backward pass: this is a bug trap)
             raise RuntimeError(f'{left} queued weight-gradient job(s) of fused ResNet stages were never launched: their '
                                'parameters would be reduced without these contributions')
+        self._defer(False)   # every deferred reduce of the step runs now, ahead of whatever reads the buckets
         while self._next < len(self.buckets):
             b = self.buckets[self._next]
             for p, v in zip(b['params'], b['views']):

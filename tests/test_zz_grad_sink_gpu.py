@@ -41,3 +41,39 @@ def test_sunk_gradients_equal_classic_gradients(task, backbone):
     # every bucketed parameter reported at least one contribution per step
     red = wrapped.reducer
     assert red._expected and all(red._expected.get(p, 0) >= 1 for _, p in params)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('task,backbone,mb', [('bbox', 'r50', 4096), ('bbox', 'r50', 64), ('segm', 'x101-dcn', 4096)])
+def test_deferred_weight_gradient_reduces_give_the_same_bits(task, backbone, mb, monkeypatch):
+    """Round 5 (include/lsnet_hip.h lsn_wgrad_defer): while a step's gradients collect in the buckets the library queues the
+    reduce of every accumulating weight-gradient call and runs them in a few multi-gradient launches (all of them in finish()
+    with the default arena limit; every ~64 MB of partial tiles with the small one).  Per element the arithmetic and its
+    order are those of the immediate reduce: the gradients must come back with the SAME BITS, step after step."""
+    from lsnet_amd import _lib
+    from lsnet_amd.parallel import reducer as red_mod
+    dev = torch.device('cuda:0')
+    batch = synthetic_batch(task, 2, 384, 480, seed=5, device=dev)
+
+    def run(defer_mb):
+        monkeypatch.setattr(red_mod, 'WGRAD_DEFER_MB', defer_mb)
+        torch.manual_seed(0)
+        model, _ = build_lsnet(task, backbone)
+        wrapped = DataParallelModel(model.to(dev).to(memory_format=torch.channels_last).train())
+        out = []
+        for _ in range(2):
+            wrapped.zero_grad_buckets()
+            wrapped.train_step(batch, None)['loss'].backward()
+            wrapped.reduce_gradients()
+            torch.cuda.synchronize()
+            out.append({n: p.grad.detach().clone() for n, p in wrapped.module.named_parameters() if p.grad is not None})
+        return out
+
+    s0 = _lib.scratch_stats()
+    plain = run(0)
+    deferred = run(mb)
+    assert len(plain[0]) > 100
+    for a, b in zip(plain, deferred):
+        diff = [n for n in a if not torch.equal(a[n], b[n])]
+        assert not diff, f'{len(diff)} of {len(a)} gradients differ between the immediate and the deferred reduces, e.g. {diff[:4]}'
+    assert _lib.scratch_stats()['mallocs'] >= s0['mallocs']
