@@ -39,6 +39,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')   # ROCm 7.2 hipGraph workaround, see lsnet_amd/__init__.py
+os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')             # kernel arguments in device memory, see lsnet_amd/__init__.py
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 

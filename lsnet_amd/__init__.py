@@ -14,3 +14,7 @@ import os as _os
 # (tools/try_capture4.py).  The variable is read when the HIP runtime initialises, i.e. at the first device call,
 # so setting it at import time is early enough; an explicit user setting wins.
 _os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')
+# Kernel arguments in device memory.  The step is ~1 050 dispatches, most of them short: with HIP_FORCE_DEV_KERNARG=0 it takes
+# 35.0 ms instead of 32.6 (profiles/r5_env_switches.txt).  1 is the default of this ROCm build; stated here so that the
+# step does not depend on it (read at runtime initialisation like the switch above; a user setting wins).
+_os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')
