@@ -75,26 +75,46 @@ static Arena *arena_of(hipStream_t st, bool create)
     g_arena[g_narena] = Arena{st, nullptr, 0, 0, 0, new std::vector<RJob>()};
     return &g_arena[g_narena++];
 }
+static int wgrad_flush(Arena *ar);
+
+// `floats` of arena space for the partial tiles of ONE weight-gradient call.  When the arena is full the queued reduces run
+// first (they consume every tile handed out so far, in stream order) and the arena starts over; while it is smaller than the
+// caller's limit (lsn_wgrad_defer) it is also replaced by a larger block -- nothing refers to the old one after the flush, so it is
+// freed once the stream has drained.  That synchronisation happens only while the arena is still finding its size (the first
+// step at the largest shape); in the steady state this function does pointer arithmetic and nothing else.
 static int arena_alloc(Arena *ar, size_t floats, float **p)
 {
     const size_t off = (ar->used + 63) & ~(size_t)63;
-    if (off + floats > ar->floats) {
+    if (off + floats <= ar->floats) {
+        *p = ar->p + off;
+        ar->used = off + floats;
+        return 0;
+    }
+    if (int rc = wgrad_flush(ar)) return rc;
+    ar->used = 0;
+    const size_t limit = (size_t)ar->defer_mb << 18;   // MB -> floats
+    if (floats > ar->floats || ar->floats < limit) {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(ar->st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
             return fail(LSN_ERR_RUNTIME, "scratch would grow inside a stream capture: run the step eagerly once before capturing");
-        // a new block of twice the demand seen so far; the old one stays allocated (queued descriptors and captured graphs
-        // may hold its addresses) and the arena continues at the start of the new block
-        const size_t want = 2 * (off + floats) + ((size_t)16 << 20);
+        size_t want = 2 * ar->floats > off + floats ? 2 * ar->floats : off + floats;   // what this step has needed so far, at least doubled
+        if (want > limit + floats) want = limit + floats;
+        if (want < floats + floats / 4) want = floats + floats / 4;
+        want += (size_t)4 << 20;
+        if (ar->p) {
+            LSN_HIP(hipStreamSynchronize(ar->st));
+            lib_stat(STAT_BLOCKING_SYNCS, 1);
+            LSN_HIP(hipFree(ar->p));
+            lib_stat(STAT_HELD_BYTES, -(long long)(ar->floats * sizeof(float)));
+            ar->p = nullptr, ar->floats = 0;
+        }
         float *np = nullptr;
         LSN_HIP(hipMalloc(reinterpret_cast<void **>(&np), want * sizeof(float)));
         lib_stat(STAT_MALLOCS, 1), lib_stat(STAT_HELD_BYTES, (long long)(want * sizeof(float)));
-        ar->p = np, ar->floats = want, ar->used = 0;
-        *p = np;
-        ar->used = floats;
-        return 0;
+        ar->p = np, ar->floats = want;
     }
-    *p = ar->p + off;
-    ar->used = off + floats;
+    *p = ar->p;
+    ar->used = floats;
     return 0;
 }
 
@@ -740,8 +760,6 @@ static int reduce_ls(int splits)
     while (LS < 64 && LS * PER_LANE <= splits) LS <<= 1;
     return LS;
 }
-
-static int wgrad_flush(Arena *ar);
 
 int conv_wgrad_reduce(const float *part, float *gw, size_t n, const float *part_b, float *gb, int nb, int splits, int splits_b,
                       int accumulate, hipStream_t st)
