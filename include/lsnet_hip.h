@@ -453,6 +453,11 @@ typedef struct lsn_gn_level {
     const float *dy;   /* backward: gradient w.r.t. output   */
     float *dx;         /* backward: gradient w.r.t. input    */
     int B, HW;
+    /* floats between the images of y / dy; 0 = dense (HW * C).  A level of the concatenated pixel tensor LSHead runs its
+     * pointwise convolutions on ((B, N_all, C): the pixel rows of all levels back to back, lsnet_head.py:640-755) is a view
+     * with the batch stride N_all * C: the forward writes there, the backward reads the gradient there -- no torch.cat in
+     * front of the 1x1 convolution, no per-level copies of its input gradient behind it. */
+    long long y_batch_stride, dy_batch_stride;
 } lsn_gn_level;
 int64_t lsn_group_norm_workspace_bytes(int n_levels, const lsn_gn_level *levels, int C, int G);
 int lsn_group_norm_forward(int n_levels, const lsn_gn_level *levels, int C, int G, const float *gamma,

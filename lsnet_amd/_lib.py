@@ -74,7 +74,8 @@ class ConvWprep(ctypes.Structure):
 
 class GnLevel(ctypes.Structure):
     _fields_ = [('x', ctypes.c_void_p), ('y', ctypes.c_void_p), ('dy', ctypes.c_void_p), ('dx', ctypes.c_void_p),
-                ('B', ctypes.c_int), ('HW', ctypes.c_int)]
+                ('B', ctypes.c_int), ('HW', ctypes.c_int), ('y_batch_stride', ctypes.c_longlong),
+                ('dy_batch_stride', ctypes.c_longlong)]
 
 
 class ProfEntry(ctypes.Structure):

@@ -30,6 +30,7 @@ struct GnLvl {
     const float *x, *dy;
     float *y, *dx;
     int B, HW;
+    long long ybs, dybs;   // floats between the images of y / dy (HW * C when dense)
     int tile0;   // first block of this level
     int img0;    // first (image) slot of this level in the statistics buffers
 };
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a)
     const GnPos p = gn_pos(a, L);
     const int cpg = a.C / a.G, g = (p.q * 4) / cpg;
     const float *xb = L.x + (size_t)p.b * L.HW * a.C;
-    float *yb = L.y + (size_t)p.b * L.HW * a.C;
+    float *yb = L.y + (size_t)p.b * L.ybs;
     float mean, rstd;
     gn_moments(a, L, p.b, g, xb[g * cpg], mean, rstd);
     if (p.p0 == 0 && p.row == 0 && (p.q * 4) % cpg == 0) {   // saved for backward
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const GnArgs a)
     const GnPos p = gn_pos(a, L);
     const int cpg = a.C / a.G, g = (p.q * 4) / cpg;
     const float *xb = L.x + (size_t)p.b * L.HW * a.C;
-    const float *db = L.dy + (size_t)p.b * L.HW * a.C;
+    const float *db = L.dy + (size_t)p.b * L.dybs;
     const float *mr = a.mean_rstd + ((size_t)(L.img0 + p.b) * a.G + g) * 2;
     const float mean = mr[0], rstd = mr[1];
     const float4 ga = *reinterpret_cast<const float4 *>(a.gamma + p.q * 4);
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const GnArgs a)
     const GnPos p = gn_pos(a, L);
     const int cpg = a.C / a.G, g = (p.q * 4) / cpg;
     const float *xb = L.x + (size_t)p.b * L.HW * a.C;
-    const float *db = L.dy + (size_t)p.b * L.HW * a.C;
+    const float *db = L.dy + (size_t)p.b * L.dybs;
     float *ob = L.dx + (size_t)p.b * L.HW * a.C;
     const float *mr = a.mean_rstd + ((size_t)(L.img0 + p.b) * a.G + g) * 2;
     const float mean = mr[0], rstd = mr[1];
@@ -318,6 +319,11 @@ static int gn_fill(GnArgs &a, int n, const lsn_gn_level *lv, int C, int G, int *
         a.lv[i].dx = lv[i].dx;
         a.lv[i].B = lv[i].B;
         a.lv[i].HW = lv[i].HW;
+        a.lv[i].ybs = lv[i].y_batch_stride ? lv[i].y_batch_stride : (long long)lv[i].HW * C;
+        a.lv[i].dybs = lv[i].dy_batch_stride ? lv[i].dy_batch_stride : (long long)lv[i].HW * C;
+        LSN_CHECK(a.lv[i].ybs >= (long long)lv[i].HW * C && a.lv[i].dybs >= (long long)lv[i].HW * C && a.lv[i].ybs % 4 == 0 &&
+                      a.lv[i].dybs % 4 == 0,
+                  "level %d: batch strides must cover an image and keep 16-byte alignment", i);
         a.lv[i].tile0 = t;
         a.lv[i].img0 = im;
         t += lv[i].B * ((lv[i].HW + GN_PIX - 1) / GN_PIX);

@@ -279,6 +279,12 @@ class LSHead(nn.Module):
             return [lvl, lvl - 1, lvl - 2]
         return [lvl, lvl - 1, lvl + 1]
 
+    def _gn_cat(self, gn, maps):
+        """relu(GN(maps)) as _cat_px lays it out; the library's GroupNorm writes the concatenated tensor itself"""
+        if hasattr(gn, 'forward_cat_px'):
+            return gn.forward_cat_px(maps, relu=True)
+        return self._cat_px(gn.forward_multi(maps, relu=True))
+
     @staticmethod
     def _cat_px(maps):
         """Per-level maps (B, C, H_l, W_l) -> ONE (B, C, N_all, 1) tensor in channels-last memory (pixel rows of all
@@ -355,13 +361,13 @@ class LSHead(nn.Module):
             return [x + y for x, y in zip(a, f)]
 
         fused = fuse(self.cls_af_dcn_conv, self.cls_feat_conv, cls_raw, cls_feats)
-        outs['cls'] = self._split_px(self.pts_cls_out(self._cat_px(self.cls_GN.forward_multi(fused, relu=True))), shapes)
+        outs['cls'] = self._split_px(self.pts_cls_out(self._gn_cat(self.cls_GN, fused)), shapes)
         for b in self.branches:
             raw = gather(getattr(self, f'pts_{b}_refine_conv'), st[b]['feat'], scaled[b])
             af, fc = getattr(self, f'{b}_af_dcn_conv'), getattr(self, f'{b}_feat_conv')
             gn, ro = getattr(self, f'{b}_GN'), getattr(self, f'pts_{b}_refine_out')
             fused = fuse(af, fc, raw, st[b]['feat'])
-            refine = self.softplus(ro(self._cat_px(gn.forward_multi(fused, relu=True))) + st[b]['sp_all'].detach())
+            refine = self.softplus(ro(self._gn_cat(gn, fused)) + st[b]['sp_all'].detach())
             outs[b] = self._split_px(refine, shapes)
 
         none = [None] * nl

@@ -74,18 +74,35 @@ class HipBackend:
             L.B, L.HW = B, H * W
         return levels
 
-    def group_norm_forward(self, xs, gamma, beta, groups, eps, relu):
-        """xs: channels-last (B, C, H, W) tensors sharing gamma/beta.  Returns (ys, mean_rstd)."""
+    def group_norm_forward(self, xs, gamma, beta, groups, eps, relu, cat_px=False):
+        """xs: channels-last (B, C, H, W) tensors sharing gamma/beta.  Returns (ys, mean_rstd).
+        cat_px: the outputs are written as the levels of ONE (B, N_all, C) tensor (pixel rows of all levels back to back:
+        LSHead._cat_px's layout); ys is then that tensor, viewed as (B, C, N_all, 1)."""
         lib = _lib.load()
         n, C = len(xs), xs[0].shape[1]
-        ys = [torch.empty_like(x, memory_format=_CL) for x in xs]
-        levels = self._gn_levels(xs, ys=ys)
+        if cat_px:
+            B = xs[0].shape[0]
+            assert all(x.shape[0] == B for x in xs)
+            hw = [x.shape[2] * x.shape[3] for x in xs]
+            flat = torch.empty((B, sum(hw), C), device=xs[0].device, dtype=torch.float32)
+            ys, o = [], 0
+            for k in hw:
+                ys.append(flat[:, o:o + k])      # (B, k, C), batch stride N_all * C
+                o += k
+            levels = self._gn_levels(xs, ys=ys)
+            for L in levels:
+                L.y_batch_stride = flat.stride(0)
+        else:
+            ys = [torch.empty_like(x, memory_format=_CL) for x in xs]
+            levels = self._gn_levels(xs, ys=ys)
         images = sum(x.shape[0] for x in xs)
         mean_rstd = torch.empty(images, groups, 2, device=xs[0].device, dtype=torch.float32)
         ws = torch.empty(lib.lsn_group_norm_workspace_bytes(n, levels, C, groups), device=xs[0].device,
                          dtype=torch.uint8)
         _lib.check(lib.lsn_group_norm_forward(n, levels, C, groups, _ptr(gamma), _ptr(beta), ctypes.c_float(eps),
                                               1 if relu else 0, _ptr(mean_rstd), _ptr(ws), _stream()))
+        if cat_px:
+            return flat.unsqueeze(2).permute(0, 3, 1, 2), mean_rstd      # (B, C, N_all, 1), channels-last memory
         return ys, mean_rstd
 
     supports_grad_sinks = True
@@ -95,9 +112,23 @@ class HipBackend:
         to ADD the parameter gradients to (ops/grad_sink.py)."""
         lib = _lib.load()
         n, C = len(xs), xs[0].shape[1]
-        dys = [d.contiguous(memory_format=_CL) for d in dys]
         dxs = [torch.empty_like(x, memory_format=_CL) for x in xs]
-        levels = self._gn_levels(xs, dys=dys, dxs=dxs)
+        if torch.is_tensor(dys):     # the gradient of a cat_px output: (B, C, N_all, 1); its levels are read in place
+            B = dys.shape[0]
+            flat = dys.permute(0, 2, 3, 1).reshape(B, -1, C)
+            if not flat.is_contiguous():
+                flat = flat.contiguous()
+            dyl, o = [], 0
+            for x in xs:
+                k = x.shape[2] * x.shape[3]
+                dyl.append(flat[:, o:o + k])
+                o += k
+            levels = self._gn_levels(xs, dys=dyl, dxs=dxs)
+            for L in levels:
+                L.dy_batch_stride = flat.stride(0)
+        else:
+            dys = [d.contiguous(memory_format=_CL) for d in dys]
+            levels = self._gn_levels(xs, dys=dys, dxs=dxs)
         if sinks:
             dg, db = sinks
         else:

@@ -477,6 +477,42 @@ def test_group_norm_matches_torch(C, G, relu, shapes):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('relu', [False, True])
+def test_group_norm_writes_the_concatenated_pixel_tensor(relu):
+    """GroupNorm.forward_cat_px: the levels' outputs as ONE (B, C, N_all, 1) tensor, pixel rows of all levels back to back,
+    written by the kernels themselves (lsn_gn_level.y_batch_stride), and the backward reading the levels of that tensor's
+    gradient where they lie (dy_batch_stride) -- the same BITS as concatenating forward_multi's outputs and as backward over
+    per-level copies: output, input gradients, gamma / beta gradients."""
+    from lsnet_amd.ops.group_norm import GroupNorm
+    torch.manual_seed(8)
+    dev = torch.device('cuda:0')
+    C, G = 256, 32
+    m = GroupNorm(G, C).to(dev)
+    with torch.no_grad():
+        m.weight.copy_(torch.randn(C) * 0.5 + 1.0)
+        m.bias.copy_(torch.randn(C) * 0.3)
+    shapes = [(2, 25, 42), (2, 13, 21), (2, 7, 11), (2, 4, 6), (2, 2, 3)]
+    xs = [torch.randn(b, C, h, w, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_() for b, h, w in shapes]
+
+    def cat(maps):
+        B = maps[0].shape[0]
+        return torch.cat([t.permute(0, 2, 3, 1).reshape(B, -1, C) for t in maps], dim=1).unsqueeze(2).permute(0, 3, 1, 2)
+    y_ref = cat(m.forward_multi(xs, relu=relu))
+    go = torch.randn_like(y_ref)
+    ref = torch.autograd.grad(y_ref, xs + [m.weight, m.bias], go)
+    y = m.forward_cat_px(xs, relu=relu)
+    assert y.shape == y_ref.shape and y.stride() == y_ref.stride()
+    got = torch.autograd.grad(y, xs + [m.weight, m.bias], go)
+    assert torch.equal(y, y_ref)
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
+    # a gradient that arrives in another layout is brought into the concatenated one first
+    got2 = torch.autograd.grad(m.forward_cat_px(xs, relu=relu), xs, go.contiguous())
+    for a, b in zip(got2, ref):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
 def test_group_norm_unsupported_shape_uses_aten():
     from lsnet_amd.ops.group_norm import GroupNorm
     dev = torch.device('cuda:0')
