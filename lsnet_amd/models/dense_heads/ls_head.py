@@ -356,7 +356,11 @@ class LSHead(nn.Module):
         def fuse(af, fc, raw, feat):
             # relu(1x1 over the three gathered maps of a level) + 3x3 over the level's tower output: each of the two
             # convolutions runs over all levels in one launch
+            # (round 5: the sum rides in the epilogue of the second launch -- (conv + bias) + a, the additions and roundings of
+            # `f + a` -- instead of five element-wise launches per branch)
             a = af[0].forward_multi(raw, relu=True)
+            if hasattr(fc, 'forward_multi') and 'residuals' in fc.forward_multi.__code__.co_varnames:
+                return fc.forward_multi(feat, residuals=a)
             f = fc.forward_multi(feat)
             return [x + y for x, y in zip(a, f)]
 

@@ -416,8 +416,9 @@ def hip_group_conv_ok(x, weight, stride, padding, dilation, groups, padding_mode
     return x.numel() < 2 ** 31 and Co * x.shape[0] * x.shape[2] * x.shape[3] < 2 ** 31
 
 
-def conv_multi_fwd(xs, w, bias, pad, dil, relu):
-    """[conv2d(x, w, bias, 1, pad, dil) for x in xs] in ONE launch (channels-last device tensors; no autograd)."""
+def conv_multi_fwd(xs, w, bias, pad, dil, relu, residuals=None):
+    """[conv2d(x, w, bias, 1, pad, dil) for x in xs] in ONE launch (channels-last device tensors; no autograd).
+    residuals: per-map tensors of the outputs' shape, added in the epilogue (before the ReLU, lsn_conv_level.residual)."""
     Co, C, kh, kw = w.shape
     n = len(xs)
     levels = (_lib.ConvLevel * n)()
@@ -429,6 +430,9 @@ def conv_multi_fwd(xs, w, bias, pad, dil, relu):
         outs.append(out)
         L = levels[i]
         L.x, L.out, L.B, L.H, L.W = _p(x), _p(out), B, H, W
+        if residuals is not None:
+            assert residuals[i].shape == out.shape and residuals[i].is_contiguous(memory_format=_CL)
+            L.residual = _p(residuals[i])
     _lib.check(_lib.load().lsn_conv2d_forward_prepared(n, levels, _p(weight_image(w, 0)), _p(bias), C, C, Co, kh, kw, 1, pad, dil,
                                                        1 if relu else 0, _stream()))
     return outs
@@ -481,11 +485,14 @@ class _ConvMultiFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, w, bias, cfg, *xs):
-        pad, dil, relu = cfg
+        pad, dil, relu = cfg[:3]
+        nres = cfg[3] if len(cfg) > 3 else 0     # the last nres tensors are residuals of the first maps' outputs (round 5)
+        res = list(xs[len(xs) - nres:]) if nres else None
+        xs = xs[:len(xs) - nres] if nres else xs
         w = w.contiguous(memory_format=_CL)
-        outs = conv_multi_fwd(xs, w, bias, pad, dil, relu)
+        outs = conv_multi_fwd(xs, w, bias, pad, dil, relu, res)
         ctx.save_for_backward(w, *xs, *(outs if relu else []))
-        ctx.cfg, ctx.n, ctx.has_bias = cfg, len(xs), bias is not None
+        ctx.cfg, ctx.n, ctx.has_bias, ctx.nres = (pad, dil, relu), len(xs), bias is not None, nres
         ctx.bias_ref = bias
         return tuple(outs)
 
@@ -508,12 +515,18 @@ class _ConvMultiFn(torch.autograd.Function):
         if ctx.needs_input_grad[0] or (ctx.has_bias and ctx.needs_input_grad[1]):
             gw, gb = conv_multi_wgrad(xs, gos, w, ctx.bias_ref, pad, dil, ctx.needs_input_grad[0],
                                       ctx.has_bias and ctx.needs_input_grad[1])
-        return (gw, gb, None, *gxs)
+        # the residual sits in front of the ReLU: its gradient is the (gated) output gradient itself
+        gres = [gos[i] if ctx.needs_input_grad[3 + n + i] else None for i in range(ctx.nres)]
+        return (gw, gb, None, *gxs, *gres)
 
 
-def conv2d_multi(xs, weight, bias=None, padding=0, dilation=1, relu=False):
-    """[conv2d(x, weight, bias, 1, padding, dilation) for x in xs] in one launch per pass (stride 1, up to 8 maps)."""
-    return list(_ConvMultiFn.apply(weight, bias, (int(padding), int(dilation), bool(relu)), *xs))
+def conv2d_multi(xs, weight, bias=None, padding=0, dilation=1, relu=False, residuals=None):
+    """[conv2d(x, weight, bias, 1, padding, dilation) (+ residual) for x in xs] in one launch per pass (stride 1, up to 8 maps).
+    residuals: one tensor of the output's shape per map, added in the launch's epilogue (before the ReLU) -- the sum of two
+    branches without an element-wise launch of its own (LSHead's `relu(1x1(gathered)) + 3x3(tower)`, lsnet_head.py:640-755)."""
+    nres = 0 if residuals is None else len(residuals)
+    assert nres in (0, len(xs))
+    return list(_ConvMultiFn.apply(weight, bias, (int(padding), int(dilation), bool(relu), nres), *xs, *(residuals or [])))
 
 
 def hip_conv_ok(x, weight, stride, padding, dilation, groups, padding_mode='zeros'):
@@ -711,14 +724,19 @@ class Conv2d(nn.Conv2d):
             return self._run(x, weight)
         return self._run(x, self.weight)
 
-    def forward_multi(self, xs, relu=False):
-        """The same convolution over several maps (FPN levels) in ONE launch per pass."""
+    def forward_multi(self, xs, relu=False, residuals=None):
+        """The same convolution over several maps (FPN levels) in ONE launch per pass.  residuals: per-map tensors added to the
+        outputs (before the ReLU) -- in the launch's epilogue on the device."""
         xs = list(xs)
         if (1 < len(xs) <= 8 and self.stride[0] == 1 and xs[0].shape[1] % 4 == 0
                 and all(hip_conv_ok(x, self.weight, self.stride, self.padding, self.dilation, self.groups,
-                                    self.padding_mode) for x in xs)):
-            return conv2d_multi([_as_cl(x) for x in xs], self.weight, self.bias, self.padding[0], self.dilation[0], relu)
+                                    self.padding_mode) for x in xs)
+                and (residuals is None or (self.weight.shape[0] % 4 == 0 and all(r.is_cuda and r.dtype == torch.float32 for r in residuals)))):
+            res = None if residuals is None else [_as_cl(r) for r in residuals]
+            return conv2d_multi([_as_cl(x) for x in xs], self.weight, self.bias, self.padding[0], self.dilation[0], relu, res)
         outs = [self._run(x, self.weight) for x in xs]
+        if residuals is not None:
+            outs = [o + r for o, r in zip(outs, residuals)]
         return [F.relu(o) for o in outs] if relu else outs
 
     def _run(self, x, w):

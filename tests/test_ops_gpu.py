@@ -782,6 +782,32 @@ def test_conv2d_stream_k_is_deterministic(C, Co, k, s, H, W):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('relu', [False, True])
+def test_conv2d_multi_level_residual_in_the_epilogue(relu):
+    """Conv2d.forward_multi(xs, residuals=rs): the per-level sum conv(x) + r rides in the launch's epilogue (in front of the
+    ReLU).  Without ReLU it is LSHead's `3x3(tower) + relu(1x1(gathered))`: the same additions and roundings as the separate
+    element-wise launch it replaces -- the same BITS, outputs and all gradients (the residual's gradient is the output
+    gradient itself)."""
+    from lsnet_amd.ops.conv import Conv2d
+    torch.manual_seed(9)
+    dev = _dev()
+    m = Conv2d(256, 256, 3, padding=1).to(dev).to(memory_format=torch.channels_last)
+    sizes = [(50, 84), (25, 42), (13, 21), (7, 11), (4, 6)]
+    xs = [torch.randn(2, 256, h, w, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_() for h, w in sizes]
+    rs = [torch.randn(2, 256, h, w, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_() for h, w in sizes]
+    outs = m.forward_multi(xs, relu=relu, residuals=rs)
+    gos = [torch.randn_like(o) for o in outs]
+    got = torch.autograd.grad(outs, xs + rs + list(m.parameters()), gos)
+    plain = [a + b for a, b in zip(m.forward_multi(xs), rs)]
+    plain = [F.relu(o) for o in plain] if relu else plain
+    ref = torch.autograd.grad(plain, xs + rs + list(m.parameters()), gos)
+    for a, b in zip(outs, plain):
+        assert torch.equal(a, b)
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
 def test_stem_row_merged_forward(split_mode):
     """The frozen 7x7 stride-2 stem on the 3-channel image: row-merged form (lsn_conv2d_forward_pitched)."""
     from lsnet_amd.ops.conv import Conv2d
