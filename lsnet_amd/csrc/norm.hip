@@ -7,8 +7,8 @@
 // cost a layout copy before and after every deformable conv (324 permute launches per training step).  These
 // kernels read and write NHWC directly and fold the ReLU in:
 //   forward : gn_stats_kernel (shifted sums -> fp64 atomics per (image, group)), gn_apply_kernel (y = x*a + b)
-//   backward: gn_bwd_reduce_kernel (per (image, channel) sums of dy and dy*xhat), gn_bwd_apply_kernel,
-//             gn_param_grad_kernel (d gamma, d beta over images and levels)
+//   backward: gn_bwd_reduce_kernel (per (image, channel) sums of dy and dy*xhat), gn_bwd_imgsum_kernel (the same per image,
+//             d gamma / d beta by its last block), gn_bwd_apply_kernel
 // All are HBM-bound streaming kernels: one pixel row (C floats) is read by C/4 lanes as float4.
 // Numerics: variance from shifted sums (shift = the group's first element of the image), accumulated in fp32
 // per thread and in fp64 across threads / blocks -- robust when |mean| >> std.
@@ -39,7 +39,9 @@ struct GnArgs {
     int nlv, C, G, relu;
     float eps;
     const float *gamma, *beta;
-    double *sums;      // [images][G][2]   shifted sum, shifted sum of squares   (zero-filled by the launcher)
+    double *sums;      // [images][G][2]   shifted sum, shifted sum of squares   (zero when the statistics kernel starts)
+    double *clear;     // the statistics kernel zeroes clear[0 .. nclear): the sums the PREVIOUS call of this stream left behind
+    int nclear;
     unsigned *ticket;  // self-resetting counters of this stream (conv.hip lib_tickets); [1]: the backward's image sums
     float *mean_rstd;  // [images][G][2]
     float *ab;         // [images][C][2]   backward: sum dy*xhat, sum dy
@@ -73,12 +75,14 @@ __device__ __forceinline__ GnPos gn_pos(const GnArgs &a, const GnLvl &L)
     return r;
 }
 
-// (Round 5 tried the statistics without the fill launch and the fp64 atomics: per-block partials + a ticket, the last block of
+// (Round 5 tried the statistics without the fp64 atomics: per-block partials + a ticket, the last block of
 // an image adding them in block order -- correct and bit-stable, but 0.1 ms per step SLOWER than this form, 32.60 vs 32.50 ms,
 // old and new library alternating on one box: the finisher's tail costs more than 16 fills and 45 k atomics.  With
-// __threadfence() instead of agent-scope stores it lost 0.4 ms.  profiles/r5_gn_ticket.txt.)
+// __threadfence() instead of agent-scope stores it lost 0.4 ms.  profiles/r5_gn_ticket.txt.  The fills went another way:
+// gn_sums() below.)
 __global__ __launch_bounds__(256) void gn_stats_kernel(const GnArgs a)
 {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < a.nclear; i += gridDim.x * 256) a.clear[i] = 0.0;
     int li;
     const GnLvl &L = gn_level(a, blockIdx.x, li);
     const GnPos p = gn_pos(a, L);
@@ -300,6 +304,42 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const GnArgs a)
         o.w = rstd * (ga.w * d.w - m1 - h3 * m2);
         *reinterpret_cast<float4 *>(ob + (size_t)px * a.C + p.q * 4) = o;
     }
+}
+
+// The statistics sums without a fill launch: two library-owned buffers per stream.  Call k accumulates into one of them and its
+// statistics kernel clears what call k - 1 left in the other (stream order: the apply kernel of call k - 1, the only reader, has
+// finished).  16 memsets per training step go; calls with more than GN_SUMS_CAP sums keep the caller's workspace + memset.
+constexpr int GN_SUMS_CAP = 8192;   // doubles per buffer (images * G * 2)
+struct GnSums {
+    hipStream_t st;
+    double *buf;   // [2][GN_SUMS_CAP], zeroed once
+    int cur, dirty[2];
+};
+static GnSums g_gns[16];
+static int g_ngns = 0;
+static int gn_sums(hipStream_t st, int n, GnArgs &a)
+{
+    GnSums *s = nullptr;
+    for (int i = 0; i < g_ngns; ++i)
+        if (g_gns[i].st == st) s = &g_gns[i];
+    if (!s) {
+        if (g_ngns == 16) return fail(LSN_ERR_RUNTIME, "group norm: more than 16 streams use the library");
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+            return fail(LSN_ERR_RUNTIME, "group norm: first call inside a stream capture: run the step eagerly once before capturing");
+        double *np = nullptr;
+        LSN_HIP(hipMalloc(reinterpret_cast<void **>(&np), 2 * GN_SUMS_CAP * sizeof(double)));
+        lib_stat(STAT_MALLOCS, 1), lib_stat(STAT_HELD_BYTES, (long long)(2 * GN_SUMS_CAP * sizeof(double)));
+        LSN_HIP(hipMemsetAsync(np, 0, 2 * GN_SUMS_CAP * sizeof(double), st));
+        s = &g_gns[g_ngns++];
+        *s = GnSums{st, np, 0, {0, 0}};
+    }
+    const int cur = s->cur, oth = cur ^ 1;
+    a.sums = s->buf + (size_t)cur * GN_SUMS_CAP;
+    a.clear = s->buf + (size_t)oth * GN_SUMS_CAP;
+    a.nclear = s->dirty[oth];
+    s->dirty[oth] = 0, s->dirty[cur] = n, s->cur = oth;
+    return 0;
 }
 
 static int gn_fill(GnArgs &a, int n, const lsn_gn_level *lv, int C, int G, int *tiles, int *images)
@@ -534,9 +574,13 @@ int lsn_group_norm_forward(int n_levels, const lsn_gn_level *levels, int C, int 
     a.beta = beta;
     a.eps = eps;
     a.relu = relu;
-    a.sums = reinterpret_cast<double *>(workspace);
     a.mean_rstd = mean_rstd;
-    LSN_HIP(hipMemsetAsync(a.sums, 0, sizeof(double) * (size_t)images * G * 2, st));
+    if (images * G * 2 <= GN_SUMS_CAP) {
+        if (int rc = gn_sums(st, images * G * 2, a)) return rc;
+    } else {
+        a.sums = reinterpret_cast<double *>(workspace);
+        LSN_HIP(hipMemsetAsync(a.sums, 0, sizeof(double) * (size_t)images * G * 2, st));
+    }
     double el = 0;
     for (int i = 0; i < n_levels; ++i) el += (double)levels[i].B * levels[i].HW * C;
     ProfSpan prof(PROF_NORM, 8.0 * el, 4.0 * 2 * el, st);   // algorithmic: x read once, y written once

@@ -513,6 +513,35 @@ def test_group_norm_writes_the_concatenated_pixel_tensor(relu):
 
 
 @pytest.mark.gpu
+def test_group_norm_statistics_buffers_alternate_between_calls():
+    """The statistics sums live in two library-owned buffers per stream; each call's statistics kernel clears what the call
+    before left in the other one (norm.hip gn_sums) -- no memset launch.  Calls of very different sizes back to back, then
+    one with more sums than a buffer holds (the caller's workspace + memset path), then a small one again."""
+    from lsnet_amd.ops.group_norm import GroupNorm
+    torch.manual_seed(9)
+    dev = torch.device('cuda:0')
+    m = GroupNorm(32, 128).to(dev)
+    with torch.no_grad():
+        m.weight.copy_(torch.randn(128) * 0.5 + 1.0)
+        m.bias.copy_(torch.randn(128) * 0.3)
+    sizes = [[(2, 9, 7), (2, 5, 4)], [(1, 3, 3)], [(16, 6, 5), (16, 3, 3), (16, 2, 2)], [(2, 9, 7), (2, 5, 4)], [(1, 3, 3)],
+             [(136, 2, 2)],          # 136 images x 32 groups x 2 sums > 8192
+             [(1, 3, 3)], [(3, 11, 5)]]
+    first = {}
+    for rep, shapes in enumerate(sizes):
+        xs = [(torch.randn(b, 128, h, w, device=dev) * 2 + 5).contiguous(memory_format=torch.channels_last) for b, h, w in shapes]
+        with torch.no_grad():
+            ys = m.forward_multi(xs, relu=False)
+        for x, y in zip(xs, ys):
+            assert _err(y, F.group_norm(x, 32, m.weight, m.bias, m.eps)) < 1e-5, (rep, tuple(x.shape))
+    # the same input gives the same bits whichever buffer the call lands on
+    x = torch.randn(2, 128, 9, 7, device=dev).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        outs = [m.forward_multi([x], relu=True)[0].clone() for _ in range(3)]
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+@pytest.mark.gpu
 def test_group_norm_unsupported_shape_uses_aten():
     from lsnet_amd.ops.group_norm import GroupNorm
     dev = torch.device('cuda:0')
