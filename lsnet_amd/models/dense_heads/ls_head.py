@@ -18,6 +18,7 @@ Same parameters, state-dict keys, outputs and losses as the reference, organised
     the training step never synchronises with the host.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -31,6 +32,9 @@ from ...ops import ModulatedDeformConvPack, PyramidDeformConv
 from ...ops.dcn import offset_scale_chain
 from ...ops import cross_iou as fused_ciou
 from ..builder import HEADS, build_loss
+
+# LSNET_SIDE_STREAM_TARGETS=0: the init-stage targets on the main stream, between the head's forward and the loss (A/B switch)
+SIDE_STREAM_TARGETS = os.environ.get('LSNET_SIDE_STREAM_TARGETS', '1') != '0'
 
 # regression branches of each task; the LAST branch's offsets also drive the classification
 # PyramidDeformConv (lsnet_head.py:638, 653, 680, 695)
@@ -301,10 +305,12 @@ class LSHead(nn.Module):
             return list(_SplitPxFn.apply(x, tuple(shapes)))
         return _split_px_views(x, shapes)
 
-    def forward(self, feats):
+    def forward(self, feats, after_init=None):
         """feats: tuple of 5 FPN maps.  Returns the reference's 7-tuple of per-level lists
         (cls, bbox_init, bbox_refine, segm_init, segm_refine, pose_init, pose_refine); branches the
-        task does not have are lists of None (lsnet_head.py:479-500)."""
+        task does not have are lists of None (lsnet_head.py:479-500).
+        after_init: called with {branch: per-level init predictions} as soon as those are issued, before the pyramid
+        convolutions (forward_train starts the refine-stage assignment there, on its second stream)."""
         nl = len(feats)
         shapes = [tuple(f.shape[2:]) for f in feats]
         base_offset = self.dcn_base_offset.type_as(feats[0])
@@ -321,6 +327,9 @@ class LSHead(nn.Module):
             reg = (1 - self.gradient_mul) * reg.detach() + self.gradient_mul * reg
             st[b] = dict(feat=tower, sp_all=sp, sp=self._split_px(sp, shapes),
                          off=self._split_px(reg - base_offset, shapes))
+
+        if after_init is not None:
+            after_init({b: st[b]['sp'] for b in self.branches})
 
         # --- offsets handed to the pyramid convs.  The reference rescales the offset tensor IN PLACE
         # while looping over the three source levels, so the multipliers accumulate:
@@ -382,9 +391,31 @@ class LSHead(nn.Module):
 
     def forward_train(self, x, img_metas, gt_bboxes, gt_extremes=None, gt_keypoints=None, gt_masks=None,
                       gt_labels=None, gt_bboxes_ignore=None, proposal_cfg=None, **kwargs):
-        outs = self(x)
+        # The init-stage targets (ground-truth preparation, grid points, CentroidAssigner, dense targets: ~100 launches of a few
+        # microseconds) depend on the ground truth and the map sizes only: they are issued on a second stream BEFORE the head's
+        # forward and run in the shadow of its deformable convolutions instead of between forward and backward.
+        # The refine-stage assignment needs the init predictions and nothing later: it starts on that stream as soon as the head
+        # has issued them (`after_init`) and runs beside the pyramid convolutions.
+        pre, stage2, hook = None, [], None
+        if SIDE_STREAM_TARGETS and x[0].is_cuda:
+            main = torch.cuda.current_stream(x[0].device)
+            side = self._side_stream(x[0].device)
+            side.wait_stream(main)                      # the ground truth may have been produced on the main stream
+            with torch.cuda.stream(side):
+                pre = self.init_stage_targets([tuple(f.shape[-2:]) for f in x], x[0], gt_bboxes, gt_extremes, gt_keypoints,
+                                              gt_masks, gt_labels, img_metas)
+
+            def hook(init_preds):
+                side.wait_stream(main)                  # the init predictions are main-stream work
+                with torch.cuda.stream(side):
+                    stage2.append(self.refine_stage_targets(pre, [p.detach() for p in init_preds[self._box_branch()]]))
+        outs = self(x, after_init=hook)
+        if pre is not None:
+            # (no record_stream: the next use of the side stream starts with wait_stream(main) again, i.e. behind every reader of
+            # these tensors, and that is the only place where the allocator can hand their memory out again)
+            main.wait_stream(side)
         losses = self.loss(*outs, gt_bboxes, gt_extremes, gt_keypoints, gt_masks, gt_labels, img_metas,
-                           gt_bboxes_ignore=gt_bboxes_ignore)
+                           gt_bboxes_ignore=gt_bboxes_ignore, init_stage=pre, refine_stage=stage2[0] if stage2 else None)
         if proposal_cfg is None:
             return losses
         return losses, self.get_bboxes(*outs, img_metas, cfg=proposal_cfg)
@@ -566,14 +597,20 @@ class LSHead(nn.Module):
                 losses[f'{b}_{stage}'] = [r.sum() / n for r in per_level]
         return losses
 
-    def loss(self, cls_scores, bbox_pts_preds_init, bbox_pts_preds_refine, segm_pts_preds_init,
-             segm_pts_preds_refine, pose_pts_preds_init, pose_pts_preds_refine, gt_bboxes, gt_extremes,
-             gt_keypoints_vs, gt_masks, gt_labels, img_metas, gt_bboxes_ignore=None):
-        """lsnet_head.py:1272-1437"""
-        preds = dict(bbox=(bbox_pts_preds_init, bbox_pts_preds_refine),
-                     segm=(segm_pts_preds_init, segm_pts_preds_refine),
-                     pose=(pose_pts_preds_init, pose_pts_preds_refine))
-        device = cls_scores[0].device
+    def _side_stream(self, device):
+        key = ('side_stream', str(device))
+        st = self._streams.get(key) if hasattr(self, '_streams') else None
+        if st is None:
+            if not hasattr(self, '_streams'):
+                self._streams = {}
+            st = self._streams[key] = torch.cuda.Stream(device)
+        return st
+
+    def init_stage_targets(self, featmap_sizes, like, gt_bboxes, gt_extremes, gt_keypoints_vs, gt_masks, gt_labels, img_metas):
+        """Everything of `loss` (lsnet_head.py:1272-1437) that does not depend on a prediction: the ground truth in the head's
+        formats, grid points and flags, the init-stage assignment and its dense targets.  `like`: a tensor of the head's device
+        and dtype."""
+        device = like.device
         num_imgs = len(img_metas)
         extra = [dict() for _ in range(num_imgs)]
         if self.task in ('bbox', 'pose_bbox'):
@@ -582,7 +619,7 @@ class LSHead(nn.Module):
             for i in range(num_imgs):
                 extra[i]['extremes_gt'] = gt_extremes[i]
         if self.task == 'segm':
-            gt_polygons, gt_bboxes = self.process_polygons(gt_masks, cls_scores)
+            gt_polygons, gt_bboxes = self.process_polygons(gt_masks, [like])
             for i in range(num_imgs):
                 extra[i]['polygons_gt'] = gt_polygons[i]
         elif self.task == 'pose_bbox':
@@ -594,27 +631,57 @@ class LSHead(nn.Module):
             for i in range(num_imgs):
                 extra[i].update(keypoints_gt=kps[i], keypoints_vs=vs[i])
 
-        featmap_sizes = [tuple(m.shape[-2:]) for m in cls_scores]
+        featmap_sizes = [tuple(s) for s in featmap_sizes]
         assert len(featmap_sizes) == len(self.point_generators)
         points, flags, all_valid = self.get_points(featmap_sizes, img_metas, device)
         num_level = [p.shape[0] for p in points]
         flat_points = torch.cat(points)
         flat_flags = [torch.cat(f) for f in flags]
-
         tg_init, n_init = self.get_targets([flat_points] * num_imgs, flat_flags, all_valid, num_level, gt_bboxes,
                                            gt_labels, extra, 'init')
-        # refine stage: assign on the boxes decoded from the (detached) init predictions
-        box_branch = 'bbox' if 'bbox' in self.branches else self.branches[0]
+        return dict(featmap_sizes=featmap_sizes, extra=extra, gt_bboxes=gt_bboxes, gt_labels=gt_labels, points=points,
+                    all_valid=all_valid, num_level=num_level, flat_flags=flat_flags, tg_init=tg_init, n_init=n_init)
+
+    def _box_branch(self):
+        return 'bbox' if 'bbox' in self.branches else self.branches[0]
+
+    def refine_stage_targets(self, init_stage, init_preds):
+        """The refine-stage assignment: on the boxes decoded from the (detached) init predictions of the box branch
+        (lsnet_head.py:1342-1378).  Returns (targets, positive count)."""
+        points, box_branch = init_stage['points'], self._box_branch()
+        num_imgs = init_preds[0].shape[0]
         decoded = []
-        for lvl, p in enumerate(preds[box_branch][0]):
+        for lvl, p in enumerate(init_preds):
             p = p.detach()
             box = self.extreme_points2bbox(p) if box_branch == 'bbox' else self.vectors2bbox(p)
             box = box * self.point_strides[lvl]
             centre = torch.cat([points[lvl][:, :2], points[lvl][:, :2]], dim=1)
             decoded.append(centre[None] + box.permute(0, 2, 3, 1).reshape(num_imgs, -1, 4))
         boxes = torch.cat(decoded, dim=1)
-        tg_refine, n_refine = self.get_targets([boxes[i] for i in range(num_imgs)], flat_flags, all_valid,
-                                               num_level, gt_bboxes, gt_labels, extra, 'refine')
+        return self.get_targets([boxes[i] for i in range(num_imgs)], init_stage['flat_flags'], init_stage['all_valid'],
+                                init_stage['num_level'], init_stage['gt_bboxes'], init_stage['gt_labels'], init_stage['extra'],
+                                'refine')
+
+    def loss(self, cls_scores, bbox_pts_preds_init, bbox_pts_preds_refine, segm_pts_preds_init,
+             segm_pts_preds_refine, pose_pts_preds_init, pose_pts_preds_refine, gt_bboxes, gt_extremes,
+             gt_keypoints_vs, gt_masks, gt_labels, img_metas, gt_bboxes_ignore=None, init_stage=None, refine_stage=None):
+        """lsnet_head.py:1272-1437.  init_stage / refine_stage: the results of `init_stage_targets` / `refine_stage_targets`
+        when the caller has computed them already (forward_train does, on a second stream)."""
+        preds = dict(bbox=(bbox_pts_preds_init, bbox_pts_preds_refine),
+                     segm=(segm_pts_preds_init, segm_pts_preds_refine),
+                     pose=(pose_pts_preds_init, pose_pts_preds_refine))
+        num_imgs = len(img_metas)
+        featmap_sizes = [tuple(m.shape[-2:]) for m in cls_scores]
+        if init_stage is None or init_stage['featmap_sizes'] != featmap_sizes:
+            refine_stage = None
+            init_stage = self.init_stage_targets(featmap_sizes, cls_scores[0], gt_bboxes, gt_extremes, gt_keypoints_vs, gt_masks,
+                                                 gt_labels, img_metas)
+        extra, gt_bboxes, points = init_stage['extra'], init_stage['gt_bboxes'], init_stage['points']
+        all_valid, num_level, flat_flags = init_stage['all_valid'], init_stage['num_level'], init_stage['flat_flags']
+        tg_init, n_init = init_stage['tg_init'], init_stage['n_init']
+        if refine_stage is None:
+            refine_stage = self.refine_stage_targets(init_stage, preds[self._box_branch()][0])
+        tg_refine, n_refine = refine_stage
 
         lv = self.loss_levels(cls_scores, {b: preds[b] for b in self.branches}, tg_init, tg_refine, points, num_level,
                               n_init, n_refine)
