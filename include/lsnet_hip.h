@@ -231,6 +231,24 @@ int lsn_sigmoid_focal_loss_backward_weighted(const float *logits, const int64_t 
                                              const float *weight, const float *scale, float *d_logits,
                                              int N, int C, float gamma, float alpha, lsn_stream_t stream);
 
+/* [fused] Per-LEVEL loss sums over LSHead's concatenated rows.  The head keeps the pixels of all FPN levels of an image back to
+ * back (row r = b * N_all + i; level l owns i in [level_starts[l], level_starts[l + 1]), level_starts: HOST array of L + 1
+ * entries, L <= 8, B * L <= 64).  The reference computes every loss term per level (lsnet_head.py:1021-1270 `loss_single` through
+ * `multi_apply`, then base.py:176-209 adds the levels up): these calls return the L per-level values of one term in one launch.
+ *   lsn_sigmoid_focal_loss_level_sums: loss_sums[l] = sum over level l's rows of weight[n] * sum_c FL(n, c)  (focal_loss.py:74-116)
+ *   lsn_sigmoid_focal_loss_backward_levels: d_logits[n, c] = scales[level(n)] * weight[n] * dFL(n, c)/dlogit  (scales: DEVICE, L)
+ *   lsn_level_sums: sums[l] = sum over level l's rows of rows[r]   (the per-row cross-IOU terms)
+ *   lsn_level_expand: out_rows[r] = g[level(r)]                    (its gradient)
+ * Fixed summation orders: the same bits on every run. */
+int lsn_sigmoid_focal_loss_level_sums(const float *logits, const int64_t *targets, const float *weight, float *loss_sums,
+                                      int B, int N_all, int C, int L, const int *level_starts, float gamma, float alpha,
+                                      lsn_stream_t stream);
+int lsn_sigmoid_focal_loss_backward_levels(const float *logits, const int64_t *targets, const float *weight, const float *scales,
+                                           float *d_logits, int B, int N_all, int C, int L, const int *level_starts,
+                                           float gamma, float alpha, lsn_stream_t stream);
+int lsn_level_sums(const float *rows, float *sums, int B, int N_all, int L, const int *level_starts, lsn_stream_t stream);
+int lsn_level_expand(const float *g, float *out_rows, int B, int N_all, int L, const int *level_starts, lsn_stream_t stream);
+
 /* ---- gradient clipping + SGD: mmcv/runner/hooks/optimizer.py:8-28 ----------------------------- [fused]
  * clip_grad_norm_(parameters, max_norm, norm_type = 2) followed by torch.optim.SGD.step() (momentum, weight decay; no
  * dampening, no Nesterov) over all parameter tensors in three launches instead of ATen's dozen multi-tensor ones.

@@ -91,7 +91,8 @@ EXPORTS = [
     'lsn_pyramid_deform_conv_forward', 'lsn_pyramid_deform_conv_backward_input',
     'lsn_pyramid_deform_conv_backward_parameters',
     'lsn_sigmoid_focal_loss_forward', 'lsn_sigmoid_focal_loss_backward', 'lsn_sigmoid_focal_loss_sum',
-    'lsn_sigmoid_focal_loss_backward_weighted',
+    'lsn_sigmoid_focal_loss_backward_weighted', 'lsn_sigmoid_focal_loss_level_sums', 'lsn_sigmoid_focal_loss_backward_levels',
+    'lsn_level_sums', 'lsn_level_expand',
     'lsn_nms_workspace_bytes', 'lsn_nms', 'lsn_topk_columns', 'lsn_offset_chain_forward', 'lsn_offset_chain_backward', 'lsn_clip_sgd_workspace_bytes', 'lsn_clip_sgd_step', 'lsn_selftest_mfma', 'lsn_debug_phase_clocks',
     'lsn_prof_enable', 'lsn_prof_read', 'lsn_scratch_stats', 'lsn_wgrad_defer', 'lsn_wgrad_flush',
     'lsn_group_norm_workspace_bytes', 'lsn_group_norm_forward', 'lsn_group_norm_backward',

@@ -120,6 +120,107 @@ __global__ void focal_bwd_w_kernel(const float *__restrict__ logits, const int64
     }
 }
 
+// ---- per-LEVEL sums over LSHead's concatenated pixel rows ----
+// The head keeps the levels of an image back to back: row r = b * nall + i, level l owns i in [start[l], start[l + 1]).  The
+// reference sums every loss per level (lsnet_head.py:1021-1270 loss_single through multi_apply): per level a slice copy, a sum
+// kernel, a division and a multiplication, forward and backward -- ~70 launches of a few microseconds per step, each with its
+// dispatch latency on the chain between forward and backward.  Here all levels are one launch and the sums come back as (L,).
+constexpr int LV_MAX = 8;       // levels
+constexpr int LV_RANGES = 64;   // (image, level) ranges of one launch
+struct LevelTab {
+    int B, nall, L;
+    int start[LV_MAX + 1];      // first row of level l inside an image
+    int blk0[LV_RANGES + 1];    // focal: first block of range k = b * L + l
+};
+__device__ __forceinline__ int level_of(const LevelTab &t, int i)
+{
+    int l = 0;
+    while (l + 1 < t.L && i >= t.start[l + 1]) ++l;
+    return l;
+}
+
+// sums[l] = sum over the rows of level l (all images) of w[n] * sum_c FL(n, c).  A block works inside ONE (image, level) range,
+// leaves its sum in part[] and takes a ticket; the last block adds, per level, the partials of that level's blocks in block order.
+__global__ void focal_level_sums_kernel(const float *__restrict__ logits, const int64_t *__restrict__ targets,
+                                        const float *__restrict__ weight, float *sums, int C, float gamma, float alpha,
+                                        float *part, unsigned *ticket, const LevelTab t)
+{
+    int k = 0;
+    while ((int)blockIdx.x >= t.blk0[k + 1]) ++k;
+    const int b = k / t.L, l = k - b * t.L;
+    const int r0 = b * t.nall + t.start[l];
+    const int nb = t.blk0[k + 1] - t.blk0[k], bi = blockIdx.x - t.blk0[k];
+    const size_t total = (size_t)(t.start[l + 1] - t.start[l]) * C, base = (size_t)r0 * C;
+    float s = 0.f;
+    for (size_t i = bi * (size_t)256 + threadIdx.x; i < total; i += (size_t)nb * 256) {
+        const int n = (int)(i / C), d = (int)(i - (size_t)n * C);
+        const int tg = (int)targets[r0 + n];
+        const float w = weight ? weight[r0 + n] : 1.f;
+        s += w * fl_forward_one(logits[base + i], tg == d, (tg >= 0) & (tg != d), gamma, alpha);
+    }
+    s = block_sum_256(s);
+    __shared__ int last;
+    if (threadIdx.x == 0) {
+        store_agent(part + blockIdx.x, s);
+        wait_stores();
+        last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    for (int lv = 0; lv < t.L; ++lv) {
+        float v = 0.f;
+        for (int img = 0; img < t.B; ++img) {
+            const int kk = img * t.L + lv;
+            for (int blk = t.blk0[kk] + threadIdx.x; blk < t.blk0[kk + 1]; blk += 256) v += load_agent(part + blk);
+        }
+        __syncthreads();   // (block_sum_256 reuses its LDS words)
+        const float tot = block_sum_256(v);
+        if (threadIdx.x == 0) sums[lv] = tot;
+    }
+    if (threadIdx.x == 0) *ticket = 0;
+}
+
+// d_logits = scale[level(n)] * w[n] * dFL/dx
+__global__ void focal_bwd_w_levels_kernel(const float *__restrict__ logits, const int64_t *__restrict__ targets,
+                                          const float *__restrict__ weight, const float *__restrict__ scale,
+                                          float *__restrict__ d_logits, int N, int C, float gamma, float alpha, const LevelTab t)
+{
+    const size_t total = (size_t)N * C;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i / C), d = (int)(i - (size_t)n * C);
+        const int tg = (int)targets[n];
+        const float sc = scale[level_of(t, n % t.nall)] * (weight ? weight[n] : 1.f);
+        d_logits[i] = sc * fl_backward_one(logits[i], tg == d, (tg >= 0) & (tg != d), gamma, alpha);
+    }
+}
+
+// sums[l] = sum of rows[b * nall + i] over the images and the rows i of level l: one block per level, a fixed order
+__global__ __launch_bounds__(1024) void level_sums_kernel(const float *__restrict__ rows, float *sums, const LevelTab t)
+{
+    const int l = blockIdx.x;
+    float v = 0.f;
+    for (int b = 0; b < t.B; ++b)
+        for (int i = t.start[l] + threadIdx.x; i < t.start[l + 1]; i += 1024) v += rows[(size_t)b * t.nall + i];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    __shared__ float part[16];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float tot = 0.f;
+        for (int w = 0; w < 16; ++w) tot += part[w];
+        sums[l] = tot;
+    }
+}
+
+// out[r] = g[level(r)]: the gradient of level_sums
+__global__ void level_expand_kernel(const float *__restrict__ g, float *__restrict__ out, int N, const LevelTab t)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < N) out[r] = g[level_of(t, r % t.nall)];
+}
+
 static int ew_grid(size_t total) { size_t g = (total + 255) / 256; return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g)); }
 
 // ---------------------------------------------------------------------------------------------
@@ -499,15 +600,9 @@ int lsn_sigmoid_focal_loss_backward(const float *logits, const int64_t *targets,
     return 0;
 }
 
-int lsn_sigmoid_focal_loss_sum(const float *logits, const int64_t *targets, const float *weight, float *loss_sum,
-                               int N, int C, float gamma, float alpha, lsn_stream_t stream)
+// library-owned scratch of the two-stage focal sums (one stream at a time, like the other scratch buffers of the library)
+static int focal_scratch(float **part_out, unsigned **ticket_out)
 {
-    LSN_CHECK(N >= 0 && C > 0, "invalid focal loss shape (%d, %d)", N, C);
-    if (N == 0) {
-        LSN_HIP(hipMemsetAsync(loss_sum, 0, sizeof(float), stream));
-        return 0;
-    }
-    // library-owned scratch of the two-stage sum (one stream at a time, like the other scratch buffers of the library)
     static float *part = nullptr;
     static unsigned *ticket = nullptr;
     if (!part) {
@@ -516,6 +611,31 @@ int lsn_sigmoid_focal_loss_sum(const float *logits, const int64_t *targets, cons
         ticket = reinterpret_cast<unsigned *>(part + 1024);
         LSN_HIP(hipMemset(ticket, 0, sizeof(unsigned)));
     }
+    *part_out = part, *ticket_out = ticket;
+    return 0;
+}
+
+static int level_tab(lsn::LevelTab &t, int B, int N_all, int L, const int *level_starts)
+{
+    LSN_CHECK(B >= 1 && L >= 1 && L <= lsn::LV_MAX && B * L <= lsn::LV_RANGES && level_starts, "level sums: %d images x %d levels", B, L);
+    LSN_CHECK(level_starts[0] == 0 && level_starts[L] == N_all, "level sums: the levels must cover rows 0 .. %d", N_all);
+    t.B = B, t.nall = N_all, t.L = L;
+    for (int l = 0; l <= L; ++l) t.start[l] = level_starts[l];
+    for (int l = 0; l < L; ++l) LSN_CHECK(t.start[l + 1] > t.start[l], "level sums: level %d is empty", l);
+    return 0;
+}
+
+int lsn_sigmoid_focal_loss_sum(const float *logits, const int64_t *targets, const float *weight, float *loss_sum,
+                               int N, int C, float gamma, float alpha, lsn_stream_t stream)
+{
+    LSN_CHECK(N >= 0 && C > 0, "invalid focal loss shape (%d, %d)", N, C);
+    if (N == 0) {
+        LSN_HIP(hipMemsetAsync(loss_sum, 0, sizeof(float), stream));
+        return 0;
+    }
+    float *part = nullptr;
+    unsigned *ticket = nullptr;
+    if (int rc = focal_scratch(&part, &ticket)) return rc;
     int grid = ew_grid((size_t)N * C);
     if (grid > 1024) grid = 1024;
     hipLaunchKernelGGL(focal_sum_kernel, dim3(grid), dim3(256), 0, stream, logits, targets, weight, loss_sum, N, C, gamma,
@@ -532,6 +652,72 @@ int lsn_sigmoid_focal_loss_backward_weighted(const float *logits, const int64_t 
     if (N == 0) return 0;
     hipLaunchKernelGGL(focal_bwd_w_kernel, dim3(ew_grid((size_t)N * C)), dim3(256), 0, stream, logits, targets,
                        weight, scale, d_logits, N, C, gamma, alpha);
+    LSN_HIP(hipGetLastError());
+    return 0;
+}
+
+int lsn_sigmoid_focal_loss_level_sums(const float *logits, const int64_t *targets, const float *weight, float *loss_sums,
+                                      int B, int N_all, int C, int L, const int *level_starts, float gamma, float alpha,
+                                      lsn_stream_t stream)
+{
+    using namespace lsn;
+    LSN_CHECK(C > 0 && logits && targets && loss_sums, "invalid focal loss arguments");
+    LevelTab t;
+    if (int rc = level_tab(t, B, N_all, L, level_starts)) return rc;
+    float *part = nullptr;
+    unsigned *ticket = nullptr;
+    if (int rc = focal_scratch(&part, &ticket)) return rc;
+    // ~16 elements per thread; coarser until the launch fits the 1024 partial sums
+    for (long long per = 4096;; per *= 2) {
+        int nb = 0;
+        for (int k = 0; k < B * L; ++k) {
+            const long long el = (long long)(t.start[k % L + 1] - t.start[k % L]) * C;
+            t.blk0[k] = nb;
+            nb += (int)((el + per - 1) / per);
+        }
+        t.blk0[B * L] = nb;
+        if (nb <= 1024) break;
+    }
+    hipLaunchKernelGGL(focal_level_sums_kernel, dim3(t.blk0[B * L]), dim3(256), 0, stream, logits, targets, weight, loss_sums, C,
+                       gamma, alpha, part, ticket, t);
+    LSN_HIP(hipGetLastError());
+    return 0;
+}
+
+int lsn_sigmoid_focal_loss_backward_levels(const float *logits, const int64_t *targets, const float *weight, const float *scales,
+                                           float *d_logits, int B, int N_all, int C, int L, const int *level_starts,
+                                           float gamma, float alpha, lsn_stream_t stream)
+{
+    using namespace lsn;
+    LSN_CHECK(C > 0 && logits && targets && scales && d_logits, "invalid focal loss arguments");
+    LevelTab t;
+    if (int rc = level_tab(t, B, N_all, L, level_starts)) return rc;
+    const int N = B * N_all;
+    hipLaunchKernelGGL(focal_bwd_w_levels_kernel, dim3(ew_grid((size_t)N * C)), dim3(256), 0, stream, logits, targets, weight,
+                       scales, d_logits, N, C, gamma, alpha, t);
+    LSN_HIP(hipGetLastError());
+    return 0;
+}
+
+int lsn_level_sums(const float *rows, float *sums, int B, int N_all, int L, const int *level_starts, lsn_stream_t stream)
+{
+    using namespace lsn;
+    LSN_CHECK(rows && sums, "level sums: NULL argument");
+    LevelTab t;
+    if (int rc = level_tab(t, B, N_all, L, level_starts)) return rc;
+    hipLaunchKernelGGL(level_sums_kernel, dim3(L), dim3(1024), 0, stream, rows, sums, t);
+    LSN_HIP(hipGetLastError());
+    return 0;
+}
+
+int lsn_level_expand(const float *g, float *out_rows, int B, int N_all, int L, const int *level_starts, lsn_stream_t stream)
+{
+    using namespace lsn;
+    LSN_CHECK(g && out_rows, "level sums: NULL argument");
+    LevelTab t;
+    if (int rc = level_tab(t, B, N_all, L, level_starts)) return rc;
+    const int N = B * N_all;
+    hipLaunchKernelGGL(level_expand_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, g, out_rows, N, t);
     LSN_HIP(hipGetLastError());
     return 0;
 }

@@ -31,8 +31,11 @@ from ...core import PointGenerator, build_assigner, build_sampler, multiclass_nm
 from ...ops import ModulatedDeformConvPack, PyramidDeformConv
 from ...ops.dcn import offset_scale_chain
 from ...ops import cross_iou as fused_ciou
+from ...ops.focal import level_rows_ok, level_sums
 from ..builder import HEADS, build_loss
 
+# LSNET_FUSED_LEVEL_SUMS=0: every loss term level by level (the host path's form) on the device as well (A/B switch)
+FUSED_LEVEL_SUMS = os.environ.get('LSNET_FUSED_LEVEL_SUMS', '1') != '0'
 # LSNET_SIDE_STREAM_TARGETS=0: the init-stage targets on the main stream, between the head's forward and the loss (A/B switch)
 SIDE_STREAM_TARGETS = os.environ.get('LSNET_SIDE_STREAM_TARGETS', '1') != '0'
 
@@ -302,8 +305,23 @@ class LSHead(nn.Module):
     def _split_px(x, shapes):
         """Inverse of `_cat_px`: per-level (B, C, H_l, W_l) VIEWS of a (B, C, N_all, 1) tensor."""
         if x.requires_grad and torch.is_grad_enabled():
-            return list(_SplitPxFn.apply(x, tuple(shapes)))
-        return _split_px_views(x, shapes)
+            outs = list(_SplitPxFn.apply(x, tuple(shapes)))
+        else:
+            outs = _split_px_views(x, shapes)
+        for i, o in enumerate(outs):
+            o._px_cat = (x, i)     # `_px_base`: the loss reads the concatenated tensor itself instead of gluing the views together
+        return outs
+
+    @staticmethod
+    def _px_base(maps):
+        """The (B, C, N_all, 1) tensor the per-level maps are `_split_px` views of, as (B, N_all, C) rows -- or None."""
+        tags = [getattr(m, '_px_cat', None) for m in maps]
+        if any(t is None for t in tags) or any(t[0] is not tags[0][0] or t[1] != i for i, t in enumerate(tags)):
+            return None
+        x = tags[0][0]
+        if sum(m.shape[2] * m.shape[3] for m in maps) != x.shape[2] or x.shape[3] != 1:
+            return None
+        return x.permute(0, 2, 3, 1).reshape(x.shape[0], x.shape[2], x.shape[1])
 
     def forward(self, feats, after_init=None):
         """feats: tuple of 5 FPN maps.  Returns the reference's 7-tuple of per-level lists
@@ -553,12 +571,28 @@ class LSHead(nn.Module):
         -- and only the final sums are taken per level, so the returned lists hold the same per-level values."""
         B = cls_scores[0].shape[0]
         losses = {'cls': []}
-        labels = torch.split(tg_refine['labels'], num_level, dim=1)
-        label_w = torch.split(tg_refine['label_weights'], num_level, dim=1)
-        for lvl, cs in enumerate(cls_scores):
-            cs = cs.permute(0, 2, 3, 1).reshape(-1, self.cls_out_channels)
-            losses['cls'].append(self.loss_cls(cs, labels[lvl].reshape(-1), label_w[lvl].reshape(-1),
-                                               avg_factor=n_refine))
+        # On the device every term's levels are ONE launch (ops/focal.py: per-level focal sums, per-level row sums) over the head's
+        # concatenated tensors, which `_split_px` left on the per-level views; elsewhere level by level as the reference does.
+        by_level = FUSED_LEVEL_SUMS and level_rows_ok(cls_scores[0], B, num_level)
+        cls_cat = self._px_base(cls_scores) if by_level and hasattr(self.loss_cls, 'forward_levels') \
+            and getattr(self.loss_cls, 'reduction', None) == 'mean' else None
+        if cls_cat is not None and cls_cat.is_contiguous() and tg_refine['labels'].is_contiguous() \
+                and tg_refine['label_weights'].is_contiguous():
+            lv_cls = self.loss_cls.forward_levels(cls_cat.reshape(-1, self.cls_out_channels), tg_refine['labels'].reshape(-1),
+                                                  tg_refine['label_weights'].reshape(-1), B, num_level, avg_factor=n_refine)
+            losses['cls'] = list(lv_cls.unbind(0))
+        else:
+            labels = torch.split(tg_refine['labels'], num_level, dim=1)
+            label_w = torch.split(tg_refine['label_weights'], num_level, dim=1)
+            for lvl, cs in enumerate(cls_scores):
+                cs = cs.permute(0, 2, 3, 1).reshape(-1, self.cls_out_channels)
+                losses['cls'].append(self.loss_cls(cs, labels[lvl].reshape(-1), label_w[lvl].reshape(-1),
+                                                   avg_factor=n_refine))
+
+        def per_level_terms(rows, n):
+            if by_level and rows.dtype == torch.float32:
+                return list((level_sums(rows.reshape(-1), B, num_level) / n).unbind(0))
+            return [r.sum() / n for r in torch.split(rows.reshape(B, -1), num_level, dim=1)]
         stride = self._level_rows(num_level, points[0]).repeat(B).unsqueeze(1)            # (B*N_all, 1)
         norm = self.point_base_scale * stride
         anchor = torch.cat(points)[None].expand(B, -1, -1).reshape(-1, 3)
@@ -577,7 +611,9 @@ class LSHead(nn.Module):
                     kw = dict(bbox_gt=None, vs=tg['keypoints_vs'].reshape(-1, self.num_vectors))
                 width = gt_pts.shape[1] * 2
                 weights = bw[:, :1].expand(-1, width)
-                pred = torch.cat([p.permute(0, 2, 3, 1).reshape(B, -1, width) for p in plist], dim=1)
+                pred = self._px_base(plist) if by_level else None
+                if pred is None or pred.shape[2] != width:
+                    pred = torch.cat([p.permute(0, 2, 3, 1).reshape(B, -1, width) for p in plist], dim=1)
                 loss_fn = getattr(self, f'loss_{b}_{stage}')
                 if (b == 'bbox' and width == 20 and fused_ciou.enabled() and pred.is_cuda and pred.dtype == torch.float32
                         and getattr(loss_fn, 'loss_type', None) == 'bbox'):
@@ -586,15 +622,13 @@ class LSHead(nn.Module):
                     rows = loss_fn.loss_weight * fused_ciou.cross_iou_bbox_stage_rows(
                         pred.reshape(-1, width), gt_pts, anchor, bbox_gt, bw[:, 0], self.point_base_scale, loss_fn.alpha,
                         loss_fn.eps)
-                    per_level = torch.split(rows.reshape(B, -1), num_level, dim=1)
-                    losses[f'{b}_{stage}'] = [r.sum() / n for r in per_level]
+                    losses[f'{b}_{stage}'] = per_level_terms(rows, n)
                     continue
                 pred = pred.reshape(-1, width) * stride
                 gt_reg, active = self._gt_reg(gt_pts, anchor, weights)
                 rows = loss_fn(pred / norm, gt_reg / norm, weights, reduction_override='none',
                                anchor_pts=anchor[:, :-1] / norm, pos_inds=active, **kw)   # weighted, per row
-                per_level = torch.split(rows.reshape(B, -1), num_level, dim=1)
-                losses[f'{b}_{stage}'] = [r.sum() / n for r in per_level]
+                losses[f'{b}_{stage}'] = per_level_terms(rows, n)
         return losses
 
     def _side_stream(self, device):

@@ -7,6 +7,7 @@ import torch.nn as nn
 
 from ...ops import sigmoid_focal_loss as _sigmoid_focal_loss
 from ...ops import sigmoid_focal_loss_sum
+from ...ops.focal import sigmoid_focal_loss_level_sums
 from ..builder import LOSSES
 from .utils import weight_reduce_loss
 
@@ -41,3 +42,10 @@ class FocalLoss(nn.Module):
         reduction = reduction_override if reduction_override else self.reduction
         return self.loss_weight * sigmoid_focal_loss(pred, target, weight, gamma=self.gamma, alpha=self.alpha,
                                                      reduction=reduction, avg_factor=avg_factor)
+
+    def forward_levels(self, pred, target, weight, B, num_level, avg_factor):
+        """(L,): what `forward(pred_l, target_l, weight_l, avg_factor)` returns for the rows of every level l of LSHead's
+        concatenated tensor (B images x N_all rows, levels back to back per image) -- one launch for all levels."""
+        assert self.reduction == 'mean' and avg_factor is not None
+        sums = sigmoid_focal_loss_level_sums(pred, target, weight, B, num_level, self.gamma, self.alpha)
+        return self.loss_weight * (sums / avg_factor)

@@ -361,6 +361,58 @@ class HipBackend:
             ctypes.c_float(gamma), ctypes.c_float(alpha), _stream()))
         return out
 
+    # ------------------------------------------------------------------ per-level loss sums (LSHead's concatenated rows)
+    @staticmethod
+    def _level_starts(num_level):
+        starts = [0]
+        for n in num_level:
+            starts.append(starts[-1] + int(n))
+        return (ctypes.c_int * len(starts))(*starts), starts[-1]
+
+    def focal_level_sums(self, logits, targets, weight, B, num_level, gamma, alpha):
+        """(L,) per-level sums of weight * focal loss over the (B * N_all, C) rows, levels back to back per image."""
+        lib = _lib.load()
+        assert logits.is_contiguous() and targets.is_contiguous() and (weight is None or weight.is_contiguous())
+        _f32(logits, 'logits')
+        if targets.dtype != torch.int64:
+            raise TypeError('targets must be int64')
+        starts, nall = self._level_starts(num_level)
+        N, C = logits.shape
+        assert N == B * nall and targets.numel() == N
+        out = torch.empty(len(num_level), device=logits.device, dtype=torch.float32)
+        _lib.check(lib.lsn_sigmoid_focal_loss_level_sums(_ptr(logits), _ptr(targets), _ptr(weight), _ptr(out), B, nall, C,
+                                                         len(num_level), starts, ctypes.c_float(gamma), ctypes.c_float(alpha),
+                                                         _stream()))
+        return out
+
+    def focal_backward_levels(self, logits, targets, weight, scales, B, num_level, gamma, alpha):
+        lib = _lib.load()
+        starts, nall = self._level_starts(num_level)
+        N, C = logits.shape
+        out = torch.empty_like(logits)
+        scales = scales.to(torch.float32).contiguous()
+        assert scales.numel() == len(num_level)
+        _lib.check(lib.lsn_sigmoid_focal_loss_backward_levels(_ptr(logits), _ptr(targets), _ptr(weight), _ptr(scales), _ptr(out),
+                                                              B, nall, C, len(num_level), starts, ctypes.c_float(gamma),
+                                                              ctypes.c_float(alpha), _stream()))
+        return out
+
+    def level_sums(self, rows, B, num_level):
+        lib = _lib.load()
+        starts, nall = self._level_starts(num_level)
+        assert rows.is_contiguous() and rows.numel() == B * nall and rows.dtype == torch.float32
+        out = torch.empty(len(num_level), device=rows.device, dtype=torch.float32)
+        _lib.check(lib.lsn_level_sums(_ptr(rows), _ptr(out), B, nall, len(num_level), starts, _stream()))
+        return out
+
+    def level_expand(self, g, B, num_level):
+        lib = _lib.load()
+        starts, nall = self._level_starts(num_level)
+        g = g.to(torch.float32).contiguous()
+        out = torch.empty(B * nall, device=g.device, dtype=torch.float32)
+        _lib.check(lib.lsn_level_expand(_ptr(g), _ptr(out), B, nall, len(num_level), starts, _stream()))
+        return out
+
     # ------------------------------------------------------------------ NMS
     def nms(self, dets, iou_thr):
         """dets (n,5) float32 on the device -> keep indices (int64), descending score."""

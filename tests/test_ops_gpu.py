@@ -296,6 +296,52 @@ def test_focal_loss_parity():
                               rtol=1e-4, atol=1e-6)
 
 
+def test_per_level_loss_sums_match_the_level_by_level_form():
+    """lsn_sigmoid_focal_loss_level_sums / lsn_level_sums over LSHead's concatenated rows (B images x N_all rows, levels back to
+    back per image) against what the reference's per-level calls compute (focal_loss.py:74-116 per level slice, then .sum()):
+    values to fp32 summation order, gradients element-wise, the same bits on every run."""
+    from lsnet_amd import ops
+    from lsnet_amd.ops.focal import level_sums, sigmoid_focal_loss_level_sums
+    dev = _dev()
+    torch.manual_seed(12)
+    for B, num_level, C in [(2, [1200, 300, 80, 20, 6], 80), (3, [7, 5], 11), (1, [4000], 80), (8, [33, 17, 9, 5, 3, 2, 1, 1], 4)]:
+        nall = sum(num_level)
+        lg = (torch.randn(B * nall, C) * 4).to(dev).requires_grad_()
+        tg = torch.randint(0, C + 1, (B * nall,), device=dev)
+        w = torch.rand(B * nall, device=dev)
+        up = torch.randn(len(num_level), device=dev)
+        got = sigmoid_focal_loss_level_sums(lg, tg, w, B, num_level, 2.0, 0.25)
+        assert got.shape == (len(num_level),)
+        ggot, = torch.autograd.grad(got, lg, up)
+        again = sigmoid_focal_loss_level_sums(lg, tg, w, B, num_level, 2.0, 0.25)
+        assert torch.equal(got, again)
+        x2 = lg.detach().clone().requires_grad_()
+        ref, o = [], 0
+        for n in num_level:
+            sl = torch.cat([torch.arange(b * nall + o, b * nall + o + n, device=dev) for b in range(B)])
+            ref.append(ops.sigmoid_focal_loss_sum(x2[sl], tg[sl], w[sl], 2.0, 0.25))
+            o += n
+        ref = torch.stack(ref)
+        gref, = torch.autograd.grad(ref, x2, up)
+        assert torch.allclose(got, ref, rtol=2e-6, atol=1e-6), (got, ref)
+        assert torch.allclose(ggot, gref, rtol=1e-6, atol=1e-9)
+        # no weights
+        g0 = sigmoid_focal_loss_level_sums(lg, tg, None, B, num_level, 2.0, 0.25)
+        r0 = ops.sigmoid_focal_loss(lg.detach(), tg, 2.0, 0.25).sum(1).reshape(B, nall)
+        r0 = torch.stack([c.sum() for c in torch.split(r0, num_level, dim=1)])
+        assert torch.allclose(g0, r0, rtol=2e-6, atol=1e-6)
+
+        rows = torch.randn(B * nall, device=dev).requires_grad_()
+        s = level_sums(rows, B, num_level)
+        sref = torch.stack([c.double().sum() for c in torch.split(rows.detach().reshape(B, nall), num_level, dim=1)])
+        assert torch.allclose(s.double(), sref, rtol=1e-6, atol=1e-5)
+        gr, = torch.autograd.grad(s, rows, up)
+        exp = torch.cat([up[l].expand(n) for l, n in enumerate(num_level)]).repeat(B)
+        assert torch.equal(gr, exp)
+    with pytest.raises(RuntimeError):
+        level_sums(torch.zeros(10, device=dev), 1, [10, 0])       # an empty level
+
+
 def test_topk_columns_matches_torch():
     """lsn_topk_columns against torch.topk on the CPU (the reference's call, centroid_assigner.py:74 and
     atss_assigner.py:103-111): same values in the same order, same rows; equal values come out by ascending row."""

@@ -154,3 +154,41 @@ def test_training_step_is_bit_reproducible(task, backbone):
     assert len(g1) > 100
     diff = [n for n in g1 if not torch.equal(g1[n], g2[n])]
     assert not diff, f'{len(diff)} of {len(g1)} parameter gradients differ between two identical steps, e.g. {diff[:4]}'
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('task', ['bbox', 'segm'])
+def test_fused_level_sums_and_side_stream_targets_leave_the_step_unchanged(task, monkeypatch):
+    """Round 5: every loss term's levels in one launch over the head's concatenated tensors (LSNET_FUSED_LEVEL_SUMS) and the
+    target assignment on a second stream (LSNET_SIDE_STREAM_TARGETS) against the level-by-level, single-stream form: the same
+    per-level loss terms (summation order only) and the same parameter gradients; identical targets, hence no tolerance for
+    anything the assignment decides."""
+    from lsnet_amd.models.dense_heads import ls_head
+    dev = torch.device('cuda:0')
+
+    def run(fused, side):
+        monkeypatch.setattr(ls_head, 'FUSED_LEVEL_SUMS', fused)
+        monkeypatch.setattr(ls_head, 'SIDE_STREAM_TARGETS', side)
+        torch.manual_seed(3)
+        model, _ = build_lsnet(task, 'r50')
+        model = model.to(dev).to(memory_format=torch.channels_last).train()
+        data = synthetic_batch(task, 2, 384, 480, boxes_per_img=5, num_classes=80, seed=11, device='cuda:0', channels_last=True)
+        losses = model(**data)
+        loss = sum(v if torch.is_tensor(v) else sum(v) for k, v in losses.items() if 'loss' in k)
+        loss.backward()
+        torch.cuda.synchronize()
+        terms = {k: torch.stack([t.detach().reshape(()) for t in (v if isinstance(v, list) else [v])]) for k, v in losses.items()}
+        return terms, {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    t0, g0 = run(False, False)
+    t_side, g_side = run(False, True)
+    for k in t0:
+        assert torch.equal(t0[k], t_side[k]), k                  # the stream does not change a bit
+    assert all(torch.equal(g0[n], g_side[n]) for n in g0)
+    t1, g1 = run(True, True)
+    for k in t0:
+        assert t0[k].shape == t1[k].shape == (5,)
+        assert torch.allclose(t0[k], t1[k], rtol=1e-5, atol=1e-7), (k, t0[k], t1[k])
+    worst = max(float((g0[n] - g1[n]).abs().max() / g0[n].abs().max().clamp(min=1e-12)) for n in g0)
+    print(f'fused level sums: worst parameter-gradient deviation {worst:.2e} of the tensor range')
+    assert worst < 1e-4
