@@ -90,6 +90,15 @@ class _SplitPxFn(torch.autograd.Function):
         return flat.unsqueeze(2).permute(0, 3, 1, 2), None              # (B, C, N_all, 1), channels-last memory
 
 
+class LevelTerms(list):
+    """The per-level values of one loss term as the reference returns them (a list of 0-dim tensors) that also remembers the
+    (L,) tensor they are views of: `_parse_losses` (detectors/base.py) then adds the levels up with one launch."""
+
+    def __init__(self, base):
+        super().__init__(base.unbind(0))
+        self.base = base
+
+
 def _signed_pairs(t, dim):
     """Collapse (neg, pos) pairs along `dim` (size 2): pos if pos > neg else -neg.  Index 0 wins ties
     and is negated, which is what torch.max(dim) + `inds == 0` gives (lsnet_head.py:323-325)."""
@@ -580,7 +589,7 @@ class LSHead(nn.Module):
                 and tg_refine['label_weights'].is_contiguous():
             lv_cls = self.loss_cls.forward_levels(cls_cat.reshape(-1, self.cls_out_channels), tg_refine['labels'].reshape(-1),
                                                   tg_refine['label_weights'].reshape(-1), B, num_level, avg_factor=n_refine)
-            losses['cls'] = list(lv_cls.unbind(0))
+            losses['cls'] = LevelTerms(lv_cls)
         else:
             labels = torch.split(tg_refine['labels'], num_level, dim=1)
             label_w = torch.split(tg_refine['label_weights'], num_level, dim=1)
@@ -591,7 +600,7 @@ class LSHead(nn.Module):
 
         def per_level_terms(rows, n):
             if by_level and rows.dtype == torch.float32:
-                return list((level_sums(rows.reshape(-1), B, num_level) / n).unbind(0))
+                return LevelTerms(level_sums(rows.reshape(-1), B, num_level) / n)
             return [r.sum() / n for r in torch.split(rows.reshape(B, -1), num_level, dim=1)]
         stride = self._level_rows(num_level, points[0]).repeat(B).unsqueeze(1)            # (B*N_all, 1)
         norm = self.point_base_scale * stride

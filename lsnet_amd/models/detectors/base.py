@@ -85,7 +85,8 @@ class BaseDetector(nn.Module):
             if isinstance(value, torch.Tensor):
                 log_vars[name] = mean(value)
             elif isinstance(value, list):
-                log_vars[name] = total(mean(v) for v in value)
+                base = getattr(value, 'base', None)     # ls_head.LevelTerms: the levels of the term are one (L,) tensor
+                log_vars[name] = base.sum() if base is not None and len(value) > 1 else total(mean(v) for v in value)
             else:
                 raise TypeError(f'{name} is not a tensor or list of tensors')
         loss = total(v for k, v in log_vars.items() if 'loss' in k)

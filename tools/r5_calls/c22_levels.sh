@@ -4,7 +4,7 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 timeout 900 python -m pytest tests/test_ops_gpu.py tests/test_variants_gpu.py tests/test_golden_gpu.py tests/test_graph_gpu.py -q -m gpu -x -s \
-  -k "per_level or fused_level or focal or head_forward or head_at_256 or bit_reproducible or iteration0 or graph or curve" > gpurun_out/r5_c22_tests.log 2>&1; echo "tests rc $?"
+  -k "per_level or fused_level or focal or runner or head_forward or head_at_256 or bit_reproducible or iteration0 or graph or curve" > gpurun_out/r5_c22_tests.log 2>&1; echo "tests rc $?"
 grep -E "passed|failed|worst parameter|Error" gpurun_out/r5_c22_tests.log | tail -8
 for sw in 0 1 0 1; do
   echo "== LSNET_FUSED_LEVEL_SUMS=$sw"
