@@ -11,6 +11,7 @@ in every math mode.  Contiguous (NCHW) inputs are re-laid channels-last and LSN_
 kernels: no vendor convolution is reached from a CUDA fp32 tensor.  Other group shapes, dtypes and CPU tensors go to ATen's
 convolution, which is a different operator, not a fallback of the HIP path."""
 import ctypes
+import os
 import weakref
 
 import torch
@@ -56,14 +57,34 @@ def _pad_channels(t, c_to):
 
 
 _images = {}    # (id(weight), kind, stride, pad, dil, math mode, id(bn) or 0) -> [weakref, version, data_ptr, image,
-#                  optimizer epoch, weakref(bn) or None, shift tensor or None, bn versions]
+#                  optimizer epoch, weakref(bn) or None, shift tensor or None, bn versions,
+#                  (version, data_ptr, bn versions) at the last optimizer step or None]
 _opt_epoch = [0]
+
+
+# LSNET_SIDE_STREAM_IMAGES=0: the images are rebuilt on the stream that asks for them (A/B switch)
+SIDE_STREAM_IMAGES = os.environ.get('LSNET_SIDE_STREAM_IMAGES', '1') != '0'
+_step_done = {}      # device index -> event recorded right behind the last optimizer step (on the stream that ran it)
+_image_streams = {}  # device index -> the stream the stale images are rebuilt on
 
 
 def _after_optimizer_step(*_):
     """Global optimizer post-step hook: every image of a trainable weight is stale now.  (The tensors' version counters
     are not enough: torch's FUSED optimizers update parameters without bumping them.)"""
     _opt_epoch[0] += 1
+    if SIDE_STREAM_IMAGES and torch.cuda.is_available() and torch.cuda.is_initialized() \
+            and not torch.cuda.is_current_stream_capturing():
+        dev = torch.cuda.current_device()
+        ev = _step_done.get(dev)
+        if ev is None:
+            ev = _step_done[dev] = torch.cuda.Event()
+        ev.record()
+        # what every weight looks like NOW: an image may be rebuilt behind this event only if nothing has written its weight since
+        for ent in _images.values():
+            w = ent[0]()
+            if w is not None:
+                bn = ent[5]() if ent[5] is not None else None
+                ent[8] = (w._version, w.data_ptr(), _bn_versions(bn) if bn is not None else None)
 
 
 def parameters_updated():
@@ -86,6 +107,7 @@ def invalidate_weight_images():
     into the graph (captured with fresh images, every replay would run forward and data gradient on the capture-time
     weights while the optimizer keeps moving them)."""
     _opt_epoch[0] += 1
+    _step_done.clear()      # (the writes this call stands for came after the optimizer step: no rebuild behind its event)
     for ent in _images.values():
         ent[1] = -1
 
@@ -146,7 +168,25 @@ def _refresh_stale(mode):
         arr = (_lib.ConvWprep * len(items))()
         for it, (key, ent, w) in zip(arr, items):
             _fill_item(it, key, ent, w)
-        _lib.check(lib.lsn_conv2d_prepare_weights_multi(len(items), arr, _stream()))
+        dev = items[0][2].device.index
+        ev = _step_done.get(dev) if SIDE_STREAM_IMAGES and len(items) > 1 else None
+        if ev is not None and not all(w.device.index == dev and ent[8] is not None and ent[8] == (
+                w._version, w.data_ptr(), _bn_versions(ent[5]()) if ent[5] is not None else None) for _, ent, w in items):
+            ev = None           # something wrote a weight after the optimizer step (or the image is new): rebuild in stream order
+        if ev is not None:
+            # The rebuild (one bandwidth-bound launch, ~0.2 ms for LSNet R-50) needs the optimizer step and nothing later: it runs on
+            # a second stream behind the event recorded there, beside whatever the asking stream has queued since -- the frozen stem
+            # and first stage of the next forward, whose images never change -- and the asking stream waits for it here.
+            main = torch.cuda.current_stream(dev)
+            side = _image_streams.get(dev)
+            if side is None:
+                side = _image_streams[dev] = torch.cuda.Stream(dev)
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                _lib.check(lib.lsn_conv2d_prepare_weights_multi(len(items), arr, _stream()))
+            main.wait_stream(side)
+        else:
+            _lib.check(lib.lsn_conv2d_prepare_weights_multi(len(items), arr, _stream()))
     for key, ent, w in items:
         _mark_fresh(ent, w)
 
@@ -175,7 +215,7 @@ def weight_image(w, kind, stride=1, pad=0, dil=1, bn=None):
     img = torch.empty(nbytes, device=w.device, dtype=torch.uint8)
     shift = torch.empty(Co, device=w.device, dtype=torch.float32) if (bn is not None and kind == 0) else None
     ent = [weakref.ref(w, lambda _, k=key: _images.pop(k, None)), w._version, w.data_ptr(), img, _opt_epoch[0],
-           weakref.ref(bn) if bn is not None else None, shift, _bn_versions(bn) if bn is not None else None]
+           weakref.ref(bn) if bn is not None else None, shift, _bn_versions(bn) if bn is not None else None, None]
     it = _lib.ConvWprep()
     _fill_item(it, key, ent, w)
     _lib.check(lib.lsn_conv2d_prepare_weights_item(ctypes.byref(it), _stream()))
