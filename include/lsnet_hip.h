@@ -510,6 +510,18 @@ int lsn_bn_eval_act_backward(const float *grad_y, const float *y, const float *x
  * gradient is produced by one of this library's backward-data launches the gate rides in its epilogue instead
  * (lsn_conv_level.gate). */
 int lsn_relu_gate(const float *grad_y, const float *y, float *grad, int64_t n, lsn_stream_t stream);
+/* The same for up to 8 tensors in one launch -- the FPN levels of one multi-level convolution with a ReLU epilogue
+ * (lsn_conv2d_forward_multi: LSHead's init and fusion convolutions, lsnet_head.py:502-638).  y and grad: B dense images of
+ * per_image floats; grad_y: the same images gy_batch_stride floats apart (per_image when dense) -- the gradient of a level that
+ * is a slice of the head's concatenated pixel tensor is gated where it lies, without a copy.  per_image, gy_batch_stride: multiples
+ * of 4; 16-byte aligned pointers. */
+typedef struct lsn_gate_job {
+    const float *grad_y, *y;
+    float *grad;
+    int B;
+    int64_t per_image, gy_batch_stride;
+} lsn_gate_job;
+int lsn_relu_gate_multi(int n_jobs, const lsn_gate_job *jobs, lsn_stream_t stream);
 
 /* ---- diagnostics ---------------------------------------------------------------------------- */
 /* When set to a device buffer of 512 int64 (NULL disables), thread 0 of workgroup `block` of the

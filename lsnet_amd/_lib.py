@@ -78,6 +78,11 @@ class GnLevel(ctypes.Structure):
                 ('dy_batch_stride', ctypes.c_longlong)]
 
 
+class GateJob(ctypes.Structure):     # lsn_gate_job
+    _fields_ = [('grad_y', ctypes.c_void_p), ('y', ctypes.c_void_p), ('grad', ctypes.c_void_p), ('B', ctypes.c_int),
+                ('per_image', ctypes.c_int64), ('gy_batch_stride', ctypes.c_int64)]
+
+
 class ProfEntry(ctypes.Structure):
     _fields_ = [('name', ctypes.c_char * 48), ('launches', ctypes.c_longlong), ('total_ms', ctypes.c_double),
                 ('flops', ctypes.c_double), ('bytes', ctypes.c_double)]
@@ -104,7 +109,7 @@ EXPORTS = [
     'lsn_conv2d_forward_multi', 'lsn_conv2d_backward_data_multi', 'lsn_conv2d_backward_weight_multi', 'lsn_conv2d_backward_weight',
     'lsn_grouped_conv2d_forward', 'lsn_grouped_conv2d_backward_data', 'lsn_grouped_conv2d_backward_weight',
     'lsn_bn_eval_act_forward', 'lsn_bn_eval_act_backward', 'lsn_bn_eval_act_workspace_bytes',
-    'lsn_relu_gate', 'lsn_conv2d_backward_weight_bn', 'lsn_conv2d_backward_weight_bn_jobs',
+    'lsn_relu_gate', 'lsn_relu_gate_multi', 'lsn_conv2d_backward_weight_bn', 'lsn_conv2d_backward_weight_bn_jobs',
     'lsn_image_prep_u8', 'lsn_cross_iou_bbox_forward', 'lsn_cross_iou_bbox_backward',
     'lsn_cross_iou_bbox_stage_forward', 'lsn_cross_iou_bbox_stage_backward',
     'lsn_cross_iou_rows_forward', 'lsn_cross_iou_rows_backward',

@@ -515,6 +515,35 @@ __global__ __launch_bounds__(256) void relu_gate_kernel(const float4 *__restrict
     }
 }
 
+// the same over several tensors (the FPN levels of one multi-level convolution) in one launch; grad_y may keep its images apart
+// (a slice of a concatenated gradient: lsn_gate_job.gy_batch_stride)
+constexpr int GATE_MAX_JOBS = 8;
+struct GateJob {
+    const float4 *gy, *y;
+    float4 *g;
+    long long per4, gy_stride4, n4;   // float4 per image, between the images of gy, in all
+    int blk0;                         // first block; a block gates 1024 float4
+};
+struct GateJobs {
+    GateJob j[GATE_MAX_JOBS];
+    int n;
+};
+__global__ __launch_bounds__(256) void relu_gate_multi_kernel(const GateJobs a)
+{
+    int k = 0;
+    while (k + 1 < a.n && (int)blockIdx.x >= a.j[k + 1].blk0) ++k;
+    const GateJob &J = a.j[k];
+    const long long base = (long long)(blockIdx.x - J.blk0) * 1024;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const long long i = base + u * 256 + threadIdx.x;
+        if (i >= J.n4) break;
+        const long long b = i / J.per4, r = i - b * J.per4;
+        const float4 d = J.gy[b * J.gy_stride4 + r], v = J.y[i];
+        J.g[i] = make_float4(v.x > 0.f ? d.x : 0.f, v.y > 0.f ? d.y : 0.f, v.z > 0.f ? d.z : 0.f, v.w > 0.f ? d.w : 0.f);
+    }
+}
+
 static int bn_check(int N, int C);
 
 // shared tail of the backward entry point; `reads`: tensors of N x C floats the kernel reads
@@ -672,6 +701,34 @@ int lsn_relu_gate(const float *grad_y, const float *y, float *grad, int64_t n, l
     const int blocks = (int)((n4 + 255) / 256 < 16384 ? (n4 + 255) / 256 : 16384);
     hipLaunchKernelGGL(relu_gate_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float4 *>(grad_y),
                        reinterpret_cast<const float4 *>(y), reinterpret_cast<float4 *>(grad), n4);
+    LSN_HIP(hipGetLastError());
+    return 0;
+}
+
+int lsn_relu_gate_multi(int n_jobs, const lsn_gate_job *jobs, lsn_stream_t stream)
+{
+    using namespace lsn;
+    LSN_CHECK(n_jobs >= 1 && n_jobs <= GATE_MAX_JOBS && jobs, "relu gate: 1 .. %d tensors per launch", GATE_MAX_JOBS);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    GateJobs a = {};
+    a.n = n_jobs;
+    int nb = 0;
+    double el = 0;
+    for (int k = 0; k < n_jobs; ++k) {
+        const lsn_gate_job &q = jobs[k];
+        LSN_CHECK(q.grad_y && q.y && q.grad && q.B >= 1 && q.per_image > 0 && q.per_image % 4 == 0 && q.gy_batch_stride % 4 == 0 &&
+                      q.gy_batch_stride >= q.per_image, "relu gate: tensor %d: bad arguments", k);
+        LSN_CHECK(((reinterpret_cast<uintptr_t>(q.grad_y) | reinterpret_cast<uintptr_t>(q.y) | reinterpret_cast<uintptr_t>(q.grad)) & 15) == 0,
+                  "relu gate: tensor %d is not 16-byte aligned", k);
+        GateJob &J = a.j[k];
+        J.gy = reinterpret_cast<const float4 *>(q.grad_y), J.y = reinterpret_cast<const float4 *>(q.y);
+        J.g = reinterpret_cast<float4 *>(q.grad);
+        J.per4 = q.per_image / 4, J.gy_stride4 = q.gy_batch_stride / 4, J.n4 = J.per4 * q.B, J.blk0 = nb;
+        nb += (int)((J.n4 + 1023) / 1024);
+        el += 4.0 * J.n4;
+    }
+    ProfSpan prof(PROF_NORM, el, 12.0 * el, st);
+    hipLaunchKernelGGL(relu_gate_multi_kernel, dim3(nb), dim3(256), 0, st, a);
     LSN_HIP(hipGetLastError());
     return 0;
 }

@@ -602,9 +602,14 @@ class LSHead(nn.Module):
             if by_level and rows.dtype == torch.float32:
                 return LevelTerms(level_sums(rows.reshape(-1), B, num_level) / n)
             return [r.sum() / n for r in torch.split(rows.reshape(B, -1), num_level, dim=1)]
-        stride = self._level_rows(num_level, points[0]).repeat(B).unsqueeze(1)            # (B*N_all, 1)
-        norm = self.point_base_scale * stride
-        anchor = torch.cat(points)[None].expand(B, -1, -1).reshape(-1, 3)
+        # (constants of the grid geometry and the batch size: built once, like the points themselves)
+        key = ('loss_rows', B, tuple(id(p) for p in points))     # (the entry holds `points`: the ids stay theirs while it lives)
+        hit = self._consts.get(key)
+        if hit is None:
+            stride = self._level_rows(num_level, points[0]).repeat(B).unsqueeze(1)            # (B*N_all, 1)
+            hit = self._consts[key] = (stride, self.point_base_scale * stride,
+                                       torch.cat(points)[None].expand(B, -1, -1).reshape(-1, 3), list(points))
+        stride, norm, anchor = hit[:3]
         for b in self.branches:
             for stage, tg, plist, n in (('init', tg_init, preds[b][0], n_init), ('refine', tg_refine, preds[b][1], n_refine)):
                 bw = tg['bbox_weights'].reshape(-1, 4)

@@ -251,6 +251,39 @@ def _param_grad_results(w, bias, gw, gb, acc, want_w):
 
 
 # ---- kernel-level primitives (one C call each; the autograd Functions below and ops/resblock.py compose them) ----------
+# LSNET_GATE_MULTI=0: one gate launch per map, on dense copies of sliced gradients (A/B switch)
+GATE_MULTI = os.environ.get('LSNET_GATE_MULTI', '1') != '0'
+
+
+def _images_apart(g):
+    """Is g (B, C, H, W) a stack of dense channels-last images (whatever lies between them)?  -> floats between two images, or 0"""
+    B, C, H, W = g.shape
+    if g.dtype != torch.float32 or not g.is_cuda or g.data_ptr() % 16 or (C * H * W) % 4:
+        return 0
+    sb, sc, sh, sw = g.stride()
+    if (C == 1 or sc == 1) and (W == 1 or sw == C) and (H == 1 or sh == W * C) and (B == 1 or (sb >= C * H * W and sb % 4 == 0)):
+        return sb if B > 1 else C * H * W
+    return 0
+
+
+def relu_gate_multi(gys, ys):
+    """[grad_y where y > 0 else 0] for the maps of one multi-level convolution in ONE launch (lsn_relu_gate_multi).  A gradient
+    whose images lie apart -- a level sliced out of the head's concatenated tensor -- is read where it lies: no copy first."""
+    n = len(gys)
+    strides = [_images_apart(g) for g in gys]
+    if not (0 < n <= 8 and all(strides) and all(y.is_contiguous(memory_format=_CL) and y.numel() % 4 == 0 and y.shape == g.shape
+                                                 for g, y in zip(gys, ys))):
+        gys = [g.contiguous(memory_format=_CL) for g in gys]
+        return [relu_gate(g, o) if o.numel() % 4 == 0 else g * (o > 0) for g, o in zip(gys, ys)]
+    outs = [torch.empty_like(y) for y in ys]
+    jobs = (_lib.GateJob * n)()
+    for j, (g, y, o, sb) in enumerate(zip(gys, ys, outs, strides)):
+        jobs[j].grad_y, jobs[j].y, jobs[j].grad = g.data_ptr(), y.data_ptr(), o.data_ptr()
+        jobs[j].B, jobs[j].per_image, jobs[j].gy_batch_stride = y.shape[0], y.numel() // y.shape[0], sb
+    _lib.check(_lib.load().lsn_relu_gate_multi(n, jobs, _stream()))
+    return outs
+
+
 def relu_gate(gy, y):
     """grad_y where y > 0, else 0 -- the gradient through a ReLU whose output was stored (lsn_relu_gate)."""
     g = torch.empty_like(y, memory_format=_CL)
@@ -544,9 +577,13 @@ class _ConvMultiFn(torch.autograd.Function):
         saved = ctx.saved_tensors
         w, xs = saved[0], saved[1:1 + n]
         outs = saved[1 + n:] if relu else None
-        gos = [g.contiguous(memory_format=_CL) for g in gos]
-        if relu:
+        if relu and GATE_MULTI:
+            gos = relu_gate_multi(list(gos), outs)      # one launch for all maps, reading sliced gradients where they lie
+        elif relu:
+            gos = [g.contiguous(memory_format=_CL) for g in gos]
             gos = [relu_gate(g, o) if o.numel() % 4 == 0 else g * (o > 0) for g, o in zip(gos, outs)]
+        else:
+            gos = [g.contiguous(memory_format=_CL) for g in gos]
         need_x = [ctx.needs_input_grad[3 + i] for i in range(n)]
         gxs = [None] * n
         if any(need_x):

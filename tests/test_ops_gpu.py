@@ -342,6 +342,47 @@ def test_per_level_loss_sums_match_the_level_by_level_form():
         level_sums(torch.zeros(10, device=dev), 1, [10, 0])       # an empty level
 
 
+def test_relu_gate_multi_reads_sliced_gradients_where_they_lie():
+    """lsn_relu_gate_multi: the ReLU gates of all maps of a multi-level convolution in one launch; a gradient that is a level
+    sliced out of the head's concatenated (B, N_all, C) tensor (images N_all * C floats apart) is gated without a copy.  Through
+    the convolution: conv2d_multi(relu=True) followed by the head's concatenation gives the gradients of the level-by-level form."""
+    from lsnet_amd.ops import conv as cv
+    dev = _dev()
+    torch.manual_seed(14)
+    shapes = [(2, 64, 9, 7), (2, 64, 5, 4), (2, 64, 3, 2), (2, 64, 1, 1)]
+    ys = [torch.randn(s, device=dev).contiguous(memory_format=torch.channels_last) for s in shapes]
+    B, C = 2, 64
+    nall = sum(h * w for _, _, h, w in shapes)
+    cat = torch.randn(B, nall, C, device=dev)
+    gys, o = [], 0
+    for _, _, h, w in shapes:
+        gys.append(cat[:, o:o + h * w].reshape(B, h, w, C).permute(0, 3, 1, 2))
+        o += h * w
+    assert cv._images_apart(gys[0]) == nall * C and not gys[0].is_contiguous(memory_format=torch.channels_last)
+    got = cv.relu_gate_multi(gys, ys)
+    for g, gy, y in zip(got, gys, ys):
+        assert g.is_contiguous(memory_format=torch.channels_last)
+        assert torch.equal(g, torch.where(y > 0, gy, torch.zeros_like(gy)))
+    # dense gradients, odd layouts (fallback), and the whole thing behind a convolution
+    got = cv.relu_gate_multi([g.contiguous(memory_format=torch.channels_last) for g in gys], ys)
+    assert all(torch.equal(g, torch.where(y > 0, gy, torch.zeros_like(gy))) for g, gy, y in zip(got, gys, ys))
+    got = cv.relu_gate_multi([g.contiguous() for g in gys], ys)
+    assert all(torch.equal(g, torch.where(y > 0, gy, torch.zeros_like(gy))) for g, gy, y in zip(got, gys, ys))
+
+    w = (torch.randn(64, 64, 3, 3, device=dev) * 0.05).contiguous(memory_format=torch.channels_last).requires_grad_()
+    b = torch.randn(64, device=dev).requires_grad_()
+    xs = [torch.randn(s, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_() for s in shapes]
+    up = torch.randn(B, nall, C, device=dev)
+
+    def run(multi):
+        outs = cv.conv2d_multi(xs, w, b, 1, 1, relu=True) if multi else \
+            [torch.relu(cv.conv2d_multi([x], w, b, 1, 1)[0]) for x in xs]
+        flat = torch.cat([t.permute(0, 2, 3, 1).reshape(B, -1, C) for t in outs], dim=1)
+        return torch.autograd.grad(flat, xs + [w, b], up)
+    for a, r in zip(run(True), run(False)):
+        assert torch.allclose(a, r, rtol=1e-4, atol=1e-5), float((a - r).abs().max())
+
+
 def test_topk_columns_matches_torch():
     """lsn_topk_columns against torch.topk on the CPU (the reference's call, centroid_assigner.py:74 and
     atss_assigner.py:103-111): same values in the same order, same rows; equal values come out by ascending row."""
