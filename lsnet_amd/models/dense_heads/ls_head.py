@@ -32,6 +32,7 @@ from ...ops import ModulatedDeformConvPack, PyramidDeformConv
 from ...ops.dcn import offset_scale_chain
 from ...ops import cross_iou as fused_ciou
 from ...ops.focal import level_rows_ok, level_sums
+from ...ops.streams import side_stream
 from ..builder import HEADS, build_loss
 
 # LSNET_FUSED_LEVEL_SUMS=0: every loss term level by level (the host path's form) on the device as well (A/B switch)
@@ -646,13 +647,7 @@ class LSHead(nn.Module):
         return losses
 
     def _side_stream(self, device):
-        key = ('side_stream', str(device))
-        st = self._streams.get(key) if hasattr(self, '_streams') else None
-        if st is None:
-            if not hasattr(self, '_streams'):
-                self._streams = {}
-            st = self._streams[key] = torch.cuda.Stream(device)
-        return st
+        return side_stream(device)      # (ONE per process and device: ops/streams.py says why)
 
     def init_stage_targets(self, featmap_sizes, like, gt_bboxes, gt_extremes, gt_keypoints_vs, gt_masks, gt_labels, img_metas):
         """Everything of `loss` (lsnet_head.py:1272-1437) that does not depend on a prediction: the ground truth in the head's

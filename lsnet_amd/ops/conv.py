@@ -20,6 +20,7 @@ import torch.nn.functional as F
 
 from .. import _lib
 from . import grad_sink
+from .streams import side_stream
 
 _CL = torch.channels_last
 
@@ -57,15 +58,13 @@ def _pad_channels(t, c_to):
 
 
 _images = {}    # (id(weight), kind, stride, pad, dil, math mode, id(bn) or 0) -> [weakref, version, data_ptr, image,
-#                  optimizer epoch, weakref(bn) or None, shift tensor or None, bn versions,
-#                  (version, data_ptr, bn versions) at the last optimizer step or None]
+#                  optimizer epoch, weakref(bn) or None, shift tensor or None, bn versions]
 _opt_epoch = [0]
 
 
 # LSNET_SIDE_STREAM_IMAGES=0: the images are rebuilt on the stream that asks for them (A/B switch)
 SIDE_STREAM_IMAGES = os.environ.get('LSNET_SIDE_STREAM_IMAGES', '1') != '0'
 _step_done = {}      # device index -> event recorded right behind the last optimizer step (on the stream that ran it)
-_image_streams = {}  # device index -> the stream the stale images are rebuilt on
 
 
 def _after_optimizer_step(*_):
@@ -79,12 +78,6 @@ def _after_optimizer_step(*_):
         if ev is None:
             ev = _step_done[dev] = torch.cuda.Event()
         ev.record()
-        # what every weight looks like NOW: an image may be rebuilt behind this event only if nothing has written its weight since
-        for ent in _images.values():
-            w = ent[0]()
-            if w is not None:
-                bn = ent[5]() if ent[5] is not None else None
-                ent[8] = (w._version, w.data_ptr(), _bn_versions(bn) if bn is not None else None)
 
 
 def parameters_updated():
@@ -170,17 +163,19 @@ def _refresh_stale(mode):
             _fill_item(it, key, ent, w)
         dev = items[0][2].device.index
         ev = _step_done.get(dev) if SIDE_STREAM_IMAGES and len(items) > 1 else None
-        if ev is not None and not all(w.device.index == dev and ent[8] is not None and ent[8] == (
-                w._version, w.data_ptr(), _bn_versions(ent[5]()) if ent[5] is not None else None) for _, ent, w in items):
-            ev = None           # something wrote a weight after the optimizer step (or the image is new): rebuild in stream order
+        if ev is not None and not all(w.device.index == dev and ent[1] == w._version and ent[2] == w.data_ptr() and
+                                      (ent[5] is None or ent[7] == _bn_versions(ent[5]())) for _, ent, w in items):
+            # Behind the event only what the event is known to cover: every image here must be stale for ONE reason, the optimizer
+            # epoch -- same tensor version and storage as when it was built, so that no torch operation has written the weight since
+            # (any in-place write bumps the version) and the writer was the library's own optimizer kernel (runner/fused_sgd.py calls
+            # parameters_updated() right behind it).  torch's optimizers bump the versions: their steps rebuild in stream order.
+            ev = None
         if ev is not None:
             # The rebuild (one bandwidth-bound launch, ~0.2 ms for LSNet R-50) needs the optimizer step and nothing later: it runs on
             # a second stream behind the event recorded there, beside whatever the asking stream has queued since -- the frozen stem
             # and first stage of the next forward, whose images never change -- and the asking stream waits for it here.
             main = torch.cuda.current_stream(dev)
-            side = _image_streams.get(dev)
-            if side is None:
-                side = _image_streams[dev] = torch.cuda.Stream(dev)
+            side = side_stream(torch.device('cuda', dev))       # (ONE per process and device: ops/streams.py says why)
             side.wait_event(ev)
             with torch.cuda.stream(side):
                 _lib.check(lib.lsn_conv2d_prepare_weights_multi(len(items), arr, _stream()))
@@ -215,7 +210,7 @@ def weight_image(w, kind, stride=1, pad=0, dil=1, bn=None):
     img = torch.empty(nbytes, device=w.device, dtype=torch.uint8)
     shift = torch.empty(Co, device=w.device, dtype=torch.float32) if (bn is not None and kind == 0) else None
     ent = [weakref.ref(w, lambda _, k=key: _images.pop(k, None)), w._version, w.data_ptr(), img, _opt_epoch[0],
-           weakref.ref(bn) if bn is not None else None, shift, _bn_versions(bn) if bn is not None else None, None]
+           weakref.ref(bn) if bn is not None else None, shift, _bn_versions(bn) if bn is not None else None]
     it = _lib.ConvWprep()
     _fill_item(it, key, ent, w)
     _lib.check(lib.lsn_conv2d_prepare_weights_item(ctypes.byref(it), _stream()))

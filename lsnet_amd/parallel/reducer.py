@@ -242,6 +242,12 @@ class DataParallelModel(nn.Module):
     def __init__(self, module, bucket_mb=25.0, broadcast_params=True):
         super().__init__()
         self.module = module
+        p0 = next(module.parameters(), None)
+        if p0 is not None and p0.is_cuda:
+            # the step's second stream (ops/streams.py) before the first collective: RCCL creates streams of its own there, and
+            # which hardware queue a stream shares depends on the order of creation
+            from ..ops.streams import side_stream
+            side_stream(p0.device)
         if dist.is_initialized() and dist.get_world_size() > 1 and broadcast_params:
             for t in list(module.parameters()) + list(module.buffers()):
                 dist.broadcast(t.data, src=0)
