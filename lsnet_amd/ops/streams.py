@@ -19,3 +19,34 @@ def side_stream(device=None):
     if st is None:
         st = _side[idx] = torch.cuda.Stream(torch.device('cuda', idx))
     return st
+
+
+_warm = set()
+
+
+def warm_library_streams(device):
+    """The library has a second stream of its own (csrc/dcn.hip: the anchor lists of a deformable backward are built beside its
+    GEMM), created at the first deformable backward of a process -- in a data-parallel process that is after RCCL has created its
+    streams, i.e. at a position in the creation order nobody has measured.  One tiny deformable forward + backward (a 256 -> 256
+    3x3 DCNv2 on an 8 x 8 map of zeros: the tower's launch kinds) creates it NOW; DataParallelModel calls this right after
+    `side_stream()` and before its first collective, which gives every process the creation order of the single-GPU run.  Never
+    raises: a failure here must not keep a model from being built."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if idx in _warm:
+        return
+    _warm.add(idx)
+    try:
+        from .dcn import modulated_deform_conv
+        cl = torch.channels_last
+        dev = torch.device('cuda', idx)
+        with torch.enable_grad():
+            x = torch.zeros(1, 256, 8, 8, device=dev).contiguous(memory_format=cl).requires_grad_()
+            w = torch.zeros(256, 256, 3, 3, device=dev).contiguous(memory_format=cl).requires_grad_()
+            off = torch.zeros(1, 18, 8, 8, device=dev).contiguous(memory_format=cl).requires_grad_()
+            msk = torch.ones(1, 9, 8, 8, device=dev).contiguous(memory_format=cl)
+            modulated_deform_conv(x, off, msk, w, None, 1, 1, 1).sum().backward()
+    except Exception as ex:   # noqa: BLE001
+        import warnings
+        warnings.warn(f'lsnet_amd: the warm-up of the library\'s second stream failed ({type(ex).__name__}: {ex}); continuing',
+                      RuntimeWarning)

@@ -246,8 +246,9 @@ class DataParallelModel(nn.Module):
         if p0 is not None and p0.is_cuda:
             # the step's second stream (ops/streams.py) before the first collective: RCCL creates streams of its own there, and
             # which hardware queue a stream shares depends on the order of creation
-            from ..ops.streams import side_stream
+            from ..ops.streams import side_stream, warm_library_streams
             side_stream(p0.device)
+            warm_library_streams(p0.device)     # (the library's own second stream, likewise)
         if dist.is_initialized() and dist.get_world_size() > 1 and broadcast_params:
             for t in list(module.parameters()) + list(module.buffers()):
                 dist.broadcast(t.data, src=0)
