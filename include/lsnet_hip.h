@@ -548,6 +548,19 @@ typedef struct lsn_prof_entry {
 int lsn_prof_enable(int on);
 int lsn_prof_read(lsn_prof_entry *out, int max_entries);
 
+/* Per-call log of the dense convolutions (forward / backward-data entry points, prepared or one-shot): while it is on, every
+ * call records its arguments and a pair of HIP events on the launch stream.  lsn_prof_launch_log(on) clears the log and
+ * switches it; lsn_prof_read_launches(NULL, 0) returns the number of records, with a buffer it waits for the events and
+ * copies up to max_entries records in call order.  tools/instep_vs_isolated.py replays every record back to back on its own
+ * and compares (profiles/r6_instep_vs_isolated.txt).  kind 0: forward, 1: backward-data (B/H/W = the forward INPUT sizes). */
+typedef struct lsn_prof_launch {
+    int kind, C, Co, kh, kw, stride, pad, dil, relu, xpitch, n_levels, has_residual, has_gate;
+    int B[16], H[16], W[16];
+    float ms;
+} lsn_prof_launch;
+int lsn_prof_launch_log(int on);
+int lsn_prof_read_launches(lsn_prof_launch *out, int max_entries);
+
 /* What the library itself has asked of the HIP runtime outside kernel launches since it was loaded:
  *   out4[0] hipMalloc calls (library-owned scratch: partial tiles, stream-K slots and counters, tables -- grown on demand,
  *           never freed), out4[1] bytes they hold, out4[2] blocking stream synchronisations (a weight-image job table

@@ -88,6 +88,12 @@ class ProfEntry(ctypes.Structure):
                 ('flops', ctypes.c_double), ('bytes', ctypes.c_double)]
 
 
+class ProfLaunch(ctypes.Structure):     # lsn_prof_launch
+    _fields_ = [(k, ctypes.c_int) for k in ('kind', 'C', 'Co', 'kh', 'kw', 'stride', 'pad', 'dil', 'relu', 'xpitch', 'n_levels',
+                                            'has_residual', 'has_gate')] + \
+               [('B', ctypes.c_int * 16), ('H', ctypes.c_int * 16), ('W', ctypes.c_int * 16), ('ms', ctypes.c_float)]
+
+
 # every symbol include/lsnet_hip.h declares (checked by tests/test_capi.py without a GPU)
 EXPORTS = [
     'lsn_last_error', 'lsn_version', 'lsn_dcn_forward', 'lsn_dcn_backward', 'lsn_dcn_backward_workspace_bytes', 'lsn_dcn_pitched_ok',
@@ -99,7 +105,7 @@ EXPORTS = [
     'lsn_sigmoid_focal_loss_backward_weighted', 'lsn_sigmoid_focal_loss_level_sums', 'lsn_sigmoid_focal_loss_backward_levels',
     'lsn_level_sums', 'lsn_level_expand',
     'lsn_nms_workspace_bytes', 'lsn_nms', 'lsn_topk_columns', 'lsn_offset_chain_forward', 'lsn_offset_chain_backward', 'lsn_clip_sgd_workspace_bytes', 'lsn_clip_sgd_step', 'lsn_selftest_mfma', 'lsn_debug_phase_clocks',
-    'lsn_prof_enable', 'lsn_prof_read', 'lsn_scratch_stats', 'lsn_wgrad_defer', 'lsn_wgrad_flush',
+    'lsn_prof_enable', 'lsn_prof_read', 'lsn_prof_launch_log', 'lsn_prof_read_launches', 'lsn_scratch_stats', 'lsn_wgrad_defer', 'lsn_wgrad_flush',
     'lsn_group_norm_workspace_bytes', 'lsn_group_norm_forward', 'lsn_group_norm_backward',
     'lsn_set_math_mode', 'lsn_get_math_mode', 'lsn_conv2d_forward', 'lsn_conv2d_forward_pitched', 'lsn_conv2d_backward_data',
     'lsn_conv2d_prepared_bytes', 'lsn_conv2d_prepare_weights', 'lsn_conv2d_prepare_weights_multi',

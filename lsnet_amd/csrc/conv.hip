@@ -464,6 +464,39 @@ struct ConvProf : ProfSpan {
     ConvProf(int fam, const ConvArgs &a, hipStream_t s) : ProfSpan(fam, fl(a), by(a), s) {}
 };
 
+// prof.h launch log: one record per forward / backward-data call (all residue classes of a strided data gradient included)
+struct LaunchLog {
+    LaunchRec r;
+    hipStream_t st;
+    bool on;
+    LaunchLog(int kind, int n, const lsn_conv_level *lv, int C, int xpitch, int Co, int kh, int kw, int stride, int pad, int dil,
+              int relu, hipStream_t s) : st(s), on(launch_log_on())
+    {
+        if (!on) return;
+        memset(&r, 0, sizeof(r));
+        int res = 0, gate = 0;
+        for (int i = 0; i < n && i < 16; ++i) {
+            r.B[i] = lv[i].B, r.H[i] = lv[i].H, r.W[i] = lv[i].W;
+            res |= lv[i].residual != nullptr, gate |= lv[i].gate != nullptr;
+        }
+        const int v[13] = {kind, C, Co, kh, kw, stride, pad, dil, relu, xpitch, n, res, gate};
+        memcpy(r.v, v, sizeof(v));
+        if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) {
+            on = false;
+            return;
+        }
+        (void)hipEventRecord(r.e0, st);
+    }
+    ~LaunchLog()
+    {
+        if (!on) return;
+        (void)hipEventRecord(r.e1, st);
+        launch_log_push(r);
+    }
+    LaunchLog(const LaunchLog &) = delete;
+    LaunchLog &operator=(const LaunchLog &) = delete;
+};
+
 static int conv_out_size(int in, int k, int stride, int pad, int dil) { return (in + 2 * pad - (dil * (k - 1) + 1)) / stride + 1; }
 
 static int conv_check(int B, int H, int W, int C, int Co, int kh, int kw, int stride, int pad, int dil, int *Ho,
@@ -503,6 +536,7 @@ static int conv_forward_impl(int n, const lsn_conv_level *lv, const void *prepar
 {
     LSN_CHECK(n >= 1 && n <= CV_MAXLV && lv && prepared, "conv2d: bad level list");
     LSN_CHECK(xpitch > 0, "conv2d: bad pixel pitch %d", xpitch);
+    LaunchLog log(0, n, lv, C, xpitch, Co, kh, kw, stride, pad, dil, relu, st);
     if ((C % 4 != 0 || xpitch % 4 != 0) && Co <= 64)
         return fail(LSN_ERR_UNSUPPORTED, "conv2d: C %% 4 != 0 needs more than 64 output channels");
     ConvArgs a = {};
@@ -600,6 +634,7 @@ static int conv_backward_data_impl(int n, const lsn_conv_level *lv, const void *
                                    int stride, int pad, int dil, hipStream_t st)
 {
     LSN_CHECK(n >= 1 && n <= CV_MAXLV && lv && prepared, "conv2d backward: bad arguments");
+    LaunchLog log(1, n, lv, C, C, Co, kh, kw, stride, pad, dil, 0, st);
     if (Co % 4 != 0 && C <= 64) return fail(LSN_ERR_UNSUPPORTED, "conv2d backward-data: Co %% 4 != 0 needs C > 64");
     const int s = stride;
     int Ho[CV_MAXLV], Wo[CV_MAXLV];

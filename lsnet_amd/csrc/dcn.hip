@@ -56,6 +56,10 @@ static unsigned g_prof_mask = 0;   // bit f: family f records events
 static std::vector<ProfRec> g_prof;
 bool prof_on(int fam) { return fam >= 0 && fam < 32 && ((g_prof_mask >> fam) & 1u); }
 void prof_push(const ProfRec &r) { g_prof.push_back(r); }
+static bool g_launch_log = false;
+static std::vector<LaunchRec> g_launches;
+bool launch_log_on() { return g_launch_log; }
+void launch_log_push(const LaunchRec &r) { g_launches.push_back(r); }
 
 static double dcn_flops(const DcnArgs &a)
 {
@@ -1424,6 +1428,37 @@ int lsn_prof_enable(int on)
     lsn::g_prof.clear();
     lsn::g_prof_mask = on == 1 ? ~0u : (unsigned)on;
     return 0;
+}
+
+int lsn_prof_launch_log(int on)
+{
+    for (auto &r : lsn::g_launches) {
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
+    }
+    lsn::g_launches.clear();
+    lsn::g_launch_log = on != 0;
+    return 0;
+}
+
+int lsn_prof_read_launches(lsn_prof_launch *out, int max_entries)
+{
+    using namespace lsn;
+    const int n = (int)g_launches.size();
+    if (out == nullptr) return n;
+    int k = 0;
+    for (; k < n && k < max_entries; ++k) {
+        const LaunchRec &r = g_launches[k];
+        LSN_HIP(hipEventSynchronize(r.e1));
+        float ms = 0.f;
+        LSN_HIP(hipEventElapsedTime(&ms, r.e0, r.e1));
+        lsn_prof_launch &o = out[k];
+        o.kind = r.v[0], o.C = r.v[1], o.Co = r.v[2], o.kh = r.v[3], o.kw = r.v[4], o.stride = r.v[5], o.pad = r.v[6];
+        o.dil = r.v[7], o.relu = r.v[8], o.xpitch = r.v[9], o.n_levels = r.v[10], o.has_residual = r.v[11], o.has_gate = r.v[12];
+        for (int i = 0; i < 16; ++i) o.B[i] = r.B[i], o.H[i] = r.H[i], o.W[i] = r.W[i];
+        o.ms = ms;
+    }
+    return k;
 }
 
 int lsn_prof_read(lsn_prof_entry *out, int max_entries)

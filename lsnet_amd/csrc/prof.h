@@ -29,6 +29,17 @@ struct ProfRec {
 bool prof_on(int fam);
 void prof_push(const ProfRec &r);
 
+// Per-launch log of the dense convolutions (lsn_prof_launch_log): what was asked (the arguments of the entry point) and how long
+// it took on the launch stream -- tools/instep_vs_isolated.py replays every logged call on its own and puts the two durations
+// side by side.
+struct LaunchRec {
+    hipEvent_t e0, e1;
+    int v[13];   // kind, C, Co, kh, kw, stride, pad, dil, relu, xpitch, nlv, has_res, has_gate
+    int B[16], H[16], W[16];
+};
+bool launch_log_on();
+void launch_log_push(const LaunchRec &r);
+
 // RAII: events around the launches issued while the object lives
 struct ProfSpan {
     ProfRec r;
