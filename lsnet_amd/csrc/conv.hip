@@ -908,6 +908,14 @@ static int wgrad_flush(Arena *ar)
     return 0;
 }
 
+// dcn.hip (stream-K pieces of the deformable forward): slots in this stream's scratch block and its tile counters
+int conv_sk_scratch(size_t floats, float **part, unsigned **cnt, hipStream_t st)
+{
+    if (int rc = part_buffer(floats, part, st)) return rc;
+    return sk_counters(cnt, st);
+}
+int conv_sk_max_tiles() { return SK_MAX_TILES; }
+
 // library-owned scratch (also for dcn.hip's weight-gradient pass): grows, never shrinks
 int conv_scratch(size_t floats, float **p, hipStream_t st) { return part_buffer(floats, p, st, true); }   // (weight-gradient passes of dcn.hip)
 

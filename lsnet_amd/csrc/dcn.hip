@@ -307,14 +307,52 @@ static int mm_prepare_weights(DcnArgs &a, bool backward, void *dst, hipStream_t 
     return 0;
 }
 
+// Work distribution of a forward launch (dcn_mm_kernels.h DcnSk).  The chip holds 512 workgroups of the kernel; whole rounds
+// stay one workgroup per tile, the r tiles of the last round are cut into pieces of >= 4 chunks spread evenly over up to 512
+// workgroups.  Measured (tools/ubench/dcn_step, debug bit 19 = whole tiles only, profiles/r6_dcn_sk.txt): the pyramid launch
+// (2 100 tiles: four rounds and 52 tiles) 780 -> 759 us; the tower launch (700 tiles: one round and 188 tiles) 278 -> 283 us --
+// its second round runs one workgroup per CU, which has the matrix pipe to itself and finishes in ~0.65 of a round, so the
+// even split has little to return and the pieces' table rebuild and hand-over cost more.  Hence: launches of two rounds and
+// more only (the opposite of the dense kernel's rule, conv.hip sk_plan, whose short tiles lose to the longer prologue there).
+int conv_sk_scratch(size_t floats, float **part, unsigned **cnt, hipStream_t st);
+int conv_sk_max_tiles();
+static bool dcn_sk_env() { return !((g_dbg_block >> 19) & 1); }   // debug bit 19: whole tiles only (A/B)
+static void dcn_sk_plan(int ntw, int Tall, DcnSk *sk)
+{
+    sk->n_dp = ntw, sk->sk_n = 0, sk->sk_tiles = 0, sk->part = nullptr, sk->cnt = nullptr;
+    constexpr int SLOTS = 512;
+    const bool forced = (g_dbg_block >> 18) & 1;   // debug bit 18: pieces for launches of any size (tests)
+    if (!dcn_sk_env() || Tall < 8 || (ntw < 2 * SLOTS && !forced)) return;
+    const int r = ntw % SLOTS;
+    if (r == 0 || r > 448) return;
+    int per_tile = Tall / 4;
+    const int cap = ntw > SLOTS ? 16 : 4;
+    if (per_tile > cap) per_tile = cap;
+    const long long pieces = (long long)r * per_tile;
+    const int ns = pieces < SLOTS ? (int)pieces : SLOTS;
+    if (ns <= r) return;
+    if (r > conv_sk_max_tiles() || ((long long)r * Tall + 1) * ns >= ((long long)1 << 31)) return;
+    sk->n_dp = ntw - r, sk->sk_n = ns, sk->sk_tiles = r;
+}
+
 template <int TM, int TN, int WM, int WN, int NP, bool FINE = false>
 static int launch_fwd_mm_cfg(const DcnArgs &a, hipStream_t st)
 {
-    auto k = dcn_fwd_mm_kernel<TM, TN, WM, WN, NP, FINE>;
+    constexpr int BN = WN * TN * 32;
     const size_t lds = dcn_fwd_mm_lds_bytes(SplitCfg<NP>::NPL, a.kh * a.kw * a.dg);
-    if (int rc = set_lds(k, lds)) return rc;
-    const int blocks = a.ntiles * (a.Co / (WN * TN * 32));
-    hipLaunchKernelGGL(k, dim3(blocks), dim3(256), lds, st, a, a.wtp, a.wtp_bytes);
+    const int blocks = a.ntiles * (a.Co / BN);
+    DcnSk sk;
+    dcn_sk_plan(blocks, a.kh * a.kw * (a.C / 32), &sk);
+    if (sk.sk_n) {
+        if (int rc = conv_sk_scratch((size_t)2 * sk.sk_n * 64 * BN, &sk.part, &sk.cnt, st)) return rc;
+        auto k = dcn_fwd_mm_kernel<TM, TN, WM, WN, NP, FINE, true>;
+        if (int rc = set_lds(k, lds)) return rc;
+        hipLaunchKernelGGL(k, dim3(sk.n_dp + sk.sk_n), dim3(256), lds, st, a, a.wtp, a.wtp_bytes, sk);
+    } else {
+        auto k = dcn_fwd_mm_kernel<TM, TN, WM, WN, NP, FINE, false>;
+        if (int rc = set_lds(k, lds)) return rc;
+        hipLaunchKernelGGL(k, dim3(blocks), dim3(256), lds, st, a, a.wtp, a.wtp_bytes, sk);
+    }
     LSN_HIP(hipGetLastError());
     return 0;
 }

@@ -30,11 +30,81 @@ struct __align__(16) FTap {
 
 __host__ __device__ inline size_t dcn_fwd_mm_lds_bytes(int npl, int KD) { return (size_t)2 * npl * 64 * 64 + (size_t)64 * KD * sizeof(FTap); }
 
+// Work distribution of a forward launch (dcn.hip dcn_sk_plan), the scheme of conv_kernels.h: workgroups [0, n_dp) take one whole
+// (pixel tile, column block) each; workgroups [n_dp, n_dp + sk_n) share the LAST sk_tiles tiles evenly by chunks.  A tower
+// launch of the LSNet step has 700 tiles for 512 resident workgroups (two rounds, the second 37 % full), a pyramid launch 2 100
+// (five rounds, the last 10 % full).  A piece that holds part of a tile's sum leaves its accumulators in a slot, draws a ticket,
+// and the piece that draws the last ticket adds the slots in chunk order (fixed order: bit-reproducible) and runs the epilogue.
+struct DcnSk {
+    int n_dp, sk_n, sk_tiles;
+    float *part;
+    unsigned *cnt;   // one counter per stream-K tile, zero between launches
+};
+
+// The hand-over of conv_mm_kernel's stream-K pieces as a function (agent-scope slot accesses, no fence: conv_kernels.h).
+// Returns true in the workgroup that finishes tile kt (acc then holds the whole sum).
+template <int TM, int TN>
+__device__ __forceinline__ bool sk_hand_over(f32x16 (&acc)[TN][TM], const DcnSk &sk, int kt, int sk_s, bool opens_piece, int sk_U,
+                                             int Tall, int tid, unsigned *ticket_lds)
+{
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int SLOT = TM * TN * 1024 * 4;   // floats of a workgroup tile; element (q, tid) = float4 number q of thread tid
+    constexpr int SC1 = 16;                    // agent scope (cache-policy bit 4 of the raw buffer intrinsics)
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(sk.part, 0, 2 * sk.sk_n * SLOT * 4, 0x00020000);
+    {
+        const int soff = (2 * sk_s + (opens_piece ? 0 : 1)) * (SLOT * 4);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 v = {acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]};
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), prs, (((j * TM + i) * 4 + g) * 256 + tid) * 16,
+                                                           soff, SC1);
+                }
+    }
+    const int u_lo = kt * Tall, u_hi = u_lo + Tall - 1;
+    const int s_lo = (int)(((unsigned)(u_lo + 1) * (unsigned)sk.sk_n + (unsigned)sk_U - 1u) / (unsigned)sk_U) - 1;
+    const int s_hi = (int)(((unsigned)(u_hi + 1) * (unsigned)sk.sk_n + (unsigned)sk_U - 1u) / (unsigned)sk_U) - 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's slot elements have reached the coherence point
+    __syncthreads();
+    if (tid == 0) *ticket_lds = __hip_atomic_fetch_add(sk.cnt + kt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if ((int)*ticket_lds != s_hi - s_lo) return false;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+    for (int c = s_lo; c <= s_hi; ++c) {   // chunk order = piece order
+        const int cs = (int)((unsigned)sk_U * (unsigned)c / (unsigned)sk.sk_n);
+        const int soff = (2 * c + (cs >= u_lo ? 0 : 1)) * (SLOT * 4);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            f32x4 pv[TM * 4];
+#pragma unroll
+            for (int q = 0; q < TM * 4; ++q)
+                pv[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, ((j * TM * 4 + q) * 256 + tid) * 16, soff, SC1));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[j][i][4 * g + e] += pv[i * 4 + g][e];
+        }
+    }
+    if (tid == 0) __hip_atomic_store(sk.cnt + kt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed
+    return true;
+}
+
 // FINE (experiment, LSNET_DCN_FWD_FINE=1): as in conv_mm_kernel -- the slice commit without its branch + sched_group_barrier
 // groups put the blend / split instructions of a slice between its MFMAs instead of behind them.
-template <int TM, int TN, int WM, int WN, int NP, bool FINE = false>
+// SK: the launch has stream-K pieces (DcnSk); a template parameter as in conv_mm_kernel.
+template <int TM, int TN, int WM, int WN, int NP, bool FINE = false, bool SK = false>
 __global__ __launch_bounds__(256, 2) void dcn_fwd_mm_kernel(const DcnArgs a, const unsigned short *__restrict__ wf,
-                                                            int wf_bytes)
+                                                            int wf_bytes, const DcnSk sk)
 {
     using SC = SplitCfg<NP>;
     constexpr int NPL = SC::NPL;
@@ -49,14 +119,35 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_mm_kernel(const DcnArgs a, con
     const int wm = wave / WN, wn = wave % WN;
     const int K = a.kh * a.kw, KD = K * a.dg;
     const int ncb = a.Co / BN;
-    const int work = xcd_remap(blockIdx.x, a.ntiles * ncb);
+    const int ncc = a.C / 32, NT = cv_nt(a.Co);
+    const int Tall = K * ncc;
+    const int ccpd = ncc / a.dg;   // chunks per deformable group
+    // ---- this workgroup's share: one whole tile, or a stream-K piece ----
+    const bool is_sk = SK && (int)blockIdx.x >= sk.n_dp;
+    int sk_u = 0, sk_end = 0, sk_start = 0, sk_U = 0, sk_s = 0;
+    if (is_sk) {
+        sk_s = xcd_remap((int)blockIdx.x - sk.n_dp, sk.sk_n);
+        sk_U = sk.sk_tiles * Tall;
+        sk_start = sk_u = (int)((unsigned)sk_U * (unsigned)sk_s / (unsigned)sk.sk_n);
+        sk_end = (int)((unsigned)sk_U * (unsigned)(sk_s + 1) / (unsigned)sk.sk_n);
+    }
+    __shared__ unsigned sk_ticket;
+  for (;;) {   // one pass per segment (whole tiles: exactly one)
+    int work, t_begin = 0, T = Tall;
+    if (!is_sk) {
+        work = xcd_remap((int)blockIdx.x, SK ? sk.n_dp : a.ntiles * ncb);
+    } else {
+        const int kt = (int)((unsigned)sk_u / (unsigned)Tall);
+        work = sk.n_dp + kt;
+        t_begin = sk_u - kt * Tall;
+        const int te = sk_end - kt * Tall;
+        T = (te < Tall ? te : Tall) - t_begin;
+    }
+    const bool sk_partial = SK && T != Tall;
     const int ptile = work / ncb;
     const Lvl &L = find_level(a, ptile);
     const int tile_p = (ptile - L.tile0) * BM;
     const int co_blk = (work - ptile * ncb) * BN;
-    const int ncc = a.C / 32, NT = cv_nt(a.Co);
-    const int T = K * ncc;
-    const int ccpd = ncc / a.dg;   // chunks per deformable group
 
     for (int e = tid; e < BM * KD; e += 256) {
         const int pl = e / KD, r = e - pl * KD;
@@ -127,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_mm_kernel(const DcnArgs a, con
 
     // ---- weight operand: fragments straight from L2 (conv_kernels.h) ----
     const int wvoff = lane * 16 + wn * TN * (2 * NPL * 1024);
-    const int wsbase = (co_blk / 32) * (2 * NPL * 1024), wsstep = NT * (2 * NPL * 1024);
+    const int wsbase = (t_begin * NT + co_blk / 32) * (2 * NPL * 1024), wsstep = NT * (2 * NPL * 1024);
     bf16x8 Wf[2][TN][NPL];
     auto issue_w = [&](int t, int ks) {   // t saturates at the last chunk (a repeated L2 hit, never used)
         const int soff = wsbase + (t < T ? t : T - 1) * wsstep;
@@ -150,9 +241,11 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_mm_kernel(const DcnArgs a, con
 
     // ---- prologue: chunk 0 -> LDS buffer 0, raw corners of chunk 1 and the weight fragments of chunk 0 in flight ----
     Ck ci = {0, 0};        // chunk under issue
+    if (SK) ci.k = t_begin / ncc, ci.cc = t_begin - ci.k * ncc;
     int kd_o = kd_of(ci), kd_w = kd_o;
     load_offsets(kd_o);
     load_wgts(kd_w);
+    sx_soff = ci.cc * 128;
 #pragma unroll
     for (int ps = 0; ps < NLD; ++ps) issue_slice(ps);
 #pragma unroll
@@ -242,7 +335,12 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_mm_kernel(const DcnArgs a, con
         __builtin_amdgcn_sched_barrier(0);
     }
 
+    if (SK) __syncthreads();   // (the next segment rebuilds the table and buffer 0: every wave is past its last LDS read)
+    bool do_out = true;
+    if (SK && sk_partial) do_out = sk_hand_over<TM, TN>(acc, sk, work - sk.n_dp, sk_s, sk_u == sk_start, sk_U, Tall, tid, &sk_ticket);
+
     // ---- epilogue: lane = pixel (lane & 31) of tile i, output channels 8 g + 4 (lane >> 5) + (0..3) of tile j ----
+    if (do_out) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int pix = tile_p + wm * TM * 32 + i * 32 + (lane & 31);
@@ -261,6 +359,11 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_mm_kernel(const DcnArgs a, con
                 *reinterpret_cast<float4 *>(orow + co) = v;
             }
     }
+    }
+    if (!SK || !is_sk) break;
+    sk_u += T;
+    if (sk_u >= sk_end) break;
+  }
 }
 
 // =============================================================================================

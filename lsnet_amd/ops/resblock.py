@@ -21,11 +21,43 @@ convolutions --
 The composition is written against the primitives of ops/conv.py (conv_fwd_bn, relu_gate, dgrad, wgrad_bn) through the
 module attribute `K`, so that tests/test_resblock.py can run the very same orchestration on the CPU with torch
 statements of the four primitives and compare it with autograd over the plain modules."""
+import os
 import weakref
 
 import torch
 
 from . import conv as K   # the primitives; tests swap this attribute for a torch restatement
+from .streams import side_stream
+
+# LSNET_WGRAD_SIDE=1 (round-6 experiment, VERDICT r5 item 1b): the weight-gradient launches of the fused stages run on the process's
+# second stream (ops/streams.py) behind an event of the launch stream, beside the data-gradient chain; the reducer joins the
+# stream before anything reads the gradient buckets (join_side).
+WGRAD_SIDE = os.environ.get('LSNET_WGRAD_SIDE', '0') == '1'
+_side_busy = [False]
+
+
+def _on_side(tensors, fn):
+    """fn() on the second stream, ordered behind everything the launch stream has been given so far; `tensors` (allocated on the
+    launch stream) stay out of the allocator's hands until the second stream is through with them."""
+    if not (WGRAD_SIDE and tensors and tensors[0].is_cuda):
+        return fn()
+    main = torch.cuda.current_stream(tensors[0].device)
+    side = side_stream(tensors[0].device)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        r = fn()
+    for t in tensors:
+        t.record_stream(side)
+    _side_busy[0] = True
+    return r
+
+
+def join_side(device=None):
+    """The launch stream waits for the weight gradients issued on the second stream (the reducer: before a bucket leaves and in
+    finish())."""
+    if _side_busy[0]:
+        torch.cuda.current_stream(device).wait_stream(side_stream(device))
+        _side_busy[0] = False
 
 # Queues that hold weight-gradient jobs of the backward pass in flight (ResLayer.forward's per-stage dicts).  The stage's
 # first block flushes its queue when its backward runs -- the last of the stage.  If that node never runs (a partial
@@ -141,7 +173,7 @@ class _BottleneckFn(torch.autograd.Function):
                     _live_queues.add(queue)
                     _arm_flush_callback()
                 return None, None, None
-            return K.wgrad_bn(xin, g, conv.weight, bn, *_cfg(conv))
+            return _on_side([xin, g], lambda: K.wgrad_bn(xin, g, conv.weight, bn, *_cfg(conv)))
 
         g2 = fused_dgrad(g3, c3, n3, h2.shape, h2)
         grads.append(wgrad(h2, g3, c3, n3, 'conv3'))
@@ -172,10 +204,11 @@ def flush_wgrad_queue(queue):
     for key in list(queue):
         jobs = queue.pop(key)
         cfg = key[2]
+        held = [t for j in jobs for t in j[:2]]
         if len(jobs) > 1:
-            K.wgrad_bn_jobs(jobs, *cfg)
+            _on_side(held, lambda: K.wgrad_bn_jobs(jobs, *cfg))
         else:
-            K.wgrad_bn(*jobs[0], *cfg)
+            _on_side(held, lambda: K.wgrad_bn(*jobs[0], *cfg))
 
 
 def bottleneck_ok(blk):

@@ -7,9 +7,12 @@ streams onto a few hardware queues in creation order, and a stream that lands on
 serialises with it -- measured: with one stream per LSHead instance the step of the 2nd, 3rd, 7th model of a process ran 50 - 54 ms
 instead of 31 - 32 (profiles/r5_stream_queues.txt), whatever the stream's priority.  The first stream a process creates after the
 default one has its own queue."""
+import os
+
 import torch
 
 _side = {}
+CLAIM_QUEUE = os.environ.get('LSNET_SIDE_STREAM_CLAIM', '1') != '0'   # (0: the A/B arm of tools/rccl_streams.py)
 
 
 def side_stream(device=None):
@@ -18,6 +21,14 @@ def side_stream(device=None):
     st = _side.get(idx)
     if st is None:
         st = _side[idx] = torch.cuda.Stream(torch.device('cuda', idx))
+        if CLAIM_QUEUE:
+            # A stream gets its hardware queue with its first SUBMISSION, not at creation (profiles/r6_rccl_streams.txt: with the
+            # library's stream and RCCL's streams submitting first -- what DataParallelModel's warm-up and first broadcast do in a
+            # data-parallel process -- this stream came fourth, landed on the queue of the step's stream and every step took 49 ms
+            # instead of 31.5).  One empty-handed kernel now: the second queue of the process is this stream's.
+            with torch.cuda.stream(st):
+                torch.zeros(1, device=torch.device('cuda', idx)).add_(1.0)
+            st.synchronize()
     return st
 
 

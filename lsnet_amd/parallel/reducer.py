@@ -167,6 +167,8 @@ class BucketedGradReducer:
             return
         while self._next < len(self.buckets) and self.buckets[self._next]['pending'] == 0:
             b = self.buckets[self._next]
+            from ..ops import resblock
+            resblock.join_side(b['flat'].device if b['flat'].is_cuda else None)   # (weight gradients issued on the second stream)
             self._defer(None)     # queued weight-gradient reduces write into this bucket: run them before it leaves
             b['work'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self._next += 1
@@ -207,6 +209,8 @@ class BucketedGradReducer:
         if left:   # (the engine callback of ops/resblock.py flushes at the end of every backward pass: this is a bug trap)
             raise RuntimeError(f'{left} queued weight-gradient job(s) of fused ResNet stages were never launched: their '
                                'parameters would be reduced without these contributions')
+        if self.buckets and self.buckets[0]['flat'].is_cuda:
+            resblock.join_side(self.buckets[0]['flat'].device)
         self._defer(False)   # every deferred reduce of the step runs now, ahead of whatever reads the buckets
         while self._next < len(self.buckets):
             b = self.buckets[self._next]

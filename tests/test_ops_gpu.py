@@ -1163,6 +1163,44 @@ def test_tower_launch_at_bench_shape(choice):
     assert all(e < TOL for e in errs.values()), errs
 
 
+@pytest.mark.parametrize('sizes', [[(25, 42), (13, 21), (7, 11)], [(50, 84), (25, 42), (13, 21), (7, 11)], [(9, 13)]],
+                         ids=['3lv', '4lv_one_round_and_more', 'one_tile_row'])
+def test_dcn_forward_stream_k_pieces(sizes):
+    """Round 6: the deformable forward's stream-K pieces (dcn_mm_kernels.h DcnSk; production: launches of two rounds of workgroups
+    and more, i.e. the 15-pair pyramid launch -- test_pyramid_launch_at_bench_shape runs that one against the oracle).  Debug bit
+    18 asks for pieces at any size: the result must equal the oracle's, agree with the whole-tile launch up to the summation order of
+    the pieces, and come out bit for bit the same on every run (the tile's last arriver adds the slots in chunk order)."""
+    from lsnet_amd import _lib, ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(41)
+    C = Co = 256
+    w = torch.randn(Co, C, 3, 3, generator=g) / (3 * C ** 0.5)
+    b = torch.randn(Co, generator=g)
+    xs = [torch.randn(2, C, h, ww, generator=g) for h, ww in sizes]
+    offs = [torch.randn(2, 18, h, ww, generator=g) * 1.5 for h, ww in sizes]
+    msks = [torch.rand(2, 9, h, ww, generator=g) for h, ww in sizes]
+    wd, bd = _to(w, dev, True), b.to(dev)
+    xd, od, md = [_to(t, dev, True) for t in xs], [_to(t, dev, True) for t in offs], [_to(t, dev, True) for t in msks]
+
+    def run(flag):
+        _lib.load().lsn_debug_phase_clocks(None, flag)
+        try:
+            with torch.no_grad():
+                return [o.clone() for o in ops.dcn_multi(xd, od, md, wd, bd, 1, 1, 1)]
+        finally:
+            _lib.load().lsn_debug_phase_clocks(None, 0)
+
+    whole = run(1 << 19)
+    pieces = run(1 << 18)
+    again = run(1 << 18)
+    for i in range(len(sizes)):
+        ref = orc.deform_conv_forward(xs[i], w, b, offs[i], msks[i], 1, 1, 1)
+        assert _report(f'sk/out{i}', pieces[i], ref) < TOL
+        assert torch.equal(pieces[i], again[i]), f'level {i}: two launches with pieces differ'
+        scale = float(whole[i].abs().max())
+        assert float((pieces[i] - whole[i]).abs().max()) <= 2e-6 * scale
+
+
 @pytest.mark.parametrize('mode', ['bf16x6', 'fp32'])
 def test_pyramid_outputs_side_by_side(mode):
     """`concat=3` of the pyramid op (lsn_dcn_shape.out_pitch: the three maps of a destination level written into one

@@ -20,7 +20,10 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-ORDERS = ['plain', 'side,lib,rccl', 'rccl,side,lib', 'side,rccl,lib', 'rccl,side', 'lazy']
+ORDERS = ['plain', 'side,lib,rccl', 'rccl,side,lib', 'side,rccl,lib', 'rccl,side', 'lazy',
+          # `side!`: the second stream SUBMITS something the moment it is created (a stream seems to get its hardware queue with its
+          # first submission, not at creation)
+          'side!,lib,rccl', 'rccl,side!,lib', 'side!,rccl,lib', 'lib,rccl,side!', 'product']
 
 
 def child(order):
@@ -41,8 +44,14 @@ def child(order):
     dummy = torch.zeros(1024, device=dev)
 
     def make(what):
-        if what == 'side':
-            streams.side_stream(dev)
+        if what in ('side', 'side!'):
+            st = streams._side.get(0)
+            if st is None:
+                st = streams._side[0] = torch.cuda.Stream(dev)     # (the module's own constructor may submit by now)
+            if what == 'side!':
+                with torch.cuda.stream(st):
+                    dummy.add_(1.0)
+                torch.cuda.synchronize()
         elif what == 'lib':
             streams.warm_library_streams(dev)
         elif what == 'rccl':
@@ -55,8 +64,10 @@ def child(order):
             sk.bind(('127.0.0.1', 0))
             port = sk.getsockname()[1]
         dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1)
-    seq = [] if order in ('plain', 'lazy') else order.split(',')
-    if order != 'plain' and 'lib' not in seq:
+    seq = [] if order in ('plain', 'lazy', 'product') else order.split(',')
+    if order != 'product':
+        streams.CLAIM_QUEUE = False     # (the arms place the second stream's first submission themselves; `product` = the package as it is)
+    if order not in ('plain', 'product') and 'lib' not in seq:
         streams.warm_library_streams = lambda device: None       # DataParallelModel must not arrange anything itself
     if order == 'lazy':
         streams._side.clear()
@@ -84,12 +95,18 @@ def main():
         return child(sys.argv[1])
     print('# LSNet R-50 bbox step (2 x 3x800x1344) by stream creation order; one fresh process per row; RCCL rows all-reduce the 7 gradient '
           'buckets of every step through a one-rank group, launched from the hooks during backward')
-    for order in ORDERS:
-        t0 = time.time()
-        p = subprocess.run([sys.executable, os.path.abspath(__file__), order], capture_output=True, text=True, timeout=600)
-        lines = [ln for ln in p.stdout.splitlines() if ln.startswith('RESULT')]
-        print(lines[-1][7:] if lines else f'{order}: FAILED rc {p.returncode}: ' + (p.stderr.strip().splitlines() or ['?'])[-1][:300], flush=True)
-        print(f'#   ({time.time() - t0:.0f} s)', flush=True)
+    for queues in (None, '8', '2'):
+        print(f'## GPU_MAX_HW_QUEUES = {queues or "(runtime default)"}', flush=True)
+        env = dict(os.environ)
+        env.pop('GPU_MAX_HW_QUEUES', None)
+        if queues:
+            env['GPU_MAX_HW_QUEUES'] = queues
+        for order in ORDERS:
+            t0 = time.time()
+            p = subprocess.run([sys.executable, os.path.abspath(__file__), order], capture_output=True, text=True, timeout=600, env=env)
+            lines = [ln for ln in p.stdout.splitlines() if ln.startswith('RESULT')]
+            print(lines[-1][7:] if lines else f'{order}: FAILED rc {p.returncode}: ' + (p.stderr.strip().splitlines() or ['?'])[-1][:300], flush=True)
+            print(f'#   ({time.time() - t0:.0f} s)', flush=True)
 
 
 if __name__ == '__main__':
