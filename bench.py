@@ -40,6 +40,7 @@ if ROOT not in sys.path:
 
 os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')   # ROCm 7.2 hipGraph workaround, see lsnet_amd/__init__.py
 os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')             # kernel arguments in device memory, see lsnet_amd/__init__.py
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '2')                 # two hardware queues per process, see lsnet_amd/__init__.py
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -535,6 +536,20 @@ def main():
             dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1)
             comm1 = allreduce_probe(model, dev, 1)
             comm1['rccl_ranks'] = dist.get_world_size()
+            # the TIMED step with the seven bucket all-reduces of every step sent through that group (launched from the hooks
+            # during backward, on RCCL's stream, waited for in finish()) beside the plain step, alternating: the closest
+            # single-GPU proxy of what a rank of an N-GPU run pays besides the wire
+            red = model.reducer
+            t_plain, t_coll = [], []
+            for _ in range(2):
+                red.collective = False
+                t_plain.append(timed_steps(step, data, 5, 1))
+                red.collective = True
+                t_coll.append(timed_steps(step, data, 5, 1))
+            red.collective = False
+            comm1['step_ms_plain'] = min(t_plain) * 1e3
+            comm1['step_ms_with_collectives'] = min(t_coll) * 1e3
+            comm1['step_overhead_frac'] = min(t_coll) / min(t_plain) - 1.0
             dist.destroy_process_group()
             flush_c_stdio()
         except Exception as ex:   # must never take the bench line down
@@ -617,6 +632,11 @@ def main():
         if ks and dominant in ks:
             dom = dominant   # the kernel family with the most GPU time (survey pass), timed here over the K steps
             k = ks[dom]
+            for fam, v in survey.items():      # every family against its own roof
+                if fam in HBM_BOUND:
+                    v['bound'], v['frac'] = 'hbm', v['alg_gbps'] / HBM_PEAK_GBPS
+                else:
+                    v['bound'], v['frac'] = 'mfma', v['tflops'] / peak
             res['kernels'] = survey
             traffic, traffic_note = None, 'not measured'
             try:
@@ -643,6 +663,19 @@ def main():
                                'gflop_per_launch': k['gflop_per_launch'],
                                'alg_gbytes_per_launch': k['alg_gbytes_per_launch'],
                                'ms_per_step': k['total_ms'] / max(nk, 1)}
+            # the whole step: algorithmic flops of every matrix-pipe family of one step (survey pass) / the timed step
+            nsurvey = 3 if not use_graph else max(nk, 1)
+            step_flops = sum(v['gflop_per_launch'] * 1e9 * v['launches'] / nsurvey for f, v in survey.items() if f not in HBM_BOUND)
+            res['roofline']['step_tflops'] = step_flops / (dt / args.steps) / 1e12
+            res['roofline']['step_frac'] = res['roofline']['step_tflops'] / peak
+            if traffic is not None and not hbm:
+                # what the counters say about the same launches: counted HBM bytes per launch / its duration.  A family whose
+                # counted rate is a large share of HBM's while its flop rate is a small share of the matrix pipe's is bound by
+                # the memory system in practice, whatever its algorithmic intensity promises ('bound' stays the paper roof)
+                cg = traffic / (k['avg_ms'] * 1e-3)
+                res['roofline']['counted_gbps'] = cg
+                res['roofline']['counted_hbm_frac'] = cg / HBM_PEAK_GBPS
+                res['roofline']['bound_by_counters'] = 'hbm' if cg / HBM_PEAK_GBPS > k['tflops'] / peak else 'mfma'
         if extra:
             res['extra'] = extra
         if world == 1 and not args.no_cpu_baseline:

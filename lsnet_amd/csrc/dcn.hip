@@ -13,6 +13,7 @@
 
 #include "dcn_kernels.h"
 #include "dcn_mm_kernels.h"
+#include "dcn_grouped_kernels.h"
 #include "prof.h"
 
 namespace lsn {
@@ -401,9 +402,50 @@ static bool pipe_ok(const DcnArgs &a)
     return !((g_dbg_block >> 29) & 1);   // bit 29 of the debug word forces the two-workgroup variant (A/B runs)
 }
 
+// ---- grouped calls (dcn_grouped_kernels.h): ResNeXt's 64 groups of 8 / 16 / 32 channels ----
+static bool grouped_env() { return !((g_dbg_block >> 17) & 1); }   // debug bit 17: the general kernels for grouped calls (tests, A/B)
+
+static bool grouped_fwd_ok(const DcnArgs &a)
+{
+    if (a.groups <= 1 || !grouped_env() || a.C % a.groups != 0 || a.Co != a.C) return false;
+    const int cg = a.C / a.groups;
+    if (!(cg == 8 || cg == 16 || cg == 32) || a.C % GF_CH != 0 || a.C % a.dg != 0 || (a.C / a.dg) % GF_CH != 0) return false;
+    if (dcn_fwd_grouped_lds_bytes(a.kh * a.kw) > 64 * 1024) return false;
+    for (int i = 0; i < a.nlv; ++i)
+        if ((int64_t)a.lv[i].B * a.lv[i].H * a.lv[i].W * a.C >= ((int64_t)1 << 31) || (reinterpret_cast<uintptr_t>(a.lv[i].x) & 15) != 0)
+            return false;
+    return true;
+}
+
+static int launch_forward_grouped(const DcnArgs &a_in, hipStream_t st)
+{
+    DcnArgs a = a_in;
+    int tiles = 0;
+    for (int i = 0; i < a.nlv; ++i) {
+        a.lv[i].tile0 = tiles;
+        tiles += cdiv(a.lv[i].P, GF_PX);
+    }
+    a.ntiles = tiles;
+    ProfScope prof(PROF_FWD, a, st);
+    const size_t lds = dcn_fwd_grouped_lds_bytes(a.kh * a.kw);
+    const dim3 grid(tiles * (a.C / GF_CH));
+    auto go = [&](auto kern) -> int {
+        if (int rc = set_lds(kern, lds)) return rc;
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
+        LSN_HIP(hipGetLastError());
+        return 0;
+    };
+    switch (a.C / a.groups) {
+    case 8: return go(dcn_fwd_grouped_kernel<8>);
+    case 16: return go(dcn_fwd_grouped_kernel<16>);
+    default: return go(dcn_fwd_grouped_kernel<32>);
+    }
+}
+
 static int launch_forward(const DcnArgs &a, hipStream_t st)
 {
     if (a.mm) return launch_forward_mm(a, st);
+    if (grouped_fwd_ok(a)) return launch_forward_grouped(a, st);
     if (a.Co / a.groups <= 64 || !pipe_ok(a)) {
         ProfScope prof(PROF_FWD, a, st);
         return (a.Co / a.groups <= 64) ? launch_forward_t<64, 64, 2, 2>(a, st) : launch_forward_t<64, 256, 1, 4>(a, st);
@@ -962,8 +1004,74 @@ static int launch_wgrad_mm(const DcnArgs &a_in, int nchunks, bool accumulate, hi
     return conv_wgrad_reduce(part, a.gw, nW, part_b, a.gb, a.Co, S, nblk_s, accumulate ? 1 : 0, st);
 }
 
+static bool grouped_wgrad_ok(const DcnArgs &a)
+{
+    if (a.groups <= 1 || !grouped_env() || a.C % a.groups != 0 || a.Co != a.C || a.kh * a.kw > 9) return false;
+    const int cg = a.C / a.groups;
+    if (!(cg == 4 || cg == 8 || cg == 16 || cg == 32) || ((int64_t)a.C * cg) % 256 != 0 || a.C % a.dg != 0) return false;
+    const int nch = cg >= 16 ? cg : 256 / cg;
+    if ((a.C / a.dg) % nch != 0 || a.C % nch != 0) return false;
+    for (int i = 0; i < a.nlv; ++i)
+        if ((int64_t)a.lv[i].B * a.lv[i].H * a.lv[i].W * a.C >= ((int64_t)1 << 31) || (reinterpret_cast<uintptr_t>(a.lv[i].x) & 15) != 0)
+            return false;
+    return true;
+}
+
+// grouped weight gradient (dcn_grouped_kernels.h): pixel splits leave partial tiles, the ordered reduce adds them (or queues)
+static int launch_wgrad_grouped(const DcnArgs &a_in, bool accumulate, hipStream_t st)
+{
+    DcnArgs a = a_in;
+    int64_t rows = 0;
+    for (int i = 0; i < a.nlv; ++i) {
+        a.lv[i].prow0 = (int)rows;      // (the numbering of the backward-data pass's table, when there is one)
+        rows += a.lv[i].P;
+    }
+    if (rows >= ((int64_t)1 << 30)) return 1;
+    if ((reinterpret_cast<uintptr_t>(a.gtap) & 15) != 0 || a.gtap_rows != (int)rows) a.gtap = nullptr;
+    const int K = a.kh * a.kw, cg = a.C / a.groups;
+    const int ny = (int)((int64_t)a.C * cg / 256);
+    const int nch = cg >= 16 ? cg : 256 / cg, nco = 256 / cg;
+    int splits = cdiv(3072, ny);                               // ~12 workgroups per CU: the kernel lives on loads in flight
+    int per = cdiv((int)rows, splits);
+    per = cdiv(per, GRP_PB) * GRP_PB;
+    if (per < 4 * GRP_PB) per = 4 * GRP_PB;
+    splits = cdiv((int)rows, per);
+    const size_t nW = (size_t)a.Co * K * cg;
+    const size_t cap = ((size_t)256 << 20) / 4 / (nW + a.Co);  // partial tiles: at most 256 MB
+    if ((size_t)splits > cap) {
+        splits = (int)(cap > 0 ? cap : 1);
+        per = cdiv(cdiv((int)rows, splits), GRP_PB) * GRP_PB;
+        splits = cdiv((int)rows, per);
+    }
+    float *base = nullptr;
+    if (int rc = conv_scratch((size_t)splits * (nW + a.Co) + 16, &base, st)) return rc;
+    float *part = base, *part_b = a.gb ? base + (((size_t)splits * nW + 3) & ~(size_t)3) : nullptr;
+    ProfScope prof(PROF_WGRAD, a, st);
+    const size_t lds = dcn_wgrad_grouped_lds_bytes(K, nch, nco);
+    const dim3 grid(splits, ny);
+    auto go = [&](auto kern) -> int {
+        if (int rc = set_lds(kern, lds)) return rc;
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a, (int)rows, per, part, part_b);
+        LSN_HIP(hipGetLastError());
+        return 0;
+    };
+    int rc;
+    switch (cg) {
+    case 4: rc = go(dcn_wgrad_grouped_kernel<4, 9>); break;
+    case 8: rc = go(dcn_wgrad_grouped_kernel<8, 9>); break;
+    case 16: rc = go(dcn_wgrad_grouped_kernel<16, 9>); break;
+    default: rc = go(dcn_wgrad_grouped_kernel<32, 9>); break;
+    }
+    if (rc) return rc;
+    return conv_wgrad_reduce(part, a.gw, nW, part_b, a.gb, a.Co, splits, splits, accumulate ? 1 : 0, st);
+}
+
 static int launch_wgrad(const DcnArgs &a_in, int nsteps, bool accumulate, hipStream_t st)
 {
+    if (grouped_wgrad_ok(a_in) && a_in.opitch == a_in.Co && ((size_t)a_in.Co * a_in.kh * a_in.kw * (a_in.C / a_in.groups)) % 4 == 0) {
+        const int rc = launch_wgrad_grouped(a_in, accumulate, st);
+        if (rc != 1) return rc;
+    }
     if (mm_wgrad_ok(a_in)) {
         const int rc = launch_wgrad_mm(a_in, nsteps, accumulate, st);
         if (rc != 1) return rc;   // 1: not served (sizes), fall through

@@ -22,10 +22,12 @@ def side_stream(device=None):
     if st is None:
         st = _side[idx] = torch.cuda.Stream(torch.device('cuda', idx))
         if CLAIM_QUEUE:
-            # A stream gets its hardware queue with its first SUBMISSION, not at creation (profiles/r6_rccl_streams.txt: with the
-            # library's stream and RCCL's streams submitting first -- what DataParallelModel's warm-up and first broadcast do in a
-            # data-parallel process -- this stream came fourth, landed on the queue of the step's stream and every step took 49 ms
-            # instead of 31.5).  One empty-handed kernel now: the second queue of the process is this stream's.
+            # What decides which streams share a hardware queue is the order of their first SUBMISSIONS, not of their creation
+            # (profiles/r6_rccl_streams.txt, default queue count: of ten orders of {this stream, the library's, RCCL's} only those in
+            # which this stream submits first and the library's second run the step at 32 ms; DataParallelModel's round-5
+            # arrangement -- create this stream, warm the library's, then the first broadcast -- was one of the 49 ms orders because
+            # this stream had submitted nothing by then).  One empty-handed kernel now.  The package also asks for two hardware
+            # queues (lsnet_amd/__init__.py), with which every order measured fine; this claim covers a user's own setting.
             with torch.cuda.stream(st):
                 torch.zeros(1, device=torch.device('cuda', idx)).add_(1.0)
             st.synchronize()

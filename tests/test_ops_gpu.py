@@ -80,6 +80,11 @@ DCN_CASES = [
     dict(name='x101_l2_s2', C=512, Co=512, groups=64, stride=2, hw=(50, 84), bias=False),
     dict(name='x101_l3', C=1024, Co=1024, groups=64, hw=(13, 21), bias=False),
     dict(name='x101_l4', C=2048, Co=2048, groups=64, hw=(7, 11), bias=False),
+    # round 6 (dcn_grouped_kernels.h): bias, two deformable groups, a ragged last pixel tile, 16 / 4 channels per group with one
+    # 64-channel span (4 per group: the new weight gradient, the general forward)
+    dict(name='g64_c8_dg2_bias', C=512, Co=512, groups=64, dg=2, hw=(9, 14)),
+    dict(name='g4_c16', C=64, Co=64, groups=4, hw=(9, 12), mask=False),
+    dict(name='g16_c4', C=64, Co=64, groups=16, hw=(7, 9)),
     # Res2Net-50/101 26w x 4s (the headline 53.5-AP backbone): per-scale widths 52 / 104 / 208, the first block of a stage
     # with stride 2 (round 4: the backbone's gradient fixture localised a device-only error to these calls)
     dict(name='r2_l2_s2', C=52, Co=52, stride=2, hw=(24, 32), bias=False),

@@ -95,7 +95,9 @@ def main():
         return child(sys.argv[1])
     print('# LSNet R-50 bbox step (2 x 3x800x1344) by stream creation order; one fresh process per row; RCCL rows all-reduce the 7 gradient '
           'buckets of every step through a one-rank group, launched from the hooks during backward')
-    for queues in (None, '8', '2'):
+    # (profiles/r6_rccl_streams.txt was measured before the package asked for two queues itself, with None = the runtime's default in
+    # the first block; bench.py / lsnet_amd now set GPU_MAX_HW_QUEUES=2 unless the environment says otherwise, so every arm is explicit)
+    for queues in ('4', '8', '2'):
         print(f'## GPU_MAX_HW_QUEUES = {queues or "(runtime default)"}', flush=True)
         env = dict(os.environ)
         env.pop('GPU_MAX_HW_QUEUES', None)
