@@ -40,7 +40,6 @@ if ROOT not in sys.path:
 
 os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')   # ROCm 7.2 hipGraph workaround, see lsnet_amd/__init__.py
 os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')             # kernel arguments in device memory, see lsnet_amd/__init__.py
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '2')                 # two hardware queues per process, see lsnet_amd/__init__.py
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 

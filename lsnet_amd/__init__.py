@@ -18,10 +18,10 @@ _os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')
 # 35.0 ms instead of 32.6 (profiles/r5_env_switches.txt).  1 is the default of this ROCm build; stated here so that the
 # step does not depend on it (read at runtime initialisation like the switch above; a user setting wins).
 _os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')
-# Two hardware queues per process.  A training process has five streams that carry kernels: the step's, the package's second
-# stream (ops/streams.py), the library's own (csrc/dcn.hip), and two of RCCL's once a process group exists.  With the runtime's
-# default number of hardware queues the ORDER in which those streams first submit work decides which of them share a queue, and
-# in eight of ten orders the step of a process with a (one-rank) RCCL group ran 49 ms instead of 31.5 (profiles/r6_rccl_streams.txt);
-# with 8 queues six of ten.  With 2 every order runs 32.1 - 32.3 ms and the step without a process group is unchanged (31.25 vs
-# 31.30 ms, profiles/r6_side_wgrad.txt).  Read at runtime initialisation; a user setting wins.
-_os.environ.setdefault('GPU_MAX_HW_QUEUES', '2')
+# (GPU_MAX_HW_QUEUES is deliberately NOT set here.  With two hardware queues every order in which the process's five
+# kernel-carrying streams -- the step's, the package's second one, the library's, two of RCCL's -- first submit work runs the step at
+# 32.1 - 32.3 ms, where the runtime's default leaves eight of ten orders at 49 ms (profiles/r6_rccl_streams.txt); but a hipGraph
+# replay of the captured step, whose branches want queues of their own, segfaults inside the runtime with two
+# (tests/test_graph_gpu.py, profiles/r6_graph_queues.txt).  The package instead arranges the one order that is fast under the
+# default: ops/streams.py makes the second stream the process's second submitter, DataParallelModel warms the library's stream
+# before the first collective.)

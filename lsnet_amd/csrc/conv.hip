@@ -109,7 +109,13 @@ static int arena_alloc(Arena *ar, size_t floats, float **p)
             ar->p = nullptr, ar->floats = 0;
         }
         float *np = nullptr;
-        LSN_HIP(hipMalloc(reinterpret_cast<void **>(&np), want * sizeof(float)));
+        if (hipMalloc(reinterpret_cast<void **>(&np), want * sizeof(float)) != hipSuccess) {
+            //  no room for the arena: the queue is empty (flushed above), deferral ends for this stream and the call
+            // -- like every later one -- takes the per-stream scratch block with an immediate reduce
+            (void)hipGetLastError();
+            ar->defer_mb = 0, ar->used = 0;
+            return 1;
+        }
         lib_stat(STAT_MALLOCS, 1), lib_stat(STAT_HELD_BYTES, (long long)(want * sizeof(float)));
         ar->p = np, ar->floats = want;
     }
@@ -118,11 +124,21 @@ static int arena_alloc(Arena *ar, size_t floats, float **p)
     return 0;
 }
 
+static bool stream_capturing(hipStream_t st)
+{
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+}
+
 static int part_buffer(size_t floats, float **p, hipStream_t st, bool keep = false)
 {
     if (keep) {
+        // (never while the stream is being captured: a queued reduce is host state, a replay would not run it)
         Arena *ar = arena_of(st, false);
-        if (ar && ar->defer_mb > 0) return arena_alloc(ar, floats, p);
+        if (ar && ar->defer_mb > 0 && !stream_capturing(st)) {
+            const int rc = arena_alloc(ar, floats, p);
+            if (rc != 1) return rc;   // 1: the arena could not be allocated, deferral is off now
+        }
     }
     Scratch *sc = nullptr;
     for (int i = 0; i < g_nscr; ++i)
@@ -800,7 +816,7 @@ int conv_wgrad_reduce(const float *part, float *gw, size_t n, const float *part_
                       int accumulate, hipStream_t st)
 {
     Arena *ar = arena_of(st, false);
-    if (ar && ar->defer_mb > 0 && accumulate) {
+    if (ar && ar->defer_mb > 0 && accumulate && !stream_capturing(st)) {
         // queue instead of launching.  A gradient that already has a queued job is reduced first: two jobs of one launch must
         // not add onto the same addresses.
         const int nj = g_wg_fold ? g_wg_fold->njobs : 1;

@@ -323,7 +323,10 @@ static void dcn_sk_plan(int ntw, int Tall, DcnSk *sk)
     sk->n_dp = ntw, sk->sk_n = 0, sk->sk_tiles = 0, sk->part = nullptr, sk->cnt = nullptr;
     constexpr int SLOTS = 512;
     const bool forced = (g_dbg_block >> 18) & 1;   // debug bit 18: pieces for launches of any size (tests)
-    if (!dcn_sk_env() || Tall < 8 || (ntw < 2 * SLOTS && !forced)) return;
+    // launches of less than HALF a round (a backbone layer of configs 3 / 4: 8 400 pixels = 132 tiles, 2 100 = 33) leave most
+    // of the chip idle as whole tiles: up to four pieces per tile (the dense kernel's rule); between half a round and two
+    // rounds (the tower launch) whole tiles win, see above
+    if (!dcn_sk_env() || Tall < 8 || (ntw >= SLOTS / 2 && ntw < 2 * SLOTS && !forced)) return;
     const int r = ntw % SLOTS;
     if (r == 0 || r > 448) return;
     int per_tile = Tall / 4;

@@ -604,7 +604,13 @@ int lsn_group_norm_forward(int n_levels, const lsn_gn_level *levels, int C, int 
     a.eps = eps;
     a.relu = relu;
     a.mean_rstd = mean_rstd;
-    if (images * G * 2 <= GN_SUMS_CAP) {
+    // (the two alternating buffers are HOST state baked into the launch -- which buffer this call sums into, how much
+    // of the other it clears.  A captured graph replays the capture-time choice, which is right only while replays and eager
+    // calls keep the parity the capture saw; a capturing stream therefore takes the self-contained form: the caller's
+    // workspace and a memset node.)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+    if (images * G * 2 <= GN_SUMS_CAP && !capturing) {
         if (int rc = gn_sums(st, images * G * 2, a)) return rc;
     } else {
         a.sums = reinterpret_cast<double *>(workspace);

@@ -82,6 +82,15 @@ def pending_wgrad_jobs():
     return sum(len(v) for q in list(_live_queues) for v in q.values())
 
 
+def reset_pending():
+    """A new step begins (the reducer's zero_grad): whatever an aborted backward pass left behind -- the armed flag of a callback the
+    engine never ran (it stayed True for the rest of the process and later partial backwards were never flushed), jobs
+    of a graph that will not run again -- goes."""
+    _callback_armed[0] = False
+    for q in list(_live_queues):
+        q.clear()
+
+
 def _flush_pending():
     _callback_armed[0] = False
     for q in list(_live_queues):

@@ -26,8 +26,8 @@ def side_stream(device=None):
             # (profiles/r6_rccl_streams.txt, default queue count: of ten orders of {this stream, the library's, RCCL's} only those in
             # which this stream submits first and the library's second run the step at 32 ms; DataParallelModel's round-5
             # arrangement -- create this stream, warm the library's, then the first broadcast -- was one of the 49 ms orders because
-            # this stream had submitted nothing by then).  One empty-handed kernel now.  The package also asks for two hardware
-            # queues (lsnet_amd/__init__.py), with which every order measured fine; this claim covers a user's own setting.
+            # this stream had submitted nothing by then).  One empty-handed kernel now.  (Two hardware queues --
+            # GPU_MAX_HW_QUEUES=2 -- make every order fast, but hipGraph replay segfaults with them: lsnet_amd/__init__.py.)
             with torch.cuda.stream(st):
                 torch.zeros(1, device=torch.device('cuda', idx)).add_(1.0)
             st.synchronize()

@@ -143,6 +143,8 @@ class BucketedGradReducer:
                 if getattr(p, '_lsn_sink', None) is not v:
                     grad_sink.register(p, v, self._on_sink)
         self._zeroed = True
+        from ..ops import resblock
+        resblock.reset_pending()
         self._defer(True)
 
     def _defer(self, on):

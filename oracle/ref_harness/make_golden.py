@@ -165,6 +165,37 @@ def golden_head_cpv():
     _save('head_cpv', data)
 
 
+def golden_decode_cpv():
+    """Round 6: the REFERENCE's LSCPVHead.get_bboxes (lscpvnet_head.py:905-1090: per-level top-k, decode,
+    corner verification against the stride-8 / stride-16 corner heat maps, multiclass NMS) on gu.cpv_decode_inputs -- head
+    outputs derived from a seed alone, every hard selection away from a tie, so that the checking side holds labels, keep order
+    and the max_per_img cut EXACTLY (tests/golden_cases.py cpv_decode_case)."""
+    import mmcv
+    from mmdet.models import build_head
+    cfg, train_cfg, test_cfg = gu.cpv_head_cfg()
+    cfg = mmcv.Config(copy.deepcopy(cfg))._cfg_dict
+    cfg.update(train_cfg=mmcv.Config(train_cfg), test_cfg=mmcv.Config(test_cfg))
+    head = build_head(cfg)
+    gu.fill_params(head, seed=7)
+    head.eval()
+    data = {}
+    with torch.no_grad():
+        outs = head(gu.head_inputs(11))
+        syn, gap = gu.cpv_decode_inputs(outs, 79)
+        assert gap > 1e-3, gap
+        _, _, _, _, _, metas = _gt_for('bbox')
+        dets = head.get_bboxes(*syn, metas, cfg=mmcv.Config(gu.DECODE_CFG))
+        raw = head.get_bboxes(*syn, metas, cfg=mmcv.Config(gu.DECODE_CFG), nms=False)
+    data['min_gap'] = np.float64(gap)
+    for i, (b, l) in enumerate(dets):
+        print('cpv image', i, len(l), 'detections; top score', float(b[0, 4]) if len(l) else None)
+        assert 20 < len(l) <= gu.DECODE_CFG['max_per_img']
+        data[f'{i}/bboxes'] = b.numpy()
+        data[f'{i}/labels'] = l.numpy()
+        data[f'{i}/raw_bboxes'] = raw[i][0].numpy()       # every candidate's box after corner verification, before NMS
+    _save('decode_cpv', data)
+
+
 def golden_coco_eval():
     """(f-4) COCO metrics of the reference's vendored evaluator (cocoapi/pycocotools: coco.py loadRes, cocoeval.py, its
     maskApi.c bound by pycoco_mask.py) on gu.synthetic_eval_case: boxes, masks (polygons -> RLE), keypoints; also with
@@ -224,7 +255,7 @@ def curve_cfg():
     return cfg
 
 
-def golden_train_curve(lr=0.01, fixture='train_curve'):
+def golden_train_curve(lr=0.01, fixture='train_curve', init0=False):
     """(8d) loss parity over an SGD run: the REFERENCE's detector, losses, optimizer hook (grad clip 35), SGD and
     step-LR warm-up hooks (mmcv runner, mmcv/runner/hooks/{optimizer,lr_updater}.py) for 12 iterations on one
     seeded synthetic batch per iteration, native ops backed by the CPU oracle.  Stores the loss curves, the learning
@@ -238,15 +269,29 @@ def golden_train_curve(lr=0.01, fixture='train_curve'):
     cfg = curve_cfg()
     model_cfg = mmcv.Config(copy.deepcopy(cfg.model.to_dict() if hasattr(cfg.model, 'to_dict') else dict(cfg.model)))._cfg_dict
     model = build_detector(model_cfg, train_cfg=mmcv.Config(dict(cfg.train_cfg)), test_cfg=mmcv.Config(dict(cfg.test_cfg)))
-    gu.fill_params(model, seed=11, head_norm_shift=0.0, pair_gap=1.0)   # (round 4's fill: golden_util.fill_params)
+    if init0:
+        # round 6: the UNTOUCHED seed-0 init_weights model -- the model `python bench.py` trains -- at
+        # 2 x 3 x 384 x 512: the loss starts near 5.4 and moves smoothly, unlike the parameter-fill fixtures whose first iterations
+        # are the collapse of a loss of 442
+        from lsnet_amd.model_zoo import build_lsnet
+        torch.manual_seed(0)
+        own, _ = build_lsnet('bbox', 'r50')
+        missing = model.load_state_dict(own.state_dict(), strict=True)
+        assert not missing.missing_keys and not missing.unexpected_keys
+    else:
+        gu.fill_params(model, seed=11, head_norm_shift=0.0, pair_gap=1.0)   # (round 4's fill: golden_util.fill_params)
     model.train()
     opt = torch.optim.SGD(model.parameters(), lr=lr, momentum=0.9, weight_decay=0.0001)
     logger = logging.getLogger('curve')
     logger.setLevel(logging.ERROR)
     runner = EpochBasedRunner(model, optimizer=opt, work_dir=None, logger=logger)
     runner.register_training_hooks(dict(cfg.lr_config), dict(cfg.optimizer_config), None, dict(interval=10 ** 9, hooks=[]))
-    batches = [synthetic_batch('bbox', 1, *CURVE_HW, boxes_per_img=3, num_classes=80, seed=900 + i, device='cpu',
-                               channels_last=False) for i in range(CURVE_ITERS)]
+    if init0:
+        batches = [synthetic_batch('bbox', 2, *gu.CURVE0_HW, num_classes=80, seed=700 + i, device='cpu', channels_last=False)
+                   for i in range(CURVE_ITERS)]
+    else:
+        batches = [synthetic_batch('bbox', 1, *CURVE_HW, boxes_per_img=3, num_classes=80, seed=900 + i, device='cpu',
+                                   channels_last=False) for i in range(CURVE_ITERS)]
     curves = {k: [] for k in ('loss', 'loss_cls', 'loss_bbox_init', 'loss_bbox_refine', 'lr')}
 
     class Tap(mmcv.runner.Hook):
@@ -413,15 +458,43 @@ def golden_backbones_dcn():
     from mmdet.models import build_backbone
     sys.path.insert(0, '/root/repo')
     from lsnet_amd.model_zoo import backbone_cfg
+    def relu_margin(bb, x):
+        """smallest |pre-activation| of any ReLU of the network, relative to the largest of the same tensor: how far the
+        forward pass stays from the kinks of the network (an implementation whose sums differ in the last bits flips a gate
+        whose pre-activation lies within ~1e-6 of zero, and a flip deep in the network moves a patch of the input gradient)"""
+        worst = [float('inf')]
+
+        def pre(mod, inp):
+            t = inp[0].detach()
+            worst[0] = min(worst[0], float(t.abs().min() / t.abs().max().clamp_min(1e-30)))
+        hooks = [m.register_forward_pre_hook(pre) for m in bb.modules() if isinstance(m, torch.nn.ReLU)]
+        with torch.no_grad():
+            bb(x)
+        for h in hooks:
+            h.remove()
+        return worst[0]
+
     for name, fixture in (('r101-dcn', 'backbone_r101_dcn'), ('x101-dcn', 'backbone_x101_dcn')):
         cfg = backbone_cfg(name)
         cfg.pop('with_cp', None)
         bb = build_backbone(mmcv.Config(copy.deepcopy(cfg))._cfg_dict)
-        gu.fill_params(bb, seed=13)
         bb.train()
+        # round 6 (VERDICT r5 item 5c): the X-101 fixture's parameter fill is the first seed whose forward pass keeps every ReLU
+        # pre-activation at least 4e-6 of its tensor's range away from zero (seed 13, rounds 3 - 5: 0.28 % of the input-gradient
+        # samples moved by more than 1e-3 on the device -- flipped gates of a 101-layer network).  The seed travels in the fixture.
+        seed = 13
+        if name == 'x101-dcn':
+            xs = torch.randn(1, 3, 96, 128, generator=gu.gen(41))
+            for seed in range(13, 80):
+                gu.fill_params(bb, seed=seed)
+                m = relu_margin(bb, xs)
+                print(f'x101-dcn fill seed {seed}: ReLU margin {m:.2e}', flush=True)
+                if m >= 4e-6:
+                    break
+        gu.fill_params(bb, seed=seed)
         x = torch.randn(1, 3, 96, 128, generator=gu.gen(41)).requires_grad_()
         data = {'keys': np.array(sorted(bb.state_dict().keys())),
-                'nparams': np.array(sum(p.numel() for p in bb.parameters()))}
+                'nparams': np.array(sum(p.numel() for p in bb.parameters())), 'fill_seed': np.array(seed)}
         feats = bb(x)
         proj = sum((f * torch.randn(f.shape, generator=gu.gen(50 + i))).sum() / f.numel() ** 0.5 for i, f in enumerate(feats))
         names = gu.backbone_grad_names(bb)
@@ -693,10 +766,10 @@ def golden_data_pipeline():
     _save('data_pipeline', data)
 
 
-ALL = dict(decode=golden_decode, backbones_dcn=golden_backbones_dcn, bench_iter0=golden_bench_iter0, train_curve=golden_train_curve,
+ALL = dict(decode=golden_decode, decode_cpv=golden_decode_cpv, backbones_dcn=golden_backbones_dcn, bench_iter0=golden_bench_iter0, train_curve=golden_train_curve,
            # the same run at a tenth of the learning rate: the loss falls 475 -> 60 instead of 475 -> 1 and rounding
            # differences between two correct implementations stay at rounding level over all twelve iterations
-           train_curve_lowlr=lambda: golden_train_curve(0.001, 'train_curve_lowlr'), coco_eval=golden_coco_eval, head_cpv=golden_head_cpv, data_pipeline=golden_data_pipeline, gt_formats=golden_gt_formats, res2net=golden_res2net, vote=golden_vote, head_bbox=lambda: golden_head('bbox'), head_segm=lambda: golden_head('segm'),
+           train_curve_lowlr=lambda: golden_train_curve(0.001, 'train_curve_lowlr'), train_curve_init0=lambda: golden_train_curve(0.01, 'train_curve_init0', init0=True), coco_eval=golden_coco_eval, head_cpv=golden_head_cpv, data_pipeline=golden_data_pipeline, gt_formats=golden_gt_formats, res2net=golden_res2net, vote=golden_vote, head_bbox=lambda: golden_head('bbox'), head_segm=lambda: golden_head('segm'),
            head_bbox_256=lambda: golden_head('bbox', 256),
            head_pose_bbox=lambda: golden_head('pose_bbox'), head_pose_kbox=lambda: golden_head('pose_kbox'),
            assign=golden_assign, cross_iou=golden_cross_iou, backbone=golden_backbone, nms=golden_nms)

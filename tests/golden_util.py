@@ -274,6 +274,27 @@ def decode_inputs(outs, seed, num_classes=8):
     return new, min_gap
 
 
+def cpv_decode_inputs(outs, seed, num_classes=8):
+    """decode_inputs for LSCPVHead.forward's six lists (cls, bbox_init, bbox_refine, hm_score, hm_offset, sem): the corner
+    verification of the decode adds two hard selections -- floor(coordinate / stride), exact IEEE arithmetic on identical bits,
+    and the arg-max of 2x2 windows of sigmoid(hm_score) -- so the corner heat-map logits are a random permutation of an evenly
+    spaced grid over [-4, 4] per image and channel (neighbouring values differ by >= 8 / cells: 2.6e-3 at stride 8, which no two
+    sigmoid implementations reorder), the sub-cell offsets uniform in [0, 1)."""
+    new, gap = decode_inputs(outs, seed, num_classes)
+    g = gen(seed + 1)
+    for i, t in enumerate(outs[3]):
+        B, Cc, H, W = t.shape
+        n = H * W
+        m = torch.empty(B, Cc, n)
+        for b in range(B):
+            for c in range(Cc):
+                m[b, c] = (-4.0 + 8.0 * (torch.randperm(n, generator=g).double() + 0.5) / n).float()
+        new[3][i] = m.reshape(B, Cc, H, W)
+    for i, t in enumerate(outs[4]):
+        new[4][i] = torch.rand(tuple(t.shape), generator=g)
+    return new, gap
+
+
 HEAD_IMG = (384, 512)   # -> grids 48x64, 24x32, 12x16, 6x8, 3x4 (>= 9 cells on every level for ATSS)
 
 
@@ -420,3 +441,6 @@ def backbone_grad_names(bb):
                 if n in params and params[n].requires_grad:
                     names.append(n)
     return names
+
+
+CURVE0_HW = (384, 512)   # training-curve fixture of the seed-0 init_weights model: 2 images of this size per iteration

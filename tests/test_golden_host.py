@@ -19,6 +19,10 @@ def test_decode_is_exact(task, cpu_oracle_backend):
     gc.decode_case(task, CPU)
 
 
+def test_cpv_decode_is_exact(cpu_oracle_backend):
+    gc.cpv_decode_case(CPU)
+
+
 def test_assigners_exact():
     gc.assign_case(CPU)
 

@@ -19,3 +19,11 @@ def test_cpv_head_forward_loss_backward_decode(channels_last):
         print('cpv', 'channels_last' if channels_last else 'contiguous', f'worst sample err {worst:.2e}')
     finally:
         print('cpv', 'channels_last' if channels_last else 'contiguous', gu.stats_report())
+
+
+@pytest.mark.parametrize('channels_last', [False, True], ids=['nchw', 'nhwc'])
+def test_cpv_decode_is_exact_on_the_device(channels_last):
+    """Round 6: LSCPVHead.get_bboxes against the reference's on bit-identical inputs (decode_cpv.npz): the
+    corner-verified candidate boxes, labels, keep order and the max_per_img cut np.array_equal on the MI355X."""
+    assert torch.cuda.is_available()
+    gc.cpv_decode_case(torch.device('cuda:0'), channels_last)
