@@ -390,15 +390,10 @@ static int launch_forward_t(const DcnArgs &a, hipStream_t st)
     return 0;
 }
 
-static size_t pipe_lds_bytes(const DcnArgs &a)
+// the split one-workgroup-per-CU kernel (dcn_fwd_xn_kernel) needs float4 rows and 32-bit byte offsets into x and w
+static bool xn_ok(const DcnArgs &a)
 {
-    return (size_t)2 * (PIPE_BM + PIPE_BN) * PIPE_LDK * 4 + (size_t)PIPE_BM * a.kh * a.kw * a.dg * sizeof(Tap);
-}
-
-// the pipelined kernel needs float4 rows and 32-bit byte offsets into x and w (buffer addressing)
-static bool pipe_ok(const DcnArgs &a)
-{
-    if (a.Co / a.groups <= 64 || !vec_ok(a) || pipe_lds_bytes(a) > 160 * 1024) return false;
+    if (a.Co / a.groups <= 64 || !vec_ok(a)) return false;
     if ((int64_t)a.Co * a.kh * a.kw * (a.C / a.groups) * 4 >= (int64_t)1 << 31) return false;
     for (int i = 0; i < a.nlv; ++i)
         if ((int64_t)a.lv[i].B * a.lv[i].H * a.lv[i].W * a.C * 4 >= (int64_t)1 << 31) return false;
@@ -449,40 +444,23 @@ static int launch_forward(const DcnArgs &a, hipStream_t st)
 {
     if (a.mm) return launch_forward_mm(a, st);
     if (grouped_fwd_ok(a)) return launch_forward_grouped(a, st);
-    if (a.Co / a.groups <= 64 || !pipe_ok(a)) {
+    const int np = math_np(), KDf = a.kh * a.kw * a.dg;
+    // exact fp32 (LSN_MATH_FP32, narrow outputs, odd channel counts): the fp32-MFMA kernel with two workgroups per CU
+    if (np == 0 || !xn_ok(a) || (np == 6 ? xn_lds_bytes<6>(KDf) : xn_lds_bytes<3>(KDf)) > 160 * 1024) {
         ProfScope prof(PROF_FWD, a, st);
         return (a.Co / a.groups <= 64) ? launch_forward_t<64, 64, 2, 2>(a, st) : launch_forward_t<64, 256, 1, 4>(a, st);
     }
     dim3 grid(a.ntiles, cdiv(a.Co / a.groups, PIPE_BN), a.groups);
-    const int np = math_np(), KDf = a.kh * a.kw * a.dg;
-    if (np && (np == 6 ? xn_lds_bytes<6>(KDf) : xn_lds_bytes<3>(KDf)) <= 160 * 1024) {
-        ProfScope prof(PROF_FWD, a, st);
-        const size_t ldsn = np == 6 ? xn_lds_bytes<6>(KDf) : xn_lds_bytes<3>(KDf);
-        auto gox = [&](auto kern) -> int {
-            if (int rc = set_lds(kern, ldsn)) return rc;
-            hipLaunchKernelGGL(kern, grid, dim3(256), ldsn, st, a);
-            LSN_HIP(hipGetLastError());
-            return 0;
-        };
-        if (np == 6) return a.wtp ? gox(dcn_fwd_xn_kernel<true, 6>) : gox(dcn_fwd_xn_kernel<false, 6>);
-        return a.wtp ? gox(dcn_fwd_xn_kernel<true, 3>) : gox(dcn_fwd_xn_kernel<false, 3>);
-    }
-    const size_t lds = pipe_lds_bytes(a);
-    auto go = [&](auto kern) -> int {
-        if (int rc = set_lds(kern, lds)) return rc;
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
+    ProfScope prof(PROF_FWD, a, st);
+    const size_t ldsn = np == 6 ? xn_lds_bytes<6>(KDf) : xn_lds_bytes<3>(KDf);
+    auto gox = [&](auto kern) -> int {
+        if (int rc = set_lds(kern, ldsn)) return rc;
+        hipLaunchKernelGGL(kern, grid, dim3(256), ldsn, st, a);
         LSN_HIP(hipGetLastError());
         return 0;
     };
-    ProfScope prof(PROF_FWD, a, st);
-    switch ((g_dbg_block >> 20) & 15) {   // diagnostic ablations (tools/phase_clocks.py); 0 in production
-    case 1: return go(dcn_fwd_pipe_kernel<1>);
-    case 2: return go(dcn_fwd_pipe_kernel<2>);
-    case 3: return go(dcn_fwd_pipe_kernel<3>);
-    case 6: return go(dcn_fwd_pipe_kernel<6>);
-    case 10: return go(dcn_fwd_pipe_kernel<10>);
-    default: return go(dcn_fwd_pipe_kernel<0>);
-    }
+    if (np == 6) return a.wtp ? gox(dcn_fwd_xn_kernel<true, 6>) : gox(dcn_fwd_xn_kernel<false, 6>);
+    return a.wtp ? gox(dcn_fwd_xn_kernel<true, 3>) : gox(dcn_fwd_xn_kernel<false, 3>);
 }
 
 template <int RED>
@@ -521,15 +499,20 @@ static bool bwd_colbuf_env()
     return !((g_dbg_block >> 23) & 1);   // bit 23 of the debug word forces the atomic scatter kernels (tests)
 }
 
-// grouped calls (config 4: 64 groups) on the atomic-free path: dcn_gcol_grouped_kernel in front of the gather pass.  Every
-// math mode (the kernel is exact fp32); levels that want offset / mask gradients must want grad_input (anchor lists).
+// Exact-fp32 column gradients (dcn_gcol_grouped_kernel: fmaf chains per group) in front of the gather pass: grouped calls
+// (config 4: 64 groups) in every math mode, and -- round 6 -- EVERY call of LSN_MATH_FP32: the exact mode used to scatter
+// with fp32 atomics (round 1's kernels) and was the less reproducible, less exact of the modes; it now
+// shares the atomic-free, bit-reproducible gather with the default mode and differs from it in the GEMM arithmetic only.
+// Levels that want offset / mask gradients must want grad_input (anchor lists).
 static bool bwd_grouped_ok(const DcnArgs &a)
 {
-    if (a.groups <= 1 || a.C % a.groups != 0 || a.Co % a.groups != 0 || (a.C / a.groups) % 4 != 0 || a.C % a.dg != 0) return false;
+    if (a.groups <= 1 && math_np() != 0) return false;
+    if (a.C % a.groups != 0 || a.Co % a.groups != 0 || (a.C / a.groups) % 4 != 0 || a.C % a.dg != 0) return false;
     if ((a.C / a.dg) % 4 != 0 || !bwd_colbuf_env()) return false;
     for (int i = 0; i < a.nlv; ++i) {
         if ((a.lv[i].goff || a.lv[i].gmsk) && !a.lv[i].gx) return false;
         if ((int64_t)a.lv[i].B * a.lv[i].H * a.lv[i].W * a.C * 4 >= ((int64_t)1 << 31)) return false;
+        if ((int64_t)a.lv[i].P * a.kh * a.kw * a.C * 4 >= ((int64_t)1 << 31)) return false;
     }
     return true;
 }
@@ -544,55 +527,6 @@ static bool bwd_gather_ok(const DcnArgs &a)
     for (int i = 0; i < a.nlv; ++i)   // 32-bit offsets into the level's column-gradient rows
         if ((int64_t)a.lv[i].P * a.kh * a.kw * a.C * 4 >= ((int64_t)1 << 31)) return false;
     return true;
-}
-
-// windowed-scatter variant: 16x8 output patches (its own tile table), see dcn_kernels.h
-static bool bwd_win_ok(const DcnArgs &a)
-{
-    const int KD = a.kh * a.kw * a.dg, RED = (a.Co / a.groups > 64) ? 256 : 64;
-    if (bwd_win_lds_bytes(RED, KD) > 160 * 1024) return false;
-    for (int i = 0; i < a.nlv; ++i)
-        if (a.lv[i].H > 32767 || a.lv[i].W > 32767) return false;   // 15-bit packed window coordinates
-    if ((g_dbg_block >> 25) & 1) return false;   // bits 25 / 24 of the debug word force one kernel (A/B runs)
-    if ((g_dbg_block >> 24) & 1) return true;
-    // Measured in the LSNet step (profiles/, bench.py kernel timers).  Exact fp32: the windowed kernel beat the first
-    // kernel on the pyramid op (3.76 vs 4.23 ms) and lost on the tower convolutions (1.46 vs 1.33 ms).  Split bf16:
-    // merged-scatter kernel 1.0 ms (towers) / 2.7 ms (pyramid); windowed kernel with the GEMM on the matrix pipe
-    // 1.0 ms / 1.95 ms.  So a launch that resamples (scale != 1: the pyramid op, whose samples travel far and
-    // converge on landmarks) takes the windowed kernel, everything else the merged-scatter kernel.
-    for (int i = 0; i < a.nlv; ++i)
-        if (a.lv[i].sh != 1.f || a.lv[i].sw != 1.f) return true;
-    return false;
-}
-
-template <int RED>
-static int launch_bwd_data_win_t(DcnArgs a, hipStream_t st)
-{
-    int tiles = 0;
-    for (int i = 0; i < a.nlv; ++i) {
-        a.lv[i].tile0 = tiles;
-        tiles += a.lv[i].B * cdiv(a.lv[i].Ho, BW3_PH) * cdiv(a.lv[i].Wo, BW3_PW);
-    }
-    a.ntiles = tiles;
-    if (RED == 256 && math_np() == 3 && bwd_x3_ok(a) && bwd_win_x3_lds_bytes(a.kh * a.kw * a.dg) <= 160 * 1024) {
-        const size_t lds3 = bwd_win_x3_lds_bytes(a.kh * a.kw * a.dg);   // GEMM on the bf16 matrix pipe
-        if (int rc = set_lds(dcn_bwd_data_win_x3_kernel, lds3)) return rc;
-        hipLaunchKernelGGL(dcn_bwd_data_win_x3_kernel, dim3(tiles), dim3(512), lds3, st, a);
-        LSN_HIP(hipGetLastError());
-        return 0;
-    }
-    const size_t lds = bwd_win_lds_bytes(RED, a.kh * a.kw * a.dg);
-    if (vec_ok(a)) {
-        auto k = dcn_bwd_data_win_kernel<RED, true>;
-        if (int rc = set_lds(k, lds)) return rc;
-        hipLaunchKernelGGL(k, dim3(tiles), dim3(512), lds, st, a);
-    } else {
-        auto k = dcn_bwd_data_win_kernel<RED, false>;
-        if (int rc = set_lds(k, lds)) return rc;
-        hipLaunchKernelGGL(k, dim3(tiles), dim3(512), lds, st, a);
-    }
-    LSN_HIP(hipGetLastError());
-    return 0;
 }
 
 // ---- atomic-free grad_input: workspace plan of the bin / scan / fill / sort / gather sequence (dcn_kernels.h) ----
@@ -818,7 +752,7 @@ static int launch_bwd_colbuf(DcnArgs &a, GatherPlan &pl, unsigned char *ws, hipS
         st = st_main;
     }
     float *Hb = nullptr;
-    const bool grouped = a.groups > 1;
+    const bool grouped = a.groups > 1 || NP == 0;   // (NP = 0: LSN_MATH_FP32, every call)
     if (grouped) {   // exact-fp32 column gradients per group, unweighted; the gather pass does the rest as for the dense GEMM
         const long long nquads = (long long)pl.nsamples / a.dg * (a.C / 4);
         const int blocks = (int)((nquads + 255) / 256 < 16384 ? (nquads + 255) / 256 : 16384);
@@ -839,11 +773,12 @@ static int launch_bwd_colbuf(DcnArgs &a, GatherPlan &pl, unsigned char *ws, hipS
         if (int rc = conv_mm_rows(a.nlv, xs, outs, rows, a.Co, a.opitch, a.kh * a.kw * a.C, a.wtp, st)) return rc;
         if (side) LSN_HIP(hipStreamWaitEvent(st_main, side->join, 0));
         if (any_off) Hb = reinterpret_cast<float *>(ws + pl.o_H);
-    } else {
+    } else if constexpr (NP != 0) {
         size_t lds = bwd_xn_lds_bytes(NP, a.kh * a.kw * a.dg);
-        if ((g_dbg_block >> 22) & 1) lds = 100 * 1024;   // diagnostic: one workgroup per CU
         if (int rc = set_lds(dcn_bwd_data_xn_kernel<NP, true>, lds)) return rc;
         hipLaunchKernelGGL((dcn_bwd_data_xn_kernel<NP, true>), dim3(a.ntiles, bwd_tap_groups(a)), dim3(256), lds, st, a);
+    } else {
+        return fail(LSN_ERR_RUNTIME, "deformable backward: exact mode without the exact column-gradient kernel");
     }
     pl.ga.raw = pl.aa.raw = (a.mm || grouped) ? 1 : 0;
     pl.ga.Hb = pl.aa.Hb = Hb;
@@ -882,9 +817,9 @@ static int launch_bwd_data(DcnArgs &a, void *gather_ws, size_t gather_ws_bytes, 
         GatherPlan pl;
         gather_plan(a, pl);
         if (pl.ok && pl.bytes <= gather_ws_bytes) {
-            const int rc = np == 3 ? launch_bwd_colbuf<3>(a, pl, reinterpret_cast<unsigned char *>(gather_ws), st)
-                                   : launch_bwd_colbuf<6>(a, pl, reinterpret_cast<unsigned char *>(gather_ws), st);
-            return rc;
+            unsigned char *ws = reinterpret_cast<unsigned char *>(gather_ws);
+            return np == 3 ? launch_bwd_colbuf<3>(a, pl, ws, st) : np == 6 ? launch_bwd_colbuf<6>(a, pl, ws, st)
+                                                                           : launch_bwd_colbuf<0>(a, pl, ws, st);
         }
     }
     if (a.mm) return fail(LSN_ERR_RUNTIME, "deformable backward: fragment-order weights without the gather path");
@@ -892,7 +827,7 @@ static int launch_bwd_data(DcnArgs &a, void *gather_ws, size_t gather_ws_bytes, 
     for (int i = 0; i < a.nlv; ++i)   // the scatter kernels accumulate: start from zero (once per buffer is enough)
         if (a.lv[i].gx)
             LSN_HIP(hipMemsetAsync(a.lv[i].gx, 0, sizeof(float) * (size_t)a.lv[i].B * a.lv[i].H * a.lv[i].W * a.C, st));
-    if (bwd_x3_ok(a) && (np == 6 || !bwd_win_ok(a))) {
+    if (bwd_x3_ok(a)) {
         const size_t lds = bwd_xn_lds_bytes(np, a.kh * a.kw * a.dg);
         auto gox = [&](auto kern) -> int {
             if (int rc = set_lds(kern, lds)) return rc;
@@ -902,8 +837,6 @@ static int launch_bwd_data(DcnArgs &a, void *gather_ws, size_t gather_ws_bytes, 
         };
         return np == 6 ? gox(dcn_bwd_data_xn_kernel<6, false>) : gox(dcn_bwd_data_xn_kernel<3, false>);
     }
-    if (bwd_win_ok(a))
-        return (a.Co / a.groups > 64) ? launch_bwd_data_win_t<256>(a, st) : launch_bwd_data_win_t<64>(a, st);
     return (a.Co / a.groups > 64) ? launch_bwd_data_t<256>(a, st) : launch_bwd_data_t<64>(a, st);
 }
 
@@ -1095,7 +1028,7 @@ static int launch_wgrad(const DcnArgs &a_in, int nsteps, bool accumulate, hipStr
     // split-bf16 kernels: one partial gradient per pixel split + an ordered reduce instead of fp32 atomics (deterministic);
     // a block that runs no step still stores its zero tile, so every partial element is written
     const size_t nW = (size_t)a.Co * K * Cg;
-    const bool ordered = math_np() && !((g_dbg_block >> 30) & 1) && nW % 4 == 0 &&
+    const bool ordered = !((g_dbg_block >> 30) & 1) && nW % 4 == 0 &&
                          (size_t)splits * (nW + a.Co) * sizeof(float) <= ((size_t)256 << 20);
     if (ordered) {
         float *base = nullptr;
@@ -1107,6 +1040,14 @@ static int launch_wgrad(const DcnArgs &a_in, int nsteps, bool accumulate, hipStr
         if (a.gb) LSN_HIP(hipMemsetAsync(a.gb, 0, sizeof(float) * (size_t)a.Co, st));
     }
     ProfScope prof(PROF_WGRAD, a, st);
+    if (ordered && math_np() == 0) {   // exact fp32 (fp32 MFMA), partial gradients per split: deterministic
+        if (vec_ok(a))
+            hipLaunchKernelGGL(dcn_wgrad_kernel<true>, dim3(ncol, splits, nz), dim3(256), lds, st, a, nsteps);
+        else
+            hipLaunchKernelGGL(dcn_wgrad_kernel<false>, dim3(ncol, splits, nz), dim3(256), lds, st, a, nsteps);
+        LSN_HIP(hipGetLastError());
+        return conv_wgrad_reduce(a.wg_part, a.gw, nW, a.wg_part_b, a.gb, a.Co, splits, splits, accumulate ? 1 : 0, st);
+    }
     if (ordered) {
         const size_t ldsn = math_np() == 6 ? wgrad_xn_lds_bytes<6>() : wgrad_xn_lds_bytes<3>();
         auto kern = math_np() == 6 ? dcn_wgrad_xn_kernel<false, 6> : dcn_wgrad_xn_kernel<false, 3>;
@@ -1178,7 +1119,7 @@ static int dcn_forward_impl(const lsn_dcn_shape &s, int n, const lsn_dcn_level *
                     "(lsn_dcn_pitched_ok)", a.opitch, a.Co);
     if (s.workspace && mm_fwd_ok(a)) {
         if (int rc = mm_prepare_weights(a, false, s.workspace, st)) return rc;
-    } else if (s.workspace && math_np() && (Cg % 8 == 0) && a.Co / a.groups > 64 && pipe_ok(a)) {
+    } else if (s.workspace && math_np() && (Cg % 8 == 0) && a.Co / a.groups > 64 && xn_ok(a)) {
         const size_t nw = (size_t)s.Co * K * Cg;   // split the weights once instead of in every block
         if (math_np() == 6)
             hipLaunchKernelGGL(dcn_prepare_w_kernel<3>, dim3(512), dim3(256), 0, st, a.w,
@@ -1504,7 +1445,6 @@ int64_t lsn_dcn_backward_workspace_bytes(const lsn_dcn_shape *shape, int n_level
 {
     using namespace lsn;
     if (!shape || !levels || !bwd_colbuf_env()) return 0;
-    if (shape->groups == 1 && math_np() == 0) return 0;   // (exact mode, dense: the fp32-MFMA scatter kernels)
     if (check_shape(*shape) != 0) return 0;
     DcnArgs a;
     if (fill_levels(a, *shape, n_levels, levels, BWD_BM) != 0) return 0;

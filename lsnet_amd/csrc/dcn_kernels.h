@@ -327,14 +327,9 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_kernel(const DcnArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const bool abl_no_x = (a.dbg_block >> 21) & 1, abl_no_w = (a.dbg_block >> 20) & 1;  // tuning ablations
     auto load_chunk = [&](int t) {
         const Chunk ch = decode_chunk<BK>(a, g, t, segs, ncc);
         const int c = g * Cg + ch.c0 + (kk < ch.nval ? kk : 0);
-        if (abl_no_x) {
-#pragma unroll
-            for (int ps = 0; ps < NPA; ++ps) xv[ps][0] = xv[ps][1] = xv[ps][2] = xv[ps][3] = 1.f;
-        } else
 #pragma unroll
         for (int ps = 0; ps < NPA; ++ps) {
             const Tap *tp = &tab[(ps * 8 + prow) * KD + ch.dgi * K + ch.k];
@@ -346,10 +341,6 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_kernel(const DcnArgs a)
         }
         const float *wbase = a.w + (size_t)co_base * Kdim + ch.k * Cg + ch.c0;
         const int rem = ch.nval - wq * 4;
-        if (abl_no_w) {
-#pragma unroll
-            for (int ps = 0; ps < NPB; ++ps) wv[ps] = make_float4(1.f, 1.f, 1.f, 1.f);
-        } else
 #pragma unroll
         for (int ps = 0; ps < NPB; ++ps) {
             const int col = ps * 32 + wrow;
@@ -433,27 +424,9 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_kernel(const DcnArgs a)
         }
 }
 
-// =============================================================================================
-// Forward, software-pipelined kernel for wide layers (Co/groups > 64, channel counts % 4 == 0).
-//
-// What the measurements on MI355X said (tools/phase_clocks.py, tools/ablate_fwd.py):
-//   * the two-workgroups-per-CU kernel above is NOT memory bound (removing every global load only takes
-//     it from 0.80 to 0.63 ms): its staging phases are instruction/latency bound, and
-//   * they do not overlap the partner workgroup's MFMA phase -- a wave issuing back-to-back fp32 MFMAs
-//     starves its SIMD partner's VALU/LDS issue (staging 2.3k -> 5.7k cycles, s_setprio does not help).
-// A wave's OWN independent instructions do issue in the 64-cycle shadow of its MFMAs.  So: ONE
-// workgroup per CU (one wave per SIMD), double-buffered LDS, and every wave interleaves per k-step
-//     4 MFMAs of chunk t | 1/16 of the staging of chunk t+1 | 1/16 of the loads of chunk t+2
-// with one barrier per chunk; and the staging stream is cut to ~110 instructions per chunk:
-//   * sampling offsets / corner weights of the thread's 8 pixels live in REGISTERS for all chunks of a
-//     tap (no LDS table reads, no address arithmetic in the loop);
-//   * gathers and weight rows are raw buffer loads (32-bit per-lane offset + scalar chunk offset,
-//     hardware bounds check returns 0 for out-of-range rows);
-//   * LDS rows are 36 floats (16-byte aligned): weight rows are written with ds_write_b128, and MFMA
-//     operands are fetched with ds_read_b128 by assigning k = 16*h + s to k-step s of lane-half h
-//     (each lane reads 16 contiguous floats of its row per chunk) -- conflict-free (36*i mod 64 is a
-//     distinct multiple of 4 for the 16 lanes of a b128 group).
-// =============================================================================================
+// Raw buffer loads (32-bit per-lane offset + scalar offset, the hardware bounds check returns 0 beyond num_records) and the
+// tile constants of the one-workgroup-per-CU kernels.  (Rounds 1 - 5 kept an fp32 software-pipelined forward here,
+// dcn_fwd_pipe_kernel; round 6 removed it with the windowed scatter kernels: exact fp32 is dcn_fwd_kernel.)
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float buf_load_f32(__amdgpu_buffer_rsrc_t rs, int voff, int soff)
@@ -481,236 +454,6 @@ __device__ __forceinline__ float2 buf_load_f32x2(__amdgpu_buffer_rsrc_t rs, int 
 }
 
 constexpr int PIPE_BM = 64, PIPE_BN = 256, PIPE_BK = 32, PIPE_LDK = 36;
-
-// ABL (diagnostic builds of the same kernel): bit 0 drops the LDS commits, bit 1 the global-load issues
-template <int ABL>
-__global__ __launch_bounds__(256, 1) void dcn_fwd_pipe_kernel(const DcnArgs a)
-{
-    constexpr int BM = PIPE_BM, BN = PIPE_BN, BK = PIPE_BK, LDK = PIPE_LDK;
-    constexpr int NPA = BM / 8, NPB = BN / 32;   // 8 gather passes, 8 weight passes per thread
-    static_assert(NPA == 8 && NPB == 8, "one pass of each kind per pair of k-steps");
-    extern __shared__ __align__(16) unsigned char smem[];
-    float *As0 = reinterpret_cast<float *>(smem);          // [2][BM][LDK]
-    float *Bs0 = As0 + 2 * BM * LDK;                        // [2][BN][LDK]
-    Tap *tab = reinterpret_cast<Tap *>(Bs0 + 2 * BN * LDK);  // [BM][K*dg]
-
-    const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
-    const int K = a.kh * a.kw, KD = K * a.dg;
-    const int Cg = a.C / a.groups, Cog = a.Co / a.groups, Kdim = K * Cg;
-
-    const int tile = xcd_remap(blockIdx.x, a.ntiles);
-    const Lvl &L = find_level(a, tile);
-    const int tile_p = (tile - L.tile0) * BM;
-    const int g = blockIdx.z;
-    const int co_blk = blockIdx.y * BN;
-    const int nco = min(BN, Cog - co_blk);
-    const int co_base = g * Cog + co_blk;
-
-    for (int e = tid; e < BM * KD; e += 256) {
-        const int pl = e / KD, r = e - pl * KD;
-        const int dgi = r / K, k = r - dgi * K;
-        tab[e] = make_tap(a, L, tile_p + pl, k, dgi);
-    }
-    const int segs = Cg / a.SL, ncc = (a.SL + BK - 1) / BK;
-    const int T = K * segs * ncc;
-    const int kk = tid & 31, prow = tid >> 5;   // gather: channel lane, pixel row
-    const int wq = tid & 7, wrow = tid >> 3;    // weights: float4 slot along k, co row
-
-    const __amdgpu_buffer_rsrc_t xrs =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(L.x), 0, L.B * L.H * L.W * a.C * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t wrs =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.w), 0, a.Co * Kdim * 4, 0x00020000);
-
-    int wvoff[NPB];   // byte offset of this thread's float4 inside weight row (co_base + col); OOB if col >= nco
-#pragma unroll
-    for (int ps = 0; ps < NPB; ++ps) {
-        const int col = ps * 32 + wrow;
-        wvoff[ps] = (col < nco) ? ((co_base + col) * Kdim + wq * 4) * 4 : 0x7ffffff0;
-    }
-
-    // per-tap registers: byte offsets of the 4 bilinear corners (issue side) and their weights, already
-    // multiplied by the modulation scalar and zeroed for invalid corners (commit side)
-    int voffI[NPA][4];
-    float wgtC[NPA][4];
-    auto load_offsets = [&](const Chunk &ch) {
-#pragma unroll
-        for (int ps = 0; ps < NPA; ++ps) {
-            const int4 idx = *reinterpret_cast<const int4 *>(&tab[(ps * 8 + prow) * KD + ch.dgi * K + ch.k]);
-            voffI[ps][0] = (idx.x + kk) * 4;
-            voffI[ps][1] = (idx.y + kk) * 4;
-            voffI[ps][2] = (idx.z + kk) * 4;
-            voffI[ps][3] = (idx.w + kk) * 4;
-        }
-    };
-    auto load_weights = [&](const Chunk &ch) {
-#pragma unroll
-        for (int ps = 0; ps < NPA; ++ps) {
-            const Tap tp = tab[(ps * 8 + prow) * KD + ch.dgi * K + ch.k];
-            float b00, b01, b10, b11;
-            corner_weights(tp, b00, b01, b10, b11);
-            wgtC[ps][0] = b00 * tp.m;
-            wgtC[ps][1] = b01 * tp.m;
-            wgtC[ps][2] = b10 * tp.m;
-            wgtC[ps][3] = b11 * tp.m;
-        }
-    };
-
-    float xv[NPA][4];
-    float4 wv[NPB];
-    auto issue_x = [&](const Chunk &ch, int ps) {
-        const int soff = (g * Cg + ch.c0) * 4;
-        xv[ps][0] = buf_load_f32(xrs, voffI[ps][0], soff);
-        xv[ps][1] = buf_load_f32(xrs, voffI[ps][1], soff);
-        xv[ps][2] = buf_load_f32(xrs, voffI[ps][2], soff);
-        xv[ps][3] = buf_load_f32(xrs, voffI[ps][3], soff);
-    };
-    auto issue_w = [&](const Chunk &ch, int ps) { wv[ps] = buf_load_f32x4(wrs, wvoff[ps], (ch.k * Cg + ch.c0) * 4); };
-    auto commit_x = [&](const Chunk &ch, int ps, float *Asb) {
-        if (ABL & 8) {   // diagnostic: LDS write only
-            Asb[(ps * 8 + prow) * LDK + kk] = xv[ps][0];
-            return;
-        }
-        const float v = wgtC[ps][0] * xv[ps][0] + wgtC[ps][1] * xv[ps][1] + wgtC[ps][2] * xv[ps][2] +
-                        wgtC[ps][3] * xv[ps][3];
-        const float r = (kk < ch.nval) ? v : 0.f;
-        if (ABL & 4)     // diagnostic: VALU only
-            asm volatile("" ::"v"(r));
-        else
-            Asb[(ps * 8 + prow) * LDK + kk] = r;
-    };
-    auto commit_w = [&](const Chunk &ch, int ps, float *Bsb) {
-        if (ABL & 8) {
-            *reinterpret_cast<float4 *>(Bsb + (ps * 32 + wrow) * LDK + wq * 4) = wv[ps];
-            return;
-        }
-        const float4 v = (wq * 4 < ch.nval) ? wv[ps] : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ABL & 4)
-            asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
-        else
-            *reinterpret_cast<float4 *>(Bsb + (ps * 32 + wrow) * LDK + wq * 4) = v;
-    };
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    __syncthreads();  // sampling table complete
-    // ---- prologue: chunk 0 -> buffer 0, loads of chunk 1 in flight ----
-    ChunkIter<BK> it1(a, g, segs, ncc, T), it2(a, g, segs, ncc, T);   // chunk t+1 / chunk t+2 walkers
-    Chunk cI = it1.get();   // chunk whose offsets are in voffI
-    Chunk cC = cI;          // chunk whose weights are in wgtC
-    load_offsets(cI);
-    load_weights(cC);
-    {
-#pragma unroll
-        for (int ps = 0; ps < NPA; ++ps) issue_x(cI, ps);
-#pragma unroll
-        for (int ps = 0; ps < NPB; ++ps) issue_w(cI, ps);
-#pragma unroll
-        for (int ps = 0; ps < NPA; ++ps) commit_x(cC, ps, As0);
-#pragma unroll
-        for (int ps = 0; ps < NPB; ++ps) commit_w(cC, ps, Bs0);
-        it1.next();                 // -> chunk 1
-        it2.next();
-        it2.next();                 // -> chunk 2
-        const Chunk c1 = it1.get();
-        if (c1.k != cI.k || c1.dgi != cI.dgi) load_offsets(c1);
-        cI = c1;
-#pragma unroll
-        for (int ps = 0; ps < NPA; ++ps) issue_x(c1, ps);
-#pragma unroll
-        for (int ps = 0; ps < NPB; ++ps) issue_w(c1, ps);
-    }
-    __syncthreads();
-
-    int dbg_n = 0;
-    for (int t = 0; t < T; ++t) {
-        LSN_STAMP(2);
-        const int cur = t & 1;
-        const float *Asc = As0 + cur * BM * LDK, *Bsc = Bs0 + cur * BN * LDK;
-        float *Asn = As0 + (cur ^ 1) * BM * LDK, *Bsn = Bs0 + (cur ^ 1) * BN * LDK;
-        // chunk t+1 is committed, chunk t+2 is issued; indices clamp at the tail (the last iterations redo
-        // harmless staging work instead of branching inside the interleaved block)
-        const Chunk c1 = it1.get();
-        const Chunk c2 = it2.get();
-        it1.next();
-        it2.next();
-        if (c1.k != cC.k || c1.dgi != cC.dgi) load_weights(c1);   // once per (tap, deformable group)
-        cC = c1;
-        // note: the loads of chunk t+1 (issued with the OLD voffI) are already in flight, so the issue
-        // side may move on to the next tap now
-        if (c2.k != cI.k || c2.dgi != cI.dgi) load_offsets(c2);
-        cI = c2;
-
-        // MFMA operands: lane (i = lane & 31, h = lane >> 5) holds k = 16 h + s for k-step s
-        const float *ap = Asc + (lane & 31) * LDK + (lane >> 5) * 16;
-        const float *bp = Bsc + (wn * 64 + (lane & 31)) * LDK + (lane >> 5) * 16;
-        float4 A0[4], A1[4], B0[4], B1[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            A0[q] = *reinterpret_cast<const float4 *>(ap + 4 * q);
-            A1[q] = *reinterpret_cast<const float4 *>(ap + 32 * LDK + 4 * q);
-            B0[q] = *reinterpret_cast<const float4 *>(bp + 4 * q);
-            B1[q] = *reinterpret_cast<const float4 *>(bp + 32 * LDK + 4 * q);
-        }
-        if (a.dbg != nullptr) {
-            __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): diagnostic only
-            LSN_STAMP(5);
-        }
-#pragma unroll
-        for (int s = 0; s < BK / 2; ++s) {
-            const float a0 = reinterpret_cast<const float *>(&A0[s >> 2])[s & 3];
-            const float a1 = reinterpret_cast<const float *>(&A1[s >> 2])[s & 3];
-            const float b0 = reinterpret_cast<const float *>(&B0[s >> 2])[s & 3];
-            const float b1 = reinterpret_cast<const float *>(&B1[s >> 2])[s & 3];
-            // order pinned: MFMA, a slice of staging, MFMA, ... (a wave stalls at an MFMA until the pipe
-            // accepts it, so only what sits BETWEEN two MFMAs issues in their 64-cycle shadow)
-            const int ps = s >> 1;
-            acc[0][0] = mfma32(a0, b0, acc[0][0]);
-            __builtin_amdgcn_sched_barrier(0);
-            if (!(ABL & 1)) {
-                if ((s & 1) == 0)
-                    commit_x(c1, ps, Asn);   // chunk t+1, loaded one iteration ago
-                else
-                    commit_w(c1, ps, Bsn);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            acc[0][1] = mfma32(a0, b1, acc[0][1]);
-            __builtin_amdgcn_sched_barrier(0);
-            if (!(ABL & 2)) {
-                if ((s & 1) == 0)
-                    issue_x(c2, ps);         // chunk t+2 into the registers just consumed
-                else
-                    issue_w(c2, ps);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            acc[1][0] = mfma32(a1, b0, acc[1][0]);
-            acc[1][1] = mfma32(a1, b1, acc[1][1]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        LSN_STAMP(6);
-        __syncthreads();  // everyone finished reading buf[cur] and writing buf[cur^1]
-        LSN_STAMP(7);
-    }
-
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = wn * 64 + j * 32 + (lane & 31);
-            if (col >= nco) continue;
-            const float bv = a.bias ? a.bias[co_base + col] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int pix = tile_p + i * 32 + mfma32_row(r, lane);
-                if (pix < L.P) L.out[(size_t)pix * a.Co + co_base + col] = acc[i][j][r] + bv;
-            }
-        }
-}
 
 // =============================================================================================
 // Forward on the bf16 matrix pipe with split operands (dcn_fwd_xn_kernel<PREP, NP>).
@@ -2213,704 +1956,12 @@ __global__ void dcn_offgrad_kernel(const DcnArgs a, int nsamples, const float4 *
 }
 
 // =============================================================================================
-// Backward-data with a windowed scatter (dcn_bwd_data_win_kernel).
-//
-// Same contraction as dcn_bwd_data_kernel; what changes is where the 36 scatter-adds per input element go.
-// Measured on the first kernel: 2.0 GB of memory-side writes per launch against 0.05 GB of grad_input (every fp32
-// global atomic reaches the fabric), and 13.5k of the 18k cycles of its epilogue are those atomics.  Here
-//   * a tile is a 16x8 PATCH of output pixels (8 waves x 16 pixels, 512 threads, one workgroup per CU), so the
-//     samples of its taps land in a compact window of the input map (20x12 pixels for offsets within +-1);
-//   * chunks run slab-major (all taps of a 32-channel slab, then the next slab) and the scatter of a slab is
-//     accumulated in LDS, in a [256 window pixels][32 ch] buffer of 64-bit FIXED-POINT numbers (2^-32 units) with
-//     ds_add_u64, then flushed to grad_input with one global atomic per touched element and slab: ~9x fewer
-//     global atomics.  Fixed point because LDS float atomics are unusable on gfx950: ds_add_f32 measured 1580
-//     cycles per wave-instruction against 160-180 for ds_add_u32 / ds_add_u64 (tools/ubench/lds_atomics.hip).
-//     Integer addition is also order-independent, so this part of the sum is deterministic.  Resolution 2.3e-10,
-//     range +-2.1e9 per accumulated element;
-//   * the window is the bounding box of the samples actually present (from the tap table): when the box of all
-//     taps exceeds the buffer (large learned offsets; the pyramid op, whose taps point at far-apart landmarks)
-//     each tap gets its own box and is flushed per chunk, and a tap whose own box is too large falls back to
-//     direct global atomics.  All three modes produce the same sums up to rounding.
-// MFMA row -> pixel mapping: the 4 pixels that share one scatter instruction (rows r, r+4, r+8, r+12 of a wave's
-// 16) are x-adjacent in the patch, so their window rows are adjacent and the row-parity swizzle keeps the two
-// 32-lane halves of a ds_add_u64 on disjoint banks.
-// =============================================================================================
-constexpr int BW3_PX = 128, BW3_PW = 16, BW3_PH = 8;   // patch: 16 wide x 8 high
-constexpr int BW3_WIN = 256;                            // window pixels
-constexpr int BW3_WPAR = 8;                             // ints per window descriptor: y0, x0, ww, mode, rows
-constexpr float BW3_SCALE = 4294967296.f, BW3_INV = 1.f / 4294967296.f;
-
-__host__ __device__ inline size_t bwd_win_lds_bytes(int RED, int KD)
-{
-    return (size_t)RED * 32 * 4 + (size_t)BW3_WIN * 32 * 8 + (size_t)BW3_PX * KD * (sizeof(Tap) + 12 + 4) +
-           (size_t)KD * 16 + (size_t)(KD + 1) * BW3_WPAR * 4;
-}
-
-// fp32 -> 2^-32 fixed point (round toward zero; |v| < 2^31)
-__device__ __forceinline__ long long to_fixed(float v)
-{
-    const float t = v * BW3_SCALE;                       // exact: power-of-two scaling
-    const float hi = truncf(t * BW3_INV);                // integer part of v
-    const float lo = t - hi * BW3_SCALE;                 // |lo| < 2^32, exact (Sterbenz-like: same exponent range)
-    return ((long long)(int)hi << 32) + (long long)lo;   // (long long)lo: |lo| < 2^32 fits
-}
-
-__host__ __device__ inline size_t bwd_win_x3_lds_bytes(int KD)
-{
-    return (size_t)2 * 32 * 528 + (size_t)BW3_WIN * 32 * 8 + (size_t)BW3_PX * KD * (sizeof(Tap) + 12 + 4) +
-           (size_t)KD * 16 + (size_t)(KD + 1) * BW3_WPAR * 4;
-}
-
-template <int RED, bool VEC>
-__global__ __launch_bounds__(512, 1) void dcn_bwd_data_win_kernel(const DcnArgs a)
-{
-    constexpr int BK = 32, QR = RED / 4;
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int K = a.kh * a.kw, KD = K * a.dg;
-    float *Bs = reinterpret_cast<float *>(smem);                              // [RED][32] swizzled weight slab
-    unsigned long long *win = reinterpret_cast<unsigned long long *>(Bs + RED * BK);   // [BW3_WIN][32]
-    Tap *tab = reinterpret_cast<Tap *>(win + BW3_WIN * BK);                   // [128][KD]
-    float *gacc = reinterpret_cast<float *>(tab + BW3_PX * KD);               // [128][KD][3]  (dy, dx, mask)
-    int *wb = reinterpret_cast<int *>(gacc + BW3_PX * KD * 3);                // [128][KD] window row | dx<<16 | dy*ww<<17
-    int *bb = wb + BW3_PX * KD;                                               // [KD][4] ymin, xmin, ymax, xmax
-    int *wpar = bb + KD * 4;                                                  // [KD+1][BW3_WPAR]; entry KD = all taps
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j16 = lane & 15, kq = lane >> 4;
-    const int Cg = a.C / a.groups, Cog = a.Co / a.groups, Kdim = K * Cg;
-
-    const Lvl &L = find_level(a, blockIdx.x);
-    const int ntx = (L.Wo + BW3_PW - 1) / BW3_PW, nty = (L.Ho + BW3_PH - 1) / BW3_PH;
-    const int tl = blockIdx.x - L.tile0;
-    const int pb = tl / (ntx * nty);
-    const int trem = tl - pb * ntx * nty;
-    const int pty = trem / ntx, ptx = trem - pty * ntx;
-    // local pixel pl = y * 16 + x of the patch
-    auto pix_of = [&](int pl) {
-        const int ho = pty * BW3_PH + (pl >> 4), wo = ptx * BW3_PW + (pl & 15);
-        return (ho < L.Ho && wo < L.Wo) ? (pb * L.Ho + ho) * L.Wo + wo : L.P;
-    };
-    // MFMA row i (0..15) of wave w  ->  local pixel: x = 4 * (i & 3) + (i >> 2), y = w
-    auto pl_of = [&](int i) { return (wave << 4) + ((i & 3) << 2) + (i >> 2); };
-
-    for (int e = tid; e < KD * 4; e += 512) bb[e] = (e & 3) < 2 ? INT_MAX : INT_MIN;
-    for (int e = tid; e < BW3_WIN * BK; e += 512) win[e] = 0ull;
-    for (int e = tid; e < BW3_PX * KD * 3; e += 512) gacc[e] = 0.f;
-    __syncthreads();
-    for (int e = tid; e < BW3_PX * KD; e += 512) {
-        const int pl = e / KD, r = e - pl * KD;
-        const int dgi = r / K, k = r - dgi * K;
-        int4 yx = make_int4(0, 0, 0, 0);
-        const Tap t = make_tap_ex(a, L, pix_of(pl), k, dgi, &yx);
-        tab[e] = t;
-        wb[e] = (int)((unsigned)yx.x | ((unsigned)yx.y << 15) | ((unsigned)(yx.z - yx.x) << 30) |
-                      ((unsigned)(yx.w - yx.y) << 31));
-        if (t.flags) {
-            atomicMin(&bb[r * 4 + 0], yx.x);
-            atomicMin(&bb[r * 4 + 1], yx.y);
-            atomicMax(&bb[r * 4 + 2], yx.z);
-            atomicMax(&bb[r * 4 + 3], yx.w);
-        }
-    }
-    __syncthreads();
-    if (tid == 0) {
-        const bool off = (a.dbg_block >> 26) & 1;   // diagnostic: force direct atomics
-        int uy0 = INT_MAX, ux0 = INT_MAX, uy1 = INT_MIN, ux1 = INT_MIN;
-        for (int kd = 0; kd < KD; ++kd) {
-            const int y0 = bb[kd * 4], x0 = bb[kd * 4 + 1], y1 = bb[kd * 4 + 2], x1 = bb[kd * 4 + 3];
-            int *wp = wpar + kd * BW3_WPAR;
-            if (y0 <= y1) {
-                uy0 = min(uy0, y0), ux0 = min(ux0, x0), uy1 = max(uy1, y1), ux1 = max(ux1, x1);
-                const int hh = y1 - y0 + 1, ww = x1 - x0 + 1;
-                const bool fits = (long long)hh * ww <= BW3_WIN && !off;
-                wp[0] = y0, wp[1] = x0, wp[2] = fits ? ww : 1, wp[3] = fits ? 1 : 2, wp[4] = fits ? hh * ww : 0;
-            } else {
-                wp[0] = wp[1] = 0, wp[2] = 1, wp[3] = 1, wp[4] = 0;
-            }
-        }
-        int *up = wpar + KD * BW3_WPAR;
-        if (uy0 > uy1) {
-            up[0] = up[1] = 0, up[2] = 1, up[3] = 1, up[4] = 0;
-        } else {
-            const int hh = uy1 - uy0 + 1, ww = ux1 - ux0 + 1;
-            const bool fits = (long long)hh * ww <= BW3_WIN && !off;
-            up[0] = uy0, up[1] = ux0, up[2] = fits ? ww : 1, up[3] = fits ? 1 : 0, up[4] = fits ? hh * ww : 0;
-        }
-    }
-    __syncthreads();
-    const bool umode = wpar[KD * BW3_WPAR + 3] == 1;   // one window for all taps of a slab
-    for (int e = tid; e < BW3_PX * KD; e += 512) {
-        const int pl = e / KD, r = e - pl * KD;
-        const int *wp = wpar + (umode ? KD : r) * BW3_WPAR;
-        const unsigned v = (unsigned)wb[e];
-        const int cy0 = v & 0x7fff, cx0 = (v >> 15) & 0x7fff, dy = (v >> 30) & 1, dx = v >> 31;
-        int o = 0;
-        if (tab[e].flags && wp[3] == 1) o = ((cy0 - wp[0]) * wp[2] + (cx0 - wp[1])) | (dx << 16) | ((dy * wp[2]) << 17);
-        wb[e] = o;
-    }
-
-    const int segs = Cg / a.SL, ncc = (a.SL + BK - 1) / BK;
-    const int T = K * segs * ncc;
-    const int nrb = (Cog + RED - 1) / RED;  // reduction blocks (1 for Co/groups <= RED)
-    const bool want_off = (L.goff != nullptr) || (L.gmsk != nullptr);
-    const int cpdg = a.C / a.dg;
-
-    const int wq = tid & 7, wrow = tid >> 3;  // weight staging: float4 slot along k, 64 rows/pass
-    constexpr int NPB = (RED + 63) / 64;
-
-    const int my_pix = pix_of(pl_of(j16));  // A operand row (pixel) of this lane
-
-    float areg[QR];
-    float4 wv[NPB];
-    __syncthreads();
-
-    auto load_a = [&](int g, int rb) {
-        const int cb = rb * RED + kq * QR;
-        const bool pix_ok = my_pix < L.P;
-        const float *grow = L.gout + (size_t)(pix_ok ? my_pix : 0) * a.Co + g * Cog;
-#pragma unroll
-        for (int s4 = 0; s4 < QR / 4; ++s4) {
-            const float4 v = load4_guarded<VEC>(grow, cb + s4 * 4, Cog - (cb + s4 * 4), pix_ok);
-            areg[s4 * 4 + 0] = v.x;
-            areg[s4 * 4 + 1] = v.y;
-            areg[s4 * 4 + 2] = v.z;
-            areg[s4 * 4 + 3] = v.w;
-        }
-    };
-    // slab-major chunk walk: tap fastest, then 32-channel sub-chunk, then segment
-    struct Walk {
-        int k, cc, seg;
-    };
-    auto chunk_of = [&](const Walk &w, int g) {
-        Chunk c;
-        c.k = __builtin_amdgcn_readfirstlane(w.k);
-        c.c0 = __builtin_amdgcn_readfirstlane(w.seg * a.SL + w.cc * BK);
-        c.nval = __builtin_amdgcn_readfirstlane(min(BK, a.SL - w.cc * BK));
-        c.dgi = __builtin_amdgcn_readfirstlane((g * Cg + w.seg * a.SL) / cpdg);
-        return c;
-    };
-    auto advance = [&](Walk &w) {
-        if (++w.k == K) {
-            w.k = 0;
-            if (++w.cc == ncc) {
-                w.cc = 0;
-                ++w.seg;
-            }
-        }
-    };
-    auto load_w = [&](int g, const Chunk &ch, int rb) {
-        const float *wbase = a.w + (size_t)(g * Cog + rb * RED) * Kdim + ch.k * Cg + ch.c0;
-        const int rem = ch.nval - wq * 4;
-#pragma unroll
-        for (int ps = 0; ps < NPB; ++ps) {
-            const int row = ps * 64 + wrow;
-            const bool ok = row < RED && rb * RED + row < Cog;
-            wv[ps] = load4_guarded<VEC>(wbase + (size_t)(ok ? row : 0) * Kdim, wq * 4, rem, ok);
-        }
-    };
-    auto store_w = [&]() {
-#pragma unroll
-        for (int ps = 0; ps < NPB; ++ps) {
-            const int row = ps * 64 + wrow;
-            if (row < RED) {
-                const int sw = ((row / QR) & 1) << 4;
-                *reinterpret_cast<float4 *>(Bs + row * BK + ((wq * 4) ^ sw)) = wv[ps];
-            }
-        }
-    };
-    // window -> grad_input: elements that received something are added to global memory and cleared
-    auto flush = [&](const int *wp, int cbase, int nval) {
-        const int nrows = wp[4], ww = wp[2];
-        const int q2 = (tid & 15) * 2;
-        for (int row = tid >> 4; row < nrows; row += 32) {
-            unsigned long long *p = win + row * BK + (q2 ^ ((row & 1) << 4));
-            const long long v0 = (long long)p[0], v1 = (long long)p[1];
-            if ((v0 | v1) != 0) {
-                p[0] = 0ull;
-                p[1] = 0ull;
-                const int wy = row / ww, wx = row - wy * ww;
-                float *gp = L.gx + ((size_t)(pb * L.H + wp[0] + wy) * L.W + wp[1] + wx) * a.C + cbase + q2;
-                if (q2 + 0 < nval && v0 != 0) atomic_add_f32(gp + 0, (float)((double)v0 * (double)BW3_INV));
-                if (q2 + 1 < nval && v1 != 0) atomic_add_f32(gp + 1, (float)((double)v1 * (double)BW3_INV));
-            }
-        }
-    };
-
-    int dbg_n = 0;
-    for (int g = 0; g < a.groups; ++g) {
-        Walk wc = {0, 0, 0}, wn = {0, 0, 0};
-        if (nrb == 1) load_a(g, 0);
-        load_w(g, chunk_of(wn, g), 0);
-        advance(wn);
-        for (int t = 0; t < T; ++t) {
-            const Chunk ch = chunk_of(wc, g);
-            advance(wc);
-            const int kd = ch.dgi * K + ch.k;
-            const int *wp = wpar + (umode ? KD : kd) * BW3_WPAR;
-            const bool use_win = wp[3] == 1;
-            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-            for (int rb = 0; rb < nrb; ++rb) {
-                if (nrb > 1) load_a(g, rb);  // Co/groups > RED: re-read the gout rows per slab
-                LSN_STAMP(2);
-                store_w();
-                LSN_STAMP(3);
-                __syncthreads();
-                LSN_STAMP(4);
-                if (rb + 1 < nrb)
-                    load_w(g, ch, rb + 1);
-                else if (t + 1 < T) {
-                    load_w(g, chunk_of(wn, g), 0);
-                    advance(wn);
-                }
-                {
-                    const int sw = (kq & 1) << 4;
-                    const float *bp = Bs + (kq * QR) * BK;
-                    const int c0i = j16 ^ sw, c1i = (16 + j16) ^ sw;
-#pragma unroll
-                    for (int s = 0; s < QR; ++s) {
-                        const float b0 = bp[s * BK + c0i];
-                        const float b1 = bp[s * BK + c1i];
-                        acc0 = mfma16(areg[s], b0, acc0);
-                        acc1 = mfma16(areg[s], b1, acc1);
-                    }
-                }
-                LSN_STAMP(5);
-                if (rb + 1 < nrb) __syncthreads();  // slab consumed; next slab may overwrite Bs
-            }
-
-            // ---- consume gcol[16 px][32 ch] of this wave: D row = 4*kq + r, col = tn*16 + j16 ----
-            float sy[4] = {0.f, 0.f, 0.f, 0.f}, sx[4] = {0.f, 0.f, 0.f, 0.f}, sm[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int tn = 0; tn < 2; ++tn) {
-                const int cl = tn * 16 + j16;
-                const bool cval = cl < ch.nval;
-                const int c = g * Cg + ch.c0 + (cval ? cl : 0);
-                float xv[4][4];
-                if (want_off) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const Tap *tp = &tab[pl_of(kq * 4 + r) * KD + kd];
-                        const int4 idx = *reinterpret_cast<const int4 *>(tp);
-                        xv[r][0] = L.x[idx.x + c];
-                        xv[r][1] = L.x[idx.y + c];
-                        xv[r][2] = L.x[idx.z + c];
-                        xv[r][3] = L.x[idx.w + c];
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float gval = cval ? (tn == 0 ? acc0[r] : acc1[r]) : 0.f;
-                    const int e = pl_of(kq * 4 + r) * KD + kd;
-                    const Tap tp = tab[e];
-                    float b00, b01, b10, b11;
-                    corner_weights(tp, b00, b01, b10, b11);
-                    const float gm = gval * tp.m;
-                    if (L.gx != nullptr && cval && tp.flags) {
-                        if (use_win) {
-                            const int wv0 = wb[e];
-                            const int w00 = wv0 & 0xffff, dx = (wv0 >> 16) & 1, o10 = wv0 >> 17;
-                            const int w01 = w00 + dx, w10 = w00 + o10, w11 = w10 + dx;
-                            atomicAdd(win + w00 * BK + (cl ^ ((w00 & 1) << 4)), (unsigned long long)to_fixed(b00 * gm));
-                            atomicAdd(win + w01 * BK + (cl ^ ((w01 & 1) << 4)), (unsigned long long)to_fixed(b01 * gm));
-                            atomicAdd(win + w10 * BK + (cl ^ ((w10 & 1) << 4)), (unsigned long long)to_fixed(b10 * gm));
-                            atomicAdd(win + w11 * BK + (cl ^ ((w11 & 1) << 4)), (unsigned long long)to_fixed(b11 * gm));
-                        } else {
-                            atomic_add_f32(L.gx + tp.i00 + c, b00 * gm);
-                            atomic_add_f32(L.gx + tp.i01 + c, b01 * gm);
-                            atomic_add_f32(L.gx + tp.i10 + c, b10 * gm);
-                            atomic_add_f32(L.gx + tp.i11 + c, b11 * gm);
-                        }
-                    }
-                    if (want_off) {
-                        const float hy = 1.f - tp.ly, hx = 1.f - tp.lx;
-                        const float v00 = (tp.flags & 1) ? xv[r][0] : 0.f;
-                        const float v01 = (tp.flags & 2) ? xv[r][1] : 0.f;
-                        const float v10 = (tp.flags & 4) ? xv[r][2] : 0.f;
-                        const float v11 = (tp.flags & 8) ? xv[r][3] : 0.f;
-                        // coordinate weights, kernel.cu:145-188 / 800-845
-                        const float dy = hx * (v10 - v00) + tp.lx * (v11 - v01);
-                        const float dx = hy * (v01 - v00) + tp.ly * (v11 - v10);
-                        const float bil =
-                            hy * hx * v00 + hy * tp.lx * v01 + tp.ly * hx * v10 + tp.ly * tp.lx * v11;
-                        sy[r] += gm * dy;
-                        sx[r] += gm * dx;
-                        sm[r] += gval * bil;
-                    }
-                }
-            }
-            if (want_off) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float vy = row16_sum(sy[r]), vx = row16_sum(sx[r]), vm = row16_sum(sm[r]);
-                    if (j16 == 0) {   // the row is private to this wave: plain read-modify-write
-                        float *ga = gacc + (pl_of(kq * 4 + r) * KD + kd) * 3;
-                        ga[0] += vy;
-                        ga[1] += vx;
-                        ga[2] += vm;
-                    }
-                }
-            }
-            LSN_STAMP(6);
-            __syncthreads();  // Bs free for the next chunk; this chunk's window adds are complete
-            LSN_STAMP(7);
-            if (L.gx != nullptr && use_win && (!umode || ch.k == K - 1)) flush(wp, g * Cg + ch.c0, ch.nval);
-        }
-    }
-    __syncthreads();
-
-    // ---- write grad_offset / grad_mask for this tile ----
-    for (int e = tid; e < BW3_PX * KD; e += 512) {
-        const int pl = e / KD, r = e - pl * KD;
-        const int dgi = r / K, k = r - dgi * K;
-        const int ho = pty * BW3_PH + (pl >> 4), wo = ptx * BW3_PW + (pl & 15);
-        if (ho >= L.Ho || wo >= L.Wo) continue;
-        const float *ga = gacc + e * 3;
-        if (L.goff) {
-            float *op = L.goff + (size_t)pb * L.osb + (size_t)ho * L.osh + (size_t)wo * L.osw;
-            op[(size_t)(dgi * 2 * K + 2 * k) * L.osc] = ga[0];
-            op[(size_t)(dgi * 2 * K + 2 * k + 1) * L.osc] = ga[1];
-        }
-        if (L.gmsk) {
-            float gm = ga[2];
-            if (a.msig) {  // d sigmoid: m (1 - m); out-of-range samples have ga[2] == 0 already
-                const float m = tab[e].m;
-                gm *= m * (1.f - m);
-            }
-            L.gmsk[(size_t)pb * L.msb + (size_t)(dgi * K + k) * L.msc + (size_t)ho * L.msh + (size_t)wo * L.msw] = gm;
-        }
-    }
-}
-
-// The windowed scatter with the GEMM on the bf16 matrix pipe (split operands as in dcn_bwd_data_x3_kernel): the
-// fixed-point conversions and LDS adds of the epilogue then overlap the MFMAs instead of queueing behind them.
-__global__ __launch_bounds__(512, 1) void dcn_bwd_data_win_x3_kernel(const DcnArgs a)
-{
-    constexpr int BK = 32, RED = 256, NS = RED / 32, RS = BX3_RS;
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int K = a.kh * a.kw, KD = K * a.dg;
-    unsigned char *Bh = smem, *Bl = smem + 32 * RS;                           // [32 ch][RED co] bf16 planes
-    unsigned long long *win = reinterpret_cast<unsigned long long *>(smem + 2 * 32 * RS);   // [BW3_WIN][32]
-    Tap *tab = reinterpret_cast<Tap *>(win + BW3_WIN * BK);                   // [128][KD]
-    float *gacc = reinterpret_cast<float *>(tab + BW3_PX * KD);               // [128][KD][3]  (dy, dx, mask)
-    int *wb = reinterpret_cast<int *>(gacc + BW3_PX * KD * 3);                // [128][KD] window row | dx<<16 | dy*ww<<17
-    int *bb = wb + BW3_PX * KD;                                               // [KD][4] ymin, xmin, ymax, xmax
-    int *wpar = bb + KD * 4;                                                  // [KD+1][BW3_WPAR]; entry KD = all taps
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j16 = lane & 15, kq = lane >> 4;
-    const int Cg = a.C, C = a.C, Co = a.Co;   // groups == 1
-
-    const Lvl &L = find_level(a, blockIdx.x);
-    const int ntx = (L.Wo + BW3_PW - 1) / BW3_PW, nty = (L.Ho + BW3_PH - 1) / BW3_PH;
-    const int tl = blockIdx.x - L.tile0;
-    const int pb = tl / (ntx * nty);
-    const int trem = tl - pb * ntx * nty;
-    const int pty = trem / ntx, ptx = trem - pty * ntx;
-    // local pixel pl = y * 16 + x of the patch
-    auto pix_of = [&](int pl) {
-        const int ho = pty * BW3_PH + (pl >> 4), wo = ptx * BW3_PW + (pl & 15);
-        return (ho < L.Ho && wo < L.Wo) ? (pb * L.Ho + ho) * L.Wo + wo : L.P;
-    };
-    // MFMA row i (0..15) of wave w  ->  local pixel: x = 4 * (i & 3) + (i >> 2), y = w
-    auto pl_of = [&](int i) { return (wave << 4) + ((i & 3) << 2) + (i >> 2); };
-
-    for (int e = tid; e < KD * 4; e += 512) bb[e] = (e & 3) < 2 ? INT_MAX : INT_MIN;
-    for (int e = tid; e < BW3_WIN * BK; e += 512) win[e] = 0ull;
-    for (int e = tid; e < BW3_PX * KD * 3; e += 512) gacc[e] = 0.f;
-    __syncthreads();
-    for (int e = tid; e < BW3_PX * KD; e += 512) {
-        const int pl = e / KD, r = e - pl * KD;
-        const int dgi = r / K, k = r - dgi * K;
-        int4 yx = make_int4(0, 0, 0, 0);
-        const Tap t = make_tap_ex(a, L, pix_of(pl), k, dgi, &yx);
-        tab[e] = t;
-        wb[e] = (int)((unsigned)yx.x | ((unsigned)yx.y << 15) | ((unsigned)(yx.z - yx.x) << 30) |
-                      ((unsigned)(yx.w - yx.y) << 31));
-        if (t.flags) {
-            atomicMin(&bb[r * 4 + 0], yx.x);
-            atomicMin(&bb[r * 4 + 1], yx.y);
-            atomicMax(&bb[r * 4 + 2], yx.z);
-            atomicMax(&bb[r * 4 + 3], yx.w);
-        }
-    }
-    __syncthreads();
-    if (tid == 0) {
-        const bool off = (a.dbg_block >> 26) & 1;   // diagnostic: force direct atomics
-        int uy0 = INT_MAX, ux0 = INT_MAX, uy1 = INT_MIN, ux1 = INT_MIN;
-        for (int kd = 0; kd < KD; ++kd) {
-            const int y0 = bb[kd * 4], x0 = bb[kd * 4 + 1], y1 = bb[kd * 4 + 2], x1 = bb[kd * 4 + 3];
-            int *wp = wpar + kd * BW3_WPAR;
-            if (y0 <= y1) {
-                uy0 = min(uy0, y0), ux0 = min(ux0, x0), uy1 = max(uy1, y1), ux1 = max(ux1, x1);
-                const int hh = y1 - y0 + 1, ww = x1 - x0 + 1;
-                const bool fits = (long long)hh * ww <= BW3_WIN && !off;
-                wp[0] = y0, wp[1] = x0, wp[2] = fits ? ww : 1, wp[3] = fits ? 1 : 2, wp[4] = fits ? hh * ww : 0;
-            } else {
-                wp[0] = wp[1] = 0, wp[2] = 1, wp[3] = 1, wp[4] = 0;
-            }
-        }
-        int *up = wpar + KD * BW3_WPAR;
-        if (uy0 > uy1) {
-            up[0] = up[1] = 0, up[2] = 1, up[3] = 1, up[4] = 0;
-        } else {
-            const int hh = uy1 - uy0 + 1, ww = ux1 - ux0 + 1;
-            const bool fits = (long long)hh * ww <= BW3_WIN && !off;
-            up[0] = uy0, up[1] = ux0, up[2] = fits ? ww : 1, up[3] = fits ? 1 : 0, up[4] = fits ? hh * ww : 0;
-        }
-    }
-    __syncthreads();
-    const bool umode = wpar[KD * BW3_WPAR + 3] == 1;   // one window for all taps of a slab
-    for (int e = tid; e < BW3_PX * KD; e += 512) {
-        const int pl = e / KD, r = e - pl * KD;
-        const int *wp = wpar + (umode ? KD : r) * BW3_WPAR;
-        const unsigned v = (unsigned)wb[e];
-        const int cy0 = v & 0x7fff, cx0 = (v >> 15) & 0x7fff, dy = (v >> 30) & 1, dx = v >> 31;
-        int o = 0;
-        if (tab[e].flags && wp[3] == 1) o = ((cy0 - wp[0]) * wp[2] + (cx0 - wp[1])) | (dx << 16) | ((dy * wp[2]) << 17);
-        wb[e] = o;
-    }
-
-    const int segs = Cg / a.SL, ncc = (a.SL + BK - 1) / BK;
-    const int T = K * segs * ncc;
-    const bool want_off = (L.goff != nullptr) || (L.gmsk != nullptr);
-    const int cpdg = a.C / a.dg;
-
-    // A operand: gout row of pixel pl_of(j16), k-step s covers co = 32 s + 8 kq .. + 7, split once
-    bf16x8 ah[NS], al[NS];
-    {
-        const int my_pix = pix_of(pl_of(j16));
-        const bool pix_ok = my_pix < L.P;
-        const float *grow = L.gout + (size_t)(pix_ok ? my_pix : 0) * Co;
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const int cb = s * 32 + kq * 8;
-            float v[8];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const bool ok = pix_ok && cb + h * 4 < Co;
-                const float4 f = *reinterpret_cast<const float4 *>(grow + (ok ? cb + h * 4 : 0));
-                v[h * 4 + 0] = ok ? f.x : 0.f, v[h * 4 + 1] = ok ? f.y : 0.f, v[h * 4 + 2] = ok ? f.z : 0.f,
-                          v[h * 4 + 3] = ok ? f.w : 0.f;
-            }
-            unsigned hi[4], lo[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) split_bf16x2(v[2 * e], v[2 * e + 1], hi[e], lo[e]);
-            const uint4 H = make_uint4(hi[0], hi[1], hi[2], hi[3]), Lo = make_uint4(lo[0], lo[1], lo[2], lo[3]);
-            __builtin_memcpy(&ah[s], &H, 16);
-            __builtin_memcpy(&al[s], &Lo, 16);
-        }
-    }
-    // slab-major chunk walk: tap fastest, then 32-channel sub-chunk, then segment
-    struct Walk {
-        int k, cc, seg;
-    };
-    auto chunk_of = [&](const Walk &w) {
-        Chunk c;
-        c.k = __builtin_amdgcn_readfirstlane(w.k);
-        c.c0 = __builtin_amdgcn_readfirstlane(w.seg * a.SL + w.cc * BK);
-        c.nval = __builtin_amdgcn_readfirstlane(min(BK, a.SL - w.cc * BK));
-        c.dgi = __builtin_amdgcn_readfirstlane((w.seg * a.SL) / cpdg);
-        return c;
-    };
-    auto advance = [&](Walk &w) {
-        if (++w.k == K) {
-            w.k = 0;
-            if (++w.cc == ncc) {
-                w.cc = 0;
-                ++w.seg;
-            }
-        }
-    };
-    // weight slab staging from the prepared [K][C][Co] planes: 512 threads = 2 planes x 8 rows x 32 pieces per pass
-    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(a.wtp), 0,
-                                                                         K * C * Co * 4, 0x00020000);
-    const int piece = tid & 31, srow = (tid >> 5) & 7, plane = tid >> 8;
-    float4 wv[4];
-    auto load_w = [&](const Chunk &ch) {
-        const int rowbase = ch.k * C + ch.c0;
-#pragma unroll
-        for (int ps = 0; ps < 4; ++ps) {
-            const int r = ps * 8 + srow;
-            const bool ok = piece * 8 < Co && r < ch.nval;
-            const int voff = ok ? (plane * K * C * Co + (rowbase + r) * Co) * 2 + piece * 16 : 0x7ffffff0;
-            auto v = __builtin_amdgcn_raw_buffer_load_b128(wrs, voff, 0, 0);
-            __builtin_memcpy(&wv[ps], &v, 16);
-        }
-    };
-    auto store_w = [&]() {
-#pragma unroll
-        for (int ps = 0; ps < 4; ++ps)
-            *reinterpret_cast<float4 *>((plane ? Bl : Bh) + (ps * 8 + srow) * RS + piece * 16) = wv[ps];
-    };
-    // window -> grad_input: elements that received something are added to global memory and cleared
-    auto flush = [&](const int *wp, int cbase, int nval) {
-        const int nrows = wp[4], ww = wp[2];
-        const int q2 = (tid & 15) * 2;
-        for (int row = tid >> 4; row < nrows; row += 32) {
-            unsigned long long *p = win + row * BK + (q2 ^ ((row & 1) << 4));
-            const long long v0 = (long long)p[0], v1 = (long long)p[1];
-            if ((v0 | v1) != 0) {
-                p[0] = 0ull;
-                p[1] = 0ull;
-                const int wy = row / ww, wx = row - wy * ww;
-                float *gp = L.gx + ((size_t)(pb * L.H + wp[0] + wy) * L.W + wp[1] + wx) * a.C + cbase + q2;
-                if (q2 + 0 < nval && v0 != 0) atomic_add_f32(gp + 0, (float)((double)v0 * (double)BW3_INV));
-                if (q2 + 1 < nval && v1 != 0) atomic_add_f32(gp + 1, (float)((double)v1 * (double)BW3_INV));
-            }
-        }
-    };
-
-    int dbg_n = 0;
-    __syncthreads();
-    {
-        const int g = 0;
-        Walk wc = {0, 0, 0}, wn = {0, 0, 0};
-        load_w(chunk_of(wn));
-        advance(wn);
-        for (int t = 0; t < T; ++t) {
-            const Chunk ch = chunk_of(wc);
-            advance(wc);
-            const int kd = ch.dgi * K + ch.k;
-            const int *wp = wpar + (umode ? KD : kd) * BW3_WPAR;
-            const bool use_win = wp[3] == 1;
-            LSN_STAMP(2);
-            store_w();
-            LSN_STAMP(3);
-            __syncthreads();
-            LSN_STAMP(4);
-            if (t + 1 < T) {
-                load_w(chunk_of(wn));
-                advance(wn);
-            }
-            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-            {
-                const unsigned char *b0 = Bh + j16 * RS + kq * 16, *b1 = Bh + (16 + j16) * RS + kq * 16;
-#pragma unroll
-                for (int s = 0; s < NS; ++s) {
-                    const bf16x8 h0 = *reinterpret_cast<const bf16x8 *>(b0 + s * 64);
-                    const bf16x8 h1 = *reinterpret_cast<const bf16x8 *>(b1 + s * 64);
-                    const bf16x8 l0 = *reinterpret_cast<const bf16x8 *>(b0 + 32 * RS + s * 64);
-                    const bf16x8 l1 = *reinterpret_cast<const bf16x8 *>(b1 + 32 * RS + s * 64);
-                    acc0 = mfma16_bf16(ah[s], h0, acc0);
-                    acc1 = mfma16_bf16(ah[s], h1, acc1);
-                    acc0 = mfma16_bf16(ah[s], l0, acc0);
-                    acc1 = mfma16_bf16(ah[s], l1, acc1);
-                    acc0 = mfma16_bf16(al[s], h0, acc0);
-                    acc1 = mfma16_bf16(al[s], h1, acc1);
-                }
-            }
-            LSN_STAMP(5);
-
-            // ---- consume gcol[16 px][32 ch] of this wave: D row = 4*kq + r, col = tn*16 + j16 ----
-            float sy[4] = {0.f, 0.f, 0.f, 0.f}, sx[4] = {0.f, 0.f, 0.f, 0.f}, sm[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int tn = 0; tn < 2; ++tn) {
-                const int cl = tn * 16 + j16;
-                const bool cval = cl < ch.nval;
-                const int c = g * Cg + ch.c0 + (cval ? cl : 0);
-                float xv[4][4];
-                if (want_off) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const Tap *tp = &tab[pl_of(kq * 4 + r) * KD + kd];
-                        const int4 idx = *reinterpret_cast<const int4 *>(tp);
-                        xv[r][0] = L.x[idx.x + c];
-                        xv[r][1] = L.x[idx.y + c];
-                        xv[r][2] = L.x[idx.z + c];
-                        xv[r][3] = L.x[idx.w + c];
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float gval = cval ? (tn == 0 ? acc0[r] : acc1[r]) : 0.f;
-                    const int e = pl_of(kq * 4 + r) * KD + kd;
-                    const Tap tp = tab[e];
-                    float b00, b01, b10, b11;
-                    corner_weights(tp, b00, b01, b10, b11);
-                    const float gm = gval * tp.m;
-                    if (L.gx != nullptr && cval && tp.flags) {
-                        if (use_win) {
-                            const int wv0 = wb[e];
-                            const int w00 = wv0 & 0xffff, dx = (wv0 >> 16) & 1, o10 = wv0 >> 17;
-                            const int w01 = w00 + dx, w10 = w00 + o10, w11 = w10 + dx;
-                            atomicAdd(win + w00 * BK + (cl ^ ((w00 & 1) << 4)), (unsigned long long)to_fixed(b00 * gm));
-                            atomicAdd(win + w01 * BK + (cl ^ ((w01 & 1) << 4)), (unsigned long long)to_fixed(b01 * gm));
-                            atomicAdd(win + w10 * BK + (cl ^ ((w10 & 1) << 4)), (unsigned long long)to_fixed(b10 * gm));
-                            atomicAdd(win + w11 * BK + (cl ^ ((w11 & 1) << 4)), (unsigned long long)to_fixed(b11 * gm));
-                        } else {
-                            atomic_add_f32(L.gx + tp.i00 + c, b00 * gm);
-                            atomic_add_f32(L.gx + tp.i01 + c, b01 * gm);
-                            atomic_add_f32(L.gx + tp.i10 + c, b10 * gm);
-                            atomic_add_f32(L.gx + tp.i11 + c, b11 * gm);
-                        }
-                    }
-                    if (want_off) {
-                        const float hy = 1.f - tp.ly, hx = 1.f - tp.lx;
-                        const float v00 = (tp.flags & 1) ? xv[r][0] : 0.f;
-                        const float v01 = (tp.flags & 2) ? xv[r][1] : 0.f;
-                        const float v10 = (tp.flags & 4) ? xv[r][2] : 0.f;
-                        const float v11 = (tp.flags & 8) ? xv[r][3] : 0.f;
-                        // coordinate weights, kernel.cu:145-188 / 800-845
-                        const float dy = hx * (v10 - v00) + tp.lx * (v11 - v01);
-                        const float dx = hy * (v01 - v00) + tp.ly * (v11 - v10);
-                        const float bil =
-                            hy * hx * v00 + hy * tp.lx * v01 + tp.ly * hx * v10 + tp.ly * tp.lx * v11;
-                        sy[r] += gm * dy;
-                        sx[r] += gm * dx;
-                        sm[r] += gval * bil;
-                    }
-                }
-            }
-            if (want_off) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float vy = row16_sum(sy[r]), vx = row16_sum(sx[r]), vm = row16_sum(sm[r]);
-                    if (j16 == 0) {   // the row is private to this wave: plain read-modify-write
-                        float *ga = gacc + (pl_of(kq * 4 + r) * KD + kd) * 3;
-                        ga[0] += vy;
-                        ga[1] += vx;
-                        ga[2] += vm;
-                    }
-                }
-            }
-            LSN_STAMP(6);
-            __syncthreads();  // Bs free for the next chunk; this chunk's window adds are complete
-            LSN_STAMP(7);
-            if (L.gx != nullptr && use_win && (!umode || ch.k == K - 1)) flush(wp, g * Cg + ch.c0, ch.nval);
-        }
-    }
-    __syncthreads();
-
-    // ---- write grad_offset / grad_mask for this tile ----
-    for (int e = tid; e < BW3_PX * KD; e += 512) {
-        const int pl = e / KD, r = e - pl * KD;
-        const int dgi = r / K, k = r - dgi * K;
-        const int ho = pty * BW3_PH + (pl >> 4), wo = ptx * BW3_PW + (pl & 15);
-        if (ho >= L.Ho || wo >= L.Wo) continue;
-        const float *ga = gacc + e * 3;
-        if (L.goff) {
-            float *op = L.goff + (size_t)pb * L.osb + (size_t)ho * L.osh + (size_t)wo * L.osw;
-            op[(size_t)(dgi * 2 * K + 2 * k) * L.osc] = ga[0];
-            op[(size_t)(dgi * 2 * K + 2 * k + 1) * L.osc] = ga[1];
-        }
-        if (L.gmsk) {
-            float gm = ga[2];
-            if (a.msig) {  // d sigmoid: m (1 - m); out-of-range samples have ga[2] == 0 already
-                const float m = tab[e].m;
-                gm *= m * (1.f - m);
-            }
-            L.gmsk[(size_t)pb * L.msb + (size_t)(dgi * K + k) * L.msc + (size_t)ho * L.msh + (size_t)wo * L.msw] = gm;
-        }
-    }
-}
-
-// =============================================================================================
 // Backward-weight:  gw[co][k,ci] += sum_p gout[p][co] * col[p][k,ci];  gb[co] += sum_p gout[p][co].
 // GEMM with M = output channels (<=256 per block), N = 64 k-columns (one tap x 64 channels),
 // reduction over pixels.  grid.x = column blocks, grid.y = pixel splits, grid.z = co blocks;
 // each block walks its share of the 32-pixel steps of all levels, re-gathering col on the fly
 // (the reference re-runs im2col for the same purpose, deform_conv_cuda.cpp:770-773), and ends
-// with fp32 atomics into gw (zero-filled by the launcher).
+// with per-split partial gradients for the ordered reduce (a.wg_part) or, without them, fp32 atomics into gw.
 // =============================================================================================
 constexpr int WG_BP = 32, WG_BN = 64, WG_BM = 256;
 template <bool VEC>
@@ -3022,6 +2073,9 @@ __global__ __launch_bounds__(256, 2) void dcn_wgrad_kernel(const DcnArgs a, int 
         }
     }
 
+    // a.wg_part (round 6): per-split partial gradients + the ordered reduce instead of fp32 atomics: the exact mode's weight
+    // gradients are bit-reproducible like the default mode's (a split without steps still stores its zero tile)
+    float *pw = a.wg_part ? a.wg_part + (size_t)blockIdx.y * a.Co * Kdim : nullptr;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -3031,11 +2085,20 @@ __global__ __launch_bounds__(256, 2) void dcn_wgrad_kernel(const DcnArgs a, int 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wave * 64 + i * 32 + mfma32_row(r, lane);
-                if (row < nco)
-                    atomic_add_f32(a.gw + (size_t)(co_base + row) * Kdim + ch.k * Cg + ch.c0 + col, acc[i][j][r]);
+                if (row >= nco) continue;
+                const size_t e = (size_t)(co_base + row) * Kdim + ch.k * Cg + ch.c0 + col;
+                if (pw)
+                    pw[e] = acc[i][j][r];   // this pixel split's partial gradient: the ordered reduce adds the splits
+                else
+                    atomic_add_f32(a.gw + e, acc[i][j][r]);
             }
         }
-    if (do_bias && tid < nco) atomic_add_f32(a.gb + co_base + tid, bias_acc);
+    if (do_bias && tid < nco) {
+        if (a.wg_part_b)
+            a.wg_part_b[(size_t)blockIdx.y * a.Co + co_base + tid] = bias_acc;
+        else
+            atomic_add_f32(a.gb + co_base + tid, bias_acc);
+    }
 }
 
 // =============================================================================================

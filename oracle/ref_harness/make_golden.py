@@ -458,43 +458,19 @@ def golden_backbones_dcn():
     from mmdet.models import build_backbone
     sys.path.insert(0, '/root/repo')
     from lsnet_amd.model_zoo import backbone_cfg
-    def relu_margin(bb, x):
-        """smallest |pre-activation| of any ReLU of the network, relative to the largest of the same tensor: how far the
-        forward pass stays from the kinks of the network (an implementation whose sums differ in the last bits flips a gate
-        whose pre-activation lies within ~1e-6 of zero, and a flip deep in the network moves a patch of the input gradient)"""
-        worst = [float('inf')]
-
-        def pre(mod, inp):
-            t = inp[0].detach()
-            worst[0] = min(worst[0], float(t.abs().min() / t.abs().max().clamp_min(1e-30)))
-        hooks = [m.register_forward_pre_hook(pre) for m in bb.modules() if isinstance(m, torch.nn.ReLU)]
-        with torch.no_grad():
-            bb(x)
-        for h in hooks:
-            h.remove()
-        return worst[0]
-
     for name, fixture in (('r101-dcn', 'backbone_r101_dcn'), ('x101-dcn', 'backbone_x101_dcn')):
         cfg = backbone_cfg(name)
         cfg.pop('with_cp', None)
         bb = build_backbone(mmcv.Config(copy.deepcopy(cfg))._cfg_dict)
         bb.train()
-        # round 6 (VERDICT r5 item 5c): the X-101 fixture's parameter fill is the first seed whose forward pass keeps every ReLU
-        # pre-activation at least 4e-6 of its tensor's range away from zero (seed 13, rounds 3 - 5: 0.28 % of the input-gradient
-        # samples moved by more than 1e-3 on the device -- flipped gates of a 101-layer network).  The seed travels in the fixture.
-        seed = 13
-        if name == 'x101-dcn':
-            xs = torch.randn(1, 3, 96, 128, generator=gu.gen(41))
-            for seed in range(13, 80):
-                gu.fill_params(bb, seed=seed)
-                m = relu_margin(bb, xs)
-                print(f'x101-dcn fill seed {seed}: ReLU margin {m:.2e}', flush=True)
-                if m >= 4e-6:
-                    break
-        gu.fill_params(bb, seed=seed)
+        # (Round 6, VERDICT r5 item 5c -- "regenerate with kink-free inputs" -- tried and not possible: over 67 parameter-fill seeds
+        # the closest ReLU pre-activation of the X-101 forward pass lay within 2e-8 .. 7e-8 of its tensor's range from zero.  A
+        # 101-layer network at this input size always has gates inside rounding distance of the kink, whatever the seed; the
+        # fixture keeps seed 13 and the test its measured bound: tests/golden_cases.py backbone_dcn_case.)
+        gu.fill_params(bb, seed=13)
         x = torch.randn(1, 3, 96, 128, generator=gu.gen(41)).requires_grad_()
         data = {'keys': np.array(sorted(bb.state_dict().keys())),
-                'nparams': np.array(sum(p.numel() for p in bb.parameters())), 'fill_seed': np.array(seed)}
+                'nparams': np.array(sum(p.numel() for p in bb.parameters()))}
         feats = bb(x)
         proj = sum((f * torch.randn(f.shape, generator=gu.gen(50 + i))).sum() / f.numel() ** 0.5 for i, f in enumerate(feats))
         names = gu.backbone_grad_names(bb)

@@ -108,7 +108,10 @@ def test_training_curve_follows_reference_runner(math):
         # (loss_cls 1.70 against 2.48) -- these iterations only have to stay within a factor of two, as in round 3 (late 1.0 for the
         # exact and 3-product modes; the default mode is bit-reproducible and keeps 0.3).  What holds all twenty iterations tight is
         # the low-lr test.
-        worst = gc.train_curve_case(_dev(), early_tol=3e-3 if math == 'bf16x6' else 3e-2, late_tol=0.3 if math == 'bf16x6' else 1.0,
+        # Round 6: the exact mode no longer scatters with atomics (bit-reproducible like the default mode) and takes the default
+        # mode's tolerances; only the 3-product mode (16 mantissa bits per operand under a collapsing loss) keeps the wide ones.
+        tight = math in ('bf16x6', 'fp32')
+        worst = gc.train_curve_case(_dev(), early_tol=3e-3 if tight else 3e-2, late_tol=0.3 if tight else 1.0,
                                     rtol_weight=5e-2, channels_last=True)
     finally:
         _lib.set_math_mode(before)
@@ -140,10 +143,9 @@ def test_training_curve_low_learning_rate(math):
         # round 5: ALL twenty iterations (the loss falls 442 -> 3.5).  Iterations 1 - 8 to `tol`; 9 - 20: 5e-3 for the total and
         # the classification loss in the fp32-equivalent mode (measured 1.0e-3), 3e-2 for the regression terms and for the exact
         # mode (measured 1.6e-2: its round-1 deformable kernels scatter with fp32 atomics)
-        late = dict(tol, loss=5e-3, loss_cls=5e-3, loss_bbox_init=3e-2, loss_bbox_refine=3e-2) if math == 'bf16x6' else \
-            dict(loss=3e-2, loss_cls=3e-2, loss_bbox_init=5e-2, loss_bbox_refine=5e-2)
-        if math != 'bf16x6':   # (exact mode, a second run: the refine term 2.3e-2 at iteration 7 -- one re-assigned point)
-            tol = dict(tol, loss_bbox_init=5e-2, loss_bbox_refine=5e-2)
+        # (round 6: the exact mode is bit-reproducible now -- atomic-free gather, ordered weight-gradient partials -- and is held
+        # to the default mode's bounds; rounds 3 - 5 gave it 3e-2 / 5e-2 because its atomics re-assigned a point in some runs)
+        late = dict(tol, loss=5e-3, loss_cls=5e-3, loss_bbox_init=3e-2, loss_bbox_refine=3e-2)
         worst = gc.train_curve_case(_dev(), early_tol=tol, late_tol=late, rtol_weight=1e-2, channels_last=True,
                                     fixture='train_curve_lowlr', lr=0.001, iters=LOWLR_ITERS)
     finally:
@@ -152,6 +154,27 @@ def test_training_curve_low_learning_rate(math):
 
 
 LOWLR_ITERS = 20
+
+
+@pytest.mark.parametrize('math', ['bf16x6', 'fp32'])
+def test_training_curve_of_the_benchmark_model(math):
+    """Round 6: the curve the reference's schedule_1x.py:5-10 actually produces -- the UNTOUCHED
+    seed-0 init_weights model (the model `python bench.py` trains), 2 images 3 x 384 x 512 per iteration, lr 0.01 behind a
+    10-iteration linear warm-up, clip 35, SGD momentum 0.9 -- against the reference's detector + mmcv runner on the same weights
+    and batches (fixture train_curve_init0.npz, make_golden.py train_curve_init0): the loss goes 5.02 -> 3.22 smoothly, no
+    collapse, so ALL twenty iterations are held to 1e-2 (total and classification loss; 2e-2 for the two regression terms,
+    where one re-assigned point shows) in both modes -- the 0.3 / 1.0 late tolerances of the parameter-fill fixture above
+    are what a 442 -> 3.4 collapse needs, not what the kernels need."""
+    from lsnet_amd import _lib
+    before = _lib.get_math_mode()
+    _lib.set_math_mode(math)
+    try:
+        tol = dict(loss=1e-2, loss_cls=1e-2, loss_bbox_init=2e-2, loss_bbox_refine=2e-2)
+        worst = gc.train_curve_case(_dev(), early_tol=tol, late_tol=tol, rtol_weight=2e-2, channels_last=True,
+                                    fixture='train_curve_init0', init0=True)
+    finally:
+        _lib.set_math_mode(before)
+    print(math, f'benchmark-model curve: worst relative loss deviation over twenty iterations {worst:.2e}')
 
 
 def test_iteration0_losses_at_the_benchmark_shape():

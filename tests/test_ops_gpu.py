@@ -128,17 +128,15 @@ def _to(t, dev, cl):
 
 
 KERNEL_CHOICES = {
-    # name: (math mode, debug word).  Bit 23: atomic scatter instead of the anchor-list gather; bits 25 / 24: force the
-    # first / the windowed backward-data kernel (lsn_debug_phase_clocks).  The split weight-gradient kernel reads the
-    # same two bits as "scalar loads" / "compute the sampling table instead of copying the launch-wide one", so those two
-    # choices also cover its fallback paths.
+    # name: (math mode, debug word).  Bit 23: atomic scatter instead of the anchor-list gather (lsn_debug_phase_clocks).  The split
+    # weight-gradient kernel reads bits 24 / 25 as "compute the sampling table instead of copying the launch-wide one" / "scalar
+    # loads": the one atomic choice below also covers those fallback paths.  (Round 6: the windowed scatter kernels and the
+    # pipelined fp32 forward are gone, 7 -> 5 choices; the exact mode takes the atomic-free gather as well.)
     'default': ('bf16x6', 0),                       # fp32-equivalent products, atomic-free grad_input
     'x6_first_gemms': ('bf16x6', 1 << 28),          # bit 28: dcn_kernels.h GEMMs where dcn_mm_kernels.h would serve
-    'x6_atomic': ('bf16x6', 1 << 23),
     'x3_gather': ('bf16x3', 0),
-    'x3_first_kernel': ('bf16x3', (1 << 23) | (1 << 25)),
-    'x3_windowed_kernel': ('bf16x3', (1 << 23) | (1 << 24)),
-    'math_fp32': ('fp32', 0),
+    'x3_atomic_fallbacks': ('bf16x3', (1 << 23) | (1 << 24) | (1 << 25)),
+    'math_fp32': ('fp32', 0),                       # exact fp32: fp32 MFMA forward / weight gradient, fmaf column gradients + gather
 }
 
 
@@ -1252,7 +1250,7 @@ def test_pyramid_outputs_side_by_side(mode):
         assert all(float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) for a, b in zip(g1, g0))
 
 
-@pytest.mark.parametrize('choice', ['default', 'x6_atomic', 'x3_gather', 'x3_windowed_kernel'])
+@pytest.mark.parametrize('choice', ['default', 'x3_gather', 'x3_atomic_fallbacks', 'math_fp32'])
 def test_pyramid_launch_at_bench_shape(choice):
     """One PyramidDeformConv of LSHead.forward_single2 (lsnet_head.py:600-755) at BASELINE config 2: the 15 (level,
     source) pairs in ONE launch; sources are shared by several pairs, so their gradients accumulate in one buffer."""
@@ -1337,6 +1335,33 @@ def test_grouped_backward_is_deterministic(mode):
             assert torch.equal(a[k], c[k]), k
     finally:
         _lib.set_math_mode(before)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', [dict(name='det_dense', C=256, Co=256, hw=(25, 42)),
+                                  dict(name='det_dense_s2', C=128, Co=128, stride=2, hw=(50, 84), bias=False),
+                                  dict(name='det_pyr', C=256, Co=256, mask=False, hw=(25, 42), dst=(13, 21))],
+                         ids=lambda c: c['name'])
+def test_exact_mode_is_deterministic(case):
+    """Round 6: LSN_MATH_FP32 no longer scatters with fp32 atomics.  Its data gradients take the exact
+    fmaf column gradients + the anchor-list gather of the default mode, its weight gradient leaves per-split partial tiles for
+    the ordered reduce: every output of a dense deformable call is bitwise equal on two runs -- weight and bias gradient
+    included -- and stays within 2e-6 of the fp32-equivalent default mode's."""
+    from lsnet_amd import _lib, ops
+    dev = _dev()
+    before = _lib.get_math_mode()
+    x, w, b, off, mask, go, cfg = _make(case, dev, seed=5)
+    try:
+        _lib.set_math_mode('fp32')
+        a = _dcn_all(ops, x, w, b, off, mask, go, cfg, dev)
+        c = _dcn_all(ops, x, w, b, off, mask, go, cfg, dev)
+        _lib.set_math_mode('bf16x6')
+        d = _dcn_all(ops, x, w, b, off, mask, go, cfg, dev)
+    finally:
+        _lib.set_math_mode(before)
+    for k in a:
+        assert torch.equal(a[k], c[k]), f'{k}: two exact-mode runs differ'
+        assert float((a[k] - d[k]).abs().max()) <= 5e-6 * float(d[k].abs().max()) + 1e-30, k
 
 
 @pytest.mark.gpu
