@@ -296,13 +296,12 @@ class HipBackend:
         if cfg['groups'] == 1 and _lib.split_math():
             ws = torch.empty(2 * w.numel(), device=w.device, dtype=torch.float32)   # split + transposed weight planes
             shape.workspace = ws.data_ptr()
-        if cfg['groups'] > 1 or _lib.split_math():
-            # column-gradient buffer + anchor lists of the atomic-free grad_input path (dense: split-bf16 modes; grouped
-            # calls -- ResNeXt-DCN, config 4 -- in every mode: their column gradients are exact fp32)
-            nbytes = int(lib.lsn_dcn_backward_workspace_bytes(ctypes.byref(shape), n, levels))
-            if nbytes > 0:
-                gws = torch.empty(nbytes, device=w.device, dtype=torch.uint8)
-                shape.gather_workspace, shape.gather_workspace_bytes = gws.data_ptr(), nbytes
+        # column-gradient buffer + anchor lists of the atomic-free grad_input path, in every math mode (round 6: the exact mode's
+        # column gradients are fmaf chains in front of the same gather; 0 bytes: a shape only the scatter kernels serve)
+        nbytes = int(lib.lsn_dcn_backward_workspace_bytes(ctypes.byref(shape), n, levels))
+        if nbytes > 0:
+            gws = torch.empty(nbytes, device=w.device, dtype=torch.uint8)
+            shape.gather_workspace, shape.gather_workspace_bytes = gws.data_ptr(), nbytes
         shape.accumulate_param_grads = 1 if accumulate else 0
         pitch = _pixel_pitch(gos[0]) if nhwc else None
         if pitch is not None and pitch != w.shape[0]:
