@@ -104,9 +104,10 @@ KERNEL_NOTES = {
                      'as split-bf16 MFMA, grad_output pre-arranged in fragment order, split partial tiles: grad weight/bias)',
     }),
     'fp32': dict(_COMMON_NOTES, **{
-        'dcn_fwd': 'lsn::dcn_fwd_pipe_kernel (fused bilinear gather + fp32 MFMA implicit GEMM, forward)',
-        'dcn_bwd_data': 'lsn::dcn_bwd_data_kernel / _win_kernel (gout x W^T on fp32 MFMA, fused bilinear scatter)',
-        'dcn_wgrad': 'lsn::dcn_wgrad_kernel (gathered columns^T x gout on fp32 MFMA: grad weight/bias)',
+        'dcn_fwd': 'lsn::dcn_fwd_kernel (fused bilinear gather + fp32 MFMA implicit GEMM, forward)',
+        'dcn_bwd_data': 'lsn::dcn_gcol_mfma_kernel (gout x W^T on fp32 MFMA -> unweighted column gradients) + the atomic-free '
+                        'per-anchor gather of the default mode (dcn_anchor_sum / _combine / dcn_offgrad kernels): bit-reproducible',
+        'dcn_wgrad': 'lsn::dcn_wgrad_kernel (gathered columns^T x gout on fp32 MFMA, per-split partial tiles + ordered reduce)',
     }),
 }
 MATH_NOTES = {
@@ -115,8 +116,8 @@ MATH_NOTES = {
               'rounding of an fp32 product), fp32 accumulation: fp32-equivalent, <= 1e-6 of the output range against the '
               'exact-fp32 MFMA kernels (tests/test_ops_gpu.py::test_split6_matches_exact_fp32)',
     'bf16x3': 'fp32 tensors; products as 3 bf16 MFMA terms of 2-way splits (hh+hl+lh), fp32 accumulation, rel. err 5e-6',
-    'fp32': 'exact fp32 MFMA for the deformable family; dense convolutions on the 6-term split kernels (fp32-equivalent): no '
-            'vendor convolution in any mode',
+    'fp32': 'exact fp32 MFMA for the deformable family (round 6: atomic-free, bit-reproducible like the default mode); dense '
+            'convolutions on the 6-term split kernels (fp32-equivalent): no vendor convolution in any mode',
 }
 
 

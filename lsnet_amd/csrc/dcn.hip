@@ -754,9 +754,43 @@ static int launch_bwd_colbuf(DcnArgs &a, GatherPlan &pl, unsigned char *ws, hipS
     float *Hb = nullptr;
     const bool grouped = a.groups > 1 || NP == 0;   // (NP = 0: LSN_MATH_FP32, every call)
     if (grouped) {   // exact-fp32 column gradients per group, unweighted; the gather pass does the rest as for the dense GEMM
-        const long long nquads = (long long)pl.nsamples / a.dg * (a.C / 4);
-        const int blocks = (int)((nquads + 255) / 256 < 16384 ? (nquads + 255) / 256 : 16384);
-        hipLaunchKernelGGL(dcn_gcol_grouped_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, st, a, nquads);
+        int ks = 0;   // k-steps of the fp32-MFMA form (dcn_grouped_kernels.h dcn_gcol_mfma_kernel); 0: the fmaf-chain kernel
+        const int Cg = a.C / a.groups, Cog = a.Co / a.groups;
+        if (grouped_env() && a.C % GC_COLS == 0 && a.opitch % 4 == 0) {
+            if (a.groups == 1 && (a.Co == 64 || a.Co == 128 || a.Co == 256)) ks = a.Co / 4;
+            if (a.groups > 1 && Cog == Cg && (Cg == 4 || Cg == 8 || Cg == 16 || Cg == 32)) ks = Cg == 32 ? 8 : 4;
+            for (int i = 0; i < a.nlv; ++i)
+                if ((reinterpret_cast<uintptr_t>(a.lv[i].gout) & 15) != 0) ks = 0;
+        }
+        if (ks) {
+            DcnArgs g = a;
+            int tiles = 0;
+            for (int i = 0; i < g.nlv; ++i) {
+                g.lv[i].tile0 = tiles;
+                tiles += cdiv(g.lv[i].P, GC_PX);
+            }
+            const int nred = a.groups == 1 ? a.Co : GC_COLS;
+            const size_t lds = dcn_gcol_mfma_lds_bytes(nred);
+            const dim3 grid(tiles * (a.C / GC_COLS));
+            auto go = [&](auto kern) -> int {
+                if (int rc = set_lds(kern, lds)) return rc;
+                hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, g, nred);
+                return 0;
+            };
+            int rc = 0;
+            switch (ks) {
+            case 4: rc = go(dcn_gcol_mfma_kernel<4>); break;
+            case 8: rc = go(dcn_gcol_mfma_kernel<8>); break;
+            case 16: rc = go(dcn_gcol_mfma_kernel<16>); break;
+            case 32: rc = go(dcn_gcol_mfma_kernel<32>); break;
+            default: rc = go(dcn_gcol_mfma_kernel<64>); break;
+            }
+            if (rc) return rc;
+        } else {
+            const long long nquads = (long long)pl.nsamples / a.dg * (a.C / 4);
+            const int blocks = (int)((nquads + 255) / 256 < 16384 ? (nquads + 255) / 256 : 16384);
+            hipLaunchKernelGGL(dcn_gcol_grouped_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, st, a, nquads);
+        }
         for (int i = 0; i < a.nlv; ++i)
             if (a.lv[i].goff || a.lv[i].gmsk) Hb = reinterpret_cast<float *>(ws + pl.o_H);
     } else if (a.mm) {   // the dense kernel writes the unweighted column gradients; everything else happens in the gather pass

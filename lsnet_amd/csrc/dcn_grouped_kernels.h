@@ -231,4 +231,85 @@ __global__ __launch_bounds__(256) void dcn_fwd_grouped_kernel(const DcnArgs a)
         }
 }
 
+// ---- column gradients of the backward-data pass on the fp32 matrix instructions ----
+//   gcol[(row, k)][c] = sum_{j < Co / groups} gout[row][g Cog + j] * w[g Cog + j][k][c - g Cg],   g = c / Cg      (UNWEIGHTED)
+// -- what dcn_gcol_grouped_kernel (dcn_kernels.h) computes with one fmaf chain per thread: 14.6 of the 108 ms of the config-4
+// step, and ~5 ms per tower launch when the exact mode sends dense calls through it (round 6).  Here: workgroup = 32 launch-wide
+// pixel rows x 64 columns, wave = 16 columns for both 16-row halves.  The grad_output tile is staged in LDS once and a wave keeps
+// its A fragments (rows x the gout channels its columns reduce over: the group's Cog, or all Co of a dense call; below 16 channels
+// per group the groups of a 16-column tile share the fragment through a block-diagonal weight fragment) in registers for all
+// taps; per tap the weight fragments come from L2, KS steps of v_mfma_f32_16x16x4_f32 per half, then the 16 x 16 tile of the tap
+// is stored.  Exact fp32 (the fmaf chain of the reference up to summation order).
+// KS = k-steps of four gout channels: 4 (groups of 4 / 8 / 16 channels), 8 (32), Co / 4 for a dense call (Co <= 256).
+constexpr int GC_PX = 32, GC_COLS = 64;
+__host__ __device__ inline int dcn_gcol_mfma_pitch(int nred) { return nred + 4; }   // LDS row pitch in floats: 4 n + kk hits 64 banks
+__host__ __device__ inline size_t dcn_gcol_mfma_lds_bytes(int nred) { return (size_t)GC_PX * dcn_gcol_mfma_pitch(nred) * sizeof(float); }
+
+template <int KS>
+__global__ __launch_bounds__(256) void dcn_gcol_mfma_kernel(const DcnArgs a, int nred)
+{
+    extern __shared__ __align__(16) float csm[];   // [GC_PX][pitch]: the gout channels [red0, red0 + nred) of the tile's rows
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = a.kh * a.kw, C = a.C;
+    const int Cg = C / a.groups, Cog = a.Co / a.groups;
+    const int nspan = C / GC_COLS;
+    const int ptile = blockIdx.x / nspan, span = blockIdx.x - ptile * nspan;
+    const Lvl &L = find_level(a, ptile);
+    const int p0 = (ptile - L.tile0) * GC_PX;
+    const int c0 = span * GC_COLS;
+    // gout channels this workgroup reduces over: all of them (dense), or those of the span's groups
+    const int red0 = a.groups == 1 ? 0 : (c0 / Cg) * Cog;
+    const int pitch = dcn_gcol_mfma_pitch(nred);
+    for (int e = tid; e < GC_PX * (nred / 4); e += 256) {
+        const int px = e / (nred / 4), q = e - px * (nred / 4);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p0 + px < L.P) v = *reinterpret_cast<const float4 *>(L.gout + (size_t)(p0 + px) * a.opitch + red0 + 4 * q);
+        *reinterpret_cast<float4 *>(csm + px * pitch + 4 * q) = v;
+    }
+    __syncthreads();
+    const int n = lane & 15, kk = lane >> 4;
+    const int col = c0 + 16 * wave + n;                 // this lane's output column (B / D column n)
+    const int g = col / Cg, ci = col - g * Cg;
+    // the wave's reduction window inside the staged channels: KS * 4 channels starting at wred0 (relative to red0)
+    const int wred0 = a.groups == 1 ? 0 : (c0 + 16 * wave) / Cg * Cog - red0;
+    float af[2][KS];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) af[h][s] = csm[(16 * h + n) * pitch + wred0 + 4 * s + kk];
+    const size_t row0 = (size_t)(L.prow0 + p0);
+    // weight fragment element (tap k, step s): w[j][k][ci], j = red0 + wred0 + 4 s + kk -- a raw buffer load at a 32-bit offset
+    // (per-lane part: j of step 0 and ci; per-step and per-tap parts are wave-uniform), zero for the other groups of the tile
+    const __amdgpu_buffer_rsrc_t wrs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.w), 0, (int)((size_t)a.Co * K * Cg * 4), 0x00020000);
+    const int wv0 = (((red0 + wred0 + kk) * K) * Cg + ci) * 4, wstep = 4 * K * Cg * 4;
+    const int jrel0 = red0 + wred0 + kk - g * Cog;          // gout channel of step 0 relative to the lane's group
+    for (int k = 0; k < K; ++k) {
+        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        constexpr int WB = KS < 16 ? KS : 16;   // weight fragments in flight (a dense call has up to 64 k-steps per tap)
+#pragma unroll
+        for (int s0 = 0; s0 < KS; s0 += WB) {
+            float wf[WB];
+#pragma unroll
+            for (int s = 0; s < WB; ++s) {
+                const float v = buf_load_f32(wrs, wv0 + (s0 + s) * wstep, k * Cg * 4);
+                wf[s] = (unsigned)(jrel0 + 4 * (s0 + s)) < (unsigned)Cog ? v : 0.f;
+            }
+#pragma unroll
+            for (int s = 0; s < WB; ++s) {
+                acc[0] = mfma16(af[0][s0 + s], wf[s], acc[0]);
+                acc[1] = mfma16(af[1][s0 + s], wf[s], acc[1]);
+            }
+            if (KS > WB) __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int px = 16 * h + 4 * kk + i;
+                if (p0 + px < L.P) a.gcol[((row0 + px) * K + k) * C + col] = acc[h][i];
+            }
+    }
+}
+
 }  // namespace lsn
