@@ -89,6 +89,13 @@ typedef struct {
                                       * side by side and reads their gradient where the next convolution left it, no
                                       * concatenation or slice copy in between.  Served by the matrix-pipe kernels only:
                                       * ask lsn_dcn_pitched_ok() first, the calls fail with LSN_ERR_UNSUPPORTED otherwise. */
+    int weights_prepared;            /* 1: `workspace` already HOLDS the weight's fragment image for this pass -- forward: the
+                                      * image lsn_conv2d_prepare_weights(kind 0) builds of the (Co, kh, kw, C) weight; backward:
+                                      * kind 2 -- and the call does not rebuild it (round 6: the head's deformable layers keep
+                                      * their images per optimizer step like the dense convolutions, 16 launches less per step;
+                                      * the reference re-reads its weight in every call, deform_conv_cuda.cpp:662-684).  Only for
+                                      * calls the matrix-pipe kernels serve: ask lsn_dcn_prepared_ok() first, the call fails
+                                      * with LSN_ERR_UNSUPPORTED otherwise.  The image is read, not modified. */
 } lsn_dcn_shape;
 
 /* One (source map, offset field, output) triple of a batched launch.  All levels of a launch
@@ -151,6 +158,10 @@ int64_t lsn_dcn_backward_workspace_bytes(const lsn_dcn_shape *shape, int n_level
 /* 1 when lsn_dcn_forward (backward == 0) / lsn_dcn_backward (backward != 0) would serve this call with
  * shape->out_pitch != Co in the current math mode (shape->workspace / gather_workspace as they will be passed), else 0. */
 int lsn_dcn_pitched_ok(const lsn_dcn_shape *shape, int n_levels, const lsn_dcn_level *levels, int backward);
+/* 1 when the call would read its weight from a fragment image in shape->workspace (the matrix-pipe kernels: forward, and the
+ * backward's column-gradient GEMM), i.e. when shape->weights_prepared may be set; workspace / gather_workspace as they will
+ * be passed. */
+int lsn_dcn_prepared_ok(const lsn_dcn_shape *shape, int n_levels, const lsn_dcn_level *levels, int backward);
 
 /* ---- one-to-one replacements of the reference extension's functions ----------------------- */
 /* Each takes contiguous NCHW tensors like the reference and the same scalar arguments in the

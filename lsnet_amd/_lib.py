@@ -25,7 +25,7 @@ class DcnShape(ctypes.Structure):
                 ('scale_h', ctypes.c_float), ('scale_w', ctypes.c_float), ('mask_is_logit', ctypes.c_int),
                 ('workspace', ctypes.c_void_p), ('gather_workspace', ctypes.c_void_p),
                 ('gather_workspace_bytes', ctypes.c_int64), ('accumulate_param_grads', ctypes.c_int),
-                ('out_pitch', ctypes.c_int)]
+                ('out_pitch', ctypes.c_int), ('weights_prepared', ctypes.c_int)]
 
 
 class DcnLevel(ctypes.Structure):
@@ -96,7 +96,7 @@ class ProfLaunch(ctypes.Structure):     # lsn_prof_launch
 
 # every symbol include/lsnet_hip.h declares (checked by tests/test_capi.py without a GPU)
 EXPORTS = [
-    'lsn_last_error', 'lsn_version', 'lsn_dcn_forward', 'lsn_dcn_backward', 'lsn_dcn_backward_workspace_bytes', 'lsn_dcn_pitched_ok',
+    'lsn_last_error', 'lsn_version', 'lsn_dcn_forward', 'lsn_dcn_backward', 'lsn_dcn_backward_workspace_bytes', 'lsn_dcn_pitched_ok', 'lsn_dcn_prepared_ok',
     'lsn_deform_conv_forward', 'lsn_deform_conv_backward_input', 'lsn_deform_conv_backward_parameters',
     'lsn_modulated_deform_conv_forward', 'lsn_modulated_deform_conv_backward',
     'lsn_pyramid_deform_conv_forward', 'lsn_pyramid_deform_conv_backward_input',

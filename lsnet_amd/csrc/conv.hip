@@ -696,6 +696,7 @@ static int conv_backward_data_impl(int n, const lsn_conv_level *lv, const void *
 static int64_t prepared_bytes(int kind, int C, int Co, int kh, int kw, int stride, int pad, int dil)
 {
     if (kind == 0) return (int64_t)cv_wfrag_bytes(Co, kh * kw, C, conv_npl());
+    if (kind == 2) return (int64_t)cv_wfrag_bytes(kh * kw * C, 1, Co, conv_npl());   // deformable backward GEMM: N = K C columns
     BwdPlan pl;
     if (bwd_plan(C, Co, kh, kw, stride, pad, dil, &pl)) return -1;
     return (int64_t)pl.bytes;
@@ -724,6 +725,8 @@ static int prepare_weights(int kind, const float *w, void *prepared, int C, int 
         return fail(LSN_ERR_UNSUPPORTED, "conv2d: weight too large for 32-bit buffer offsets");
     if (kind == 0) {
         conv_wfrag(w, reinterpret_cast<unsigned short *>(prepared), Co, kh * kw, C, 0, TapSub{}, st, bn);
+    } else if (kind == 2) {
+        conv_wfrag(w, reinterpret_cast<unsigned short *>(prepared), kh * kw * C, 1, Co, 1, TapSub{0, 1, 1, 0, 1, 1, 1}, st, bn);
     } else {
         BwdPlan pl;
         if (int rc = bwd_plan(C, Co, kh, kw, stride, pad, dil, &pl)) return rc;
@@ -1000,6 +1003,12 @@ static int prepare_weights_multi(int n, const lsn_conv_wprep *it, hipStream_t st
         if (p.kind == 0) {
             WfragJob j;
             wfrag_job(j, p.w, reinterpret_cast<unsigned short *>(p.prepared), p.Co, p.kh * p.kw, p.C, 0, TapSub{}, bn);
+            j.start = total;
+            total += wfrag_threads(j);
+            jobs.push_back(j);
+        } else if (p.kind == 2) {
+            WfragJob j;
+            wfrag_job(j, p.w, reinterpret_cast<unsigned short *>(p.prepared), p.kh * p.kw * p.C, 1, p.Co, 1, TapSub{0, 1, 1, 0, 1, 1, 1}, bn);
             j.start = total;
             total += wfrag_threads(j);
             jobs.push_back(j);

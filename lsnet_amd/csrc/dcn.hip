@@ -287,21 +287,24 @@ static bool mm_bwd_ok(const DcnArgs &a)
 
 // weight image in fragment order into `dst` (forward: (Co, K, C) as it lies; backward: the transposed 1x1 view with
 // N = K * C columns and the reduction over Co)
-static int mm_prepare_weights(DcnArgs &a, bool backward, void *dst, hipStream_t st)
+// (prepared: the caller's image is already there -- lsn_dcn_shape.weights_prepared)
+static int mm_prepare_weights(DcnArgs &a, bool backward, void *dst, hipStream_t st, bool prepared = false)
 {
     const int K = a.kh * a.kw;
     const int Co = backward ? K * a.C : a.Co, Kd = backward ? 1 : K, C = backward ? a.Co : a.C;
     TapSub ts = {0, 1, 1, 0, 1, 1, 1};
     unsigned short *out = reinterpret_cast<unsigned short *>(dst);
-    WfragJob j = {};
-    j.w = a.w, j.out = out, j.Co = Co, j.K = Kd, j.C = C, j.flipT = backward ? 1 : 0, j.ts = ts;
-    const long long total = wfrag_threads(j);
-    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    if (mm_npl() == 3)
-        hipLaunchKernelGGL(conv_wfrag_kernel<3>, dim3(blocks), dim3(256), 0, st, j);
-    else
-        hipLaunchKernelGGL(conv_wfrag_kernel<2>, dim3(blocks), dim3(256), 0, st, j);
-    LSN_HIP(hipGetLastError());
+    if (!prepared) {
+        WfragJob j = {};
+        j.w = a.w, j.out = out, j.Co = Co, j.K = Kd, j.C = C, j.flipT = backward ? 1 : 0, j.ts = ts;
+        const long long total = wfrag_threads(j);
+        const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+        if (mm_npl() == 3)
+            hipLaunchKernelGGL(conv_wfrag_kernel<3>, dim3(blocks), dim3(256), 0, st, j);
+        else
+            hipLaunchKernelGGL(conv_wfrag_kernel<2>, dim3(blocks), dim3(256), 0, st, j);
+        LSN_HIP(hipGetLastError());
+    }
     a.wtp = out;
     a.wtp_bytes = (int)cv_wfrag_bytes(Co, Kd, C, mm_npl());
     a.mm = 1;
@@ -1151,8 +1154,10 @@ static int dcn_forward_impl(const lsn_dcn_shape &s, int n, const lsn_dcn_level *
     if (a.opitch != a.Co && !(layout == LSN_NHWC && s.workspace && mm_fwd_ok(a)))
         return fail(LSN_ERR_UNSUPPORTED, "deformable forward: out_pitch %d != Co %d outside the matrix-pipe kernels "
                     "(lsn_dcn_pitched_ok)", a.opitch, a.Co);
+    if (s.weights_prepared && !(layout == LSN_NHWC && s.workspace && mm_fwd_ok(a)))
+        return fail(LSN_ERR_UNSUPPORTED, "deformable forward: weights_prepared outside the matrix-pipe kernels (lsn_dcn_prepared_ok)");
     if (s.workspace && mm_fwd_ok(a)) {
-        if (int rc = mm_prepare_weights(a, false, s.workspace, st)) return rc;
+        if (int rc = mm_prepare_weights(a, false, s.workspace, st, s.weights_prepared != 0)) return rc;
     } else if (s.workspace && math_np() && (Cg % 8 == 0) && a.Co / a.groups > 64 && xn_ok(a)) {
         const size_t nw = (size_t)s.Co * K * Cg;   // split the weights once instead of in every block
         if (math_np() == 6)
@@ -1245,8 +1250,10 @@ static int dcn_backward_impl(const lsn_dcn_shape &s, int n, const lsn_dcn_level 
         if (a.opitch != a.Co && !(mm && layout == LSN_NHWC))
             return fail(LSN_ERR_UNSUPPORTED, "deformable backward: out_pitch %d != Co %d outside the matrix-pipe kernels "
                         "(lsn_dcn_pitched_ok)", a.opitch, a.Co);
+        if (s.weights_prepared && !(mm && layout == LSN_NHWC))
+            return fail(LSN_ERR_UNSUPPORTED, "deformable backward: weights_prepared outside the matrix-pipe kernels (lsn_dcn_prepared_ok)");
         if (mm) {
-            if (int rc = mm_prepare_weights(a, true, s.workspace, st)) return rc;
+            if (int rc = mm_prepare_weights(a, true, s.workspace, st, s.weights_prepared != 0)) return rc;
         } else if (can_split) {
             if (math_np() == 6)
                 hipLaunchKernelGGL(dcn_prepare_wt_kernel<3>, dim3(512), dim3(256), 0, st, a.w,
@@ -1488,6 +1495,26 @@ int64_t lsn_dcn_backward_workspace_bytes(const lsn_dcn_shape *shape, int n_level
     GatherPlan pl;
     gather_plan(a, pl);
     return pl.ok ? (int64_t)pl.bytes : 0;
+}
+
+int lsn_dcn_prepared_ok(const lsn_dcn_shape *shape, int n_levels, const lsn_dcn_level *levels, int backward)
+{
+    using namespace lsn;
+    if (!shape || !levels || !shape->workspace || check_shape(*shape) != 0) return 0;
+    DcnArgs a;
+    if (fill_levels(a, *shape, n_levels, levels, backward ? BWD_BM : 64) != 0) return 0;
+    if (!backward) return mm_fwd_ok(a) ? 1 : 0;
+    bool any_data = false;
+    for (int i = 0; i < n_levels; ++i) {
+        a.lv[i].gx = levels[i].grad_input, a.lv[i].goff = levels[i].grad_offset, a.lv[i].gmsk = levels[i].grad_mask;
+        any_data = any_data || levels[i].grad_input || levels[i].grad_offset || levels[i].grad_mask;
+    }
+    a.wtp = reinterpret_cast<const unsigned short *>(shape->workspace);
+    if (!any_data || !shape->gather_workspace || !bwd_colbuf_env() || math_np() == 0 || shape->groups != 1 || a.Co % 2 != 0) return 0;
+    if (!mm_bwd_ok(a) || !bwd_gather_ok(a)) return 0;
+    GatherPlan pl;
+    gather_plan(a, pl);
+    return (pl.ok && (int64_t)pl.bytes <= shape->gather_workspace_bytes) ? 1 : 0;
 }
 
 int lsn_dcn_pitched_ok(const lsn_dcn_shape *shape, int n_levels, const lsn_dcn_level *levels, int backward)

@@ -7,6 +7,8 @@ from .. import _lib
 from .backend import register_backend
 
 _CL = torch.channels_last
+# LSNET_CACHE_DCN_IMAGES=0: the deformable layers build their weight images inside every call, as until round 5 (A/B switch)
+CACHE_DCN_IMAGES = __import__('os').environ.get('LSNET_CACHE_DCN_IMAGES', '1') != '0'
 
 
 def _stream():
@@ -170,6 +172,20 @@ class HipBackend:
         mask logits in the rest; the mask pointer is the same buffer advanced by 2*dg*K channels."""
         return ctypes.c_void_p(om.data_ptr() + 2 * cfg['dg'] * kk * om.stride(1) * om.element_size())
 
+    @staticmethod
+    def _cached_image(w, weight, cfg, kind, nhwc):
+        """The fragment image of a deformable layer's weight from the per-optimizer-step cache of the dense convolutions
+        (ops/conv.py weight_image; kind 0: forward, 2: the backward GEMM) -- only for a channels-last PARAMETER handed over as it is
+        (a temporary's image would be built and dropped per call: the in-call build is cheaper), groups = 1.  None: build per call.
+        The library has the last word (lsn_dcn_prepared_ok)."""
+        if not (CACHE_DCN_IMAGES and nhwc and w is weight and cfg['groups'] == 1 and isinstance(weight, torch.nn.Parameter)):
+            return None
+        from .conv import weight_image
+        try:
+            return weight_image(w, kind, 1, cfg['pad'], cfg['dil'])
+        except NotImplementedError:
+            return None
+
     def dcn_forward(self, inputs, offsets, masks, weight, bias, cfg, out_hw):
         """inputs/offsets/masks: per-level lists (mask entries may be None); cfg: stride, pad, dil,
         groups, dg, scales[(sh, sw)]; out_hw: per-level (Ho, Wo).  Returns the per-level outputs."""
@@ -210,8 +226,14 @@ class HipBackend:
             L.scale_h, L.scale_w = cfg['scales'][i]
         b = None if bias is None else _f32(bias.contiguous(), 'bias')
         if _lib.split_math():
-            ws = torch.empty(2 * w.numel(), device=w.device, dtype=torch.float32)   # pre-split weight planes
-            shape.workspace = ws.data_ptr()
+            img = self._cached_image(w, weight, cfg, 0, nhwc)
+            if img is not None:
+                shape.workspace, shape.weights_prepared = img.data_ptr(), 1
+                if not lib.lsn_dcn_prepared_ok(ctypes.byref(shape), n, levels, 0):
+                    img, shape.weights_prepared = None, 0
+            if img is None:
+                ws = torch.empty(2 * w.numel(), device=w.device, dtype=torch.float32)   # pre-split weight planes
+                shape.workspace = ws.data_ptr()
         if wide is not None:
             shape.out_pitch = g * Co
             if not lib.lsn_dcn_pitched_ok(ctypes.byref(shape), n, levels, 0):   # (exact-fp32 mode, odd channel counts)
@@ -266,10 +288,10 @@ class HipBackend:
         # (One call per image -- the column gradients of ONE image of a tower launch, 207 MB, fit the 256 MB Infinity Cache,
         # those of the batch, 413 MB, do not -- was measured SLOWER: deformable backward-data 7.6 vs 6.8 ms per step,
         # profiles/r4_per_image.txt: half-size launches lose more to their tails than the cache returns.)
-        self._dcn_backward_call(xs, offs, msks, w, gos, bufs, goffs, gmsks, gw, gb, acc, cfg, nhwc)
+        self._dcn_backward_call(xs, offs, msks, w, gos, bufs, goffs, gmsks, gw, gb, acc, cfg, nhwc, weight)
         return gxs, goffs, gmsks, gw, gb
 
-    def _dcn_backward_call(self, xs, offs, msks, w, gos, gx_bufs, goffs, gmsks, gw, gb, accumulate, cfg, nhwc):
+    def _dcn_backward_call(self, xs, offs, msks, w, gos, gx_bufs, goffs, gmsks, gw, gb, accumulate, cfg, nhwc, weight=None):
         """One lsn_dcn_backward call over the given (level) tensors; every output buffer is the caller's."""
         lib = _lib.load()
         n = len(xs)
@@ -293,7 +315,10 @@ class HipBackend:
             L.B, L.H, L.W, L.Ho, L.Wo = B, H, W, Ho, Wo
             L.scale_h, L.scale_w = cfg['scales'][i]
         ws = gws = None
-        if cfg['groups'] == 1 and _lib.split_math():
+        img = self._cached_image(w, weight, cfg, 2, nhwc) if _lib.split_math() else None
+        if img is not None:
+            shape.workspace = img.data_ptr()       # (weights_prepared is decided below, when the gather workspace is known)
+        elif cfg['groups'] == 1 and _lib.split_math():
             ws = torch.empty(2 * w.numel(), device=w.device, dtype=torch.float32)   # split + transposed weight planes
             shape.workspace = ws.data_ptr()
         # column-gradient buffer + anchor lists of the atomic-free grad_input path, in every math mode (round 6: the exact mode's
@@ -302,6 +327,12 @@ class HipBackend:
         if nbytes > 0:
             gws = torch.empty(nbytes, device=w.device, dtype=torch.uint8)
             shape.gather_workspace, shape.gather_workspace_bytes = gws.data_ptr(), nbytes
+        if img is not None:
+            shape.weights_prepared = 1
+            if not lib.lsn_dcn_prepared_ok(ctypes.byref(shape), n, levels, 1):   # (the cached image must not be written: own scratch)
+                shape.weights_prepared = 0
+                ws = torch.empty(2 * w.numel(), device=w.device, dtype=torch.float32)
+                shape.workspace = ws.data_ptr()
         shape.accumulate_param_grads = 1 if accumulate else 0
         pitch = _pixel_pitch(gos[0]) if nhwc else None
         if pitch is not None and pitch != w.shape[0]:

@@ -1204,6 +1204,43 @@ def test_dcn_forward_stream_k_pieces(sizes):
         assert float((pieces[i] - whole[i]).abs().max()) <= 2e-6 * scale
 
 
+def test_dcn_weight_images_cached_per_optimizer_step():
+    """Round 6: a deformable layer whose weight is a channels-last Parameter reads its fragment images from
+    the cache of the dense convolutions (lsn_dcn_shape.weights_prepared: forward = kind 0, backward GEMM = kind 2) instead of
+    rebuilding them in every call.  Same bits as the in-call build, forward and every gradient, also after the weight moved."""
+    from lsnet_amd import ops
+    from lsnet_amd.ops import hip_backend
+    dev = _dev()
+    g = torch.Generator().manual_seed(51)
+    C = Co = 256
+    sizes = [(25, 42), (13, 21)]
+    w = torch.nn.Parameter(_to(torch.randn(Co, C, 3, 3, generator=g) / (3 * C ** 0.5), dev, True))
+    b = torch.nn.Parameter(torch.randn(Co, generator=g).to(dev))
+    xs = [_to(torch.randn(2, C, h, ww, generator=g), dev, True).requires_grad_() for h, ww in sizes]
+    offs = [_to(torch.randn(2, 18, h, ww, generator=g) * 1.5, dev, True).requires_grad_() for h, ww in sizes]
+    msks = [_to(torch.rand(2, 9, h, ww, generator=g), dev, True).requires_grad_() for h, ww in sizes]
+    gos = [_to(torch.randn(2, Co, h, ww, generator=g), dev, True) for h, ww in sizes]
+
+    def run(cached):
+        old = hip_backend.CACHE_DCN_IMAGES
+        hip_backend.CACHE_DCN_IMAGES = cached
+        try:
+            outs = ops.dcn_multi(xs, offs, msks, w, b, 1, 1, 1)
+            grads = torch.autograd.grad(outs, [w, b] + xs + offs + msks, gos)
+            return [o.detach().clone() for o in outs] + [t.clone() for t in grads]
+        finally:
+            hip_backend.CACHE_DCN_IMAGES = old
+
+    for step in range(2):
+        ref = run(False)
+        got = run(True)
+        again = run(True)        # (second call: the images come from the cache untouched)
+        for k, (a, c, d) in enumerate(zip(ref, got, again)):
+            assert torch.equal(a, c) and torch.equal(a, d), (step, k)
+        with torch.no_grad():
+            w.add_(0.01)          # the version counter moves: the cached images are stale and rebuilt on the next call
+
+
 @pytest.mark.parametrize('mode', ['bf16x6', 'fp32'])
 def test_pyramid_outputs_side_by_side(mode):
     """`concat=3` of the pyramid op (lsn_dcn_shape.out_pitch: the three maps of a destination level written into one
