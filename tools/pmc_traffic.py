@@ -72,8 +72,9 @@ KIB = 1024 / 1e9
 fam = defaultdict(lambda: {'tower': [0.0, 0.0], 'pyramid': [0.0, 0.0]})
 print(f'{"kernel":64s} {"n":>3s} | tower: FETCHx2 + WRITE (MB) | pyramid: FETCHx2 + WRITE (MB)   (per launch of that kind)')
 # per launch of a kind = sum over the kernel's dispatches of that kind / number of launches of that kind
-prep = next(n for n in fetch if 'dcn_fwd_' in n)
-n_launch = {k: max(len(fetch[prep][k]), 1) for k in ('tower', 'pyramid')}
+# (round 6: the forward kernel has two instantiations -- whole tiles for the tower launch, stream-K pieces for the pyramid
+# launch -- so the launches of a kind are counted over every forward kernel name)
+n_launch = {k: max(sum(len(v[k]) for n, v in fetch.items() if 'dcn_fwd_' in n), 1) for k in ('tower', 'pyramid')}
 for name in sorted(set(fetch) | set(write)):
     f, w = fetch.get(name, {'tower': [], 'pyramid': []}), write.get(name, {'tower': [], 'pyramid': []})
     per = lambda v, k: sum(v[k]) / n_launch[k]
