@@ -70,7 +70,7 @@ def needs_build(so=None, obj_dir=None):
 
 def build(force=False, verbose=False, defines=(), so=None):
     """One object per translation unit (compiled in parallel, only the stale ones), then the link.  `defines` / `so`: an
-    A/B variant of the library beside the product one (tools/r4_calls), with its own object directory."""
+    A/B variant of the library beside the product one (tools/README.md), with its own object directory."""
     so = so or SO
     obj_dir = OBJ_DIR if so == SO else so + '.build'
     if not force and not needs_build(so, obj_dir):
