@@ -36,10 +36,18 @@ WGRAD_SIDE = os.environ.get('LSNET_WGRAD_SIDE', '0') == '1'
 _side_busy = [False]
 
 
+def _collectives_possible():
+    """A process group exists: a gradient sink's `done` may launch a bucket's all-reduce from inside fn(), ordered against the
+    CURRENT stream -- which would be the second stream, not the one the bucket's other gradients were written on.  The
+    experiment is therefore confined to processes without a process group."""
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()
+
+
 def _on_side(tensors, fn):
     """fn() on the second stream, ordered behind everything the launch stream has been given so far; `tensors` (allocated on the
     launch stream) stay out of the allocator's hands until the second stream is through with them."""
-    if not (WGRAD_SIDE and tensors and tensors[0].is_cuda):
+    if not (WGRAD_SIDE and tensors and tensors[0].is_cuda) or _collectives_possible():
         return fn()
     main = torch.cuda.current_stream(tensors[0].device)
     side = side_stream(tensors[0].device)

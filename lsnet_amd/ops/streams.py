@@ -6,7 +6,19 @@ All of it uses ONE stream per device, created as early as possible, and never on
 streams onto a few hardware queues in creation order, and a stream that lands on the queue of the stream the step runs on
 serialises with it -- measured: with one stream per LSHead instance the step of the 2nd, 3rd, 7th model of a process ran 50 - 54 ms
 instead of 31 - 32 (profiles/r5_stream_queues.txt), whatever the stream's priority.  The first stream a process creates after the
-default one has its own queue."""
+default one has its own queue.
+
+Rules for whoever puts work on this stream:
+  * begin with `side.wait_stream(main)` -- or, where overlap with already queued main-stream work is the point (ops/conv.py: the
+    weight-image rebuild behind the optimizer step), with `side.wait_event(ev)` of an event that covers every WRITER of what the
+    work reads; that caller checks tensor versions and storage pointers so that nothing but the library's own optimizer kernel
+    can have written the weights since the event;
+  * tensors allocated under `torch.cuda.stream(side)` belong to the side stream's allocator pool: they are handed to the main
+    stream only behind `main.wait_stream(side)`, and their memory returns to the pool when the next side-stream block starts with
+    `wait_stream(main)` again (LSHead.forward_train) -- no `record_stream` needed under this rule, and a block that begins with
+    `wait_event` must not allocate at all (the rebuild writes into long-lived image buffers);
+  * main-stream tensors READ on the side stream while the main stream runs on are protected with `record_stream`
+    (ops/resblock.py `_on_side`)."""
 import os
 
 import torch

@@ -72,5 +72,5 @@ def test_training_curve_of_the_benchmark_model(cpu_oracle_backend):
     """A prefix of fixture train_curve_init0.npz (the seed-0 init_weights model, 2 x 3 x 384 x 512) on the host; the MI355X test
     runs all twenty iterations."""
     torch.set_num_threads(8)
-    worst = gc.train_curve_case(CPU, early_tol=1e-4, late_tol=1e-4, rtol_weight=5e-2, iters=2, fixture='train_curve_init0', init0=True)
-    print(f'benchmark-model curve, worst relative loss deviation over 2 iterations: {worst:.2e}')
+    worst = gc.train_curve_case(CPU, early_tol=1e-4, late_tol=1e-4, rtol_weight=5e-2, iters=1, fixture='train_curve_init0', init0=True)
+    print(f'benchmark-model curve, worst relative loss deviation of the first iteration: {worst:.2e}')
