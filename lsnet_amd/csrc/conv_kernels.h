@@ -609,7 +609,9 @@ __global__ __launch_bounds__(256, 2) void conv_mm_kernel(const ConvArgs a)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const int co = co_blk + (wn * TN + j) * 32 + (lane & 31);
-                    if (co < a.Co) orow[co] = acc[j][i][r];
+                    // (nontemporal: the 413 MB of column gradients of a tower launch stream THROUGH the L2s that hold the
+                    // weight image and the pixel rows every column block of a tile re-reads; profiles/r6_gemm_l2.txt)
+                    if (co < a.Co) __builtin_nontemporal_store(acc[j][i][r], orow + co);
                 }
             }
     } else {
