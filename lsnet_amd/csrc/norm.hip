@@ -80,6 +80,9 @@ __device__ __forceinline__ GnPos gn_pos(const GnArgs &a, const GnLvl &L)
 // old and new library alternating on one box: the finisher's tail costs more than 16 fills and 45 k atomics.  With
 // __threadfence() instead of agent-scope stores it lost 0.4 ms.  profiles/r5_gn_ticket.txt.  The fills went another way:
 // gn_sums() below.)
+// EG ("element groups"): fewer than four channels per group (C / G = 1 or 2: the test-size heads, 32 channels in 32 groups, 16 in
+// 8) -- the four channels of a thread's quad belong to different groups, so shift, moments and group sums are kept per element.
+template <bool EG>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const GnArgs a)
 {
     for (int i = blockIdx.x * 256 + threadIdx.x; i < a.nclear; i += gridDim.x * 256) a.clear[i] = 0.0;
@@ -88,6 +91,40 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnArgs a)
     const GnPos p = gn_pos(a, L);
     const int cpg = a.C / a.G, g = (p.q * 4) / cpg;
     const float *xb = L.x + (size_t)p.b * L.HW * a.C;
+    __shared__ double acc[256 * 2 * (EG ? 4 : 1)];
+    const int qn = a.C >> 2;
+    if constexpr (EG) {
+        float K[4], s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) K[e] = xb[(p.q * 4 + e) / cpg * cpg];   // shift: first element of the element's group
+#pragma unroll 4
+        for (int px = p.p0 + p.row; px < p.p1; px += p.rows) {
+            const float4 v = *reinterpret_cast<const float4 *>(xb + (size_t)px * a.C + p.q * 4);
+            const float d[4] = {v.x - K[0], v.y - K[1], v.z - K[2], v.w - K[3]};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s1[e] += d[e], s2[e] += d[e] * d[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            acc[(threadIdx.x * 4 + e) * 2] = (double)s1[e];
+            acc[(threadIdx.x * 4 + e) * 2 + 1] = (double)s2[e];
+        }
+        __syncthreads();
+        if (threadIdx.x < a.G) {   // one thread per group: its cpg channels of every row
+            double t1 = 0.0, t2 = 0.0;
+            for (int r = 0; r < p.rows; ++r)
+                for (int j = 0; j < cpg; ++j) {
+                    const int c = threadIdx.x * cpg + j;
+                    const int t = (r * qn + (c >> 2)) * 4 + (c & 3);
+                    t1 += acc[t * 2];
+                    t2 += acc[t * 2 + 1];
+                }
+            double *dst = a.sums + ((size_t)(L.img0 + p.b) * a.G + threadIdx.x) * 2;
+            unsafeAtomicAdd(dst, t1);
+            unsafeAtomicAdd(dst + 1, t2);
+        }
+        return;
+    }
     const float K = xb[g * cpg];   // shift: first element of the group in this image
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll 4
@@ -98,12 +135,11 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnArgs a)
         s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
     }
     // block reduction per group in fp64 through LDS
-    __shared__ double acc[256 * 2];
     acc[threadIdx.x * 2] = (double)s1;
     acc[threadIdx.x * 2 + 1] = (double)s2;
     __syncthreads();
     // threads of one group: quads q with (q*4)/cpg == g, all rows.  One thread per group sums them.
-    const int qn = a.C >> 2, qpg = cpg >> 2;
+    const int qpg = cpg >> 2;
     if (threadIdx.x < a.G) {
         double t1 = 0.0, t2 = 0.0;
         for (int r = 0; r < p.rows; ++r)
@@ -131,25 +167,66 @@ __device__ __forceinline__ void gn_moments(const GnArgs &a, const GnLvl &L, int 
     rstd = (float)(1.0 / sqrt(var + (double)a.eps));
 }
 
+// mean / rstd of the four channels of quad q: one group (EG = false) or one per element
+template <bool EG>
+__device__ __forceinline__ void gn_quad_moments_fwd(const GnArgs &a, const GnLvl &L, const float *xb, int b, int q, float (&mean)[4],
+                                                    float (&rstd)[4])
+{
+    const int cpg = a.C / a.G;
+    if constexpr (EG) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int g = (q * 4 + e) / cpg;
+            gn_moments(a, L, b, g, xb[g * cpg], mean[e], rstd[e]);
+        }
+    } else {
+        const int g = (q * 4) / cpg;
+        gn_moments(a, L, b, g, xb[g * cpg], mean[0], rstd[0]);
+        mean[1] = mean[2] = mean[3] = mean[0], rstd[1] = rstd[2] = rstd[3] = rstd[0];
+    }
+}
+template <bool EG>
+__device__ __forceinline__ void gn_quad_moments_saved(const GnArgs &a, const GnLvl &L, int b, int q, float (&mean)[4], float (&rstd)[4])
+{
+    const int cpg = a.C / a.G;
+    const float *mr = a.mean_rstd + (size_t)(L.img0 + b) * a.G * 2;
+    if constexpr (EG) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int g = (q * 4 + e) / cpg;
+            mean[e] = mr[g * 2], rstd[e] = mr[g * 2 + 1];
+        }
+    } else {
+        const int g = (q * 4) / cpg;
+        mean[0] = mr[g * 2], rstd[0] = mr[g * 2 + 1];
+        mean[1] = mean[2] = mean[3] = mean[0], rstd[1] = rstd[2] = rstd[3] = rstd[0];
+    }
+}
+
+template <bool EG>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a)
 {
     int li;
     const GnLvl &L = gn_level(a, blockIdx.x, li);
     const GnPos p = gn_pos(a, L);
-    const int cpg = a.C / a.G, g = (p.q * 4) / cpg;
+    const int cpg = a.C / a.G;
     const float *xb = L.x + (size_t)p.b * L.HW * a.C;
     float *yb = L.y + (size_t)p.b * L.ybs;
-    float mean, rstd;
-    gn_moments(a, L, p.b, g, xb[g * cpg], mean, rstd);
-    if (p.p0 == 0 && p.row == 0 && (p.q * 4) % cpg == 0) {   // saved for backward
-        float *mr = a.mean_rstd + ((size_t)(L.img0 + p.b) * a.G + g) * 2;
-        mr[0] = mean;
-        mr[1] = rstd;
+    float mean[4], rstd[4];
+    gn_quad_moments_fwd<EG>(a, L, xb, p.b, p.q, mean, rstd);
+    if (p.p0 == 0 && p.row == 0) {   // saved for backward
+#pragma unroll
+        for (int e = 0; e < (EG ? 4 : 1); ++e)
+            if ((p.q * 4 + e) % cpg == 0) {
+                float *mr = a.mean_rstd + ((size_t)(L.img0 + p.b) * a.G + (p.q * 4 + e) / cpg) * 2;
+                mr[0] = mean[e];
+                mr[1] = rstd[e];
+            }
     }
     const float4 ga = *reinterpret_cast<const float4 *>(a.gamma + p.q * 4);
     const float4 be = *reinterpret_cast<const float4 *>(a.beta + p.q * 4);
-    const float a0 = rstd * ga.x, a1 = rstd * ga.y, a2 = rstd * ga.z, a3 = rstd * ga.w;
-    const float b0 = be.x - mean * a0, b1 = be.y - mean * a1, b2 = be.z - mean * a2, b3 = be.w - mean * a3;
+    const float a0 = rstd[0] * ga.x, a1 = rstd[1] * ga.y, a2 = rstd[2] * ga.z, a3 = rstd[3] * ga.w;
+    const float b0 = be.x - mean[0] * a0, b1 = be.y - mean[1] * a1, b2 = be.z - mean[2] * a2, b3 = be.w - mean[3] * a3;
 #pragma unroll 4
     for (int px = p.p0 + p.row; px < p.p1; px += p.rows) {
         const float4 v = *reinterpret_cast<const float4 *>(xb + (size_t)px * a.C + p.q * 4);
@@ -160,27 +237,27 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a)
 }
 
 // per (image, channel): A = sum dy' * xhat, Bc = sum dy'   (dy' = dy gated by the ReLU of the forward)
+template <bool EG>
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const GnArgs a)
 {
     int li;
     const GnLvl &L = gn_level(a, blockIdx.x, li);
     const GnPos p = gn_pos(a, L);
-    const int cpg = a.C / a.G, g = (p.q * 4) / cpg;
     const float *xb = L.x + (size_t)p.b * L.HW * a.C;
     const float *db = L.dy + (size_t)p.b * L.dybs;
-    const float *mr = a.mean_rstd + ((size_t)(L.img0 + p.b) * a.G + g) * 2;
-    const float mean = mr[0], rstd = mr[1];
+    float mean[4], rstd[4];
+    gn_quad_moments_saved<EG>(a, L, p.b, p.q, mean, rstd);
     const float4 ga = *reinterpret_cast<const float4 *>(a.gamma + p.q * 4);
     const float4 be = *reinterpret_cast<const float4 *>(a.beta + p.q * 4);
-    const float a0 = rstd * ga.x, a1 = rstd * ga.y, a2 = rstd * ga.z, a3 = rstd * ga.w;
-    const float b0 = be.x - mean * a0, b1 = be.y - mean * a1, b2 = be.z - mean * a2, b3 = be.w - mean * a3;
+    const float a0 = rstd[0] * ga.x, a1 = rstd[1] * ga.y, a2 = rstd[2] * ga.z, a3 = rstd[3] * ga.w;
+    const float b0 = be.x - mean[0] * a0, b1 = be.y - mean[1] * a1, b2 = be.z - mean[2] * a2, b3 = be.w - mean[3] * a3;
     float A[4] = {0.f, 0.f, 0.f, 0.f}, Bc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
     for (int px = p.p0 + p.row; px < p.p1; px += p.rows) {
         const float4 v = *reinterpret_cast<const float4 *>(xb + (size_t)px * a.C + p.q * 4);
         float4 d = *reinterpret_cast<const float4 *>(db + (size_t)px * a.C + p.q * 4);
-        const float h0 = (v.x - mean) * rstd, h1 = (v.y - mean) * rstd, h2 = (v.z - mean) * rstd,
-                    h3 = (v.w - mean) * rstd;
+        const float h0 = (v.x - mean[0]) * rstd[0], h1 = (v.y - mean[1]) * rstd[1], h2 = (v.z - mean[2]) * rstd[2],
+                    h3 = (v.w - mean[3]) * rstd[3];
         if (a.relu) {   // the forward's own expression, so the gate is bitwise the one that was applied
             d.x = (v.x * a0 + b0 > 0.f) ? d.x : 0.f;
             d.y = (v.y * a1 + b1 > 0.f) ? d.y : 0.f;
@@ -260,37 +337,44 @@ __global__ __launch_bounds__(256) void gn_bwd_imgsum_kernel(const GnArgs a, int 
     if (threadIdx.x == 0) a.ticket[1] = 0;
 }
 
+template <bool EG>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const GnArgs a)
 {
     int li;
     const GnLvl &L = gn_level(a, blockIdx.x, li);
     const GnPos p = gn_pos(a, L);
-    const int cpg = a.C / a.G, g = (p.q * 4) / cpg;
+    const int cpg = a.C / a.G;
     const float *xb = L.x + (size_t)p.b * L.HW * a.C;
     const float *db = L.dy + (size_t)p.b * L.dybs;
     float *ob = L.dx + (size_t)p.b * L.HW * a.C;
-    const float *mr = a.mean_rstd + ((size_t)(L.img0 + p.b) * a.G + g) * 2;
-    const float mean = mr[0], rstd = mr[1];
+    float mean[4], rstd[4];
+    gn_quad_moments_saved<EG>(a, L, p.b, p.q, mean, rstd);
     // group sums S1 = sum_c gamma_c * Bc[c], S2 = sum_c gamma_c * A[c]
-    float S1 = 0.f, S2 = 0.f;
-    const float *ab = a.ab + ((size_t)(L.img0 + p.b) * a.C + g * cpg) * 2;
-    for (int c = 0; c < cpg; ++c) {
-        const float gm = a.gamma[g * cpg + c];
-        S2 += gm * ab[c * 2];
-        S1 += gm * ab[c * 2 + 1];
-    }
     const float inv_n = 1.f / ((float)L.HW * (float)cpg);
-    const float m1 = S1 * inv_n, m2 = S2 * inv_n;
+    float m1[4], m2[4];
+#pragma unroll
+    for (int e = 0; e < (EG ? 4 : 1); ++e) {
+        const int g = (p.q * 4 + e) / cpg;
+        float S1 = 0.f, S2 = 0.f;
+        const float *ab = a.ab + ((size_t)(L.img0 + p.b) * a.C + g * cpg) * 2;
+        for (int c = 0; c < cpg; ++c) {
+            const float gm = a.gamma[g * cpg + c];
+            S2 += gm * ab[c * 2];
+            S1 += gm * ab[c * 2 + 1];
+        }
+        m1[e] = S1 * inv_n, m2[e] = S2 * inv_n;
+    }
+    if constexpr (!EG) m1[1] = m1[2] = m1[3] = m1[0], m2[1] = m2[2] = m2[3] = m2[0];
     const float4 ga = *reinterpret_cast<const float4 *>(a.gamma + p.q * 4);
     const float4 be = *reinterpret_cast<const float4 *>(a.beta + p.q * 4);
-    const float a0 = rstd * ga.x, a1 = rstd * ga.y, a2 = rstd * ga.z, a3 = rstd * ga.w;
-    const float b0 = be.x - mean * a0, b1 = be.y - mean * a1, b2 = be.z - mean * a2, b3 = be.w - mean * a3;
+    const float a0 = rstd[0] * ga.x, a1 = rstd[1] * ga.y, a2 = rstd[2] * ga.z, a3 = rstd[3] * ga.w;
+    const float b0 = be.x - mean[0] * a0, b1 = be.y - mean[1] * a1, b2 = be.z - mean[2] * a2, b3 = be.w - mean[3] * a3;
 #pragma unroll 4
     for (int px = p.p0 + p.row; px < p.p1; px += p.rows) {
         const float4 v = *reinterpret_cast<const float4 *>(xb + (size_t)px * a.C + p.q * 4);
         float4 d = *reinterpret_cast<const float4 *>(db + (size_t)px * a.C + p.q * 4);
-        const float h0 = (v.x - mean) * rstd, h1 = (v.y - mean) * rstd, h2 = (v.z - mean) * rstd,
-                    h3 = (v.w - mean) * rstd;
+        const float h0 = (v.x - mean[0]) * rstd[0], h1 = (v.y - mean[1]) * rstd[1], h2 = (v.z - mean[2]) * rstd[2],
+                    h3 = (v.w - mean[3]) * rstd[3];
         if (a.relu) {   // the forward's own expression, so the gate is bitwise the one that was applied
             d.x = (v.x * a0 + b0 > 0.f) ? d.x : 0.f;
             d.y = (v.y * a1 + b1 > 0.f) ? d.y : 0.f;
@@ -298,10 +382,10 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const GnArgs a)
             d.w = (v.w * a3 + b3 > 0.f) ? d.w : 0.f;
         }
         float4 o;
-        o.x = rstd * (ga.x * d.x - m1 - h0 * m2);
-        o.y = rstd * (ga.y * d.y - m1 - h1 * m2);
-        o.z = rstd * (ga.z * d.z - m1 - h2 * m2);
-        o.w = rstd * (ga.w * d.w - m1 - h3 * m2);
+        o.x = rstd[0] * (ga.x * d.x - m1[0] - h0 * m2[0]);
+        o.y = rstd[1] * (ga.y * d.y - m1[1] - h1 * m2[1]);
+        o.z = rstd[2] * (ga.z * d.z - m1[2] - h2 * m2[2]);
+        o.w = rstd[3] * (ga.w * d.w - m1[3] - h3 * m2[3]);
         *reinterpret_cast<float4 *>(ob + (size_t)px * a.C + p.q * 4) = o;
     }
 }
@@ -347,9 +431,9 @@ static int gn_fill(GnArgs &a, int n, const lsn_gn_level *lv, int C, int G, int *
     LSN_CHECK(n >= 1 && n <= GN_MAXLV, "n_levels must be in [1,%d], got %d", GN_MAXLV, n);
     LSN_CHECK(C > 0 && G > 0 && C % G == 0, "num_channels %d must be divisible by num_groups %d", C, G);
     const int qn = C / 4;
-    if (C % 4 != 0 || (C / G) % 4 != 0 || qn > 256 || 256 % qn != 0 || G > 256)
-        return fail(LSN_ERR_UNSUPPORTED, "group norm kernel needs C in {64..1024} with 256 %% (C/4) == 0 and "
-                                         "(C/G) %% 4 == 0, got C=%d G=%d", C, G);
+    if (C % 4 != 0 || ((C / G) % 4 != 0 && 4 % (C / G) != 0) || qn > 256 || 256 % qn != 0 || G > 256)
+        return fail(LSN_ERR_UNSUPPORTED, "group norm kernel needs C in {4..1024} with 256 %% (C/4) == 0 and "
+                                         "C/G a multiple or a divisor of 4, got C=%d G=%d", C, G);
     int t = 0, im = 0;
     for (int i = 0; i < n; ++i) {
         LSN_CHECK(lv[i].B > 0 && lv[i].HW > 0 && lv[i].x != nullptr, "level %d: empty tensor", i);
@@ -619,8 +703,13 @@ int lsn_group_norm_forward(int n_levels, const lsn_gn_level *levels, int C, int 
     double el = 0;
     for (int i = 0; i < n_levels; ++i) el += (double)levels[i].B * levels[i].HW * C;
     ProfSpan prof(PROF_NORM, 8.0 * el, 4.0 * 2 * el, st);   // algorithmic: x read once, y written once
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(tiles), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(tiles), dim3(256), 0, st, a);
+    if ((C / G) % 4 != 0) {   // one or two channels per group
+        hipLaunchKernelGGL(gn_stats_kernel<true>, dim3(tiles), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(tiles), dim3(256), 0, st, a);
+    } else {
+        hipLaunchKernelGGL(gn_stats_kernel<false>, dim3(tiles), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(tiles), dim3(256), 0, st, a);
+    }
     LSN_HIP(hipGetLastError());
     return 0;
 }
@@ -649,9 +738,16 @@ int lsn_group_norm_backward(int n_levels, const lsn_gn_level *levels, int C, int
     double el = 0;
     for (int i = 0; i < n_levels; ++i) el += (double)levels[i].B * levels[i].HW * C;
     ProfSpan prof(PROF_NORM, 16.0 * el, 4.0 * 3 * el, st);   // x, dy read, dx written
-    hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(tiles), dim3(256), 0, st, a);
+    const bool eg = (C / G) % 4 != 0;   // one or two channels per group
+    if (eg)
+        hipLaunchKernelGGL(gn_bwd_reduce_kernel<true>, dim3(tiles), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL(gn_bwd_reduce_kernel<false>, dim3(tiles), dim3(256), 0, st, a);
     hipLaunchKernelGGL(gn_bwd_imgsum_kernel, dim3(images, (2 * C + 31) / 32), dim3(256), 0, st, a, images, accumulate);
-    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(tiles), dim3(256), 0, st, a);
+    if (eg)
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, dim3(tiles), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<false>, dim3(tiles), dim3(256), 0, st, a);
     LSN_HIP(hipGetLastError());
     return 0;
 }

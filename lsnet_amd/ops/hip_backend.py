@@ -60,7 +60,7 @@ class HipBackend:
     # ------------------------------------------------------------------ group norm (+ReLU), channels-last
     @staticmethod
     def group_norm_supported(C, G):
-        return C % 4 == 0 and C % G == 0 and (C // G) % 4 == 0 and C // 4 <= 256 and 256 % (C // 4) == 0 and G <= 256
+        return C % 4 == 0 and C % G == 0 and ((C // G) % 4 == 0 or 4 % (C // G) == 0) and C // 4 <= 256 and 256 % (C // 4) == 0 and G <= 256
 
     @staticmethod
     def _gn_levels(xs, ys=None, dys=None, dxs=None):

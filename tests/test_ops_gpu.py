@@ -531,6 +531,9 @@ def test_dcn_pack_fused_offset_mask_logits(layout):
     (64, 8, True, [(3, 9, 5)]),
     (1024, 32, False, [(1, 6, 7), (2, 3, 3)]),
     (128, 32, True, [(2, 130, 67)]),                               # HW not a multiple of the block size
+    (32, 32, True, [(2, 25, 42), (2, 13, 21)]),                    # one channel per group (the test-size heads' towers)
+    (16, 8, False, [(2, 17, 9)]),                                  # two channels per group
+    (32, 16, True, [(1, 130, 67), (3, 4, 5)]),
 ])
 def test_group_norm_matches_torch(C, G, relu, shapes):
     """fp32 reference: torch.nn.functional.group_norm (+relu) on the same device and on the CPU."""
@@ -562,8 +565,12 @@ def test_group_norm_matches_torch(C, G, relu, shapes):
             assert _err(y, r.detach().to(dev)) < 1e-5
         for gx, r in zip(got[1], xr):
             assert _err(gx, r.grad.to(dev)) < 2e-5
-        assert _err(got[2], w.grad.to(dev)) < 2e-5
-        assert _err(got[3], b.grad.to(dev)) < 2e-5
+        # (one or two channels per group: x_hat of a channel is normalised by that channel's own few-pixel statistics, and
+        # two fp32 orders of the per-channel sum of dy * x_hat are ~3e-5 of the range apart -- ATen's CPU and device
+        # kernels differ from each other by as much)
+        ptol = 2e-5 if (C // G) % 4 == 0 else 6e-5
+        assert _err(got[2], w.grad.to(dev)) < ptol
+        assert _err(got[3], b.grad.to(dev)) < ptol
 
 
 @pytest.mark.gpu
@@ -635,7 +642,7 @@ def test_group_norm_statistics_buffers_alternate_between_calls():
 def test_group_norm_unsupported_shape_uses_aten():
     from lsnet_amd.ops.group_norm import GroupNorm
     dev = torch.device('cuda:0')
-    m = GroupNorm(3, 6).to(dev)                 # C/G = 2: not a float4 multiple
+    m = GroupNorm(3, 6).to(dev)                 # C = 6: a pixel row is not a whole number of float4
     x = torch.randn(2, 6, 5, 5, device=dev).contiguous(memory_format=torch.channels_last)
     assert torch.allclose(m(x), F.group_norm(x, 3, m.weight, m.bias, m.eps), atol=1e-6)
     y = GroupNorm(32, 256)(torch.randn(2, 256, 5, 5))      # CPU tensors take ATen's kernel as well
