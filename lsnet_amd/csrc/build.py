@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.path.join(HERE, 'liblsnet_hip.so')
 SOURCES = ['dcn.hip', 'misc.hip', 'norm.hip', 'conv.hip', 'gconv.hip', 'image.hip', 'loss.hip']
-HEADERS = ['common.h', 'dcn_kernels.h', 'dcn_grouped_kernels.h', 'conv_kernels.h', 'conv_wgrad_kernels.h', 'dcn_mm_kernels.h', 'prof.h', 'cross_iou_row.h', os.path.join('..', '..', 'include', 'lsnet_hip.h')]
+HEADERS = ['common.h', 'dcn_kernels.h', 'dcn_gather_kernels.h', 'dcn_grouped_kernels.h', 'conv_kernels.h', 'conv_wgrad_kernels.h', 'dcn_mm_kernels.h', 'prof.h', 'cross_iou_row.h', os.path.join('..', '..', 'include', 'lsnet_hip.h')]
 # -fno-slp-vectorize: hipcc (ROCm 7.2) packs adjacent scalar fp32 adds / fmas into v_pk_add_f32 / v_pk_fma_f32.  In the
 # backward-data kernels the HIGH dword of such packed accumulators came back wrong for the last 16 lanes of a wave in
 # 0.7 % of the cases, differently on every run, whenever two workgroups shared a CU (tools/dbg_goff.py on the MI355X:
@@ -24,7 +24,7 @@ def kernel_signature():
     matches (a counter reading of other kernels is not a measurement of these)."""
     import hashlib
     h = hashlib.sha256()
-    for f in ('common.h', 'conv_kernels.h', 'conv_wgrad_kernels.h', 'conv.hip', 'dcn_kernels.h', 'dcn_mm_kernels.h', 'dcn_grouped_kernels.h', 'dcn.hip'):
+    for f in ('common.h', 'conv_kernels.h', 'conv_wgrad_kernels.h', 'conv.hip', 'dcn_kernels.h', 'dcn_gather_kernels.h', 'dcn_mm_kernels.h', 'dcn_grouped_kernels.h', 'dcn.hip'):
         with open(os.path.join(HERE, f), 'rb') as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -40,7 +40,7 @@ def _hipcc():
 OBJ_DIR = os.path.join(HERE, 'build')
 # headers each translation unit includes (an object is rebuilt when its source or one of these is newer)
 UNIT_HEADERS = {
-    'dcn.hip': ['common.h', 'dcn_kernels.h', 'dcn_mm_kernels.h', 'dcn_grouped_kernels.h', 'conv_kernels.h', 'prof.h'],
+    'dcn.hip': ['common.h', 'dcn_kernels.h', 'dcn_gather_kernels.h', 'dcn_mm_kernels.h', 'dcn_grouped_kernels.h', 'conv_kernels.h', 'prof.h'],
     'conv.hip': ['common.h', 'conv_kernels.h', 'conv_wgrad_kernels.h', 'prof.h'],
     'misc.hip': ['common.h', 'prof.h'], 'norm.hip': ['common.h', 'prof.h'], 'gconv.hip': ['common.h', 'prof.h'],
     'image.hip': ['common.h'], 'loss.hip': ['common.h', 'cross_iou_row.h'],

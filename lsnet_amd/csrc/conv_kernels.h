@@ -616,6 +616,15 @@ __global__ __launch_bounds__(256, 2) void conv_mm_kernel(const ConvArgs a)
             }
     } else {
     // lane = pixel (lane & 31) of tile i, output channels 8 g + 4 (lane >> 5) + (0..3) of tile j
+    // Round 6: the epilogue's operands (bias, residual, gate) are FETCHED FIRST, all quads of a pixel tile at once, through
+    // buffer loads whose masked-out lanes point past the tensor -- no branch between the loads, one wait per operand kind.
+    // (Written quad by quad -- load bias, wait, load residual, wait, load gate, wait, store -- every one of the sixteen quads
+    // of a thread paid up to three memory round trips in a row: 61 vs 38 us for the 1024 -> 256 data gradient of stage 3
+    // with and without its residual and gate, profiles/r6_instep_vs_isolated.txt "warm" vs "warm-epi".)
+    const size_t out_px = a.ostep ? (size_t)L.B * a.OH * a.OW : (size_t)L.P;
+    const int ep_bytes = (int)(out_px * a.Co * 4);   // (conv.hip conv_check: the output fits 32-bit byte offsets)
+    const bool fin = !partial;   // bias, residual, ReLU and gate belong to the finished sum
+    const bool has_bias = fin && a.bias != nullptr, has_res = fin && L.res != nullptr, has_gate = fin && L.gate != nullptr;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int pix = tile_p + wm * TM * 32 + i * 32 + (lane & 31);
@@ -628,46 +637,88 @@ __global__ __launch_bounds__(256, 2) void conv_mm_kernel(const ConvArgs a)
             opix = ((size_t)b * a.OH + a.oy0 + ho * a.ostep) * a.OW + a.ox0 + wo * a.ostep;
         }
         float *orow = partial ? a.part + ((size_t)blockIdx.z * a.part_rows + (pix - a.part_pix0)) * a.Co : L.out + opix * a.Co;
-        const bool fin = !partial;   // bias and ReLU belong to the finished sum
+        if (vec_ok && !has_bias && !has_res && !has_gate) {   // nothing to fetch (partial tiles, plain data gradients)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int co = co_blk + (wn * TN + j) * 32 + 8 * g + 4 * (lane >> 5);
-                if (co >= a.Co) continue;
-                float v[4];
+                for (int g = 0; g < 4; ++g) {
+                    const int co = co_blk + (wn * TN + j) * 32 + 8 * g + 4 * (lane >> 5);
+                    if (co >= a.Co) continue;
+                    float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[j][i][4 * g + e];
-                if (vec_ok) {
-                    if (fin && a.bias) {
-                        const float4 bv = *reinterpret_cast<const float4 *>(a.bias + co);
-                        v[0] += bv.x, v[1] += bv.y, v[2] += bv.z, v[3] += bv.w;
-                    }
-                    if (fin && L.res) {
-                        const float4 rv = *reinterpret_cast<const float4 *>(L.res + opix * a.Co + co);
-                        v[0] += rv.x, v[1] += rv.y, v[2] += rv.z, v[3] += rv.w;
-                    }
+                    for (int e = 0; e < 4; ++e) v[e] = (fin && a.relu) ? fmaxf(acc[j][i][4 * g + e], 0.f) : acc[j][i][4 * g + e];
+                    *reinterpret_cast<float4 *>(orow + co) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+        } else if (vec_ok) {
+            float4 bv[TN * 4], rv[TN * 4], gv[TN * 4];
+            const int obase = (int)(opix * a.Co) * 4;
+            // (a quad beyond Co -- the padded column tiles of a narrow output -- reads past the bias, i.e. zero, and the first
+            // channels of the NEXT pixel of the residual / gate, i.e. memory of the same tensor or, behind the last pixel,
+            // zero: it is never stored, so no select sits between the address and the load)
+            const int cobase = (co_blk + wn * TN * 32 + 4 * (lane >> 5)) * 4;
+            // (zero first, although every use sits behind its operand's flag: left unset hipcc re-serialises the loads -- the
+            // step's forward shapes 3.73 -> 4.03 ms in tools/ubench/conv_step)
+#pragma unroll
+            for (int q = 0; q < TN * 4; ++q) bv[q] = rv[q] = gv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            // (each descriptor lives only around its own loads: twelve scalar registers held across the whole epilogue cost
+            // the stream-K instantiations ~100 more spilled ones)
+            if (has_bias) {
+                const __amdgpu_buffer_rsrc_t brs =
+                    __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.bias), 0, a.Co * 4, 0x00020000);
+#pragma unroll
+                for (int q = 0; q < TN * 4; ++q) bv[q] = cv_load4(brs, cobase + ((q >> 2) * 32 + (q & 3) * 8) * 4, 0);
+            }
+            if (has_res) {
+                const __amdgpu_buffer_rsrc_t rrs =
+                    __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(L.res), 0, ep_bytes, 0x00020000);
+#pragma unroll
+                for (int q = 0; q < TN * 4; ++q) rv[q] = cv_load4(rrs, obase + cobase + ((q >> 2) * 32 + (q & 3) * 8) * 4, 0);
+            }
+            if (has_gate) {
+                const __amdgpu_buffer_rsrc_t grs =
+                    __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(L.gate), 0, ep_bytes, 0x00020000);
+#pragma unroll
+                for (int q = 0; q < TN * 4; ++q) gv[q] = cv_load4(grs, obase + cobase + ((q >> 2) * 32 + (q & 3) * 8) * 4, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int co = co_blk + (wn * TN + j) * 32 + 8 * g + 4 * (lane >> 5);
+                    if (co >= a.Co) continue;
+                    const float4 b4 = bv[j * 4 + g], r4 = rv[j * 4 + g], g4 = gv[j * 4 + g];
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[j][i][4 * g + e];
+                    if (has_bias) v[0] += b4.x, v[1] += b4.y, v[2] += b4.z, v[3] += b4.w;
+                    if (has_res) v[0] += r4.x, v[1] += r4.y, v[2] += r4.z, v[3] += r4.w;
                     if (fin && a.relu)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                    if (fin && L.gate) {
-                        const float4 gv = *reinterpret_cast<const float4 *>(L.gate + opix * a.Co + co);
-                        v[0] = gv.x > 0.f ? v[0] : 0.f, v[1] = gv.y > 0.f ? v[1] : 0.f;
-                        v[2] = gv.z > 0.f ? v[2] : 0.f, v[3] = gv.w > 0.f ? v[3] : 0.f;
+                    if (has_gate) {
+                        v[0] = g4.x > 0.f ? v[0] : 0.f, v[1] = g4.y > 0.f ? v[1] : 0.f;
+                        v[2] = g4.z > 0.f ? v[2] : 0.f, v[3] = g4.w > 0.f ? v[3] : 0.f;
                     }
                     *reinterpret_cast<float4 *>(orow + co) = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
+                }
+        } else {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int co = co_blk + (wn * TN + j) * 32 + 8 * g + 4 * (lane >> 5);
+                    if (co >= a.Co) continue;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         if (co + e >= a.Co) break;
-                        float u = v[e] + ((fin && a.bias) ? a.bias[co + e] : 0.f);
-                        if (fin && L.res) u += L.res[opix * a.Co + co + e];
+                        float u = acc[j][i][4 * g + e] + (has_bias ? a.bias[co + e] : 0.f);
+                        if (has_res) u += L.res[opix * a.Co + co + e];
                         if (fin && a.relu) u = fmaxf(u, 0.f);
-                        if (fin && L.gate && !(L.gate[opix * a.Co + co + e] > 0.f)) u = 0.f;
+                        if (has_gate && !(L.gate[opix * a.Co + co + e] > 0.f)) u = 0.f;
                         orow[co + e] = u;
                     }
                 }
-            }
+        }
     }
     }
     }

@@ -532,7 +532,7 @@ static bool bwd_gather_ok(const DcnArgs &a)
     return true;
 }
 
-// ---- atomic-free grad_input: workspace plan of the bin / scan / fill / sort / gather sequence (dcn_kernels.h) ----
+// ---- atomic-free grad_input: workspace plan of the bin / scan / fill / sort / gather sequence (dcn_gather_kernels.h) ----
 struct GatherPlan {
     bool ok = false;
     int nsamples = 0, nanchors = 0;

@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void dcn_fwd_grouped_kernel(const DcnArgs a)
 
 // ---- column gradients of the backward-data pass on the fp32 matrix instructions ----
 //   gcol[(row, k)][c] = sum_{j < Co / groups} gout[row][g Cog + j] * w[g Cog + j][k][c - g Cg],   g = c / Cg      (UNWEIGHTED)
-// -- what dcn_gcol_grouped_kernel (dcn_kernels.h) computes with one fmaf chain per thread: 14.6 of the 108 ms of the config-4
+// -- what dcn_gcol_grouped_kernel (dcn_gather_kernels.h) computes with one fmaf chain per thread: 14.6 of the 108 ms of the config-4
 // step, and ~5 ms per tower launch when the exact mode sends dense calls through it (round 6).  Here: workgroup = 32 launch-wide
 // pixel rows x 64 columns, wave = 16 columns for both 16-row halves.  The grad_output tile is staged in LDS once and a wave keeps
 // its A fragments (rows x the gout channels its columns reduce over: the group's Cog, or all Co of a dense call; below 16 channels

@@ -15,7 +15,7 @@
 // kernel of its own: it IS conv_mm_kernel as a 1x1 convolution of grad_output with N = K * C output columns
 // (conv.hip conv_mm_rows), writing the column gradients unweighted; the modulation scalar, the scatter into grad_input
 // and the corner sums of grad_offset / grad_mask all belong to the gather pass that reads those rows anyway
-// (dcn_kernels.h: dcn_gather_kernel, dcn_anchor_sum_kernel, dcn_offgrad_kernel).
+// (dcn_gather_kernels.h: dcn_gather_kernel, dcn_anchor_sum_kernel, dcn_offgrad_kernel).
 #pragma once
 #include "conv_kernels.h"
 #include "dcn_kernels.h"
