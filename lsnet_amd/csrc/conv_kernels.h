@@ -637,7 +637,17 @@ __global__ __launch_bounds__(256, 2) void conv_mm_kernel(const ConvArgs a)
             opix = ((size_t)b * a.OH + a.oy0 + ho * a.ostep) * a.OW + a.ox0 + wo * a.ostep;
         }
         float *orow = partial ? a.part + ((size_t)blockIdx.z * a.part_rows + (pix - a.part_pix0)) * a.Co : L.out + opix * a.Co;
-        if (vec_ok && !has_bias && !has_res && !has_gate) {   // nothing to fetch (partial tiles, plain data gradients)
+        // one finished quad -> memory: 16 bytes, or element by element when a pixel's row is not a whole number of quads
+        auto put = [&](int co, const float (&v)[4]) __attribute__((always_inline)) {
+            if (vec_ok) {
+                *reinterpret_cast<float4 *>(orow + co) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (co + e < a.Co) orow[co + e] = v[e];
+            }
+        };
+        if (!has_bias && !has_res && !has_gate) {   // nothing to fetch (partial tiles, plain data gradients)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -647,39 +657,44 @@ __global__ __launch_bounds__(256, 2) void conv_mm_kernel(const ConvArgs a)
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = (fin && a.relu) ? fmaxf(acc[j][i][4 * g + e], 0.f) : acc[j][i][4 * g + e];
-                    *reinterpret_cast<float4 *>(orow + co) = make_float4(v[0], v[1], v[2], v[3]);
+                    put(co, v);
                 }
-        } else if (vec_ok) {
+        } else {
             float4 bv[TN * 4], rv[TN * 4], gv[TN * 4];
             const int obase = (int)(opix * a.Co) * 4;
             // (a quad beyond Co -- the padded column tiles of a narrow output -- reads past the bias, i.e. zero, and the first
             // channels of the NEXT pixel of the residual / gate, i.e. memory of the same tensor or, behind the last pixel,
-            // zero: it is never stored, so no select sits between the address and the load)
+            // zero: it is never stored, so no select sits between the address and the load.  The same holds for the last
+            // elements of a quad that straddles Co (Co % 4 != 0: the 27 offset / mask channels of LSHead).)
             const int cobase = (co_blk + wn * TN * 32 + 4 * (lane >> 5)) * 4;
+            // 16-byte loads where rows are whole quads, four 4-byte loads per quad otherwise (a row of 27 floats starts anywhere)
+            auto fetch = [&](__amdgpu_buffer_rsrc_t rs, int base, float4 (&dst)[TN * 4]) __attribute__((always_inline)) {
+                if (vec_ok) {
+#pragma unroll
+                    for (int q = 0; q < TN * 4; ++q) dst[q] = cv_load4(rs, base + ((q >> 2) * 32 + (q & 3) * 8) * 4, 0);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < TN * 4; ++q) {
+                        const int o = base + ((q >> 2) * 32 + (q & 3) * 8) * 4;
+                        dst[q].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, o, 0, 0));
+                        dst[q].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, o + 4, 0, 0));
+                        dst[q].z = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, o + 8, 0, 0));
+                        dst[q].w = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, o + 12, 0, 0));
+                    }
+                }
+            };
             // (zero first, although every use sits behind its operand's flag: left unset hipcc re-serialises the loads -- the
             // step's forward shapes 3.73 -> 4.03 ms in tools/ubench/conv_step)
 #pragma unroll
             for (int q = 0; q < TN * 4; ++q) bv[q] = rv[q] = gv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
             // (each descriptor lives only around its own loads: twelve scalar registers held across the whole epilogue cost
             // the stream-K instantiations ~100 more spilled ones)
-            if (has_bias) {
-                const __amdgpu_buffer_rsrc_t brs =
-                    __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.bias), 0, a.Co * 4, 0x00020000);
-#pragma unroll
-                for (int q = 0; q < TN * 4; ++q) bv[q] = cv_load4(brs, cobase + ((q >> 2) * 32 + (q & 3) * 8) * 4, 0);
-            }
-            if (has_res) {
-                const __amdgpu_buffer_rsrc_t rrs =
-                    __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(L.res), 0, ep_bytes, 0x00020000);
-#pragma unroll
-                for (int q = 0; q < TN * 4; ++q) rv[q] = cv_load4(rrs, obase + cobase + ((q >> 2) * 32 + (q & 3) * 8) * 4, 0);
-            }
-            if (has_gate) {
-                const __amdgpu_buffer_rsrc_t grs =
-                    __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(L.gate), 0, ep_bytes, 0x00020000);
-#pragma unroll
-                for (int q = 0; q < TN * 4; ++q) gv[q] = cv_load4(grs, obase + cobase + ((q >> 2) * 32 + (q & 3) * 8) * 4, 0);
-            }
+            if (has_bias)
+                fetch(__builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.bias), 0, a.Co * 4, 0x00020000), cobase, bv);
+            if (has_res)
+                fetch(__builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(L.res), 0, ep_bytes, 0x00020000), obase + cobase, rv);
+            if (has_gate)
+                fetch(__builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(L.gate), 0, ep_bytes, 0x00020000), obase + cobase, gv);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -699,24 +714,7 @@ __global__ __launch_bounds__(256, 2) void conv_mm_kernel(const ConvArgs a)
                         v[0] = g4.x > 0.f ? v[0] : 0.f, v[1] = g4.y > 0.f ? v[1] : 0.f;
                         v[2] = g4.z > 0.f ? v[2] : 0.f, v[3] = g4.w > 0.f ? v[3] : 0.f;
                     }
-                    *reinterpret_cast<float4 *>(orow + co) = make_float4(v[0], v[1], v[2], v[3]);
-                }
-        } else {
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int co = co_blk + (wn * TN + j) * 32 + 8 * g + 4 * (lane >> 5);
-                    if (co >= a.Co) continue;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (co + e >= a.Co) break;
-                        float u = acc[j][i][4 * g + e] + (has_bias ? a.bias[co + e] : 0.f);
-                        if (has_res) u += L.res[opix * a.Co + co + e];
-                        if (fin && a.relu) u = fmaxf(u, 0.f);
-                        if (has_gate && !(L.gate[opix * a.Co + co + e] > 0.f)) u = 0.f;
-                        orow[co + e] = u;
-                    }
+                    put(co, v);
                 }
         }
     }
