@@ -123,6 +123,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgArgs a)
         int b, ho, wo0, y0, x0, H, W, Ho, Wo;
         __amdgpu_buffer_rsrc_t xrs, grs;
         bool live;
+        int s, sx, nsx, seg_next;   // this segment, its place in the output row, first segment of the next level
     } sg;
     auto open_seg = [&](int s, bool live) {
         int li = 0;
@@ -136,6 +137,26 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgArgs a)
         sg.H = L.H, sg.W = L.W, sg.Ho = L.Ho, sg.Wo = L.Wo;
         sg.xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(L.x), 0, L.B * L.H * L.W * a.C * 4, 0x00020000);
         sg.grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(L.go), 0, L.B * L.Ho * L.Wo * a.Co * 4, 0x00020000);
+        sg.live = live;
+        sg.s = s, sg.sx = sx, sg.nsx = L.nsx;
+        sg.seg_next = li + 1 < a.nlv ? a.lv[li + 1].seg0 : 0x7fffffff;
+    };
+    // Round 6: the segment BEHIND the open one by stepping -- the next 16 pixels of the row, the next row, the next image; the
+    // level search, the two integer divisions and the descriptors of open_seg (a dependent scalar chain of ~500 cycles at the
+    // top of EVERY k-step, which is 768 cycles of MFMAs for the 2 x 2 tile) only where the level changes.
+    auto next_seg = [&](bool live) {
+        const int s = sg.s + 1;
+        if (s >= sg.seg_next) {
+            open_seg(s, live);
+            return;
+        }
+        sg.s = s;
+        if (++sg.sx == sg.nsx) {
+            sg.sx = 0;
+            if (++sg.ho == sg.Ho) sg.ho = 0, ++sg.b;
+        }
+        sg.wo0 = sg.sx * 16;
+        sg.y0 = sg.ho * a.stride - a.pad, sg.x0 = sg.wo0 * a.stride - a.pad;
         sg.live = live;
     };
     auto issue_slice = [&](int sl) {   // slices 0 .. XL-1: patch passes; XL .. NSL-1: grad_output passes
@@ -234,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgArgs a)
     for (int sl = 0; sl < NSL; ++sl) issue_slice(sl);
 #pragma unroll
     for (int sl = 0; sl < NSL; ++sl) commit_slice(sl, smem);
-    open_seg(s_begin + 1, T > 1);
+    next_seg(T > 1);
 #pragma unroll
     for (int sl = 0; sl < NSL; ++sl) issue_slice(sl);
     __syncthreads();
@@ -255,7 +276,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgArgs a)
         for (int i = 0; i < TI; ++i)
 #pragma unroll
             for (int q = 0; q < NPL; ++q) Xf[0][i][q] = frag(bc + q * XPL + xaddr[0][i][0], bc + q * XPL + xaddr[0][i][1]);
-        open_seg(s_begin + t + 2, t + 2 < T);
+        next_seg(t + 2 < T);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (FINE && TG == 1) {   // one tap: its MFMAs in NSL parts, one staging slice behind each (conv_mm_kernel)
             constexpr int NMt = NP * TI * TJ;
