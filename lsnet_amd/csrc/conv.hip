@@ -422,7 +422,9 @@ int conv_mm_rows(int n, const float *const *x, float *const *out, const int *row
     a.wf_bytes = (int)cv_wfrag_bytes(N, 1, Cr, conv_npl());
     a.C = Cr, a.Co = N, a.kh = a.kw = 1, a.stride = 1, a.pad_h = a.pad_w = 0, a.dil = 1;
     a.xpitch = xpitch;
-    if (N % 256 == 0) {   // the 64 x 256 tile with whole-line stores (conv_kernels.h TRANS); plain output, one split
+    bool rows32 = true;   // the TRANS epilogue stores through a buffer descriptor of each row block: 32-bit byte offsets
+    for (int i = 0; i < n; ++i) rows32 = rows32 && (long long)rows[i] * N * 4 < (1ll << 31) - 256;
+    if (N % 256 == 0 && rows32) {   // the 64 x 256 tile with whole-line stores (conv_kernels.h TRANS); plain output, one split
 #ifdef LSNET_AB_DIST   // build.py --ab -DLSNET_AB_DIST: rounds 3 / 4 work distribution (profiles/r5_sk_*.txt)
         return conv_forward(a, st);
 #else

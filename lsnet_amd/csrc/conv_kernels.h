@@ -598,20 +598,26 @@ __global__ __launch_bounds__(256, 2) void conv_mm_kernel(const ConvArgs a)
     const bool vec_ok = (a.Co & 3) == 0;
     if (do_out) {
     if constexpr (TRANS) {
-        // lane = output channel (lane & 31) of tile j, pixels mfma32_row(r, lane) of tile i: plain stores, whole lines
+        // lane = output channel (lane & 31) of tile j, pixels mfma32_row(r, lane) of tile i: plain stores, whole lines.
+        // Round 6: through ONE buffer descriptor of the level's rows -- a pixel past the level's end lies past the descriptor
+        // and its store is dropped, so no branch and no pointer arithmetic sits between the 64 stores of a thread.  (Written
+        // with pointers the epilogue was 930 instructions for 64 stores: 96 exec branches and, per row, a scalar RELOAD of the
+        // level's output pointer with its wait -- ~2 us per workgroup behind a main loop of 5.)
+        // (nontemporal, cache-policy bit 1 = nt: the 413 MB of column gradients of a tower launch stream THROUGH the L2s that
+        // hold the weight image and the pixel rows every column block of a tile re-reads; profiles/r6_gemm_l2.txt)
+        const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(L.out, 0, L.P * a.Co * 4, 0x00020000);
+        const int cbase = (co_blk + wn * TN * 32 + (lane & 31)) * 4;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int pix = tile_p + wm * TM * 32 + i * 32 + mfma32_row(r, lane);
-                if (pix >= L.P) continue;
-                float *orow = L.out + (size_t)pix * a.Co;
+                const int voff = pix < L.P ? pix * a.Co * 4 + cbase : OOB;   // (a whole row past the end: past the descriptor)
+                // (conv.hip conv_mm_rows: every column of a TRANS launch exists -- Co is a multiple of the 256-column tile)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    const int co = co_blk + (wn * TN + j) * 32 + (lane & 31);
-                    // (nontemporal: the 413 MB of column gradients of a tower launch stream THROUGH the L2s that hold the
-                    // weight image and the pixel rows every column block of a tile re-reads; profiles/r6_gemm_l2.txt)
-                    if (co < a.Co) __builtin_nontemporal_store(acc[j][i][r], orow + co);
+                    const float v = acc[j][i][r];   // (a copy: __builtin_bit_cast of the vector ELEMENT read element 0 for every r)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ors, voff + j * 128, 0, 2);
                 }
             }
     } else {
@@ -625,6 +631,11 @@ __global__ __launch_bounds__(256, 2) void conv_mm_kernel(const ConvArgs a)
     const int ep_bytes = (int)(out_px * a.Co * 4);   // (conv.hip conv_check: the output fits 32-bit byte offsets)
     const bool fin = !partial;   // bias, residual, ReLU and gate belong to the finished sum
     const bool has_bias = fin && a.bias != nullptr, has_res = fin && L.res != nullptr, has_gate = fin && L.gate != nullptr;
+    // the stores go through a buffer descriptor as well (the output, or this split's partial tiles): a pixel past the level's
+    // end or a channel past Co becomes an offset past the descriptor and the store is dropped -- no branch per quad
+    const __amdgpu_buffer_rsrc_t ors =
+        partial ? __builtin_amdgcn_make_buffer_rsrc(a.part + (size_t)blockIdx.z * a.part_rows * a.Co, 0, a.part_rows * a.Co * 4, 0x00020000)
+                : __builtin_amdgcn_make_buffer_rsrc(L.out, 0, ep_bytes, 0x00020000);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int pix = tile_p + wm * TM * 32 + i * 32 + (lane & 31);
@@ -636,15 +647,17 @@ __global__ __launch_bounds__(256, 2) void conv_mm_kernel(const ConvArgs a)
             const int ho = rem / L.Wo, wo = rem - ho * L.Wo;
             opix = ((size_t)b * a.OH + a.oy0 + ho * a.ostep) * a.OW + a.ox0 + wo * a.ostep;
         }
-        float *orow = partial ? a.part + ((size_t)blockIdx.z * a.part_rows + (pix - a.part_pix0)) * a.Co : L.out + opix * a.Co;
+        const int orow_off = (partial ? (pix - a.part_pix0) * a.Co : (int)opix * a.Co) * 4;
         // one finished quad -> memory: 16 bytes, or element by element when a pixel's row is not a whole number of quads
         auto put = [&](int co, const float (&v)[4]) __attribute__((always_inline)) {
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
             if (vec_ok) {
-                *reinterpret_cast<float4 *>(orow + co) = make_float4(v[0], v[1], v[2], v[3]);
+                const u32x4 q = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+                __builtin_amdgcn_raw_buffer_store_b128(q, ors, co < a.Co ? orow_off + co * 4 : OOB, 0, 0);
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (co + e < a.Co) orow[co + e] = v[e];
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[e]), ors, co + e < a.Co ? orow_off + (co + e) * 4 : OOB, 0, 0);
             }
         };
         if (!has_bias && !has_res && !has_gate) {   // nothing to fetch (partial tiles, plain data gradients)
@@ -653,7 +666,6 @@ __global__ __launch_bounds__(256, 2) void conv_mm_kernel(const ConvArgs a)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int co = co_blk + (wn * TN + j) * 32 + 8 * g + 4 * (lane >> 5);
-                    if (co >= a.Co) continue;
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = (fin && a.relu) ? fmaxf(acc[j][i][4 * g + e], 0.f) : acc[j][i][4 * g + e];
@@ -700,7 +712,6 @@ __global__ __launch_bounds__(256, 2) void conv_mm_kernel(const ConvArgs a)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int co = co_blk + (wn * TN + j) * 32 + 8 * g + 4 * (lane >> 5);
-                    if (co >= a.Co) continue;
                     const float4 b4 = bv[j * 4 + g], r4 = rv[j * 4 + g], g4 = gv[j * 4 + g];
                     float v[4];
 #pragma unroll
