@@ -776,6 +776,7 @@ static int launch_wgrad_cfg(WgArgs &a, float *gw, float *gb, int accumulate, hip
     const size_t lds = (size_t)2 * npl * ((size_t)cdiv(PMAX, XP) * XP * BN * 2 + (size_t)cdiv(16, GP) * GP * BM * 2);
     if (lds > 160 * 1024) return 1;
     dim3 grid(blocks, S);
+    LSN_CHECK((long long)a.nseg * (S + 1) < (1ll << 32), "conv2d backward-weight: %d segments x %d splits exceed the kernel's 32-bit split arithmetic", a.nseg, S);
     auto launch = [&](auto kern) -> int {
         LSN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);

@@ -268,8 +268,14 @@ __global__ __launch_bounds__(256, 2) void conv_mm_kernel(const ConvArgs a)
     if (!is_sk) {
         // XCD-ordered (pixel tile, column block) with the column blocks of a pixel tile adjacent (same input rows)
         work = xcd_remap((int)blockIdx.x, a.n_dp);
-        t_begin = (int)((long long)Tall * blockIdx.z / gridDim.z);
-        T = (int)((long long)Tall * (blockIdx.z + 1) / gridDim.z) - t_begin;
+        // (32-bit: Tall <= 64 taps x 64 slabs and at most 16 splits.  As a 64-bit quotient -- two scalar software divisions of
+        // ~300 dependent instructions -- this was 60 % of the kernel's prologue, run by every workgroup of every launch)
+        if (gridDim.z == 1) {
+            t_begin = 0, T = Tall;
+        } else {
+            t_begin = (int)((unsigned)Tall * blockIdx.z / gridDim.z);
+            T = (int)((unsigned)Tall * (blockIdx.z + 1) / gridDim.z) - t_begin;
+        }
     } else {
         const int kt = (int)((unsigned)sk_u / (unsigned)Tall);
         work = a.n_dp + kt;

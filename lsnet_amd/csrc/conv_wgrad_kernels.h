@@ -86,8 +86,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgArgs a)
     const int split = work / (int)gridDim.x, blk = work - split * (int)gridDim.x;
     const int cb = blk / nib, ib = blk - cb * nib;
     const int ci_blk = ib * BN, co_blk = cb * BM;
-    const int s_begin = (int)((long long)a.nseg * split / gridDim.y);
-    const int T = (int)((long long)a.nseg * (split + 1) / gridDim.y) - s_begin;
+    // (32-bit quotients: the host checks nseg * splits < 2^32; 64-bit ones are two ~300-instruction scalar software divisions)
+    const int s_begin = (int)((unsigned)a.nseg * (unsigned)split / gridDim.y);
+    const int T = (int)((unsigned)a.nseg * (unsigned)(split + 1) / gridDim.y) - s_begin;
 
     // ---- staging roles (constant over segments) ----
     const int xc4 = tid % XT;

@@ -962,6 +962,8 @@ static int launch_wgrad_mm(const DcnArgs &a_in, int nchunks, bool accumulate, hi
     auto pre = npl == 3 ? dcn_gout_frag_kernel<3> : dcn_gout_frag_kernel<2>;
     hipLaunchKernelGGL(pre, dim3(nblk_s, a.Co / 128), dim3(256), 0, st, a, nsteps16, spb, img, a.gb ? part_b : nullptr);
     const size_t lds = dcn_wgrad_mm_lds_bytes(npl);
+    if ((long long)nchunks * (S + 1) >= (1ll << 32))
+        return fail(LSN_ERR_UNSUPPORTED, "deformable backward-weight: %d chunks x %d splits exceed the kernel's 32-bit split arithmetic", nchunks, S);
     auto go = [&](auto kern) -> int {
         if (int rc = set_lds(kern, lds)) return rc;
         hipLaunchKernelGGL(kern, dim3(ncol, S, nz), dim3(256), lds, st, a, nchunks, img, (int)img_bytes, part, meta);

@@ -491,8 +491,9 @@ __global__ __launch_bounds__(256, 2) void dcn_wgrad_mm_kernel(const DcnArgs a, i
     const int NT = a.Co / 32;
     // (readfirstlane: the 64-bit divisions run on the vector ALU; left in VGPRs, every level lookup below became a
     // vector load from the kernel arguments with a full vmcnt(0) wait in the middle of the software pipeline)
-    const int t_begin = __builtin_amdgcn_readfirstlane((int)((long long)nchunks * split / nsplit));
-    const int T = __builtin_amdgcn_readfirstlane((int)((long long)nchunks * (split + 1) / nsplit)) - t_begin;
+    // (32-bit quotients: the host checks nchunks * nsplit < 2^32)
+    const int t_begin = __builtin_amdgcn_readfirstlane((int)((unsigned)nchunks * (unsigned)split / (unsigned)nsplit));
+    const int T = __builtin_amdgcn_readfirstlane((int)((unsigned)nchunks * (unsigned)(split + 1) / (unsigned)nsplit)) - t_begin;
 
     const __amdgpu_buffer_rsrc_t grs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(gimg), 0, gimg_bytes, 0x00020000);
