@@ -243,11 +243,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgArgs a)
                 for (int r = 0; r < 16; ++r) acc[tp][i][j][r] = 0.f;
 
     auto frag = [&](const unsigned char *p0, const unsigned char *p1) {
+        // (the two 8-byte reads side by side as whole dwords.  Assembled from eight 16-bit elements hipcc emitted a v_bfi_b32 per
+        // dword -- arithmetically a no-op, but it CONSUMES the read: every fragment was waited for where it was requested, at
+        // the top of the iteration, instead of in front of the MFMA that takes it half an iteration later)
         const s16x4 lo = lds_tr16(p0), hi = lds_tr16(p1);
-        short v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        bf16x8 f;
-        __builtin_memcpy(&f, v, 16);
-        return f;
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const u32x2 a2 = __builtin_bit_cast(u32x2, lo), b2 = __builtin_bit_cast(u32x2, hi);
+        const u32x4 r = {a2.x, a2.y, b2.x, b2.y};
+        return __builtin_bit_cast(bf16x8, r);
     };
 
     // ---- prologue: segment 0 -> stage 0, loads of segment 1 in flight ----

@@ -528,6 +528,18 @@ __global__ __launch_bounds__(256, 2) void dcn_wgrad_mm_kernel(const DcnArgs a, i
         const int nrec = __builtin_amdgcn_readfirstlane(cmeta[8 * t + 2]);
         xrs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float *>(((unsigned long long)hi << 32) | lo), 0, nrec, 0x00020000);
     };
+    // Round 6: inside the loop the descriptor is fetched in two halves.  Its three scalars are REQUESTED behind the barrier in
+    // the middle of iteration t - 1 and turned into the descriptor at the top of iteration t, before the fragment reads: a
+    // scalar load can only be waited for with lgkmcnt(0), and requested at the top it drained the twelve fragment reads
+    // issued just before it in front of the first MFMA of every chunk.
+    unsigned pd_lo = 0, pd_hi = 0;
+    int pd_nrec = 0;
+    auto request_chunk = [&](int t) { pd_lo = (unsigned)cmeta[8 * t], pd_hi = (unsigned)cmeta[8 * t + 1], pd_nrec = cmeta[8 * t + 2]; };
+    auto take_chunk = [&]() {
+        const unsigned lo = __builtin_amdgcn_readfirstlane(pd_lo), hi = __builtin_amdgcn_readfirstlane(pd_hi);
+        const int nrec = __builtin_amdgcn_readfirstlane(pd_nrec);
+        xrs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float *>(((unsigned long long)hi << 32) | lo), 0, nrec, 0x00020000);
+    };
     auto issue_slice = [&](int ps, int slot) {
         const int4 idx = *reinterpret_cast<const int4 *>(&tab[slot * 32 + ps * 16 + xq]);
         const int cq = (c0 + 4 * xc4) * 4;
@@ -588,11 +600,15 @@ __global__ __launch_bounds__(256, 2) void dcn_wgrad_mm_kernel(const DcnArgs a, i
                 xaddr[ks][i][h] = pp * RBX + sl * 32 + fcq * 8;
             }
     auto frag = [&](const unsigned char *p0, const unsigned char *p1) {
+        // (the two 8-byte reads side by side as whole dwords.  Assembled from eight 16-bit elements hipcc emitted a v_bfi_b32 per
+        // dword -- arithmetically a no-op, but it CONSUMES the read: every fragment was waited for where it was requested, at
+        // the top of the iteration, instead of in front of the MFMA that takes it half an iteration later)
         const s16x4 lo = lds_tr16(p0), hi = lds_tr16(p1);
-        short v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        bf16x8 f;
-        __builtin_memcpy(&f, v, 16);
-        return f;
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const u32x2 a2 = __builtin_bit_cast(u32x2, lo), b2 = __builtin_bit_cast(u32x2, hi);
+        const u32x4 r = {a2.x, a2.y, b2.x, b2.y};
+        return __builtin_bit_cast(bf16x8, r);
     };
 
     f32x16 acc[TI][TJ];
@@ -637,16 +653,18 @@ __global__ __launch_bounds__(256, 2) void dcn_wgrad_mm_kernel(const DcnArgs a, i
                     Xf[ks][i][q] = frag(buf + q * XPL + xaddr[ks][i][0], buf + q * XPL + xaddr[ks][i][1]);
         };
         read_x(smem, 0);
+        request_chunk(sat(2));
         for (int t = 0; t < T; ++t) {
             const unsigned char *bc = smem + (t & 1) * STAGE;
             unsigned char *bn = smem + ((t & 1) ^ 1) * STAGE;
             const int slot1 = (t + 1) & 3, slot2 = (t + 2) & 3, slot3 = (t + 3) & 3;
+            take_chunk();   // chunk t + 2 (requested half an iteration ago)
+            __builtin_amdgcn_sched_barrier(0);
             // slot3 held chunk t - 1: last read in iteration t - 2 (commit) -- two barriers ago; its new entries (chunk t + 3)
             // are first read in iteration t + 1 (issue_slice), behind the barrier in the middle of this one
             if (wj == 0) gtap_put(slot3, tq);
             tq = gtap_load(sat(t + 4));
             read_x(bc, 1);
-            open_chunk(sat(t + 2));
             __builtin_amdgcn_sched_barrier(0);
             constexpr int NM = NP * TI * TJ;
 #pragma unroll
@@ -670,6 +688,8 @@ __global__ __launch_bounds__(256, 2) void dcn_wgrad_mm_kernel(const DcnArgs a, i
             issue_g(t + 1, 0);
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
+            request_chunk(sat(t + 3));
+            __builtin_amdgcn_sched_barrier(0);
             read_x(bn, 0);   // (past the last chunk: never used)
 #pragma unroll
             for (int prod = 0; prod < NP; ++prod)
