@@ -470,8 +470,8 @@ int lsn_grouped_conv2d_backward_weight(const float *x, const float *grad_out, fl
  * channels-last equivalent: y = relu?( (x - mean_g) * rstd_g * gamma_c + beta_c ), statistics per
  * (image, group) over HW x C/G elements, biased variance, eps inside the square root -- the ATen definition.
  * Several tensors that share one GroupNorm module (the FPN levels) are processed per call.
- * x / y / dy / dx: (B, HW, C) channels-last fp32, 16-byte aligned.  Supported: C % 4 == 0, (C/G) % 4 == 0,
- * 256 % (C/4) == 0 (C = 64 ... 1024); otherwise LSN_ERR_UNSUPPORTED (the caller keeps ATen's GroupNorm).
+ * x / y / dy / dx: (B, HW, C) channels-last fp32, 16-byte aligned.  Supported: C % 4 == 0, C/G a multiple of 4 or one
+ * of 1, 2 (round 6), 256 % (C/4) == 0 (C = 4 ... 1024); otherwise LSN_ERR_UNSUPPORTED (the caller keeps ATen's GroupNorm).
  * mean_rstd: (sum of B over levels, G, 2) fp32, written by forward and read by backward.
  * workspace: lsn_group_norm_workspace_bytes() bytes of device memory, contents undefined.
  * backward recomputes the ReLU gate from x (y is not needed); grad_gamma / grad_beta (C) are OVERWRITTEN with
