@@ -651,7 +651,14 @@ static void gather_plan(DcnArgs &a, GatherPlan &pl)
     pl.o_tmp = o, o = align256(o + tmp + 256);
     pl.o_gtap = o, o = align256(o + ((size_t)pl.nsamples + 1) * sizeof(Tap));   // + the all-zero entry
     pl.o_S = o, o = align256(o + (size_t)pl.aa.NA * 4 * a.C * sizeof(float));
-    pl.o_H = o, o = align256(o + (size_t)pl.nsamples * 4 * sizeof(float));   // corner sums (dcn_offgrad_kernel)
+    // corner sums (dcn_offgrad_kernel): one slot per 256-channel block where the per-anchor sums split them over blockIdx.y
+    // (every group on the per-anchor path, C > 256; dcn_gather_kernels.h AnchorArgs::ncb)
+    // (debug bit 16: one wave walks all blocks of its anchor, the form until round 6 -- A/B runs; the workspace is sized for
+    // the split either way, so a size asked for under one setting serves a launch under the other)
+    const int ncb_max = (ga.NB == 0 && aa.ng > 0 && a.C > 256) ? cdiv(a.C, 256) : 1;
+    aa.ncb = ((g_dbg_block >> 16) & 1) ? 1 : ncb_max;
+    aa.hb_slot = (long long)pl.nsamples * 4;
+    pl.o_H = o, o = align256(o + (size_t)pl.nsamples * 4 * sizeof(float) * ncb_max);
     pl.o_ent2 = o, o = align256(o + (size_t)pl.nsamples * sizeof(GEntry));   // ordering of the lists above 64 entries
     pl.bytes = o;
     pl.ok = true;
@@ -824,9 +831,9 @@ static int launch_bwd_colbuf(DcnArgs &a, GatherPlan &pl, unsigned char *ws, hipS
         pl.aa.gcol = a.gcol, pl.aa.start = start, pl.aa.ent = ent;
         pl.aa.S = reinterpret_cast<float *>(ws + pl.o_S);
         if (pl.na_long > 0)
-            hipLaunchKernelGGL(dcn_anchor_sum_kernel<4>, dim3(pl.na_long), dim3(256), 0, st, pl.aa, 0, pl.na_long);
+            hipLaunchKernelGGL(dcn_anchor_sum_kernel<4>, dim3(pl.na_long, pl.aa.ncb), dim3(256), 0, st, pl.aa, 0, pl.na_long);
         if (pl.aa.NA > pl.na_long)
-            hipLaunchKernelGGL(dcn_anchor_sum_kernel<1>, dim3(cdiv(pl.aa.NA - pl.na_long, 4)), dim3(256), 0, st, pl.aa,
+            hipLaunchKernelGGL(dcn_anchor_sum_kernel<1>, dim3(cdiv(pl.aa.NA - pl.na_long, 4), pl.aa.ncb), dim3(256), 0, st, pl.aa,
                                pl.na_long, pl.aa.NA - pl.na_long);
         hipLaunchKernelGGL(dcn_anchor_combine_kernel, dim3(cdiv(pl.anchor_pixels, 4)), dim3(256), 0, st, pl.aa, pl.anchor_pixels);
     }
@@ -840,7 +847,7 @@ static int launch_bwd_colbuf(DcnArgs &a, GatherPlan &pl, unsigned char *ws, hipS
     }
     if (Hb)
         hipLaunchKernelGGL(dcn_offgrad_kernel, dim3(cdiv(pl.nsamples, 256)), dim3(256), 0, st, a, pl.nsamples,
-                           reinterpret_cast<const float4 *>(Hb));
+                           reinterpret_cast<const float4 *>(Hb), pl.aa.ng > 0 ? pl.aa.ncb : 1);
     LSN_HIP(hipGetLastError());
     return 0;
 }

@@ -74,6 +74,12 @@ struct AnchorArgs {
     float *S;           // [NA][4][C]
     int raw;            // as in GatherArgs
     float *Hb;
+    // ncb > 1 (round 6; C > 256 with every group on this path: the 512 .. 2048-channel deformable layers of config 4's
+    // backbone): the 256-channel blocks of an anchor are blockIdx.y -- a map of 50 x 84 pixels has 8.6 k anchors, two waves per
+    // SIMD, each walking its list once per block in sequence.  Block y leaves its share of the corner dot products in slot y of
+    // Hb ([ncb][samples][4], hb_slot floats apart); dcn_offgrad_kernel adds the slots in block order.
+    int ncb;
+    long long hb_slot;
 };
 
 // Sixteen wave-wide sums at once: in, per lane, d[0..15]; out, in lane i (every 16-lane row alike), the sum over the 64
@@ -440,7 +446,9 @@ __global__ __launch_bounds__(256) void dcn_anchor_sum_kernel(const AnchorArgs ga
     // anchor -> its four corner pixels (ay + dy, ax + dx); anchors live on the (H + 1) x (W + 1) grid shifted by one
     const int la = ai - G.a0, ab = la / ((G.H + 1) * (G.W + 1)), arem = la - ab * (G.H + 1) * (G.W + 1);
     const int ay = arem / (G.W + 1) - 1, ax = arem % (G.W + 1) - 1;
-    for (int cb = 0; cb < C; cb += 256) {
+    const int cb0 = ga.ncb > 1 ? (int)blockIdx.y * 256 : 0, cb1 = ga.ncb > 1 ? min(cb0 + 256, C) : C;
+    float *const Hbase = ga.Hb != nullptr ? ga.Hb + (size_t)(ga.ncb > 1 ? blockIdx.y : 0) * ga.hb_slot : nullptr;
+    for (int cb = cb0; cb < cb1; cb += 256) {
         const int c = cb + lane * 4;
         float4 acc[2][2];
 #pragma unroll
@@ -509,8 +517,8 @@ __global__ __launch_bounds__(256) void dcn_anchor_sum_kernel(const AnchorArgs ga
                     const float tot = wave64_sum16(d, lane);
                     const int su = __shfl(e.s, min(j0 + ((lane >> 2) & 3), n - 1));
                     if (lane < 16 && ((okm >> lane) & 1u)) {
-                        float *hp = ga.Hb + (size_t)su * 4 + (lane & 3);
-                        *hp = cb == 0 ? tot : *hp + tot;
+                        float *hp = Hbase + (size_t)su * 4 + (lane & 3);
+                        *hp = cb == cb0 ? tot : *hp + tot;
                     }
                 }
             }
@@ -579,7 +587,7 @@ __global__ __launch_bounds__(256) void dcn_anchor_combine_kernel(const AnchorArg
 // times (L2).  It lost: tower backward 638 vs 600 us, pyramid 2031 vs 1603 us (profiles/r4_pixel_gather.txt); removed.)
 // grad_offset / grad_mask from the corner sums Hb[sample][4] the gather pass left (kernel.cu:973-1044): one thread per
 // sample.  A corner that lies outside the map has no list entry and no sum: its flag bit selects zero.
-__global__ void dcn_offgrad_kernel(const DcnArgs a, int nsamples, const float4 *__restrict__ Hb)
+__global__ void dcn_offgrad_kernel(const DcnArgs a, int nsamples, const float4 *__restrict__ Hb, int ncb)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nsamples) return;
@@ -590,7 +598,13 @@ __global__ void dcn_offgrad_kernel(const DcnArgs a, int nsamples, const float4 *
     if (L.goff == nullptr && L.gmsk == nullptr) return;
     const Tap tp = a.gtap[(size_t)kd * a.gtap_rows + prow];
     float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (tp.flags) h = Hb[s];
+    if (tp.flags) {
+        h = Hb[s];
+        for (int y = 1; y < ncb; ++y) {   // (the channel blocks of AnchorArgs::ncb, in block order)
+            const float4 t = Hb[(size_t)y * nsamples + s];
+            h.x += t.x, h.y += t.y, h.z += t.z, h.w += t.w;
+        }
+    }
     const float hy = 1.f - tp.ly, hx = 1.f - tp.lx;
     const float v00 = (tp.flags & 1) ? h.x : 0.f, v01 = (tp.flags & 2) ? h.y : 0.f;
     const float v10 = (tp.flags & 4) ? h.z : 0.f, v11 = (tp.flags & 8) ? h.w : 0.f;

@@ -23,6 +23,8 @@ from lsnet_amd.parallel import DataParallelModel  # noqa: E402
 
 dev = torch.device('cuda:0')
 torch.manual_seed(0)
+if os.environ.get('CONFIG_STEPS_DBG'):   # debug word of the library for the whole run (A/B arms, tools/README.md)
+    _lib.load().lsn_debug_phase_clocks(None, int(os.environ['CONFIG_STEPS_DBG']))
 model, cfg = build_lsnet(task, backbone)
 model = DataParallelModel(model.to(dev).to(memory_format=torch.channels_last).train())
 step, _ = bench.build_step(model, cfg)
