@@ -1382,6 +1382,26 @@ def test_grouped_backward_is_deterministic(mode):
 
 
 @pytest.mark.gpu
+def test_anchor_sums_by_channel_block_give_the_same_bits():
+    """Round 6: for layers of more than 256 channels the per-anchor sums of the backward-data pass put the 256-channel blocks
+    on blockIdx.y (dcn_gather_kernels.h AnchorArgs::ncb) and dcn_offgrad_kernel adds the blocks' corner dot products in block
+    order -- the order in which one wave used to accumulate them (debug bit 16): grad_input, grad_offset and grad_mask are
+    bitwise the same in both forms."""
+    from lsnet_amd import _lib, ops
+    dev = _dev()
+    case = dict(name='cb_g64', C=1024, Co=1024, groups=64, hw=(25, 42), bias=False)
+    x, w, b, off, mask, go, cfg = _make(case, dev, seed=6)
+    try:
+        a = _dcn_all(ops, x, w, b, off, mask, go, cfg, dev)
+        _lib.load().lsn_debug_phase_clocks(None, 1 << 16)
+        c = _dcn_all(ops, x, w, b, off, mask, go, cfg, dev)
+    finally:
+        _lib.load().lsn_debug_phase_clocks(None, 0)
+    for k in ('gx', 'goff', 'gmask'):
+        assert torch.equal(a[k], c[k]), k
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('case', [dict(name='det_dense', C=256, Co=256, hw=(25, 42)),
                                   dict(name='det_dense_s2', C=128, Co=128, stride=2, hw=(50, 84), bias=False),
                                   dict(name='det_pyr', C=256, Co=256, mask=False, hw=(25, 42), dst=(13, 21))],
